@@ -1,0 +1,119 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz from the VERBATIM reference.
+
+Run in the build container (needs /root/reference):
+
+    python -m oracle.gen_golden
+
+Each fixture holds seeded inputs (x, dense weight, bias, upstream grad g), the module
+hyper-parameters, and what the verbatim reference module
+(/root/reference/neuralop/layers/spectral_convolution.py, imported through
+oracle/ref_verbatim.py) returned on CPU in fp32: y, gx, gW, gbias.  Factorized cases also
+store the factors and the output of the reference's own ``_contract_tucker`` /
+``_contract_cp`` so the factorized kernels are pinned to the reference's einsum strings.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ref_verbatim
+from .tl_stub import FactorizedTensor
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                          "tests", "golden")
+
+# name, B, Cin, Cout, spatial, n_modes (ctor arg), max_n_modes (ctor arg), runtime n_modes
+DENSE_CASES = [
+    ("d1_n12_m6", 2, 3, 2, (12,), (6,), None, None),
+    ("d1_n9_m5", 2, 2, 3, (9,), (5,), None, None),
+    ("d2_12x10_m6x4", 2, 3, 4, (12, 10), (6, 4), None, None),
+    ("d2_9x11_m5x7", 2, 3, 2, (9, 11), (5, 7), None, None),
+    ("d2_16x16_m6_max8", 2, 4, 4, (16, 16), (6, 6), (8, 8), None),
+    ("d2_16x16_m8_to_6x4", 2, 4, 3, (16, 16), (8, 8), None, (6, 4)),
+    ("d2_6x6_m8_gridsmaller", 1, 2, 2, (6, 6), (8, 8), None, None),
+    ("d2_32x32_m16", 2, 4, 4, (32, 32), (16, 16), None, None),
+    ("d2_64x64_m16_c8", 2, 8, 8, (64, 64), (16, 16), None, None),
+    ("d3_8x6x10_m4x4x6", 2, 2, 3, (8, 6, 10), (4, 4, 6), None, None),
+    ("d3_9x11x8_m5x7x4", 1, 2, 2, (9, 11, 8), (5, 7, 4), None, None),
+    ("d3_16x16x16_m8", 2, 4, 4, (16, 16, 16), (8, 8, 8), None, None),
+    ("darcy_c1_16x16_m12_c32", 4, 32, 32, (16, 16), (12, 12), None, None),
+]
+
+FACT_CASES = [
+    ("tucker_2d", "Tucker", 2, 4, 4, (16, 16), (8, 8), 0.5),
+    ("cp_2d", "CP", 2, 4, 4, (16, 16), (8, 8), 0.5),
+    ("tucker_3d", "Tucker", 1, 3, 3, (8, 8, 8), (4, 4, 4), 0.6),
+    ("cp_1d", "CP", 2, 3, 3, (16,), (8,), 0.5),
+]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_dense(ref, name, b, ci, co, spatial, n_modes, max_n_modes, runtime_modes, seed):
+    torch.manual_seed(seed)
+    conv = ref.SpectralConv(ci, co, n_modes, max_n_modes=max_n_modes)
+    if runtime_modes is not None:
+        conv.n_modes = runtime_modes
+    x = torch.randn(b, ci, *spatial, requires_grad=True)
+    y = conv(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    out = dict(
+        x=_np(x), weight=_np(conv.weight.to_tensor()), bias=_np(conv.bias), g=_np(g),
+        y=_np(y), gx=_np(x.grad), gw=_np(conv.weight.tensor.grad), gbias=_np(conv.bias.grad),
+        ctor_n_modes=np.array(n_modes), n_modes_attr=np.array(conv.n_modes),
+        max_n_modes_attr=np.array(conv.max_n_modes),
+        runtime_n_modes=np.array(runtime_modes if runtime_modes is not None else []),
+    )
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+    return out
+
+
+def gen_fact(ref, name, fac, b, ci, co, spatial, n_modes, rank, seed):
+    torch.manual_seed(seed)
+    conv = ref.SpectralConv(ci, co, n_modes, factorization=fac, implementation="factorized",
+                            rank=rank)
+    # larger-than-init factors so the output is O(1) and the comparison meaningful
+    with torch.no_grad():
+        for p in conv.weight.parameters():
+            p.copy_(torch.randn_like(p) * 0.5)
+    x = torch.randn(b, ci, *spatial, requires_grad=True)
+    y = conv(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    out = dict(x=_np(x), bias=_np(conv.bias), g=_np(g), y=_np(y), gx=_np(x.grad),
+               gbias=_np(conv.bias.grad), w_dense=_np(conv.weight.to_tensor()),
+               ctor_n_modes=np.array(n_modes), n_modes_attr=np.array(conv.n_modes),
+               max_n_modes_attr=np.array(conv.max_n_modes), rank=np.array(rank))
+    w = conv.weight
+    if fac == "Tucker":
+        out["core"] = _np(w.core)
+        out["g_core"] = _np(w.core.grad)
+    else:
+        out["weights"] = _np(w.weights)
+        out["g_weights"] = _np(w.weights.grad)
+    for i, f in enumerate(w.factors):
+        out[f"factor_{i}"] = _np(f)
+        out[f"g_factor_{i}"] = _np(f.grad)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+    return out
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    ref = ref_verbatim.load_reference()
+    torch.set_num_threads(1)   # deterministic reduction order
+    for i, case in enumerate(DENSE_CASES):
+        o = gen_dense(ref, *case, seed=1000 + i)
+        print(f"{case[0]:32s} y{o['y'].shape} |y|={np.abs(o['y']).mean():.3f}")
+    for i, case in enumerate(FACT_CASES):
+        o = gen_fact(ref, *case, seed=2000 + i)
+        print(f"{case[0]:32s} y{o['y'].shape} |y|={np.abs(o['y']).mean():.3f}")
+    total = sum(os.path.getsize(os.path.join(GOLDEN_DIR, f)) for f in os.listdir(GOLDEN_DIR))
+    print(f"golden dir: {total/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
