@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""bench.py -- SpectralConv forward+backward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one forward + backward of ONE SpectralConv layer (grads for x, W, bias) over one
+batch of synthetic fields already resident in HBM.  Default workload = BASELINE configs[1]:
+B=32, C=64, 256x256, n_modes=(64,64) -> kept 64x33, fp32.  With N > 1 every rank runs the
+same per-GPU batch (data-parallel replicas, weak scaling; the layer itself has no
+cross-rank exchange in that mode) unless --parallel modeshard is given, which runs the
+mode-parallel layer (RCCL all-to-all, neuraloperator_amd/mpu).
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
+kernel, timed live with events on the launch stream) and, at N=1, `cpu_baseline` (the
+oracle's torch restatement of the reference CPU path on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (B, C, spatial, n_modes)
+    "fno2d_256_m64_c64_b32": (32, 64, (256, 256), (64, 64)),      # BASELINE configs[1] (metric)
+    "darcy_16_m12_c32_b4": (4, 32, (16, 16), (12, 12)),           # configs[0] shape
+    "fno3d_128_m32_c32_b8": (8, 32, (128, 128, 128), (32, 32, 32)),  # configs[3] shape
+    "fno2d_1024_m256_c128_b4": (4, 128, (1024, 1024), (256, 256)),   # configs[4] shape
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fno2d_256_m64_c64_b32", choices=sorted(WORKLOADS))
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "modeshard"])
+    ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-iters", type=int, default=10)
+    return ap.parse_args()
+
+
+def alg_bytes(B, C, spatial, kept):
+    """R, Wb, S and BYTES_ALG = 4R + 3Wb + 9S per fwd+bwd step."""
+    nsp = 1
+    for s in spatial:
+        nsp *= s
+    mk = 1
+    for k in kept:
+        mk *= k
+    R = 4 * B * C * nsp
+    S = 8 * B * C * mk
+    Wb = 8 * C * C * mk
+    return R, Wb, S, 4 * R + 3 * Wb + 9 * S
+
+
+def time_stage(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters      # ms
+
+
+def stage_profile(B, C, spatial, n_modes, flags, iters):
+    """Time every stage of the layer separately through the C-ABI (events on the launch
+    stream) and return {stage: {ms, alg_bytes, GBs}} plus the plan's kernel names."""
+    from neuraloperator_amd import _lib
+    from neuraloperator_amd.engine import get_plan
+    from neuraloperator_amd.modes import halve_last_mode, kept_block
+
+    lib = _lib.get_lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nm = halve_last_mode(n_modes)
+    kept, _ = kept_block(spatial, nm, nm)
+    plan = get_plan(dev, spatial, kept, "forward", flags)
+    mk = 1
+    for k in kept:
+        mk *= k
+    R, Wb, S, _ = alg_bytes(B, C, spatial, kept)
+    x = torch.randn(B, C, *spatial, device=dev)
+    y = torch.empty_like(x)
+    xh = torch.randn(B, C, mk, 2, device=dev)
+    yh = torch.randn(B, C, mk, 2, device=dev)
+    w = torch.randn(C, C, mk, 2, device=dev)
+    gw = torch.empty_like(w)
+    bias = torch.randn(C, device=dev)
+    ws = torch.empty(lib.plan_workspace_bytes(plan, B * C) + 256, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()
+
+    def gemm(a, b, c, **kw):
+        lib.modegemm(p(a), p(b), p(c), st, n_modes=mk, **kw)
+
+    stages = {
+        "fwd_transform": (lambda: lib.transform_forward(plan, _lib.SC_FWD_SCALED, p(x), p(xh), B * C, p(ws), st),
+                          R + S),
+        "contract_fwd": (lambda: gemm(xh, w, yh, P=B, Q=C, R=C, a_sp=C * mk, a_sr=mk, a_sm=1,
+                                      b_sr=C * mk, b_sq=mk, b_sm=1, c_sp=C * mk, c_sq=mk, c_sm=1),
+                         2 * S + Wb),
+        "inv_transform": (lambda: lib.transform_inverse(plan, _lib.SC_INV_PADDED, p(yh), p(bias), C, p(y),
+                                                        B * C, p(ws), st), R + S),
+        "adj_c2r_transform": (lambda: lib.transform_forward(plan, _lib.SC_FWD_ADJ_C2R, p(x), p(xh), B * C,
+                                                            p(ws), st), R + S),
+        "contract_gw": (lambda: gemm(xh, yh, gw, P=C, Q=C, R=B, a_sp=mk, a_sr=C * mk, a_sm=1, conj_a=1,
+                                     b_sr=C * mk, b_sq=mk, b_sm=1, c_sp=C * mk, c_sq=mk, c_sm=1),
+                        2 * S + Wb),
+        "contract_gx": (lambda: gemm(yh, w, xh, P=B, Q=C, R=C, a_sp=C * mk, a_sr=mk, a_sm=1,
+                                     b_sr=mk, b_sq=C * mk, b_sm=1, conj_b=1, c_sp=C * mk, c_sq=mk, c_sm=1),
+                        2 * S + Wb),
+        "adj_r2c_transform": (lambda: lib.transform_inverse(plan, _lib.SC_INV_ADJ_R2C, p(yh), 0, C, p(y),
+                                                            B * C, p(ws), st), R + S),
+    }
+    out = {}
+    for name, (fn, nbytes) in stages.items():
+        ms = time_stage(fn, iters)
+        out[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBs": round(nbytes / ms / 1e6, 1)}
+    names = {"fwd": lib.plan_kernel_name(plan, 0), "inv": lib.plan_kernel_name(plan, 1),
+             "fast": lib.plan_is_fast(plan)}
+    return out, names
+
+
+def cpu_baseline(C, spatial, n_modes, budget_s=20.0):
+    """Reference CPU path (oracle/spectral_oracle.forward_torch: the op-for-op torch
+    restatement of neuralop SpectralConv.forward, autograd backward) on the host cores."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nm = halve_last_mode(n_modes)
+    nsp = 1
+    for s in spatial:
+        nsp *= s
+    # bounded sample: shrink the batch so that one step is ~1-2 s of CPU work
+    b = max(1, min(8, int(2.5e8 // (C * nsp))))
+    torch.manual_seed(0)
+    std = (2 / (2 * C)) ** 0.5
+    x = torch.randn(b, C, *spatial, requires_grad=True)
+    w = torch.empty(C, C, *nm, dtype=torch.cfloat).normal_(0, std).requires_grad_(True)
+    bias = (std * torch.randn(C, *(1,) * len(spatial))).requires_grad_(True)
+    g = torch.randn(b, C, *spatial)
+
+    def step():
+        x.grad = w.grad = bias.grad = None
+        y = so.forward_torch(x, w, bias, nm, nm)
+        y.backward(g)
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s / 2 and n < 20):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(b / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"B={b} of the same (C={C}, {'x'.join(map(str, spatial))}, modes {n_modes}) workload, "
+                      f"{n} timed fwd+bwd steps, torch {torch.__version__} CPU fp32, oracle.forward_torch"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from neuraloperator_amd import SpectralConv, _lib
+    from neuraloperator_amd.modes import halve_last_mode, kept_block
+
+    B, C, spatial, n_modes = WORKLOADS[args.workload]
+    flags = _lib.SC_PLAN_FORCE_GENERIC if args.force_generic else 0
+    torch.manual_seed(1234 + rank)
+    if args.parallel == "modeshard" and world > 1:
+        from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+        comm.init(model_parallel_size=world)
+        conv = ModeParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        b_local = B // world if B % world == 0 else B
+        scaling = "strong" if B % world == 0 else "weak"
+        global_batch = b_local * world
+        par = f"modeshard{world}"
+    else:
+        conv = SpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        b_local = B
+        scaling = "weak"
+        global_batch = B * world
+        par = f"dp{world}-replicas" if world > 1 else "single"
+    x = torch.randn(b_local, C, *spatial, device=dev, requires_grad=True)
+    g = torch.randn(b_local, C, *spatial, device=dev)
+
+    def step():
+        x.grad = None
+        for prm in conv.parameters():
+            prm.grad = None
+        y = conv(x)
+        y.backward(g)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = global_batch / (ms / 1e3)
+
+    out = None
+    if rank == 0:
+        nm = halve_last_mode(n_modes)
+        kept, _ = kept_block(spatial, nm, nm)
+        R, Wb, S, total = alg_bytes(b_local, C, spatial, kept)
+        stages, names = stage_profile(b_local, C, spatial, n_modes, flags, args.stage_iters)
+        dom = max(stages, key=lambda k: stages[k]["ms"])
+        kern = names["fwd"] if dom in ("fwd_transform", "adj_c2r_transform") else \
+            names["inv"] if dom in ("inv_transform", "adj_r2c_transform") else "k_modegemm"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": kern, "stage": dom,
+                "achieved": stages[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": stages[dom]["alg_bytes"], "ms_per_launch": stages[dom]["ms"]}
+        step_gbs = total / ms / 1e6
+        out = {
+            "metric": "FNO SpectralConv fwd+bwd samples/sec",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "B_per_gpu": b_local, "global_batch": global_batch,
+                       "channels": C, "grid": list(spatial), "n_modes": list(n_modes), "kept": kept,
+                       "parallelism": par, "engine_path": "fused-fft" if names["fast"] else "generic-dft",
+                       "weights": "dense complex64, random init"},
+            "roofline": roof,
+            "step_roofline": {"alg_bytes_per_step": total, "achieved_GBs": round(step_gbs, 1),
+                              "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
+                              "formula": "4R+3Wb+9S (SURVEY.md 8d)"},
+            "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, spatial, n_modes)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

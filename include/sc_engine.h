@@ -1,0 +1,148 @@
+/*
+ * sc_engine.h -- C-ABI of the MI355X-native SpectralConv engine (libsc_engine.so).
+ *
+ * The reference (neuraloperator v2.0.0) is 100 % Python: its hot path is a chain of ATen
+ * calls inside neuralop/layers/spectral_convolution.py and there is no FFI boundary
+ * upstream.  This header is the boundary a maintainer would bind
+ * with ctypes from a `conv_module` drop-in; every entry point cites
+ * the reference lines it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  All data pointers are DEVICE pointers
+ *     owned by the caller (PyTorch's allocator); the plan owns only its twiddle tables.
+ *   - real tensors: float32, contiguous (B, C, d1..dN).  complex tensors: interleaved
+ *     (re, im) float32 pairs (== torch.complex64 memory).
+ *   - truncated spectra are stored (B, C, k1..kN) with the mode dims in WEIGHT order:
+ *     non-last dim row r  <->  signed frequency r - floor(k/2) (fftshift order, even k
+ *     keeps -k/2 .. k/2-1), last dim column c <-> frequency c.
+ *     (spectral_convolution.py:465-519.)
+ *   - every function returns 0 on success, non-zero on error (sc_last_error() gives the
+ *     message); no C++ exception crosses the ABI.
+ *   - all work is enqueued on the hipStream_t passed in (void* here so that the header is
+ *     usable without HIP headers); nothing synchronises the device.
+ *   - a plan is immutable after creation and may be used from several streams as long as
+ *     each call gets its own workspace.
+ */
+#ifndef SC_ENGINE_H
+#define SC_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_MAX_DIMS 4
+
+/* fft_norm of the reference module (spectral_convolution.py:303, 443, 548, 559) */
+enum { SC_NORM_FORWARD = 0, SC_NORM_BACKWARD = 1, SC_NORM_ORTHO = 2 };
+
+/* which linear map a transform call applies (all four share kernels, only tables differ) */
+enum {
+  SC_FWD_SCALED = 0,   /* rfftn(norm) restricted to the kept modes      (:443-449, 500-519) */
+  SC_FWD_ADJ_C2R = 1,  /* adjoint of the zero-padded inverse: unscaled R2C, interior
+                          last-dim columns x2  (autograd of :531-559)           */
+  SC_INV_PADDED = 0,   /* zero-pad + ifftn + irfft(norm), DC/Nyquist imag ignored (:520-559)*/
+  SC_INV_ADJ_R2C = 1   /* adjoint of SC_FWD_SCALED (autograd of :443)           */
+};
+
+typedef struct sc_plan sc_plan;
+
+typedef struct {
+  int32_t ndim;                  /* number of spatial dims, 1..SC_MAX_DIMS                  */
+  int32_t fft_norm;              /* SC_NORM_*                                               */
+  int64_t spatial[SC_MAX_DIMS];  /* d1..dN                                                  */
+  int64_t kept[SC_MAX_DIMS];     /* extents of the used weight sub-block = kept modes       */
+  int32_t flags;                 /* SC_PLAN_* bits                                          */
+  int32_t reserved;
+} sc_plan_desc;
+
+enum {
+  SC_PLAN_FORCE_GENERIC = 1  /* never take the power-of-two fast kernels (debug / A-B)     */
+};
+
+/* ---- plan ------------------------------------------------------------------------------ */
+/* replaces the per-call index math of spectral_convolution.py:429-434, 465-519 */
+int sc_plan_create(sc_plan** out, const sc_plan_desc* desc);
+void sc_plan_destroy(sc_plan* plan);
+/* bytes of scratch a transform call over `n_images` (= batch*channels) images needs */
+size_t sc_plan_workspace_bytes(const sc_plan* plan, int64_t n_images);
+/* 1 if the plan runs the fused power-of-two kernels, 0 for the generic pruned-DFT passes */
+int sc_plan_is_fast(const sc_plan* plan);
+
+/* ---- transforms -------------------------------------------------------------------------- */
+/* x: real (n_images, d1..dN)  ->  xhat: complex (n_images, k1..kN)
+ * replaces rfftn + fftshift + x[slices_x]      (spectral_convolution.py:443-449, 500-519) */
+int sc_transform_forward(const sc_plan* plan, int mode, const float* x, float* xhat,
+                         int64_t n_images, void* workspace, void* stream);
+
+/* yhat: complex (n_images, k1..kN) -> y: real (n_images, d1..dN), y += bias[image % channels]
+ * replaces zeros + out_fft[slices_x]= + ifftshift + ifftn + imag.zero_ + irfft + bias
+ * (spectral_convolution.py:456-462, 520, 531-568).  bias may be NULL. */
+int sc_transform_inverse(const sc_plan* plan, int mode, const float* yhat, const float* bias,
+                         int64_t channels, float* y, int64_t n_images, void* workspace,
+                         void* stream);
+
+/* ---- mode-batched complex GEMM ---------------------------------------------------------------
+ * C[p, q, m] (+)= sum_r opA(A[p, r, m]) * opB(B[r, q, m]),   m = 0..n_modes-1 on the lanes.
+ * Element (complex) offsets: A: p*a_sp + r*a_sr + m*a_sm;  B: r*b_sr + q*b_sq + off_b(m);
+ * C: p*c_sp + q*c_sq + off_c(m), where off(m) = idx[m] if the index table is given
+ * (device int32, lets B / C be a strided sub-block of the stored weight), else m*sm.
+ * a_sm / b_sm may be 0 (operand shared by all modes: Tucker/CP factor matrices).
+ * replaces tl.einsum('bixy,ioxy->boxy') and its two autograd einsums
+ * (spectral_convolution.py:21-46) and the pairwise steps of _contract_tucker/_contract_cp
+ * (:55-103). */
+typedef struct {
+  int64_t P, Q, R, n_modes;
+  int64_t a_sp, a_sr, a_sm;
+  int64_t b_sr, b_sq, b_sm;
+  int64_t c_sp, c_sq, c_sm;
+  int32_t conj_a, conj_b;
+  int32_t accumulate;       /* 0: C = ..., 1: C += ...                                     */
+  int32_t reserved;
+  const int32_t* b_idx;     /* optional device table [n_modes], NULL -> m*b_sm              */
+  const int32_t* c_idx;     /* optional device table [n_modes], NULL -> m*c_sm              */
+} sc_modegemm_desc;
+
+int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
+                void* stream);
+
+/* gbias[c] = sum_b Re(ghat[b, c, dc]) -- the bias gradient read off the DC coefficient of
+ * the already-computed SC_FWD_ADJ_C2R spectrum (autograd of :567-568). */
+int sc_bias_grad(const sc_plan* plan, const float* ghat, int64_t batch, int64_t channels,
+                 float* gbias, void* stream);
+
+/* ---- fused dense layer (the reference module's forward / implicit backward) -------------------
+ * w: complex (cin, cout, w_extent...) stored weight; the used sub-block starts at w_start[d]
+ * in every mode dim and has the plan's `kept` extents (centred block of :465-489).
+ * xhat_saved: complex (batch, cin, k...) written by forward, read by backward.
+ * workspace: sc_layer_workspace_bytes(plan, batch, max(cin, cout)) bytes. */
+typedef struct {
+  int32_t batch, cin, cout, reserved;
+  int64_t w_extent[SC_MAX_DIMS];
+  int64_t w_start[SC_MAX_DIMS];
+} sc_layer_desc;
+
+size_t sc_layer_workspace_bytes(const sc_plan* plan, const sc_layer_desc* L);
+
+int sc_layer_forward(const sc_plan* plan, const sc_layer_desc* L, const float* x,
+                     const float* w, const float* bias, float* y, float* xhat_saved,
+                     void* workspace, void* stream);
+
+/* gw must be zero-initialised by the caller when the used sub-block is smaller than the
+ * stored weight (only the sub-block is written).  gbias may be NULL. */
+int sc_layer_backward(const sc_plan* plan, const sc_layer_desc* L, const float* gy,
+                      const float* xhat_saved, const float* w, float* gx, float* gw,
+                      float* gbias, void* workspace, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------------ */
+const char* sc_last_error(void);
+const char* sc_version(void);
+/* name of the dominant kernel a transform over this plan launches (for profile matching) */
+const char* sc_plan_kernel_name(const sc_plan* plan, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_ENGINE_H */

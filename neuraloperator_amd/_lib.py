@@ -1,0 +1,182 @@
+"""ctypes binding of libsc_engine.so (C-ABI: include/sc_engine.h).
+
+The product loads exactly one library: ``neuraloperator_amd/libsc_engine.so``, the hipcc
+gfx950 build of ``csrc/sc_engine.cpp``.  If it is missing the import of the engine raises --
+there is no CPU or PyTorch fallback for the hot path.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_int, c_int32, c_int64, c_size_t,
+                    c_void_p)
+
+SC_MAX_DIMS = 4
+SC_NORM = {"forward": 0, "backward": 1, "ortho": 2}
+SC_FWD_SCALED, SC_FWD_ADJ_C2R = 0, 1
+SC_INV_PADDED, SC_INV_ADJ_R2C = 0, 1
+SC_PLAN_FORCE_GENERIC = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libsc_engine.so")
+
+
+class PlanDesc(Structure):
+    _fields_ = [("ndim", c_int32), ("fft_norm", c_int32),
+                ("spatial", c_int64 * SC_MAX_DIMS), ("kept", c_int64 * SC_MAX_DIMS),
+                ("flags", c_int32), ("reserved", c_int32)]
+
+
+class ModeGemmDesc(Structure):
+    _fields_ = [("P", c_int64), ("Q", c_int64), ("R", c_int64), ("n_modes", c_int64),
+                ("a_sp", c_int64), ("a_sr", c_int64), ("a_sm", c_int64),
+                ("b_sr", c_int64), ("b_sq", c_int64), ("b_sm", c_int64),
+                ("c_sp", c_int64), ("c_sq", c_int64), ("c_sm", c_int64),
+                ("conj_a", c_int32), ("conj_b", c_int32),
+                ("accumulate", c_int32), ("reserved", c_int32),
+                ("b_idx", c_void_p), ("c_idx", c_void_p)]
+
+
+class LayerDesc(Structure):
+    _fields_ = [("batch", c_int32), ("cin", c_int32), ("cout", c_int32), ("reserved", c_int32),
+                ("w_extent", c_int64 * SC_MAX_DIMS), ("w_start", c_int64 * SC_MAX_DIMS)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class ScEngineLib:
+    """Thin typed wrapper over the shared library.  Pointers are raw integers
+    (``tensor.data_ptr()``); ``stream`` is a raw hipStream_t (0 = null stream)."""
+
+    # every symbol include/sc_engine.h declares
+    SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
+               "sc_transform_forward", "sc_transform_inverse", "sc_modegemm", "sc_bias_grad",
+               "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
+               "sc_last_error", "sc_version", "sc_plan_kernel_name"]
+
+    def __init__(self, path=DEFAULT_LIB):
+        if not os.path.isfile(path):
+            raise EngineError(
+                f"{path} not found: the HIP engine is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no fallback path.")
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        for s in self.SYMBOLS:
+            if not hasattr(L, s):
+                raise EngineError(f"{path} does not export {s}")
+        L.sc_plan_create.argtypes = [POINTER(c_void_p), POINTER(PlanDesc)]
+        L.sc_plan_create.restype = c_int
+        L.sc_plan_destroy.argtypes = [c_void_p]
+        L.sc_plan_destroy.restype = None
+        L.sc_plan_workspace_bytes.argtypes = [c_void_p, c_int64]
+        L.sc_plan_workspace_bytes.restype = c_size_t
+        L.sc_plan_is_fast.argtypes = [c_void_p]
+        L.sc_plan_is_fast.restype = c_int
+        L.sc_transform_forward.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                           c_void_p, c_void_p]
+        L.sc_transform_forward.restype = c_int
+        L.sc_transform_inverse.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                           c_void_p, c_int64, c_void_p, c_void_p]
+        L.sc_transform_inverse.restype = c_int
+        L.sc_modegemm.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sc_modegemm.restype = c_int
+        L.sc_bias_grad.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+        L.sc_bias_grad.restype = c_int
+        L.sc_layer_workspace_bytes.argtypes = [c_void_p, POINTER(LayerDesc)]
+        L.sc_layer_workspace_bytes.restype = c_size_t
+        L.sc_layer_forward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 7
+        L.sc_layer_forward.restype = c_int
+        L.sc_layer_backward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 8
+        L.sc_layer_backward.restype = c_int
+        L.sc_last_error.restype = c_char_p
+        L.sc_version.restype = c_char_p
+        L.sc_plan_kernel_name.argtypes = [c_void_p, c_int]
+        L.sc_plan_kernel_name.restype = c_char_p
+
+    # -- helpers -----------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self.lib.sc_last_error().decode())
+
+    def version(self):
+        return self.lib.sc_version().decode()
+
+    # -- plan ---------------------------------------------------------------------------
+    def plan_create(self, spatial, kept, fft_norm="forward", flags=0):
+        d = PlanDesc()
+        d.ndim = len(spatial)
+        if not 1 <= d.ndim <= SC_MAX_DIMS:
+            raise EngineError(f"spatial rank {d.ndim} unsupported (1..{SC_MAX_DIMS})")
+        d.fft_norm = SC_NORM[fft_norm]
+        for i, (n, k) in enumerate(zip(spatial, kept)):
+            d.spatial[i] = int(n)
+            d.kept[i] = int(k)
+        d.flags = flags
+        h = c_void_p()
+        self._check(self.lib.sc_plan_create(byref(h), byref(d)))
+        return h
+
+    def plan_destroy(self, plan):
+        self.lib.sc_plan_destroy(plan)
+
+    def plan_workspace_bytes(self, plan, n_images):
+        return int(self.lib.sc_plan_workspace_bytes(plan, n_images))
+
+    def plan_is_fast(self, plan):
+        return bool(self.lib.sc_plan_is_fast(plan))
+
+    def plan_kernel_name(self, plan, which):
+        return self.lib.sc_plan_kernel_name(plan, which).decode()
+
+    # -- stages ------------------------------------------------------------------------
+    def transform_forward(self, plan, mode, x_ptr, xhat_ptr, n_images, ws_ptr, stream=0):
+        self._check(self.lib.sc_transform_forward(plan, mode, x_ptr, xhat_ptr, n_images,
+                                                  ws_ptr, stream))
+
+    def transform_inverse(self, plan, mode, yhat_ptr, bias_ptr, channels, y_ptr, n_images,
+                          ws_ptr, stream=0):
+        self._check(self.lib.sc_transform_inverse(plan, mode, yhat_ptr, bias_ptr, channels,
+                                                  y_ptr, n_images, ws_ptr, stream))
+
+    def modegemm(self, a_ptr, b_ptr, c_ptr, stream=0, **kw):
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    def bias_grad(self, plan, ghat_ptr, batch, channels, gbias_ptr, stream=0):
+        self._check(self.lib.sc_bias_grad(plan, ghat_ptr, batch, channels, gbias_ptr, stream))
+
+    # -- fused dense layer -------------------------------------------------------------
+    @staticmethod
+    def layer_desc(batch, cin, cout, w_extent, w_start):
+        L = LayerDesc()
+        L.batch, L.cin, L.cout = batch, cin, cout
+        for i, (e, s) in enumerate(zip(w_extent, w_start)):
+            L.w_extent[i] = int(e)
+            L.w_start[i] = int(s)
+        return L
+
+    def layer_workspace_bytes(self, plan, L):
+        return int(self.lib.sc_layer_workspace_bytes(plan, byref(L)))
+
+    def layer_forward(self, plan, L, x, w, bias, y, xhat_saved, ws, stream=0):
+        self._check(self.lib.sc_layer_forward(plan, byref(L), x, w, bias, y, xhat_saved, ws,
+                                              stream))
+
+    def layer_backward(self, plan, L, gy, xhat_saved, w, gx, gw, gbias, ws, stream=0):
+        self._check(self.lib.sc_layer_backward(plan, byref(L), gy, xhat_saved, w, gx, gw,
+                                               gbias, ws, stream))
+
+
+_LIB = None
+
+
+def get_lib():
+    """The product's engine library (HIP build); raises EngineError when it is not built."""
+    global _LIB
+    if _LIB is None:
+        _LIB = ScEngineLib(DEFAULT_LIB)
+    return _LIB

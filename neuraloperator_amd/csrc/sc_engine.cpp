@@ -1,0 +1,610 @@
+// sc_engine.cpp -- host side of libsc_engine.so: plans, twiddle tables, kernel dispatch and
+// the extern "C" entry points declared in include/sc_engine.h.
+//
+// Built with:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip sc_engine.cpp
+// (tests/emu builds the same file with g++ -DSC_EMU; see sc_device.h).
+#include "../../include/sc_engine.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sc_device.h"
+#include "sc_kernels_generic.h"
+#include "sc_kernels_fft.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int sc_fail(const std::string& msg) {
+  g_last_error = msg;
+  return 1;
+}
+
+#define SC_CHECK_ARG(cond, msg) \
+  do {                          \
+    if (!(cond)) return sc_fail(std::string("sc_engine: ") + msg); \
+  } while (0)
+
+#define SC_CHECK_HIP(expr)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return sc_fail(std::string("sc_engine: HIP error in " #expr ": ") + hipGetErrorString(e_)); \
+  } while (0)
+
+static int sc_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return sc_fail(std::string("sc_engine: launch of ") + what + " failed: " + hipGetErrorString(e));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct DeviceTable {
+  cf32* ptr = nullptr;
+  int rows = 0, cols_pad = 0;
+};
+
+struct IdxKey {
+  int64_t ext[SC_MAX_DIMS], start[SC_MAX_DIMS];
+  bool operator<(const IdxKey& o) const { return std::memcmp(this, &o, sizeof(IdxKey)) < 0; }
+};
+
+struct sc_plan {
+  sc_plan_desc d;
+  int nd;
+  int64_t n[SC_MAX_DIMS], k[SC_MAX_DIMS];
+  int64_t ntot;          // prod n
+  int64_t modes;         // prod k  (kept modes per image)
+  int64_t dc_index;      // flattened index of the zero frequency inside the kept block
+  double sf, si;         // forward / inverse norm scales
+  // last axis
+  int r2c_jt, c2r_nt;
+  DeviceTable r2c[2];    // [SC_FWD_SCALED], [SC_FWD_ADJ_C2R]
+  DeviceTable c2r[2];    // [SC_INV_PADDED], [SC_INV_ADJ_R2C]
+  // non-last axes
+  int ax_fwd_jt[SC_MAX_DIMS], ax_inv_jt[SC_MAX_DIMS];
+  DeviceTable ax_fwd[SC_MAX_DIMS], ax_inv[SC_MAX_DIMS];
+  // fast path (power-of-two 2-D), see sc_kernels_fft.h
+  Fft2dPlan fft2d;
+  bool fast = false;
+  // weight sub-block index tables (device), keyed by (w_extent, w_start)
+  std::mutex idx_mu;
+  std::map<IdxKey, int32_t*> idx_cache;
+  std::vector<void*> owned;
+};
+
+static const double kTwoPi = 6.283185307179586476925286766559;
+
+static cf32 twiddle(int64_t f, int64_t n, int64_t N, double sign, double scale) {
+  int64_t prod = ((f % N) * (n % N)) % N;
+  if (prod < 0) prod += N;
+  const double th = kTwoPi * (double)prod / (double)N;
+  return cf_make((float)(scale * std::cos(th)), (float)(sign * scale * std::sin(th)));
+}
+
+static int upload_table(sc_plan* p, const std::vector<cf32>& host, int rows, int cols_pad,
+                        DeviceTable* out) {
+  void* dev = nullptr;
+  SC_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(cf32)));
+  p->owned.push_back(dev);
+  SC_CHECK_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(cf32), hipMemcpyHostToDevice));
+  out->ptr = (cf32*)dev;
+  out->rows = rows;
+  out->cols_pad = cols_pad;
+  return 0;
+}
+
+static int pick_tile(int64_t J, const int* cands, int ncand, int mult) {
+  int best = cands[0];
+  int64_t best_pad = -1;
+  for (int c = 0; c < ncand; ++c) {
+    const int64_t w = (int64_t)cands[c] * mult;
+    const int64_t pad = (J + w - 1) / w * w;
+    if (best_pad < 0 || pad < best_pad || (pad == best_pad && cands[c] > best)) {
+      best_pad = pad;
+      best = cands[c];
+    }
+  }
+  return best;
+}
+
+static int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+static double col_weight(int64_t j, int64_t N) {
+  if (j == 0) return 1.0;
+  if (N % 2 == 0 && j == N / 2) return 1.0;
+  return 2.0;
+}
+
+extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
+  SC_CHECK_ARG(out && desc, "null argument");
+  SC_CHECK_ARG(desc->ndim >= 1 && desc->ndim <= SC_MAX_DIMS, "ndim must be 1..4");
+  sc_plan* p = new sc_plan();
+  p->d = *desc;
+  p->nd = desc->ndim;
+  p->ntot = 1;
+  p->modes = 1;
+  for (int d = 0; d < p->nd; ++d) {
+    p->n[d] = desc->spatial[d];
+    p->k[d] = desc->kept[d];
+    if (p->n[d] < 1 || p->k[d] < 1) {
+      delete p;
+      return sc_fail("sc_engine: spatial sizes and kept modes must be >= 1");
+    }
+    const int64_t lim = (d == p->nd - 1) ? (p->n[d] / 2 + 1) : p->n[d];
+    if (p->k[d] > lim) {
+      delete p;
+      return sc_fail("sc_engine: kept modes exceed the available spectrum");
+    }
+    p->ntot *= p->n[d];
+    p->modes *= p->k[d];
+  }
+  switch (desc->fft_norm) {
+    case SC_NORM_FORWARD: p->sf = 1.0 / (double)p->ntot; p->si = 1.0; break;
+    case SC_NORM_BACKWARD: p->sf = 1.0; p->si = 1.0 / (double)p->ntot; break;
+    case SC_NORM_ORTHO: p->sf = p->si = 1.0 / std::sqrt((double)p->ntot); break;
+    default: delete p; return sc_fail("sc_engine: unknown fft_norm");
+  }
+  // zero-frequency position inside the kept block (row k//2 in every non-last dim, col 0)
+  p->dc_index = 0;
+  for (int d = 0; d < p->nd; ++d) {
+    const int64_t r = (d == p->nd - 1) ? 0 : p->k[d] / 2;
+    p->dc_index = p->dc_index * p->k[d] + r;
+  }
+
+  const int L = p->nd - 1;
+  const int64_t N = p->n[L], J = p->k[L];
+  int rc = 0;
+  {
+    static const int c1[] = {2, 3, 4, 5, 8, 9, 16, 17};
+    p->r2c_jt = pick_tile(J, c1, 8, 4);
+    const int64_t Jpad = round_up(J, 4 * p->r2c_jt);
+    for (int v = 0; v < 2 && !rc; ++v) {
+      std::vector<cf32> h((size_t)N * Jpad, cf_make(0.f, 0.f));
+      for (int64_t n = 0; n < N; ++n)
+        for (int64_t j = 0; j < J; ++j) {
+          const double s = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
+          h[(size_t)n * Jpad + j] = twiddle(j, n, N, -1.0, s);
+        }
+      rc = upload_table(p, h, (int)N, (int)Jpad, &p->r2c[v]);
+    }
+    static const int c2[] = {4, 8, 16};
+    p->c2r_nt = pick_tile(N, c2, 3, 4);
+    const int64_t Npad = round_up(N, 4 * p->c2r_nt);
+    for (int v = 0; v < 2 && !rc; ++v) {
+      std::vector<cf32> h((size_t)J * Npad, cf_make(0.f, 0.f));
+      for (int64_t j = 0; j < J; ++j)
+        for (int64_t n = 0; n < N; ++n) {
+          const double s = (v == SC_INV_PADDED) ? p->si * col_weight(j, N) : p->sf;
+          h[(size_t)j * Npad + n] = twiddle(j, n, N, +1.0, s);
+        }
+      rc = upload_table(p, h, (int)J, (int)Npad, &p->c2r[v]);
+    }
+  }
+  static const int c3[] = {4, 8, 16};
+  for (int d = 0; d < L && !rc; ++d) {
+    const int64_t Nd = p->n[d], Kd = p->k[d];
+    p->ax_fwd_jt[d] = pick_tile(Kd, c3, 3, 1);
+    p->ax_inv_jt[d] = pick_tile(Nd, c3, 3, 1);
+    {
+      const int64_t Jpad = round_up(Kd, p->ax_fwd_jt[d]);
+      std::vector<cf32> h((size_t)Nd * Jpad, cf_make(0.f, 0.f));
+      for (int64_t n = 0; n < Nd; ++n)
+        for (int64_t j = 0; j < Kd; ++j) h[(size_t)n * Jpad + j] = twiddle(j - Kd / 2, n, Nd, -1.0, 1.0);
+      rc = upload_table(p, h, (int)Nd, (int)Jpad, &p->ax_fwd[d]);
+    }
+    if (!rc) {
+      const int64_t Jpad = round_up(Nd, p->ax_inv_jt[d]);
+      std::vector<cf32> h((size_t)Kd * Jpad, cf_make(0.f, 0.f));
+      for (int64_t kk = 0; kk < Kd; ++kk)
+        for (int64_t hh = 0; hh < Nd; ++hh) h[(size_t)kk * Jpad + hh] = twiddle(kk - Kd / 2, hh, Nd, +1.0, 1.0);
+      rc = upload_table(p, h, (int)Kd, (int)Jpad, &p->ax_inv[d]);
+    }
+  }
+  if (!rc && !(desc->flags & SC_PLAN_FORCE_GENERIC)) {
+    std::string why;
+    if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
+  }
+  if (rc) {
+    sc_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" void sc_plan_destroy(sc_plan* p) {
+  if (!p) return;
+  for (void* q : p->owned) (void)hipFree(q);
+  for (auto& kv : p->idx_cache) (void)hipFree(kv.second);
+  delete p;
+}
+
+extern "C" int sc_plan_is_fast(const sc_plan* p) { return p && p->fast ? 1 : 0; }
+
+// intermediate sizes (complex elements) of the generic pass chain
+static void generic_ws_sizes(const sc_plan* p, int64_t n_images, int64_t* s1, int64_t* s2) {
+  const int L = p->nd - 1;
+  int64_t lines = n_images;
+  for (int d = 0; d < L; ++d) lines *= p->n[d];
+  *s1 = (p->nd >= 2) ? lines * p->k[L] : 0;
+  if (p->nd >= 3) {
+    int64_t o = n_images;
+    for (int d = 0; d < L - 1; ++d) o *= p->n[d];
+    *s2 = o * p->k[L - 1] * p->k[L];
+  } else {
+    *s2 = 0;
+  }
+}
+
+extern "C" size_t sc_plan_workspace_bytes(const sc_plan* p, int64_t n_images) {
+  if (!p) return 0;
+  if (p->fast) return fft2d_workspace_bytes(&p->fft2d, n_images);
+  int64_t s1, s2;
+  generic_ws_sizes(p, n_images, &s1, &s2);
+  return (size_t)(s1 + s2) * sizeof(cf32) + 256;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic pass launchers
+// ------------------------------------------------------------------------------------------
+template <int JT>
+static void launch_r2c(const float* in, cf32* out, const DeviceTable& t, int64_t lines, int N, int J,
+                       sc_stream_t st) {
+  dim3 grid((unsigned)((lines + SC_LINES_PER_BLOCK - 1) / SC_LINES_PER_BLOCK),
+            (unsigned)((J + 4 * JT - 1) / (4 * JT)));
+  SC_LAUNCH((k_last_r2c<JT>), grid, dim3(SC_BLOCK), 0, st, in, out, (const cf32*)t.ptr, lines, N, J,
+            t.cols_pad);
+}
+
+static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
+  const int L = p->nd - 1;
+  const int N = (int)p->n[L], J = (int)p->k[L];
+  const DeviceTable& t = p->r2c[mode];
+  switch (p->r2c_jt) {
+    case 2: launch_r2c<2>(in, out, t, lines, N, J, st); break;
+    case 3: launch_r2c<3>(in, out, t, lines, N, J, st); break;
+    case 4: launch_r2c<4>(in, out, t, lines, N, J, st); break;
+    case 5: launch_r2c<5>(in, out, t, lines, N, J, st); break;
+    case 8: launch_r2c<8>(in, out, t, lines, N, J, st); break;
+    case 9: launch_r2c<9>(in, out, t, lines, N, J, st); break;
+    case 16: launch_r2c<16>(in, out, t, lines, N, J, st); break;
+    case 17: launch_r2c<17>(in, out, t, lines, N, J, st); break;
+    default: return sc_fail("sc_engine: bad r2c tile");
+  }
+  return sc_check_launch("k_last_r2c");
+}
+
+template <int NT>
+static void launch_c2r(const cf32* in, float* out, const DeviceTable& t, const float* bias, int64_t lines,
+                       int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
+  dim3 grid((unsigned)((lines + SC_LINES_PER_BLOCK - 1) / SC_LINES_PER_BLOCK),
+            (unsigned)((N + 4 * NT - 1) / (4 * NT)));
+  SC_LAUNCH((k_last_c2r<NT>), grid, dim3(SC_BLOCK), 0, st, in, out, (const cf32*)t.ptr, bias, lines, N, J,
+            t.cols_pad, lpi, channels);
+}
+
+static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
+                   int64_t lpi, int64_t channels, sc_stream_t st) {
+  const int L = p->nd - 1;
+  const int N = (int)p->n[L], J = (int)p->k[L];
+  const DeviceTable& t = p->c2r[mode];
+  switch (p->c2r_nt) {
+    case 4: launch_c2r<4>(in, out, t, bias, lines, N, J, lpi, channels, st); break;
+    case 8: launch_c2r<8>(in, out, t, bias, lines, N, J, lpi, channels, st); break;
+    case 16: launch_c2r<16>(in, out, t, bias, lines, N, J, lpi, channels, st); break;
+    default: return sc_fail("sc_engine: bad c2r tile");
+  }
+  return sc_check_launch("k_last_c2r");
+}
+
+template <int JT>
+static void launch_axis(const cf32* in, cf32* out, const DeviceTable& t, int64_t outer, int N, int J,
+                        int64_t inner, sc_stream_t st) {
+  const int64_t cols = outer * inner;
+  dim3 grid((unsigned)((cols + SC_BLOCK - 1) / SC_BLOCK), (unsigned)((J + JT - 1) / JT));
+  SC_LAUNCH((k_axis_pass<JT>), grid, dim3(SC_BLOCK), 0, st, in, out, (const cf32*)t.ptr, outer, N, J, inner,
+            t.cols_pad);
+}
+
+static int run_axis(int jt, const cf32* in, cf32* out, const DeviceTable& t, int64_t outer, int N, int J,
+                    int64_t inner, sc_stream_t st) {
+  switch (jt) {
+    case 4: launch_axis<4>(in, out, t, outer, N, J, inner, st); break;
+    case 8: launch_axis<8>(in, out, t, outer, N, J, inner, st); break;
+    case 16: launch_axis<16>(in, out, t, outer, N, J, inner, st); break;
+    default: return sc_fail("sc_engine: bad axis tile");
+  }
+  return sc_check_launch("k_axis_pass");
+}
+
+// ------------------------------------------------------------------------------------------
+// transforms
+// ------------------------------------------------------------------------------------------
+extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, float* xhat,
+                                    int64_t n_images, void* workspace, void* stream) {
+  SC_CHECK_ARG(p && x && xhat, "null argument");
+  SC_CHECK_ARG(mode == SC_FWD_SCALED || mode == SC_FWD_ADJ_C2R, "bad forward mode");
+  if (n_images <= 0) return 0;
+  sc_stream_t st = (sc_stream_t)stream;
+  if (p->fast) return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
+  const int L = p->nd - 1;
+  int64_t lines = n_images;
+  for (int d = 0; d < L; ++d) lines *= p->n[d];
+  if (p->nd == 1) return run_r2c(p, mode, x, (cf32*)xhat, lines, st);
+  SC_CHECK_ARG(workspace, "workspace required");
+  int64_t s1, s2;
+  generic_ws_sizes(p, n_images, &s1, &s2);
+  cf32* bufA = (cf32*)workspace;
+  cf32* bufB = bufA + s1;
+  int rc = run_r2c(p, mode, x, bufA, lines, st);
+  if (rc) return rc;
+  cf32* cur = bufA;
+  int64_t inner = p->k[L];
+  for (int d = L - 1; d >= 0; --d) {
+    int64_t outer = n_images;
+    for (int e = 0; e < d; ++e) outer *= p->n[e];
+    cf32* dst = (d == 0) ? (cf32*)xhat : (cur == bufA ? bufB : bufA);
+    rc = run_axis(p->ax_fwd_jt[d], cur, dst, p->ax_fwd[d], outer, (int)p->n[d], (int)p->k[d], inner, st);
+    if (rc) return rc;
+    cur = dst;
+    inner *= p->k[d];
+  }
+  return 0;
+}
+
+extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yhat, const float* bias,
+                                    int64_t channels, float* y, int64_t n_images, void* workspace,
+                                    void* stream) {
+  SC_CHECK_ARG(p && yhat && y, "null argument");
+  SC_CHECK_ARG(mode == SC_INV_PADDED || mode == SC_INV_ADJ_R2C, "bad inverse mode");
+  if (n_images <= 0) return 0;
+  if (channels <= 0) channels = 1;
+  sc_stream_t st = (sc_stream_t)stream;
+  if (p->fast)
+    return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
+                         &g_last_error);
+  const int L = p->nd - 1;
+  int64_t lpi = 1;
+  for (int d = 0; d < L; ++d) lpi *= p->n[d];
+  const int64_t lines = n_images * lpi;
+  if (p->nd == 1) return run_c2r(p, mode, (const cf32*)yhat, y, bias, lines, lpi, channels, st);
+  SC_CHECK_ARG(workspace, "workspace required");
+  int64_t s1, s2;
+  generic_ws_sizes(p, n_images, &s1, &s2);
+  cf32* bufA = (cf32*)workspace;  // s1: the last (largest) intermediate lives here
+  cf32* bufB = bufA + s1;
+  // choose buffers so that the final intermediate lands in bufA
+  const cf32* cur = (const cf32*)yhat;
+  int64_t outer = n_images;
+  for (int d = 0; d < L; ++d) {
+    int64_t inner = 1;
+    for (int e = d + 1; e <= L; ++e) inner *= p->k[e];
+    const int remaining = L - 1 - d;  // passes after this one
+    cf32* dst = (remaining % 2 == 0) ? bufA : bufB;
+    int rc = run_axis(p->ax_inv_jt[d], cur, dst, p->ax_inv[d], outer, (int)p->k[d], (int)p->n[d], inner, st);
+    if (rc) return rc;
+    cur = dst;
+    outer *= p->n[d];
+  }
+  return run_c2r(p, mode, cur, y, bias, lines, lpi, channels, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// mode-batched GEMM
+// ------------------------------------------------------------------------------------------
+template <int PT, int QT, bool CA, bool CB>
+static void launch_modegemm(const ModeGemmArgs& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  dim3 grid((unsigned)((g.M + SC_WAVE - 1) / SC_WAVE), (unsigned)((g.P + 4 * PT - 1) / (4 * PT)),
+            (unsigned)((g.Q + QT - 1) / QT));
+  SC_LAUNCH((k_modegemm<PT, QT, CA, CB>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
+}
+
+template <int PT, int QT>
+static int dispatch_modegemm_conj(const ModeGemmArgs& g, int ca, int cb, const cf32* A, const cf32* B, cf32* C,
+                                  sc_stream_t st) {
+  if (!ca && !cb) launch_modegemm<PT, QT, false, false>(g, A, B, C, st);
+  else if (ca && !cb) launch_modegemm<PT, QT, true, false>(g, A, B, C, st);
+  else if (!ca && cb) launch_modegemm<PT, QT, false, true>(g, A, B, C, st);
+  else launch_modegemm<PT, QT, true, true>(g, A, B, C, st);
+  return sc_check_launch("k_modegemm");
+}
+
+extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
+                           void* stream) {
+  SC_CHECK_ARG(d && A && B && C, "null argument");
+  SC_CHECK_ARG(d->P >= 0 && d->Q >= 0 && d->R >= 0 && d->n_modes >= 0, "negative extent");
+  if (d->P == 0 || d->Q == 0 || d->n_modes == 0) return 0;
+  SC_CHECK_ARG(d->R > 0, "R must be > 0");
+  ModeGemmArgs g;
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.a_sm = d->a_sm;
+  g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.b_sm = d->b_sm;
+  g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
+  g.b_idx = d->b_idx; g.c_idx = d->c_idx;
+  g.accumulate = d->accumulate;
+  SC_CHECK_ARG((g.Q + 3) / 4 <= 65535 && (g.P + 15) / 16 <= 65535, "P/Q too large for the launch grid");
+  sc_stream_t st = (sc_stream_t)stream;
+  const cf32* a = (const cf32*)A;
+  const cf32* b = (const cf32*)B;
+  cf32* c = (cf32*)C;
+  if (g.Q > 4) return dispatch_modegemm_conj<4, 8>(g, d->conj_a, d->conj_b, a, b, c, st);
+  return dispatch_modegemm_conj<4, 4>(g, d->conj_a, d->conj_b, a, b, c, st);
+}
+
+extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,
+                            float* gbias, void* stream) {
+  SC_CHECK_ARG(p && ghat && gbias, "null argument");
+  if (channels <= 0) return 0;
+  dim3 grid((unsigned)((channels + SC_BLOCK - 1) / SC_BLOCK));
+  SC_LAUNCH(k_bias_grad, grid, dim3(SC_BLOCK), 0, (sc_stream_t)stream, (const cf32*)ghat, gbias, batch,
+            channels, p->modes, p->dc_index);
+  return sc_check_launch("k_bias_grad");
+}
+
+// ------------------------------------------------------------------------------------------
+// fused dense layer
+// ------------------------------------------------------------------------------------------
+static bool layer_full_block(const sc_plan* p, const sc_layer_desc* L) {
+  for (int d = 0; d < p->nd; ++d)
+    if (L->w_start[d] != 0 || L->w_extent[d] != p->k[d]) return false;
+  return true;
+}
+
+static int layer_index_table(const sc_plan* cp, const sc_layer_desc* L, const int32_t** out) {
+  sc_plan* p = const_cast<sc_plan*>(cp);
+  if (layer_full_block(p, L)) {
+    *out = nullptr;
+    return 0;
+  }
+  IdxKey key;
+  std::memset(&key, 0, sizeof(key));
+  int64_t wtot = 1;
+  for (int d = 0; d < p->nd; ++d) {
+    key.ext[d] = L->w_extent[d];
+    key.start[d] = L->w_start[d];
+    SC_CHECK_ARG(L->w_start[d] >= 0 && L->w_start[d] + p->k[d] <= L->w_extent[d],
+                 "weight sub-block outside the stored weight");
+    wtot *= L->w_extent[d];
+  }
+  SC_CHECK_ARG(wtot < (int64_t)1 << 31, "weight slab too large for int32 index table");
+  std::lock_guard<std::mutex> lock(p->idx_mu);
+  auto it = p->idx_cache.find(key);
+  if (it != p->idx_cache.end()) {
+    *out = it->second;
+    return 0;
+  }
+  std::vector<int32_t> h((size_t)p->modes);
+  std::vector<int64_t> r(p->nd, 0);
+  for (int64_t m = 0; m < p->modes; ++m) {
+    int64_t off = 0;
+    for (int d = 0; d < p->nd; ++d) off = off * L->w_extent[d] + (L->w_start[d] + r[d]);
+    h[(size_t)m] = (int32_t)off;
+    for (int d = p->nd - 1; d >= 0; --d) {
+      if (++r[d] < p->k[d]) break;
+      r[d] = 0;
+    }
+  }
+  void* dev = nullptr;
+  SC_CHECK_HIP(hipMalloc(&dev, h.size() * sizeof(int32_t)));
+  SC_CHECK_HIP(hipMemcpy(dev, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  p->idx_cache[key] = (int32_t*)dev;
+  *out = (int32_t*)dev;
+  return 0;
+}
+
+extern "C" size_t sc_layer_workspace_bytes(const sc_plan* p, const sc_layer_desc* L) {
+  if (!p || !L) return 0;
+  const int64_t cmax = L->cin > L->cout ? L->cin : L->cout;
+  const size_t tws = round_up((int64_t)sc_plan_workspace_bytes(p, (int64_t)L->batch * cmax), 256);
+  const size_t spec = (size_t)L->batch * (size_t)(L->cin + L->cout) * (size_t)p->modes * sizeof(cf32);
+  return tws + round_up((int64_t)spec, 256) + 512;
+}
+
+static int64_t weight_slab(const sc_plan* p, const sc_layer_desc* L) {
+  int64_t w = 1;
+  for (int d = 0; d < p->nd; ++d) w *= L->w_extent[d];
+  return w;
+}
+
+extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const float* x, const float* w,
+                                const float* bias, float* y, float* xhat_saved, void* workspace,
+                                void* stream) {
+  SC_CHECK_ARG(p && L && x && w && y && xhat_saved && workspace, "null argument");
+  const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
+  if (B == 0) return 0;
+  const int32_t* idx = nullptr;
+  int rc = layer_index_table(p, L, &idx);
+  if (rc) return rc;
+  const int64_t Wm = weight_slab(p, L);
+  const int64_t cmax = Ci > Co ? Ci : Co;
+  char* ws = (char*)workspace;
+  const size_t tws = round_up((int64_t)sc_plan_workspace_bytes(p, B * cmax), 256);
+  float* yhat = (float*)(ws + tws);
+
+  rc = sc_transform_forward(p, SC_FWD_SCALED, x, xhat_saved, B * Ci, ws, stream);
+  if (rc) return rc;
+  sc_modegemm_desc g;
+  std::memset(&g, 0, sizeof(g));
+  g.P = B; g.Q = Co; g.R = Ci; g.n_modes = Mk;
+  g.a_sp = Ci * Mk; g.a_sr = Mk; g.a_sm = 1;
+  g.b_sr = Co * Wm; g.b_sq = Wm; g.b_sm = 1; g.b_idx = idx;
+  g.c_sp = Co * Mk; g.c_sq = Mk; g.c_sm = 1;
+  rc = sc_modegemm(&g, xhat_saved, w, yhat, stream);
+  if (rc) return rc;
+  return sc_transform_inverse(p, SC_INV_PADDED, yhat, bias, Co, y, B * Co, ws, stream);
+}
+
+extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const float* gy,
+                                 const float* xhat_saved, const float* w, float* gx, float* gw,
+                                 float* gbias, void* workspace, void* stream) {
+  SC_CHECK_ARG(p && L && gy && xhat_saved && w && workspace, "null argument");
+  const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
+  if (B == 0) return 0;
+  const int32_t* idx = nullptr;
+  int rc = layer_index_table(p, L, &idx);
+  if (rc) return rc;
+  const int64_t Wm = weight_slab(p, L);
+  const int64_t cmax = Ci > Co ? Ci : Co;
+  char* ws = (char*)workspace;
+  const size_t tws = round_up((int64_t)sc_plan_workspace_bytes(p, B * cmax), 256);
+  float* ghat = (float*)(ws + tws);
+  float* gxhat = ghat + 2 * B * Co * Mk;
+
+  rc = sc_transform_forward(p, SC_FWD_ADJ_C2R, gy, ghat, B * Co, ws, stream);
+  if (rc) return rc;
+  if (gbias) {
+    rc = sc_bias_grad(p, ghat, B, Co, gbias, stream);
+    if (rc) return rc;
+  }
+  sc_modegemm_desc g;
+  if (gw) {
+    // gW[i,o,m] = sum_b conj(xhat[b,i,m]) * ghat[b,o,m]
+    std::memset(&g, 0, sizeof(g));
+    g.P = Ci; g.Q = Co; g.R = B; g.n_modes = Mk;
+    g.a_sp = Mk; g.a_sr = Ci * Mk; g.a_sm = 1; g.conj_a = 1;
+    g.b_sr = Co * Mk; g.b_sq = Mk; g.b_sm = 1;
+    g.c_sp = Co * Wm; g.c_sq = Wm; g.c_sm = 1; g.c_idx = idx;
+    rc = sc_modegemm(&g, xhat_saved, ghat, gw, stream);
+    if (rc) return rc;
+  }
+  if (gx) {
+    // gxhat[b,i,m] = sum_o ghat[b,o,m] * conj(W[i,o,m])
+    std::memset(&g, 0, sizeof(g));
+    g.P = B; g.Q = Ci; g.R = Co; g.n_modes = Mk;
+    g.a_sp = Co * Mk; g.a_sr = Mk; g.a_sm = 1;
+    g.b_sr = Wm; g.b_sq = Co * Wm; g.b_sm = 1; g.b_idx = idx; g.conj_b = 1;
+    g.c_sp = Ci * Mk; g.c_sq = Mk; g.c_sm = 1;
+    rc = sc_modegemm(&g, ghat, w, gxhat, stream);
+    if (rc) return rc;
+    rc = sc_transform_inverse(p, SC_INV_ADJ_R2C, gxhat, nullptr, Ci, gx, B * Ci, ws, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" const char* sc_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char* sc_version(void) {
+#ifdef SC_EMU
+  return "sc_engine 0.1 (host emulation build -- tests only)";
+#else
+  return "sc_engine 0.1 (gfx950)";
+#endif
+}
+
+extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
+  if (!p) return "";
+  if (p->fast) return fft2d_kernel_name(which);
+  return which == 0 ? "k_last_r2c" : "k_last_c2r";
+}

@@ -1,0 +1,269 @@
+// sc_kernels_generic.h -- size-agnostic kernels of the SpectralConv engine.
+//
+// These handle ANY grid size / dimensionality (odd sizes, 1-D .. 4-D, kept-mode counts of
+// any parity) by evaluating each 1-D pruned / zero-padded DFT directly from a twiddle
+// table: only the kept modes are ever computed or stored, so the full half-spectrum of the
+// reference (spectral_convolution.py:443-462, 531-559) never exists.  Power-of-two grids
+// take the FFT kernels in sc_kernels_fft.h instead; both produce the same layout.
+//
+// Common design (CDNA4): lanes run over independent lines, the transform axis is a serial
+// loop per lane, and the twiddle for (n, j) is wave-uniform -> it is fetched with scalar
+// loads (s_load_dwordxN from the [n][j]-major table) and fed to v_fma_f32 as an SGPR
+// operand.  No cross-lane traffic; LDS is used only to turn the row-major last axis into
+// lane-per-line order and back so that every global access is coalesced.
+#pragma once
+#include "sc_device.h"
+
+#define SC_BLOCK 256
+#define SC_WAVE 64
+#define SC_LINES_PER_BLOCK 64
+
+// ------------------------------------------------------------------------------------------
+// Pass over a non-last axis:  out[o, j, i] = sum_n T[n][j] * in[o, n, i]
+//   in : complex [outer, N, inner]      out: complex [outer, J, inner]
+//   T  : complex [N][Jpad] (Jpad multiple of JT, zero padded)
+// forward:  N = n_d, J = k_d, T[n][j] = exp(-2 pi i f_j n / n_d)       (prunes)
+// inverse:  N = k_d, J = n_d, T[n][j] = exp(+2 pi i f_n j / n_d)       (zero-pads)
+// lanes = flattened (o, i); grid.y = j tiles.
+// ------------------------------------------------------------------------------------------
+template <int JT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_axis_pass(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ table,
+            int64_t outer, int N, int J, int64_t inner, int Jpad) {
+  const int64_t col = (int64_t)SC_BID_X * SC_BLOCK + SC_TID;
+  const int j0 = SC_BID_Y * JT;
+  const bool active = col < outer * inner;
+  const int64_t c = active ? col : 0;
+  const int64_t o = c / inner, i = c - o * inner;
+  const cf32* src = in + (o * N) * inner + i;
+  cf32 acc[JT];
+#pragma unroll
+  for (int jj = 0; jj < JT; ++jj) acc[jj] = cf_make(0.f, 0.f);
+#pragma unroll 2
+  for (int n = 0; n < N; ++n) {
+    const cf32 v = src[(int64_t)n * inner];
+    const cf32* t = table + (int64_t)n * Jpad + j0;
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) cf_mac(acc[jj], t[jj], v);
+  }
+  if (active) {
+    cf32* dst = out + (o * J) * inner + i;
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj)
+      if (j0 + jj < J) dst[(int64_t)(j0 + jj) * inner] = acc[jj];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Last axis, real -> complex, pruned:  out[l, j] = sum_n in[l, n] * T[n][j]
+//   in: real [lines, N]    out: complex [lines, J]    T: complex [N][Jpad]
+// A block owns 64 lines; its 4 waves own 4 adjacent j-tiles of JT columns; grid.y walks
+// groups of 4*JT columns.  The input tile goes through LDS (coalesced load, lane-per-line
+// read, row stride 65 -> conflict free); results return through LDS for coalesced stores.
+// ------------------------------------------------------------------------------------------
+#define SC_R2C_NC 64
+template <int JT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_last_r2c(const float* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ table,
+           int64_t lines, int N, int J, int Jpad) {
+  SC_SHARED float tile[SC_LINES_PER_BLOCK][SC_R2C_NC + 1];
+  SC_SHARED cf32 otile[SC_LINES_PER_BLOCK][4 * JT + 1];
+  const int tid = SC_TID;
+  const int lane = tid & 63, w = tid >> 6;
+  const int64_t l0 = (int64_t)SC_BID_X * SC_LINES_PER_BLOCK;
+  const int jg0 = SC_BID_Y * 4 * JT;
+  const int j0 = jg0 + w * JT;
+  cf32 acc[JT];
+#pragma unroll
+  for (int jj = 0; jj < JT; ++jj) acc[jj] = cf_make(0.f, 0.f);
+
+  for (int n0 = 0; n0 < N; n0 += SC_R2C_NC) {
+    for (int idx = tid; idx < SC_LINES_PER_BLOCK * SC_R2C_NC; idx += SC_BLOCK) {
+      const int l = idx / SC_R2C_NC, n = idx - l * SC_R2C_NC;
+      const int64_t gl = l0 + l;
+      const int gn = n0 + n;
+      tile[l][n] = (gl < lines && gn < N) ? in[gl * N + gn] : 0.f;
+    }
+    SC_SYNC();
+    const int nmax = (N - n0 < SC_R2C_NC) ? (N - n0) : SC_R2C_NC;
+    if (j0 < J) {
+      for (int n = 0; n < nmax; ++n) {
+        const float v = tile[lane][n];
+        const cf32* t = table + (int64_t)(n0 + n) * Jpad + j0;
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) {
+          acc[jj].x = fmaf(v, t[jj].x, acc[jj].x);
+          acc[jj].y = fmaf(v, t[jj].y, acc[jj].y);
+        }
+      }
+    }
+    SC_SYNC();
+  }
+#pragma unroll
+  for (int jj = 0; jj < JT; ++jj) otile[lane][w * JT + jj] = acc[jj];
+  SC_SYNC();
+  const int ncols = (J - jg0 < 4 * JT) ? (J - jg0) : 4 * JT;
+  for (int idx = tid; idx < SC_LINES_PER_BLOCK * ncols; idx += SC_BLOCK) {
+    const int l = idx / ncols, c = idx - l * ncols;
+    if (l0 + l < lines) out[(l0 + l) * J + jg0 + c] = otile[l][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Last axis, complex -> real, zero-padded:
+//   out[l, n] = sum_j ( in[l,j].re * T[j][n].re - in[l,j].im * T[j][n].im ) + bias[ch(l)]
+//   in: complex [lines, J]   out: real [lines, N]   T: complex [J][Npad] = w_j (cos, sin)
+// w_j carries the C2R column weight (1 for DC / Nyquist, 2 inside) and the norm, so the
+// imaginary parts of the DC and Nyquist columns drop out exactly as in irfft
+// (spectral_convolution.py:552-559).  ch(l) = (l / lines_per_image) % channels.
+// ------------------------------------------------------------------------------------------
+#define SC_C2R_JC 32
+template <int NT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_last_c2r(const cf32* __restrict__ in, float* __restrict__ out, const cf32* __restrict__ table,
+           const float* __restrict__ bias, int64_t lines, int N, int J, int Npad,
+           int64_t lines_per_image, int64_t channels) {
+  SC_SHARED cf32 itile[SC_LINES_PER_BLOCK][SC_C2R_JC + 1];
+  SC_SHARED float otile[SC_LINES_PER_BLOCK][4 * NT + 1];
+  const int tid = SC_TID;
+  const int lane = tid & 63, w = tid >> 6;
+  const int64_t l0 = (int64_t)SC_BID_X * SC_LINES_PER_BLOCK;
+  const int ng0 = SC_BID_Y * 4 * NT;
+  const int n0 = ng0 + w * NT;
+  float acc[NT];
+#pragma unroll
+  for (int nn = 0; nn < NT; ++nn) acc[nn] = 0.f;
+
+  for (int j0 = 0; j0 < J; j0 += SC_C2R_JC) {
+    for (int idx = tid; idx < SC_LINES_PER_BLOCK * SC_C2R_JC; idx += SC_BLOCK) {
+      const int l = idx / SC_C2R_JC, j = idx - l * SC_C2R_JC;
+      const int64_t gl = l0 + l;
+      const int gj = j0 + j;
+      itile[l][j] = (gl < lines && gj < J) ? in[gl * J + gj] : cf_make(0.f, 0.f);
+    }
+    SC_SYNC();
+    const int jmax = (J - j0 < SC_C2R_JC) ? (J - j0) : SC_C2R_JC;
+    if (n0 < N) {
+      for (int j = 0; j < jmax; ++j) {
+        const cf32 v = itile[lane][j];
+        const cf32* t = table + (int64_t)(j0 + j) * Npad + n0;
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+          acc[nn] = fmaf(v.x, t[nn].x, acc[nn]);
+          acc[nn] = fmaf(-v.y, t[nn].y, acc[nn]);
+        }
+      }
+    }
+    SC_SYNC();
+  }
+  float badd = 0.f;
+  if (bias != nullptr) {
+    int64_t gl = l0 + lane;
+    if (gl >= lines) gl = lines - 1;
+    badd = bias[(gl / lines_per_image) % channels];
+  }
+#pragma unroll
+  for (int nn = 0; nn < NT; ++nn) otile[lane][w * NT + nn] = acc[nn] + badd;
+  SC_SYNC();
+  const int ncols = (N - ng0 < 4 * NT) ? (N - ng0) : 4 * NT;
+  for (int idx = tid; idx < SC_LINES_PER_BLOCK * ncols; idx += SC_BLOCK) {
+    const int l = idx / ncols, c = idx - l * ncols;
+    if (l0 + l < lines) out[(l0 + l) * N + ng0 + c] = otile[l][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mode-batched complex GEMM:  C[p,q,m] (+)= sum_r opA(A[p,r,m]) * opB(B[r,q,m])
+// lanes = modes (every operand has the mode index innermost -> all accesses coalesced, no
+// LDS, no cross-lane traffic); each lane keeps a PT x QT register tile; the 4 waves of a
+// block take 4 adjacent p-tiles of the same (mode tile, q tile) so B is shared through L1.
+// ------------------------------------------------------------------------------------------
+struct ModeGemmArgs {
+  int64_t P, Q, R, M;
+  int64_t a_sp, a_sr, a_sm;
+  int64_t b_sr, b_sq, b_sm;
+  int64_t c_sp, c_sq, c_sm;
+  const int32_t* b_idx;
+  const int32_t* c_idx;
+  int accumulate;
+};
+
+template <int PT, int QT, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
+           cf32* __restrict__ C) {
+  const int tid = SC_TID;
+  const int lane = tid & 63, w = tid >> 6;
+  const int64_t m = (int64_t)SC_BID_X * SC_WAVE + lane;
+  const int64_t p0 = ((int64_t)SC_BID_Y * 4 + w) * PT;
+  const int64_t q0 = (int64_t)SC_BID_Z * QT;
+  if (p0 >= g.P) return;  // whole wave idle (no barriers in this kernel)
+  const bool active = m < g.M;
+  const int64_t mm = active ? m : g.M - 1;
+  const int64_t offa = mm * g.a_sm;
+  const int64_t offb = g.b_idx ? (int64_t)g.b_idx[mm] : mm * g.b_sm;
+  const int64_t offc = g.c_idx ? (int64_t)g.c_idx[mm] : mm * g.c_sm;
+
+  int64_t pa[PT], qb[QT];
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp) {
+    const int64_t p = (p0 + pp < g.P) ? (p0 + pp) : (g.P - 1);
+    pa[pp] = p * g.a_sp + offa;
+  }
+#pragma unroll
+  for (int qq = 0; qq < QT; ++qq) {
+    const int64_t q = (q0 + qq < g.Q) ? (q0 + qq) : (g.Q - 1);
+    qb[qq] = q * g.b_sq + offb;
+  }
+  cf32 acc[PT][QT];
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) acc[pp][qq] = cf_make(0.f, 0.f);
+
+#pragma unroll 2
+  for (int64_t r = 0; r < g.R; ++r) {
+    cf32 a[PT], b[QT];
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp) {
+      a[pp] = A[pa[pp] + r * g.a_sr];
+      if (CA) a[pp].y = -a[pp].y;
+    }
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      b[qq] = B[qb[qq] + r * g.b_sr];
+      if (CB) b[qq].y = -b[qq].y;
+    }
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) cf_mac(acc[pp][qq], a[pp], b[qq]);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp) {
+    if (p0 + pp >= g.P) continue;
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      if (q0 + qq >= g.Q) continue;
+      cf32* dst = C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq + offc;
+      cf32 v = acc[pp][qq];
+      if (g.accumulate) {
+        const cf32 old = *dst;
+        v = cf_add(v, old);
+      }
+      *dst = v;
+    }
+  }
+}
+
+// gbias[c] = sum_b Re(ghat[(b*channels + c) * modes_per_image + dc])
+SC_GLOBAL void k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias,
+                           int64_t batch, int64_t channels, int64_t modes_per_image,
+                           int64_t dc) {
+  const int64_t c = (int64_t)SC_BID_X * SC_BLOCK + SC_TID;
+  if (c >= channels) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < batch; ++b) s += ghat[(b * channels + c) * modes_per_image + dc].x;
+  gbias[c] = s;
+}

@@ -1,0 +1,226 @@
+"""Host side of the engine above the C-ABI: plan cache + autograd Functions.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); every arithmetic step
+of the hot path runs in libsc_engine.so (hand-written HIP, include/sc_engine.h).
+"""
+import atexit
+import threading
+
+import torch
+
+from . import _lib
+from .modes import kept_block
+
+_PLAN_LOCK = threading.Lock()
+_PLANS = {}
+
+
+def _require_gpu(t, what="input"):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"neuraloperator_amd: {what} is on {t.device}; the SpectralConv engine runs on "
+            "MI355X (ROCm) devices only and has no CPU path -- move the module and its inputs "
+            "to a 'cuda' device.")
+
+
+def get_plan(device, spatial, kept, fft_norm="forward", flags=0):
+    """Cached ``sc_plan`` for (device, spatial sizes, kept modes, norm)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           tuple(int(s) for s in spatial), tuple(int(k) for k in kept), fft_norm, flags)
+    with _PLAN_LOCK:
+        plan = _PLANS.get(key)
+        if plan is None:
+            lib = _lib.get_lib()
+            with torch.cuda.device(key[0]):
+                plan = lib.plan_create(key[1], key[2], fft_norm=fft_norm, flags=flags)
+            _PLANS[key] = plan
+    return plan
+
+
+@atexit.register
+def _destroy_plans():
+    # device memory is reclaimed with the process; only drop the handles
+    _PLANS.clear()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+class SpectralConvDenseFn(torch.autograd.Function):
+    """y = irfftn(pad(einsum('bi..,io..->bo..', trunc(rfftn(x)), W))) + bias, one C-ABI call
+    each way (sc_layer_forward / sc_layer_backward).
+
+    Replaces /root/reference/neuralop/layers/spectral_convolution.py:443-568 and the
+    autograd graph PyTorch derives from it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, n_modes_attr, max_n_modes_attr, fft_norm, flags):
+        _require_gpu(x)
+        _require_gpu(weight, "weight")
+        lib = _lib.get_lib()
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        w = weight.detach()
+        if w.dtype != torch.complex64:
+            w = w.to(torch.complex64)
+        w = w.contiguous()
+        b, cin = x.shape[:2]
+        cout = w.shape[1]
+        if w.shape[0] != cin:
+            raise ValueError(f"input has {cin} channels, weight expects {w.shape[0]}")
+        spatial = list(x.shape[2:])
+        kept, w_start = kept_block(spatial, n_modes_attr, max_n_modes_attr)
+        plan = get_plan(x.device, spatial, kept, fft_norm, flags)
+        L = lib.layer_desc(b, cin, cout, list(w.shape[2:]), w_start)
+        with torch.cuda.device(x.device):
+            ws = _ws(lib.layer_workspace_bytes(plan, L), x.device)
+            y = torch.empty((b, cout, *spatial), dtype=torch.float32, device=x.device)
+            xhat = torch.empty((b, cin, *kept, 2), dtype=torch.float32, device=x.device)
+            bias_flat = None
+            if bias is not None:
+                bias_flat = bias.detach().reshape(-1).float().contiguous()
+            lib.layer_forward(plan, L, x.data_ptr(), torch.view_as_real(w).data_ptr(),
+                              0 if bias_flat is None else bias_flat.data_ptr(),
+                              y.data_ptr(), xhat.data_ptr(), ws.data_ptr(), _stream())
+        ctx.save_for_backward(xhat, w)
+        ctx.plan, ctx.L = plan, L
+        ctx.x_shape = tuple(x.shape)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.w_shape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.get_lib()
+        xhat, w = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            gy = gy.float()
+        dev = gy.device
+        with torch.cuda.device(dev):
+            ws = _ws(lib.layer_workspace_bytes(ctx.plan, ctx.L), dev)
+            gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if need_x else None
+            gw = None
+            if need_w:
+                full = all(ctx.L.w_start[d] == 0 for d in range(len(ctx.w_shape) - 2)) and \
+                    tuple(xhat.shape[2:-1]) == tuple(ctx.w_shape[2:])
+                alloc = torch.empty if full else torch.zeros
+                gw = alloc((*ctx.w_shape, 2), dtype=torch.float32, device=dev)
+            gb = None
+            if need_b and ctx.bias_shape is not None:
+                gb = torch.empty(ctx.L.cout, dtype=torch.float32, device=dev)
+            lib.layer_backward(ctx.plan, ctx.L, gy.data_ptr(), xhat.data_ptr(),
+                               torch.view_as_real(w).data_ptr(),
+                               0 if gx is None else gx.data_ptr(),
+                               0 if gw is None else gw.data_ptr(),
+                               0 if gb is None else gb.data_ptr(), ws.data_ptr(), _stream())
+        gw_c = torch.view_as_complex(gw) if gw is not None else None
+        gb_r = gb.reshape(ctx.bias_shape) if gb is not None else None
+        return gx, gw_c, gb_r, None, None, None, None
+
+
+class TransformForwardFn(torch.autograd.Function):
+    """x (B, C, d1..dN) real -> truncated spectrum (B, C, k1..kN) complex (weight order).
+    forward = SC_FWD_SCALED, backward = its adjoint SC_INV_ADJ_R2C."""
+
+    @staticmethod
+    def forward(ctx, x, kept, fft_norm, flags):
+        _require_gpu(x)
+        lib = _lib.get_lib()
+        x = x.contiguous().float()
+        b, c = x.shape[:2]
+        spatial = list(x.shape[2:])
+        plan = get_plan(x.device, spatial, kept, fft_norm, flags)
+        with torch.cuda.device(x.device):
+            ws = _ws(lib.plan_workspace_bytes(plan, b * c), x.device)
+            xhat = torch.empty((b, c, *kept, 2), dtype=torch.float32, device=x.device)
+            lib.transform_forward(plan, _lib.SC_FWD_SCALED, x.data_ptr(), xhat.data_ptr(), b * c,
+                                  ws.data_ptr(), _stream())
+        ctx.plan = plan
+        ctx.x_shape = tuple(x.shape)
+        return torch.view_as_complex(xhat)
+
+    @staticmethod
+    def backward(ctx, gxhat):
+        lib = _lib.get_lib()
+        g = torch.view_as_real(gxhat.contiguous().to(torch.complex64)).contiguous()
+        b, c = ctx.x_shape[:2]
+        with torch.cuda.device(g.device):
+            ws = _ws(lib.plan_workspace_bytes(ctx.plan, b * c), g.device)
+            gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g.device)
+            lib.transform_inverse(ctx.plan, _lib.SC_INV_ADJ_R2C, g.data_ptr(), 0, c, gx.data_ptr(),
+                                  b * c, ws.data_ptr(), _stream())
+        return gx, None, None, None
+
+
+class TransformInverseFn(torch.autograd.Function):
+    """truncated spectrum (B, C, k..) complex -> y (B, C, d..) real (+ bias).
+    forward = SC_INV_PADDED, backward = its adjoint SC_FWD_ADJ_C2R (bias grad from DC)."""
+
+    @staticmethod
+    def forward(ctx, yhat, bias, spatial, fft_norm, flags):
+        _require_gpu(yhat)
+        lib = _lib.get_lib()
+        yh = torch.view_as_real(yhat.contiguous().to(torch.complex64)).contiguous()
+        b, c = yh.shape[:2]
+        kept = list(yh.shape[2:-1])
+        plan = get_plan(yh.device, spatial, kept, fft_norm, flags)
+        with torch.cuda.device(yh.device):
+            ws = _ws(lib.plan_workspace_bytes(plan, b * c), yh.device)
+            y = torch.empty((b, c, *spatial), dtype=torch.float32, device=yh.device)
+            bias_flat = None if bias is None else bias.detach().reshape(-1).float().contiguous()
+            lib.transform_inverse(plan, _lib.SC_INV_PADDED, yh.data_ptr(),
+                                  0 if bias_flat is None else bias_flat.data_ptr(), c,
+                                  y.data_ptr(), b * c, ws.data_ptr(), _stream())
+        ctx.plan = plan
+        ctx.kept = kept
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.get_lib()
+        gy = gy.contiguous().float()
+        b, c = gy.shape[:2]
+        with torch.cuda.device(gy.device):
+            ws = _ws(lib.plan_workspace_bytes(ctx.plan, b * c), gy.device)
+            ghat = torch.empty((b, c, *ctx.kept, 2), dtype=torch.float32, device=gy.device)
+            lib.transform_forward(ctx.plan, _lib.SC_FWD_ADJ_C2R, gy.data_ptr(), ghat.data_ptr(),
+                                  b * c, ws.data_ptr(), _stream())
+            gb = None
+            if ctx.bias_shape is not None and ctx.needs_input_grad[1]:
+                gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+                lib.bias_grad(ctx.plan, ghat.data_ptr(), b, c, gb.data_ptr(), _stream())
+                gb = gb.reshape(ctx.bias_shape)
+        return torch.view_as_complex(ghat), gb, None, None, None
+
+
+def _cview(t):
+    """complex64 contiguous tensor -> float32 view pointer holder."""
+    t = t.to(torch.complex64) if t.dtype != torch.complex64 else t
+    return torch.view_as_real(t.contiguous())
+
+
+def modegemm(a, b, *, P, Q, R, n_modes, a_strides, b_strides, out, c_strides, conj_a=False,
+             conj_b=False, b_idx=None, c_idx=None, accumulate=False):
+    """Raw mode-batched complex GEMM (sc_modegemm).  ``a``, ``b``, ``out`` are complex64 CUDA
+    tensors; strides are (sp, sr, sm) / (sr, sq, sm) / (sp, sq, sm) in complex elements."""
+    lib = _lib.get_lib()
+    av, bv, cv = torch.view_as_real(a), torch.view_as_real(b), torch.view_as_real(out)
+    with torch.cuda.device(out.device):
+        lib.modegemm(av.data_ptr(), bv.data_ptr(), cv.data_ptr(), _stream(),
+                     P=P, Q=Q, R=R, n_modes=n_modes,
+                     a_sp=a_strides[0], a_sr=a_strides[1], a_sm=a_strides[2],
+                     b_sr=b_strides[0], b_sq=b_strides[1], b_sm=b_strides[2],
+                     c_sp=c_strides[0], c_sq=c_strides[1], c_sm=c_strides[2],
+                     conj_a=int(conj_a), conj_b=int(conj_b), accumulate=int(accumulate),
+                     b_idx=0 if b_idx is None else b_idx.data_ptr(),
+                     c_idx=0 if c_idx is None else c_idx.data_ptr())
+    return out

@@ -1,0 +1,190 @@
+"""Drop-in ``conv_module`` for the reference's FNOBlocks / FNO / TFNO.
+
+Mirrors the constructor, attributes and methods of
+/root/reference/neuralop/layers/spectral_convolution.py:183-570 (``SpectralConv``) and the
+plug-in contract of neuralop/layers/base_spectral_conv.py:4-27 -- ``forward(x,
+output_shape=None)``, ``transform(x, output_shape=None)``, mutable ``n_modes``,
+``max_n_modes``, ``weight``, ``bias`` -- so that ``FNO(..., conv_module=SpectralConv)``
+(fno_block.py:210-240) runs the MI355X engine for every Fourier layer.
+
+All arithmetic of the layer is in libsc_engine.so; this file is argument checking and
+autograd plumbing.  Variants outside the engine's envelope raise NotImplementedError
+(no silent PyTorch fallback): complex_data, separable, half/mixed block precision,
+resolution change, TT factorization.
+"""
+from typing import List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from . import engine
+from .factorized import CPWeight, DenseWeight, SpectralWeight, TuckerWeight
+from .modes import halve_last_mode
+
+Number = Union[int, float]
+
+
+def _validate_scaling_factor(scaling_factor, n_dim):
+    """Single-layer form of neuralop/utils.py:151-197."""
+    if scaling_factor is None:
+        return None
+    if isinstance(scaling_factor, (float, int)):
+        return [float(scaling_factor)] * n_dim
+    if isinstance(scaling_factor, (list, tuple)) and len(scaling_factor) == n_dim and all(
+            isinstance(s, (float, int)) for s in scaling_factor):
+        return [float(s) for s in scaling_factor]
+    raise ValueError(f"resolution_scaling_factor={scaling_factor!r} not understood for {n_dim}-d")
+
+
+class BaseSpectralConv(nn.Module):
+    """Same contract as neuralop/layers/base_spectral_conv.py:4-27."""
+
+    def __init__(self, device=None, dtype=None):
+        super().__init__()
+        self.dtype = dtype
+        self.device = device
+
+    def transform(self, x):
+        return x
+
+
+class SpectralConv(BaseSpectralConv):
+    """N-d Fourier layer on the MI355X engine (real-valued data, fp32 spectral arithmetic).
+
+    Parameters are those of the reference class (spectral_convolution.py:285-305); see the
+    module docstring for the variants that raise NotImplementedError.
+    """
+
+    def __init__(
+        self,
+        in_channels,
+        out_channels,
+        n_modes,
+        complex_data=False,
+        max_n_modes=None,
+        bias=True,
+        separable=False,
+        resolution_scaling_factor: Optional[Union[Number, List[Number]]] = None,
+        fno_block_precision="full",
+        rank=1.0,
+        factorization=None,
+        implementation="reconstructed",
+        enforce_hermitian_symmetry=True,
+        fixed_rank_modes=False,
+        decomposition_kwargs: Optional[dict] = None,
+        init_std="auto",
+        fft_norm="forward",
+        device=None,
+        engine_flags: int = 0,
+    ):
+        super().__init__(device=device)
+        if complex_data:
+            raise NotImplementedError("complex_data=True is not on the MI355X engine yet (DESIGN.md, row f4)")
+        if fno_block_precision != "full":
+            raise NotImplementedError(
+                f"fno_block_precision={fno_block_precision!r}: the engine computes the spectral path "
+                "in fp32 (half/mixed = DESIGN.md row f4)")
+        if implementation not in ("reconstructed", "factorized"):
+            raise ValueError(
+                f'Got implementation={implementation}, expected "reconstructed" or "factorized"')
+        if fft_norm not in ("forward", "backward", "ortho"):
+            raise ValueError(f"fft_norm={fft_norm!r}")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.complex_data = complex_data
+        self.n_modes = n_modes
+        self.order = len(self.n_modes)
+        if self.order > 4:
+            raise NotImplementedError("the engine supports 1-d .. 4-d grids")
+
+        if max_n_modes is None:
+            max_n_modes = self.n_modes
+        elif isinstance(max_n_modes, int):
+            max_n_modes = [max_n_modes]
+        self.max_n_modes = max_n_modes
+
+        self.fno_block_precision = fno_block_precision
+        self.rank = rank
+        self.factorization = factorization
+        self.implementation = implementation
+        # the engine's C2R ignores Im of the DC / Nyquist columns by construction, which is what
+        # the reference's explicit fix-up enforces (:547-559); both settings give the same result
+        self.enforce_hermitian_symmetry = enforce_hermitian_symmetry
+        self.resolution_scaling_factor = _validate_scaling_factor(resolution_scaling_factor, self.order)
+        self.engine_flags = engine_flags
+
+        if init_std == "auto":
+            init_std = (2 / (in_channels + out_channels)) ** 0.5
+        if isinstance(fixed_rank_modes, bool):
+            fixed_rank_modes = [0] if fixed_rank_modes else None
+        self.fft_norm = fft_norm
+
+        if separable:
+            if in_channels != out_channels:
+                raise ValueError(
+                    "To use separable Fourier Conv, in_channels must be equal "
+                    f"to out_channels, but got in_channels={in_channels} and "
+                    f"out_channels={out_channels}",
+                )
+            raise NotImplementedError("separable=True is not on the MI355X engine yet (DESIGN.md, row f4)")
+        self.separable = separable
+        weight_shape = (in_channels, out_channels, *self.max_n_modes)
+
+        tensor_kwargs = decomposition_kwargs if decomposition_kwargs is not None else {}
+        self.weight = SpectralWeight.new(
+            weight_shape, rank=self.rank, factorization=factorization or "Dense",
+            fixed_rank_modes=fixed_rank_modes, dtype=torch.cfloat, device=device, **tensor_kwargs)
+        self.weight.normal_(0, init_std)
+
+        if bias:
+            self.bias = nn.Parameter(
+                init_std * torch.randn(*(tuple([self.out_channels]) + (1,) * self.order), device=device))
+        else:
+            self.bias = None
+
+    # ---- plug-in contract -------------------------------------------------------------------
+    def transform(self, x, output_shape=None):
+        in_shape = list(x.shape[2:])
+        if self.resolution_scaling_factor is not None and output_shape is None:
+            out_shape = [round(s * r) for (s, r) in zip(in_shape, self.resolution_scaling_factor)]
+        elif output_shape is not None:
+            out_shape = list(output_shape)
+        else:
+            out_shape = in_shape
+        if in_shape == out_shape:
+            return x
+        raise NotImplementedError("resolution change (resample of the skip path) is DESIGN.md row f4")
+
+    @property
+    def n_modes(self):
+        return self._n_modes
+
+    @n_modes.setter
+    def n_modes(self, n_modes):
+        self._n_modes = halve_last_mode(n_modes, complex_data=self.complex_data)
+
+    # ---- forward ------------------------------------------------------------------------------
+    def _dense_weight(self):
+        w = self.weight
+        if isinstance(w, DenseWeight):
+            return w.tensor
+        # Tucker / CP: rebuild the dense weight from the (small) factors on the device, then run
+        # the dense engine path -- the identity the reference's own test pins
+        # (neuralop/layers/tests/test_spectral_convolution.py:54-65).
+        return w.to_tensor()
+
+    def forward(self, x: torch.Tensor, output_shape: Optional[Tuple[int]] = None):
+        if x.ndim != self.order + 2:
+            raise ValueError(f"expected a (B, C, {self.order} spatial dims) input, got {tuple(x.shape)}")
+        spatial = list(x.shape[2:])
+        out_shape = spatial
+        if self.resolution_scaling_factor is not None and output_shape is None:
+            out_shape = [round(s * r) for (s, r) in zip(spatial, self.resolution_scaling_factor)]
+        if output_shape is not None:
+            out_shape = list(output_shape)
+        if list(out_shape) != spatial:
+            raise NotImplementedError(
+                "resolution_scaling_factor / output_shape that change the grid are DESIGN.md row f4")
+        return engine.SpectralConvDenseFn.apply(
+            x, self._dense_weight(), self.bias, list(self.n_modes), list(self.max_n_modes),
+            self.fft_norm, self.engine_flags)

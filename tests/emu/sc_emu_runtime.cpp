@@ -1,0 +1,68 @@
+// TEST INFRASTRUCTURE ONLY -- thread-per-lane executor for the SC_EMU build of the engine.
+// Runs each workgroup with real OS threads and a real barrier so that the kernels' index
+// maths and LDS/barrier choreography can be validated without a GPU.  Never shipped, never
+// loaded by neuraloperator_amd.
+#include <pthread.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define SC_EMU 1
+#include "../../neuraloperator_amd/csrc/sc_device.h"
+
+namespace scemu {
+thread_local ThreadCtx g_ctx;
+unsigned char* g_dyn_shared = nullptr;
+
+static pthread_barrier_t g_barrier;
+
+void barrier() { pthread_barrier_wait(&g_barrier); }
+
+struct Job {
+  dim3 grid;
+  int tid;
+  void (*fn)(void*);
+  void* arg;
+};
+
+static void* worker(void* p) {
+  Job* j = static_cast<Job*>(p);
+  for (unsigned bz = 0; bz < j->grid.z; ++bz)
+    for (unsigned by = 0; by < j->grid.y; ++by)
+      for (unsigned bx = 0; bx < j->grid.x; ++bx) {
+        g_ctx.tid = j->tid;
+        g_ctx.bx = (int)bx;
+        g_ctx.by = (int)by;
+        g_ctx.bz = (int)bz;
+        j->fn(j->arg);
+        // static __shared__ storage is reused by the next workgroup
+        pthread_barrier_wait(&g_barrier);
+      }
+  return nullptr;
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg) {
+  const unsigned nt = block.x * block.y * block.z;
+  if (nt == 0 || grid.x * grid.y * grid.z == 0) return;
+  std::vector<unsigned char> dyn(shmem + 64);
+  g_dyn_shared = dyn.data();
+  pthread_barrier_init(&g_barrier, nullptr, nt);
+  std::vector<pthread_t> th(nt);
+  std::vector<Job> jobs(nt);
+  pthread_attr_t attr;
+  pthread_attr_init(&attr);
+  pthread_attr_setstacksize(&attr, 1 << 20);
+  for (unsigned t = 0; t < nt; ++t) {
+    jobs[t] = Job{grid, (int)t, fn, arg};
+    if (pthread_create(&th[t], &attr, worker, &jobs[t]) != 0) {
+      std::fprintf(stderr, "scemu: pthread_create failed\n");
+      std::abort();
+    }
+  }
+  for (unsigned t = 0; t < nt; ++t) pthread_join(th[t], nullptr);
+  pthread_attr_destroy(&attr);
+  pthread_barrier_destroy(&g_barrier);
+  g_dyn_shared = nullptr;
+}
+}  // namespace scemu
