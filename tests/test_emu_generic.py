@@ -31,3 +31,55 @@ def test_generic_path_matches_golden(lib, name):
     assert rel_l2(gx.numpy(), g["gx"]) < TOL
     assert rel_l2(gw.numpy(), g["gw"]) < TOL
     assert rel_l2(gb.numpy(), g["gbias"]) < TOL
+
+
+# ------------------------------------------------------------------------------------------
+# fused power-of-two FFT kernels (sc_kernels_fft.h) in emulation, against the CPU oracle
+# ------------------------------------------------------------------------------------------
+FAST_CASES = [
+    # B, Cin, Cout, H, n_modes
+    (1, 2, 2, 256, (64, 64)),     # the BASELINE metric geometry (one image per workgroup)
+    (1, 1, 2, 64, (64, 64)),      # single row group, all 64 row frequencies kept
+    (1, 2, 1, 128, (32, 32)),
+    (1, 1, 1, 512, (10, 6)),
+    (2, 1, 1, 256, (5, 7)),       # odd kept counts
+]
+
+
+@pytest.mark.parametrize("case", FAST_CASES, ids=lambda c: f"H{c[3]}_m{c[4][0]}x{c[4][1]}")
+def test_fused_fft_path_matches_oracle(lib, case):
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode, kept_block
+
+    b, ci, co, H, modes = case
+    torch.manual_seed(11)
+    nm = halve_last_mode(modes)
+    kept, _ = kept_block([H, 256], nm, nm)
+    plan = lib.plan_create([H, 256], kept)
+    assert lib.plan_is_fast(plan)
+    assert lib.plan_kernel_name(plan, 0) == "k_fft2d_fwd"
+    lib.plan_destroy(plan)
+    x = torch.randn(b, ci, H, 256)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.5)
+    bias = torch.randn(co, 1, 1)
+    g = torch.randn(b, co, H, 256)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
+    assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
+    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+    # the saved truncated spectrum itself (weight order) against the fp64 kept-rows oracle
+    _, xk = so.forward_np64(x.numpy(), w.numpy(), bias.numpy(), nm, nm)
+    assert rel_l2(xh.numpy(), xk) < TOL
+
+
+def test_emu_library_exports_and_errors(lib):
+    for s in _lib.ScEngineLib.SYMBOLS:
+        assert hasattr(lib.lib, s)
+    with pytest.raises(_lib.EngineError):
+        lib.plan_create([16, 16], [17, 9])          # more modes than the spectrum has
+    with pytest.raises(_lib.EngineError):
+        lib.plan_create([16] * 5, [4] * 5)
