@@ -16,7 +16,7 @@ def short(name, n=110):
 def from_db(path):
     cur = sqlite3.connect(path).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    return [(short(r[0]), int(r[1]), float(r[2]) / 1e3, float(r[3]) / 1e3, float(r[4])) for r in rows]
+    return [(short(r[0]), int(r[1]), float(r[2]), float(r[3]), float(r[4])) for r in rows]
 
 
 def from_csv(path):
