@@ -193,27 +193,31 @@ SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
 k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
            cf32* __restrict__ C) {
   const int tid = SC_TID;
-  const int lane = tid & 63, w = tid >> 6;
+  const int lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
   const int64_t m = (int64_t)SC_BID_X * SC_WAVE + lane;
-  const int64_t p0 = ((int64_t)SC_BID_Y * 4 + w) * PT;
-  const int64_t q0 = (int64_t)SC_BID_Z * QT;
+  const int64_t p0 = ((int64_t)SC_BID_Y * 4 + w) * PT;      // wave-uniform
+  const int64_t q0 = (int64_t)SC_BID_Z * QT;                // wave-uniform
   if (p0 >= g.P) return;  // whole wave idle (no barriers in this kernel)
   const bool active = m < g.M;
   const int64_t mm = active ? m : g.M - 1;
-  const int64_t offa = mm * g.a_sm;
-  const int64_t offb = g.b_idx ? (int64_t)g.b_idx[mm] : mm * g.b_sm;
-  const int64_t offc = g.c_idx ? (int64_t)g.c_idx[mm] : mm * g.c_sm;
+  // per-lane part of every address: one 32-bit element offset per operand; everything else is
+  // wave-uniform and stays in SGPRs (global_load ... v_off, s[base] addressing)
+  const uint32_t la = (uint32_t)(mm * g.a_sm);
+  const uint32_t lb = g.b_idx ? (uint32_t)g.b_idx[mm] : (uint32_t)(mm * g.b_sm);
+  const uint32_t lc = g.c_idx ? (uint32_t)g.c_idx[mm] : (uint32_t)(mm * g.c_sm);
 
-  int64_t pa[PT], qb[QT];
+  const cf32* Ap[PT];
+  const cf32* Bq[QT];
 #pragma unroll
   for (int pp = 0; pp < PT; ++pp) {
     const int64_t p = (p0 + pp < g.P) ? (p0 + pp) : (g.P - 1);
-    pa[pp] = p * g.a_sp + offa;
+    Ap[pp] = A + p * g.a_sp;
   }
 #pragma unroll
   for (int qq = 0; qq < QT; ++qq) {
     const int64_t q = (q0 + qq < g.Q) ? (q0 + qq) : (g.Q - 1);
-    qb[qq] = q * g.b_sq + offb;
+    Bq[qq] = B + q * g.b_sq;
   }
   cf32 acc[PT][QT];
 #pragma unroll
@@ -224,14 +228,15 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
 #pragma unroll 2
   for (int64_t r = 0; r < g.R; ++r) {
     cf32 a[PT], b[QT];
+    const int64_t ra = r * g.a_sr, rb = r * g.b_sr;          // uniform
 #pragma unroll
     for (int pp = 0; pp < PT; ++pp) {
-      a[pp] = A[pa[pp] + r * g.a_sr];
+      a[pp] = (Ap[pp] + ra)[la];
       if (CA) a[pp].y = -a[pp].y;
     }
 #pragma unroll
     for (int qq = 0; qq < QT; ++qq) {
-      b[qq] = B[qb[qq] + r * g.b_sr];
+      b[qq] = (Bq[qq] + rb)[lb];
       if (CB) b[qq].y = -b[qq].y;
     }
 #pragma unroll
@@ -246,7 +251,7 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
 #pragma unroll
     for (int qq = 0; qq < QT; ++qq) {
       if (q0 + qq >= g.Q) continue;
-      cf32* dst = C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq + offc;
+      cf32* dst = C + ((p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq) + lc;
       cf32 v = acc[pp][qq];
       if (g.accumulate) {
         const cf32 old = *dst;

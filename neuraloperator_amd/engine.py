@@ -224,3 +224,61 @@ def modegemm(a, b, *, P, Q, R, n_modes, a_strides, b_strides, out, c_strides, co
                      b_idx=0 if b_idx is None else b_idx.data_ptr(),
                      c_idx=0 if c_idx is None else c_idx.data_ptr())
     return out
+
+
+class ModeContractDenseFn(torch.autograd.Function):
+    """yhat[b,o,m] = sum_i xhat[b,i,m] * w[i,o,m] on an arbitrary (e.g. mode-sharded) block of
+    modes; w has exactly the mode extents of xhat.  Three sc_modegemm launches in total
+    (forward, gX, gW) -- the einsum 'bixy,ioxy->boxy' of spectral_convolution.py:21-46 and its
+    two autograd einsums."""
+
+    @staticmethod
+    def forward(ctx, xhat, w):
+        _require_gpu(xhat, "xhat")
+        xhat = xhat.contiguous().to(torch.complex64)
+        w = w.contiguous().to(torch.complex64)
+        b, ci = xhat.shape[:2]
+        co = w.shape[1]
+        if tuple(w.shape[2:]) != tuple(xhat.shape[2:]) or w.shape[0] != ci:
+            raise ValueError(f"weight block {tuple(w.shape)} does not match spectrum {tuple(xhat.shape)}")
+        mk = 1
+        for k in xhat.shape[2:]:
+            mk *= int(k)
+        yhat = torch.empty((b, co, *xhat.shape[2:]), dtype=torch.complex64, device=xhat.device)
+        modegemm(xhat, w, P=b, Q=co, R=ci, n_modes=mk, a_strides=(ci * mk, mk, 1),
+                 b_strides=(co * mk, mk, 1), out=yhat, c_strides=(co * mk, mk, 1))
+        ctx.save_for_backward(xhat, w)
+        ctx.dims = (b, ci, co, mk)
+        return yhat
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, w = ctx.saved_tensors
+        b, ci, co, mk = ctx.dims
+        g = g.contiguous().to(torch.complex64)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(xhat)
+            modegemm(g, w, P=b, Q=ci, R=co, n_modes=mk, a_strides=(co * mk, mk, 1),
+                     b_strides=(mk, co * mk, 1), conj_b=True, out=gx, c_strides=(ci * mk, mk, 1))
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            modegemm(xhat, g, P=ci, Q=co, R=b, n_modes=mk, a_strides=(mk, ci * mk, 1), conj_a=True,
+                     b_strides=(co * mk, mk, 1), out=gw, c_strides=(co * mk, mk, 1))
+        return gx, gw
+
+
+class EngineOps:
+    """The three local stages of a (mode-parallel) spectral layer on the MI355X engine."""
+
+    def __init__(self, fft_norm="forward", flags=0):
+        self.fft_norm, self.flags = fft_norm, flags
+
+    def forward_transform(self, x, kept):
+        return TransformForwardFn.apply(x, list(kept), self.fft_norm, self.flags)
+
+    def contract(self, xhat, w):
+        return ModeContractDenseFn.apply(xhat, w)
+
+    def inverse_transform(self, yhat, bias, spatial):
+        return TransformInverseFn.apply(yhat, bias, list(spatial), self.fft_norm, self.flags)

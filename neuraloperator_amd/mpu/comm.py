@@ -1,0 +1,102 @@
+"""Process-group wire-up for the mode-parallel layer.
+
+Same surface as /root/reference/neuralop/mpu/comm.py:41-198 (``init``, ``get_world_size``,
+``get_model_parallel_group/size/rank``, ``get_data_parallel_*``): contiguous model-parallel
+groups of ``model_parallel_size`` ranks, strided data-parallel groups, and a size-1 / rank-0
+fallback when torch.distributed is not initialised.  One process per GPU; backend "nccl"
+(= RCCL over xGMI on ROCm) on GPUs, "gloo" for the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+_DATA_PARALLEL_GROUP = None
+_MODEL_PARALLEL_GROUP = None
+_MODEL_PARALLEL_SIZE = 1
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def get_world_rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def get_local_rank():
+    if not dist.is_initialized():
+        return 0
+    return int(os.environ.get("LOCAL_RANK", get_world_rank() % max(torch.cuda.device_count(), 1)))
+
+
+def get_data_parallel_size():
+    return dist.get_world_size(group=_DATA_PARALLEL_GROUP) if dist.is_initialized() else 1
+
+
+def get_data_parallel_rank():
+    return dist.get_rank(group=_DATA_PARALLEL_GROUP) if dist.is_initialized() else 0
+
+
+def get_data_parallel_group():
+    return _DATA_PARALLEL_GROUP
+
+
+def get_model_parallel_size():
+    return dist.get_world_size(group=_MODEL_PARALLEL_GROUP) if dist.is_initialized() else 1
+
+
+def get_model_parallel_rank():
+    return dist.get_rank(group=_MODEL_PARALLEL_GROUP) if dist.is_initialized() else 0
+
+
+def get_model_parallel_group():
+    return _MODEL_PARALLEL_GROUP
+
+
+def init(model_parallel_size=1, backend=None, verbose=False):
+    """Initialise torch.distributed (if the launcher has not) and build the groups
+    (reference comm.py:104-198).  Rendezvous comes from torchrun's env (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR/PORT)."""
+    global _DATA_PARALLEL_GROUP, _MODEL_PARALLEL_GROUP, _MODEL_PARALLEL_SIZE
+    if not dist.is_initialized():
+        if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+            return                      # single process: getters fall back to size 1 / rank 0
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, **kw)
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    if world % model_parallel_size != 0:
+        raise ValueError(f"world size {world} not divisible by model_parallel_size {model_parallel_size}")
+    _MODEL_PARALLEL_SIZE = model_parallel_size
+    n_model_groups = world // model_parallel_size
+    model_groups = [list(range(i * model_parallel_size, (i + 1) * model_parallel_size))
+                    for i in range(n_model_groups)]
+    data_groups = [sorted(list(g)) for g in zip(*model_groups)]
+    if verbose and rank == 0:
+        print("model-parallel groups:", model_groups)
+        print("data-parallel groups:", data_groups)
+    for grp in data_groups:                       # every rank must create every group
+        h = dist.new_group(ranks=grp)
+        if rank in grp:
+            _DATA_PARALLEL_GROUP = h
+    for grp in model_groups:
+        h = dist.new_group(ranks=grp)
+        if rank in grp:
+            _MODEL_PARALLEL_GROUP = h
+    dist.barrier()
+
+
+def cleanup():
+    global _DATA_PARALLEL_GROUP, _MODEL_PARALLEL_GROUP
+    _DATA_PARALLEL_GROUP = _MODEL_PARALLEL_GROUP = None
+    if dist.is_initialized():
+        dist.destroy_process_group()

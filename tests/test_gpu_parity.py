@@ -125,10 +125,8 @@ def test_full_size_properties(lib):
         bi, oi = int(torch.randint(b, (1,), generator=gen)), int(torch.randint(c, (1,), generator=gen))
         h0, w0 = int(torch.randint(n, (1,), generator=gen)), int(torch.randint(n, (1,), generator=gen))
         ph = torch.exp(2j * torch.pi * (fxs[:, None] * h0 / n + fys[None, :] * w0 / n))
-        col = (yhat[bi, oi] * ph).sum(dim=0)              # inverse along rows first
-        col[0] = col[0].real                               # C2R ignores Im of the DC column
-        want = (cw * col.real).sum().item() if True else 0.0
-        want = (cw * (col.real)).sum().item()
+        col = (yhat[bi, oi] * ph).sum(dim=0)              # inverse along rows first; C2R then takes
+        want = (cw * col.real).sum().item()                # c_k * Re(.) (Im of the DC column drops out)
         got = y1[bi, oi, h0, w0].item()
         assert abs(got - want) < 1e-4 * max(1.0, abs(want))
 
