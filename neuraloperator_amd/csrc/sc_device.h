@@ -26,6 +26,14 @@
 #define SC_BID_Y ((int)blockIdx.y)
 #define SC_BID_Z ((int)blockIdx.z)
 #define SC_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+// exchange through LDS between lanes of ONE wave: no s_barrier needed (a wave's DS operations
+// execute in order); drain the wave's own LDS queue and stop the compiler moving memory
+// operations across the point.
+#define SC_WAVE_SYNC()                                           \
+  do {                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_wave_barrier();                             \
+  } while (0)
 // value known to be identical in every lane of the wave -> keep it in an SGPR
 #define SC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define SC_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
@@ -69,6 +77,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_BID_Y (scemu::g_ctx.by)
 #define SC_BID_Z (scemu::g_ctx.bz)
 #define SC_LAUNCH_BOUNDS(n)
+#define SC_WAVE_SYNC() scemu::barrier()   /* emulated lanes are free-running threads */
 #define SC_UNIFORM(x) (x)
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)
 

@@ -403,9 +403,14 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
 // mode-batched GEMM
 // ------------------------------------------------------------------------------------------
 template <int PT, int QT, bool CA, bool CB>
-static void launch_modegemm(const ModeGemmArgs& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  dim3 grid((unsigned)((g.M + SC_WAVE - 1) / SC_WAVE), (unsigned)((g.P + 4 * PT - 1) / (4 * PT)),
-            (unsigned)((g.Q + QT - 1) / QT));
+static void launch_modegemm(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  ModeGemmArgs g = g0;
+  g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
+  g.n_pg = (int)((g.P + 4 * PT - 1) / (4 * PT));
+  g.n_qt = (int)((g.Q + QT - 1) / QT);
+  const int64_t total = (int64_t)g.n_mt * g.n_pg * g.n_qt;
+  g.per_xcd = (int)((total + 7) / 8);
+  dim3 grid((unsigned)(8 * g.per_xcd));
   SC_LAUNCH((k_modegemm<PT, QT, CA, CB>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
 }
 
@@ -432,7 +437,8 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
   g.b_idx = d->b_idx; g.c_idx = d->c_idx;
   g.accumulate = d->accumulate;
-  SC_CHECK_ARG((g.Q + 3) / 4 <= 65535 && (g.P + 15) / 16 <= 65535, "P/Q too large for the launch grid");
+  SC_CHECK_ARG(((g.M + 63) / 64) * ((g.P + 15) / 16) * ((g.Q + 3) / 4) < ((int64_t)1 << 30),
+               "problem too large for one launch grid");
   sc_stream_t st = (sc_stream_t)stream;
   const cf32* a = (const cf32*)A;
   const cf32* b = (const cf32*)B;

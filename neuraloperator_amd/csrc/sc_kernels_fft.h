@@ -163,29 +163,55 @@ k_fft2d_fwd(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* __
   for (int i = 0; i < 16; ++i) acc[i] = cf_make(0.f, 0.f);
   SC_SYNC();
 
+  // software prefetch: the 32 floats of the NEXT round are requested before the current round
+  // is computed, so HBM latency overlaps the FFT work of this workgroup (and of its CU mate)
+  float pa[16], pb[16];
+  {
+    const float* ra = xi + (int64_t)(P * (2 * f) + 0) * SC_F2D_W + t;
+    const float* rb = xi + (int64_t)(P * (2 * f + 1) + 0) * SC_F2D_W + t;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      pa[j] = ra[16 * j];
+      pb[j] = rb[16 * j];
+    }
+  }
+#pragma unroll 1
   for (int a = 0; a < P; ++a) {
     // ---------------- rows of group a -> T[b][k] ----------------
+#pragma unroll 1
     for (int r = 0; r < 2; ++r) {
       const int p = r * 16 + f;
       const int bA = 2 * p, bB = 2 * p + 1;
-      const float* ra = xi + (int64_t)(P * bA + a) * SC_F2D_W + t;
-      const float* rb = xi + (int64_t)(P * bB + a) * SC_F2D_W + t;
       cf32 v[16], o[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = cf_make(ra[16 * j], rb[16 * j]);
+      for (int j = 0; j < 16; ++j) v[j] = cf_make(pa[j], pb[j]);
+      {
+        // next round: (a, 1) after (a, 0); (a + 1, 0) after (a, 1); nothing after the last
+        const int rn = r ^ 1, an = a + r;
+        if (an < P) {
+          const int pn = rn * 16 + f;
+          const float* ra = xi + (int64_t)(P * (2 * pn) + an) * SC_F2D_W + t;
+          const float* rb = xi + (int64_t)(P * (2 * pn + 1) + an) * SC_F2D_W + t;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            pa[j] = ra[16 * j];
+            pb[j] = rb[16 * j];
+          }
+        }
+      }
       fft16<-1>(v, o);                              // over n1 (n = 16 n1 + t)
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) {
         const cf32 y = (k1 == 0) ? o[0] : cf_mul(o[k1], tw256[t * k1]);
         xch[(f * 16 + k1) * SC_F2D_XS + t] = y;
       }
-      SC_SYNC();
+      SC_WAVE_SYNC();                               // the 16 lanes of an FFT slot share a wave
 #pragma unroll
       for (int n2 = 0; n2 < 16; ++n2) v[n2] = xch[(f * 16 + t) * SC_F2D_XS + n2];
       fft16<-1>(v, o);                              // o[k2] = Z[t + 16 k2]
       sep[(f * 16 + t) * 2 + 0] = o[15];            // Z[t - 16]
       sep[(f * 16 + t) * 2 + 1] = o[14];            // Z[t - 32]
-      SC_SYNC();
+      SC_WAVE_SYNC();
       const int pt = (16 - t) & 15;
       const cf32 m1 = sep[(f * 16 + pt) * 2 + 0];   // Z[-t]       (t != 0)
       const cf32 m2 = sep[(f * 16 + pt) * 2 + 1];   // Z[-t - 16]  (t != 0)
@@ -208,6 +234,7 @@ k_fft2d_fwd(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* __
         T[bA * SC_F2D_KY + 32] = cf_make(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
         T[bB * SC_F2D_KY + 32] = cf_make(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
       }
+      SC_WAVE_SYNC();                               // sep / xch are rewritten by the next round
     }
     SC_SYNC();
     // ---------------- 33 column FFTs of 64 points on T ----------------
@@ -222,7 +249,7 @@ k_fft2d_fwd(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* __
         xch[cc * SC_F2D_CS + k1 * 4 + cu] = y;
       }
     }
-    SC_SYNC();
+    SC_WAVE_SYNC();                                 // the 4 lanes of a column share a wave
     if (ctask) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -311,6 +338,7 @@ k_fft2d_inv(const cf32* __restrict__ yhat, float* __restrict__ y, const float* _
   }
   SC_SYNC();
 
+#pragma unroll 1
   for (int a = 0; a < P; ++a) {
     // ---------------- 33 inverse column FFTs (64 points) -> T[b][c], rows h = P b + a ------------
     if (ctask) {
@@ -333,7 +361,7 @@ k_fft2d_inv(const cf32* __restrict__ yhat, float* __restrict__ y, const float* _
         }
       }
     }
-    SC_SYNC();
+    SC_WAVE_SYNC();                                 // the 4 lanes of a column share a wave
     if (ctask) {
       cf32 v[16], o[16];
 #pragma unroll
@@ -344,6 +372,7 @@ k_fft2d_inv(const cf32* __restrict__ yhat, float* __restrict__ y, const float* _
     }
     SC_SYNC();
     // ---------------- rows of group a: Hermitian-extended, zero-padded C2R, two rows packed -------
+#pragma unroll 1
     for (int r = 0; r < 2; ++r) {
       const int p = r * 16 + f;
       const int bA = 2 * p, bB = 2 * p + 1;
@@ -364,7 +393,7 @@ k_fft2d_inv(const cf32* __restrict__ yhat, float* __restrict__ y, const float* _
         const cf32 val = (n2 == 0) ? o[0] : cf_mul(o[n2], cf_conj(tw256[t * n2]));
         xch[(f * 16 + n2) * SC_F2D_XS + t] = val;
       }
-      SC_SYNC();
+      SC_WAVE_SYNC();                               // the 16 lanes of an FFT slot share a wave
       cf32 v[16];
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) v[k1] = xch[(f * 16 + t) * SC_F2D_XS + k1];
@@ -376,8 +405,9 @@ k_fft2d_inv(const cf32* __restrict__ yhat, float* __restrict__ y, const float* _
         ra[16 * n1] = o[n1].x + badd;
         rb[16 * n1] = o[n1].y + badd;
       }
-      SC_SYNC();
+      SC_WAVE_SYNC();                               // xch is rewritten by the next round
     }
+    SC_SYNC();                                      // T is rewritten by the next group
   }
 }
 

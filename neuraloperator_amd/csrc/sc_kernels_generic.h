@@ -186,6 +186,8 @@ struct ModeGemmArgs {
   const int32_t* b_idx;
   const int32_t* c_idx;
   int accumulate;
+  // launch geometry: 1-D grid of 8 * per_xcd blocks, work item = (mode tile, p group, q tile)
+  int n_mt, n_pg, n_qt, per_xcd;
 };
 
 template <int PT, int QT, bool CA, bool CB>
@@ -195,9 +197,19 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
   const int tid = SC_TID;
   const int lane = tid & 63;
   const int w = SC_UNIFORM(tid >> 6);
-  const int64_t m = (int64_t)SC_BID_X * SC_WAVE + lane;
-  const int64_t p0 = ((int64_t)SC_BID_Y * 4 + w) * PT;      // wave-uniform
-  const int64_t q0 = (int64_t)SC_BID_Z * QT;                // wave-uniform
+  // XCD-aware work mapping: the dispatcher places block b on XCD b % 8 (8 private L2s).  All
+  // (p group, q tile) blocks of one mode tile re-read the same xhat / W slices, so consecutive
+  // work items (mode tile slowest) are given to ONE XCD as a contiguous chunk: the re-reads then
+  // hit that XCD's L2 instead of going back to Infinity Cache / HBM from eight different L2s.
+  const int bid = SC_BID_X;
+  const int item = (bid & 7) * g.per_xcd + (bid >> 3);
+  if (item >= g.n_mt * g.n_pg * g.n_qt) return;
+  const int mt = item / (g.n_pg * g.n_qt);
+  const int rem = item - mt * (g.n_pg * g.n_qt);
+  const int qt = rem / g.n_pg, pg = rem - qt * g.n_pg;
+  const int64_t m = (int64_t)mt * SC_WAVE + lane;
+  const int64_t p0 = ((int64_t)pg * 4 + w) * PT;            // wave-uniform
+  const int64_t q0 = (int64_t)qt * QT;                      // wave-uniform
   if (p0 >= g.P) return;  // whole wave idle (no barriers in this kernel)
   const bool active = m < g.M;
   const int64_t mm = active ? m : g.M - 1;

@@ -1,0 +1,43 @@
+"""TEST ONLY: the three local stages of the spectral layer in plain torch (CPU, autograd),
+built on the oracle's frequency bookkeeping.  Injected into ModeParallelSpectralConv by the
+gloo tests so that the sharding / all-to-all logic can be exercised without a GPU."""
+import numpy as np
+import torch
+
+from oracle import spectral_oracle as so
+
+
+class OracleOps:
+    def __init__(self, n_modes_attr):
+        self.nm = list(n_modes_attr)
+
+    def _index(self, spatial):
+        _, freqs = so.weight_slices(list(spatial), self.nm, self.nm)
+        idx = [torch.as_tensor(np.mod(f, n)) for f, n in zip(freqs[:-1], spatial[:-1])]
+        idx.append(torch.as_tensor(freqs[-1]))
+        return idx
+
+    def forward_transform(self, x, kept):
+        nd = x.ndim - 2
+        xh = torch.fft.rfftn(x, dim=list(range(-nd, 0)), norm="forward")
+        for d, ix in enumerate(self._index(x.shape[2:])):
+            xh = xh.index_select(2 + d, ix)
+        assert list(xh.shape[2:]) == list(kept)
+        return xh
+
+    def contract(self, xhat, w):
+        return so.contract_dense(xhat, w)
+
+    def inverse_transform(self, yhat, bias, spatial):
+        nd = len(spatial)
+        full_shape = list(yhat.shape[:2]) + list(spatial[:-1]) + [spatial[-1] // 2 + 1]
+        idx = self._index(spatial)
+        cur = yhat
+        # scatter dim by dim into the zero spectrum (index_add keeps autograd happy)
+        for d in range(nd):
+            shape = list(cur.shape)
+            shape[2 + d] = full_shape[2 + d]
+            z = torch.zeros(shape, dtype=cur.dtype)
+            cur = z.index_add(2 + d, idx[d], cur)
+        y = torch.fft.irfftn(cur, s=list(spatial), dim=list(range(-nd, 0)), norm="forward")
+        return y + bias if bias is not None else y

@@ -1,0 +1,120 @@
+"""world_size-2 gloo test (CPU) of the mode-parallel layer: sharding, the two all-to-alls
+and their autograd mirror, against the single-process oracle on the full batch.  The local
+stages are the oracle's torch ops (tests/oracle_ops.py) -- the engine itself is GPU-only and
+is covered by the -m gpu tier."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, spatial, modes, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleOps
+
+    comm.init(model_parallel_size=world, backend="gloo")
+    assert comm.get_model_parallel_size() == world and comm.get_model_parallel_rank() == rank
+    assert comm.get_data_parallel_size() == 1
+    nm = halve_last_mode(modes)
+    B, ci, co = 2 * world, 3, 4
+    torch.manual_seed(0)                      # identical full tensors on every rank
+    x = torch.randn(B, ci, *spatial)
+    g = torch.randn(B, co, *spatial)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
+    bias = torch.randn(co, *(1,) * len(spatial))
+
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleOps(nm))
+    with torch.no_grad():
+        conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, rank, world))
+        conv.bias.copy_(bias)
+    bl = B // world
+    xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
+    y = conv(xs)
+    y.backward(g[rank * bl:(rank + 1) * bl])
+    conv.reduce_replicated_grads()
+
+    xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yf = so.forward_torch(xf, wf, bf, nm, nm)
+    yf.backward(g)
+    rows = nm[0] // world
+    errs = dict(
+        y=so.rel_l2(y.detach().numpy(), yf.detach()[rank * bl:(rank + 1) * bl].numpy()),
+        gx=so.rel_l2(xs.grad.numpy(), xf.grad[rank * bl:(rank + 1) * bl].numpy()),
+        gw=so.rel_l2(conv.weight.grad.numpy(), wf.grad[:, :, rank * rows:(rank + 1) * rows].numpy()),
+        gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()),
+    )
+    ret[rank] = errs
+    comm.cleanup()
+
+
+@pytest.mark.parametrize("spatial,modes", [((16, 12), (8, 6)), ((8, 8, 6), (4, 4, 4))])
+def test_mode_parallel_matches_single_process(spatial, modes):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, spatial, modes, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank, errs in ret.items():
+        for k, v in errs.items():
+            assert np.isfinite(v) and v < 1e-5, (rank, k, v)
+
+
+def _a2a_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from neuraloperator_amd.mpu import (all_to_all, comm, gather_from_model_parallel_region,
+                                        scatter_to_model_parallel_region)
+    comm.init(model_parallel_size=world, backend="gloo")
+    torch.manual_seed(1)
+    full = torch.randn(4, 3, 6, 5, dtype=torch.cfloat)           # (B, C, k1, k2), identical on all ranks
+    bl = 4 // world
+    loc = full[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
+    out = all_to_all(loc, split_dim=2, cat_dim=0)                # -> (B, C, k1/P, k2)
+    rows = 6 // world
+    ok_fwd = torch.equal(out.detach(), full[:, :, rank * rows:(rank + 1) * rows])
+    gfull = torch.randn(4, 3, 6, 5, dtype=torch.cfloat)
+    out.backward(gfull[:, :, rank * rows:(rank + 1) * rows])
+    ok_bwd = torch.allclose(loc.grad, gfull[rank * bl:(rank + 1) * bl])
+    # reference-style region mappings
+    t = torch.arange(8.0).reshape(2, 4).requires_grad_(True)
+    s = scatter_to_model_parallel_region(t, 1)
+    gth = gather_from_model_parallel_region(s, 1)
+    ok_sg = torch.equal(gth.detach(), t.detach())
+    ret[rank] = (ok_fwd, ok_bwd, ok_sg)
+    comm.cleanup()
+
+
+def test_all_to_all_autograd_and_mappings():
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_a2a_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(all(v) for v in ret.values()) and len(ret) == world
+
+
+def test_single_process_fallback_getters():
+    from neuraloperator_amd.mpu import comm
+    assert comm.get_world_size() == 1 and comm.get_model_parallel_size() == 1
+    assert comm.get_model_parallel_rank() == 0 and comm.get_data_parallel_rank() == 0
