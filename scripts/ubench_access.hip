@@ -73,6 +73,65 @@ __global__ void __launch_bounds__(256) copy_f4(const float4* __restrict__ a, flo
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
 }
 
+
+// ---- candidate patterns for the next kernel generation --------------------------------------
+// whole-row wave loads: one wave-instruction = one 1 KB row (lane l reads float4 l);
+// each wave keeps DEPTH rows in flight; LDSB bytes of dummy LDS cap the occupancy
+template <int DEPTH, int LDSB>
+__global__ void __launch_bounds__(256) rd_rows(const float* __restrict__ x, float* __restrict__ out, int nimg) {
+  __shared__ float dummy[LDSB / 4 + 1];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  float acc = 0.f;
+  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    const float4* xi = reinterpret_cast<const float4*>(x + (size_t)img * H * W);
+    for (int r0 = w * (H / 4); r0 < (w + 1) * (H / 4); r0 += DEPTH) {
+      float4 v[DEPTH];
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) v[j] = xi[(size_t)(r0 + j) * 64 + l];
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+  }
+  if (acc == 12345.678f) { dummy[tid] = acc; out[blockIdx.x] = dummy[(tid + 1) & 255]; }
+}
+
+template <int DEPTH, int LDSB>
+__global__ void __launch_bounds__(256) wr_rows(float* __restrict__ y, int nimg) {
+  __shared__ float dummy[LDSB / 4 + 1];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  if (nimg < 0) dummy[tid] = 1.f;
+  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    float4* yi = reinterpret_cast<float4*>(y + (size_t)img * H * W);
+    for (int r0 = w * (H / 4); r0 < (w + 1) * (H / 4); r0 += DEPTH) {
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) yi[(size_t)(r0 + j) * 64 + l] = make_float4(j, r0, l, 1.f);
+    }
+  }
+  if (nimg < 0) y[0] = dummy[(tid + 1) & 255];
+}
+
+// read with 8 B per lane (float2), 16-lane group = 128 B contiguous (row-pair FFT lanes holding 2 adjacent elements)
+template <int LDSB>
+__global__ void __launch_bounds__(256) rd_float2_seg128(const float* __restrict__ x, float* __restrict__ out, int nimg) {
+  __shared__ float dummy[LDSB / 4 + 1];
+  const int tid = threadIdx.x, f = tid >> 4, t = tid & 15;
+  float acc = 0.f;
+  for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+    const float* xi = x + (size_t)img * H * W;
+    for (int rr = 0; rr < 8; ++rr) {
+      const int p = rr * 16 + f;
+      const float2* ra = reinterpret_cast<const float2*>(xi + (size_t)(2 * p) * W) + t;
+      const float2* rb = reinterpret_cast<const float2*>(xi + (size_t)(2 * p + 1) * W) + t;
+      float2 v[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = ra[16 * j]; v[8 + j] = rb[16 * j]; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += v[j].x + v[j].y;
+    }
+  }
+  if (acc == 12345.678f) { dummy[tid] = acc; out[blockIdx.x] = dummy[(tid + 1) & 255]; }
+}
+
 template <class F>
 float timeit(F launch, int iters = 20) {
   hipEvent_t e0, e1;
@@ -99,5 +158,21 @@ int main() {
   t = timeit([&] { wr_float4<<<NIMG, 256>>>(y); });          printf("wr_float4      : %7.1f us  %7.1f GB/s\n", t * 1e3, gb / (t * 1e-3));
   t = timeit([&] { copy_f4<<<2048, 256>>>((const float4*)x, (float4*)y, n / 4); });
   printf("copy_f4 (r+w)  : %7.1f us  %7.1f GB/s\n", t * 1e3, 2 * gb / (t * 1e-3));
+
+#define RUN(name, call, bytes) t = timeit([&] { call; }); printf("%-34s: %7.1f us  %7.1f GB/s\n", name, t * 1e3, (bytes) / (t * 1e-3));
+  RUN("rd_rows<4,0>  grid 2048", (rd_rows<4, 0><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<8,0>  grid 2048", (rd_rows<8, 0><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<16,0> grid 2048", (rd_rows<16, 0><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<8,60000> grid 2048 (2 WG/CU)", (rd_rows<8, 60000><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<16,60000> grid 2048 (2 WG/CU)", (rd_rows<16, 60000><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<16,60000> grid 512 persistent", (rd_rows<16, 60000><<<512, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<8,36000> grid 2048 (4 WG/CU)", (rd_rows<8, 36000><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_rows<16,36000> grid 1024 persistent", (rd_rows<16, 36000><<<1024, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_float2_seg128<60000> grid 2048", (rd_float2_seg128<60000><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_float2_seg128<36000> grid 2048", (rd_float2_seg128<36000><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("wr_rows<8,0>  grid 2048", (wr_rows<8, 0><<<2048, 256>>>(y, NIMG)), gb)
+  RUN("wr_rows<16,60000> grid 2048 (2 WG/CU)", (wr_rows<16, 60000><<<2048, 256>>>(y, NIMG)), gb)
+  RUN("wr_rows<16,60000> grid 512 persistent", (wr_rows<16, 60000><<<512, 256>>>(y, NIMG)), gb)
+  RUN("wr_rows<8,36000> grid 2048 (4 WG/CU)", (wr_rows<8, 36000><<<2048, 256>>>(y, NIMG)), gb)
   return 0;
 }
