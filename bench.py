@@ -128,9 +128,28 @@ def stage_profile(B, C, spatial, n_modes, flags, iters):
         "adj_r2c_transform": (lambda: lib.transform_inverse(plan, _lib.SC_INV_ADJ_R2C, p(yh), 0, C, p(y),
                                                             B * C, p(ws), st), R + S),
     }
+    # the stages run in the layer's own order (fwd x3, bwd x4) with an event between each, so every
+    # kernel sees the cache state it sees inside a real step (the 0.5 GB real tensors evict the
+    # spectra / weights from L2 and Infinity Cache between uses); per-stage time = mean over iters
+    order = ["fwd_transform", "contract_fwd", "inv_transform", "adj_c2r_transform", "contract_gw",
+             "contract_gx", "adj_r2c_transform"]
+    for name in order:
+        stages[name][0]()
+    torch.cuda.synchronize()
+    acc = {name: 0.0 for name in order}
+    for _ in range(iters):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)]
+        ev[0].record()
+        for i, name in enumerate(order):
+            stages[name][0]()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        for i, name in enumerate(order):
+            acc[name] += ev[i].elapsed_time(ev[i + 1])
     out = {}
-    for name, (fn, nbytes) in stages.items():
-        ms = time_stage(fn, iters)
+    for name in order:
+        ms = acc[name] / iters
+        nbytes = stages[name][1]
         out[name] = {"ms": round(ms, 4), "alg_bytes": nbytes, "GBs": round(nbytes / ms / 1e6, 1)}
     names = {"fwd": lib.plan_kernel_name(plan, 0), "inv": lib.plan_kernel_name(plan, 1),
              "fast": lib.plan_is_fast(plan)}

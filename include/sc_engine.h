@@ -93,6 +93,12 @@ int sc_transform_inverse(const sc_plan* plan, int mode, const float* yhat, const
  * replaces tl.einsum('bixy,ioxy->boxy') and its two autograd einsums
  * (spectral_convolution.py:21-46) and the pairwise steps of _contract_tucker/_contract_cp
  * (:55-103). */
+enum {
+  SC_GEMM_FORCE_VALU = 1     /* never take the matrix-core kernel (debug / A-B)            */
+};
+/* flags bits 8..23: cap on the number of workgroups of the matrix-core kernel (0 = auto) */
+#define SC_GEMM_GRID(n) (((n) & 0xffff) << 8)
+
 typedef struct {
   int64_t P, Q, R, n_modes;
   int64_t a_sp, a_sr, a_sm;
@@ -100,13 +106,15 @@ typedef struct {
   int64_t c_sp, c_sq, c_sm;
   int32_t conj_a, conj_b;
   int32_t accumulate;       /* 0: C = ..., 1: C += ...                                     */
-  int32_t reserved;
+  int32_t flags;            /* SC_GEMM_* bits                                               */
   const int32_t* b_idx;     /* optional device table [n_modes], NULL -> m*b_sm              */
   const int32_t* c_idx;     /* optional device table [n_modes], NULL -> m*c_sm              */
 } sc_modegemm_desc;
 
 int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                 void* stream);
+/* 1 if this call runs on the MFMA kernel (k_modegemm_mfma), 0 for the VALU kernel */
+int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
 
 /* gbias[c] = sum_b Re(ghat[b, c, dc]) -- the bias gradient read off the DC coefficient of
  * the already-computed SC_FWD_ADJ_C2R spectrum (autograd of :567-568). */

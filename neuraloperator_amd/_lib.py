@@ -14,6 +14,12 @@ SC_NORM = {"forward": 0, "backward": 1, "ortho": 2}
 SC_FWD_SCALED, SC_FWD_ADJ_C2R = 0, 1
 SC_INV_PADDED, SC_INV_ADJ_R2C = 0, 1
 SC_PLAN_FORCE_GENERIC = 1
+SC_GEMM_FORCE_VALU = 1
+
+
+def SC_GEMM_GRID(n):
+    """flags bits 8..23 of sc_modegemm_desc: cap on the matrix-core kernel's workgroups."""
+    return (int(n) & 0xffff) << 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libsc_engine.so")
@@ -31,7 +37,7 @@ class ModeGemmDesc(Structure):
                 ("b_sr", c_int64), ("b_sq", c_int64), ("b_sm", c_int64),
                 ("c_sp", c_int64), ("c_sq", c_int64), ("c_sm", c_int64),
                 ("conj_a", c_int32), ("conj_b", c_int32),
-                ("accumulate", c_int32), ("reserved", c_int32),
+                ("accumulate", c_int32), ("flags", c_int32),
                 ("b_idx", c_void_p), ("c_idx", c_void_p)]
 
 
@@ -50,7 +56,8 @@ class ScEngineLib:
 
     # every symbol include/sc_engine.h declares
     SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
-               "sc_transform_forward", "sc_transform_inverse", "sc_modegemm", "sc_bias_grad",
+               "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
+               "sc_modegemm_uses_matrix_cores", "sc_bias_grad",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name"]
 
@@ -82,6 +89,8 @@ class ScEngineLib:
         L.sc_transform_inverse.restype = c_int
         L.sc_modegemm.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_modegemm.restype = c_int
+        L.sc_modegemm_uses_matrix_cores.argtypes = [POINTER(ModeGemmDesc)]
+        L.sc_modegemm_uses_matrix_cores.restype = c_int
         L.sc_bias_grad.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
         L.sc_bias_grad.restype = c_int
         L.sc_layer_workspace_bytes.argtypes = [c_void_p, POINTER(LayerDesc)]
@@ -145,6 +154,12 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    def modegemm_uses_matrix_cores(self, **kw):
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return bool(self.lib.sc_modegemm_uses_matrix_cores(byref(d)))
 
     def bias_grad(self, plan, ghat_ptr, batch, channels, gbias_ptr, stream=0):
         self._check(self.lib.sc_bias_grad(plan, ghat_ptr, batch, channels, gbias_ptr, stream))

@@ -36,6 +36,8 @@
   } while (0)
 // value known to be identical in every lane of the wave -> keep it in an SGPR
 #define SC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// the instruction scheduler may not move anything across this point
+#define SC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define SC_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
   type* name = reinterpret_cast<type*>(name##_raw)
 
@@ -79,6 +81,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_LAUNCH_BOUNDS(n)
 #define SC_WAVE_SYNC() scemu::barrier()   /* emulated lanes are free-running threads */
 #define SC_UNIFORM(x) (x)
+#define SC_SCHED_BARRIER() do { } while (0)
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)
 
 typedef void* sc_stream_t;
@@ -102,6 +105,12 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, sc_stream_t) { std::m
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 #endif
+
+// compile-time integer tag (selects a template body from a wave-uniform runtime value)
+template <int N>
+struct sc_int {
+  static constexpr int value = N;
+};
 
 // --------------------------------------------------------------------------- complex helpers
 struct cf32 {

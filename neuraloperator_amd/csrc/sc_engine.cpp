@@ -16,6 +16,7 @@
 #include "sc_device.h"
 #include "sc_kernels_generic.h"
 #include "sc_kernels_fft.h"
+#include "sc_kernels_mfma.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -424,6 +425,54 @@ static int dispatch_modegemm_conj(const ModeGemmArgs& g, int ca, int cb, const c
   return sc_check_launch("k_modegemm");
 }
 
+// ---- matrix-core path (sc_kernels_mfma.h): channel counts that fill 32 x 32 MFMA tiles ----------
+#define SC_MG_NM 9
+static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
+  if (d->accumulate) return false;
+  if (d->Q != 64) return false;
+  if (d->P != 32 && d->P != 64) return false;
+  if (d->n_modes >= ((int64_t)1 << 31) / SC_MG_NM) return false;
+  return true;
+}
+
+template <int PT, bool CA, bool CB>
+static void launch_mfma_gemm(const MfmaGemmArgs& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  SC_LAUNCH((k_modegemm_mfma<PT, 4, SC_MG_NM, CA, CB>), dim3((unsigned)g.G),
+            dim3((MfmaGemmCfg<PT, 4, SC_MG_NM>::THREADS)), 0, st, g, A, B, C);
+}
+
+template <int PT>
+static void dispatch_mfma_gemm(const MfmaGemmArgs& g, int ca, int cb, const cf32* A, const cf32* B, cf32* C,
+                               sc_stream_t st) {
+  if (!ca && !cb) launch_mfma_gemm<PT, false, false>(g, A, B, C, st);
+  else if (ca && !cb) launch_mfma_gemm<PT, true, false>(g, A, B, C, st);
+  else if (!ca && cb) launch_mfma_gemm<PT, false, true>(g, A, B, C, st);
+  else launch_mfma_gemm<PT, true, true>(g, A, B, C, st);
+}
+
+static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  MfmaGemmArgs g;
+  g.P = (int)d->P; g.Q = (int)d->Q; g.R = (int)d->R; g.M = (int)d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.a_sm = d->a_sm;
+  g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.b_sm = d->b_sm;
+  g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
+  g.b_idx = d->b_idx; g.c_idx = d->c_idx;
+  g.dbg = (d->flags >> 24) & 0xf;
+  // contiguous mode ranges of <= SC_MG_NM modes, split evenly: one range per CU when they fit
+  const int64_t M = d->n_modes;
+  int64_t G = (M + SC_MG_NM - 1) / SC_MG_NM;
+  const int64_t cus = 256;
+  if (G < cus) G = M < cus ? M : cus;
+  else G = (G + 7) / 8 * 8;
+  if (G > M) G = M;
+  const int64_t cap = (d->flags >> 8) & 0xffff;               // SC_GEMM_GRID(n): tests / tuning
+  if (cap > 0 && cap < G && cap * SC_MG_NM >= M) G = cap;
+  g.G = (int)G;
+  if (d->P == 32) dispatch_mfma_gemm<1>(g, d->conj_a, d->conj_b, A, B, C, st);
+  else dispatch_mfma_gemm<2>(g, d->conj_a, d->conj_b, A, B, C, st);
+  return sc_check_launch("k_modegemm_mfma");
+}
+
 extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                            void* stream) {
   SC_CHECK_ARG(d && A && B && C, "null argument");
@@ -443,8 +492,14 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   const cf32* a = (const cf32*)A;
   const cf32* b = (const cf32*)B;
   cf32* c = (cf32*)C;
+  if (!(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d))
+    return run_mfma_gemm(d, a, b, c, st);
   if (g.Q > 4) return dispatch_modegemm_conj<4, 8>(g, d->conj_a, d->conj_b, a, b, c, st);
   return dispatch_modegemm_conj<4, 4>(g, d->conj_a, d->conj_b, a, b, c, st);
+}
+
+extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) {
+  return d && !(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d) ? 1 : 0;
 }
 
 extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,
@@ -545,6 +600,7 @@ extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const 
   g.a_sp = Ci * Mk; g.a_sr = Mk; g.a_sm = 1;
   g.b_sr = Co * Wm; g.b_sq = Wm; g.b_sm = 1; g.b_idx = idx;
   g.c_sp = Co * Mk; g.c_sq = Mk; g.c_sm = 1;
+  g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
   rc = sc_modegemm(&g, xhat_saved, w, yhat, stream);
   if (rc) return rc;
   return sc_transform_inverse(p, SC_INV_PADDED, yhat, bias, Co, y, B * Co, ws, stream);
@@ -580,6 +636,7 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
     g.a_sp = Mk; g.a_sr = Ci * Mk; g.a_sm = 1; g.conj_a = 1;
     g.b_sr = Co * Mk; g.b_sq = Mk; g.b_sm = 1;
     g.c_sp = Co * Wm; g.c_sq = Wm; g.c_sm = 1; g.c_idx = idx;
+    g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
     rc = sc_modegemm(&g, xhat_saved, ghat, gw, stream);
     if (rc) return rc;
   }
@@ -590,6 +647,7 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
     g.a_sp = Co * Mk; g.a_sr = Mk; g.a_sm = 1;
     g.b_sr = Wm; g.b_sq = Co * Wm; g.b_sm = 1; g.b_idx = idx; g.conj_b = 1;
     g.c_sp = Ci * Mk; g.c_sq = Mk; g.c_sm = 1;
+    g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
     rc = sc_modegemm(&g, ghat, w, gxhat, stream);
     if (rc) return rc;
     rc = sc_transform_inverse(p, SC_INV_ADJ_R2C, gxhat, nullptr, Ci, gx, B * Ci, ws, stream);

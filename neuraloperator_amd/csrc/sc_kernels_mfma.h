@@ -1,0 +1,334 @@
+// sc_kernels_mfma.h -- the dense (i,o) x mode block GEMM of the spectral layer on the CDNA4
+// matrix cores (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32).
+//
+//   C[p, q, m] = sum_r opA(A[p, r, m]) * opB(B[r, q, m])        (complex, m = Fourier mode)
+//
+// replaces tl.einsum('bixy,ioxy->boxy') and its two autograd einsums
+// (spectral_convolution.py:21-46) for channel counts that fill MFMA tiles; everything else
+// takes the lanes-are-modes VALU kernel in sc_kernels_generic.h (same results).
+//
+// Decomposition (MI355X-first, not a batched-GEMM library call):
+//  * every operand keeps the reference's layout: the mode index is innermost, so for one mode
+//    the (p, r) / (r, q) matrix elements are 8-byte islands M*8 bytes apart.  A workgroup
+//    therefore owns a CONTIGUOUS RANGE of nm <= NM modes (M modes split evenly over the grid:
+//    256 workgroups x 8.25 modes at the metric shape, one workgroup per CU, no tail) and reads
+//    every (p, r) / (r, q) element of its range as ONE nm*8-byte segment: each byte of A and B
+//    crosses HBM exactly once, L2 only has to merge the cache lines two neighbouring ranges
+//    share (neighbouring ranges are mapped to the same XCD).
+//  * the complex product is evaluated as a real GEMM with K doubled:
+//        A'[p][2r+c] = (Re, Im)[c] of A[p][r]           (c = lane >> 5 of the MFMA A operand)
+//        B'[2r+c][2q+d] = Re B, Im B, -Im B, Re B        (n = 2q+d = lane & 31 of the B operand)
+//    so one v_mfma_f32_32x32x2_f32 consumes one r for 32 p x 16 q of one mode; conjugations
+//    are sign masks on the operand registers.  fp32 MFMA is a k-ordered fmaf chain: results
+//    are of fp32-roundoff class like the VALU kernel (MI355X_MICROARCH.md, Matrix cores).
+//  * LDS stage = RC values of r for all nm modes, split into Re/Im planes with an odd mode
+//    stride so that both the staging writes (lanes = (segment, mode)) and the MFMA operand
+//    reads (lanes = p or q) are bank-conflict free; two stages ping-pong, the global loads of
+//    stage k+1 are in flight while stage k feeds the matrix cores; one barrier per stage.
+//  * 8 waves = 2 per SIMD.  A wave owns one 32 x 32 MFMA tile column set (row tile wp, columns
+//    q = 16 (wq + 4u) .. +15) for all modes; for P = 32 two waves share a tile and split the r
+//    values of every stage (even / odd), their partial sums meet in the epilogue; for P = 64
+//    there is one wave per tile.  In-order issue means a wave's own
+//    LDS reads / sign flips / address arithmetic cannot overlap its own MFMAs (measured 86-111
+//    cycles per MFMA with one wave per SIMD against the 64-cycle issue rate); the partner wave's
+//    MFMAs fill those slots.  MFMAs of one r are issued back to back, accumulators stay in
+//    registers (NM * 16 per column group) for the whole r loop.
+#pragma once
+#include "sc_device.h"
+
+#define SC_MG_RC 8
+
+#ifndef SC_EMU
+typedef float sc_f32x16 __attribute__((ext_vector_type(16)));
+SC_DEVICE void sc_mfma_32x32x2(sc_f32x16& acc, const float a, const float b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+SC_DEVICE float sc_xor_sign(const float v, const uint32_t mask) {
+  return __uint_as_float(__float_as_uint(v) ^ mask);
+}
+#else
+struct sc_f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+namespace scemu {
+inline float g_mfma_a[16][64];
+inline float g_mfma_b[16][64];
+}  // namespace scemu
+// lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; it owns
+// D[row = (v & 3) + 8 (v >> 2) + 4 (l >> 5)][col = l & 31], v = 0..15  (cdna_hip_programming.md 3)
+inline void sc_mfma_32x32x2(sc_f32x16& acc, const float a, const float b) {
+  const int w = SC_TID >> 6, l = SC_TID & 63;
+  scemu::g_mfma_a[w][l] = a;
+  scemu::g_mfma_b[w][l] = b;
+  scemu::barrier();
+  for (int v = 0; v < 16; ++v) {
+    const int row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), col = l & 31;
+    float c = acc[v];
+    for (int k = 0; k < 2; ++k) c = fmaf(scemu::g_mfma_a[w][row + 32 * k], scemu::g_mfma_b[w][col + 32 * k], c);
+    acc[v] = c;
+  }
+  scemu::barrier();
+}
+inline float sc_xor_sign(const float v, const uint32_t mask) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u ^= mask;
+  float r;
+  std::memcpy(&r, &u, 4);
+  return r;
+}
+#endif
+
+struct MfmaGemmArgs {
+  int P, Q, R, M, G;   // G = number of mode ranges = grid size
+  int64_t a_sp, a_sr, a_sm;
+  int64_t b_sr, b_sq, b_sm;
+  int64_t c_sp, c_sq, c_sm;
+  const int32_t* b_idx;
+  const int32_t* c_idx;
+  int dbg;             // ablation bits (bench only): 1 skip MFMA, 2 skip C stores, 4 skip operand loads
+};
+
+template <int PT, int QG, int NM>
+struct MfmaGemmCfg {
+  static constexpr int P = 32 * PT, Q = 16 * QG;
+  static constexpr int RC = SC_MG_RC;                         // r values per LDS stage
+  static constexpr int NW = 8;                                // waves (2 per SIMD)
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int NT = 4 * PT;                           // (row tile, column group set) pairs
+  static constexpr int MS = NW / NT;                          // waves sharing a tile = r split
+  static constexpr int HL = RC / NW;                          // r values staged by one wave
+  static constexpr int NMS = (NM & 1) ? NM : NM + 1;          // odd mode stride (floats)
+  static constexpr int QW = QG / 4;                           // column groups per wave
+  static constexpr int A_FLOATS = RC * 2 * P * NMS;           // [rr][c][p][NMS]
+  static constexpr int BPAD = (16 - (Q * NMS) % 32 + 32) % 32;
+  static constexpr int BPS = Q * NMS + BPAD;                  // Im plane 16 banks away from Re
+  static constexpr int B_FLOATS = RC * 2 * BPS;               // [rr][plane][q][NMS]
+  static constexpr int STAGE = A_FLOATS + B_FLOATS;
+  static constexpr int LDS_BYTES = 2 * STAGE * 4;
+  static constexpr int SPI_MIN = 64 / NM;                     // segments per wave load at nm = NM
+  static constexpr int NPA = (P + SPI_MIN - 1) / SPI_MIN;     // wave loads per r for A (max)
+  static constexpr int NPB = (Q + SPI_MIN - 1) / SPI_MIN;     // ... for B
+  static constexpr int EP_FLOATS = 8 * 16 * NMS * 2;          // epilogue patch of one tile: 8 rows
+  static_assert(NT == 4 || NT == 8, "P = 32 or 64");
+  static_assert(HL * NW == RC, "the waves split the r values of a stage");
+  static_assert(QG % 4 == 0, "4 waves split the column groups");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(NT * EP_FLOATS <= 2 * STAGE, "epilogue patches fit in the stage buffers");
+};
+
+template <int PT, int QG, int NM, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS((MfmaGemmCfg<PT, QG, NM>::THREADS))
+k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
+                cf32* __restrict__ C) {
+  typedef MfmaGemmCfg<PT, QG, NM> K;
+  constexpr int P = K::P, Q = K::Q, RC = K::RC, NMS = K::NMS, QW = K::QW, BPS = K::BPS;
+  SC_SHARED __attribute__((aligned(16))) float lds[2 * K::STAGE];
+
+  // ---- which modes: contiguous range, neighbouring ranges on one XCD (block b runs on XCD b % 8)
+  int gid = SC_BID_X;
+  if ((g.G & 7) == 0) gid = (gid & 7) * (g.G >> 3) + (gid >> 3);
+  const int m0 = (int)(((int64_t)gid * g.M) / g.G);
+  const int nm = (int)(((int64_t)(gid + 1) * g.M) / g.G) - m0;       // 1 .. NM, block-uniform
+  if (nm <= 0) return;
+
+  const int tid = SC_TID, lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
+
+  // ---- staging role: lane = (segment sl, mode j) of a wave load; spi segments per load
+  const int spi = 64 / nm;
+  const int sl = lane / nm, jl = lane - sl * nm;
+  const bool lvalid = sl < spi;
+  const int mj = m0 + (lvalid ? jl : 0);
+  const int64_t la = (int64_t)(lvalid ? sl : 0) * g.a_sp + (int64_t)mj * g.a_sm;
+  const int64_t lb = (int64_t)(lvalid ? sl : 0) * g.b_sq + (g.b_idx ? (int64_t)g.b_idx[mj] : (int64_t)mj * g.b_sm);
+  const int lds_l = sl * NMS + jl;
+  const int npa = (P + spi - 1) / spi, npb = (Q + spi - 1) / spi;   // uniform
+
+  cf32 ra[K::HL][K::NPA], rb[K::HL][K::NPB];
+
+  // every load address is clamped into the operand (no exec-masked loads); what must not be
+  // used is dropped / zeroed when the stage is committed to LDS
+  const int slc = lvalid ? sl : 0;
+  auto issue = [&](const int r0) {
+#pragma unroll
+    for (int h = 0; h < K::HL; ++h) {
+      int r = r0 + w + K::NW * h;                                       // uniform
+      r = r < g.R ? r : g.R - 1;
+      const cf32* ar = A + (int64_t)r * g.a_sr + la;
+      const cf32* br = B + (int64_t)r * g.b_sr + lb;
+#pragma unroll
+      for (int pg = 0; pg < K::NPA; ++pg) {
+        if (pg < npa) {                                                 // uniform branch
+          int pb = pg * spi;
+          if (pb + slc >= P) pb = P - 1 - slc;
+          ra[h][pg] = ar[(int64_t)pb * g.a_sp];
+        }
+      }
+#pragma unroll
+      for (int qg = 0; qg < K::NPB; ++qg) {
+        if (qg < npb) {
+          int qb = qg * spi;
+          if (qb + slc >= Q) qb = Q - 1 - slc;
+          rb[h][qg] = br[(int64_t)qb * g.b_sq];
+        }
+      }
+    }
+  };
+
+  auto commit = [&](float* st, const int r0) {
+#pragma unroll
+    for (int h = 0; h < K::HL; ++h) {
+      const int rr = w + K::NW * h;
+      const float keep = (r0 + rr < g.R) ? 1.f : 0.f;                  // rows past R contribute 0
+#pragma unroll
+      for (int pg = 0; pg < K::NPA; ++pg) {
+        const int p = pg * spi + sl;
+        if (lvalid && pg < npa && p < P) {
+          float* o = st + (rr * 2 * P + pg * spi) * NMS + lds_l;
+          o[0] = ra[h][pg].x * keep;
+          o[P * NMS] = ra[h][pg].y * (CA ? -keep : keep);          // conj(A) folded in here
+        }
+      }
+#pragma unroll
+      for (int qg = 0; qg < K::NPB; ++qg) {
+        const int q = qg * spi + sl;
+        if (lvalid && qg < npb && q < Q) {
+          float* o = st + K::A_FLOATS + rr * 2 * BPS + (qg * spi) * NMS + lds_l;
+          o[0] = rb[h][qg].x;
+          o[BPS] = rb[h][qg].y;
+        }
+      }
+    }
+  };
+
+  // ---- MFMA role: lane = (c, i) for A' rows, (c, n = 2 qq + d) for B' columns
+  const int c = lane >> 5, i = lane & 31, d = lane & 1, qq = (lane & 31) >> 1;
+  const uint32_t bmask = (CB ? (c == 0 && d == 1) : (c == 1 && d == 0)) ? 0x80000000u : 0u;
+  const int tile = w & (K::NT - 1), kh = w / K::NT;       // tile = (row tile, first column group)
+  const int wp = tile >> 2, wq = tile & 3;
+  const int a_off = (c * P + wp * 32 + i) * NMS;
+  int b_off[QW];
+#pragma unroll
+  for (int u = 0; u < QW; ++u) b_off[u] = K::A_FLOATS + (c ^ d) * BPS + ((wq + 4 * u) * 16 + qq) * NMS;
+
+  sc_f32x16 acc[NM][QW];
+#pragma unroll
+  for (int j = 0; j < NM; ++j)
+#pragma unroll
+    for (int u = 0; u < QW; ++u)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[j][u][v] = 0.f;
+
+  // one stage: this wave's r values (kh, kh + MS, ...) for all NM mode slots (slots >= nm hold
+  // stale LDS and are never stored, so there are no branches).  The MFMAs of one r are issued
+  // strictly back to back after the B' sign flips of the whole batch; the partner wave on the
+  // SIMD covers the gaps.
+  auto compute = [&](const float* st) {
+#pragma unroll
+    for (int rq = 0; rq < RC / K::MS; ++rq) {
+      const float* sr = st + (rq * K::MS + kh) * 2 * P * NMS;           // A' rows of this r
+      const float* sb = st + (rq * K::MS + kh) * 2 * BPS;               // B  rows of this r
+      float av[NM], bs[NM][QW];
+#pragma unroll
+      for (int j = 0; j < NM; ++j) {
+        av[j] = sr[a_off + j];
+#pragma unroll
+        for (int u = 0; u < QW; ++u) bs[j][u] = sb[b_off[u] + j];
+      }
+#pragma unroll
+      for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int u = 0; u < QW; ++u) bs[j][u] = sc_xor_sign(bs[j][u], bmask);
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int u = 0; u < QW; ++u) sc_mfma_32x32x2(acc[j][u], av[j], bs[j][u]);
+      SC_SCHED_BARRIER();
+    }
+  };
+
+  const int nck = (g.R + RC - 1) / RC;
+#ifndef SC_EMU
+  long long dbg_t0 = 0, dbg_w0 = 0;
+#endif
+  issue(0);
+  commit(lds, 0);
+  SC_SYNC();
+#ifndef SC_EMU
+  if (g.dbg & 8) { dbg_t0 = clock64(); dbg_w0 = wall_clock64(); }
+#endif
+#pragma unroll 1
+  for (int ck = 0; ck < nck; ++ck) {
+    float* cur = lds + (ck & 1) * K::STAGE;
+    float* nxt = lds + ((ck + 1) & 1) * K::STAGE;
+    const bool more = ck + 1 < nck;
+    if (more && !(g.dbg & 4)) issue((ck + 1) * RC);
+    if (!(g.dbg & 1)) compute(cur);
+    if (g.dbg & 8) continue;
+    if (more) commit(nxt, (ck + 1) * RC);
+    SC_SYNC();
+  }
+
+  // ---- C: a lane owns column n = (q, d) and 16 rows of its tile, i.e. 4-byte pieces M*8 bytes
+  //      apart.  Eight rows at a time are transposed through the tile's LDS patch (the stage
+  //      buffers are free after the last barrier) into (row, column, mode) order and leave as
+  //      nm*8-byte segments -- the same access shape as the operand loads.  The waves sharing a
+  //      tile fill the patch together and split the segment stores.
+#ifndef SC_EMU
+  if ((g.dbg & 8) && tid == 0 && SC_BID_X < 8) {   // bench only: cycles of the bare MFMA loop
+    reinterpret_cast<long long*>(C)[2 * SC_BID_X] = clock64() - dbg_t0;
+    reinterpret_cast<long long*>(C)[2 * SC_BID_X + 1] = wall_clock64() - dbg_w0;
+  }
+#endif
+  if (g.dbg & 2) {
+    if (acc[0][0][0] != 12345.678f) return;
+  }
+  constexpr int NST = (128 + K::SPI_MIN - 1) / K::SPI_MIN;
+  float* ep = lds + tile * K::EP_FLOATS;
+  const int nst = (128 + spi - 1) / spi;
+  const int64_t lc = g.c_idx ? (int64_t)g.c_idx[mj] : (int64_t)mj * g.c_sm;
+#pragma unroll
+  for (int u = 0; u < QW; ++u) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (K::MS == 2) {                      // partner's partial sums first
+        if (kh == 1) {
+#pragma unroll
+          for (int j = 0; j < NM; ++j)
+            if (j < nm) {
+#pragma unroll
+              for (int vv = 0; vv < 4; ++vv)
+                ep[(((4 * c + vv) * 16 + qq) * NMS + j) * 2 + d] = acc[j][u][4 * k + vv];
+            }
+        }
+        SC_SYNC();
+      }
+      if (kh == 0) {
+#pragma unroll
+        for (int j = 0; j < NM; ++j)
+          if (j < nm) {
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+              float* e = ep + (((4 * c + vv) * 16 + qq) * NMS + j) * 2 + d;
+              *e = (K::MS == 2) ? acc[j][u][4 * k + vv] + *e : acc[j][u][4 * k + vv];
+            }
+          }
+      }
+      SC_SYNC();
+      cf32* crow = C + (int64_t)(wp * 32 + 8 * k) * g.c_sp + (int64_t)((wq + 4 * u) * 16) * g.c_sq + lc;
+#pragma unroll
+      for (int it = 0; it < NST; ++it) {
+        const int sg = it * spi + sl;                   // segment = (row 0..7, column 0..15)
+        if ((it % K::MS) == kh && it < nst && lvalid && sg < 128) {
+          const cf32 val = *reinterpret_cast<const cf32*>(ep + (sg * NMS + jl) * 2);
+          crow[(int64_t)(sg >> 4) * g.c_sp + (int64_t)(sg & 15) * g.c_sq] = val;
+        }
+      }
+      SC_SYNC();
+    }
+  }
+}

@@ -45,6 +45,9 @@ ORACLE_CASES = [
     (4, 6, 6, (512,), (64,), None),
     (1, 3, 3, (9, 11, 8), (5, 7, 4), None),
     (2, 4, 4, (256, 256), (256, 256), None),        # keep everything
+    (32, 64, 64, (32, 32), (16, 16), None),         # channel counts that take the MFMA contraction
+    (64, 64, 64, (24, 20), (8, 10), None),          # ... with P = 64 row tiles in forward, odd-ish grid
+    (32, 64, 64, (32, 32), (12, 12), (16, 16)),     # ... through the sub-block index tables
 ]
 
 
@@ -129,6 +132,42 @@ def test_full_size_properties(lib):
         want = (cw * col.real).sum().item()                # c_k * Re(.) (Im of the DC column drops out)
         got = y1[bi, oi, h0, w0].item()
         assert abs(got - want) < 1e-4 * max(1.0, abs(want))
+
+
+def test_mfma_contractions_full_size(lib):
+    """The three contractions of the layer at the BASELINE metric shape (2112 modes, B=32, C=64)
+    on the matrix-core kernel vs a complex128 einsum and vs the VALU kernel."""
+    from neuraloperator_amd import _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    B, C, M = 32, 64, 64 * 33
+    xh = torch.randn(B, C, M, dtype=torch.cfloat, device=dev)
+    gh = torch.randn(B, C, M, dtype=torch.cfloat, device=dev)
+    w = torch.randn(C, C, M, dtype=torch.cfloat, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(a, b, out, flags, **kw):
+        assert lib.modegemm_uses_matrix_cores(flags=flags, **kw) == (flags == 0)
+        lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                     torch.view_as_real(out).data_ptr(), st, flags=flags, **kw)
+        torch.cuda.synchronize()
+        return out
+
+    cases = {
+        "fwd": (xh, w, (B, C, M), "bim,iom->bom", dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1,
+                b_sr=C * M, b_sq=M, b_sm=1, c_sp=C * M, c_sq=M, c_sm=1), (False, False)),
+        "gx": (gh, w, (B, C, M), "bom,iom->bim", dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1,
+               b_sr=M, b_sq=C * M, b_sm=1, conj_b=1, c_sp=C * M, c_sq=M, c_sm=1), (False, True)),
+        "gw": (xh, gh, (C, C, M), "bim,bom->iom", dict(P=C, Q=C, R=B, n_modes=M, a_sp=M, a_sr=C * M, a_sm=1,
+               conj_a=1, b_sr=C * M, b_sq=M, b_sm=1, c_sp=C * M, c_sq=M, c_sm=1), (True, False)),
+    }
+    for name, (a, b, shape, eq, kw, (ca, cb)) in cases.items():
+        a128, b128 = a.to(torch.complex128), b.to(torch.complex128)
+        ref = torch.einsum(eq, a128.conj() if ca else a128, b128.conj() if cb else b128).cpu().numpy()
+        out = run(a, b, torch.full(shape, float("nan"), dtype=torch.cfloat, device=dev), 0, **kw)
+        assert rel_l2(out.cpu().numpy(), ref) < TOL, name
+        out2 = run(a, b, torch.empty(shape, dtype=torch.cfloat, device=dev), L.SC_GEMM_FORCE_VALU, **kw)
+        assert rel_l2(out2.cpu().numpy(), ref) < TOL, name
 
 
 def test_module_dropin():
