@@ -59,7 +59,8 @@ typedef struct {
 } sc_plan_desc;
 
 enum {
-  SC_PLAN_FORCE_GENERIC = 1  /* never take the power-of-two fast kernels (debug / A-B)     */
+  SC_PLAN_FORCE_GENERIC = 1, /* never take the power-of-two fast kernels (debug / A-B)     */
+  SC_PLAN_FFT_GEN2 = 2       /* fast path on the generation-2 fused kernels (A-B)           */
 };
 
 /* ---- plan ------------------------------------------------------------------------------ */

@@ -26,6 +26,8 @@
 #define SC_BID_Y ((int)blockIdx.y)
 #define SC_BID_Z ((int)blockIdx.z)
 #define SC_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+// second argument = minimum waves per SIMD the register allocator must leave room for
+#define SC_LAUNCH_BOUNDS_OCC(n, w) __launch_bounds__(n, w)
 // exchange through LDS between lanes of ONE wave: no s_barrier needed (a wave's DS operations
 // execute in order); drain the wave's own LDS queue and stop the compiler moving memory
 // operations across the point.
@@ -65,6 +67,7 @@ struct ThreadCtx {
 extern thread_local ThreadCtx g_ctx;
 extern unsigned char* g_dyn_shared;
 void barrier();
+void wave_barrier();
 // runs fn(arg) for every thread of every block; blocks sequentially, threads concurrently
 void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 }  // namespace scemu
@@ -79,7 +82,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_BID_Y (scemu::g_ctx.by)
 #define SC_BID_Z (scemu::g_ctx.bz)
 #define SC_LAUNCH_BOUNDS(n)
-#define SC_WAVE_SYNC() scemu::barrier()   /* emulated lanes are free-running threads */
+#define SC_LAUNCH_BOUNDS_OCC(n, w)
+#define SC_WAVE_SYNC() scemu::wave_barrier()   /* emulated lanes are free-running threads */
 #define SC_UNIFORM(x) (x)
 #define SC_SCHED_BARRIER() do { } while (0)
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)

@@ -16,6 +16,7 @@
 #include "sc_device.h"
 #include "sc_kernels_generic.h"
 #include "sc_kernels_fft.h"
+#include "sc_kernels_fft3.h"
 #include "sc_kernels_mfma.h"
 
 // ------------------------------------------------------------------------------------------
@@ -337,7 +338,11 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
   SC_CHECK_ARG(mode == SC_FWD_SCALED || mode == SC_FWD_ADJ_C2R, "bad forward mode");
   if (n_images <= 0) return 0;
   sc_stream_t st = (sc_stream_t)stream;
-  if (p->fast) return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
+  if (p->fast) {
+    if (p->d.flags & SC_PLAN_FFT_GEN2)
+      return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
+    return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
+  }
   const int L = p->nd - 1;
   int64_t lines = n_images;
   for (int d = 0; d < L; ++d) lines *= p->n[d];
@@ -371,9 +376,12 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
   if (n_images <= 0) return 0;
   if (channels <= 0) channels = 1;
   sc_stream_t st = (sc_stream_t)stream;
-  if (p->fast)
-    return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
-                         &g_last_error);
+  if (p->fast) {
+    if (p->d.flags & SC_PLAN_FFT_GEN2)
+      return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
+                           &g_last_error);
+    return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
+  }
   const int L = p->nd - 1;
   int64_t lpi = 1;
   for (int d = 0; d < L; ++d) lpi *= p->n[d];
@@ -669,6 +677,9 @@ extern "C" const char* sc_version(void) {
 
 extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   if (!p) return "";
-  if (p->fast) return fft2d_kernel_name(which);
+  if (p->fast) {
+    if (p->d.flags & SC_PLAN_FFT_GEN2) return fft2d_kernel_name(which);
+    return which == 0 ? "k_fft2d_fwd3" : "k_fft2d_inv3";
+  }
   return which == 0 ? "k_last_r2c" : "k_last_c2r";
 }

@@ -1,0 +1,512 @@
+// sc_kernels_fft3.h -- third generation of the fused, pruned 2-D FFT kernels (fast path).
+//
+// Same contract as sc_kernels_fft.h (one 256-thread workgroup per (b, c) image, W = 256,
+// H in {64,128,256,512}, kept block <= 64 x 33, nothing but the kept modes ever stored), but
+// re-cut for OCCUPANCY: measured on MI355X a single wave issues one VALU instruction every
+// ~7 cycles and a SIMD needs >= 4 resident waves to approach its issue rate
+// (profiles/r01_valu_issue_ubench.txt); generation 2 (16 points per lane, 194 VGPRs, 59 KB LDS)
+// ran 2 waves per SIMD and spent 42 % of its wave-cycles parked on s_waitcnt.  Here
+//
+//   * a 256-point row FFT is spread over 32 lanes x 8 points (two radix-8 passes in registers,
+//     one LDS transpose between them), the last, pruned radix-4 is a 4-term sum read back
+//     from LDS -> ~110 VGPRs, 4 waves per SIMD;
+//   * column FFTs (64 points) use 8 lanes x 8 points, so all 256 threads work in the column
+//     phase (generation 2 used 132 of 256);
+//   * twiddles that depend only on the lane live in registers for the whole kernel;
+//   * LDS: 18 KB row/column exchange + 18 KB group tile + <= 4 KB table  -> 4 workgroups per CU;
+//   * global traffic: every half-wave touches one aligned 128-byte line per instruction.
+//
+// Forward (R2C, pruned):   x[H][256] -> xhat[Mx][My]
+//   rows h = P b + a (P = H/64 groups a, b = 0..63); row pairs (2p, 2p+1) of a group are packed
+//   z = xA + i xB.  Z[k] for |k| <= 32 goes to the group tile T'[p][32 + k] WITHOUT unpacking;
+//   the column phase unpacks (A = (Z[k] + conj Z[-k])/2, B = (Z[k] - conj Z[-k])/2i) while it
+//   loads, runs 33 column FFTs of 64 points, multiplies by w_H^(a fx) and accumulates in
+//   registers over the groups.
+// Inverse (C2R, zero padded): the transpose of the above.
+#pragma once
+#include "sc_kernels_fft.h"
+
+#define SC_F3_XRS 36   // row stride (complex) of the row exchange [half-wave][k1][.]: conflict-free b64
+#define SC_F3_CCS 66   // column stride (complex) of the column exchange
+// group tile: forward T'[32 pairs][TRS] holds Z[-32..32] (65) + per group the pair's (Z[32], Z[-32])
+// stash for the deferred 33rd column; inverse T[64 rows][URS] holds 33 columns + per group the
+// precomputed 33rd column.  32 * TRS == 64 * URS.
+#define SC_F3_TRS(P) (66 + 2 * (P))
+#define SC_F3_URS(P) (33 + (P))
+
+template <int H>
+struct F3Lds {
+  static constexpr int xch_c = 8 * 8 * SC_F3_XRS;        // 2304 complex
+  static constexpr int cx_c = 33 * SC_F3_CCS;            // 2178 complex, aliases xch
+  static constexpr int P = H / 64;
+  static constexpr int TRS = SC_F3_TRS(P), URS = SC_F3_URS(P);
+  static constexpr int T_c = 32 * TRS;                   // 2368 complex at H = 256 (= 64 * URS)
+  static constexpr int tw64_c = 64;                      // w64^(mu q1), [mu][q1]
+  static constexpr int off_xch = 0;
+  static constexpr int off_T = off_xch + xch_c * 8;
+  static constexpr int off_twH = off_T + T_c * 8;
+  static constexpr int off_tw64 = off_twH + H * 8;
+  static constexpr int off_tw2 = off_tw64 + tw64_c * 8;   // [n4][k3] last-stage row twiddles (32)
+  static constexpr int off_c32 = off_tw2 + 32 * 8;        // 33rd column: accumulators / spectrum (64)
+  static constexpr int total = off_c32 + 64 * 8;
+  static_assert(cx_c <= xch_c, "column exchange aliases the row exchange");
+  static_assert(64 * URS <= T_c, "inverse tile fits");
+  static_assert((P + 1) * SC_F3_CCS + P * 64 <= xch_c, "deferred 33rd-column tasks fit in the exchange buffer");
+  static_assert(SC_F2D_KX * SC_F2D_KY <= T_c, "output tile aliases the group tile");
+  static_assert(total * (H <= 256 ? 4 : 3) <= 160 * 1024, "4 workgroups per CU (3 at H = 512)");
+};
+
+// 8-point DFT, natural order in and out: b[k] = sum_n a[n] w8^(nk), w8 = exp(DIR 2 pi i / 8)
+template <int DIR>
+SC_HD void dft8(const cf32 (&a)[8], cf32 (&b)[8]) {
+  cf32 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+  cf32 o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+  radix4<DIR>(e0, e1, e2, e3);
+  radix4<DIR>(o0, o1, o2, o3);
+  constexpr float r = 0.70710678118654752440f;
+  const cf32 t1 = DIR < 0 ? cf_make((o1.x + o1.y) * r, (o1.y - o1.x) * r)
+                          : cf_make((o1.x - o1.y) * r, (o1.y + o1.x) * r);
+  const cf32 t2 = rot90<DIR>(o2);
+  const cf32 t3 = DIR < 0 ? cf_make((o3.y - o3.x) * r, (-o3.x - o3.y) * r)
+                          : cf_make((-o3.x - o3.y) * r, (o3.x - o3.y) * r);
+  b[0] = cf_add(e0, o0);
+  b[4] = cf_sub(e0, o0);
+  b[1] = cf_add(e1, t1);
+  b[5] = cf_sub(e1, t1);
+  b[2] = cf_add(e2, t2);
+  b[6] = cf_sub(e2, t2);
+  b[3] = cf_add(e3, t3);
+  b[7] = cf_sub(e3, t3);
+}
+
+// a * i^n, n = 0..3 (lane dependent, used once at kernel start)
+SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
+  switch (n & 3) {
+    case 1: return cf_make(-a.y, a.x);
+    case 2: return cf_make(-a.x, -a.y);
+    case 3: return cf_make(a.y, -a.x);
+    default: return a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+#ifndef SC_F3_FWD_OCC
+#define SC_F3_FWD_OCC 3
+#endif
+template <int H>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? SC_F3_FWD_OCC : 3))
+k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
+             const cf32* __restrict__ tabH, int Mx, int My, float s_dc, float s_other) {
+  constexpr int P = H / 64;
+  typedef F3Lds<H> L;
+  SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
+  cf32* xch = reinterpret_cast<cf32*>(smem + L::off_xch);
+  cf32* T = reinterpret_cast<cf32*>(smem + L::off_T);
+  cf32* twH = reinterpret_cast<cf32*>(smem + L::off_twH);
+  cf32* tw64 = reinterpret_cast<cf32*>(smem + L::off_tw64);
+  cf32* tw2t = reinterpret_cast<cf32*>(smem + L::off_tw2);
+
+  const int tid = SC_TID;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int lane = tid & 63, hs = lane >> 5, lam = lane & 31;
+  const int hw = w * 2 + hs;                           // half-wave = row-pair slot of a round
+  const int64_t img = SC_BID_X;
+  const float* xi = x + img * (int64_t)H * SC_F2D_W;
+
+  for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
+  if (tid < 64) {
+    tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];   // w64^(mu q1)
+  }
+  if (tid < 32) {
+    // [n4][k3]: w32^(n4 k3), times i^n4 for k3 >= 4 (the k4 = 3 terms); slot [n4][0] = w32^(4 n4) (k = +32)
+    const int tn = tid >> 3, tk = tid & 7;
+    const cf32 t = tabW[(8 * tn * (tk == 0 ? 4 : tk)) & 255];
+    tw2t[tid] = (tk >= 4) ? cf_rot_i(t, tn) : t;
+  }
+
+  // ---- row phase roles and per-lane twiddles
+  const int k1l = lam >> 2, n4 = lam & 3;             // after the transpose: lane = (k1, n4)
+  cf32 tw1[8];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) tw1[k] = tabW[(lam * k) & 255];               // w256^(n2 k1)
+  const cf32* tw2 = tw2t + n4 * 8;                                          // LDS: keeps 16 VGPRs free
+  cf32* xb = xch + hw * 8 * SC_F3_XRS;
+
+  // ---- column phase roles: wave w owns columns 8 w .. 8 w + 7, 8 lanes per column
+  const int cl = lane >> 3, mu = lane & 7;
+  cf32 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = cf_make(0.f, 0.f);
+
+  // one column task for group a (lane = (column slot, mu)): rows b = 8 b1 + mu, pair p = 4 b1 + (mu >> 1),
+  // member mu & 1, unpacked while loading (zk -> Z_p[k], zm -> Z_p[-k], both with pair stride TRS);
+  // cb = the column's private exchange patch; result F_a[q1 + 8 q2] * w_H^(a fx) goes to acc (+=)
+  // or, for the deferred 33rd column, to dst[q]
+  auto column = [&](const cf32* zk0, const cf32* zm0, cf32* cb, const int a, auto extra_tag, cf32* dst, const bool act) {
+    constexpr bool EXTRA = decltype(extra_tag)::value != 0;
+    const float sg = (mu & 1) ? -1.f : 1.f;
+    cf32 v[8], o[8];
+#pragma unroll
+    for (int b1 = 0; b1 < 8; ++b1) {
+      const cf32 zk = zk0[(4 * b1 + (mu >> 1)) * L::TRS];
+      const cf32 zm = zm0[(4 * b1 + (mu >> 1)) * L::TRS];
+      // member 0: A = (Z[k] + conj Z[-k]) / 2;  member 1: B = -i (Z[k] - conj Z[-k]) / 2
+      const cf32 sres = cf_make(0.5f * (zk.x + sg * zm.x), 0.5f * (zk.y - sg * zm.y));
+      v[b1] = (mu & 1) ? cf_make(sres.y, -sres.x) : sres;
+    }
+    dft8<-1>(v, o);                                      // over b1 -> q1
+#pragma unroll
+    for (int q1 = 0; q1 < 8; ++q1) {
+      const cf32 y = (q1 == 0) ? o[0] : cf_mul(o[q1], tw64[mu * 8 + q1]);
+      if (act) cb[q1 * 8 + mu] = y;
+    }
+    SC_WAVE_SYNC();                                      // the 8 lanes of a column share a wave
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = cb[mu * 8 + m];   // lane mu now plays q1 = mu
+    dft8<-1>(v, o);                                      // over mu -> q2 : F_a[q1 + 8 q2]
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) {
+      const int fx = f2d_fx(mu + 8 * q2);
+      int idx = (a * fx) % H;
+      if (idx < 0) idx += H;
+      if (EXTRA) {
+        if (act) dst[mu + 8 * q2] = cf_mul(twH[idx], o[q2]);
+      } else {
+        cf_mac(acc[q2], twH[idx], o[q2]);
+      }
+    }
+    SC_WAVE_SYNC();                                      // cb is rewritten by the next task
+  };
+
+  SC_SYNC();
+
+  // software prefetch, two rounds deep: a round of this kernel is short (~1 us), shorter than the
+  // loaded HBM latency, so the values of round t + 2 are requested while round t is transformed
+  // (two register sets, rounds alternate between them)
+  cf32 pz[2][8];                                         // .x = row A, .y = row B of the pair
+  auto prefetch = [&](const int t, cf32 (&q)[8]) {        // t = 4 a + r
+    if (t < 4 * P) {
+      const int a = t >> 2, p = (t & 3) * 8 + hw;
+      const float* ra = xi + (int64_t)(P * (2 * p) + a) * SC_F2D_W + lam;
+      const float* rb = ra + P * SC_F2D_W;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#ifdef SC_F3_ABL_NOLOAD
+        q[j] = cf_make((float)(lam + j + t), (float)(lam - j));
+#else
+        q[j].x = ra[32 * j];
+        q[j].y = rb[32 * j];
+#endif
+      }
+    }
+  };
+  prefetch(0, pz[0]);
+  prefetch(1, pz[1]);
+
+#pragma unroll 1
+  for (int a = 0; a < P; ++a) {
+    // ---------------- rows of group a -> T'[p][32 + k], 4 rounds of 8 row pairs ----------------
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = r * 8 + hw;
+      cf32 v[8], o[8];
+      dft8<-1>(pz[r & 1], o);                            // over n1 (n = 32 n1 + lam) -> k1
+      prefetch(4 * a + r + 2, pz[r & 1]);                // refill the consumed register set
+#ifdef SC_F3_ABL_NOROW
+      if (o[0].x == 1234.5f) T[tid] = o[1];
+      continue;
+#endif
+#pragma unroll
+      for (int k1 = 0; k1 < 8; ++k1) xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul(o[k1], tw1[k1]);
+      SC_WAVE_SYNC();
+#pragma unroll
+      for (int n3 = 0; n3 < 8; ++n3) v[n3] = xb[k1l * SC_F3_XRS + 4 * n3 + n4];
+      SC_WAVE_SYNC();
+      dft8<-1>(v, o);                                    // over n3 (n2 = 4 n3 + n4) -> k3
+      // last stage (over n4, k = k1 + 8 k3 + 64 k4) is pruned to one k4 per (k1, k3): k4 = 0 for
+      // k3 < 4 (k = 0..31), k4 = 3 for k3 >= 4 (k = -32..-1), plus k = +32 (k1 = 0, k3 = 4, k4 = 0):
+      // write the twiddled terms, the consumer lane adds the four n4 contributions
+#pragma unroll
+      for (int k3 = 0; k3 < 8; ++k3)
+        xb[k1l * SC_F3_XRS + 4 * k3 + n4] = (k3 == 0) ? o[0] : cf_mul(o[k3], tw2[k3]);
+      if (k1l == 0) xb[32 + n4] = cf_mul(o[4], tw2[0]);                 // pad slots [0][32..35]
+      SC_WAVE_SYNC();
+      {
+        // lane j: positive k = j  (k1 = j & 7, k3 = j >> 3), negative f = j - 32 (k3 + 4)
+        const cf32* pp = xb + (lam & 7) * SC_F3_XRS + 4 * (lam >> 3);
+        const cf32 zp = cf_add(cf_add(pp[0], pp[1]), cf_add(pp[2], pp[3]));
+        const cf32 zn = cf_add(cf_add(pp[16], pp[17]), cf_add(pp[18], pp[19]));
+        cf32* tr = T + p * L::TRS;
+        tr[32 + lam] = zp;
+        tr[lam] = zn;
+        if (lam == 0) {                                  // column 32 is transformed after the group loop
+          const cf32* px = xb + 32;
+          tr[65 + 2 * a] = cf_add(cf_add(px[0], px[1]), cf_add(px[2], px[3]));   // Z[+32]
+          tr[66 + 2 * a] = zn;                                                     // Z[-32]
+        }
+      }
+      SC_WAVE_SYNC();                                   // xb is rewritten by the next round
+    }
+    SC_SYNC();
+    // ---------------- 33 column FFTs of 64 points on T' ----------------
+#ifndef SC_F3_ABL_NOCOL
+    column(T + 32 + (8 * w + cl), T + 32 - (8 * w + cl), xch + (8 * w + cl) * SC_F3_CCS, a, sc_int<0>(), nullptr, true);
+#endif
+    SC_SYNC();
+  }
+  // ---------------- 33rd column (k = 32): one 8-lane task per group, all groups at once ----------
+  cf32* part = xch + (P + 1) * SC_F3_CCS;                // [P][64] partial spectra, summed below
+#ifndef SC_F3_ABL_NOCOL32
+  if (My > 32) {
+    constexpr int ABLK = (P + 3) / 4;                    // lane blocks (of 8) per wave that carry a task
+    const int a = ((cl % ABLK) << 2) | w;                // wave w, lane block cl -> group a
+    const int ac = a < P ? a : 0;
+    column(T + 65 + 2 * ac, T + 66 + 2 * ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), part + ac * 64,
+           cl < ABLK && a < P);
+  }
+#endif
+  SC_SYNC();
+  // ---------------- kept block -> LDS -> one contiguous store ----------------
+  cf32* OUT = T;
+  {
+    const int c = 8 * w + cl;
+    if (c < My) {
+      const float s = (c == 0) ? s_dc : s_other;
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int row = f2d_fx(mu + 8 * q2) + Mx / 2;
+        if (row >= 0 && row < Mx) OUT[row * My + c] = cf_scale(acc[q2], s);
+      }
+    }
+    if (tid < 64 && 32 < My) {
+      const int row = f2d_fx(tid) + Mx / 2;
+      cf32 t = part[tid];
+#pragma unroll
+      for (int a = 1; a < P; ++a) t = cf_add(t, part[a * 64 + tid]);
+      if (row >= 0 && row < Mx) OUT[row * My + 32] = cf_scale(t, s_other);
+    }
+  }
+  SC_SYNC();
+  cf32* dst = xhat + img * (int64_t)Mx * My;
+  for (int i = tid; i < Mx * My; i += 256) dst[i] = OUT[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse
+// ------------------------------------------------------------------------------------------
+template <int H>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? 4 : 3))
+k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* __restrict__ bias,
+             int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
+             float s_dc, float s_other) {
+  constexpr int P = H / 64;
+  typedef F3Lds<H> L;
+  SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
+  cf32* xch = reinterpret_cast<cf32*>(smem + L::off_xch);
+  cf32* T = reinterpret_cast<cf32*>(smem + L::off_T);
+  cf32* twH = reinterpret_cast<cf32*>(smem + L::off_twH);
+  cf32* tw64 = reinterpret_cast<cf32*>(smem + L::off_tw64);
+  cf32* tw2t = reinterpret_cast<cf32*>(smem + L::off_tw2);
+  cf32* y32 = reinterpret_cast<cf32*>(smem + L::off_c32);
+
+  const int tid = SC_TID;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int lane = tid & 63, hs = lane >> 5, lam = lane & 31;
+  const int hw = w * 2 + hs;
+  const int64_t img = SC_BID_X;
+  float* yo = y + img * (int64_t)H * SC_F2D_W;
+  const cf32* src = yhat + img * (int64_t)Mx * My;
+
+  for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
+  if (tid < 64) tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];
+  if (tid < 32) {
+    // conjugates of the forward table: [n4][k3] = conj(w32^(n4 k3) i^(n4 [k3 >= 4])), [n4][0] = conj(w32^(4 n4))
+    const int tn = tid >> 3, tk = tid & 7;
+    const cf32 t = tabW[(8 * tn * (tk == 0 ? 4 : tk)) & 255];
+    tw2t[tid] = cf_conj((tk >= 4) ? cf_rot_i(t, tn) : t);
+  }
+  cf32* IN = T;
+  for (int i = tid; i < Mx * My; i += 256) IN[i] = src[i];
+  const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
+
+  const int k1l = lam >> 2, n4 = lam & 3;
+  cf32 tw1c[8];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) tw1c[k] = cf_conj(tabW[(lam * k) & 255]);
+  const cf32* tw2c = tw2t + n4 * 8;
+  cf32* xb = xch + hw * 8 * SC_F3_XRS;
+
+  const int cl = lane >> 3, mu = lane & 7;
+  SC_SYNC();
+  // this lane's spectrum column entries: q = mu + 8 q2  (fx = q or q - 64), scaled once
+  cf32 yh[8];
+  {
+    const int c = 8 * w + cl;
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) {
+      const int row = f2d_fx(mu + 8 * q2) + Mx / 2;
+      const bool ok = row >= 0 && row < Mx;
+      yh[q2] = (ok && c < My) ? cf_scale(IN[row * My + c], (c == 0) ? s_dc : s_other) : cf_make(0.f, 0.f);
+    }
+    if (tid < 64) {                                      // 33rd column parked in LDS, indexed by q
+      const int row = f2d_fx(tid) + Mx / 2;
+      y32[tid] = (row >= 0 && row < Mx && 32 < My) ? cf_scale(IN[row * My + 32], s_other) : cf_make(0.f, 0.f);
+    }
+  }
+  SC_SYNC();
+
+  // one inverse column task of group a: spectrum column (yh regs or the parked 33rd column) ->
+  // 64 rows, written to T[b][cdst]; cb = the task's private exchange patch
+  auto column = [&](const int cdst, cf32* cb, const int a, auto extra_tag, const bool act) {
+    constexpr bool EXTRA = decltype(extra_tag)::value != 0;
+    cf32 v[8], o[8];
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) {
+      const int fx = f2d_fx(mu + 8 * q2);
+      int idx = (a * fx) % H;
+      if (idx < 0) idx += H;
+      v[q2] = cf_mul(EXTRA ? y32[mu + 8 * q2] : yh[q2], cf_conj(twH[idx]));
+    }
+    dft8<+1>(v, o);                                      // over q2 -> m (row b = m + 8 b1)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const cf32 val = (m == 0) ? o[0] : cf_mul(o[m], cf_conj(tw64[m * 8 + mu]));
+      if (act) cb[m * 8 + mu] = val;
+    }
+    SC_WAVE_SYNC();
+#pragma unroll
+    for (int q1 = 0; q1 < 8; ++q1) v[q1] = cb[mu * 8 + q1];   // lane mu now plays m = mu
+    dft8<+1>(v, o);                                      // over q1 -> b1
+    if (act) {
+#pragma unroll
+      for (int b1 = 0; b1 < 8; ++b1) T[(mu + 8 * b1) * L::URS + cdst] = o[b1];
+    }
+    SC_WAVE_SYNC();
+  };
+
+  // 33rd column (k = 32) of every group up front, one 8-lane task per group, parked in the tile's
+  // spare columns 33 + a (the regular column tasks only write columns 0..31)
+  if (My > 32) {
+    constexpr int ABLK = (P + 3) / 4;
+    const int a = ((cl % ABLK) << 2) | w;
+    const int ac = a < P ? a : 0;
+    column(33 + ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), cl < ABLK && a < P);
+  } else if (tid < 64) {
+#pragma unroll
+    for (int a = 0; a < P; ++a) T[tid * L::URS + 33 + a] = cf_make(0.f, 0.f);
+  }
+  SC_SYNC();
+
+#pragma unroll 1
+  for (int a = 0; a < P; ++a) {
+    // ---------------- 32 inverse column FFTs (64 points) -> T[b][c], rows h = P b + a ------------
+    column(8 * w + cl, xch + (8 * w + cl) * SC_F3_CCS, a, sc_int<0>(), true);
+    SC_SYNC();
+    // ---------------- rows: Hermitian-extended, zero-padded C2R of packed row pairs ---------------
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int p = r * 8 + hw;
+      {
+        // lane j builds Z[j] (k1 = j & 7, k3 = j >> 3) and Z[j - 32] (k3 + 4); lane 0 also Z[+32]
+        const cf32* ta = T + (2 * p) * L::URS;
+        const cf32* tb = ta + L::URS;
+        const cf32 ua = ta[lam], ub = tb[lam];
+        const int cm = (lam == 0) ? 33 + a : 32 - lam;   // column 32 lives in the group's spare column
+        const cf32 va = ta[cm], vb = tb[cm];
+        const cf32 zp = (lam == 0) ? cf_make(ua.x + badd, ub.x + badd) : cf_add_i(ua, ub);
+        const cf32 zn = cf_conj_add_i(va, vb);
+        cf32* zr = xb + (lam & 7) * SC_F3_XRS + (lam >> 3);
+        zr[0] = zp;
+        zr[4] = zn;
+        if (lam < 8) zr[8] = (lam == 0) ? cf_add_i(va, vb) : cf_make(0.f, 0.f);
+      }
+      SC_WAVE_SYNC();
+      cf32 v[8], o[8];
+      {
+        const cf32* zr = xb + k1l * SC_F3_XRS;
+        cf32 xk[9];
+#pragma unroll
+        for (int k3 = 0; k3 < 9; ++k3) xk[k3] = zr[k3];
+        v[0] = xk[0];
+#pragma unroll
+        for (int k3 = 1; k3 < 8; ++k3) v[k3] = cf_mul(xk[k3], tw2c[k3]);
+        cf_mac(v[4], xk[8], tw2c[0]);
+      }
+      SC_WAVE_SYNC();
+      dft8<+1>(v, o);                                    // over k3 -> n3
+#pragma unroll
+      for (int n3 = 0; n3 < 8; ++n3) xb[k1l * SC_F3_XRS + 4 * n3 + n4] = o[n3];
+      SC_WAVE_SYNC();
+#pragma unroll
+      for (int k1 = 0; k1 < 8; ++k1) {
+        const cf32 t = xb[k1 * SC_F3_XRS + lam];
+        v[k1] = (k1 == 0) ? t : cf_mul(t, tw1c[k1]);
+      }
+      SC_WAVE_SYNC();                                   // xb is rewritten by the next round
+      dft8<+1>(v, o);                                    // over k1 -> n1 : z[32 n1 + lam]
+      float* ra = yo + (int64_t)(P * (2 * p) + a) * SC_F2D_W + lam;
+      float* rb = yo + (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W + lam;
+#pragma unroll
+      for (int n1 = 0; n1 < 8; ++n1) {
+        ra[32 * n1] = o[n1].x;
+        rb[32 * n1] = o[n1].y;
+      }
+    }
+    SC_SYNC();                                          // T is rewritten by the next group
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <int H>
+static void fft3_launch_fwd(const Fft2dPlan* fp, const float* x, cf32* xhat, int64_t n_images, float s_dc,
+                            float s_other, sc_stream_t st) {
+  SC_LAUNCH((k_fft2d_fwd3<H>), dim3((unsigned)n_images), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
+            (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
+}
+
+template <int H>
+static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, float* y, const float* bias, int channels,
+                            int64_t n_images, float s_dc, float s_other, sc_stream_t st) {
+  SC_LAUNCH((k_fft2d_inv3<H>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels,
+            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
+}
+
+static inline int fft3_forward(const Fft2dPlan* fp, int mode, const float* x, cf32* xhat, int64_t n_images,
+                               sc_stream_t st, std::string* err) {
+  const float s_dc = (mode == 0) ? fp->sf : fp->si;
+  const float s_other = (mode == 0) ? fp->sf : 2.f * fp->si;
+  switch (fp->H) {
+    case 64: fft3_launch_fwd<64>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 128: fft3_launch_fwd<128>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 256: fft3_launch_fwd<256>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 512: fft3_launch_fwd<512>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    default: *err = "sc_engine: fft2d: unsupported H"; return 1;
+  }
+  if (hipGetLastError() != hipSuccess) {
+    *err = "sc_engine: launch of k_fft2d_fwd3 failed";
+    return 1;
+  }
+  return 0;
+}
+
+static inline int fft3_inverse(const Fft2dPlan* fp, int mode, const cf32* yhat, const float* bias,
+                               int64_t channels, float* y, int64_t n_images, sc_stream_t st, std::string* err) {
+  const float s_dc = (mode == 0) ? fp->si : fp->sf;
+  const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
+  switch (fp->H) {
+    case 64: fft3_launch_inv<64>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 128: fft3_launch_inv<128>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 256: fft3_launch_inv<256>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 512: fft3_launch_inv<512>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    default: *err = "sc_engine: fft2d: unsupported H"; return 1;
+  }
+  if (hipGetLastError() != hipSuccess) {
+    *err = "sc_engine: launch of k_fft2d_inv3 failed";
+    return 1;
+  }
+  return 0;
+}

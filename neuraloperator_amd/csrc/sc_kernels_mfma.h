@@ -62,14 +62,14 @@ inline void sc_mfma_32x32x2(sc_f32x16& acc, const float a, const float b) {
   const int w = SC_TID >> 6, l = SC_TID & 63;
   scemu::g_mfma_a[w][l] = a;
   scemu::g_mfma_b[w][l] = b;
-  scemu::barrier();
+  scemu::wave_barrier();
   for (int v = 0; v < 16; ++v) {
     const int row = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5), col = l & 31;
     float c = acc[v];
     for (int k = 0; k < 2; ++k) c = fmaf(scemu::g_mfma_a[w][row + 32 * k], scemu::g_mfma_b[w][col + 32 * k], c);
     acc[v] = c;
   }
-  scemu::barrier();
+  scemu::wave_barrier();
 }
 inline float sc_xor_sign(const float v, const uint32_t mask) {
   uint32_t u;

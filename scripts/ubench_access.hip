@@ -132,6 +132,36 @@ __global__ void __launch_bounds__(256) rd_float2_seg128(const float* __restrict_
   if (acc == 12345.678f) { dummy[tid] = acc; out[blockIdx.x] = dummy[(tid + 1) & 255]; }
 }
 
+// the generation-3 forward kernel's load stream, no arithmetic: half-wave = one row pair, lane reads
+// x[row][32 j + lam], rows h = 4 b + a (DIT over H) or h = 64 a + b (CONSEC), DEPTH rounds in flight
+template <int DEPTH, bool CONSEC, int LDSB>
+__global__ void __launch_bounds__(256) rd_gen3(const float* __restrict__ x, float* __restrict__ out) {
+  __shared__ float dummy[LDSB / 4 + 1];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hs = lane >> 5, lam = lane & 31, hw = w * 2 + hs;
+  const float* xi = x + (size_t)blockIdx.x * H * W;
+  float acc = 0.f;
+  float v[DEPTH][16];
+  auto issue = [&](int t, float (&q)[16]) {
+    if (t < 16) {
+      const int a = t >> 2, p = (t & 3) * 8 + hw;
+      const int ha = CONSEC ? 64 * a + 2 * p : 4 * (2 * p) + a, hb = CONSEC ? ha + 1 : 4 * (2 * p + 1) + a;
+      const float* ra = xi + (size_t)ha * W + lam;
+      const float* rb = xi + (size_t)hb * W + lam;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { q[j] = ra[32 * j]; q[8 + j] = rb[32 * j]; }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(d, v[d]);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += v[t % DEPTH][j];
+    issue(t + DEPTH, v[t % DEPTH]);
+  }
+  if (acc == 12345.678f) { dummy[tid] = acc; out[blockIdx.x] = dummy[(tid + 1) & 255]; }
+}
+
 template <class F>
 float timeit(F launch, int iters = 20) {
   hipEvent_t e0, e1;
@@ -149,7 +179,7 @@ int main() {
   const size_t n = (size_t)NIMG * H * W;
   float *x, *y, *o;
   CHECK(hipMalloc(&x, n * 4)); CHECK(hipMalloc(&y, n * 4)); CHECK(hipMalloc(&o, NIMG * 4));
-  CHECK(hipMemset(x, 0, n * 4));
+  CHECK(hipMemset(x, 1, n * 4));
   const double gb = n * 4 / 1e9;
   float t;
   t = timeit([&] { rd_dword_seg64<<<NIMG, 256>>>(x, o); });  printf("rd_dword_seg64 : %7.1f us  %7.1f GB/s\n", t * 1e3, gb / (t * 1e-3));
@@ -170,6 +200,11 @@ int main() {
   RUN("rd_rows<16,36000> grid 1024 persistent", (rd_rows<16, 36000><<<1024, 256>>>(x, o, NIMG)), gb)
   RUN("rd_float2_seg128<60000> grid 2048", (rd_float2_seg128<60000><<<2048, 256>>>(x, o, NIMG)), gb)
   RUN("rd_float2_seg128<36000> grid 2048", (rd_float2_seg128<36000><<<2048, 256>>>(x, o, NIMG)), gb)
+  RUN("rd_gen3<1,DIT,40000> (4 WG/CU)", (rd_gen3<1, false, 40000><<<2048, 256>>>(x, o)), gb)
+  RUN("rd_gen3<2,DIT,40000> (4 WG/CU)", (rd_gen3<2, false, 40000><<<2048, 256>>>(x, o)), gb)
+  RUN("rd_gen3<2,DIT,53000> (3 WG/CU)", (rd_gen3<2, false, 53000><<<2048, 256>>>(x, o)), gb)
+  RUN("rd_gen3<1,CONSEC,40000> (4 WG/CU)", (rd_gen3<1, true, 40000><<<2048, 256>>>(x, o)), gb)
+  RUN("rd_gen3<2,CONSEC,40000> (4 WG/CU)", (rd_gen3<2, true, 40000><<<2048, 256>>>(x, o)), gb)
   RUN("wr_rows<8,0>  grid 2048", (wr_rows<8, 0><<<2048, 256>>>(y, NIMG)), gb)
   RUN("wr_rows<16,60000> grid 2048 (2 WG/CU)", (wr_rows<16, 60000><<<2048, 256>>>(y, NIMG)), gb)
   RUN("wr_rows<16,60000> grid 512 persistent", (wr_rows<16, 60000><<<512, 256>>>(y, NIMG)), gb)

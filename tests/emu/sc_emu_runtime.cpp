@@ -16,8 +16,12 @@ thread_local ThreadCtx g_ctx;
 unsigned char* g_dyn_shared = nullptr;
 
 static pthread_barrier_t g_barrier;
+static std::vector<pthread_barrier_t> g_wave_barriers;   // one per 64 consecutive threads
 
 void barrier() { pthread_barrier_wait(&g_barrier); }
+// wave-level rendezvous: the product's SC_WAVE_SYNC / MFMA only couple the 64 lanes of one wave,
+// so code that diverges BETWEEN waves (e.g. one wave doing an extra task) must not deadlock here
+void wave_barrier() { pthread_barrier_wait(&g_wave_barriers[(size_t)g_ctx.tid >> 6]); }
 
 struct Job {
   dim3 grid;
@@ -48,6 +52,12 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg) {
   std::vector<unsigned char> dyn(shmem + 64);
   g_dyn_shared = dyn.data();
   pthread_barrier_init(&g_barrier, nullptr, nt);
+  const unsigned nw = (nt + 63) / 64;
+  g_wave_barriers.resize(nw);
+  for (unsigned i = 0; i < nw; ++i) {
+    const unsigned cnt = (i + 1 < nw || nt % 64 == 0) ? 64 : nt % 64;
+    pthread_barrier_init(&g_wave_barriers[i], nullptr, cnt);
+  }
   std::vector<pthread_t> th(nt);
   std::vector<Job> jobs(nt);
   pthread_attr_t attr;
@@ -63,6 +73,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg) {
   for (unsigned t = 0; t < nt; ++t) pthread_join(th[t], nullptr);
   pthread_attr_destroy(&attr);
   pthread_barrier_destroy(&g_barrier);
+  for (auto& b : g_wave_barriers) pthread_barrier_destroy(&b);
+  g_wave_barriers.clear();
   g_dyn_shared = nullptr;
 }
 }  // namespace scemu

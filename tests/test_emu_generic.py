@@ -46,8 +46,9 @@ FAST_CASES = [
 ]
 
 
+@pytest.mark.parametrize("gen", [3, 2], ids=["gen3", "gen2"])
 @pytest.mark.parametrize("case", FAST_CASES, ids=lambda c: f"H{c[3]}_m{c[4][0]}x{c[4][1]}")
-def test_fused_fft_path_matches_oracle(lib, case):
+def test_fused_fft_path_matches_oracle(lib, case, gen):
     from oracle import spectral_oracle as so
     from neuraloperator_amd.modes import halve_last_mode, kept_block
 
@@ -55,9 +56,10 @@ def test_fused_fft_path_matches_oracle(lib, case):
     torch.manual_seed(11)
     nm = halve_last_mode(modes)
     kept, _ = kept_block([H, 256], nm, nm)
-    plan = lib.plan_create([H, 256], kept)
+    flags = _lib.SC_PLAN_FFT_GEN2 if gen == 2 else 0
+    plan = lib.plan_create([H, 256], kept, flags=flags)
     assert lib.plan_is_fast(plan)
-    assert lib.plan_kernel_name(plan, 0) == "k_fft2d_fwd"
+    assert lib.plan_kernel_name(plan, 0) == ("k_fft2d_fwd" if gen == 2 else "k_fft2d_fwd3")
     lib.plan_destroy(plan)
     x = torch.randn(b, ci, H, 256)
     w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.5)
@@ -66,7 +68,7 @@ def test_fused_fft_path_matches_oracle(lib, case):
     xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     yo = so.forward_torch(xc, wc, bc, nm, nm)
     yo.backward(g)
-    y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
+    y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=flags)
     assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
     assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
