@@ -40,6 +40,11 @@
 #define SC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // the instruction scheduler may not move anything across this point
 #define SC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// streaming (non-temporal) access to the 0.5 GB real tensors: a plain store leaves up to 256 MB of
+// dirty Infinity-Cache lines whose write-back the NEXT kernel pays for (+57 us on a 537 MB reader,
+// profiles/r01_writeback_ubench.txt); nt stores drain to HBM while the producing kernel computes
+#define SC_STORE_STREAM(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define SC_LOAD_STREAM(ptr) __builtin_nontemporal_load(ptr)
 #define SC_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
   type* name = reinterpret_cast<type*>(name##_raw)
 
@@ -86,6 +91,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_WAVE_SYNC() scemu::wave_barrier()   /* emulated lanes are free-running threads */
 #define SC_UNIFORM(x) (x)
 #define SC_SCHED_BARRIER() do { } while (0)
+#define SC_STORE_STREAM(ptr, val) (*(ptr) = (val))
+#define SC_LOAD_STREAM(ptr) (*(ptr))
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)
 
 typedef void* sc_stream_t;
@@ -143,6 +150,49 @@ SC_HD void cf_mac_conj_a(cf32& acc, const cf32 a, const cf32 b) {
 }
 SC_HD cf32 cf_mul(const cf32 a, const cf32 b) {
   return cf_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// complex product on the packed-fp32 pipe: v_pk_mul_f32 + v_pk_fma_f32 (+ one v_xor for the sign
+// unless the caller keeps the twiddle pre-arranged as (c, -s, s), see cf_mul_tw).  The plain struct
+// formula compiles to 4-5 VALU instructions (pk_mul, 2 pk_fma, moves).
+#ifndef SC_EMU
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
+SC_DEVICE cf32 cf_mul_pk(const cf32 a, const cf32 b) {
+  const sc_f2 av = {a.x, a.y}, ayx = {a.y, a.x}, bxx = {b.x, b.x}, nb = {-b.y, b.y};
+  const sc_f2 r = __builtin_elementwise_fma(ayx, nb, av * bxx);
+  return cf_make(r.x, r.y);
+}
+// twiddle c + i s held as (c, ns = -s, s)
+SC_DEVICE cf32 cf_mul_tw(const cf32 a, const float c, const float ns, const float s) {
+  const sc_f2 av = {a.x, a.y}, ayx = {a.y, a.x}, cc = {c, c}, nb = {ns, s};
+  const sc_f2 r = __builtin_elementwise_fma(ayx, nb, av * cc);
+  return cf_make(r.x, r.y);
+}
+#else
+inline cf32 cf_mul_pk(const cf32 a, const cf32 b) { return cf_make(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+inline cf32 cf_mul_tw(const cf32 a, const float c, const float ns, const float s) {
+  return cf_make(a.x * c + a.y * ns, a.y * c + a.x * s);
+}
+#endif
+struct ctw3 {   // register-resident twiddle
+  float c, ns, s;
+};
+struct ctw4 {   // LDS-resident twiddle, one 16-byte read
+  float c, pad, ns, s;
+};
+SC_HD ctw3 ctw3_make(const cf32 t) {
+  ctw3 r;
+  r.c = t.x;
+  r.ns = -t.y;
+  r.s = t.y;
+  return r;
+}
+SC_HD ctw4 ctw4_make(const cf32 t) {
+  ctw4 r;
+  r.c = t.x;
+  r.pad = t.x;
+  r.ns = -t.y;
+  r.s = t.y;
+  return r;
 }
 SC_HD cf32 cf_add(const cf32 a, const cf32 b) { return cf_make(a.x + b.x, a.y + b.y); }
 SC_HD cf32 cf_sub(const cf32 a, const cf32 b) { return cf_make(a.x - b.x, a.y - b.y); }

@@ -47,7 +47,7 @@ struct F3Lds {
   static constexpr int off_twH = off_T + T_c * 8;
   static constexpr int off_tw64 = off_twH + H * 8;
   static constexpr int off_tw2 = off_tw64 + tw64_c * 8;   // [n4][k3] last-stage row twiddles (32)
-  static constexpr int off_c32 = off_tw2 + 32 * 8;        // 33rd column: accumulators / spectrum (64)
+  static constexpr int off_c32 = off_tw2 + 32 * 16;       // 33rd column spectrum of the inverse (64)
   static constexpr int total = off_c32 + 64 * 8;
   static_assert(cx_c <= xch_c, "column exchange aliases the row exchange");
   static_assert(64 * URS <= T_c, "inverse tile fits");
@@ -106,7 +106,7 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
   cf32* T = reinterpret_cast<cf32*>(smem + L::off_T);
   cf32* twH = reinterpret_cast<cf32*>(smem + L::off_twH);
   cf32* tw64 = reinterpret_cast<cf32*>(smem + L::off_tw64);
-  cf32* tw2t = reinterpret_cast<cf32*>(smem + L::off_tw2);
+  ctw4* tw2t = reinterpret_cast<ctw4*>(smem + L::off_tw2);
 
   const int tid = SC_TID;
   const int w = SC_UNIFORM(tid >> 6);
@@ -120,18 +120,18 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
     tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];   // w64^(mu q1)
   }
   if (tid < 32) {
-    // [n4][k3]: w32^(n4 k3), times i^n4 for k3 >= 4 (the k4 = 3 terms); slot [n4][0] = w32^(4 n4) (k = +32)
-    const int tn = tid >> 3, tk = tid & 7;
+    // [k3][n4]: w32^(n4 k3), times i^n4 for k3 >= 4 (the k4 = 3 terms); slot [0][n4] = w32^(4 n4) (k = +32)
+    const int tn = tid & 3, tk = tid >> 2;
     const cf32 t = tabW[(8 * tn * (tk == 0 ? 4 : tk)) & 255];
-    tw2t[tid] = (tk >= 4) ? cf_rot_i(t, tn) : t;
+    tw2t[tid] = ctw4_make((tk >= 4) ? cf_rot_i(t, tn) : t);
   }
 
   // ---- row phase roles and per-lane twiddles
   const int k1l = lam >> 2, n4 = lam & 3;             // after the transpose: lane = (k1, n4)
-  cf32 tw1[8];
+  ctw3 tw1[8];
 #pragma unroll
-  for (int k = 1; k < 8; ++k) tw1[k] = tabW[(lam * k) & 255];               // w256^(n2 k1)
-  const cf32* tw2 = tw2t + n4 * 8;                                          // LDS: keeps 16 VGPRs free
+  for (int k = 1; k < 8; ++k) tw1[k] = ctw3_make(tabW[(lam * k) & 255]);    // w256^(n2 k1)
+  const ctw4* tw2 = tw2t + n4;                           // LDS table [k3][n4]: four adjacent 16-B slots per read
   cf32* xb = xch + hw * 8 * SC_F3_XRS;
 
   // ---- column phase roles: wave w owns columns 8 w .. 8 w + 7, 8 lanes per column
@@ -159,7 +159,7 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
     dft8<-1>(v, o);                                      // over b1 -> q1
 #pragma unroll
     for (int q1 = 0; q1 < 8; ++q1) {
-      const cf32 y = (q1 == 0) ? o[0] : cf_mul(o[q1], tw64[mu * 8 + q1]);
+      const cf32 y = (q1 == 0) ? o[0] : cf_mul_pk(o[q1], tw64[mu * 8 + q1]);
       if (act) cb[q1 * 8 + mu] = y;
     }
     SC_WAVE_SYNC();                                      // the 8 lanes of a column share a wave
@@ -181,7 +181,6 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
   };
 
   SC_SYNC();
-
   // software prefetch, two rounds deep: a round of this kernel is short (~1 us), shorter than the
   // loaded HBM latency, so the values of round t + 2 are requested while round t is transformed
   // (two register sets, rounds alternate between them)
@@ -196,8 +195,13 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
 #ifdef SC_F3_ABL_NOLOAD
         q[j] = cf_make((float)(lam + j + t), (float)(lam - j));
 #else
+#ifdef SC_F3_PLAIN_IO
         q[j].x = ra[32 * j];
         q[j].y = rb[32 * j];
+#else
+        q[j].x = SC_LOAD_STREAM(&ra[32 * j]);          // read once: keep it out of the caches the
+        q[j].y = SC_LOAD_STREAM(&rb[32 * j]);          // spectra and weights live in
+#endif
 #endif
       }
     }
@@ -219,7 +223,8 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
       continue;
 #endif
 #pragma unroll
-      for (int k1 = 0; k1 < 8; ++k1) xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul(o[k1], tw1[k1]);
+      for (int k1 = 0; k1 < 8; ++k1)
+        xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul_tw(o[k1], tw1[k1].c, tw1[k1].ns, tw1[k1].s);
       SC_WAVE_SYNC();
 #pragma unroll
       for (int n3 = 0; n3 < 8; ++n3) v[n3] = xb[k1l * SC_F3_XRS + 4 * n3 + n4];
@@ -228,21 +233,23 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
       // last stage (over n4, k = k1 + 8 k3 + 64 k4) is pruned to one k4 per (k1, k3): k4 = 0 for
       // k3 < 4 (k = 0..31), k4 = 3 for k3 >= 4 (k = -32..-1), plus k = +32 (k1 = 0, k3 = 4, k4 = 0):
       // write the twiddled terms, the consumer lane adds the four n4 contributions
+      // layout of this second exchange: [k3][lane] (lane = 4 k1 + n4), so the writes are one
+      // contiguous 256-byte row per instruction and the consumer's four terms are 32 contiguous bytes
 #pragma unroll
       for (int k3 = 0; k3 < 8; ++k3)
-        xb[k1l * SC_F3_XRS + 4 * k3 + n4] = (k3 == 0) ? o[0] : cf_mul(o[k3], tw2[k3]);
-      if (k1l == 0) xb[32 + n4] = cf_mul(o[4], tw2[0]);                 // pad slots [0][32..35]
+        xb[32 * k3 + lam] = (k3 == 0) ? o[0] : cf_mul_tw(o[k3], tw2[4 * k3].c, tw2[4 * k3].ns, tw2[4 * k3].s);
+      if (k1l == 0) xb[256 + n4] = cf_mul_tw(o[4], tw2[0].c, tw2[0].ns, tw2[0].s);   // k = +32 terms
       SC_WAVE_SYNC();
       {
         // lane j: positive k = j  (k1 = j & 7, k3 = j >> 3), negative f = j - 32 (k3 + 4)
-        const cf32* pp = xb + (lam & 7) * SC_F3_XRS + 4 * (lam >> 3);
+        const cf32* pp = xb + 32 * (lam >> 3) + 4 * (lam & 7);
         const cf32 zp = cf_add(cf_add(pp[0], pp[1]), cf_add(pp[2], pp[3]));
-        const cf32 zn = cf_add(cf_add(pp[16], pp[17]), cf_add(pp[18], pp[19]));
+        const cf32 zn = cf_add(cf_add(pp[128], pp[129]), cf_add(pp[130], pp[131]));
         cf32* tr = T + p * L::TRS;
         tr[32 + lam] = zp;
         tr[lam] = zn;
         if (lam == 0) {                                  // column 32 is transformed after the group loop
-          const cf32* px = xb + 32;
+          const cf32* px = xb + 256;
           tr[65 + 2 * a] = cf_add(cf_add(px[0], px[1]), cf_add(px[2], px[3]));   // Z[+32]
           tr[66 + 2 * a] = zn;                                                     // Z[-32]
         }
@@ -308,7 +315,7 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
   cf32* T = reinterpret_cast<cf32*>(smem + L::off_T);
   cf32* twH = reinterpret_cast<cf32*>(smem + L::off_twH);
   cf32* tw64 = reinterpret_cast<cf32*>(smem + L::off_tw64);
-  cf32* tw2t = reinterpret_cast<cf32*>(smem + L::off_tw2);
+  ctw4* tw2t = reinterpret_cast<ctw4*>(smem + L::off_tw2);
   cf32* y32 = reinterpret_cast<cf32*>(smem + L::off_c32);
 
   const int tid = SC_TID;
@@ -322,20 +329,20 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
   for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
   if (tid < 64) tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];
   if (tid < 32) {
-    // conjugates of the forward table: [n4][k3] = conj(w32^(n4 k3) i^(n4 [k3 >= 4])), [n4][0] = conj(w32^(4 n4))
-    const int tn = tid >> 3, tk = tid & 7;
+    // conjugates of the forward table: [k3][n4] = conj(w32^(n4 k3) i^(n4 [k3 >= 4])), [0][n4] = conj(w32^(4 n4))
+    const int tn = tid & 3, tk = tid >> 2;
     const cf32 t = tabW[(8 * tn * (tk == 0 ? 4 : tk)) & 255];
-    tw2t[tid] = cf_conj((tk >= 4) ? cf_rot_i(t, tn) : t);
+    tw2t[tid] = ctw4_make(cf_conj((tk >= 4) ? cf_rot_i(t, tn) : t));
   }
   cf32* IN = T;
   for (int i = tid; i < Mx * My; i += 256) IN[i] = src[i];
   const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
 
   const int k1l = lam >> 2, n4 = lam & 3;
-  cf32 tw1c[8];
+  ctw3 tw1c[8];
 #pragma unroll
-  for (int k = 1; k < 8; ++k) tw1c[k] = cf_conj(tabW[(lam * k) & 255]);
-  const cf32* tw2c = tw2t + n4 * 8;
+  for (int k = 1; k < 8; ++k) tw1c[k] = ctw3_make(cf_conj(tabW[(lam * k) & 255]));
+  const ctw4* tw2c = tw2t + n4;                          // LDS table [k3][n4]
   cf32* xb = xch + hw * 8 * SC_F3_XRS;
 
   const int cl = lane >> 3, mu = lane & 7;
@@ -367,12 +374,12 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
       const int fx = f2d_fx(mu + 8 * q2);
       int idx = (a * fx) % H;
       if (idx < 0) idx += H;
-      v[q2] = cf_mul(EXTRA ? y32[mu + 8 * q2] : yh[q2], cf_conj(twH[idx]));
+      v[q2] = cf_mul_pk(EXTRA ? y32[mu + 8 * q2] : yh[q2], cf_conj(twH[idx]));
     }
     dft8<+1>(v, o);                                      // over q2 -> m (row b = m + 8 b1)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const cf32 val = (m == 0) ? o[0] : cf_mul(o[m], cf_conj(tw64[m * 8 + mu]));
+      const cf32 val = (m == 0) ? o[0] : cf_mul_pk(o[m], cf_conj(tw64[m * 8 + mu]));
       if (act) cb[m * 8 + mu] = val;
     }
     SC_WAVE_SYNC();
@@ -431,8 +438,8 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
         for (int k3 = 0; k3 < 9; ++k3) xk[k3] = zr[k3];
         v[0] = xk[0];
 #pragma unroll
-        for (int k3 = 1; k3 < 8; ++k3) v[k3] = cf_mul(xk[k3], tw2c[k3]);
-        cf_mac(v[4], xk[8], tw2c[0]);
+        for (int k3 = 1; k3 < 8; ++k3) v[k3] = cf_mul_tw(xk[k3], tw2c[4 * k3].c, tw2c[4 * k3].ns, tw2c[4 * k3].s);
+        v[4] = cf_add(v[4], cf_mul_tw(xk[8], tw2c[0].c, tw2c[0].ns, tw2c[0].s));
       }
       SC_WAVE_SYNC();
       dft8<+1>(v, o);                                    // over k3 -> n3
@@ -442,7 +449,7 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1) {
         const cf32 t = xb[k1 * SC_F3_XRS + lam];
-        v[k1] = (k1 == 0) ? t : cf_mul(t, tw1c[k1]);
+        v[k1] = (k1 == 0) ? t : cf_mul_tw(t, tw1c[k1].c, tw1c[k1].ns, tw1c[k1].s);
       }
       SC_WAVE_SYNC();                                   // xb is rewritten by the next round
       dft8<+1>(v, o);                                    // over k1 -> n1 : z[32 n1 + lam]
@@ -450,8 +457,13 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
       float* rb = yo + (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W + lam;
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1) {
+#ifdef SC_F3_PLAIN_IO
         ra[32 * n1] = o[n1].x;
         rb[32 * n1] = o[n1].y;
+#else
+        SC_STORE_STREAM(&ra[32 * n1], o[n1].x);
+        SC_STORE_STREAM(&rb[32 * n1], o[n1].y);
+#endif
       }
     }
     SC_SYNC();                                          // T is rewritten by the next group
