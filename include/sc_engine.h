@@ -95,7 +95,8 @@ int sc_transform_inverse(const sc_plan* plan, int mode, const float* yhat, const
  * (spectral_convolution.py:21-46) and the pairwise steps of _contract_tucker/_contract_cp
  * (:55-103). */
 enum {
-  SC_GEMM_FORCE_VALU = 1     /* never take the matrix-core kernel (debug / A-B)            */
+  SC_GEMM_FORCE_VALU = 1,    /* never take the matrix-core kernel (debug / A-B)            */
+  SC_GEMM_STREAM_C = 2       /* C is not consumed by the next kernel: non-temporal stores    */
 };
 /* flags bits 8..23: cap on the number of workgroups of the matrix-core kernel (0 = auto) */
 #define SC_GEMM_GRID(n) (((n) & 0xffff) << 8)

@@ -466,6 +466,7 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
   g.b_idx = d->b_idx; g.c_idx = d->c_idx;
   g.dbg = (d->flags >> 24) & 0xf;
+  g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
   // contiguous mode ranges of <= SC_MG_NM modes, split evenly: one range per CU when they fit
   const int64_t M = d->n_modes;
   int64_t G = (M + SC_MG_NM - 1) / SC_MG_NM;
@@ -514,9 +515,8 @@ extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, 
                             float* gbias, void* stream) {
   SC_CHECK_ARG(p && ghat && gbias, "null argument");
   if (channels <= 0) return 0;
-  dim3 grid((unsigned)((channels + SC_BLOCK - 1) / SC_BLOCK));
-  SC_LAUNCH(k_bias_grad, grid, dim3(SC_BLOCK), 0, (sc_stream_t)stream, (const cf32*)ghat, gbias, batch,
-            channels, p->modes, p->dc_index);
+  SC_LAUNCH(k_bias_grad, dim3((unsigned)channels), dim3(SC_WAVE), 0, (sc_stream_t)stream, (const cf32*)ghat,
+            gbias, batch, channels, p->modes, p->dc_index);
   return sc_check_launch("k_bias_grad");
 }
 
@@ -644,7 +644,7 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
     g.a_sp = Mk; g.a_sr = Ci * Mk; g.a_sm = 1; g.conj_a = 1;
     g.b_sr = Co * Mk; g.b_sq = Mk; g.b_sm = 1;
     g.c_sp = Co * Wm; g.c_sq = Wm; g.c_sm = 1; g.c_idx = idx;
-    g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
+    g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : SC_GEMM_STREAM_C;
     rc = sc_modegemm(&g, xhat_saved, ghat, gw, stream);
     if (rc) return rc;
   }

@@ -275,12 +275,23 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
 }
 
 // gbias[c] = sum_b Re(ghat[(b*channels + c) * modes_per_image + dc])
-SC_GLOBAL void k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias,
-                           int64_t batch, int64_t channels, int64_t modes_per_image,
-                           int64_t dc) {
-  const int64_t c = (int64_t)SC_BID_X * SC_BLOCK + SC_TID;
-  if (c >= channels) return;
+// one wave per channel, lanes run over the batch, xor-butterfly through LDS-free wave reduction
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_WAVE)
+k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias, int64_t batch, int64_t channels,
+            int64_t modes_per_image, int64_t dc) {
+  SC_SHARED float part[SC_WAVE];
+  const int64_t c = SC_BID_X;
+  const int lane = SC_TID;
   float s = 0.f;
-  for (int64_t b = 0; b < batch; ++b) s += ghat[(b * channels + c) * modes_per_image + dc].x;
-  gbias[c] = s;
+  for (int64_t b = lane; b < batch; b += SC_WAVE) s += ghat[(b * channels + c) * modes_per_image + dc].x;
+  part[lane] = s;
+  SC_WAVE_SYNC();
+#pragma unroll
+  for (int off = SC_WAVE / 2; off > 0; off >>= 1) {
+    const float o = (lane < off) ? part[lane + off] : 0.f;
+    SC_WAVE_SYNC();
+    if (lane < off) part[lane] += o;
+    SC_WAVE_SYNC();
+  }
+  if (lane == 0) gbias[c] = part[0];
 }

@@ -89,6 +89,7 @@ struct MfmaGemmArgs {
   const int32_t* b_idx;
   const int32_t* c_idx;
   int dbg;             // ablation bits (bench only): 1 skip MFMA, 2 skip C stores, 4 skip operand loads
+  int stream_c;        // 1: C is not read by the next kernel -> non-temporal stores
 };
 
 template <int PT, int QG, int NM>
@@ -325,7 +326,13 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
         const int sg = it * spi + sl;                   // segment = (row 0..7, column 0..15)
         if ((it % K::MS) == kh && it < nst && lvalid && sg < 128) {
           const cf32 val = *reinterpret_cast<const cf32*>(ep + (sg * NMS + jl) * 2);
-          crow[(int64_t)(sg >> 4) * g.c_sp + (int64_t)(sg & 15) * g.c_sq] = val;
+          cf32* cd = crow + (int64_t)(sg >> 4) * g.c_sp + (int64_t)(sg & 15) * g.c_sq;
+          if (g.stream_c) {
+            SC_STORE_STREAM(&cd->x, val.x);
+            SC_STORE_STREAM(&cd->y, val.y);
+          } else {
+            *cd = val;
+          }
         }
       }
       SC_SYNC();
