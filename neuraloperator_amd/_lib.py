@@ -16,6 +16,8 @@ SC_INV_PADDED, SC_INV_ADJ_R2C = 0, 1
 SC_PLAN_FORCE_GENERIC = 1
 SC_PLAN_FFT_GEN2 = 2
 SC_GEMM_FORCE_VALU = 1
+SC_GEMM_STREAM_C = 2
+SC_GEMM_PAIRED = 4
 
 
 def SC_GEMM_GRID(n):

@@ -92,11 +92,11 @@ struct MfmaGemmArgs {
   int stream_c;        // 1: C is not read by the next kernel -> non-temporal stores
 };
 
-template <int PT, int QG, int NM>
+template <int PT, int QG, int NM, int NWV = 8>
 struct MfmaGemmCfg {
   static constexpr int P = 32 * PT, Q = 16 * QG;
   static constexpr int RC = SC_MG_RC;                         // r values per LDS stage
-  static constexpr int NW = 8;                                // waves (2 per SIMD)
+  static constexpr int NW = NWV;                              // waves per workgroup (8, or 4 with 2 workgroups per CU)
   static constexpr int THREADS = 64 * NW;
   static constexpr int NT = 4 * PT;                           // (row tile, column group set) pairs
   static constexpr int MS = NW / NT;                          // waves sharing a tile = r split
@@ -114,17 +114,18 @@ struct MfmaGemmCfg {
   static constexpr int NPB = (Q + SPI_MIN - 1) / SPI_MIN;     // ... for B
   static constexpr int EP_FLOATS = 8 * 16 * NMS * 2;          // epilogue patch of one tile: 8 rows
   static_assert(NT == 4 || NT == 8, "P = 32 or 64");
+  static_assert(NW % NT == 0 && NW >= NT, "whole number of waves per tile");
   static_assert(HL * NW == RC, "the waves split the r values of a stage");
   static_assert(QG % 4 == 0, "4 waves split the column groups");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(NT * EP_FLOATS <= 2 * STAGE, "epilogue patches fit in the stage buffers");
 };
 
-template <int PT, int QG, int NM, bool CA, bool CB>
-SC_GLOBAL void SC_LAUNCH_BOUNDS((MfmaGemmCfg<PT, QG, NM>::THREADS))
+template <int PT, int QG, int NM, bool CA, bool CB, int NWV = 8>
+SC_GLOBAL void SC_LAUNCH_BOUNDS((MfmaGemmCfg<PT, QG, NM, NWV>::THREADS))
 k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
                 cf32* __restrict__ C) {
-  typedef MfmaGemmCfg<PT, QG, NM> K;
+  typedef MfmaGemmCfg<PT, QG, NM, NWV> K;
   constexpr int P = K::P, Q = K::Q, RC = K::RC, NMS = K::NMS, QW = K::QW, BPS = K::BPS;
   SC_SHARED __attribute__((aligned(16))) float lds[2 * K::STAGE];
 
@@ -269,6 +270,16 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
     const bool more = ck + 1 < nck;
     if (more && !(g.dbg & 4)) issue((ck + 1) * RC);
     if (!(g.dbg & 1)) compute(cur);
+#ifndef SC_EMU
+    if constexpr (K::NW == 4) {
+      // 256-thread shape: hipcc puts the accumulators in AGPRs but carries them across the loop
+      // back-edge in VGPRs (copying every register in and out each stage) unless they are pinned
+#pragma unroll
+      for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int u = 0; u < QW; ++u) asm volatile("" : "+a"(acc[j][u]));
+    }
+#endif
     if (g.dbg & 8) continue;
     if (more) commit(nxt, (ck + 1) * RC);
     SC_SYNC();

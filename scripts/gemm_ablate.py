@@ -34,8 +34,8 @@ def t(fn, cold, iters=10):
 
 variants = [("full", 0), ("no-mfma", 1 << 24), ("no-store", 2 << 24), ("no-load", 4 << 24),
             ("no-mfma no-store", 3 << 24), ("loads only(no mfma/store)", 3 << 24), ("mfma only", 6 << 24), ("mfma only, no commit/barrier", 14 << 24),
-            ("VALU kernel", _lib.SC_GEMM_FORCE_VALU)]
-for name, (a, b, c, kw) in list(kws.items())[::2]:
+            ("paired (2 WG/CU, 5 modes)", _lib.SC_GEMM_PAIRED), ("VALU kernel", _lib.SC_GEMM_FORCE_VALU)]
+for name, (a, b, c, kw) in list(kws.items()):
     for vn, fl in variants:
         fn = lambda: lib.modegemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), st, flags=fl, **kw)
         print(f"{name:4s} {vn:28s} warm {t(fn, False):8.1f} us   cold {t(fn, True):8.1f} us", flush=True)

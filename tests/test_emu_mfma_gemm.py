@@ -41,7 +41,8 @@ CASES = [
     (32, 64, 64, 5, 0),      # nm = 1 everywhere
     (32, 64, 64, 26, 3),     # ranges of 8, 9, 9 modes
     (32, 12, 64, 17, 2),     # r tail (12 = 8 + 4), ranges 8 and 9
-    (64, 64, 64, 9, 1),      # P = 64 for forward (8 waves)
+    (64, 64, 64, 9, 1),      # P = 64 for forward (8 waves, 9 modes)
+    (64, 16, 64, 17, 2),     # wide shape, ranges 8 and 9
 ]
 
 
@@ -55,6 +56,12 @@ def test_forward_contraction(lib, case):
              a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=Co * M, b_sq=M, b_sm=1, c_sp=Co * M, c_sq=M, c_sm=1)
     ref = np.einsum("bim,iom->bom", x.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
     assert rel_l2(y.numpy(), ref) < TOL
+    if B == 32:   # the paired (4-wave, <= 5 modes) shape of the same contraction
+        y3 = torch.zeros_like(y)
+        wcap = max(1, -(-M // 5))
+        run_gemm(lib, x, w, y3, flags=_lib.SC_GEMM_PAIRED | _lib.SC_GEMM_GRID(wcap), P=B, Q=Co, R=Ci, n_modes=M,
+                 a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=Co * M, b_sq=M, b_sm=1, c_sp=Co * M, c_sq=M, c_sm=1)
+        assert rel_l2(y3.numpy(), ref) < TOL
     # same call on the VALU kernel
     y2 = torch.zeros_like(y)
     run_gemm(lib, x, w, y2, flags=_lib.SC_GEMM_FORCE_VALU, P=B, Q=Co, R=Ci, n_modes=M,
