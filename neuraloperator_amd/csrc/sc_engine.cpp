@@ -334,9 +334,10 @@ static int run_axis(int jt, const cf32* in, cf32* out, const DeviceTable& t, int
 // ------------------------------------------------------------------------------------------
 extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, float* xhat,
                                     int64_t n_images, void* workspace, void* stream) {
-  SC_CHECK_ARG(p && x && xhat, "null argument");
+  SC_CHECK_ARG(p, "null argument");
   SC_CHECK_ARG(mode == SC_FWD_SCALED || mode == SC_FWD_ADJ_C2R, "bad forward mode");
   if (n_images <= 0) return 0;
+  SC_CHECK_ARG(x && xhat, "null argument");
   sc_stream_t st = (sc_stream_t)stream;
   if (p->fast) {
     if (p->d.flags & SC_PLAN_FFT_GEN2)
@@ -371,9 +372,10 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
 extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yhat, const float* bias,
                                     int64_t channels, float* y, int64_t n_images, void* workspace,
                                     void* stream) {
-  SC_CHECK_ARG(p && yhat && y, "null argument");
+  SC_CHECK_ARG(p, "null argument");
   SC_CHECK_ARG(mode == SC_INV_PADDED || mode == SC_INV_ADJ_R2C, "bad inverse mode");
   if (n_images <= 0) return 0;
+  SC_CHECK_ARG(yhat && y, "null argument");
   if (channels <= 0) channels = 1;
   sc_stream_t st = (sc_stream_t)stream;
   if (p->fast) {
@@ -597,9 +599,10 @@ static int64_t weight_slab(const sc_plan* p, const sc_layer_desc* L) {
 extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const float* x, const float* w,
                                 const float* bias, float* y, float* xhat_saved, void* workspace,
                                 void* stream) {
-  SC_CHECK_ARG(p && L && x && w && y && xhat_saved && workspace, "null argument");
+  SC_CHECK_ARG(p && L, "null argument");
   const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
-  if (B == 0) return 0;
+  if (B == 0) return 0;                      // empty batch: nothing to do (pointers may be null)
+  SC_CHECK_ARG(x && w && y && xhat_saved && workspace, "null argument");
   const int32_t* idx = nullptr;
   int rc = layer_index_table(p, L, &idx);
   if (rc) return rc;
@@ -626,9 +629,14 @@ extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const 
 extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const float* gy,
                                  const float* xhat_saved, const float* w, float* gx, float* gw,
                                  float* gbias, void* workspace, void* stream) {
-  SC_CHECK_ARG(p && L && gy && xhat_saved && w && workspace, "null argument");
+  SC_CHECK_ARG(p && L, "null argument");
   const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
-  if (B == 0) return 0;
+  if (B == 0) {                              // empty batch: gradients of the parameters are zero
+    if (gw) SC_CHECK_HIP(hipMemsetAsync(gw, 0, (size_t)Ci * Co * weight_slab(p, L) * sizeof(cf32), (sc_stream_t)stream));
+    if (gbias) SC_CHECK_HIP(hipMemsetAsync(gbias, 0, (size_t)Co * sizeof(float), (sc_stream_t)stream));
+    return 0;
+  }
+  SC_CHECK_ARG(gy && xhat_saved && w && workspace, "null argument");
   const int32_t* idx = nullptr;
   int rc = layer_index_table(p, L, &idx);
   if (rc) return rc;

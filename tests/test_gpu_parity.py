@@ -203,6 +203,44 @@ def test_module_dropin():
         conv(torch.randn(2, 3, 12, 12))        # CPU tensor: loud failure, no fallback
 
 
+def test_module_edge_inputs():
+    """Empty batch, non-contiguous input, fp64 / bf16 inputs (computed in fp32 like the reference's
+    fp32 spectral path), odd n_modes, grid smaller than the modes."""
+    from neuraloperator_amd import SpectralConv
+    from oracle import spectral_oracle as so
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    conv = SpectralConv(4, 6, (7, 9)).to(dev)
+    w, b = conv.weight.tensor.detach().cpu(), conv.bias.detach().cpu()
+    # empty batch
+    y0 = conv(torch.randn(0, 4, 16, 20, device=dev))
+    assert tuple(y0.shape) == (0, 6, 16, 20)
+    # non-contiguous view of a larger tensor
+    big = torch.randn(3, 4, 16, 40, device=dev)
+    xv = big[:, :, :, ::2]
+    assert not xv.is_contiguous()
+    y = conv(xv)
+    yo = so.forward_torch(xv.cpu().contiguous(), w, b, conv.n_modes, conv.max_n_modes)
+    assert rel_l2(y.detach().cpu().numpy(), yo.numpy()) < TOL
+    # grid smaller than the modes along one dim (6 rows < 7 modes)
+    xs = torch.randn(2, 4, 6, 20, device=dev)
+    ys = conv(xs)
+    yso = so.forward_torch(xs.cpu(), w, b, conv.n_modes, conv.max_n_modes)
+    assert rel_l2(ys.detach().cpu().numpy(), yso.numpy()) < TOL
+    # double input: engine computes in fp32 and returns fp32
+    xd = torch.randn(2, 4, 16, 20, device=dev, dtype=torch.float64)
+    yd = conv(xd)
+    assert yd.dtype == torch.float32
+    ydo = so.forward_torch(xd.float().cpu(), w, b, conv.n_modes, conv.max_n_modes)
+    assert rel_l2(yd.detach().cpu().numpy(), ydo.numpy()) < TOL
+    # wrong rank / channel count fail loudly
+    with pytest.raises(ValueError):
+        conv(torch.randn(2, 4, 16, device=dev))
+    with pytest.raises(ValueError):
+        conv(torch.randn(2, 5, 16, 20, device=dev))
+
+
 @pytest.mark.parametrize("fac", ["Tucker", "CP"])
 def test_module_factorized_matches_dense(fac):
     """factorized weight == dense conv with weight.to_tensor()
