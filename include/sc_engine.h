@@ -60,7 +60,8 @@ typedef struct {
 
 enum {
   SC_PLAN_FORCE_GENERIC = 1, /* never take the power-of-two fast kernels (debug / A-B)     */
-  SC_PLAN_FFT_GEN2 = 2       /* fast path on the generation-2 fused kernels (A-B)           */
+  SC_PLAN_FFT_GEN2 = 2,      /* fast path on the generation-2 fused kernels (A-B)           */
+  SC_PLAN_NO_MDFT = 4        /* generic passes on the VALU kernels instead of the matrix cores (A-B) */
 };
 
 /* ---- plan ------------------------------------------------------------------------------ */

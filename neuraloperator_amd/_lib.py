@@ -15,6 +15,7 @@ SC_FWD_SCALED, SC_FWD_ADJ_C2R = 0, 1
 SC_INV_PADDED, SC_INV_ADJ_R2C = 0, 1
 SC_PLAN_FORCE_GENERIC = 1
 SC_PLAN_FFT_GEN2 = 2
+SC_PLAN_NO_MDFT = 4
 SC_GEMM_FORCE_VALU = 1
 SC_GEMM_STREAM_C = 2
 SC_GEMM_PAIRED = 4

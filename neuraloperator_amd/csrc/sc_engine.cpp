@@ -18,6 +18,7 @@
 #include "sc_kernels_fft.h"
 #include "sc_kernels_fft3.h"
 #include "sc_kernels_mfma.h"
+#include "sc_kernels_mdft.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -75,6 +76,12 @@ struct sc_plan {
   // non-last axes
   int ax_fwd_jt[SC_MAX_DIMS], ax_inv_jt[SC_MAX_DIMS];
   DeviceTable ax_fwd[SC_MAX_DIMS], ax_inv[SC_MAX_DIMS];
+  // matrix-core versions of the generic passes (sc_kernels_mdft.h): tables in MFMA lane order
+  bool mdft = false;
+  float* m_r2c[2] = {nullptr, nullptr};
+  float* m_c2r[2] = {nullptr, nullptr};
+  float* m_ax_fwd[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
+  float* m_ax_inv[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   // fast path (power-of-two 2-D), see sc_kernels_fft.h
   Fft2dPlan fft2d;
   bool fast = false;
@@ -125,6 +132,81 @@ static double col_weight(int64_t j, int64_t N) {
   if (j == 0) return 1.0;
   if (N % 2 == 0 && j == N / 2) return 1.0;
   return 2.0;
+}
+
+static int upload_floats(sc_plan* p, const std::vector<float>& host, float** out) {
+  void* dev = nullptr;
+  SC_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(float)));
+  p->owned.push_back(dev);
+  SC_CHECK_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = (float*)dev;
+  return 0;
+}
+
+// tables of the matrix-core passes, in MFMA lane order (layouts: sc_kernels_mdft.h)
+static int build_mdft_tables(sc_plan* p) {
+  const int L = p->nd - 1;
+  const int64_t N = p->n[L], J = p->k[L];
+  int rc = 0;
+  if (N % 8 == 0) {
+    const int64_t NG = N / 8, CT = (2 * J + 31) / 32;
+    for (int v = 0; v < 2 && !rc; ++v) {
+      std::vector<float> h((size_t)(CT * NG * 4 * 64), 0.f);
+      for (int64_t ct = 0; ct < CT; ++ct)
+        for (int64_t t = 0; t < NG; ++t)
+          for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int64_t f = 32 * ct + (lane & 31), j = f >> 1, n = 8 * t + 4 * (lane >> 5) + q;
+              if (j >= J || n >= N) continue;
+              const double s = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
+              const cf32 tw = twiddle(j, n, N, -1.0, s);
+              h[(size_t)(((ct * NG + t) * 4 + q) * 64 + lane)] = (f & 1) ? tw.y : tw.x;
+            }
+      rc = upload_floats(p, h, &p->m_r2c[v]);
+    }
+  }
+  {
+    const int64_t JS = (J + 1) / 2, NT = (N + 31) / 32;
+    for (int v = 0; v < 2 && !rc; ++v) {
+      std::vector<float> h((size_t)(NT * JS * 2 * 64), 0.f);
+      for (int64_t nt = 0; nt < NT; ++nt)
+        for (int64_t t = 0; t < JS; ++t)
+          for (int comp = 0; comp < 2; ++comp)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int64_t n = 32 * nt + (lane & 31), j = 2 * t + (lane >> 5);
+              if (j >= J || n >= N) continue;
+              const double s = (v == SC_INV_PADDED) ? p->si * col_weight(j, N) : p->sf;
+              const cf32 tw = twiddle(j, n, N, +1.0, s);
+              h[(size_t)(((nt * JS + t) * 2 + comp) * 64 + lane)] = comp ? -tw.y : tw.x;
+            }
+      rc = upload_floats(p, h, &p->m_c2r[v]);
+    }
+  }
+  for (int d = 0; d < L && !rc; ++d) {
+    const int64_t Nd = p->n[d], Kd = p->k[d];
+    for (int dir = 0; dir < 2 && !rc; ++dir) {
+      // dir 0: forward (N = n_d inputs -> J = k_d kept rows), dir 1: inverse (N = k_d -> J = n_d)
+      const int64_t Nin = dir ? Kd : Nd, Jout = dir ? Nd : Kd;
+      const int64_t NS = (Nin + 1) / 2, JT = (Jout + 15) / 16;
+      std::vector<float> h((size_t)(JT * NS * 2 * 64), 0.f);
+      for (int64_t jt = 0; jt < JT; ++jt)
+        for (int64_t sidx = 0; sidx < NS; ++sidx)
+          for (int comp = 0; comp < 2; ++comp)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int row = lane & 31;
+              const int64_t j = 16 * jt + (row >> 1), n = 2 * sidx + (lane >> 5);
+              if (j >= Jout || n >= Nin) continue;
+              const cf32 tw = dir ? twiddle(n - Kd / 2, j, Nd, +1.0, 1.0) : twiddle(j - Kd / 2, n, Nd, -1.0, 1.0);
+              float val;
+              if (comp == 0) val = (row & 1) ? tw.y : tw.x;        // times Re(in): (Re out, Im out)
+              else val = (row & 1) ? tw.x : -tw.y;                 // times Im(in)
+              h[(size_t)(((jt * NS + sidx) * 2 + comp) * 64 + lane)] = val;
+            }
+      rc = upload_floats(p, h, dir ? &p->m_ax_inv[d] : &p->m_ax_fwd[d]);
+    }
+  }
+  if (!rc) p->mdft = true;
+  return rc;
 }
 
 extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
@@ -216,6 +298,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     std::string why;
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
+  if (!rc && !p->fast && !(desc->flags & SC_PLAN_NO_MDFT)) rc = build_mdft_tables(p);
   if (rc) {
     sc_plan_destroy(p);
     return rc;
@@ -268,9 +351,24 @@ static void launch_r2c(const float* in, cf32* out, const DeviceTable& t, int64_t
             t.cols_pad);
 }
 
+template <int RT, int CT>
+static void launch_mdft_r2c(const float* in, cf32* out, const float* tab, int64_t lines, int N, int J, int n_ct,
+                            sc_stream_t st) {
+  const int64_t items = (lines + 32 * RT - 1) / (32 * RT);
+  SC_LAUNCH((k_mdft_r2c<RT, CT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, (float*)out, tab, lines,
+            N, J, n_ct);
+}
+
 static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
+  if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
+    const int n_ct = (2 * J + 31) / 32;
+    if (n_ct <= 2) launch_mdft_r2c<4, 2>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+    else if (n_ct <= 4) launch_mdft_r2c<2, 4>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+    else launch_mdft_r2c<1, 8>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+    return sc_check_launch("k_mdft_r2c");
+  }
   const DeviceTable& t = p->r2c[mode];
   switch (p->r2c_jt) {
     case 2: launch_r2c<2>(in, out, t, lines, N, J, st); break;
@@ -295,10 +393,28 @@ static void launch_c2r(const cf32* in, float* out, const DeviceTable& t, const f
             t.cols_pad, lpi, channels);
 }
 
+template <int RT, int CT>
+static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const float* bias, int64_t lines, int N,
+                            int J, int n_nt, int64_t lpi, int64_t channels, sc_stream_t st) {
+  const int64_t items = (lines + 32 * RT - 1) / (32 * RT);
+  SC_LAUNCH((k_mdft_c2r<RT, CT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, out, tab, bias, lines, N,
+            J, n_nt, lpi, channels);
+}
+
 static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
                    int64_t lpi, int64_t channels, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
+  if (p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
+    const int n_nt = (N + 31) / 32;
+    const int rt = n_nt <= 2 ? 4 : (n_nt <= 4 ? 2 : 1);
+    if (bias == nullptr || lpi % (32 * rt) == 0) {     // bias must be uniform per wave (32 rt lines)
+      if (rt == 4) launch_mdft_c2r<4, 2>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+      else if (rt == 2) launch_mdft_c2r<2, 4>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+      else launch_mdft_c2r<1, 8>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+      return sc_check_launch("k_mdft_c2r");
+    }
+  }
   const DeviceTable& t = p->c2r[mode];
   switch (p->c2r_nt) {
     case 4: launch_c2r<4>(in, out, t, bias, lines, N, J, lpi, channels, st); break;
@@ -316,6 +432,23 @@ static void launch_axis(const cf32* in, cf32* out, const DeviceTable& t, int64_t
   dim3 grid((unsigned)((cols + SC_BLOCK - 1) / SC_BLOCK), (unsigned)((J + JT - 1) / JT));
   SC_LAUNCH((k_axis_pass<JT>), grid, dim3(SC_BLOCK), 0, st, in, out, (const cf32*)t.ptr, outer, N, J, inner,
             t.cols_pad);
+}
+
+template <int JT, int CT>
+static void launch_mdft_axis(const cf32* in, cf32* out, const float* tab, int64_t outer, int N, int J, int64_t inner,
+                             int n_jt, sc_stream_t st) {
+  const int64_t items = (outer * inner + 32 * CT - 1) / (32 * CT);
+  SC_LAUNCH((k_mdft_axis<JT, CT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, out, tab, outer, N, J,
+            inner, n_jt);
+}
+
+static int run_axis_mdft(const float* tab, const cf32* in, cf32* out, int64_t outer, int N, int J, int64_t inner,
+                         sc_stream_t st) {
+  const int n_jt = (J + 15) / 16;
+  if (n_jt <= 2) launch_mdft_axis<2, 4>(in, out, tab, outer, N, J, inner, n_jt, st);
+  else if (n_jt <= 4) launch_mdft_axis<4, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
+  else launch_mdft_axis<8, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+  return sc_check_launch("k_mdft_axis");
 }
 
 static int run_axis(int jt, const cf32* in, cf32* out, const DeviceTable& t, int64_t outer, int N, int J,
@@ -361,7 +494,10 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
     int64_t outer = n_images;
     for (int e = 0; e < d; ++e) outer *= p->n[e];
     cf32* dst = (d == 0) ? (cf32*)xhat : (cur == bufA ? bufB : bufA);
-    rc = run_axis(p->ax_fwd_jt[d], cur, dst, p->ax_fwd[d], outer, (int)p->n[d], (int)p->k[d], inner, st);
+    if (p->mdft && p->m_ax_fwd[d])
+      rc = run_axis_mdft(p->m_ax_fwd[d], cur, dst, outer, (int)p->n[d], (int)p->k[d], inner, st);
+    else
+      rc = run_axis(p->ax_fwd_jt[d], cur, dst, p->ax_fwd[d], outer, (int)p->n[d], (int)p->k[d], inner, st);
     if (rc) return rc;
     cur = dst;
     inner *= p->k[d];
@@ -402,7 +538,11 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
     for (int e = d + 1; e <= L; ++e) inner *= p->k[e];
     const int remaining = L - 1 - d;  // passes after this one
     cf32* dst = (remaining % 2 == 0) ? bufA : bufB;
-    int rc = run_axis(p->ax_inv_jt[d], cur, dst, p->ax_inv[d], outer, (int)p->k[d], (int)p->n[d], inner, st);
+    int rc;
+    if (p->mdft && p->m_ax_inv[d])
+      rc = run_axis_mdft(p->m_ax_inv[d], cur, dst, outer, (int)p->k[d], (int)p->n[d], inner, st);
+    else
+      rc = run_axis(p->ax_inv_jt[d], cur, dst, p->ax_inv[d], outer, (int)p->k[d], (int)p->n[d], inner, st);
     if (rc) return rc;
     cur = dst;
     outer *= p->n[d];
@@ -698,5 +838,6 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
     if (p->d.flags & SC_PLAN_FFT_GEN2) return fft2d_kernel_name(which);
     return which == 0 ? "k_fft2d_fwd3" : "k_fft2d_inv3";
   }
+  if (p->mdft) return which == 0 ? (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c") : "k_mdft_c2r";
   return which == 0 ? "k_last_r2c" : "k_last_c2r";
 }

@@ -21,12 +21,15 @@ def lib():
 SMALL = [n for n in DENSE_GOLDEN if n not in ("darcy_c1_16x16_m12_c32", "d2_64x64_m16_c8", "d3_16x16x16_m8")]
 
 
+@pytest.mark.parametrize("passes", ["mdft", "valu"])
 @pytest.mark.parametrize("name", SMALL)
-def test_generic_path_matches_golden(lib, name):
+def test_generic_path_matches_golden(lib, name, passes):
+    """size-agnostic passes: on the matrix cores (k_mdft_*, emulated MFMA) and on the VALU kernels"""
     g = load_golden(name)
     x, w, b, gy = (torch.from_numpy(g[k]) for k in ("x", "weight", "bias", "g"))
+    flags = _lib.SC_PLAN_FORCE_GENERIC | (_lib.SC_PLAN_NO_MDFT if passes == "valu" else 0)
     y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, b, gy, list(g["n_modes_attr"]), list(g["max_n_modes_attr"]),
-                                     flags=_lib.SC_PLAN_FORCE_GENERIC)
+                                     flags=flags)
     assert rel_l2(y.numpy(), g["y"]) < TOL
     assert rel_l2(gx.numpy(), g["gx"]) < TOL
     assert rel_l2(gw.numpy(), g["gw"]) < TOL

@@ -20,7 +20,7 @@ def lib():
     return _lib.get_lib()      # raises if libsc_engine.so is missing: no fallback
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["default", "force_generic"])
+@pytest.mark.parametrize("flags", [0, 1, 5], ids=["default", "force_generic", "force_generic_valu"])
 @pytest.mark.parametrize("name", DENSE_GOLDEN)
 def test_golden(lib, name, flags):
     g = load_golden(name)
@@ -51,7 +51,7 @@ ORACLE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["default", "force_generic"])
+@pytest.mark.parametrize("flags", [0, 1, 5], ids=["default", "force_generic", "force_generic_valu"])
 @pytest.mark.parametrize("case", ORACLE_CASES, ids=lambda c: "x".join(map(str, c[3])) + f"_m{c[4][0]}_c{c[1]}")
 def test_vs_oracle(lib, case, flags):
     from oracle import spectral_oracle as so
