@@ -40,6 +40,12 @@
 #define SC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // the instruction scheduler may not move anything across this point
 #define SC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// returns x, but opaque to the optimiser: address arithmetic that depends on it cannot be hoisted
+// above this point (epilogue store addresses computed -- and spilled -- before the main loop otherwise)
+SC_DEVICE int sc_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 // streaming (non-temporal) access to the 0.5 GB real tensors: a plain store leaves up to 256 MB of
 // dirty Infinity-Cache lines whose write-back the NEXT kernel pays for (+57 us on a 537 MB reader,
 // profiles/r01_writeback_ubench.txt); nt stores drain to HBM while the producing kernel computes
@@ -93,6 +99,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_SCHED_BARRIER() do { } while (0)
 #define SC_STORE_STREAM(ptr, val) (*(ptr) = (val))
 #define SC_LOAD_STREAM(ptr) (*(ptr))
+inline int sc_opaque(int x) { return x; }
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)
 
 typedef void* sc_stream_t;

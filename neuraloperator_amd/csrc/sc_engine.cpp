@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -364,9 +365,18 @@ static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64
   const int N = (int)p->n[L], J = (int)p->k[L];
   if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
     const int n_ct = (2 * J + 31) / 32;
-    if (n_ct <= 2) launch_mdft_r2c<4, 2>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
-    else if (n_ct <= 4) launch_mdft_r2c<2, 4>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
-    else launch_mdft_r2c<1, 8>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+    // 8 accumulator tiles per wave by default; SC_MDFT_TILE=4 selects 4-tile waves (2-3 waves per
+    // SIMD) for A-B: measured equal on 128^3 (5.38 vs 5.43 ms/step) and slower on 1024^2 (33.1 vs 30.5)
+    const char* tile = getenv("SC_MDFT_TILE");
+    const bool big = !(tile && tile[0] == '4');
+    if (big) {
+      if (n_ct <= 2) launch_mdft_r2c<4, 2>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+      else if (n_ct <= 4) launch_mdft_r2c<2, 4>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+      else launch_mdft_r2c<1, 8>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+    } else {
+      if (n_ct <= 2) launch_mdft_r2c<2, 2>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+      else launch_mdft_r2c<1, 4>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+    }
     return sc_check_launch("k_mdft_r2c");
   }
   const DeviceTable& t = p->r2c[mode];
@@ -407,11 +417,18 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
   const int N = (int)p->n[L], J = (int)p->k[L];
   if (p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
     const int n_nt = (N + 31) / 32;
-    const int rt = n_nt <= 2 ? 4 : (n_nt <= 4 ? 2 : 1);
+    const char* tile = getenv("SC_MDFT_TILE");
+    const bool big = !(tile && tile[0] == '4');
+    const int rt = big ? (n_nt <= 2 ? 4 : (n_nt <= 4 ? 2 : 1)) : (n_nt <= 2 ? 2 : 1);
     if (bias == nullptr || lpi % (32 * rt) == 0) {     // bias must be uniform per wave (32 rt lines)
-      if (rt == 4) launch_mdft_c2r<4, 2>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
-      else if (rt == 2) launch_mdft_c2r<2, 4>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
-      else launch_mdft_c2r<1, 8>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+      if (big) {
+        if (rt == 4) launch_mdft_c2r<4, 2>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+        else if (rt == 2) launch_mdft_c2r<2, 4>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+        else launch_mdft_c2r<1, 8>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+      } else {
+        if (rt == 2) launch_mdft_c2r<2, 2>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+        else launch_mdft_c2r<1, 4>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
+      }
       return sc_check_launch("k_mdft_c2r");
     }
   }
@@ -445,9 +462,15 @@ static void launch_mdft_axis(const cf32* in, cf32* out, const float* tab, int64_
 static int run_axis_mdft(const float* tab, const cf32* in, cf32* out, int64_t outer, int N, int J, int64_t inner,
                          sc_stream_t st) {
   const int n_jt = (J + 15) / 16;
-  if (n_jt <= 2) launch_mdft_axis<2, 4>(in, out, tab, outer, N, J, inner, n_jt, st);
-  else if (n_jt <= 4) launch_mdft_axis<4, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
-  else launch_mdft_axis<8, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+  const char* tile = getenv("SC_MDFT_TILE");
+  if (!(tile && tile[0] == '4')) {
+    if (n_jt <= 2) launch_mdft_axis<2, 4>(in, out, tab, outer, N, J, inner, n_jt, st);
+    else if (n_jt <= 4) launch_mdft_axis<4, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
+    else launch_mdft_axis<8, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+  } else {
+    if (n_jt <= 2) launch_mdft_axis<2, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
+    else launch_mdft_axis<4, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+  }
   return sc_check_launch("k_mdft_axis");
 }
 

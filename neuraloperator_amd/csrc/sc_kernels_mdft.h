@@ -53,31 +53,49 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
       if (line >= lines) line = lines - 1;
       rowp[r] = in + line * N + 4 * half;
     }
-#pragma unroll 1
-    for (int t = 0; t < NG; ++t) {
-      float a[RT][4];
+    // operands of step t+1 are requested before the MFMAs of step t are issued (two register sets)
+    float a0[RT][4], b0[CT][4], a1[RT][4], b1[CT][4];
+    auto fetch = [&](const int t, float (&a)[RT][4], float (&b)[CT][4]) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
         const cf32 lo = *reinterpret_cast<const cf32*>(rowp[r] + 8 * t);
         const cf32 hi = *reinterpret_cast<const cf32*>(rowp[r] + 8 * t + 2);
         a[r][0] = lo.x; a[r][1] = lo.y; a[r][2] = hi.x; a[r][3] = hi.y;
       }
-      float b[CT][4];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int ct = (ct0 + c < n_ct) ? ct0 + c : n_ct - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[c][q] = tab[(((int64_t)ct * NG + t) * 4 + q) * 64 + lane];
       }
-      SC_SCHED_BARRIER();
+    };
+    auto multiply = [&](const float (&a)[RT][4], const float (&b)[CT][4]) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
           for (int c = 0; c < CT; ++c) sc_mfma_32x32x2(acc[r][c], a[r][q], b[c][q]);
+    };
+    fetch(0, a0, b0);
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < NG; t += 2) {                         // single-exit loop: the accumulators stay put
+      fetch(t + 1, a1, b1);
       SC_SCHED_BARRIER();
+      multiply(a0, b0);
+      SC_SCHED_BARRIER();
+      if (t + 2 < NG) fetch(t + 2, a0, b0);
+      SC_SCHED_BARRIER();
+      multiply(a1, b1);
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[r][c]);
     }
+    if (t < NG) multiply(a0, b0);                        // odd step count
+    const int64_t l0e = l0 + sc_opaque(0);               // keep the store addresses out of the loop
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -86,7 +104,7 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
         if (ct0 + c < n_ct && f < 2 * J) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
-            const int64_t line = l0 + 32 * r + mdft_row(v, half);
+            const int64_t line = l0e + 32 * r + mdft_row(v, half);
             if (line < lines) out[line * 2 * J + f] = acc[r][c][v];
           }
         }
@@ -132,21 +150,21 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][c][v] = 0.f;
-#pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
+    cf32 d0[CT], d1[CT];
+    float a0[JT][2], a1[JT][2];
+    auto fetch = [&](const int s, cf32 (&d)[CT], float (&a)[JT][2]) {
       int n = 2 * s + half;
       if (n >= N) n = N - 1;                                  // table entry is zero there
-      cf32 d[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) d[c] = colp[c][(int64_t)n * inner];
-      float a[JT][2];
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
         const int jt = (jt0 + j < n_jt) ? jt0 + j : n_jt - 1;
         a[j][0] = tab[(((int64_t)jt * NS + s) * 2 + 0) * 64 + lane];
         a[j][1] = tab[(((int64_t)jt * NS + s) * 2 + 1) * 64 + lane];
       }
-      SC_SCHED_BARRIER();
+    };
+    auto multiply = [&](const cf32 (&d)[CT], const float (&a)[JT][2]) {
 #pragma unroll
       for (int j = 0; j < JT; ++j)
 #pragma unroll
@@ -154,8 +172,26 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
           sc_mfma_32x32x2(acc[j][c], a[j][0], d[c].x);
           sc_mfma_32x32x2(acc[j][c], a[j][1], d[c].y);
         }
+    };
+    fetch(0, d0, a0);
+    int s = 0;
+#pragma unroll 1
+    for (; s + 1 < NS; s += 2) {
+      fetch(s + 1, d1, a1);
       SC_SCHED_BARRIER();
+      multiply(d0, a0);
+      SC_SCHED_BARRIER();
+      if (s + 2 < NS) fetch(s + 2, d0, a0);
+      SC_SCHED_BARRIER();
+      multiply(d1, a1);
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[j][c]);
     }
+    if (s < NS) multiply(d0, a0);
+    const int64_t zo = sc_opaque(0);
 #pragma unroll
     for (int j = 0; j < JT; ++j)
 #pragma unroll
@@ -164,7 +200,7 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
 #pragma unroll
           for (int v = 0; v < 16; v += 2) {
             const int jj = 16 * (jt0 + j) + (mdft_row(v, half) >> 1);
-            if (jj < J) out[obase[c] + (int64_t)jj * inner] = cf_make(acc[j][c][v], acc[j][c][v + 1]);
+            if (jj < J) out[obase[c] + zo + (int64_t)jj * inner] = cf_make(acc[j][c][v], acc[j][c][v + 1]);
           }
         }
       }
@@ -206,21 +242,21 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < JS; ++t) {
+    cf32 d0[RT], d1[RT];
+    float b0[CT][2], b1[CT][2];
+    auto fetch = [&](const int t, cf32 (&d)[RT], float (&b)[CT][2]) {
       int j = 2 * t + half;
       if (j >= J) j = J - 1;                                  // table entry is zero there
-      cf32 d[RT];
 #pragma unroll
       for (int r = 0; r < RT; ++r) d[r] = rowp[r][j];
-      float b[CT][2];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int nt = (nt0 + c < n_nt) ? nt0 + c : n_nt - 1;
         b[c][0] = tab[(((int64_t)nt * JS + t) * 2 + 0) * 64 + lane];
         b[c][1] = tab[(((int64_t)nt * JS + t) * 2 + 1) * 64 + lane];
       }
-      SC_SCHED_BARRIER();
+    };
+    auto multiply = [&](const cf32 (&d)[RT], const float (&b)[CT][2]) {
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -228,13 +264,31 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
           sc_mfma_32x32x2(acc[r][c], d[r].x, b[c][0]);
           sc_mfma_32x32x2(acc[r][c], d[r].y, b[c][1]);
         }
+    };
+    fetch(0, d0, b0);
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < JS; t += 2) {
+      fetch(t + 1, d1, b1);
       SC_SCHED_BARRIER();
+      multiply(d0, b0);
+      SC_SCHED_BARRIER();
+      if (t + 2 < JS) fetch(t + 2, d0, b0);
+      SC_SCHED_BARRIER();
+      multiply(d1, b1);
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[r][c]);
     }
+    if (t < JS) multiply(d0, b0);
+    const int64_t l0e = l0 + sc_opaque(0);
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int64_t line = l0 + 32 * r + mdft_row(v, half);
+        const int64_t line = l0e + 32 * r + mdft_row(v, half);
         if (line < lines) {
           float* orow = out + line * N;
 #pragma unroll

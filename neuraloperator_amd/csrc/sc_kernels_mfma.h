@@ -81,6 +81,14 @@ inline float sc_xor_sign(const float v, const uint32_t mask) {
 }
 #endif
 
+// keep an MFMA accumulator in the AGPR file across a loop back-edge (hipcc otherwise carries it in
+// VGPRs and copies every register in and out of the AGPRs each iteration)
+#ifndef SC_EMU
+#define SC_PIN_ACC(x) asm volatile("" : "+a"(x))
+#else
+#define SC_PIN_ACC(x) do { } while (0)
+#endif
+
 struct MfmaGemmArgs {
   int P, Q, R, M, G;   // G = number of mode ranges = grid size
   int64_t a_sp, a_sr, a_sm;
