@@ -117,6 +117,12 @@ typedef struct {
 
 int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                 void* stream);
+/* C[p, q] += sum_m sum_r opA(A[p, r, m]) * opB(B[r, q, m]) -- the gradient of a mode-independent
+ * operand (Tucker / CP factor matrices, autograd of spectral_convolution.py:55-103): lanes run over
+ * the modes, wave reduction, one atomic add per (p, q) and mode tile.  C (element offsets
+ * p*c_sp + q*c_sq) must be zeroed by the caller; c_sm / c_idx / accumulate are ignored. */
+int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
+                     void* stream);
 /* 1 if this call runs on the MFMA kernel (k_modegemm_mfma), 0 for the VALU kernel */
 int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
 

@@ -61,7 +61,7 @@ class ScEngineLib:
     # every symbol include/sc_engine.h declares
     SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
                "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
-               "sc_modegemm_uses_matrix_cores", "sc_bias_grad",
+               "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_bias_grad",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name"]
 
@@ -93,6 +93,8 @@ class ScEngineLib:
         L.sc_transform_inverse.restype = c_int
         L.sc_modegemm.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_modegemm.restype = c_int
+        L.sc_modegemm_msum.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sc_modegemm_msum.restype = c_int
         L.sc_modegemm_uses_matrix_cores.argtypes = [POINTER(ModeGemmDesc)]
         L.sc_modegemm_uses_matrix_cores.restype = c_int
         L.sc_bias_grad.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
@@ -158,6 +160,12 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    def modegemm_msum(self, a_ptr, b_ptr, c_ptr, stream=0, **kw):
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        self._check(self.lib.sc_modegemm_msum(byref(d), a_ptr, b_ptr, c_ptr, stream))
 
     def modegemm_uses_matrix_cores(self, **kw):
         d = ModeGemmDesc()

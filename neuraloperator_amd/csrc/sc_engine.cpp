@@ -681,6 +681,42 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   return dispatch_modegemm_conj<4, 4>(g, d->conj_a, d->conj_b, a, b, c, st);
 }
 
+template <bool CA, bool CB>
+static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  ModeGemmArgs g = g0;
+  g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
+  g.n_pg = (int)((g.P + 4 * 2 - 1) / (4 * 2));
+  g.n_qt = (int)((g.Q + 4 - 1) / 4);
+  const int64_t total = (int64_t)g.n_mt * g.n_pg * g.n_qt;
+  SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
+}
+
+/* C[p,q] += sum_m sum_r opA(A[p,r,m]) opB(B[r,q,m]); C (strides c_sp, c_sq) zeroed by the caller */
+extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
+                                void* stream) {
+  SC_CHECK_ARG(d && A && B && C, "null argument");
+  SC_CHECK_ARG(d->P >= 0 && d->Q >= 0 && d->R >= 0 && d->n_modes >= 0, "negative extent");
+  if (d->P == 0 || d->Q == 0 || d->n_modes == 0 || d->R == 0) return 0;
+  ModeGemmArgs g;
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.a_sm = d->a_sm;
+  g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.b_sm = d->b_sm;
+  g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = 0;
+  g.b_idx = d->b_idx; g.c_idx = nullptr;
+  g.accumulate = 1;
+  SC_CHECK_ARG(((g.M + 63) / 64) * ((g.P + 7) / 8) * ((g.Q + 3) / 4) < ((int64_t)1 << 30),
+               "problem too large for one launch grid");
+  sc_stream_t st = (sc_stream_t)stream;
+  const cf32* a = (const cf32*)A;
+  const cf32* b = (const cf32*)B;
+  cf32* c = (cf32*)C;
+  if (!d->conj_a && !d->conj_b) launch_msum<false, false>(g, a, b, c, st);
+  else if (d->conj_a && !d->conj_b) launch_msum<true, false>(g, a, b, c, st);
+  else if (!d->conj_a && d->conj_b) launch_msum<false, true>(g, a, b, c, st);
+  else launch_msum<true, true>(g, a, b, c, st);
+  return sc_check_launch("k_modegemm_msum");
+}
+
 extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) {
   return d && !(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d) ? 1 : 0;
 }

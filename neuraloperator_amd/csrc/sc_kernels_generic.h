@@ -274,6 +274,88 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Mode-summed complex GEMM:  C[p,q] += sum_m sum_r opA(A[p,r,m]) * opB(B[r,q,m])
+// the gradient of a mode-INDEPENDENT operand (Tucker / CP factor matrices, spectral_convolution.py
+// :55-103): same lanes-are-modes tiles as k_modegemm, then a wave reduction over the 64 modes of
+// the tile and one atomic add per (p, q) and mode tile.  C must be zeroed by the caller.
+// ------------------------------------------------------------------------------------------
+template <int PT, int QT, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
+                cf32* __restrict__ C) {
+  SC_SHARED cf32 red[4][SC_WAVE];
+  const int tid = SC_TID;
+  const int lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int item = SC_BID_X;
+  const int mt = item / (g.n_pg * g.n_qt);
+  const int rem = item - mt * (g.n_pg * g.n_qt);
+  const int qt = rem / g.n_pg, pg = rem - qt * g.n_pg;
+  const int64_t m = (int64_t)mt * SC_WAVE + lane;
+  const int64_t p0 = ((int64_t)pg * 4 + w) * PT;
+  const int64_t q0 = (int64_t)qt * QT;
+  const bool wave_on = p0 < g.P;                            // wave-uniform; idle waves still meet the syncs
+  const bool active = m < g.M;
+  const int64_t mm = active ? m : g.M - 1;
+  const uint32_t la = (uint32_t)(mm * g.a_sm);
+  const uint32_t lb = g.b_idx ? (uint32_t)g.b_idx[mm] : (uint32_t)(mm * g.b_sm);
+  cf32 acc[PT][QT];
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) acc[pp][qq] = cf_make(0.f, 0.f);
+  if (wave_on && active) {
+    for (int64_t r = 0; r < g.R; ++r) {
+      cf32 a[PT], b[QT];
+#pragma unroll
+      for (int pp = 0; pp < PT; ++pp) {
+        const int64_t p = (p0 + pp < g.P) ? (p0 + pp) : (g.P - 1);
+        a[pp] = (A + p * g.a_sp + r * g.a_sr)[la];
+        if (CA) a[pp].y = -a[pp].y;
+      }
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) {
+        const int64_t q = (q0 + qq < g.Q) ? (q0 + qq) : (g.Q - 1);
+        b[qq] = (B + r * g.b_sr + q * g.b_sq)[lb];
+        if (CB) b[qq].y = -b[qq].y;
+      }
+#pragma unroll
+      for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+        for (int qq = 0; qq < QT; ++qq) cf_mac(acc[pp][qq], a[pp], b[qq]);
+    }
+  }
+  // wave reduction through LDS (one value at a time: these launches are small)
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      red[w][lane] = acc[pp][qq];
+      SC_WAVE_SYNC();
+#pragma unroll
+      for (int off = SC_WAVE / 2; off > 0; off >>= 1) {
+        cf32 o = cf_make(0.f, 0.f);
+        if (lane < off) o = red[w][lane + off];
+        SC_WAVE_SYNC();
+        if (lane < off) red[w][lane] = cf_add(red[w][lane], o);
+        SC_WAVE_SYNC();
+      }
+      if (lane == 0 && wave_on && p0 + pp < g.P && q0 + qq < g.Q) {
+        cf32* dst = C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq;
+        const cf32 v = red[w][0];
+#ifndef SC_EMU
+        atomicAdd(&dst->x, v.x);
+        atomicAdd(&dst->y, v.y);
+#else
+        dst->x += v.x;    // emulated workgroups run one after another, waves own different p
+        dst->y += v.y;
+#endif
+      }
+      SC_WAVE_SYNC();
+    }
+}
+
 // gbias[c] = sum_b Re(ghat[(b*channels + c) * modes_per_image + dc])
 // one wave per channel, lanes run over the batch, xor-butterfly through LDS-free wave reduction
 SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_WAVE)

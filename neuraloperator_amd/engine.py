@@ -268,6 +268,79 @@ class ModeContractDenseFn(torch.autograd.Function):
         return gx, gw
 
 
+# ------------------------------------------------------------------------------------------
+# generic mode GEMM with autograd: the pairwise steps of the factorized contractions
+# ------------------------------------------------------------------------------------------
+def _strides3(t, lead):
+    """(s0, s1, sm) in complex elements of a [lead0, lead1, M] or [lead0, lead1] (mode-independent) view."""
+    if t.dim() == 3:
+        return int(t.stride(0)), int(t.stride(1)), int(t.stride(2))
+    return int(t.stride(0)), int(t.stride(1)), 0
+
+
+def _raw_mode_gemm(a, b, n_modes, conj_a, conj_b, reduce_modes=False):
+    """a: [P, R, M] or [P, R]; b: [R, Q, M] or [R, Q]; complex64 CUDA tensors/views (any strides).
+    Returns C[P, Q, M] (or C[P, Q] = sum over modes when reduce_modes)."""
+    lib = _lib.get_lib()
+    P, R = int(a.shape[0]), int(a.shape[1])
+    Q = int(b.shape[1])
+    a_sp, a_sr, a_sm = _strides3(a, 2)
+    b_sr, b_sq, b_sm = _strides3(b, 2)
+    dev = a.device
+    with torch.cuda.device(dev):
+        if reduce_modes:
+            out = torch.zeros((P, Q), dtype=torch.complex64, device=dev)
+            fn, c = lib.modegemm_msum, dict(c_sp=Q, c_sq=1, c_sm=0)
+        else:
+            out = torch.empty((P, Q, n_modes), dtype=torch.complex64, device=dev)
+            fn, c = lib.modegemm, dict(c_sp=Q * n_modes, c_sq=n_modes, c_sm=1)
+        if P and Q and n_modes:
+            fn(a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream(), P=P, Q=Q, R=R, n_modes=n_modes,
+               a_sp=a_sp, a_sr=a_sr, a_sm=a_sm, b_sr=b_sr, b_sq=b_sq, b_sm=b_sm,
+               conj_a=int(conj_a), conj_b=int(conj_b), **c)
+    return out
+
+
+class ModeGemmFn(torch.autograd.Function):
+    """C[p,q,m] = sum_r opA(A)[p,r,m] * opB(B)[r,q,m] with either operand possibly mode-independent
+    (a 2-D tensor: Tucker / CP factor matrices).  Forward and both gradients run on sc_modegemm /
+    sc_modegemm_msum (gradient of a mode-independent operand = sum over the modes: wave reduction).
+    One pairwise step of the reference's _contract_tucker / _contract_cp einsums
+    (spectral_convolution.py:55-103) and of their autograd."""
+
+    @staticmethod
+    def forward(ctx, a, b, n_modes, conj_a, conj_b):
+        _require_gpu(a, "A")
+        _require_gpu(b, "B")
+        a = a if a.dtype == torch.complex64 else a.to(torch.complex64)
+        b = b if b.dtype == torch.complex64 else b.to(torch.complex64)
+        if a.shape[1] != b.shape[0]:
+            raise ValueError(f"inner extents differ: A {tuple(a.shape)} B {tuple(b.shape)}")
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (int(n_modes), bool(conj_a), bool(conj_b))
+        return _raw_mode_gemm(a, b, int(n_modes), conj_a, conj_b)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        M, ca, cb = ctx.cfg
+        gc = gc.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            # grad_a = sum_q gC * conj(opB(B)); conj_a: grad_A = conj(grad_a) = sum_q conj(gC) * opB(B)
+            bt = b.transpose(0, 1)
+            ga = _raw_mode_gemm(gc, bt, M, ca, cb if ca else not cb, reduce_modes=(a.dim() == 2))
+        if ctx.needs_input_grad[1]:
+            # grad_b = sum_p conj(opA(A)) * gC; conj_b: grad_B = conj(grad_b) = sum_p opA(A) * conj(gC)
+            at = a.transpose(0, 1)
+            gb = _raw_mode_gemm(at, gc, M, ca if cb else not ca, cb, reduce_modes=(b.dim() == 2))
+        return ga, gb, None, None, None
+
+
+def mode_gemm(a, b, n_modes, conj_a=False, conj_b=False):
+    return ModeGemmFn.apply(a, b, n_modes, conj_a, conj_b)
+
+
 class EngineOps:
     """The three local stages of a (mode-parallel) spectral layer on the MI355X engine."""
 

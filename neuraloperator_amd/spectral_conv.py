@@ -19,7 +19,7 @@ from torch import nn
 
 from . import engine
 from .factorized import CPWeight, DenseWeight, SpectralWeight, TuckerWeight
-from .modes import halve_last_mode
+from .modes import halve_last_mode, kept_block
 
 Number = Union[int, float]
 
@@ -185,6 +185,34 @@ class SpectralConv(BaseSpectralConv):
         if list(out_shape) != spatial:
             raise NotImplementedError(
                 "resolution_scaling_factor / output_shape that change the grid are DESIGN.md row f4")
+        if self.implementation == "factorized" and isinstance(self.weight, TuckerWeight):
+            return self._forward_tucker(x, spatial)
         return engine.SpectralConvDenseFn.apply(
             x, self._dense_weight(), self.bias, list(self.n_modes), list(self.max_n_modes),
             self.fft_norm, self.engine_flags)
+
+    def _forward_tucker(self, x, spatial):
+        """implementation="factorized" with a Tucker weight: the contraction never forms the dense
+        weight.  Pairwise order of SURVEY.md section 8(a6) (the minimum-FLOP order of the reference's
+        einsum 'abcd,fghi,bf,eg,ch,di->aecd', spectral_convolution.py:76-103):
+            T[f,g,modes] = core x_modes U_modes     (batch independent, small: torch.tensordot)
+            z[b,f,m] = sum_i xhat[b,i,m] U_in[i,f]; t[b,g,m] = sum_f z[b,f,m] T[f,g,m];
+            yhat[b,o,m] = sum_g t[b,g,m] U_out[o,g]  (three sc_modegemm launches, autograd through
+            sc_modegemm / sc_modegemm_msum)."""
+        kept, w_start = kept_block(spatial, list(self.n_modes), list(self.max_n_modes))
+        idx = (slice(None), slice(None)) + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))
+        wsl = self.weight[idx]                              # factors row-sliced to the used block
+        u_in, u_out = wsl.factors[0], wsl.factors[1]
+        t_core = wsl.core
+        for d, u in enumerate(wsl.factors[2:]):
+            t_core = torch.movedim(torch.tensordot(u, t_core, dims=([1], [2 + d])), 0, 2 + d)
+        m = 1
+        for k in kept:
+            m *= int(k)
+        ops = engine.EngineOps(self.fft_norm, self.engine_flags)
+        xhat = ops.forward_transform(x, kept)               # (B, Cin, *kept) complex64
+        b, ci = xhat.shape[:2]
+        z = engine.mode_gemm(xhat.reshape(b, ci, m), u_in, m)
+        t = engine.mode_gemm(z, t_core.reshape(t_core.shape[0], t_core.shape[1], m).contiguous(), m)
+        yhat = engine.mode_gemm(t, u_out.transpose(0, 1), m)
+        return ops.inverse_transform(yhat.reshape(b, u_out.shape[0], *kept), self.bias, spatial)

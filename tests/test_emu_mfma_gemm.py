@@ -117,3 +117,30 @@ def test_sub_block_index_tables(lib):
     ref[:, :, idx.numpy()] = np.einsum("bim,bom->iom", np.conj(x64.numpy().astype(np.complex128)),
                                        g.numpy().astype(np.complex128))
     assert rel_l2(gw.numpy(), ref) < TOL
+
+
+def test_mode_summed_gemm_factor_gradient(lib):
+    """sc_modegemm_msum: C[p,q] = sum_m sum_r conj(A[p,r,m]) B[r,q,m] (gradient of a Tucker factor),
+    strided / transposed operands and a mode-independent B."""
+    P, Q, R, M = 5, 7, 3, 70
+    a = _rand(R, P, M, seed=11)            # stored [r][p][m]: transposed view of the A operand
+    b = _rand(R, Q, M, seed=12)
+    c = torch.zeros(P, Q, dtype=torch.complex64)
+    d = _lib.ModeGemmDesc()
+    for k, v in dict(P=P, Q=Q, R=R, n_modes=M, a_sp=M, a_sr=P * M, a_sm=1, conj_a=1,
+                     b_sr=Q * M, b_sq=M, b_sm=1, c_sp=Q, c_sq=1).items():
+        setattr(d, k, v)
+    lib.modegemm_msum(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                      torch.view_as_real(c).data_ptr(), 0, **{k: getattr(d, k) for k, _ in d._fields_
+                                                             if k not in ("b_idx", "c_idx")})
+    ref = np.einsum("rpm,rqm->pq", np.conj(a.numpy().astype(np.complex128)), b.numpy().astype(np.complex128))
+    assert rel_l2(c.numpy(), ref) < TOL
+    # mode-independent B (b_sm = 0): C[p,q] = sum_m sum_r A[p,r,m] U[r,q]
+    a2 = _rand(P, R, M, seed=13)
+    u = _rand(R, Q, seed=14)
+    c2 = torch.zeros(P, Q, dtype=torch.complex64)
+    lib.modegemm_msum(torch.view_as_real(a2).data_ptr(), torch.view_as_real(u).data_ptr(),
+                      torch.view_as_real(c2).data_ptr(), 0, P=P, Q=Q, R=R, n_modes=M, a_sp=R * M, a_sr=M, a_sm=1,
+                      b_sr=Q, b_sq=1, b_sm=0, c_sp=Q, c_sq=1)
+    ref2 = np.einsum("prm,rq->pq", a2.numpy().astype(np.complex128), u.numpy().astype(np.complex128))
+    assert rel_l2(c2.numpy(), ref2) < TOL
