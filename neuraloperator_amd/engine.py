@@ -332,8 +332,18 @@ class ModeGemmFn(torch.autograd.Function):
             ga = _raw_mode_gemm(gc, bt, M, ca, cb if ca else not cb, reduce_modes=(a.dim() == 2))
         if ctx.needs_input_grad[1]:
             # grad_b = sum_p conj(opA(A)) * gC; conj_b: grad_B = conj(grad_b) = sum_p opA(A) * conj(gC)
-            at = a.transpose(0, 1)
-            gb = _raw_mode_gemm(at, gc, M, ca if cb else not ca, cb, reduce_modes=(b.dim() == 2))
+            P, Q = int(a.shape[0]), int(b.shape[1])
+            if a.dim() == 2 and b.dim() == 3 and P >= 8 * Q * M:
+                # long reduction over p, few outputs (core x last-mode-factor step of a Tucker weight):
+                # put p on the lanes -- sc_modegemm_msum with modes := p, columns := (q, m) -- instead
+                # of a handful of workgroups walking all of p serially (21.7 ms -> ~0.1 ms at rank 0.1)
+                a2 = a.transpose(0, 1).unsqueeze(1)                          # [R, 1, P]
+                g2 = gc.reshape(P, Q * M).transpose(0, 1).unsqueeze(0)       # [1, Q M, P]
+                gb = _raw_mode_gemm(a2, g2, P, ca if cb else not ca, cb, reduce_modes=True).reshape(
+                    int(b.shape[0]), Q, M)
+            else:
+                at = a.transpose(0, 1)
+                gb = _raw_mode_gemm(at, gc, M, ca if cb else not ca, cb, reduce_modes=(b.dim() == 2))
         return ga, gb, None, None, None
 
 

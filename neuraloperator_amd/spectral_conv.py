@@ -185,34 +185,70 @@ class SpectralConv(BaseSpectralConv):
         if list(out_shape) != spatial:
             raise NotImplementedError(
                 "resolution_scaling_factor / output_shape that change the grid are DESIGN.md row f4")
-        if self.implementation == "factorized" and isinstance(self.weight, TuckerWeight):
-            return self._forward_tucker(x, spatial)
+        if isinstance(self.weight, TuckerWeight) and x.is_cuda:
+            if self.implementation == "factorized":
+                return self._forward_tucker(x, spatial)
+            kept, wsl = self._used_block(spatial)           # "reconstructed": rebuild only the used block
+            return engine.SpectralConvDenseFn.apply(x, self._tucker_dense(wsl, kept), self.bias, list(kept),
+                                                    list(kept), self.fft_norm, self.engine_flags)
         return engine.SpectralConvDenseFn.apply(
             x, self._dense_weight(), self.bias, list(self.n_modes), list(self.max_n_modes),
             self.fft_norm, self.engine_flags)
+
+    # ---- Tucker weights on the engine -----------------------------------------------------------
+    def _used_block(self, spatial):
+        kept, w_start = kept_block(spatial, list(self.n_modes), list(self.max_n_modes))
+        idx = (slice(None), slice(None)) + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))
+        return kept, self.weight[idx]                       # factors row-sliced to the used block
+
+    @staticmethod
+    def _tucker_core_times_modes(wsl, kept):
+        """T[f, g, modes] = core x_modes U_modes as a chain of sc_modegemm launches (autograd through
+        ModeGemmFn).  rocBLAS' complex GEMMs behind torch.tensordot took 9-37 ms per call on these
+        skinny shapes; the whole chain is ~0.3 ms here."""
+        core = wsl.core
+        mode_f = list(wsl.factors[2:])
+        f, g = int(core.shape[0]), int(core.shape[1])
+        ranks = [int(r) for r in core.shape[2:]]
+        nd = len(mode_f)
+        # last mode dim: lanes = its modes, the core is the mode-independent operand
+        xk = core.reshape(-1, ranks[-1])
+        u = mode_f[-1]                                       # (M_N, R_N)
+        xk = engine.mode_gemm(xk, u.transpose(0, 1).unsqueeze(1), int(kept[-1]))     # (P, 1, M_N)
+        tail = int(kept[-1])
+        for d in range(nd - 2, -1, -1):                      # remaining mode dims: lanes = expanded tail
+            lead = f * g
+            for r in ranks[:d]:
+                lead *= r
+            xk = xk.reshape(lead, ranks[d], tail)
+            xk = engine.mode_gemm(xk, mode_f[d].transpose(0, 1), tail)              # (lead, M_d, tail)
+            tail *= int(kept[d])
+        return xk.reshape(f, g, tail)
+
+    def _tucker_dense(self, wsl, kept):
+        """W[i, o, modes] of the used block from the factors, on the engine (implementation="reconstructed")."""
+        t3 = self._tucker_core_times_modes(wsl, kept)
+        m = int(t3.shape[2])
+        w1 = engine.mode_gemm(wsl.factors[0], t3, m)                                  # (Cin, G, M)
+        w = engine.mode_gemm(w1, wsl.factors[1].transpose(0, 1), m)                  # (Cin, Cout, M)
+        return w.reshape(w.shape[0], w.shape[1], *kept)
 
     def _forward_tucker(self, x, spatial):
         """implementation="factorized" with a Tucker weight: the contraction never forms the dense
         weight.  Pairwise order of SURVEY.md section 8(a6) (the minimum-FLOP order of the reference's
         einsum 'abcd,fghi,bf,eg,ch,di->aecd', spectral_convolution.py:76-103):
-            T[f,g,modes] = core x_modes U_modes     (batch independent, small: torch.tensordot)
+            T[f,g,modes] = core x_modes U_modes     (batch independent)
             z[b,f,m] = sum_i xhat[b,i,m] U_in[i,f]; t[b,g,m] = sum_f z[b,f,m] T[f,g,m];
-            yhat[b,o,m] = sum_g t[b,g,m] U_out[o,g]  (three sc_modegemm launches, autograd through
-            sc_modegemm / sc_modegemm_msum)."""
-        kept, w_start = kept_block(spatial, list(self.n_modes), list(self.max_n_modes))
-        idx = (slice(None), slice(None)) + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))
-        wsl = self.weight[idx]                              # factors row-sliced to the used block
+            yhat[b,o,m] = sum_g t[b,g,m] U_out[o,g]
+        every step an sc_modegemm launch, autograd through sc_modegemm / sc_modegemm_msum."""
+        kept, wsl = self._used_block(spatial)
         u_in, u_out = wsl.factors[0], wsl.factors[1]
-        t_core = wsl.core
-        for d, u in enumerate(wsl.factors[2:]):
-            t_core = torch.movedim(torch.tensordot(u, t_core, dims=([1], [2 + d])), 0, 2 + d)
-        m = 1
-        for k in kept:
-            m *= int(k)
+        t3 = self._tucker_core_times_modes(wsl, kept)
+        m = int(t3.shape[2])
         ops = engine.EngineOps(self.fft_norm, self.engine_flags)
         xhat = ops.forward_transform(x, kept)               # (B, Cin, *kept) complex64
         b, ci = xhat.shape[:2]
         z = engine.mode_gemm(xhat.reshape(b, ci, m), u_in, m)
-        t = engine.mode_gemm(z, t_core.reshape(t_core.shape[0], t_core.shape[1], m).contiguous(), m)
+        t = engine.mode_gemm(z, t3, m)
         yhat = engine.mode_gemm(t, u_out.transpose(0, 1), m)
         return ops.inverse_transform(yhat.reshape(b, u_out.shape[0], *kept), self.bias, spatial)
