@@ -27,17 +27,19 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not is_stale():
+def build(force=False, verbose=True, out=None, defines=()):
+    """out/defines: measurement variants (scripts/) -- the product library takes neither."""
+    if out is None and not force and not is_stale():
         if verbose:
             print(f"[build] {OUT} up to date")
         return OUT
-    cmd = [find_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-x", "hip"] + [os.path.join(HERE, s) for s in SOURCES] + ["-o", OUT]
+    out = out or OUT
+    cmd = [find_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + \
+          [f"-D{d}" for d in defines] + ["-x", "hip"] + [os.path.join(HERE, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print("[build]", " ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

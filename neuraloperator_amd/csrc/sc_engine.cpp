@@ -80,7 +80,14 @@ struct sc_plan {
   // matrix-core versions of the generic passes (sc_kernels_mdft.h): tables in MFMA lane order
   bool mdft = false;
   float* m_r2c[2] = {nullptr, nullptr};
+  cf32* m_r2c_tail[2] = {nullptr, nullptr};   // last kept column on the VALU when 2J % 32 == 2
   float* m_c2r[2] = {nullptr, nullptr};
+  // LDS-staged generation of the two last-axis passes (small tables only, see sc_kernels_mdft.h)
+  float* l_r2c[2] = {nullptr, nullptr};
+  cf32* l_r2c_tail[2] = {nullptr, nullptr};
+  int l_r2c_ct = 0;                            // MFMA column tiles (tail column excluded)
+  float* l_c2r[2] = {nullptr, nullptr};
+  int l_c2r_s = 0;                             // LDS row stride of the c2r tile, floats
   float* m_ax_fwd[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   float* m_ax_inv[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   // fast path (power-of-two 2-D), see sc_kernels_fft.h
@@ -164,6 +171,21 @@ static int build_mdft_tables(sc_plan* p) {
               h[(size_t)(((ct * NG + t) * 4 + q) * 64 + lane)] = (f & 1) ? tw.y : tw.x;
             }
       rc = upload_floats(p, h, &p->m_r2c[v]);
+      if (!rc && J > 1 && (2 * J) % 32 == 2) {
+        std::vector<float> ht((size_t)(NG * 4 * 2 * 2), 0.f);
+        for (int64_t t = 0; t < NG; ++t)
+          for (int q = 0; q < 4; ++q)
+            for (int hh = 0; hh < 2; ++hh) {
+              const int64_t n = 8 * t + 4 * hh + q, j = J - 1;
+              const double s = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
+              const cf32 tw = twiddle(j, n, N, -1.0, s);
+              ht[(size_t)(((t * 4 + q) * 2 + hh) * 2 + 0)] = tw.x;
+              ht[(size_t)(((t * 4 + q) * 2 + hh) * 2 + 1)] = tw.y;
+            }
+        float* dev = nullptr;
+        rc = upload_floats(p, ht, &dev);
+        p->m_r2c_tail[v] = (cf32*)dev;
+      }
     }
   }
   {
@@ -181,6 +203,62 @@ static int build_mdft_tables(sc_plan* p) {
               h[(size_t)(((nt * JS + t) * 2 + comp) * 64 + lane)] = comp ? -tw.y : tw.x;
             }
       rc = upload_floats(p, h, &p->m_c2r[v]);
+    }
+  }
+  // LDS-staged r2c: whole table resident in LDS (<= 32 KB), at most 2 column tiles
+  if (!rc && N % 32 == 0 && N <= 256) {
+    const bool tail = J > 1 && (2 * J) % 32 == 2 && 2 * J > 32;
+    const int64_t NG = N / 8, CT = tail ? (2 * J - 2) / 32 : (2 * J + 31) / 32;
+    if (CT <= 2 && NG * CT * 256 <= 8192) {
+      p->l_r2c_ct = (int)CT;
+      for (int v = 0; v < 2 && !rc; ++v) {
+        std::vector<float> h((size_t)(CT * NG * 256), 0.f);
+        for (int64_t ct = 0; ct < CT; ++ct)
+          for (int64_t t = 0; t < NG; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int q = 0; q < 4; ++q) {
+                const int64_t f = 32 * ct + (lane & 31), j = f >> 1, n = 8 * t + 4 * (lane >> 5) + q;
+                if (j >= J) continue;
+                const double sc = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
+                const cf32 tw = twiddle(j, n, N, -1.0, sc);
+                h[(size_t)(((ct * NG + t) * 64 + lane) * 4 + q)] = (f & 1) ? tw.y : tw.x;
+              }
+        rc = upload_floats(p, h, &p->l_r2c[v]);
+        if (!rc && tail) {
+          std::vector<float> ht((size_t)(2 * N), 0.f);
+          for (int64_t n = 0; n < N; ++n) {
+            const double sc = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(J - 1, N);
+            const cf32 tw = twiddle(J - 1, n, N, -1.0, sc);
+            ht[(size_t)(2 * n)] = tw.x;
+            ht[(size_t)(2 * n + 1)] = tw.y;
+          }
+          float* dev = nullptr;
+          rc = upload_floats(p, ht, &dev);
+          p->l_r2c_tail[v] = (cf32*)dev;
+        }
+      }
+    }
+  }
+  // LDS-staged c2r: table + one 128-line tile of the spectrum within 48 KB (3+ blocks per CU)
+  if (!rc) {
+    const int64_t JS = (J + 1) / 2, NT = (N + 31) / 32;
+    const int64_t S = (J % 2) ? 2 * J : 2 * J + 2;
+    if ((NT * JS * 128 + SC_MDFT_LB * S) * 4 <= 48 * 1024) {
+      p->l_c2r_s = (int)S;
+      for (int v = 0; v < 2 && !rc; ++v) {
+        std::vector<float> h((size_t)(NT * JS * 128), 0.f);
+        for (int64_t nt = 0; nt < NT; ++nt)
+          for (int64_t t = 0; t < JS; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int64_t n = 32 * nt + (lane & 31), j = 2 * t + (lane >> 5);
+              if (j >= J || n >= N) continue;
+              const double sc = (v == SC_INV_PADDED) ? p->si * col_weight(j, N) : p->sf;
+              const cf32 tw = twiddle(j, n, N, +1.0, sc);
+              h[(size_t)(((nt * JS + t) * 64 + lane) * 2 + 0)] = tw.x;
+              h[(size_t)(((nt * JS + t) * 64 + lane) * 2 + 1)] = -tw.y;
+            }
+        rc = upload_floats(p, h, &p->l_c2r[v]);
+      }
     }
   }
   for (int d = 0; d < L && !rc; ++d) {
@@ -352,31 +430,73 @@ static void launch_r2c(const float* in, cf32* out, const DeviceTable& t, int64_t
             t.cols_pad);
 }
 
-template <int RT, int CT>
-static void launch_mdft_r2c(const float* in, cf32* out, const float* tab, int64_t lines, int N, int J, int n_ct,
-                            sc_stream_t st) {
+template <int RT, int CT, bool TAIL>
+static void launch_mdft_r2c(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
+                            int J, int n_ct, sc_stream_t st) {
   const int64_t items = (lines + 32 * RT - 1) / (32 * RT);
-  SC_LAUNCH((k_mdft_r2c<RT, CT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, (float*)out, tab, lines,
-            N, J, n_ct);
+  SC_LAUNCH((k_mdft_r2c<RT, CT, TAIL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, (float*)out, tab,
+            tail, lines, N, J, n_ct);
+}
+
+template <bool TAIL>
+static void dispatch_mdft_r2c(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
+                              int J, int n_ct, sc_stream_t st) {
+  // 8 accumulator tiles per wave by default; SC_MDFT_TILE=4 selects 4-tile waves (2-3 waves per
+  // SIMD) for A-B: measured equal on 128^3 (5.38 vs 5.43 ms/step) and slower on 1024^2 (33.1 vs 30.5)
+  const char* tile = getenv("SC_MDFT_TILE");
+  const bool big = !(tile && tile[0] == '4');
+  if (n_ct == 1) {                       // J = 17 with the tail column on the VALU: no second column tile to pad
+    if (big) launch_mdft_r2c<4, 1, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+    else launch_mdft_r2c<2, 1, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+  } else if (big) {
+    if (n_ct <= 2) launch_mdft_r2c<4, 2, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+    else if (n_ct <= 4) launch_mdft_r2c<2, 4, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+    else launch_mdft_r2c<1, 8, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+  } else {
+    if (n_ct <= 2) launch_mdft_r2c<2, 2, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+    else launch_mdft_r2c<1, 4, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
+  }
+}
+
+// tiles per block of the LDS-staged passes: amortise the table copy once the grid covers the chip 8 x over
+static int mdft_lds_tiles_per_block(int64_t lines) {
+  const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
+  int64_t tpb = n_tiles / 2048;
+  if (tpb < 1) tpb = 1;
+  if (tpb > 16) tpb = 16;
+  return (int)tpb;
+}
+
+template <int CT, bool TAIL>
+static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
+                                int J, sc_stream_t st) {
+  const int tpb = mdft_lds_tiles_per_block(lines);
+  const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
+  SC_LAUNCH((k_mdft_r2c_lds<CT, TAIL>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256),
+            (size_t)(N / 8) * CT * 1024, st, in, (float*)out, tab, tail, lines, N, J, tpb);
 }
 
 static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
-  if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
-    const int n_ct = (2 * J + 31) / 32;
-    // 8 accumulator tiles per wave by default; SC_MDFT_TILE=4 selects 4-tile waves (2-3 waves per
-    // SIMD) for A-B: measured equal on 128^3 (5.38 vs 5.43 ms/step) and slower on 1024^2 (33.1 vs 30.5)
-    const char* tile = getenv("SC_MDFT_TILE");
-    const bool big = !(tile && tile[0] == '4');
-    if (big) {
-      if (n_ct <= 2) launch_mdft_r2c<4, 2>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
-      else if (n_ct <= 4) launch_mdft_r2c<2, 4>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
-      else launch_mdft_r2c<1, 8>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+  if (p->mdft && p->l_r2c[mode] && lines < ((int64_t)1 << 36) && !getenv("SC_MDFT_NOLDS")) {
+    const float* tab = p->l_r2c[mode];
+    const cf32* tail = p->l_r2c_tail[mode];
+    if (tail) {
+      if (p->l_r2c_ct == 1) launch_mdft_r2c_lds<1, true>(in, out, tab, tail, lines, N, J, st);
+      else launch_mdft_r2c_lds<2, true>(in, out, tab, tail, lines, N, J, st);
     } else {
-      if (n_ct <= 2) launch_mdft_r2c<2, 2>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
-      else launch_mdft_r2c<1, 4>(in, out, p->m_r2c[mode], lines, N, J, n_ct, st);
+      if (p->l_r2c_ct == 1) launch_mdft_r2c_lds<1, false>(in, out, tab, tail, lines, N, J, st);
+      else launch_mdft_r2c_lds<2, false>(in, out, tab, tail, lines, N, J, st);
     }
+    return sc_check_launch("k_mdft_r2c_lds");
+  }
+  if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
+    const char* notail = getenv("SC_MDFT_NOTAIL");
+    if (p->m_r2c_tail[mode] && !notail && 2 * J > 32)
+      dispatch_mdft_r2c<true>(in, out, p->m_r2c[mode], p->m_r2c_tail[mode], lines, N, J, (2 * J - 2) / 32, st);
+    else
+      dispatch_mdft_r2c<false>(in, out, p->m_r2c[mode], nullptr, lines, N, J, (2 * J + 31) / 32, st);
     return sc_check_launch("k_mdft_r2c");
   }
   const DeviceTable& t = p->r2c[mode];
@@ -411,10 +531,29 @@ static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const 
             J, n_nt, lpi, channels);
 }
 
+template <int CT>
+static void launch_mdft_c2r_lds(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
+                                int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
+  const int tpb = mdft_lds_tiles_per_block(lines);
+  const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
+  const int n_nt = (N + 31) / 32, JS = (J + 1) / 2;
+  const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s) * sizeof(float);
+  SC_LAUNCH((k_mdft_c2r_lds<CT>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
+            (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb);
+}
+
 static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
                    int64_t lpi, int64_t channels, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
+  if (p->mdft && p->l_c2r[mode] && lines < ((int64_t)1 << 36) && (bias == nullptr || lpi % 32 == 0) &&
+      !getenv("SC_MDFT_NOLDS")) {
+    const int n_nt = (N + 31) / 32;
+    if (n_nt >= 4) launch_mdft_c2r_lds<4>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else if (n_nt >= 2) launch_mdft_c2r_lds<2>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else launch_mdft_c2r_lds<1>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    return sc_check_launch("k_mdft_c2r_lds");
+  }
   if (p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
     const int n_nt = (N + 31) / 32;
     const char* tile = getenv("SC_MDFT_TILE");
@@ -897,6 +1036,9 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
     if (p->d.flags & SC_PLAN_FFT_GEN2) return fft2d_kernel_name(which);
     return which == 0 ? "k_fft2d_fwd3" : "k_fft2d_inv3";
   }
-  if (p->mdft) return which == 0 ? (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c") : "k_mdft_c2r";
+  if (p->mdft) {
+    if (which == 0) return p->l_r2c[0] ? "k_mdft_r2c_lds" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c");
+    return p->l_c2r[0] ? "k_mdft_c2r_lds" : "k_mdft_c2r";
+  }
   return which == 0 ? "k_last_r2c" : "k_last_c2r";
 }

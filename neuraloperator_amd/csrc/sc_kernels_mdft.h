@@ -18,6 +18,18 @@
 #pragma once
 #include "sc_kernels_mfma.h"
 
+// measurement builds only (scripts/mdft_time.py): take one resource out of a pass to see what it costs
+#ifdef SC_MDFT_ABL_NOMFMA
+#define MDFT_MFMA(acc, a, b) ((acc)[0] = fmaf((a), (b), (acc)[0]))
+#else
+#define MDFT_MFMA(acc, a, b) sc_mfma_32x32x2((acc), (a), (b))
+#endif
+#ifdef SC_MDFT_ABL_NOSTORE
+#define MDFT_STORE_OK(val) ((val) == 12345.678f)
+#else
+#define MDFT_STORE_OK(val) true
+#endif
+
 // row of the 32 x 32 MFMA result held in accumulator register v of a lane in half `half`
 SC_HD int mdft_row(const int v, const int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
 
@@ -27,18 +39,28 @@ SC_HD int mdft_row(const int v, const int half) { return (v & 3) + 8 * (v >> 2) 
 //   B operand = table: tab[((ct * NG + t) * 4 + q) * 64 + lane]
 // requires N % 8 == 0 (16-byte aligned float4 loads); RT row tiles x CT column tiles per wave.
 // ------------------------------------------------------------------------------------------
-template <int RT, int CT>
+// TAIL: kept-mode counts of the form 2^k + 1 (n_modes/2 + 1 with power-of-two n_modes: the usual
+// case) put exactly one complex column past a 32-float tile boundary; a whole MFMA column tile for 2
+// of 32 columns was 47 % of this pass's matrix work at J = 17.  That column is a plain dot product
+// per line on the VALU instead (tail[(t*4 + q)*2 + h] = T[8t + 4h + q][J-1]), riding on the operand
+// registers the MFMAs already hold.
+template <int RT, int CT, bool TAIL>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
-           int64_t lines, int N, int J, int n_ct) {
+           const cf32* __restrict__ tail, int64_t lines, int N, int J, int n_ct) {
+  SC_SHARED cf32 tsum[4][64][RT];
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
   const int64_t item = (int64_t)SC_BID_X * 4 + w;               // one wave = RT row tiles
   const int64_t l0 = item * (32 * RT);
   if (l0 >= lines) return;
   const int NG = N / 8;
+  cf32 tacc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) tacc[r] = cf_make(0.f, 0.f);
 #pragma unroll 1
   for (int ct0 = 0; ct0 < n_ct; ct0 += CT) {
+    const bool do_tail = TAIL && ct0 == 0;
     sc_f32x16 acc[RT][CT];
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -51,16 +73,22 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
     for (int r = 0; r < RT; ++r) {
       int64_t line = l0 + 32 * r + col;
       if (line >= lines) line = lines - 1;
-      rowp[r] = in + line * N + 4 * half;
+      rowp[r] = in + line * N;
     }
     // operands of step t+1 are requested before the MFMAs of step t are issued (two register sets)
     float a0[RT][4], b0[CT][4], a1[RT][4], b1[CT][4];
-    auto fetch = [&](const int t, float (&a)[RT][4], float (&b)[CT][4]) {
+    cf32 w0[4], w1[4];
+    auto fetch = [&](const int t, float (&a)[RT][4], float (&b)[CT][4], cf32 (&tw)[4]) {
+      const int n0 = 8 * t + 4 * half;
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
-        const cf32 lo = *reinterpret_cast<const cf32*>(rowp[r] + 8 * t);
-        const cf32 hi = *reinterpret_cast<const cf32*>(rowp[r] + 8 * t + 2);
+#ifdef SC_MDFT_ABL_NOLOAD
+        a[r][0] = (float)(n0 + r); a[r][1] = a[r][0] + 1.f; a[r][2] = a[r][0] + 2.f; a[r][3] = a[r][0] + 3.f;
+#else
+        const cf32 lo = *reinterpret_cast<const cf32*>(rowp[r] + n0);
+        const cf32 hi = *reinterpret_cast<const cf32*>(rowp[r] + n0 + 2);
         a[r][0] = lo.x; a[r][1] = lo.y; a[r][2] = hi.x; a[r][3] = hi.y;
+#endif
       }
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
@@ -68,33 +96,47 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[c][q] = tab[(((int64_t)ct * NG + t) * 4 + q) * 64 + lane];
       }
+      if (TAIL) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tw[q] = tail[(t * 4 + q) * 2 + half];
+      }
     };
-    auto multiply = [&](const float (&a)[RT][4], const float (&b)[CT][4]) {
+    auto multiply = [&](const float (&a)[RT][4], const float (&b)[CT][4], const cf32 (&tw)[4]) {
+      if (do_tail) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            tacc[r].x = fmaf(a[r][q], tw[q].x, tacc[r].x);
+            tacc[r].y = fmaf(a[r][q], tw[q].y, tacc[r].y);
+          }
+      }
+      SC_SCHED_BARRIER();
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int c = 0; c < CT; ++c) sc_mfma_32x32x2(acc[r][c], a[r][q], b[c][q]);
+          for (int c = 0; c < CT; ++c) MDFT_MFMA(acc[r][c], a[r][q], b[c][q]);
     };
-    fetch(0, a0, b0);
+    fetch(0, a0, b0, w0);
     int t = 0;
 #pragma unroll 1
     for (; t + 1 < NG; t += 2) {                         // single-exit loop: the accumulators stay put
-      fetch(t + 1, a1, b1);
+      fetch(t + 1, a1, b1, w1);
       SC_SCHED_BARRIER();
-      multiply(a0, b0);
+      multiply(a0, b0, w0);
       SC_SCHED_BARRIER();
-      if (t + 2 < NG) fetch(t + 2, a0, b0);
+      if (t + 2 < NG) fetch(t + 2, a0, b0, w0);
       SC_SCHED_BARRIER();
-      multiply(a1, b1);
+      multiply(a1, b1, w1);
       SC_SCHED_BARRIER();
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[r][c]);
     }
-    if (t < NG) multiply(a0, b0);                        // odd step count
+    if (t < NG) multiply(a0, b0, w0);                    // odd step count
     const int64_t l0e = l0 + sc_opaque(0);               // keep the store addresses out of the loop
 #pragma unroll
     for (int r = 0; r < RT; ++r)
@@ -105,10 +147,26 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
             const int64_t line = l0e + 32 * r + mdft_row(v, half);
-            if (line < lines) out[line * 2 * J + f] = acc[r][c][v];
+            if (line < lines && MDFT_STORE_OK(acc[r][c][v])) out[line * 2 * J + f] = acc[r][c][v];
           }
         }
       }
+  }
+  if (TAIL) {
+    // the two halves of a line's dot product meet through LDS; lane (line, 0) stores column J - 1
+#pragma unroll
+    for (int r = 0; r < RT; ++r) tsum[w][lane][r] = tacc[r];
+    SC_WAVE_SYNC();
+    if (half == 0) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int64_t line = l0 + 32 * r + col;
+        if (line < lines) {
+          const cf32 o = tsum[w][lane + 32][r];
+          reinterpret_cast<cf32*>(out)[line * J + (J - 1)] = cf_add(tacc[r], o);
+        }
+      }
+    }
   }
 }
 
@@ -169,8 +227,8 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
       for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          sc_mfma_32x32x2(acc[j][c], a[j][0], d[c].x);
-          sc_mfma_32x32x2(acc[j][c], a[j][1], d[c].y);
+          MDFT_MFMA(acc[j][c], a[j][0], d[c].x);
+          MDFT_MFMA(acc[j][c], a[j][1], d[c].y);
         }
     };
     fetch(0, d0, a0);
@@ -261,8 +319,8 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
       for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          sc_mfma_32x32x2(acc[r][c], d[r].x, b[c][0]);
-          sc_mfma_32x32x2(acc[r][c], d[r].y, b[c][1]);
+          MDFT_MFMA(acc[r][c], d[r].x, b[c][0]);
+          MDFT_MFMA(acc[r][c], d[r].y, b[c][1]);
         }
     };
     fetch(0, d0, b0);
@@ -294,9 +352,280 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
 #pragma unroll
           for (int c = 0; c < CT; ++c) {
             const int n = 32 * (nt0 + c) + col;
-            if (nt0 + c < n_nt && n < N) orow[n] = acc[r][c][v] + badd;
+            if (nt0 + c < n_nt && n < N && MDFT_STORE_OK(acc[r][c][v])) {
+#ifdef SC_MDFT_PLAIN_STORE
+              orow[n] = acc[r][c][v] + badd;
+#else
+              SC_STORE_STREAM(&orow[n], acc[r][c][v] + badd);   // 2 GB written once, read by a later kernel
+#endif
+            }
           }
         }
       }
+  }
+}
+
+// ==========================================================================================
+// LDS-staged last-axis passes (generation 2 of k_mdft_r2c / k_mdft_c2r for small tables).
+//
+// What the straight-from-global kernels above cost on 128^3 / 17 kept columns (2.15 GB real tensor,
+// profiles/r01_mdft_ablation.txt): r2c 898 us, of which 677 us remain with the MFMAs AND the stores
+// taken out -- the "lane = line" operand loads (32 different 128-byte lines per load instruction) and
+// the per-wave re-read of the table from L1/L2 with a one-step prefetch are the whole bill; c2r 832 us,
+// 697 us of it without MFMAs and stores.  Here a 256-thread block owns 128 consecutive lines
+// (one contiguous span of memory), copies it global -> LDS with fully coalesced 16-byte loads, keeps
+// the WHOLE constant table in LDS for its lifetime (several tiles), and the waves read MFMA operands
+// from LDS (padded rows: conflict-free).  One 32-line row tile per wave and <= 64 accumulator
+// registers: 3-4 blocks per CU hide each other's barriers and memory latency.
+// ==========================================================================================
+#ifndef SC_EMU
+typedef float sc_f4 __attribute__((ext_vector_type(4)));
+#else
+struct alignas(16) sc_f4 {
+  float x, y, z, w;
+};
+#endif
+SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
+
+#define SC_MDFT_LB 128          // lines per block tile (4 waves x one 32-line MFMA row tile)
+
+// ------------------------------------------------------------------------------------------
+// last axis, real -> complex through LDS.  N % 32 == 0, N <= 256, CT column tiles (2J floats <= 32 CT,
+// minus the tail column when TAIL).  The tile is consumed in chunks of 32 input samples: chunk c + 1
+// sits in registers (requested right after the barrier) while chunk c is multiplied out of LDS.
+//   tab  [((ct * NG + t) * 64 + lane) * 4 + q] = T[8t + 4(lane>>5) + q][32 ct + (lane & 31)]   (floats)
+//   tail [n] = T[n][J - 1]                                                                     (cf32)
+// dynamic LDS: the table, NG * CT * 1 KB.
+// ------------------------------------------------------------------------------------------
+template <int CT, bool TAIL>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 1 ? 4 : 3))
+k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
+               const cf32* __restrict__ tail, int64_t lines, int N, int J, int tiles_per_block) {
+  constexpr int LB = SC_MDFT_LB, KC = 32, S4 = 9;            // LDS row = 36 floats = 9 float4
+  SC_DYN_SHARED(sc_f4, tabL);
+  SC_SHARED sc_f4 dat[LB * S4];
+  SC_SHARED sc_f4 tailL[TAIL ? 128 : 1];                     // 256 cf32
+  SC_SHARED cf32 tsum[TAIL ? 128 : 1];
+  const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int NC = N / KC, NG = N / 8;
+  const int64_t n_tiles = (lines + LB - 1) / LB;
+  const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
+  if (tile0 >= n_tiles) return;
+  const int my_tiles = (int)((n_tiles - tile0 < tiles_per_block) ? n_tiles - tile0 : tiles_per_block);
+  const int total = my_tiles * NC;
+
+  {
+    const sc_f4* t4 = reinterpret_cast<const sc_f4*>(tab);
+    for (int i = tid; i < NG * CT * 64; i += 256) tabL[i] = t4[i];
+    if (TAIL) {
+      const sc_f4* s4 = reinterpret_cast<const sc_f4*>(tail);
+      for (int i = tid; i < N / 2; i += 256) tailL[i] = s4[i];
+    }
+  }
+  // loader: thread (lrow, lc4) brings 16 bytes of lines lrow + 32 m, m = 0..3, per chunk
+  const int lrow = tid >> 3, lc4 = tid & 7;
+  int ld_c = 0;
+  int64_t ld_l0 = tile0 * LB;
+  sc_f4 r[4];
+  auto gload = [&]() {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      int64_t line = ld_l0 + lrow + 32 * m;
+      if (line >= lines) line = lines - 1;
+      r[m] = SC_LOAD_STREAM(reinterpret_cast<const sc_f4*>(in + line * N + ld_c * KC) + lc4);
+    }
+    if (++ld_c == NC) {
+      ld_c = 0;
+      ld_l0 += LB;
+    }
+  };
+  gload();
+
+  sc_f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+  cf32 tacc = cf_make(0.f, 0.f);
+  int c = 0;
+  int64_t l0 = tile0 * LB;
+  const int fmax = TAIL ? 2 * J - 2 : 2 * J;
+#pragma unroll 1
+  for (int g = 0; g < total; ++g) {
+    SC_SYNC();                                   // the previous chunk has been read (g = 0: tables are in)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dat[(lrow + 32 * m) * S4 + lc4] = r[m];
+    SC_SYNC();
+    if (g + 1 < total) gload();
+    const sc_f4* arow = dat + (32 * w + col) * S4 + half;
+    const sc_f4* brow = tabL + (4 * c) * 64 + lane;
+    const sc_f4* trow = tailL + (32 * c + 4 * half) / 2;
+    // operands of step s + 1 are read from LDS before the MFMAs of step s are issued
+    sc_f4 a = arow[0], b[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) b[ct] = brow[ct * NG * 64];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sc_f4 an = a, bn[CT], tw0, tw1;
+      if (s < 3) an = arow[2 * (s + 1)];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) bn[ct] = (s < 3) ? brow[(ct * NG + s + 1) * 64] : b[ct];
+      if (TAIL) {
+        tw0 = trow[4 * s];
+        tw1 = trow[4 * s + 1];
+      }
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) MDFT_MFMA(acc[ct], sc_f4_at(a, q), sc_f4_at(b[ct], q));
+      if (TAIL) {
+        tacc.x = fmaf(a.x, tw0.x, tacc.x); tacc.y = fmaf(a.x, tw0.y, tacc.y);
+        tacc.x = fmaf(a.y, tw0.z, tacc.x); tacc.y = fmaf(a.y, tw0.w, tacc.y);
+        tacc.x = fmaf(a.z, tw1.x, tacc.x); tacc.y = fmaf(a.z, tw1.y, tacc.y);
+        tacc.x = fmaf(a.w, tw1.z, tacc.x); tacc.y = fmaf(a.w, tw1.w, tacc.y);
+      }
+      a = an;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) b[ct] = bn[ct];
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) SC_PIN_ACC(acc[ct]);
+    if (++c == NC) {                             // tile finished: store its 32 x (2J) results per wave
+      const int64_t lw = l0 + 32 * w + sc_opaque(0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int f = 32 * ct + col;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int64_t line = lw + mdft_row(v, half);
+          if (f < fmax && line < lines && MDFT_STORE_OK(acc[ct][v])) out[line * 2 * J + f] = acc[ct][v];
+          acc[ct][v] = 0.f;
+        }
+      }
+      if (TAIL) {
+        if (half == 1) tsum[32 * w + col] = tacc;
+        SC_WAVE_SYNC();
+        if (half == 0) {
+          const int64_t line = lw + col;
+          if (line < lines) reinterpret_cast<cf32*>(out)[line * J + (J - 1)] = cf_add(tacc, tsum[32 * w + col]);
+        }
+        tacc = cf_make(0.f, 0.f);
+      }
+      c = 0;
+      l0 += LB;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) SC_PIN_ACC(acc[ct]);      // both paths leave the accumulators where they are
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// last axis, complex -> real through LDS.  One tile = 128 lines x J cf32 (contiguous in memory) copied
+// to rows of S floats (S/2 odd: the 8-byte operand reads of 32 lines hit 32 different bank pairs).
+//   tab [(((nt * JS + t) * 64 + lane) * 2 + comp] : comp 0 multiplies Re(in[l][2t + (lane>>5)]), comp 1 Im
+// dynamic LDS: the table (n_nt * JS * 128 floats) followed by the tile (128 * S floats).
+// A wave's 32 lines must share one bias value (lines_per_image % 32 == 0 when bias != nullptr).
+// ------------------------------------------------------------------------------------------
+template <int CT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 4 ? 3 : 4))
+k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
+               const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
+               int64_t lines_per_image, int64_t channels, int tiles_per_block) {
+  constexpr int LB = SC_MDFT_LB;
+  SC_DYN_SHARED(sc_f4, lds);
+  const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int JS = (J + 1) / 2, SC2 = S / 2;
+  const int tab4 = n_nt * JS * 32;                               // table size in float4
+  const cf32* tabL = reinterpret_cast<const cf32*>(lds);
+  cf32* dat = reinterpret_cast<cf32*>(lds + tab4);
+  const int64_t n_tiles = (lines + LB - 1) / LB;
+  const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
+  if (tile0 >= n_tiles) return;
+  const int my_tiles = (int)((n_tiles - tile0 < tiles_per_block) ? n_tiles - tile0 : tiles_per_block);
+  {
+    const sc_f4* t4 = reinterpret_cast<const sc_f4*>(tab);
+    for (int i = tid; i < tab4; i += 256) lds[i] = t4[i];
+  }
+  // copy coordinates of element tid, tid + 256, ... of a tile: (line, j) advance by (256 / J, 256 % J)
+  const int dq = 256 / J, dr = 256 - dq * J;
+  const int line_first = tid / J, j_first = tid - line_first * J;
+  const int E = LB * J;
+#pragma unroll 1
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int64_t l0 = (tile0 + ti) * LB;
+    const int64_t rem = lines - l0;
+    const int Ev = (int)((rem < LB ? rem : LB) * J);             // valid elements (ragged last tile)
+    const cf32* src = in + l0 * J;
+    SC_SYNC();                                                   // previous tile consumed / table staged
+    {
+      int line = line_first, j = j_first;
+#pragma unroll 1
+      for (int base = tid; base < E; base += 1024) {
+        cf32 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int idx = base + 256 * u;
+          if (idx >= Ev) idx = Ev - 1;                           // rows past the end repeat finite data
+          v[u] = src[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (base + 256 * u < E) dat[line * SC2 + j] = v[u];
+          j += dr;
+          line += dq;
+          if (j >= J) {
+            j -= J;
+            ++line;
+          }
+        }
+      }
+    }
+    SC_SYNC();
+    const int64_t lw = l0 + 32 * w;
+    if (lw >= lines) continue;                                   // wave-uniform; barriers stay matched below
+    const float badd = (bias != nullptr) ? bias[(lw / lines_per_image) % channels] : 0.f;
+    const cf32* drow = dat + (32 * w + col) * SC2;
+#pragma unroll 1
+    for (int nt0 = 0; nt0 < n_nt; nt0 += CT) {
+      sc_f32x16 acc[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+      const cf32* tp[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int nt = (nt0 + c < n_nt) ? nt0 + c : n_nt - 1;
+        tp[c] = tabL + (int64_t)nt * JS * 64 + lane;
+      }
+#pragma unroll 2
+      for (int t = 0; t < JS; ++t) {
+        int j = 2 * t + half;
+        if (j >= J) j = J - 1;                                   // table entry is zero there
+        const cf32 d = drow[j];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const cf32 b = tp[c][t * 64];
+          MDFT_MFMA(acc[c], d.x, b.x);
+          MDFT_MFMA(acc[c], d.y, b.y);
+        }
+      }
+      const int64_t lwe = lw + sc_opaque(0);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t line = lwe + mdft_row(v, half);
+        if (line < lines) {
+          float* orow = out + line * N;
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            const int n = 32 * (nt0 + c) + col;
+            if (nt0 + c < n_nt && n < N && MDFT_STORE_OK(acc[c][v])) SC_STORE_STREAM(&orow[n], acc[c][v] + badd);
+          }
+        }
+      }
+    }
   }
 }

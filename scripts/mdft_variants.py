@@ -1,0 +1,21 @@
+"""Build measurement variants of libsc_engine.so (ablations / A-B switches of the MFMA DFT passes)
+into scripts/abl/.  Usage: python scripts/mdft_variants.py"""
+import os, sys
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neuraloperator_amd.csrc import build as b
+
+VARIANTS = {
+    "plainst": ["SC_MDFT_PLAIN_STORE"],
+    "nostore": ["SC_MDFT_ABL_NOSTORE"],
+    "nomfma": ["SC_MDFT_ABL_NOMFMA"],
+    "noload": ["SC_MDFT_ABL_NOLOAD"],
+    "nomfma_nostore": ["SC_MDFT_ABL_NOMFMA", "SC_MDFT_ABL_NOSTORE"],
+}
+out_dir = os.path.join(ROOT, "scripts", "abl")
+os.makedirs(out_dir, exist_ok=True)
+with ThreadPoolExecutor(4) as ex:
+    list(ex.map(lambda kv: b.build(out=os.path.join(out_dir, f"libsc_{kv[0]}.so"), defines=kv[1], verbose=False),
+                VARIANTS.items()))
+print("built", sorted(os.listdir(out_dir)))

@@ -88,3 +88,32 @@ def test_emu_library_exports_and_errors(lib):
         lib.plan_create([16, 16], [17, 9])          # more modes than the spectrum has
     with pytest.raises(_lib.EngineError):
         lib.plan_create([16] * 5, [4] * 5)
+
+
+@pytest.mark.parametrize("width", [64, 48, 40])
+def test_mdft_tail_column_matches_oracle(lib, width):
+    """last axis keeps 2^k + 1 columns (J = 17): the matrix-core pass does 16 columns as one MFMA tile
+    and the 17th as a VALU dot product.  Width 64 takes the LDS-staged kernel (k_mdft_r2c_lds<.., TAIL>),
+    48 and 40 (not multiples of 32) the straight-from-global one (k_mdft_r2c<.., TAIL>)."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+    torch.manual_seed(5)
+    spatial, modes = (12, width), (6, 32)
+    nm = halve_last_mode(modes)
+    assert nm[-1] == 17
+    x = torch.randn(2, 3, *spatial)
+    w = torch.empty(3, 2, *nm, dtype=torch.cfloat).normal_(0, 0.5)
+    bias = torch.randn(2, 1, 1)
+    g = torch.randn(2, 2, *spatial)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    plan = lib.plan_create(list(spatial), list(nm))
+    assert lib.plan_kernel_name(plan, 0) == ("k_mdft_r2c_lds" if width % 32 == 0 else "k_mdft_r2c")
+    assert lib.plan_kernel_name(plan, 1) == "k_mdft_c2r_lds"
+    lib.plan_destroy(plan)
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
+    assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
+    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
