@@ -55,13 +55,29 @@ typedef struct {
   int64_t spatial[SC_MAX_DIMS];  /* d1..dN                                                  */
   int64_t kept[SC_MAX_DIMS];     /* extents of the used weight sub-block = kept modes       */
   int32_t flags;                 /* SC_PLAN_* bits                                          */
-  int32_t reserved;
+  int32_t real_col;              /* last-dim column whose imaginary part the zero-padded inverse
+                                    ignores besides DC / Nyquist: the reference zeroes Im of the
+                                    INPUT grid's last half-spectrum column before an irfft onto a
+                                    different grid (:552-556).  0 = none (DC is always ignored)  */
+  /* Optional frequency maps (host arrays, read during sc_plan_create only; NULL = default):
+   * freq[d][r], r < kept[d], is the FFT index on THIS plan's grid (0 .. spatial[d]-1, negative
+   * values taken mod spatial[d]) that kept row r of dim d reads / is written to, or
+   * SC_FREQ_DROPPED when the row falls off the grid.  Defaults: non-last dims r - floor(k/2),
+   * last dim r (real data) -- the same-grid rule of :502-517.  The host passes explicit maps
+   * for the reference's resolution-changing inverse (rows stay at their INPUT-grid FFT index,
+   * :524-559), its complex-data branch and the skip-path resample (resample.py:54-66); see
+   * neuraloperator_amd/modes.py.  A plan with maps never takes the fused power-of-two kernels. */
+  const int64_t* freq[SC_MAX_DIMS];
 } sc_plan_desc;
+#define SC_FREQ_DROPPED INT64_MIN
 
 enum {
   SC_PLAN_FORCE_GENERIC = 1, /* never take the power-of-two fast kernels (debug / A-B)     */
   SC_PLAN_FFT_GEN2 = 2,      /* fast path on the generation-2 fused kernels (A-B)           */
-  SC_PLAN_NO_MDFT = 4        /* generic passes on the VALU kernels instead of the matrix cores (A-B) */
+  SC_PLAN_NO_MDFT = 4,       /* generic passes on the VALU kernels instead of the matrix cores (A-B) */
+  SC_PLAN_COMPLEX = 8        /* complex_data=True (:439-441, 536-538): x and y are complex (n_images,
+                                d1..dN), every dim is a complex-to-complex pass, bias must be NULL
+                                (the host adds the real bias); transforms only, no sc_layer_*      */
 };
 
 /* ---- plan ------------------------------------------------------------------------------ */
@@ -74,7 +90,7 @@ size_t sc_plan_workspace_bytes(const sc_plan* plan, int64_t n_images);
 int sc_plan_is_fast(const sc_plan* plan);
 
 /* ---- transforms -------------------------------------------------------------------------- */
-/* x: real (n_images, d1..dN)  ->  xhat: complex (n_images, k1..kN)
+/* x: real (n_images, d1..dN) [complex with SC_PLAN_COMPLEX]  ->  xhat: complex (n_images, k1..kN)
  * replaces rfftn + fftshift + x[slices_x]      (spectral_convolution.py:443-449, 500-519) */
 int sc_transform_forward(const sc_plan* plan, int mode, const float* x, float* xhat,
                          int64_t n_images, void* workspace, void* stream);

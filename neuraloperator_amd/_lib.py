@@ -16,6 +16,8 @@ SC_INV_PADDED, SC_INV_ADJ_R2C = 0, 1
 SC_PLAN_FORCE_GENERIC = 1
 SC_PLAN_FFT_GEN2 = 2
 SC_PLAN_NO_MDFT = 4
+SC_PLAN_COMPLEX = 8
+SC_FREQ_DROPPED = -(1 << 63)
 SC_GEMM_FORCE_VALU = 1
 SC_GEMM_STREAM_C = 2
 SC_GEMM_PAIRED = 4
@@ -32,7 +34,8 @@ DEFAULT_LIB = os.path.join(_HERE, "libsc_engine.so")
 class PlanDesc(Structure):
     _fields_ = [("ndim", c_int32), ("fft_norm", c_int32),
                 ("spatial", c_int64 * SC_MAX_DIMS), ("kept", c_int64 * SC_MAX_DIMS),
-                ("flags", c_int32), ("reserved", c_int32)]
+                ("flags", c_int32), ("real_col", c_int32),
+                ("freq", POINTER(c_int64) * SC_MAX_DIMS)]
 
 
 class ModeGemmDesc(Structure):
@@ -119,7 +122,9 @@ class ScEngineLib:
         return self.lib.sc_version().decode()
 
     # -- plan ---------------------------------------------------------------------------
-    def plan_create(self, spatial, kept, fft_norm="forward", flags=0):
+    def plan_create(self, spatial, kept, fft_norm="forward", flags=0, freq=None, real_col=0):
+        """freq: optional per-dim frequency maps (None = the default same-grid rule, an entry of None
+        or SC_FREQ_DROPPED = row falls off the grid); see include/sc_engine.h and modes.py."""
         d = PlanDesc()
         d.ndim = len(spatial)
         if not 1 <= d.ndim <= SC_MAX_DIMS:
@@ -129,6 +134,17 @@ class ScEngineLib:
             d.spatial[i] = int(n)
             d.kept[i] = int(k)
         d.flags = flags
+        d.real_col = int(real_col)
+        keep = []                                            # host arrays must outlive the call only
+        if freq is not None:
+            for i, f in enumerate(freq):
+                if f is None:
+                    continue
+                if len(f) != int(kept[i]):
+                    raise EngineError(f"frequency map of dim {i} has {len(f)} entries, kept = {kept[i]}")
+                arr = (c_int64 * len(f))(*[SC_FREQ_DROPPED if v is None else int(v) for v in f])
+                keep.append(arr)
+                d.freq[i] = ctypes.cast(arr, POINTER(c_int64))
         h = c_void_p()
         self._check(self.lib.sc_plan_create(byref(h), byref(d)))
         return h

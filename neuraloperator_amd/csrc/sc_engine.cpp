@@ -68,8 +68,13 @@ struct sc_plan {
   int64_t n[SC_MAX_DIMS], k[SC_MAX_DIMS];
   int64_t ntot;          // prod n
   int64_t modes;         // prod k  (kept modes per image)
-  int64_t dc_index;      // flattened index of the zero frequency inside the kept block
+  int64_t dc_index;      // flattened index of the zero frequency inside the kept block (-1: not kept)
   double sf, si;         // forward / inverse norm scales
+  std::vector<int64_t> fmap[SC_MAX_DIMS];   // kept row -> FFT index on this grid (SC_FREQ_DROPPED: none)
+  bool custom_map = false;
+  bool cplx = false;     // SC_PLAN_COMPLEX: last dim is a complex-to-complex pass as well
+  DeviceTable cx_fwd[2], cx_inv[2];         // its tables, scales folded in (modes as r2c[] / c2r[])
+  int cx_fwd_jt = 0, cx_inv_jt = 0;
   // last axis
   int r2c_jt, c2r_nt;
   DeviceTable r2c[2];    // [SC_FWD_SCALED], [SC_FWD_ADJ_C2R]
@@ -142,6 +147,23 @@ static double col_weight(int64_t j, int64_t N) {
   return 2.0;
 }
 
+// table entry of the last (real-data) axis: kept column j at sample n.  `weighted` = the two modes that are
+// (the adjoint of) the zero-padded inverse: C2R column weight, inverse scale, and real_col honoured.
+static cf32 last_tw(const sc_plan* p, int64_t j, int64_t n, double sign, bool weighted) {
+  const int L = p->nd - 1;
+  const int64_t N = p->n[L], f = p->fmap[L][(size_t)j];
+  if (f == SC_FREQ_DROPPED) return cf_make(0.f, 0.f);
+  cf32 tw = twiddle(f, n, N, sign, weighted ? p->si * col_weight(f, N) : p->sf);
+  if (weighted && p->d.real_col > 0 && j == p->d.real_col) tw.y = 0.f;
+  return tw;
+}
+// table entry of a complex-to-complex axis: kept row r of dim d at sample n
+static cf32 axis_tw(const sc_plan* p, int d, int64_t r, int64_t n, double sign, double scale = 1.0) {
+  const int64_t f = p->fmap[d][(size_t)r];
+  if (f == SC_FREQ_DROPPED) return cf_make(0.f, 0.f);
+  return twiddle(f, n, p->n[d], sign, scale);
+}
+
 static int upload_floats(sc_plan* p, const std::vector<float>& host, float** out) {
   void* dev = nullptr;
   SC_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(float)));
@@ -156,7 +178,7 @@ static int build_mdft_tables(sc_plan* p) {
   const int L = p->nd - 1;
   const int64_t N = p->n[L], J = p->k[L];
   int rc = 0;
-  if (N % 8 == 0) {
+  if (N % 8 == 0 && !p->cplx) {
     const int64_t NG = N / 8, CT = (2 * J + 31) / 32;
     for (int v = 0; v < 2 && !rc; ++v) {
       std::vector<float> h((size_t)(CT * NG * 4 * 64), 0.f);
@@ -166,8 +188,7 @@ static int build_mdft_tables(sc_plan* p) {
             for (int lane = 0; lane < 64; ++lane) {
               const int64_t f = 32 * ct + (lane & 31), j = f >> 1, n = 8 * t + 4 * (lane >> 5) + q;
               if (j >= J || n >= N) continue;
-              const double s = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
-              const cf32 tw = twiddle(j, n, N, -1.0, s);
+              const cf32 tw = last_tw(p, j, n, -1.0, v != SC_FWD_SCALED);
               h[(size_t)(((ct * NG + t) * 4 + q) * 64 + lane)] = (f & 1) ? tw.y : tw.x;
             }
       rc = upload_floats(p, h, &p->m_r2c[v]);
@@ -177,8 +198,7 @@ static int build_mdft_tables(sc_plan* p) {
           for (int q = 0; q < 4; ++q)
             for (int hh = 0; hh < 2; ++hh) {
               const int64_t n = 8 * t + 4 * hh + q, j = J - 1;
-              const double s = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
-              const cf32 tw = twiddle(j, n, N, -1.0, s);
+              const cf32 tw = last_tw(p, j, n, -1.0, v != SC_FWD_SCALED);
               ht[(size_t)(((t * 4 + q) * 2 + hh) * 2 + 0)] = tw.x;
               ht[(size_t)(((t * 4 + q) * 2 + hh) * 2 + 1)] = tw.y;
             }
@@ -188,7 +208,7 @@ static int build_mdft_tables(sc_plan* p) {
       }
     }
   }
-  {
+  if (!p->cplx) {
     const int64_t JS = (J + 1) / 2, NT = (N + 31) / 32;
     for (int v = 0; v < 2 && !rc; ++v) {
       std::vector<float> h((size_t)(NT * JS * 2 * 64), 0.f);
@@ -198,15 +218,14 @@ static int build_mdft_tables(sc_plan* p) {
             for (int lane = 0; lane < 64; ++lane) {
               const int64_t n = 32 * nt + (lane & 31), j = 2 * t + (lane >> 5);
               if (j >= J || n >= N) continue;
-              const double s = (v == SC_INV_PADDED) ? p->si * col_weight(j, N) : p->sf;
-              const cf32 tw = twiddle(j, n, N, +1.0, s);
+              const cf32 tw = last_tw(p, j, n, +1.0, v == SC_INV_PADDED);
               h[(size_t)(((nt * JS + t) * 2 + comp) * 64 + lane)] = comp ? -tw.y : tw.x;
             }
       rc = upload_floats(p, h, &p->m_c2r[v]);
     }
   }
   // LDS-staged r2c: whole table resident in LDS (<= 32 KB), at most 2 column tiles
-  if (!rc && N % 32 == 0 && N <= 256) {
+  if (!rc && !p->cplx && N % 32 == 0 && N <= 256) {
     const bool tail = J > 1 && (2 * J) % 32 == 2 && 2 * J > 32;
     const int64_t NG = N / 8, CT = tail ? (2 * J - 2) / 32 : (2 * J + 31) / 32;
     if (CT <= 2 && NG * CT * 256 <= 8192) {
@@ -219,16 +238,14 @@ static int build_mdft_tables(sc_plan* p) {
               for (int q = 0; q < 4; ++q) {
                 const int64_t f = 32 * ct + (lane & 31), j = f >> 1, n = 8 * t + 4 * (lane >> 5) + q;
                 if (j >= J) continue;
-                const double sc = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
-                const cf32 tw = twiddle(j, n, N, -1.0, sc);
+                const cf32 tw = last_tw(p, j, n, -1.0, v != SC_FWD_SCALED);
                 h[(size_t)(((ct * NG + t) * 64 + lane) * 4 + q)] = (f & 1) ? tw.y : tw.x;
               }
         rc = upload_floats(p, h, &p->l_r2c[v]);
         if (!rc && tail) {
           std::vector<float> ht((size_t)(2 * N), 0.f);
           for (int64_t n = 0; n < N; ++n) {
-            const double sc = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(J - 1, N);
-            const cf32 tw = twiddle(J - 1, n, N, -1.0, sc);
+            const cf32 tw = last_tw(p, J - 1, n, -1.0, v != SC_FWD_SCALED);
             ht[(size_t)(2 * n)] = tw.x;
             ht[(size_t)(2 * n + 1)] = tw.y;
           }
@@ -240,7 +257,7 @@ static int build_mdft_tables(sc_plan* p) {
     }
   }
   // LDS-staged c2r: table + one 128-line tile of the spectrum within 48 KB (3+ blocks per CU)
-  if (!rc) {
+  if (!rc && !p->cplx) {
     const int64_t JS = (J + 1) / 2, NT = (N + 31) / 32;
     const int64_t S = (J % 2) ? 2 * J : 2 * J + 2;
     if ((NT * JS * 128 + SC_MDFT_LB * S) * 4 <= 48 * 1024) {
@@ -252,8 +269,7 @@ static int build_mdft_tables(sc_plan* p) {
             for (int lane = 0; lane < 64; ++lane) {
               const int64_t n = 32 * nt + (lane & 31), j = 2 * t + (lane >> 5);
               if (j >= J || n >= N) continue;
-              const double sc = (v == SC_INV_PADDED) ? p->si * col_weight(j, N) : p->sf;
-              const cf32 tw = twiddle(j, n, N, +1.0, sc);
+              const cf32 tw = last_tw(p, j, n, +1.0, v == SC_INV_PADDED);
               h[(size_t)(((nt * JS + t) * 64 + lane) * 2 + 0)] = tw.x;
               h[(size_t)(((nt * JS + t) * 64 + lane) * 2 + 1)] = -tw.y;
             }
@@ -275,7 +291,7 @@ static int build_mdft_tables(sc_plan* p) {
               const int row = lane & 31;
               const int64_t j = 16 * jt + (row >> 1), n = 2 * sidx + (lane >> 5);
               if (j >= Jout || n >= Nin) continue;
-              const cf32 tw = dir ? twiddle(n - Kd / 2, j, Nd, +1.0, 1.0) : twiddle(j - Kd / 2, n, Nd, -1.0, 1.0);
+              const cf32 tw = dir ? axis_tw(p, d, n, j, +1.0) : axis_tw(p, d, j, n, -1.0);
               float val;
               if (comp == 0) val = (row & 1) ? tw.y : tw.x;        // times Re(in): (Re out, Im out)
               else val = (row & 1) ? tw.x : -tw.y;                 // times Im(in)
@@ -296,6 +312,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   p->nd = desc->ndim;
   p->ntot = 1;
   p->modes = 1;
+  p->cplx = (desc->flags & SC_PLAN_COMPLEX) != 0;
   for (int d = 0; d < p->nd; ++d) {
     p->n[d] = desc->spatial[d];
     p->k[d] = desc->kept[d];
@@ -303,31 +320,80 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
       delete p;
       return sc_fail("sc_engine: spatial sizes and kept modes must be >= 1");
     }
-    const int64_t lim = (d == p->nd - 1) ? (p->n[d] / 2 + 1) : p->n[d];
-    if (p->k[d] > lim) {
-      delete p;
-      return sc_fail("sc_engine: kept modes exceed the available spectrum");
+    const bool half = (d == p->nd - 1) && !p->cplx;       // real data: the last dim has n/2+1 columns
+    const int64_t lim = half ? (p->n[d] / 2 + 1) : p->n[d];
+    p->fmap[d].resize((size_t)p->k[d]);
+    if (desc->freq[d]) {
+      p->custom_map = true;
+      for (int64_t r = 0; r < p->k[d]; ++r) {
+        int64_t f = desc->freq[d][r];
+        if (f != SC_FREQ_DROPPED) {
+          if (f <= -p->n[d] || f >= p->n[d] || (half && (f < 0 || f >= lim))) {
+            delete p;
+            return sc_fail("sc_engine: frequency map entry outside the grid");
+          }
+          if (f < 0) f += p->n[d];
+        }
+        p->fmap[d][(size_t)r] = f;
+      }
+    } else {
+      if (p->k[d] > lim) {
+        delete p;
+        return sc_fail("sc_engine: kept modes exceed the available spectrum");
+      }
+      for (int64_t r = 0; r < p->k[d]; ++r) {
+        int64_t f = half ? r : r - p->k[d] / 2;
+        if (f < 0) f += p->n[d];
+        p->fmap[d][(size_t)r] = f;
+      }
     }
     p->ntot *= p->n[d];
     p->modes *= p->k[d];
   }
+  p->d.real_col = (desc->real_col > 0 && desc->real_col < p->k[p->nd - 1] && !p->cplx) ? desc->real_col : 0;
+  for (int d = 0; d < SC_MAX_DIMS; ++d) p->d.freq[d] = nullptr;      // host arrays are not kept
   switch (desc->fft_norm) {
     case SC_NORM_FORWARD: p->sf = 1.0 / (double)p->ntot; p->si = 1.0; break;
     case SC_NORM_BACKWARD: p->sf = 1.0; p->si = 1.0 / (double)p->ntot; break;
     case SC_NORM_ORTHO: p->sf = p->si = 1.0 / std::sqrt((double)p->ntot); break;
     default: delete p; return sc_fail("sc_engine: unknown fft_norm");
   }
-  // zero-frequency position inside the kept block (row k//2 in every non-last dim, col 0)
+  // zero-frequency position inside the kept block (-1 when a map leaves it out: no DC-based bias gradient)
   p->dc_index = 0;
   for (int d = 0; d < p->nd; ++d) {
-    const int64_t r = (d == p->nd - 1) ? 0 : p->k[d] / 2;
-    p->dc_index = p->dc_index * p->k[d] + r;
+    int64_t r0 = -1;
+    for (int64_t r = 0; r < p->k[d]; ++r)
+      if (p->fmap[d][(size_t)r] == 0) {
+        r0 = r;
+        break;
+      }
+    if (r0 < 0 || p->dc_index < 0) p->dc_index = -1;
+    else p->dc_index = p->dc_index * p->k[d] + r0;
   }
 
   const int L = p->nd - 1;
   const int64_t N = p->n[L], J = p->k[L];
   int rc = 0;
-  {
+  if (p->cplx) {
+    // complex data: the last dim is one more complex-to-complex pass (inner = 1) with the norm folded in
+    static const int cc[] = {4, 8, 16};
+    p->cx_fwd_jt = pick_tile(J, cc, 3, 1);
+    p->cx_inv_jt = pick_tile(N, cc, 3, 1);
+    for (int v = 0; v < 2 && !rc; ++v) {
+      const int64_t Jpad = round_up(J, p->cx_fwd_jt);
+      std::vector<cf32> h((size_t)N * Jpad, cf_make(0.f, 0.f));
+      for (int64_t n = 0; n < N; ++n)
+        for (int64_t j = 0; j < J; ++j) h[(size_t)n * Jpad + j] = axis_tw(p, L, j, n, -1.0, v == SC_FWD_SCALED ? p->sf : p->si);
+      rc = upload_table(p, h, (int)N, (int)Jpad, &p->cx_fwd[v]);
+    }
+    for (int v = 0; v < 2 && !rc; ++v) {
+      const int64_t Npad = round_up(N, p->cx_inv_jt);
+      std::vector<cf32> h((size_t)J * Npad, cf_make(0.f, 0.f));
+      for (int64_t j = 0; j < J; ++j)
+        for (int64_t n = 0; n < N; ++n) h[(size_t)j * Npad + n] = axis_tw(p, L, j, n, +1.0, v == SC_INV_PADDED ? p->si : p->sf);
+      rc = upload_table(p, h, (int)J, (int)Npad, &p->cx_inv[v]);
+    }
+  } else {
     static const int c1[] = {2, 3, 4, 5, 8, 9, 16, 17};
     p->r2c_jt = pick_tile(J, c1, 8, 4);
     const int64_t Jpad = round_up(J, 4 * p->r2c_jt);
@@ -335,8 +401,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
       std::vector<cf32> h((size_t)N * Jpad, cf_make(0.f, 0.f));
       for (int64_t n = 0; n < N; ++n)
         for (int64_t j = 0; j < J; ++j) {
-          const double s = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(j, N);
-          h[(size_t)n * Jpad + j] = twiddle(j, n, N, -1.0, s);
+          h[(size_t)n * Jpad + j] = last_tw(p, j, n, -1.0, v != SC_FWD_SCALED);
         }
       rc = upload_table(p, h, (int)N, (int)Jpad, &p->r2c[v]);
     }
@@ -347,8 +412,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
       std::vector<cf32> h((size_t)J * Npad, cf_make(0.f, 0.f));
       for (int64_t j = 0; j < J; ++j)
         for (int64_t n = 0; n < N; ++n) {
-          const double s = (v == SC_INV_PADDED) ? p->si * col_weight(j, N) : p->sf;
-          h[(size_t)j * Npad + n] = twiddle(j, n, N, +1.0, s);
+          h[(size_t)j * Npad + n] = last_tw(p, j, n, +1.0, v == SC_INV_PADDED);
         }
       rc = upload_table(p, h, (int)J, (int)Npad, &p->c2r[v]);
     }
@@ -362,18 +426,18 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
       const int64_t Jpad = round_up(Kd, p->ax_fwd_jt[d]);
       std::vector<cf32> h((size_t)Nd * Jpad, cf_make(0.f, 0.f));
       for (int64_t n = 0; n < Nd; ++n)
-        for (int64_t j = 0; j < Kd; ++j) h[(size_t)n * Jpad + j] = twiddle(j - Kd / 2, n, Nd, -1.0, 1.0);
+        for (int64_t j = 0; j < Kd; ++j) h[(size_t)n * Jpad + j] = axis_tw(p, d, j, n, -1.0);
       rc = upload_table(p, h, (int)Nd, (int)Jpad, &p->ax_fwd[d]);
     }
     if (!rc) {
       const int64_t Jpad = round_up(Nd, p->ax_inv_jt[d]);
       std::vector<cf32> h((size_t)Kd * Jpad, cf_make(0.f, 0.f));
       for (int64_t kk = 0; kk < Kd; ++kk)
-        for (int64_t hh = 0; hh < Nd; ++hh) h[(size_t)kk * Jpad + hh] = twiddle(kk - Kd / 2, hh, Nd, +1.0, 1.0);
+        for (int64_t hh = 0; hh < Nd; ++hh) h[(size_t)kk * Jpad + hh] = axis_tw(p, d, kk, hh, +1.0);
       rc = upload_table(p, h, (int)Kd, (int)Jpad, &p->ax_inv[d]);
     }
   }
-  if (!rc && !(desc->flags & SC_PLAN_FORCE_GENERIC)) {
+  if (!rc && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !p->custom_map && !p->cplx) {
     std::string why;
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
@@ -642,13 +706,19 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
   const int L = p->nd - 1;
   int64_t lines = n_images;
   for (int d = 0; d < L; ++d) lines *= p->n[d];
-  if (p->nd == 1) return run_r2c(p, mode, x, (cf32*)xhat, lines, st);
+  // last dim first: real -> complex, or (complex data) one more axis pass with inner = 1
+  auto last_pass = [&](cf32* dst) {
+    if (p->cplx)
+      return run_axis(p->cx_fwd_jt, (const cf32*)x, dst, p->cx_fwd[mode], lines, (int)p->n[L], (int)p->k[L], 1, st);
+    return run_r2c(p, mode, x, dst, lines, st);
+  };
+  if (p->nd == 1) return last_pass((cf32*)xhat);
   SC_CHECK_ARG(workspace, "workspace required");
   int64_t s1, s2;
   generic_ws_sizes(p, n_images, &s1, &s2);
   cf32* bufA = (cf32*)workspace;
   cf32* bufB = bufA + s1;
-  int rc = run_r2c(p, mode, x, bufA, lines, st);
+  int rc = last_pass(bufA);
   if (rc) return rc;
   cf32* cur = bufA;
   int64_t inner = p->k[L];
@@ -686,7 +756,13 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
   int64_t lpi = 1;
   for (int d = 0; d < L; ++d) lpi *= p->n[d];
   const int64_t lines = n_images * lpi;
-  if (p->nd == 1) return run_c2r(p, mode, (const cf32*)yhat, y, bias, lines, lpi, channels, st);
+  SC_CHECK_ARG(!(p->cplx && bias), "complex-data plans take no bias (the host adds it)");
+  auto last_pass = [&](const cf32* src) {
+    if (p->cplx)
+      return run_axis(p->cx_inv_jt, src, (cf32*)y, p->cx_inv[mode], lines, (int)p->k[L], (int)p->n[L], 1, st);
+    return run_c2r(p, mode, src, y, bias, lines, lpi, channels, st);
+  };
+  if (p->nd == 1) return last_pass((const cf32*)yhat);
   SC_CHECK_ARG(workspace, "workspace required");
   int64_t s1, s2;
   generic_ws_sizes(p, n_images, &s1, &s2);
@@ -709,7 +785,7 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
     cur = dst;
     outer *= p->n[d];
   }
-  return run_c2r(p, mode, cur, y, bias, lines, lpi, channels, st);
+  return last_pass(cur);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -863,6 +939,7 @@ extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) {
 extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,
                             float* gbias, void* stream) {
   SC_CHECK_ARG(p && ghat && gbias, "null argument");
+  SC_CHECK_ARG(p->dc_index >= 0, "the plan's frequency maps keep no zero-frequency coefficient");
   if (channels <= 0) return 0;
   SC_LAUNCH(k_bias_grad, dim3((unsigned)channels), dim3(SC_WAVE), 0, (sc_stream_t)stream, (const cf32*)ghat,
             gbias, batch, channels, p->modes, p->dc_index);
@@ -938,6 +1015,7 @@ extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const 
                                 const float* bias, float* y, float* xhat_saved, void* workspace,
                                 void* stream) {
   SC_CHECK_ARG(p && L, "null argument");
+  SC_CHECK_ARG(!p->cplx, "complex-data plans: call the transform / contraction stages (no fused layer)");
   const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
   if (B == 0) return 0;                      // empty batch: nothing to do (pointers may be null)
   SC_CHECK_ARG(x && w && y && xhat_saved && workspace, "null argument");
@@ -968,6 +1046,7 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
                                  const float* xhat_saved, const float* w, float* gx, float* gw,
                                  float* gbias, void* workspace, void* stream) {
   SC_CHECK_ARG(p && L, "null argument");
+  SC_CHECK_ARG(!p->cplx, "complex-data plans: call the transform / contraction stages (no fused layer)");
   const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
   if (B == 0) {                              // empty batch: gradients of the parameters are zero
     if (gw) SC_CHECK_HIP(hipMemsetAsync(gw, 0, (size_t)Ci * Co * weight_slab(p, L) * sizeof(cf32), (sc_stream_t)stream));
@@ -1036,6 +1115,7 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
     if (p->d.flags & SC_PLAN_FFT_GEN2) return fft2d_kernel_name(which);
     return which == 0 ? "k_fft2d_fwd3" : "k_fft2d_inv3";
   }
+  if (p->cplx) return "k_axis_pass";
   if (p->mdft) {
     if (which == 0) return p->l_r2c[0] ? "k_mdft_r2c_lds" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c");
     return p->l_c2r[0] ? "k_mdft_c2r_lds" : "k_mdft_c2r";

@@ -11,6 +11,7 @@ import torch
 from . import _lib
 from .modes import kept_block
 
+SC_PLAN_COMPLEX = _lib.SC_PLAN_COMPLEX
 _PLAN_LOCK = threading.Lock()
 _PLANS = {}
 
@@ -23,16 +24,24 @@ def _require_gpu(t, what="input"):
             "to a 'cuda' device.")
 
 
-def get_plan(device, spatial, kept, fft_norm="forward", flags=0):
-    """Cached ``sc_plan`` for (device, spatial sizes, kept modes, norm)."""
+def _freeze(freq):
+    if freq is None:
+        return None
+    return tuple(None if f is None else tuple(f) for f in freq)
+
+
+def get_plan(device, spatial, kept, fft_norm="forward", flags=0, freq=None, real_col=0):
+    """Cached ``sc_plan`` for (device, spatial sizes, kept modes, norm, frequency maps)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),
-           tuple(int(s) for s in spatial), tuple(int(k) for k in kept), fft_norm, flags)
+           tuple(int(s) for s in spatial), tuple(int(k) for k in kept), fft_norm, flags,
+           _freeze(freq), int(real_col))
     with _PLAN_LOCK:
         plan = _PLANS.get(key)
         if plan is None:
             lib = _lib.get_lib()
             with torch.cuda.device(key[0]):
-                plan = lib.plan_create(key[1], key[2], fft_norm=fft_norm, flags=flags)
+                plan = lib.plan_create(key[1], key[2], fft_norm=fft_norm, flags=flags, freq=freq,
+                                       real_col=real_col)
             _PLANS[key] = plan
     return plan
 
@@ -131,13 +140,18 @@ class TransformForwardFn(torch.autograd.Function):
     forward = SC_FWD_SCALED, backward = its adjoint SC_INV_ADJ_R2C."""
 
     @staticmethod
-    def forward(ctx, x, kept, fft_norm, flags):
+    def forward(ctx, x, kept, fft_norm, flags, freq=None):
         _require_gpu(x)
         lib = _lib.get_lib()
-        x = x.contiguous().float()
+        cplx = bool(flags & _lib.SC_PLAN_COMPLEX)
+        if cplx:
+            x = torch.view_as_real(x.contiguous().to(torch.complex64)).contiguous()
+            spatial = list(x.shape[2:-1])
+        else:
+            x = x.contiguous().float()
+            spatial = list(x.shape[2:])
         b, c = x.shape[:2]
-        spatial = list(x.shape[2:])
-        plan = get_plan(x.device, spatial, kept, fft_norm, flags)
+        plan = get_plan(x.device, spatial, kept, fft_norm, flags, freq)
         with torch.cuda.device(x.device):
             ws = _ws(lib.plan_workspace_bytes(plan, b * c), x.device)
             xhat = torch.empty((b, c, *kept, 2), dtype=torch.float32, device=x.device)
@@ -145,6 +159,7 @@ class TransformForwardFn(torch.autograd.Function):
                                   ws.data_ptr(), _stream())
         ctx.plan = plan
         ctx.x_shape = tuple(x.shape)
+        ctx.cplx = cplx
         return torch.view_as_complex(xhat)
 
     @staticmethod
@@ -157,7 +172,9 @@ class TransformForwardFn(torch.autograd.Function):
             gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=g.device)
             lib.transform_inverse(ctx.plan, _lib.SC_INV_ADJ_R2C, g.data_ptr(), 0, c, gx.data_ptr(),
                                   b * c, ws.data_ptr(), _stream())
-        return gx, None, None, None
+        if ctx.cplx:
+            gx = torch.view_as_complex(gx)
+        return gx, None, None, None, None
 
 
 class TransformInverseFn(torch.autograd.Function):
@@ -165,29 +182,36 @@ class TransformInverseFn(torch.autograd.Function):
     forward = SC_INV_PADDED, backward = its adjoint SC_FWD_ADJ_C2R (bias grad from DC)."""
 
     @staticmethod
-    def forward(ctx, yhat, bias, spatial, fft_norm, flags):
+    def forward(ctx, yhat, bias, spatial, fft_norm, flags, freq=None, real_col=0):
         _require_gpu(yhat)
         lib = _lib.get_lib()
+        cplx = bool(flags & _lib.SC_PLAN_COMPLEX)
+        if cplx and bias is not None:
+            raise ValueError("complex-data inverse transform takes no bias (add it afterwards)")
         yh = torch.view_as_real(yhat.contiguous().to(torch.complex64)).contiguous()
         b, c = yh.shape[:2]
         kept = list(yh.shape[2:-1])
-        plan = get_plan(yh.device, spatial, kept, fft_norm, flags)
+        plan = get_plan(yh.device, spatial, kept, fft_norm, flags, freq, real_col)
         with torch.cuda.device(yh.device):
             ws = _ws(lib.plan_workspace_bytes(plan, b * c), yh.device)
-            y = torch.empty((b, c, *spatial), dtype=torch.float32, device=yh.device)
+            y = torch.empty((b, c, *spatial) + ((2,) if cplx else ()), dtype=torch.float32, device=yh.device)
             bias_flat = None if bias is None else bias.detach().reshape(-1).float().contiguous()
             lib.transform_inverse(plan, _lib.SC_INV_PADDED, yh.data_ptr(),
                                   0 if bias_flat is None else bias_flat.data_ptr(), c,
                                   y.data_ptr(), b * c, ws.data_ptr(), _stream())
         ctx.plan = plan
         ctx.kept = kept
+        ctx.cplx = cplx
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
-        return y
+        return torch.view_as_complex(y) if cplx else y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.get_lib()
-        gy = gy.contiguous().float()
+        if ctx.cplx:
+            gy = torch.view_as_real(gy.contiguous().to(torch.complex64)).contiguous()
+        else:
+            gy = gy.contiguous().float()
         b, c = gy.shape[:2]
         with torch.cuda.device(gy.device):
             ws = _ws(lib.plan_workspace_bytes(ctx.plan, b * c), gy.device)
@@ -199,7 +223,7 @@ class TransformInverseFn(torch.autograd.Function):
                 gb = torch.empty(c, dtype=torch.float32, device=gy.device)
                 lib.bias_grad(ctx.plan, ghat.data_ptr(), b, c, gb.data_ptr(), _stream())
                 gb = gb.reshape(ctx.bias_shape)
-        return torch.view_as_complex(ghat), gb, None, None, None
+        return torch.view_as_complex(ghat), gb, None, None, None, None, None
 
 
 def _cview(t):
@@ -357,11 +381,11 @@ class EngineOps:
     def __init__(self, fft_norm="forward", flags=0):
         self.fft_norm, self.flags = fft_norm, flags
 
-    def forward_transform(self, x, kept):
-        return TransformForwardFn.apply(x, list(kept), self.fft_norm, self.flags)
+    def forward_transform(self, x, kept, freq=None):
+        return TransformForwardFn.apply(x, list(kept), self.fft_norm, self.flags, freq)
 
     def contract(self, xhat, w):
         return ModeContractDenseFn.apply(xhat, w)
 
-    def inverse_transform(self, yhat, bias, spatial):
-        return TransformInverseFn.apply(yhat, bias, list(spatial), self.fft_norm, self.flags)
+    def inverse_transform(self, yhat, bias, spatial, freq=None, real_col=0):
+        return TransformInverseFn.apply(yhat, bias, list(spatial), self.fft_norm, self.flags, freq, real_col)

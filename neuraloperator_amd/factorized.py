@@ -6,7 +6,7 @@ third-party class.  These containers give the drop-in module the same surface th
 reference's consumers touch:
 
 * state-dict names ``weight.tensor`` (Dense), ``weight.core`` + ``weight.factors.{i}``
-  (Tucker), ``weight.weights`` + ``weight.factors.{i}`` (CP)
+  (Tucker), ``weight.weights`` + ``weight.factors.{i}`` (CP), ``weight.factors.{i}`` (TT)
 * ``.shape``, ``.name``, ``.normal_()``, ``.to_tensor()``, ``w[slices]`` (factor-row slicing
   for Tucker/CP), and use as a tensor in torch functions (``torch.zeros_like(w)``,
   ``w += ...``) as neuralop/training/incremental.py:215-238 does.
@@ -59,8 +59,33 @@ def cp_rank(shape: Sequence[int], rank) -> int:
     return max(int(round(float(rank) * np.prod(shape) / np.sum(shape))), 1)
 
 
+def tt_rank(shape: Sequence[int], rank) -> List[int]:
+    """Bond ranks (1, r_1, .., r_{n-1}, 1) of a tensor-train: tensorly's validate_tt_rank with its
+    default constant_rank=False -- r_k proportional to the mean of the two neighbouring mode sizes,
+    the proportion solving  sum(r_k s_k r_{k+1}) = rank * prod(shape)."""
+    n = len(shape)
+    if isinstance(rank, (list, tuple)):
+        r = [int(x) for x in rank]
+        if len(r) != n + 1 or r[0] != 1 or r[-1] != 1:
+            raise ValueError(f"a TT rank for {n} modes has {n + 1} entries and starts/ends with 1, got {r}")
+        return r
+    if isinstance(rank, int) and not isinstance(rank, bool):
+        return [1] + [int(rank)] * (n - 1) + [1]
+    if rank == "same":
+        rank = 1.0
+    rank = float(rank)
+    if n == 1:
+        return [1, 1]
+    avg = [(shape[i] + shape[i + 1]) / 2.0 for i in range(n - 1)]
+    a = sum(avg[i - 1] * shape[i] * avg[i] for i in range(1, n - 1)) if n > 2 else avg[0] ** 2 * shape[0]
+    b = shape[0] * avg[0] + shape[-1] * avg[-1]
+    c = -float(np.prod(shape)) * rank
+    frac = (-b + math.sqrt(b * b - 4 * a * c)) / (2 * a)
+    return [1] + [max(int(round(d * frac)), 1) for d in avg] + [1]
+
+
 class SpectralWeight(nn.Module):
-    """Base container.  Sub-classes: DenseWeight, TuckerWeight, CPWeight."""
+    """Base container.  Sub-classes: DenseWeight, TuckerWeight, CPWeight, TTWeight."""
 
     name = "Base"
 
@@ -79,9 +104,11 @@ class SpectralWeight(nn.Module):
             r = cp_rank(shape, rank)
             return CPWeight(torch.ones(r, dtype=dtype, device=device),
                             [torch.empty(s, r, dtype=dtype, device=device) for s in shape])
-        raise NotImplementedError(
-            f"factorization={factorization!r}: only Dense / Tucker / CP weights are implemented "
-            "in the MI355X engine (TT is listed as a later row in DESIGN.md)")
+        if f in ("tt", "complextt"):
+            r = tt_rank(shape, rank)
+            return TTWeight([torch.empty(r[i], s, r[i + 1], dtype=dtype, device=device)
+                             for i, s in enumerate(shape)])
+        raise ValueError(f"factorization={factorization!r}: expected Dense, Tucker, CP or TT")
 
     # tensor-like behaviour for host code (incremental trainer, regularisers)
     @classmethod
@@ -224,3 +251,43 @@ class CPWeight(SpectralWeight):
         idx = _slices(idx, len(self.factors))
         return CPWeight(self.weights, [f[s, :] for f, s in zip(self.factors, idx)],
                         as_parameters=False)
+
+
+class TTWeight(SpectralWeight):
+    """Tensor-train cores G_k of shape (r_k, s_k, r_{k+1}), r_0 = r_n = 1
+    (the operand layout of the reference's ``_contract_tt``, spectral_convolution.py:106-132)."""
+
+    name = "TT"
+
+    def __init__(self, factors, as_parameters=True):
+        super().__init__()
+        if as_parameters:
+            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+        else:
+            self.factors = list(factors)
+
+    @property
+    def shape(self):
+        return torch.Size([f.shape[1] for f in self.factors])
+
+    @property
+    def rank(self):
+        return tuple(int(f.shape[0]) for f in self.factors) + (1,)
+
+    def normal_(self, mean=0.0, std=1.0):
+        r = float(np.prod(self.rank))
+        std_f = (std / r) ** (1.0 / len(self.factors))
+        with torch.no_grad():
+            for f in self.factors:
+                f.normal_(0, std_f)
+        return self
+
+    def to_tensor(self):
+        res = self.factors[0]                               # (1, s_0, r_1)
+        for f in self.factors[1:]:
+            res = torch.tensordot(res, f, dims=([res.ndim - 1], [0]))
+        return res.squeeze(0).squeeze(-1)
+
+    def __getitem__(self, idx):
+        idx = _slices(idx, len(self.factors))
+        return TTWeight([f[:, s, :] for f, s in zip(self.factors, idx)], as_parameters=False)

@@ -8,9 +8,10 @@ output_shape=None)``, ``transform(x, output_shape=None)``, mutable ``n_modes``,
 (fno_block.py:210-240) runs the MI355X engine for every Fourier layer.
 
 All arithmetic of the layer is in libsc_engine.so; this file is argument checking and
-autograd plumbing.  Variants outside the engine's envelope raise NotImplementedError
-(no silent PyTorch fallback): complex_data, separable, half/mixed block precision,
-resolution change, TT factorization.
+autograd plumbing.  Dense / Tucker / CP / TT weights, separable weights, complex data and
+resolution-changing layers (``resolution_scaling_factor`` / ``output_shape``, with the reference's
+end-padding behaviour) all run on the engine; half / mixed block precision raises
+NotImplementedError (the engine's spectral arithmetic is fp32) -- there is no silent PyTorch fallback.
 """
 from typing import List, Optional, Tuple, Union
 
@@ -18,7 +19,8 @@ import torch
 from torch import nn
 
 from . import engine
-from .factorized import CPWeight, DenseWeight, SpectralWeight, TuckerWeight
+from .factorized import CPWeight, DenseWeight, SpectralWeight, TTWeight, TuckerWeight
+from . import modes
 from .modes import halve_last_mode, kept_block
 
 Number = Union[int, float]
@@ -78,8 +80,6 @@ class SpectralConv(BaseSpectralConv):
         engine_flags: int = 0,
     ):
         super().__init__(device=device)
-        if complex_data:
-            raise NotImplementedError("complex_data=True is not on the MI355X engine yet (DESIGN.md, row f4)")
         if fno_block_precision != "full":
             raise NotImplementedError(
                 f"fno_block_precision={fno_block_precision!r}: the engine computes the spectral path "
@@ -126,9 +126,10 @@ class SpectralConv(BaseSpectralConv):
                     f"to out_channels, but got in_channels={in_channels} and "
                     f"out_channels={out_channels}",
                 )
-            raise NotImplementedError("separable=True is not on the MI355X engine yet (DESIGN.md, row f4)")
+            weight_shape = (in_channels, *self.max_n_modes)                # :347-353
+        else:
+            weight_shape = (in_channels, out_channels, *self.max_n_modes)
         self.separable = separable
-        weight_shape = (in_channels, out_channels, *self.max_n_modes)
 
         tensor_kwargs = decomposition_kwargs if decomposition_kwargs is not None else {}
         self.weight = SpectralWeight.new(
@@ -153,7 +154,22 @@ class SpectralConv(BaseSpectralConv):
             out_shape = in_shape
         if in_shape == out_shape:
             return x
-        raise NotImplementedError("resolution change (resample of the skip path) is DESIGN.md row f4")
+        return self._resample(x, out_shape)
+
+    def _resample(self, x, out_shape):
+        """``resample(x, 1.0, spatial dims, output_shape)`` of neuralop/layers/resample.py:7-71: 1-d linear and
+        2-d bicubic interpolation are ATen's interpolators exactly as in the reference (:49-52); 3-d and
+        up is the spectral resample (:54-66) on the engine -- truncated forward transform on the old grid,
+        zero-padded inverse on the new one, rows by the resample's own convention (modes.resample_block)."""
+        nd = x.ndim - 2
+        out_shape = [int(v) for v in out_shape]
+        if nd == 1:
+            return torch.nn.functional.interpolate(x, size=out_shape[0], mode="linear", align_corners=True)
+        if nd == 2:
+            return torch.nn.functional.interpolate(x, size=tuple(out_shape), mode="bicubic", align_corners=True)
+        kept, fa, fs = modes.resample_block(list(x.shape[2:]), out_shape)
+        ops = engine.EngineOps("forward", self.engine_flags)
+        return ops.inverse_transform(ops.forward_transform(x.float(), kept, fa), None, out_shape, fs)
 
     @property
     def n_modes(self):
@@ -182,9 +198,15 @@ class SpectralConv(BaseSpectralConv):
             out_shape = [round(s * r) for (s, r) in zip(spatial, self.resolution_scaling_factor)]
         if output_shape is not None:
             out_shape = list(output_shape)
-        if list(out_shape) != spatial:
-            raise NotImplementedError(
-                "resolution_scaling_factor / output_shape that change the grid are DESIGN.md row f4")
+        out_shape = [int(v) for v in out_shape]
+        if self.complex_data or out_shape != spatial:
+            return self._forward_staged(x, spatial, out_shape)
+        if self.separable:
+            return self._forward_separable(x, spatial)
+        if isinstance(self.weight, TTWeight) and x.is_cuda:
+            kept, wsl = self._used_block(spatial)
+            return engine.SpectralConvDenseFn.apply(x, self._tt_dense(wsl, kept), self.bias, list(kept),
+                                                    list(kept), self.fft_norm, self.engine_flags)
         if isinstance(self.weight, TuckerWeight) and x.is_cuda:
             if self.implementation == "factorized":
                 return self._forward_tucker(x, spatial)
@@ -198,8 +220,82 @@ class SpectralConv(BaseSpectralConv):
     # ---- Tucker weights on the engine -----------------------------------------------------------
     def _used_block(self, spatial):
         kept, w_start = kept_block(spatial, list(self.n_modes), list(self.max_n_modes))
-        idx = (slice(None), slice(None)) + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))
+        lead = (slice(None),) if self.separable else (slice(None), slice(None))       # :471-474
+        idx = lead + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))
         return kept, self.weight[idx]                       # factors row-sliced to the used block
+
+    # ---- complex data / a different output grid: stage by stage with two plans --------------------
+    def _block_dense(self, wsl, kept):
+        """dense (Cin, Cout, *kept) -- (C, *kept) when separable -- tensor of the used weight block"""
+        if torch.is_tensor(wsl):
+            return wsl
+        if not self.separable and isinstance(wsl, TuckerWeight):
+            return self._tucker_dense(wsl, kept)
+        if not self.separable and isinstance(wsl, TTWeight):
+            return self._tt_dense(wsl, kept)
+        return wsl.to_tensor()
+
+    def _forward_staged(self, x, spatial, out_shape):
+        """Forward transform on the input grid, contraction, inverse transform onto ``out_shape`` with the
+        reference's placement of the kept rows (modes.synthesis_freqs: rows keep their input-grid FFT
+        index, spectral_convolution.py:524-559), each its own plan; complex data (:439-441, 536-538)
+        takes the same route with complex-to-complex passes in every dim."""
+        cplx = self.complex_data
+        if cplx:
+            kept, w_start = modes.kept_block_complex(spatial, list(self.n_modes), list(self.max_n_modes))
+        else:
+            kept, w_start = kept_block(spatial, list(self.n_modes), list(self.max_n_modes))
+        lead = (slice(None),) if self.separable else (slice(None), slice(None))
+        wsl = self.weight[lead + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))]
+        w = self._block_dense(wsl, kept)
+        fa = modes.analysis_freqs(spatial, kept, cplx)
+        fs, real_col = modes.synthesis_freqs(spatial, out_shape, kept, cplx)
+        ops = engine.EngineOps(self.fft_norm, self.engine_flags | (engine.SC_PLAN_COMPLEX if cplx else 0))
+        xhat = ops.forward_transform(x, kept, fa)
+        if self.separable:
+            b, c = xhat.shape[:2]
+            m = c
+            for k in kept:
+                m *= int(k)
+            yhat = engine.mode_gemm(xhat.reshape(b, 1, m), w.reshape(1, 1, m), m).reshape(b, c, *kept)
+        else:
+            yhat = ops.contract(xhat, w)
+        if cplx:                          # real bias added to a complex field: elementwise glue (:567-568)
+            y = ops.inverse_transform(yhat, None, out_shape, fs)
+            return y if self.bias is None else y + self.bias
+        return ops.inverse_transform(yhat, self.bias, out_shape, fs, real_col)
+
+    # ---- depth-wise (separable) weights -----------------------------------------------------------
+    def _forward_separable(self, x, spatial):
+        """yhat[b,c,m] = xhat[b,c,m] * w[c,m] (``_contract_dense_separable``, spectral_convolution.py:49-52;
+        factorized separable weights are rebuilt first, the identity test_spectral_convolution.py:54-65
+        pins).  One sc_modegemm launch with (channel, mode) as its lane index and R = Q = 1; its
+        autograd is ModeGemmFn's."""
+        kept, wsl = self._used_block(spatial)
+        w = wsl if torch.is_tensor(wsl) else wsl.to_tensor()                       # (C, *kept)
+        ops = engine.EngineOps(self.fft_norm, self.engine_flags)
+        xhat = ops.forward_transform(x, kept)                                      # (B, C, *kept)
+        b, c = xhat.shape[:2]
+        m = c
+        for k in kept:
+            m *= int(k)
+        yhat = engine.mode_gemm(xhat.reshape(b, 1, m), w.reshape(1, 1, m), m)
+        return ops.inverse_transform(yhat.reshape(b, c, *kept), self.bias, spatial)
+
+    # ---- tensor-train weights on the engine -----------------------------------------------------
+    @staticmethod
+    def _tt_dense(wsl, kept):
+        """W[i, o, modes] of the used block from the TT cores, left to right, every step an sc_modegemm
+        launch whose lanes are the (s_k, r_{k+1}) pairs of the core being absorbed -- the dense weight
+        the reference's ``_contract_tt`` einsum (spectral_convolution.py:106-132) is equivalent to."""
+        cores = list(wsl.factors)
+        res = cores[0].reshape(cores[0].shape[1], cores[0].shape[2])              # (s_0, r_1)
+        for g in cores[1:]:
+            r, sk, rn = (int(v) for v in g.shape)
+            lanes = sk * rn
+            res = engine.mode_gemm(res, g.reshape(r, 1, lanes), lanes)            # (P, 1, s_k r_{k+1})
+            res = res.reshape(-1, rn)
+        return res.reshape(*[int(c.shape[1]) for c in cores])
 
     @staticmethod
     def _tucker_core_times_modes(wsl, kept):

@@ -47,6 +47,37 @@ FACT_CASES = [
 ]
 
 
+# name, ctor kwargs, B, Cin, Cout, spatial, n_modes (ctor arg), forward output_shape
+VARIANT_CASES = [
+    ("sep_2d", dict(separable=True), 2, 4, 4, (16, 16), (8, 8), None),
+    ("sep_3d_odd", dict(separable=True), 2, 3, 3, (9, 11, 8), (5, 7, 4), None),
+    ("sep_tucker_2d", dict(separable=True, factorization="Tucker", rank=0.5, implementation="factorized"),
+     2, 4, 4, (16, 16), (8, 8), None),
+    ("tt_2d", dict(factorization="TT", rank=0.5, implementation="factorized"), 2, 4, 4, (16, 16), (8, 8), None),
+    ("tt_3d", dict(factorization="TT", rank=0.5, implementation="factorized"), 1, 3, 3, (8, 8, 8), (4, 4, 4), None),
+    ("res_2d_up2", dict(resolution_scaling_factor=2), 2, 4, 4, (16, 16), (8, 8), None),
+    ("res_2d_half", dict(resolution_scaling_factor=0.5), 2, 4, 4, (16, 16), (8, 8), None),
+    ("res_2d_shape", dict(), 2, 4, 3, (16, 16), (8, 8), (24, 20)),
+    ("res_2d_odd", dict(), 2, 3, 4, (9, 11), (5, 7), (13, 8)),
+    ("res_2d_allmodes", dict(), 2, 4, 4, (16, 16), (16, 16), (12, 10)),
+    ("res_2d_up_allmodes", dict(), 2, 3, 3, (8, 8), (8, 8), (12, 12)),   # Im of input column n/2 is zeroed (:552-556)
+    ("res_3d", dict(resolution_scaling_factor=[2, 1, 0.5]), 2, 4, 4, (8, 8, 8), (4, 4, 4), None),
+    ("res_1d", dict(resolution_scaling_factor=1.5), 2, 4, 4, (16,), (8,), None),
+    ("cplx_2d", dict(complex_data=True), 2, 4, 4, (16, 16), (8, 8), None),
+    ("cplx_2d_odd", dict(complex_data=True), 2, 3, 4, (9, 11), (5, 6), None),
+    ("cplx_3d_res", dict(complex_data=True), 2, 4, 4, (8, 6, 10), (4, 4, 6), (10, 6, 7)),
+    ("cplx_1d", dict(complex_data=True), 2, 4, 4, (16,), (6,), None),
+]
+
+# skip-path resample (SpectralConv.transform -> resample.py:7-71): name, spatial, output_shape
+TRANSFORM_CASES = [
+    ("xform_1d", (16,), (24,)),
+    ("xform_2d", (12, 10), (18, 7)),
+    ("xform_3d", (8, 8, 8), (12, 6, 10)),
+    ("xform_3d_odd", (9, 7, 6), (5, 10, 9)),
+]
+
+
 def _np(t):
     return t.detach().cpu().numpy()
 
@@ -101,6 +132,43 @@ def gen_fact(ref, name, fac, b, ci, co, spatial, n_modes, rank, seed):
     return out
 
 
+def gen_variant(ref, name, kw, b, ci, co, spatial, n_modes, output_shape, seed):
+    """Any constructor variant: stores every parameter of the weight container (state-dict order) and
+    its gradient, the constructor kwargs as JSON, and what the verbatim module returned."""
+    import json
+    torch.manual_seed(seed)
+    conv = ref.SpectralConv(ci, co, n_modes, **kw)
+    with torch.no_grad():
+        for p in conv.weight.parameters():
+            p.copy_(torch.randn_like(p) * 0.5)
+    cplx = bool(kw.get("complex_data", False))
+    x = torch.randn(b, ci, *spatial, dtype=torch.cfloat if cplx else torch.float32, requires_grad=True)
+    y = conv(x, output_shape=output_shape) if output_shape is not None else conv(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    out = dict(x=_np(x), bias=_np(conv.bias), g=_np(g), y=_np(y), gx=_np(x.grad), gbias=_np(conv.bias.grad),
+               w_dense=_np(conv.weight.to_tensor()), ctor_n_modes=np.array(n_modes),
+               n_modes_attr=np.array(conv.n_modes), max_n_modes_attr=np.array(conv.max_n_modes),
+               output_shape=np.array(output_shape if output_shape is not None else []),
+               ctor_kwargs=np.array(json.dumps(kw)), weight_kind=np.array(type(conv.weight).__name__))
+    for i, (pn, p) in enumerate(conv.weight.named_parameters()):
+        out[f"param_{i}"] = _np(p)
+        out[f"g_param_{i}"] = _np(p.grad)
+        out[f"param_name_{i}"] = np.array(pn)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+    return out
+
+
+def gen_transform(ref, name, spatial, output_shape, seed):
+    torch.manual_seed(seed)
+    conv = ref.SpectralConv(2, 2, tuple(4 for _ in spatial))
+    x = torch.randn(2, 3, *spatial)
+    t = conv.transform(x, output_shape=tuple(output_shape))
+    out = dict(x=_np(x), t=_np(t), output_shape=np.array(output_shape))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+    return out
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     ref = ref_verbatim.load_reference()
@@ -111,6 +179,12 @@ def main():
     for i, case in enumerate(FACT_CASES):
         o = gen_fact(ref, *case, seed=2000 + i)
         print(f"{case[0]:32s} y{o['y'].shape} |y|={np.abs(o['y']).mean():.3f}")
+    for i, case in enumerate(VARIANT_CASES):
+        o = gen_variant(ref, *case, seed=3000 + i)
+        print(f"{case[0]:32s} y{o['y'].shape} |y|={np.abs(o['y']).mean():.3f}")
+    for i, case in enumerate(TRANSFORM_CASES):
+        o = gen_transform(ref, *case, seed=4000 + i)
+        print(f"{case[0]:32s} t{o['t'].shape}")
     total = sum(os.path.getsize(os.path.join(GOLDEN_DIR, f)) for f in os.listdir(GOLDEN_DIR))
     print(f"golden dir: {total/1024:.0f} KiB")
 

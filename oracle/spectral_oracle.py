@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference SpectralConv hot path.
 
-Two independent statements of the same maths (real-valued data, no resolution
-change, ``fft_norm="forward"`` unless said otherwise):
+Two independent statements of the same maths (``fft_norm="forward"`` unless said
+otherwise).  ``forward_torch`` also restates the separable, complex-data and
+resolution-changing branches; ``forward_np64`` covers real data on an unchanged grid:
 
 ``forward_torch``   op-for-op torch restatement of
     /root/reference/neuralop/layers/spectral_convolution.py:417-570
@@ -34,9 +35,10 @@ def halve_last(n_modes, complex_data=False):
     return n
 
 
-def weight_slices(spatial, n_modes_h, max_n_modes):
+def weight_slices(spatial, n_modes_h, max_n_modes, complex_data=False):
     """Which sub-block of the stored weight is used and which signed frequencies
-    it multiplies.  Follows spectral_convolution.py:465-519 (real data).
+    it multiplies.  Follows spectral_convolution.py:465-519 (complex data: every dim is
+    treated like a non-last dim, :475-479).
 
     spatial      : input spatial sizes
     n_modes_h    : the module's ``n_modes`` attribute (last entry already halved)
@@ -48,21 +50,25 @@ def weight_slices(spatial, n_modes_h, max_n_modes):
     """
     nd = len(spatial)
     fft_size = list(spatial)
-    fft_size[-1] = fft_size[-1] // 2 + 1
+    if not complex_data:
+        fft_size[-1] = fft_size[-1] // 2 + 1
     starts = [mx - min(sz, nm) for sz, nm, mx in zip(fft_size, n_modes_h, max_n_modes)]
     sl = []
-    for d in range(nd - 1):
+    n_centred = nd if complex_data else nd - 1
+    for d in range(n_centred):
         s = starts[d]
         sl.append(slice(s // 2, -s // 2) if s else slice(s, None))
-    sl.append(slice(None, -starts[-1]) if starts[-1] else slice(None))
+    if not complex_data:
+        sl.append(slice(None, -starts[-1]) if starts[-1] else slice(None))
     kept = [len(range(*s.indices(mx))) for s, mx in zip(sl, max_n_modes)]
     freqs = []
-    for d in range(nd - 1):
+    for d in range(n_centred):
         k = kept[d]
         freqs.append(np.arange(-(k // 2), k // 2 + k % 2))
-    k = kept[-1]
-    # spectral_convolution.py:514-517: last dim keeps columns [:k] (all if k >= fft_size)
-    freqs.append(np.arange(min(k, fft_size[-1])))
+    if not complex_data:
+        k = kept[-1]
+        # spectral_convolution.py:514-517: last dim keeps columns [:k] (all if k >= fft_size)
+        freqs.append(np.arange(min(k, fft_size[-1])))
     return sl, freqs
 
 
@@ -105,6 +111,26 @@ def reconstruct_cp(weights, factors):
     return res.sum(-1)
 
 
+def reconstruct_tt(cores):
+    """Dense tensor of a tensor-train with cores (r_k, s_k, r_{k+1})."""
+    res = cores[0]
+    for g in cores[1:]:
+        res = torch.einsum("...a,abc->...bc", res, g)
+    return res.squeeze(0).squeeze(-1)
+
+
+def contract_tt(x, cores):
+    """``abcd, r0 b r1, r1 e r2, r2 c r3, r3 d r4 -> aecd`` (spectral_convolution.py:106-132): cores over
+    (in, out, modes...), contracted left to right after absorbing the in-channel core into x."""
+    nd = x.ndim - 2
+    m = _SYMS[7:7 + nd]
+    z = torch.einsum(f"ab{m},pbq->aq{m}", x, cores[0])            # r0 = 1 summed away, q = r1
+    z = torch.einsum(f"aq{m},qer->aer{m}", z, cores[1])           # out-channel core, r = r2
+    for d in range(nd):                                           # mode cores: Hadamard over m[d]
+        z = torch.einsum(f"aer{m},r{m[d]}s->aes{m}", z, cores[2 + d])
+    return z.squeeze(2)
+
+
 def contract_tucker(x, core, factors):
     """``abcd,fghi,bf,eg,ch,di->aecd`` (spectral_convolution.py:76-103) evaluated in the
     min-FLOP pairwise order of SURVEY.md section 8 row a6:
@@ -141,50 +167,69 @@ def contract_cp(x, weights, factors):
 # forward, torch restatement of spectral_convolution.py:417-570
 # --------------------------------------------------------------------------
 def forward_torch(x, weight, bias, n_modes_h, max_n_modes=None, fft_norm="forward",
-                  contract=contract_dense, enforce_hermitian_symmetry=True):
-    """x: (B, Cin, *spatial) real.  weight: dense (Cin, Cout, *max_n_modes) complex, or
-    whatever ``contract`` expects after slicing through ``weight_fn``.
-    n_modes_h: module ``n_modes`` (last already halved)."""
+                  contract=contract_dense, enforce_hermitian_symmetry=True, separable=False,
+                  output_shape=None, complex_data=False):
+    """x: (B, Cin, *spatial) real (complex when ``complex_data``).  weight: dense
+    (Cin, Cout, *max_n_modes) complex -- (C, *max_n_modes) when ``separable`` -- or a callable
+    ``weight(mode_slices)`` returning whatever ``contract`` expects.
+    n_modes_h: module ``n_modes`` (last already halved for real data).
+    output_shape: spatial sizes of the result when they differ from the input's (the module's
+    ``resolution_scaling_factor`` / ``output_shape``, :524-528)."""
     nd = x.ndim - 2
     spatial = list(x.shape[2:])
     if max_n_modes is None:
         max_n_modes = list(n_modes_h)
     fft_size = list(spatial)
-    fft_size[-1] = fft_size[-1] // 2 + 1
+    if not complex_data:
+        fft_size[-1] = fft_size[-1] // 2 + 1
     fft_dims = list(range(-nd, 0))
 
-    xh = torch.fft.rfftn(x, norm=fft_norm, dim=fft_dims)                      # :443
+    if complex_data:                                                          # :439-441
+        xh = torch.fft.fftn(x, norm=fft_norm, dim=fft_dims)
+        shift_dims = fft_dims
+    else:
+        xh = torch.fft.rfftn(x, norm=fft_norm, dim=fft_dims)                  # :443
+        shift_dims = fft_dims[:-1]
     if nd > 1:
-        xh = torch.fft.fftshift(xh, dim=fft_dims[:-1])                        # :446-449
+        xh = torch.fft.fftshift(xh, dim=shift_dims)                           # :446-449
 
-    w_sl, freqs = weight_slices(spatial, n_modes_h, max_n_modes)
-    wk = weight[(slice(None), slice(None)) + tuple(w_sl)] if torch.is_tensor(weight) \
-        else weight(tuple(w_sl))
+    w_sl, freqs = weight_slices(spatial, n_modes_h, max_n_modes, complex_data)
+    lead = (slice(None),) if separable else (slice(None), slice(None))         # :471-474
+    wk = weight[lead + tuple(w_sl)] if torch.is_tensor(weight) else weight(tuple(w_sl))
     kept = [len(f) for f in freqs]
-    cout = wk.shape[1] if torch.is_tensor(wk) else wk.out_channels
+    if separable:
+        cout = x.shape[1]
+        contract = contract_dense_separable if contract is contract_dense else contract
+    else:
+        cout = wk.shape[1] if torch.is_tensor(wk) else wk.out_channels
 
     sl_x = [slice(None), slice(None)]
-    for d in range(nd - 1):                                                    # :502-512
+    for d in range(nd):                                                        # :502-512
         c = fft_size[d] // 2
         k = kept[d]
         sl_x.append(slice(c - k // 2, c + k // 2 + k % 2))
-    sl_x.append(slice(None, kept[-1]))                                         # :514-517
+    # :514-517 -- the last slice is replaced by [:k] (real AND complex data: with complex data
+    # the reference therefore multiplies the first k shifted columns, not the centred ones)
+    sl_x[-1] = slice(None, kept[-1]) if kept[-1] < fft_size[-1] else slice(None)
     sl_x = tuple(sl_x)
 
     out_fft = torch.zeros([x.shape[0], cout, *fft_size], dtype=xh.dtype)       # :460-462
     out_fft[sl_x] = contract(xh[sl_x], wk)                                     # :520-522
+    out_sizes = list(spatial) if output_shape is None else list(output_shape)  # :524-528
     if nd > 1:
-        out_fft = torch.fft.ifftshift(out_fft, dim=fft_dims[:-1])             # :531-532
-    if enforce_hermitian_symmetry:                                             # :547-559
+        out_fft = torch.fft.ifftshift(out_fft, dim=fft_dims[:-1])             # :531-532 (never the last dim)
+    if complex_data:                                                           # :536-538
+        y = torch.fft.ifftn(out_fft, s=out_sizes, dim=fft_dims, norm=fft_norm)
+    elif enforce_hermitian_symmetry:                                           # :547-559
         if nd > 1:
-            out_fft = torch.fft.ifftn(out_fft, s=spatial[:-1], dim=fft_dims[:-1], norm=fft_norm)
+            out_fft = torch.fft.ifftn(out_fft, s=out_sizes[:-1], dim=fft_dims[:-1], norm=fft_norm)
         out_fft = out_fft.clone()
         out_fft[..., 0].imag.zero_()
-        if spatial[-1] % 2 == 0:
+        if out_sizes[-1] % 2 == 0:
             out_fft[..., -1].imag.zero_()
-        y = torch.fft.irfft(out_fft, n=spatial[-1], dim=-1, norm=fft_norm)
+        y = torch.fft.irfft(out_fft, n=out_sizes[-1], dim=-1, norm=fft_norm)
     else:                                                                      # :564
-        y = torch.fft.irfftn(out_fft, s=spatial, dim=fft_dims, norm=fft_norm)
+        y = torch.fft.irfftn(out_fft, s=out_sizes, dim=fft_dims, norm=fft_norm)
     if bias is not None:
         y = y + bias                                                           # :567-568
     return y

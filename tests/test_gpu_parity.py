@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DENSE_GOLDEN, FACT_GOLDEN, load_golden
+from conftest import DENSE_GOLDEN, FACT_GOLDEN, golden_names, load_golden
 from engine_runner import layer_fwd_bwd, rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -292,3 +292,59 @@ def test_module_factorized_matches_dense(fac):
     y.sum().backward()
     for p in conv.parameters():
         assert p.grad is not None and torch.isfinite(torch.view_as_real(p.grad)).all()
+
+
+# ------------------------------------------------------------------------------------------
+# constructor variants of the drop-in module against golden vectors of the verbatim reference:
+# separable, TT, resolution_scaling_factor / output_shape, complex_data, skip-path transform
+# ------------------------------------------------------------------------------------------
+VARIANT_GOLDEN = [n for n in golden_names() if n.startswith(("sep_", "tt_", "res_", "cplx_"))]
+
+
+@pytest.mark.parametrize("name", VARIANT_GOLDEN)
+def test_module_variants_match_golden(name):
+    import json
+    from neuraloperator_amd import SpectralConv
+    g = load_golden(name)
+    kw = json.loads(str(g["ctor_kwargs"]))
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    ci, co = x.shape[1], g["y"].shape[1]
+    n_par = sum(1 for k in g if k.startswith("param_name_"))
+    if str(g["weight_kind"]) == "TTTensor":
+        # the rank RULE is tensorly's and unpinned by any reference test: take the bond ranks
+        # of the fixture's cores so that the contraction itself is what gets compared
+        kw["rank"] = [int(g[f"param_{i}"].shape[0]) for i in range(n_par)] + [1]
+    conv = SpectralConv(ci, co, tuple(int(v) for v in g["ctor_n_modes"]), **kw).to(dev)
+    assert list(conv.n_modes) == [int(v) for v in g["n_modes_attr"]]
+    params = dict(conv.weight.named_parameters())
+    assert len(params) == n_par
+    with torch.no_grad():
+        for i in range(n_par):
+            p = params[str(g[f"param_name_{i}"])]
+            assert tuple(p.shape) == tuple(g[f"param_{i}"].shape), (i, p.shape)
+            p.copy_(torch.from_numpy(g[f"param_{i}"]))
+        conv.bias.copy_(torch.from_numpy(g["bias"]))
+    out_shape = tuple(int(v) for v in g["output_shape"]) or None
+    y = conv(x, output_shape=out_shape) if out_shape else conv(x)
+    assert tuple(y.shape) == tuple(g["y"].shape) and y.dtype == torch.from_numpy(g["y"]).dtype
+    y.backward(torch.from_numpy(g["g"]).to(dev))
+    assert rel_l2(y.detach().cpu().numpy(), g["y"]) < TOL
+    assert rel_l2(x.grad.cpu().numpy(), g["gx"]) < TOL
+    assert rel_l2(conv.bias.grad.cpu().numpy(), g["gbias"]) < TOL
+    for i in range(n_par):
+        p = params[str(g[f"param_name_{i}"])]
+        assert rel_l2(p.grad.cpu().numpy(), g[f"g_param_{i}"]) < TOL, str(g[f"param_name_{i}"])
+
+
+@pytest.mark.parametrize("name", golden_names("xform_"))
+def test_module_transform_matches_golden(name):
+    """SpectralConv.transform (the skip path of a resolution-changing FNO block, fno_block.py:380-384)"""
+    from neuraloperator_amd import SpectralConv
+    g = load_golden(name)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(g["x"]).to(dev)
+    conv = SpectralConv(2, 2, tuple(4 for _ in x.shape[2:])).to(dev)
+    t = conv.transform(x, output_shape=tuple(int(v) for v in g["output_shape"]))
+    assert rel_l2(t.cpu().numpy(), g["t"]) < TOL
+    assert conv.transform(x) is x                                   # identity without a resolution change
