@@ -207,6 +207,12 @@ class SpectralConv(BaseSpectralConv):
             kept, wsl = self._used_block(spatial)
             return engine.SpectralConvDenseFn.apply(x, self._tt_dense(wsl, kept), self.bias, list(kept),
                                                     list(kept), self.fft_norm, self.engine_flags)
+        if isinstance(self.weight, CPWeight) and x.is_cuda:
+            if self.implementation == "factorized":
+                return self._forward_cp(x, spatial)
+            kept, wsl = self._used_block(spatial)
+            return engine.SpectralConvDenseFn.apply(x, self._cp_dense(wsl, kept), self.bias, list(kept),
+                                                    list(kept), self.fft_norm, self.engine_flags)
         if isinstance(self.weight, TuckerWeight) and x.is_cuda:
             if self.implementation == "factorized":
                 return self._forward_tucker(x, spatial)
@@ -233,6 +239,8 @@ class SpectralConv(BaseSpectralConv):
             return self._tucker_dense(wsl, kept)
         if not self.separable and isinstance(wsl, TTWeight):
             return self._tt_dense(wsl, kept)
+        if not self.separable and isinstance(wsl, CPWeight):
+            return self._cp_dense(wsl, kept)
         return wsl.to_tensor()
 
     def _forward_staged(self, x, spatial, out_shape):
@@ -281,6 +289,45 @@ class SpectralConv(BaseSpectralConv):
             m *= int(k)
         yhat = engine.mode_gemm(xhat.reshape(b, 1, m), w.reshape(1, 1, m), m)
         return ops.inverse_transform(yhat.reshape(b, c, *kept), self.bias, spatial)
+
+    # ---- CP weights on the engine ------------------------------------------------------------------
+    @staticmethod
+    def _cp_mode_rows(wsl, kept):
+        """S[r, modes] = lambda_r * prod_d U_d[m_d, r]: the Khatri-Rao row products of the (small) mode
+        factors -- parameter-space elementwise glue, R x modes numbers."""
+        s = wsl.weights
+        for u in wsl.factors[2:]:
+            s = s.unsqueeze(-1) * u.transpose(0, 1).reshape(u.shape[1], *([1] * (s.dim() - 1)), u.shape[0])
+        m = 1
+        for k in kept:
+            m *= int(k)
+        return s.reshape(s.shape[0], m)
+
+    def _cp_dense(self, wsl, kept):
+        """W[(i,o), m] = sum_r (U_in[i,r] U_out[o,r]) S[r,m]: one sc_modegemm launch (lanes = modes)."""
+        u_in, u_out = wsl.factors[0], wsl.factors[1]
+        s = self._cp_mode_rows(wsl, kept)
+        r, m = int(s.shape[0]), int(s.shape[1])
+        ab = (u_in.unsqueeze(1) * u_out.unsqueeze(0)).reshape(-1, r)               # (Cin Cout, R)
+        w = engine.mode_gemm(ab, s.reshape(r, 1, m), m)
+        return w.reshape(u_in.shape[0], u_out.shape[0], *kept)
+
+    def _forward_cp(self, x, spatial):
+        """implementation="factorized" with a CP weight, 'abcd,r,br,er,cr,dr->aecd'
+        (spectral_convolution.py:55-73) in its minimum-FLOP pairwise order, never forming the dense weight:
+            z[b,r,m] = sum_i xhat[b,i,m] U_in[i,r];  z *= S[r,m] (Hadamard: one launch with (r, m) as lanes);
+            yhat[b,o,m] = sum_r z[b,r,m] U_out[o,r]."""
+        kept, wsl = self._used_block(spatial)
+        u_in, u_out = wsl.factors[0], wsl.factors[1]
+        s = self._cp_mode_rows(wsl, kept)
+        r, m = int(s.shape[0]), int(s.shape[1])
+        ops = engine.EngineOps(self.fft_norm, self.engine_flags)
+        xhat = ops.forward_transform(x, kept)
+        b, ci = xhat.shape[:2]
+        z = engine.mode_gemm(xhat.reshape(b, ci, m), u_in, m)                      # (B, R, M)
+        z = engine.mode_gemm(z.reshape(b, 1, r * m), s.reshape(1, 1, r * m), r * m).reshape(b, r, m)
+        yhat = engine.mode_gemm(z, u_out.transpose(0, 1), m)
+        return ops.inverse_transform(yhat.reshape(b, u_out.shape[0], *kept), self.bias, spatial)
 
     # ---- tensor-train weights on the engine -----------------------------------------------------
     @staticmethod

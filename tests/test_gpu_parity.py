@@ -274,7 +274,35 @@ def test_tucker_factorized_native_matches_golden(name):
         assert rel_l2(conv.weight.factors[i].grad.cpu().numpy(), g[f"g_factor_{i}"]) < TOL, i
 
 
-@pytest.mark.parametrize("fac", ["Tucker", "CP"])
+@pytest.mark.parametrize("impl", ["factorized", "reconstructed"])
+@pytest.mark.parametrize("name", [n for n in FACT_GOLDEN if n.startswith("cp")])
+def test_cp_native_matches_golden(name, impl):
+    """CP weight on the sc_modegemm chain (factorized: never forms the dense weight; reconstructed: one
+    launch builds it) against the verbatim reference's _contract_cp, gradients of weights and factors."""
+    from neuraloperator_amd import SpectralConv
+    g = load_golden(name)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    nd = x.ndim - 2
+    ci, co = g["factor_0"].shape[0], g["factor_1"].shape[0]
+    conv = SpectralConv(ci, co, tuple(int(v) for v in g["ctor_n_modes"]), factorization="CP",
+                        implementation=impl, rank=int(g["weights"].shape[0])).to(dev)
+    with torch.no_grad():
+        conv.weight.weights.copy_(torch.from_numpy(g["weights"]))
+        for i in range(nd + 2):
+            conv.weight.factors[i].copy_(torch.from_numpy(g[f"factor_{i}"]))
+        conv.bias.copy_(torch.from_numpy(g["bias"]))
+    y = conv(x)
+    y.backward(torch.from_numpy(g["g"]).to(dev))
+    assert rel_l2(y.detach().cpu().numpy(), g["y"]) < TOL
+    assert rel_l2(x.grad.cpu().numpy(), g["gx"]) < TOL
+    assert rel_l2(conv.bias.grad.cpu().numpy(), g["gbias"]) < TOL
+    assert rel_l2(conv.weight.weights.grad.cpu().numpy(), g["g_weights"]) < TOL
+    for i in range(nd + 2):
+        assert rel_l2(conv.weight.factors[i].grad.cpu().numpy(), g[f"g_factor_{i}"]) < TOL, i
+
+
+@pytest.mark.parametrize("fac", ["Tucker", "CP", "TT"])
 def test_module_factorized_matches_dense(fac):
     """factorized weight == dense conv with weight.to_tensor()
     (the reference's identity, test_spectral_convolution.py:54-65)."""
