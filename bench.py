@@ -79,6 +79,24 @@ def time_stage(fn, iters):
     return e0.elapsed_time(e1) / iters      # ms
 
 
+def device_copy_ceiling(nbytes, iters=10):
+    """GB/s (read + written bytes) of a plain device-to-device copy of one real tensor: the practical
+    ceiling a read-once / write-once pass can be held against on this box."""
+    n = max(int(nbytes) // 4, 1 << 20)
+    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2 * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def stage_profile(B, C, spatial, n_modes, flags, iters):
     """Time every stage of the layer separately through the C-ABI (events on the launch
     stream) and return {stage: {ms, alg_bytes, GBs}} plus the plan's kernel names."""
@@ -304,6 +322,9 @@ def main():
                 "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": stages[dom]["alg_bytes"], "ms_per_launch": stages[dom]["ms"]}
         step_gbs = total / ms / 1e6
+        copy_gbs = device_copy_ceiling(R)
+        roof["measured_copy_GBs"] = copy_gbs
+        roof["frac_of_measured_copy"] = round(stages[dom]["GBs"] / copy_gbs, 4)
         out = {
             "metric": "FNO SpectralConv fwd+bwd samples/sec",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -316,6 +337,7 @@ def main():
             "roofline": roof,
             "step_roofline": {"alg_bytes_per_step": total, "achieved_GBs": round(step_gbs, 1),
                               "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
+                              "frac_of_measured_copy": round(step_gbs / copy_gbs, 4),
                               "formula": "4R+3Wb+9S (SURVEY.md 8d)"},
             "stages": stages,
         }

@@ -525,7 +525,7 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // last axis, complex -> real through LDS.  One tile = 128 lines x J cf32 (contiguous in memory) copied
 // to rows of S floats (S/2 odd: the 8-byte operand reads of 32 lines hit 32 different bank pairs).
 //   tab [(((nt * JS + t) * 64 + lane) * 2 + comp] : comp 0 multiplies Re(in[l][2t + (lane>>5)]), comp 1 Im
-// dynamic LDS: the table (n_nt * JS * 128 floats) followed by the tile (128 * S floats).
+// dynamic LDS: the table (n_nt * JS * 128 floats), the tile (128 * S floats), 4 x 2 store patches (8 x 36 floats).
 // A wave's 32 lines must share one bias value (lines_per_image % 32 == 0 when bias != nullptr).
 // ------------------------------------------------------------------------------------------
 template <int CT>
@@ -541,6 +541,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
   const int tab4 = n_nt * JS * 32;                               // table size in float4
   const cf32* tabL = reinterpret_cast<const cf32*>(lds);
   cf32* dat = reinterpret_cast<cf32*>(lds + tab4);
+  float* stg = reinterpret_cast<float*>(lds + tab4) + LB * S;   // 4 waves x 2 patches x 8 x 36 floats
   const int64_t n_tiles = (lines + LB - 1) / LB;
   const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
   if (tile0 >= n_tiles) return;
@@ -614,6 +615,9 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
         }
       }
       const int64_t lwe = lw + sc_opaque(0);
+#ifdef SC_MDFT_C2R_DIRECT_STORE
+      // first version: 64 dword stores per wave tile (2 x 128 bytes each) -- 500 us of store issue alone
+      // on the 2.15 GB tensor, not overlapping the MFMA phase (profiles/r01_mdft_ablation.txt)
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int64_t line = lwe + mdft_row(v, half);
@@ -626,6 +630,30 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
           }
         }
       }
+#else
+      // accumulator registers 4g..4g+3 of the two lane halves are 8 consecutive lines x 32 floats: through a
+      // per-wave LDS patch they leave as ONE 16-byte-per-lane store (8 lines x 128 bytes) instead of four
+      // dword stores -- a quarter of the store instructions.  N % 4 == 0 (host checks).
+      float* patch = stg + w * (2 * 8 * 36);
+      const int prow = lane >> 3, pc4 = lane & 7;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (nt0 + c >= n_nt) continue;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          float* pb = patch + ((c * 4 + gq) & 1) * (8 * 36);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pb[(u + 4 * half) * 36 + col] = acc[c][4 * gq + u] + badd;
+          SC_WAVE_SYNC();
+          const sc_f4 o = *reinterpret_cast<const sc_f4*>(pb + prow * 36 + 4 * pc4);
+          const int64_t line = lwe + 8 * gq + prow;
+          const int n = 32 * (nt0 + c) + 4 * pc4;
+          if (line < lines && n < N && MDFT_STORE_OK(o.x))
+            SC_STORE_STREAM(reinterpret_cast<sc_f4*>(out + line * N + n), o);
+        }
+      }
+      SC_WAVE_SYNC();                 // the two patches are free again before the next column group writes
+#endif
     }
   }
 }

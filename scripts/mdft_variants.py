@@ -7,10 +7,9 @@ sys.path.insert(0, ROOT)
 from neuraloperator_amd.csrc import build as b
 
 VARIANTS = {
-    "plainst": ["SC_MDFT_PLAIN_STORE"],
+    "directst": ["SC_MDFT_C2R_DIRECT_STORE"],
     "nostore": ["SC_MDFT_ABL_NOSTORE"],
     "nomfma": ["SC_MDFT_ABL_NOMFMA"],
-    "noload": ["SC_MDFT_ABL_NOLOAD"],
     "nomfma_nostore": ["SC_MDFT_ABL_NOMFMA", "SC_MDFT_ABL_NOSTORE"],
 }
 out_dir = os.path.join(ROOT, "scripts", "abl")
