@@ -102,11 +102,6 @@ struct sc_plan {
   std::mutex idx_mu;
   std::map<IdxKey, int32_t*> idx_cache;
   std::vector<void*> owned;
-  // side lane of sc_layer_backward: the weight/bias gradients run beside the input-gradient chain
-  std::mutex lane_mu;
-  void* lane_stream = nullptr;
-  void* lane_fork = nullptr;
-  void* lane_join = nullptr;
 };
 
 static const double kTwoPi = 6.283185307179586476925286766559;
@@ -455,40 +450,9 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   return 0;
 }
 
-// lazily created non-blocking side stream + fork/join events of a plan; 0 on success
-static int plan_side_lane(sc_plan* p) {
-#ifdef SC_EMU
-  (void)p;
-  return 1;                                   // the emulation executes launches synchronously: nothing to overlap
-#else
-  std::lock_guard<std::mutex> lk(p->lane_mu);
-  if (p->lane_stream) return 0;
-  hipStream_t s = nullptr;
-  hipEvent_t f = nullptr, j = nullptr;
-  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return 1;
-  if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess) {
-    if (f) (void)hipEventDestroy(f);
-    (void)hipStreamDestroy(s);
-    return 1;
-  }
-  p->lane_fork = f;
-  p->lane_join = j;
-  p->lane_stream = s;
-  return 0;
-#endif
-}
-
 extern "C" void sc_plan_destroy(sc_plan* p) {
   if (!p) return;
-#ifndef SC_EMU
-  if (p->lane_stream) {
-    (void)hipStreamSynchronize((hipStream_t)p->lane_stream);
-    (void)hipEventDestroy((hipEvent_t)p->lane_fork);
-    (void)hipEventDestroy((hipEvent_t)p->lane_join);
-    (void)hipStreamDestroy((hipStream_t)p->lane_stream);
-  }
-#endif
+
   for (void* q : p->owned) (void)hipFree(q);
   for (auto& kv : p->idx_cache) (void)hipFree(kv.second);
   delete p;
@@ -1103,20 +1067,10 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
 
   rc = sc_transform_forward(p, SC_FWD_ADJ_C2R, gy, ghat, B * Co, ws, stream);
   if (rc) return rc;
-  // Ghat feeds two independent branches: {gbias, gW} and {gXhat -> gx}.  The first one (a read-heavy
-  // contraction) runs on the plan's side stream beside the second one's write-bound inverse transform:
-  // 165 -> 145 us for the pair at the metric shape (profiles/r01_stream_overlap.txt).  SC_NO_OVERLAP=1: A-B.
-  void* side = stream;
-#ifndef SC_EMU
-  const bool overlap = gw && gx && !getenv("SC_NO_OVERLAP") && plan_side_lane(const_cast<sc_plan*>(p)) == 0;
-  if (overlap) {
-    SC_CHECK_HIP(hipEventRecord((hipEvent_t)p->lane_fork, (hipStream_t)stream));
-    SC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)p->lane_stream, (hipEvent_t)p->lane_fork, 0));
-    side = p->lane_stream;
-  }
-#endif
+  // (running {gbias, gW} on a side stream beside {gXhat -> gx} was tried: 165 -> 145 us for the isolated pair,
+  // nothing measurable in the step -- every kernel here fills the chip; profiles/r01_stream_overlap.txt)
   if (gbias) {
-    rc = sc_bias_grad(p, ghat, B, Co, gbias, side);
+    rc = sc_bias_grad(p, ghat, B, Co, gbias, stream);
     if (rc) return rc;
   }
   sc_modegemm_desc g;
@@ -1128,12 +1082,9 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
     g.b_sr = Co * Mk; g.b_sq = Mk; g.b_sm = 1;
     g.c_sp = Co * Wm; g.c_sq = Wm; g.c_sm = 1; g.c_idx = idx;
     g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : SC_GEMM_STREAM_C;
-    rc = sc_modegemm(&g, xhat_saved, ghat, gw, side);
+    rc = sc_modegemm(&g, xhat_saved, ghat, gw, stream);
     if (rc) return rc;
   }
-#ifndef SC_EMU
-  if (overlap) SC_CHECK_HIP(hipEventRecord((hipEvent_t)p->lane_join, (hipStream_t)p->lane_stream));
-#endif
   if (gx) {
     // gxhat[b,i,m] = sum_o ghat[b,o,m] * conj(W[i,o,m])
     std::memset(&g, 0, sizeof(g));
@@ -1147,9 +1098,6 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
     rc = sc_transform_inverse(p, SC_INV_ADJ_R2C, gxhat, nullptr, Ci, gx, B * Ci, ws, stream);
     if (rc) return rc;
   }
-#ifndef SC_EMU
-  if (overlap) SC_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)p->lane_join, 0));
-#endif
   return 0;
 }
 
