@@ -816,9 +816,12 @@ static int dispatch_modegemm_conj(const ModeGemmArgs& g, int ca, int cb, const c
 
 // ---- matrix-core path (sc_kernels_mfma.h): channel counts that fill 32 x 32 MFMA tiles ----------
 static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
+  // one workgroup tile is 32 or 64 rows x 64 columns; ragged problems (Tucker / TT ranks such as 36) take it
+  // when they fill at least ~half of a tile, smaller ones stay on the lanes-are-modes VALU kernel
   if (d->accumulate) return false;
-  if (d->Q != 64) return false;
-  if (d->P != 32 && d->P != 64) return false;
+  if (d->Q < 24 || d->Q > 64) return false;
+  if (d->P < 24 || d->P > 64) return false;
+  if (d->R < 8) return false;
   if (d->n_modes >= ((int64_t)1 << 31) / 16) return false;
   return true;
 }
@@ -855,7 +858,7 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   g.dbg = (d->flags >> 24) & 0xf;
   g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
   // contiguous mode ranges of <= NM modes, split evenly over (workgroups per CU) x 256 CUs
-  const bool paired = d->P == 32 && (d->flags & SC_GEMM_PAIRED);
+  const bool paired = d->P <= 32 && (d->flags & SC_GEMM_PAIRED);
   const int64_t nmx = paired ? SC_MG_NM_PAIRED : SC_MG_NM_WIDE;
   const int64_t M = d->n_modes;
   int64_t G = (M + nmx - 1) / nmx;
@@ -867,7 +870,7 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   if (cap > 0 && cap < G && cap * nmx >= M) G = cap;
   g.G = (int)G;
   if (paired) dispatch_mfma_gemm<1, SC_MG_NM_PAIRED, 4>(g, d->conj_a, d->conj_b, A, B, C, st);
-  else if (d->P == 32) dispatch_mfma_gemm<1, SC_MG_NM_WIDE, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
+  else if (d->P <= 32) dispatch_mfma_gemm<1, SC_MG_NM_WIDE, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
   else dispatch_mfma_gemm<2, SC_MG_NM_WIDE, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
   return sc_check_launch("k_modegemm_mfma");
 }
@@ -903,7 +906,12 @@ static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf
   g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
   g.n_pg = (int)((g.P + 4 * 2 - 1) / (4 * 2));
   g.n_qt = (int)((g.Q + 4 - 1) / 4);
-  const int64_t total = (int64_t)g.n_mt * g.n_pg * g.n_qt;
+  // mode splits: enough workgroups to fill the chip (~4096), as few atomic adds per output as that allows
+  int64_t splits = 4096 / ((int64_t)g.n_pg * g.n_qt);
+  if (splits < 1) splits = 1;
+  if (splits > g.n_mt) splits = g.n_mt;
+  g.per_xcd = (int)splits;
+  const int64_t total = splits * g.n_pg * g.n_qt;
   SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
 }
 
@@ -920,7 +928,7 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
   g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = 0;
   g.b_idx = d->b_idx; g.c_idx = nullptr;
   g.accumulate = 1;
-  SC_CHECK_ARG(((g.M + 63) / 64) * ((g.P + 7) / 8) * ((g.Q + 3) / 4) < ((int64_t)1 << 30),
+  SC_CHECK_ARG(((g.P + 7) / 8) * ((g.Q + 3) / 4) < ((int64_t)1 << 30) && (g.M + 63) / 64 < ((int64_t)1 << 31),
                "problem too large for one launch grid");
   sc_stream_t st = (sc_stream_t)stream;
   const cf32* a = (const cf32*)A;

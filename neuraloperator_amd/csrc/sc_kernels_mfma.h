@@ -152,16 +152,24 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   const int sl = lane / nm, jl = lane - sl * nm;
   const bool lvalid = sl < spi;
   const int mj = m0 + (lvalid ? jl : 0);
-  const int64_t la = (int64_t)(lvalid ? sl : 0) * g.a_sp + (int64_t)mj * g.a_sm;
-  const int64_t lb = (int64_t)(lvalid ? sl : 0) * g.b_sq + (g.b_idx ? (int64_t)g.b_idx[mj] : (int64_t)mj * g.b_sm);
+  // ragged problems (g.P <= P, g.Q <= Q: Tucker / TT ranks): a group of spi rows that would reach past the
+  // last row is moved back to END at it (uniform, re-stages a few rows with the same values); LDS rows
+  // >= g.P keep stale data that only ever reaches output rows nobody stores
+  const int slp = lvalid ? (sl < g.P ? sl : g.P - 1) : 0, slq = lvalid ? (sl < g.Q ? sl : g.Q - 1) : 0;
+  const int64_t la = (int64_t)slp * g.a_sp + (int64_t)mj * g.a_sm;
+  const int64_t lb = (int64_t)slq * g.b_sq + (g.b_idx ? (int64_t)g.b_idx[mj] : (int64_t)mj * g.b_sm);
   const int lds_l = sl * NMS + jl;
-  const int npa = (P + spi - 1) / spi, npb = (Q + spi - 1) / spi;   // uniform
+  const int npa = (g.P + spi - 1) / spi, npb = (g.Q + spi - 1) / spi;   // uniform
+  auto group_base = [&](const int gi, const int lim) {
+    int b = gi * spi;
+    if (b + spi > lim) b = lim - spi;
+    return b < 0 ? 0 : b;
+  };
 
   cf32 ra[K::HL][K::NPA], rb[K::HL][K::NPB];
 
-  // every load address is clamped into the operand (no exec-masked loads); what must not be
-  // used is dropped / zeroed when the stage is committed to LDS
-  const int slc = lvalid ? sl : 0;
+  // every load address stays inside the operand (no exec-masked loads); r values past g.R are zeroed
+  // when the stage is committed to LDS
   auto issue = [&](const int r0) {
 #pragma unroll
     for (int h = 0; h < K::HL; ++h) {
@@ -171,19 +179,11 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
       const cf32* br = B + (int64_t)r * g.b_sr + lb;
 #pragma unroll
       for (int pg = 0; pg < K::NPA; ++pg) {
-        if (pg < npa) {                                                 // uniform branch
-          int pb = pg * spi;
-          if (pb + slc >= P) pb = P - 1 - slc;
-          ra[h][pg] = ar[(int64_t)pb * g.a_sp];
-        }
+        if (pg < npa) ra[h][pg] = ar[(int64_t)group_base(pg, g.P) * g.a_sp];   // uniform branch
       }
 #pragma unroll
       for (int qg = 0; qg < K::NPB; ++qg) {
-        if (qg < npb) {
-          int qb = qg * spi;
-          if (qb + slc >= Q) qb = Q - 1 - slc;
-          rb[h][qg] = br[(int64_t)qb * g.b_sq];
-        }
+        if (qg < npb) rb[h][qg] = br[(int64_t)group_base(qg, g.Q) * g.b_sq];
       }
     }
   };
@@ -195,18 +195,18 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
       const float keep = (r0 + rr < g.R) ? 1.f : 0.f;                  // rows past R contribute 0
 #pragma unroll
       for (int pg = 0; pg < K::NPA; ++pg) {
-        const int p = pg * spi + sl;
-        if (lvalid && pg < npa && p < P) {
-          float* o = st + (rr * 2 * P + pg * spi) * NMS + lds_l;
+        const int pb = group_base(pg, g.P);
+        if (lvalid && pg < npa && pb + sl < P) {
+          float* o = st + (rr * 2 * P + pb) * NMS + lds_l;
           o[0] = ra[h][pg].x * keep;
           o[P * NMS] = ra[h][pg].y * (CA ? -keep : keep);          // conj(A) folded in here
         }
       }
 #pragma unroll
       for (int qg = 0; qg < K::NPB; ++qg) {
-        const int q = qg * spi + sl;
-        if (lvalid && qg < npb && q < Q) {
-          float* o = st + K::A_FLOATS + rr * 2 * BPS + (qg * spi) * NMS + lds_l;
+        const int qb = group_base(qg, g.Q);
+        if (lvalid && qg < npb && qb + sl < Q) {
+          float* o = st + K::A_FLOATS + rr * 2 * BPS + qb * NMS + lds_l;
           o[0] = rb[h][qg].x;
           o[BPS] = rb[h][qg].y;
         }
@@ -343,7 +343,8 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
 #pragma unroll
       for (int it = 0; it < NST; ++it) {
         const int sg = it * spi + sl;                   // segment = (row 0..7, column 0..15)
-        if ((it % K::MS) == kh && it < nst && lvalid && sg < 128) {
+        if ((it % K::MS) == kh && it < nst && lvalid && sg < 128 && wp * 32 + 8 * k + (sg >> 4) < g.P &&
+            (wq + 4 * u) * 16 + (sg & 15) < g.Q) {
           const cf32 val = *reinterpret_cast<const cf32*>(ep + (sg * NMS + jl) * 2);
           cf32* cd = crow + (int64_t)(sg >> 4) * g.c_sp + (int64_t)(sg & 15) * g.c_sq;
           if (g.stream_c) {

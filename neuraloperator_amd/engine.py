@@ -295,6 +295,11 @@ class ModeContractDenseFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # generic mode GEMM with autograd: the pairwise steps of the factorized contractions
 # ------------------------------------------------------------------------------------------
+# row count from which the gradient steps of ModeGemmFn re-label a long reduction onto the lanes
+# (tests set it to 1 to force those paths at fixture sizes)
+RELABEL_MIN_ROWS = 4096
+
+
 def _strides3(t, lead):
     """(s0, s1, sm) in complex elements of a [lead0, lead1, M] or [lead0, lead1] (mode-independent) view."""
     if t.dim() == 3:
@@ -306,6 +311,11 @@ def _raw_mode_gemm(a, b, n_modes, conj_a, conj_b, reduce_modes=False):
     """a: [P, R, M] or [P, R]; b: [R, Q, M] or [R, Q]; complex64 CUDA tensors/views (any strides).
     Returns C[P, Q, M] (or C[P, Q] = sum over modes when reduce_modes)."""
     lib = _lib.get_lib()
+    # the lanes run over the modes: an operand whose mode stride is not 1 would be gathered
+    if a.dim() == 3 and a.stride(2) != 1 and a.shape[2] > 1:
+        a = a.contiguous()
+    if b.dim() == 3 and b.stride(2) != 1 and b.shape[2] > 1:
+        b = b.contiguous()
     P, R = int(a.shape[0]), int(a.shape[1])
     Q = int(b.shape[1])
     a_sp, a_sr, a_sm = _strides3(a, 2)
@@ -349,25 +359,39 @@ class ModeGemmFn(torch.autograd.Function):
         a, b = ctx.saved_tensors
         M, ca, cb = ctx.cfg
         gc = gc.contiguous()
+        P, R, Q = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
         ga = gb = None
         if ctx.needs_input_grad[0]:
             # grad_a = sum_q gC * conj(opB(B)); conj_a: grad_A = conj(grad_a) = sum_q conj(gC) * opB(B)
-            bt = b.transpose(0, 1)
-            ga = _raw_mode_gemm(gc, bt, M, ca, cb if ca else not cb, reduce_modes=(a.dim() == 2))
+            cbx = cb if ca else not cb
+            if a.dim() == 2 and b.dim() == 3 and P >= RELABEL_MIN_ROWS and M < 64:
+                # A is mode independent and tall, the modes are few (core x last-mode-factor step of a Tucker
+                # weight: 46656 x 19 against 33 modes): a plain (P x QM)(QM x R) product with the ROWS on the
+                # lanes instead of a 33-lane wave reduction per row -- 128 -> ~25 us
+                gt = gc.reshape(P, Q * M).t().contiguous().unsqueeze(0)                # [1, QM, P]
+                bm = b.permute(1, 2, 0).reshape(Q * M, R)                              # [QM, R], mode independent
+                ga = _raw_mode_gemm(gt, bm, P, ca, cbx).reshape(R, P).t()
+            else:
+                ga = _raw_mode_gemm(gc, b.transpose(0, 1), M, ca, cbx, reduce_modes=(a.dim() == 2))
         if ctx.needs_input_grad[1]:
             # grad_b = sum_p conj(opA(A)) * gC; conj_b: grad_B = conj(grad_b) = sum_p opA(A) * conj(gC)
-            P, Q = int(a.shape[0]), int(b.shape[1])
+            cax = ca if cb else not ca
             if a.dim() == 2 and b.dim() == 3 and P >= 8 * Q * M:
                 # long reduction over p, few outputs (core x last-mode-factor step of a Tucker weight):
                 # put p on the lanes -- sc_modegemm_msum with modes := p, columns := (q, m) -- instead
-                # of a handful of workgroups walking all of p serially (21.7 ms -> ~0.1 ms at rank 0.1)
-                a2 = a.transpose(0, 1).unsqueeze(1)                          # [R, 1, P]
-                g2 = gc.reshape(P, Q * M).transpose(0, 1).unsqueeze(0)       # [1, Q M, P]
-                gb = _raw_mode_gemm(a2, g2, P, ca if cb else not ca, cb, reduce_modes=True).reshape(
-                    int(b.shape[0]), Q, M)
+                # of a handful of workgroups walking all of p serially (21.7 ms -> ~0.1 ms at rank 0.1);
+                # both operands are laid out with p contiguous first (a strided view gathers: 296 -> ~30 us)
+                a2 = a.t().contiguous().unsqueeze(1)                                    # [R, 1, P]
+                g2 = gc.reshape(P, Q * M).t().contiguous().unsqueeze(0)                 # [1, Q M, P]
+                gb = _raw_mode_gemm(a2, g2, P, cax, cb, reduce_modes=True).reshape(R, Q, M)
+            elif b.dim() == 2 and a.dim() == 3 and P * M >= RELABEL_MIN_ROWS and P >= 8 * R:
+                # B is mode independent and the sum runs over many rows p AND the modes (mode-factor step:
+                # 1296 rows x 33 modes -> a 36 x 64 gradient): (p, m) jointly on the lanes, 430 -> ~40 us
+                a2 = a.permute(1, 0, 2).reshape(R, 1, P * M)                            # [R, 1, (p m)] (copy)
+                g2 = gc.permute(1, 0, 2).reshape(1, Q, P * M)                           # [1, Q, (p m)] (copy)
+                gb = _raw_mode_gemm(a2, g2, P * M, cax, cb, reduce_modes=True)
             else:
-                at = a.transpose(0, 1)
-                gb = _raw_mode_gemm(at, gc, M, ca if cb else not ca, cb, reduce_modes=(b.dim() == 2))
+                gb = _raw_mode_gemm(a.transpose(0, 1), gc, M, cax, cb, reduce_modes=(b.dim() == 2))
         return ga, gb, None, None, None
 
 

@@ -7,7 +7,8 @@ from neuraloperator_amd import SpectralConv
 dev = torch.device("cuda:0")
 x = torch.randn(32, 64, 256, 256, device=dev, requires_grad=True)
 g = torch.randn(32, 64, 256, 256, device=dev)
-for impl in ("factorized", "reconstructed"):
+import sys
+for impl in (sys.argv[1:] or ["factorized", "reconstructed"]):
     torch.manual_seed(0)
     conv = SpectralConv(64, 64, (64, 64), factorization="Tucker", rank=0.1, implementation=impl).to(dev)
     def step():

@@ -43,6 +43,9 @@ CASES = [
     (32, 12, 64, 17, 2),     # r tail (12 = 8 + 4), ranges 8 and 9
     (64, 64, 64, 9, 1),      # P = 64 for forward (8 waves, 9 modes)
     (64, 16, 64, 17, 2),     # wide shape, ranges 8 and 9
+    (32, 64, 36, 17, 2),     # ragged columns (a Tucker rank): 36 of the tile's 64
+    (28, 36, 36, 10, 2),     # ragged rows, columns and r
+    (36, 32, 40, 9, 1),      # 36 rows on the 64-row shape
 ]
 
 
@@ -56,7 +59,7 @@ def test_forward_contraction(lib, case):
              a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=Co * M, b_sq=M, b_sm=1, c_sp=Co * M, c_sq=M, c_sm=1)
     ref = np.einsum("bim,iom->bom", x.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
     assert rel_l2(y.numpy(), ref) < TOL
-    if B == 32:   # the paired (4-wave, <= 5 modes) shape of the same contraction
+    if B <= 32:   # the paired (4-wave, <= 5 modes) shape of the same contraction
         y3 = torch.zeros_like(y)
         wcap = max(1, -(-M // 5))
         run_gemm(lib, x, w, y3, flags=_lib.SC_GEMM_PAIRED | _lib.SC_GEMM_GRID(wcap), P=B, Q=Co, R=Ci, n_modes=M,
@@ -144,3 +147,16 @@ def test_mode_summed_gemm_factor_gradient(lib):
                       b_sr=Q, b_sq=1, b_sm=0, c_sp=Q, c_sq=1)
     ref2 = np.einsum("prm,rq->pq", a2.numpy().astype(np.complex128), u.numpy().astype(np.complex128))
     assert rel_l2(c2.numpy(), ref2) < TOL
+
+
+def test_mode_independent_factor_on_matrix_cores(lib):
+    """z[b,f,m] = sum_i xhat[b,i,m] U[i,f] with a mode-independent, ragged factor (b_sm = 0, 36 columns):
+    the first step of the Tucker chain at TFNO-like channel counts."""
+    B, Ci, F, M = 32, 64, 36, 11
+    x = _rand(B, Ci, M, seed=21)
+    u = _rand(Ci, F, seed=22)
+    z = torch.zeros(B, F, M, dtype=torch.complex64)
+    run_gemm(lib, x, u, z, flags=_lib.SC_GEMM_GRID(2), P=B, Q=F, R=Ci, n_modes=M,
+             a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=F, b_sq=1, b_sm=0, c_sp=F * M, c_sq=M, c_sm=1)
+    ref = np.einsum("bim,if->bfm", x.numpy().astype(np.complex128), u.numpy().astype(np.complex128))
+    assert rel_l2(z.numpy(), ref) < TOL

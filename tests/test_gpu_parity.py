@@ -376,3 +376,37 @@ def test_module_transform_matches_golden(name):
     t = conv.transform(x, output_shape=tuple(int(v) for v in g["output_shape"]))
     assert rel_l2(t.cpu().numpy(), g["t"]) < TOL
     assert conv.transform(x) is x                                   # identity without a resolution change
+
+
+@pytest.mark.parametrize("fac,impl", [("Tucker", "factorized"), ("Tucker", "reconstructed"), ("TT", "factorized"),
+                                      ("CP", "factorized")])
+def test_factorized_chain_at_matrix_core_sizes(fac, impl):
+    """64 channels, batch 32: the pairwise steps with ragged ranks (Tucker 0.3 -> ~40) run on the matrix-core
+    contraction.  Reference: the dense module with weight.to_tensor(), and torch autograd through to_tensor()
+    for the factor gradients (the identity test_spectral_convolution.py:54-65 pins)."""
+    from neuraloperator_amd import SpectralConv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    kw = dict(rank=0.3) if fac != "CP" else dict(rank=48)
+    conv = SpectralConv(64, 64, (16, 16), factorization=fac, implementation=impl, **kw).to(dev)
+    with torch.no_grad():
+        for p in conv.weight.parameters():
+            p.copy_(torch.randn_like(p) * 0.4)
+    dense = SpectralConv(64, 64, (16, 16)).to(dev)
+    with torch.no_grad():
+        dense.weight.tensor.copy_(conv.weight.to_tensor())
+        dense.bias.copy_(conv.bias)
+    x = torch.randn(32, 64, 32, 32, device=dev, requires_grad=True)
+    xd = x.detach().clone().requires_grad_(True)
+    g = torch.randn(32, 64, 32, 32, device=dev)
+    y, yd = conv(x), dense(xd)
+    y.backward(g)
+    yd.backward(g)
+    assert rel_l2(y.detach().cpu().numpy(), yd.detach().cpu().numpy()) < TOL
+    assert rel_l2(x.grad.cpu().numpy(), xd.grad.cpu().numpy()) < TOL
+    # factor gradients: push the dense weight gradient through to_tensor() with torch autograd (host glue)
+    ref = SpectralConv(64, 64, (16, 16), factorization=fac, implementation=impl, **kw).to(dev)
+    ref.load_state_dict(conv.state_dict())
+    ref.weight.to_tensor().backward(dense.weight.tensor.grad)
+    for (n1, p1), (n2, p2) in zip(conv.weight.named_parameters(), ref.weight.named_parameters()):
+        assert rel_l2(p1.grad.cpu().numpy(), p2.grad.cpu().numpy()) < 2 * TOL, n1
