@@ -10,8 +10,11 @@ output_shape=None)``, ``transform(x, output_shape=None)``, mutable ``n_modes``,
 All arithmetic of the layer is in libsc_engine.so; this file is argument checking and
 autograd plumbing.  Dense / Tucker / CP / TT weights, separable weights, complex data and
 resolution-changing layers (``resolution_scaling_factor`` / ``output_shape``, with the reference's
-end-padding behaviour) all run on the engine; half / mixed block precision raises
-NotImplementedError (the engine's spectral arithmetic is fp32) -- there is no silent PyTorch fallback.
+end-padding behaviour) all run on the engine -- there is no silent PyTorch fallback.
+``fno_block_precision="half"/"mixed"`` (fp16 FFT / chalf einsum upstream, :436-459) are accepted and
+computed with the engine's fp32 spectral arithmetic, i.e. at least the reference's precision; the result
+has the dtype the reference returns (fp32 with a bias, fp16 without).  That pair is "parity unpinned":
+the reference's fp16 path does not run on its CPU backend, so no golden vectors exist for it.
 """
 from typing import List, Optional, Tuple, Union
 
@@ -80,10 +83,8 @@ class SpectralConv(BaseSpectralConv):
         engine_flags: int = 0,
     ):
         super().__init__(device=device)
-        if fno_block_precision != "full":
-            raise NotImplementedError(
-                f"fno_block_precision={fno_block_precision!r}: the engine computes the spectral path "
-                "in fp32 (half/mixed = DESIGN.md row f4)")
+        if fno_block_precision not in ("full", "half", "mixed"):
+            raise ValueError(f"fno_block_precision={fno_block_precision!r}: expected full, half or mixed")
         if implementation not in ("reconstructed", "factorized"):
             raise ValueError(
                 f'Got implementation={implementation}, expected "reconstructed" or "factorized"')
@@ -199,6 +200,12 @@ class SpectralConv(BaseSpectralConv):
         if output_shape is not None:
             out_shape = list(output_shape)
         out_shape = [int(v) for v in out_shape]
+        if self.fno_block_precision in ("half", "mixed") and not self.complex_data:
+            y = self._forward_full(x.float(), spatial, out_shape)
+            return y if self.bias is not None else y.half()      # half + fp32 bias promotes to fp32 upstream
+        return self._forward_full(x, spatial, out_shape)
+
+    def _forward_full(self, x, spatial, out_shape):
         if self.complex_data or out_shape != spatial:
             return self._forward_staged(x, spatial, out_shape)
         if self.separable:

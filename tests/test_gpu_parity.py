@@ -410,3 +410,24 @@ def test_factorized_chain_at_matrix_core_sizes(fac, impl):
     ref.weight.to_tensor().backward(dense.weight.tensor.grad)
     for (n1, p1), (n2, p2) in zip(conv.weight.named_parameters(), ref.weight.named_parameters()):
         assert rel_l2(p1.grad.cpu().numpy(), p2.grad.cpu().numpy()) < 2 * TOL, n1
+
+
+@pytest.mark.parametrize("prec", ["half", "mixed"])
+def test_block_precision_flags_run_in_fp32(prec):
+    """fno_block_precision half / mixed: accepted, computed with fp32 spectral arithmetic (>= the reference's
+    fp16 path, which has no CPU backend to generate fixtures from), dtype as upstream: fp32 with a bias
+    (half + fp32 parameter promotes), fp16 without."""
+    from neuraloperator_amd import SpectralConv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    full = SpectralConv(4, 4, (8, 8)).to(dev)
+    conv = SpectralConv(4, 4, (8, 8), fno_block_precision=prec).to(dev)
+    conv.load_state_dict(full.state_dict())
+    x = torch.randn(2, 4, 16, 16, device=dev)
+    y, yf = conv(x.half() if prec == "half" else x), full(x.half().float() if prec == "half" else x)
+    assert y.dtype == torch.float32
+    assert rel_l2(y.detach().cpu().numpy(), yf.detach().cpu().numpy()) < TOL
+    nb = SpectralConv(4, 4, (8, 8), fno_block_precision=prec, bias=False).to(dev)
+    assert nb(x).dtype == torch.float16
+    with pytest.raises(ValueError):
+        SpectralConv(4, 4, (8, 8), fno_block_precision="quarter")
