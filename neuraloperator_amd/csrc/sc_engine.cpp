@@ -667,13 +667,24 @@ static int run_axis_mdft(const float* tab, const cf32* in, cf32* out, int64_t ou
                          sc_stream_t st) {
   const int n_jt = (J + 15) / 16;
   const char* tile = getenv("SC_MDFT_TILE");
-  if (!(tile && tile[0] == '4')) {
+  // column tiles per wave: 4 when that still leaves >= 4 waves per SIMD's worth of waves (4096), fewer for
+  // small passes -- the 128^3 first-axis pass (139 k columns) ran 1 wave/SIMD with every table and data
+  // load latency exposed: 180 us for 0.18 GB
+  const int64_t cols = outer * inner;
+  const int ct_max = cols >= (int64_t)4096 * 128 ? 4 : (cols >= (int64_t)4096 * 64 ? 2 : 1);
+  if (tile && tile[0] == '4') {
+    if (n_jt <= 2) launch_mdft_axis<2, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
+    else launch_mdft_axis<4, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+  } else if (ct_max == 1) {
+    if (n_jt <= 2) launch_mdft_axis<2, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+    else launch_mdft_axis<4, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
+  } else if (ct_max == 2) {
+    if (n_jt <= 2) launch_mdft_axis<2, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
+    else launch_mdft_axis<4, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
+  } else {
     if (n_jt <= 2) launch_mdft_axis<2, 4>(in, out, tab, outer, N, J, inner, n_jt, st);
     else if (n_jt <= 4) launch_mdft_axis<4, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
     else launch_mdft_axis<8, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
-  } else {
-    if (n_jt <= 2) launch_mdft_axis<2, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
-    else launch_mdft_axis<4, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
   }
   return sc_check_launch("k_mdft_axis");
 }
@@ -821,7 +832,7 @@ static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
   if (d->accumulate) return false;
   if (d->Q < 24 || d->Q > 64) return false;
   if (d->P < 24 || d->P > 64) return false;
-  if (d->R < 8) return false;
+  if (d->R < 16) return false;          // one 8-deep stage: the tile set-up outweighs it (148 vs 85 us at R = 8, 17 k modes)
   if (d->n_modes >= ((int64_t)1 << 31) / 16) return false;
   return true;
 }

@@ -40,7 +40,7 @@ def run_gemm(lib, a, b, c, flags=0, **kw):
 CASES = [
     (32, 64, 64, 5, 0),      # nm = 1 everywhere
     (32, 64, 64, 26, 3),     # ranges of 8, 9, 9 modes
-    (32, 12, 64, 17, 2),     # r tail (12 = 8 + 4), ranges 8 and 9
+    (32, 20, 64, 17, 2),     # r tail (20 = 8 + 8 + 4), ranges 8 and 9
     (64, 64, 64, 9, 1),      # P = 64 for forward (8 waves, 9 modes)
     (64, 16, 64, 17, 2),     # wide shape, ranges 8 and 9
     (32, 64, 36, 17, 2),     # ragged columns (a Tucker rank): 36 of the tile's 64
