@@ -832,7 +832,11 @@ static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
   if (d->accumulate) return false;
   if (d->Q < 24 || d->Q > 64) return false;
   if (d->P < 24 || d->P > 64) return false;
-  if (d->R < 16) return false;          // one 8-deep stage: the tile set-up outweighs it (148 vs 85 us at R = 8, 17 k modes)
+  if (d->R < 8) return false;
+  // a single 8-deep stage only pays on a (nearly) full tile: P = Q = 32, R = 8 over 17 k modes was 148 us
+  // here against 85 us on the VALU kernel
+  const int64_t rows = d->P <= 32 ? 32 : 64;
+  if (d->R < 16 && 4 * d->P * d->Q < 3 * rows * 64) return false;
   if (d->n_modes >= ((int64_t)1 << 31) / 16) return false;
   return true;
 }
