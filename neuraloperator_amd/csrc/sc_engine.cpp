@@ -532,13 +532,54 @@ static int mdft_lds_tiles_per_block(int64_t lines) {
   return (int)tpb;
 }
 
-template <int CT, bool TAIL>
+template <int CT, bool TAIL, int JP = 0>
 static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
-                                int J, sc_stream_t st) {
+                                int J, sc_stream_t st, const float* tab1 = nullptr, int K1 = 0) {
   const int tpb = mdft_lds_tiles_per_block(lines);
   const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
-  SC_LAUNCH((k_mdft_r2c_lds<CT, TAIL>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256),
-            (size_t)(N / 8) * CT * 1024, st, in, (float*)out, tab, tail, lines, N, J, tpb);
+  SC_LAUNCH((k_mdft_r2c_lds<CT, TAIL, JP>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256),
+            (size_t)(N / 8) * CT * 1024, st, in, (float*)out, tab, tail, lines, N, J, tpb, tab1, K1);
+}
+
+// ---- "plane" form: the last TWO axes in one launch when the second-to-last has exactly 128 rows ----------
+static bool plane_fwd_ok(const sc_plan* p, int mode) {
+  const int L = p->nd - 1;
+  return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_ax_fwd[L - 1] && p->n[L - 1] == SC_MDFT_LB &&
+         p->k[L - 1] <= 64 && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE");
+}
+static bool plane_inv_ok(const sc_plan* p, int mode) {
+  const int L = p->nd - 1;
+  if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_ax_inv[L - 1] && p->n[L - 1] == SC_MDFT_LB &&
+        p->k[L - 1] <= 64 && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE")))
+    return false;
+  const int64_t N = p->n[L], J = p->k[L], n_nt = (N + 31) / 32, JS = (J + 1) / 2;
+  const int64_t bytes = (n_nt * JS * 128 + SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * 4 + p->k[L - 1] * J * 8;
+  return bytes <= 60 * 1024;
+}
+
+template <int CT, bool TAIL>
+static void dispatch_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
+  const int L = p->nd - 1;
+  const int N = (int)p->n[L], J = (int)p->k[L], K1 = (int)p->k[L - 1];
+  const float* tab = p->l_r2c[mode];
+  const cf32* tail = p->l_r2c_tail[mode];
+  const float* t1 = p->m_ax_fwd[L - 1];
+  if (K1 <= 16) launch_mdft_r2c_lds<CT, TAIL, 1>(in, out, tab, tail, lines, N, J, st, t1, K1);
+  else if (K1 <= 32) launch_mdft_r2c_lds<CT, TAIL, 2>(in, out, tab, tail, lines, N, J, st, t1, K1);
+  else launch_mdft_r2c_lds<CT, TAIL, 4>(in, out, tab, tail, lines, N, J, st, t1, K1);
+}
+
+// x (planes x 128 x N real) -> (planes x K1 x J complex): last axis + second-to-last axis
+static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
+  const bool tail = p->l_r2c_tail[mode] != nullptr;
+  if (tail) {
+    if (p->l_r2c_ct == 1) dispatch_plane_fwd<1, true>(p, mode, in, out, lines, st);
+    else dispatch_plane_fwd<2, true>(p, mode, in, out, lines, st);
+  } else {
+    if (p->l_r2c_ct == 1) dispatch_plane_fwd<1, false>(p, mode, in, out, lines, st);
+    else dispatch_plane_fwd<2, false>(p, mode, in, out, lines, st);
+  }
+  return sc_check_launch("k_mdft_r2c_lds<plane>");
 }
 
 static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
@@ -596,15 +637,31 @@ static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const 
             J, n_nt, lpi, channels);
 }
 
-template <int CT>
+template <int CT, bool PLANE = false>
 static void launch_mdft_c2r_lds(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
                                 int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
   const int tpb = mdft_lds_tiles_per_block(lines);
   const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
   const int n_nt = (N + 31) / 32, JS = (J + 1) / 2;
-  const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * sizeof(float);
-  SC_LAUNCH((k_mdft_c2r_lds<CT>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
-            (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb);
+  const int L = p->nd - 1;
+  const int K1 = PLANE ? (int)p->k[L - 1] : 0;
+  const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * sizeof(float) +
+                     (size_t)K1 * J * sizeof(cf32);
+  SC_LAUNCH((k_mdft_c2r_lds<CT, PLANE>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
+            (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb,
+            PLANE ? (const float*)p->m_ax_inv[L - 1] : (const float*)nullptr, K1);
+}
+
+// (planes x K1 x J complex) -> y (planes x 128 x N real): second-to-last axis + last axis (+ bias)
+static int run_plane_inv(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
+                         int64_t lpi, int64_t channels, sc_stream_t st) {
+  const int L = p->nd - 1;
+  const int N = (int)p->n[L], J = (int)p->k[L];
+  const int n_nt = (N + 31) / 32;
+  if (n_nt >= 4) launch_mdft_c2r_lds<4, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  else if (n_nt >= 2) launch_mdft_c2r_lds<2, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  else launch_mdft_c2r_lds<1, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  return sc_check_launch("k_mdft_c2r_lds<plane>");
 }
 
 static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
@@ -725,16 +782,26 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
     return run_r2c(p, mode, x, dst, lines, st);
   };
   if (p->nd == 1) return last_pass((cf32*)xhat);
+  if (p->nd == 2 && plane_fwd_ok(p, mode)) return run_plane_fwd(p, mode, x, (cf32*)xhat, lines, st);
   SC_CHECK_ARG(workspace, "workspace required");
   int64_t s1, s2;
   generic_ws_sizes(p, n_images, &s1, &s2);
   cf32* bufA = (cf32*)workspace;
   cf32* bufB = bufA + s1;
-  int rc = last_pass(bufA);
-  if (rc) return rc;
+  int rc;
   cf32* cur = bufA;
   int64_t inner = p->k[L];
-  for (int d = L - 1; d >= 0; --d) {
+  int d_first = L - 1;
+  if (plane_fwd_ok(p, mode)) {               // last two axes in one launch; its result takes the place of
+    cur = bufB;                              // the second-to-last axis pass' (bufB)
+    rc = run_plane_fwd(p, mode, x, cur, lines, st);
+    inner *= p->k[L - 1];
+    d_first = L - 2;
+  } else {
+    rc = last_pass(bufA);
+  }
+  if (rc) return rc;
+  for (int d = d_first; d >= 0; --d) {
     int64_t outer = n_images;
     for (int e = 0; e < d; ++e) outer *= p->n[e];
     cf32* dst = (d == 0) ? (cf32*)xhat : (cur == bufA ? bufB : bufA);
@@ -775,6 +842,8 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
     return run_c2r(p, mode, src, y, bias, lines, lpi, channels, st);
   };
   if (p->nd == 1) return last_pass((const cf32*)yhat);
+  if (p->nd == 2 && plane_inv_ok(p, mode))
+    return run_plane_inv(p, mode, (const cf32*)yhat, y, bias, lines, lpi, channels, st);
   SC_CHECK_ARG(workspace, "workspace required");
   int64_t s1, s2;
   generic_ws_sizes(p, n_images, &s1, &s2);
@@ -783,7 +852,9 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
   // choose buffers so that the final intermediate lands in bufA
   const cf32* cur = (const cf32*)yhat;
   int64_t outer = n_images;
-  for (int d = 0; d < L; ++d) {
+  const bool plane = plane_inv_ok(p, mode);
+  const int d_end = plane ? L - 1 : L;
+  for (int d = 0; d < d_end; ++d) {
     int64_t inner = 1;
     for (int e = d + 1; e <= L; ++e) inner *= p->k[e];
     const int remaining = L - 1 - d;  // passes after this one
@@ -797,6 +868,7 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
     cur = dst;
     outer *= p->n[d];
   }
+  if (plane) return run_plane_inv(p, mode, cur, y, bias, lines, lpi, channels, st);
   return last_pass(cur);
 }
 
@@ -1143,6 +1215,8 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   }
   if (p->cplx) return "k_axis_pass";
   if (p->mdft) {
+    if (which == 0 && plane_fwd_ok(p, 0)) return "k_mdft_r2c_lds<plane>";
+    if (which == 1 && plane_inv_ok(p, 0)) return "k_mdft_c2r_lds<plane>";
     if (which == 0) return p->l_r2c[0] ? "k_mdft_r2c_lds" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c");
     return p->l_c2r[0] ? "k_mdft_c2r_lds" : "k_mdft_c2r";
   }

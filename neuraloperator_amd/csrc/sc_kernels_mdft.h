@@ -397,15 +397,26 @@ SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 
 //   tail [n] = T[n][J - 1]                                                                     (cf32)
 // dynamic LDS: the table, NG * CT * 1 KB.
 // ------------------------------------------------------------------------------------------
-template <int CT, bool TAIL>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 1 ? 4 : 3))
+//
+// JP > 0 ("plane" form, second-to-last axis of exactly 128 rows = one tile): the tile's 128 x J result is
+// not written out but kept in LDS (Y), and the pruned transform along the 128 rows follows at once
+// (the data x table MFMA product of k_mdft_axis, table tab1 in that kernel's layout, from L2):
+//   Z[j1][j2] = sum_n1 T1[j1][n1] Y[n1][j2],  K1 kept rows = n_jt tiles of 16, JP = 1, 2 or 4 >= n_jt.
+// Wave w takes row tile w % JP and the n1 range number w / JP of 4 / JP; partial sums meet in LDS (the
+// chunk buffer is free by then).  out is then complex (planes, K1, J).  The 128 x J intermediate (0.57 GB
+// each way on 128^3) never reaches HBM and one launch disappears.
+template <int CT, bool TAIL, int JP = 0>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (JP ? 2 : (CT == 1 ? 4 : 3)))
 k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
-               const cf32* __restrict__ tail, int64_t lines, int N, int J, int tiles_per_block) {
+               const cf32* __restrict__ tail, int64_t lines, int N, int J, int tiles_per_block,
+               const float* __restrict__ tab1, int K1) {
   constexpr int LB = SC_MDFT_LB, KC = 32, S4 = 9;            // LDS row = 36 floats = 9 float4
+  constexpr int SY = 32 * CT + 8;                            // Y row stride (floats): holds 2J <= 32 CT + 2
   SC_DYN_SHARED(sc_f4, tabL);
   SC_SHARED sc_f4 dat[LB * S4];
   SC_SHARED sc_f4 tailL[TAIL ? 128 : 1];                     // 256 cf32
   SC_SHARED cf32 tsum[TAIL ? 128 : 1];
+  SC_SHARED float Y[JP ? LB * SY : 1];
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
   const int NC = N / KC, NG = N / 8;
@@ -494,24 +505,90 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
     for (int ct = 0; ct < CT; ++ct) SC_PIN_ACC(acc[ct]);
     if (++c == NC) {                             // tile finished: store its 32 x (2J) results per wave
       const int64_t lw = l0 + 32 * w + sc_opaque(0);
+      if (JP == 0) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int f = 32 * ct + col;
+        for (int ct = 0; ct < CT; ++ct) {
+          const int f = 32 * ct + col;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int64_t line = lw + mdft_row(v, half);
-          if (f < fmax && line < lines && MDFT_STORE_OK(acc[ct][v])) out[line * 2 * J + f] = acc[ct][v];
-          acc[ct][v] = 0.f;
+          for (int v = 0; v < 16; ++v) {
+            const int64_t line = lw + mdft_row(v, half);
+            if (f < fmax && line < lines && MDFT_STORE_OK(acc[ct][v])) out[line * 2 * J + f] = acc[ct][v];
+            acc[ct][v] = 0.f;
+          }
         }
-      }
-      if (TAIL) {
-        if (half == 1) tsum[32 * w + col] = tacc;
-        SC_WAVE_SYNC();
-        if (half == 0) {
-          const int64_t line = lw + col;
-          if (line < lines) reinterpret_cast<cf32*>(out)[line * J + (J - 1)] = cf_add(tacc, tsum[32 * w + col]);
+        if (TAIL) {
+          if (half == 1) tsum[32 * w + col] = tacc;
+          SC_WAVE_SYNC();
+          if (half == 0) {
+            const int64_t line = lw + col;
+            if (line < lines) reinterpret_cast<cf32*>(out)[line * J + (J - 1)] = cf_add(tacc, tsum[32 * w + col]);
+          }
+          tacc = cf_make(0.f, 0.f);
         }
-        tacc = cf_make(0.f, 0.f);
+      } else {
+        // ---- the tile's result stays in LDS ...
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int f = 32 * ct + col;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            if (f < fmax) Y[(32 * w + mdft_row(v, half)) * SY + f] = acc[ct][v];
+            acc[ct][v] = 0.f;
+          }
+        }
+        if (TAIL) {
+          if (half == 1) tsum[32 * w + col] = tacc;
+          SC_WAVE_SYNC();
+          if (half == 0)
+            reinterpret_cast<cf32*>(Y)[(32 * w + col) * (SY / 2) + (J - 1)] = cf_add(tacc, tsum[32 * w + col]);
+          tacc = cf_make(0.f, 0.f);
+        }
+        SC_SYNC();                               // Y is complete; every wave is done with the chunk buffer
+        // ---- ... and is transformed along its 128 rows
+        constexpr int JPD = JP ? JP : 1, KP = 4 / JPD, NS = LB / 2;
+        const int n_jt = (K1 + 15) / 16;
+        const int jt = w % JPD, kp = w / JPD;
+        const int jtc = jt < n_jt ? jt : n_jt - 1;
+        const float* tp = tab1 + ((int64_t)jtc * NS) * 128 + lane;   // [((jt NS + s) 2 + comp) 64 + lane]
+        const cf32* yc = reinterpret_cast<const cf32*>(Y) + (col < J ? col : J - 1);
+        sc_f32x16 z;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) z[v] = 0.f;
+        const int s0 = kp * (NS / KP), s1 = s0 + NS / KP;
+        float a0 = tp[s0 * 128], a1 = tp[s0 * 128 + 64];
+#pragma unroll 2
+        for (int s2 = s0; s2 < s1; ++s2) {
+          const cf32 d = yc[(2 * s2 + half) * (SY / 2)];
+          const int sn = (s2 + 1 < s1) ? s2 + 1 : s2;
+          const float n0 = tp[sn * 128], n1 = tp[sn * 128 + 64];
+          MDFT_MFMA(z, a0, d.x);
+          MDFT_MFMA(z, a1, d.y);
+          a0 = n0;
+          a1 = n1;
+        }
+        if (KP > 1) {
+          float* red = reinterpret_cast<float*>(dat);
+          if (kp > 0) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[(((kp - 1) * JPD + jt) * 16 + v) * 64 + lane] = z[v];
+          }
+          SC_SYNC();
+          if (kp == 0) {
+#pragma unroll
+            for (int k = 1; k < KP; ++k)
+#pragma unroll
+              for (int v = 0; v < 16; ++v) z[v] += red[(((k - 1) * JPD + jt) * 16 + v) * 64 + lane];
+          }
+        }
+        if (kp == 0 && jt < n_jt && col < J) {
+          cf32* zo = reinterpret_cast<cf32*>(out) + ((l0 / LB) * K1) * J + col;
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const int jj = 16 * jt + (mdft_row(v, half) >> 1);
+            if (jj < K1 && MDFT_STORE_OK(z[v])) zo[(int64_t)jj * J] = cf_make(z[v], z[v + 1]);
+          }
+        }
+        SC_SYNC();                               // Y and the partial sums may be overwritten again
       }
       c = 0;
       l0 += LB;
@@ -528,11 +605,18 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // dynamic LDS: the table (n_nt * JS * 128 floats), the tile (128 * S floats), 4 x 2 store patches (8 x 36 floats).
 // A wave's 32 lines must share one bias value (lines_per_image % 32 == 0 when bias != nullptr).
 // ------------------------------------------------------------------------------------------
-template <int CT>
+//
+// PLANE (second-to-last axis of exactly 128 rows = one tile): `in` is the spectrum BEFORE that axis'
+// zero-padded inverse pass, complex (planes, K1, J).  A plane (K1 x J, a few KB) is copied to LDS, expanded
+// to its 128 rows by the data x table MFMA product of k_mdft_axis (table tabA in that kernel's layout:
+// 8 row tiles of 16 rows, two per wave) straight into the tile buffer, and the last-axis pass follows
+// as before: the 128 x J intermediate never reaches HBM and one launch disappears.
+template <int CT, bool PLANE = false>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 4 ? 3 : 4))
 k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
-               int64_t lines_per_image, int64_t channels, int tiles_per_block) {
+               int64_t lines_per_image, int64_t channels, int tiles_per_block,
+               const float* __restrict__ tabA, int K1) {
   constexpr int LB = SC_MDFT_LB;
   SC_DYN_SHARED(sc_f4, lds);
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
@@ -542,6 +626,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
   const cf32* tabL = reinterpret_cast<const cf32*>(lds);
   cf32* dat = reinterpret_cast<cf32*>(lds + tab4);
   float* stg = reinterpret_cast<float*>(lds + tab4) + LB * S;   // 4 waves x 2 patches x 8 x 36 floats
+  cf32* Zs = reinterpret_cast<cf32*>(stg + 4 * 2 * 8 * 36);     // PLANE: K1 x J
   const int64_t n_tiles = (lines + LB - 1) / LB;
   const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
   if (tile0 >= n_tiles) return;
@@ -561,7 +646,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
     const int Ev = (int)((rem < LB ? rem : LB) * J);             // valid elements (ragged last tile)
     const cf32* src = in + l0 * J;
     SC_SYNC();                                                   // previous tile consumed / table staged
-    {
+    if (!PLANE) {
       int line = line_first, j = j_first;
 #pragma unroll 1
       for (int base = tid; base < E; base += 1024) {
@@ -582,6 +667,41 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
             ++line;
           }
         }
+      }
+    } else {
+      const cf32* zsrc = in + (l0 / LB) * K1 * J;
+      for (int i = tid; i < K1 * J; i += 256) Zs[i] = zsrc[i];
+      SC_SYNC();
+      // rows 16 jt .. 16 jt + 15 of the plane for jt = w and w + 4:  Y[n1][j2] = sum_j1 T[n1][j1] Z[j1][j2]
+      const int NSa = (K1 + 1) / 2;
+      sc_f32x16 ya[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) ya[t][v] = 0.f;
+      const cf32* zc = Zs + (col < J ? col : J - 1);
+      const float* ta0 = tabA + ((int64_t)w * NSa) * 128 + lane;
+      const float* ta1 = tabA + ((int64_t)(w + 4) * NSa) * 128 + lane;
+#pragma unroll 2
+      for (int s2 = 0; s2 < NSa; ++s2) {
+        int n = 2 * s2 + half;
+        if (n >= K1) n = K1 - 1;                                 // table entry is zero there
+        const cf32 d = zc[n * J];
+        const float a00 = ta0[s2 * 128], a01 = ta0[s2 * 128 + 64];
+        const float a10 = ta1[s2 * 128], a11 = ta1[s2 * 128 + 64];
+        MDFT_MFMA(ya[0], a00, d.x);
+        MDFT_MFMA(ya[0], a01, d.y);
+        MDFT_MFMA(ya[1], a10, d.x);
+        MDFT_MFMA(ya[1], a11, d.y);
+      }
+      if (col < J) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; v += 2) {
+            const int n1 = 16 * (w + 4 * t) + (mdft_row(v, half) >> 1);
+            dat[n1 * SC2 + col] = cf_make(ya[t][v], ya[t][v + 1]);
+          }
       }
     }
     SC_SYNC();

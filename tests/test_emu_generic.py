@@ -117,3 +117,33 @@ def test_mdft_tail_column_matches_oracle(lib, width):
     assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
     assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("case", [((128, 128), (32, 32), 2, 2, 3), ((128, 64), (40, 16), 1, 3, 2),
+                                  ((3, 128, 32), (2, 12, 8), 2, 2, 2), ((128, 128), (128, 64), 1, 1, 2)],
+                         ids=["128x128_m32", "128x64_m40x16", "3x128x32", "128x128_allrows"])
+def test_plane_kernels_match_oracle(lib, case):
+    """second-to-last axis of 128 rows: the last two axes run in ONE launch each way (k_mdft_r2c_lds<.., JP>,
+    k_mdft_c2r_lds<.., PLANE>) -- 1, 2 and 4 row tiles, with and without the VALU tail column, 2-D and 3-D."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+    spatial, modes, b, ci, co = case
+    torch.manual_seed(9)
+    nm = halve_last_mode(modes)
+    x = torch.randn(b, ci, *spatial)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.5)
+    bias = torch.randn(co, *(1,) * len(spatial))
+    g = torch.randn(b, co, *spatial)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    plan = lib.plan_create(list(spatial), list(nm))
+    fused = nm[-2] <= 64
+    assert (lib.plan_kernel_name(plan, 0) == "k_mdft_r2c_lds<plane>") == fused      # > 64 kept rows: separate passes
+    assert (lib.plan_kernel_name(plan, 1) == "k_mdft_c2r_lds<plane>") == fused
+    lib.plan_destroy(plan)
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
+    assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
+    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL

@@ -47,6 +47,8 @@ ORACLE_CASES = [
     (2, 4, 4, (256, 256), (256, 256), None),        # keep everything
     (2, 3, 5, (40, 128), (8, 32), None),            # kept 8 x 17: matrix-core pass with the VALU tail column
     (2, 3, 5, (20, 72), (8, 64), None),             # ... kept 8 x 33, width not a multiple of 32
+    (1, 4, 4, (16, 128, 128), (8, 32, 32), None),   # 128-row second-to-last axis: last two axes in one launch
+    (2, 4, 4, (128, 64), (40, 16), None),           # ... 40 kept rows = 4 row tiles (3 used)
     (32, 64, 64, (32, 32), (16, 16), None),         # channel counts that take the MFMA contraction
     (64, 64, 64, (24, 20), (8, 10), None),          # ... with P = 64 row tiles in forward, odd-ish grid
     (32, 64, 64, (32, 32), (12, 12), (16, 16)),     # ... through the sub-block index tables
