@@ -402,21 +402,28 @@ SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 
 // not written out but kept in LDS (Y), and the pruned transform along the 128 rows follows at once
 // (the data x table MFMA product of k_mdft_axis, table tab1 in that kernel's layout, from L2):
 //   Z[j1][j2] = sum_n1 T1[j1][n1] Y[n1][j2],  K1 kept rows = n_jt tiles of 16, JP = 1, 2 or 4 >= n_jt.
-// Wave w takes row tile w % JP and the n1 range number w / JP of 4 / JP; partial sums meet in LDS (the
-// chunk buffer is free by then).  out is then complex (planes, K1, J).  The 128 x J intermediate (0.57 GB
+// Wave w takes row tile w % JP and the n1 range number w / JP of 4 / JP (its slice of tab1 lives in
+// registers for the whole launch); partial sums meet in LDS; Y lies over the chunk buffer.
+// out is then complex (planes, K1, J).  The 128 x J intermediate (0.57 GB
 // each way on 128^3) never reaches HBM and one launch disappears.
 template <int CT, bool TAIL, int JP = 0>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (JP ? 2 : (CT == 1 ? 4 : 3)))
+#ifndef SC_PLANE_OCC
+#define SC_PLANE_OCC 2
+#endif
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (JP ? ((JP == 4 && CT == 2) ? 1 : ((JP <= 2 && CT == 1) ? SC_PLANE_OCC : 2)) : (CT == 1 ? 4 : 3)))
 k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                const cf32* __restrict__ tail, int64_t lines, int N, int J, int tiles_per_block,
                const float* __restrict__ tab1, int K1) {
   constexpr int LB = SC_MDFT_LB, KC = 32, S4 = 9;            // LDS row = 36 floats = 9 float4
   constexpr int SY = 32 * CT + 8;                            // Y row stride (floats): holds 2J <= 32 CT + 2
+  constexpr int DAT4 = (JP && LB * SY > LB * S4 * 4) ? LB * SY / 4 : LB * S4;
+  constexpr int REDF = (JP == 1) ? 3 * 1024 : (JP == 2 ? 2 * 1024 : 1);   // partial-sum tiles of the row pass
   SC_DYN_SHARED(sc_f4, tabL);
-  SC_SHARED sc_f4 dat[LB * S4];
+  SC_SHARED sc_f4 dat[DAT4];                                 // chunk buffer; plane form: then the tile result Y
   SC_SHARED sc_f4 tailL[TAIL ? 128 : 1];                     // 256 cf32
   SC_SHARED cf32 tsum[TAIL ? 128 : 1];
-  SC_SHARED float Y[JP ? LB * SY : 1];
+  SC_SHARED float red[REDF];
+  float* Y = reinterpret_cast<float*>(dat);
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
   const int NC = N / KC, NG = N / 8;
@@ -432,6 +439,23 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
     if (TAIL) {
       const sc_f4* s4 = reinterpret_cast<const sc_f4*>(tail);
       for (int i = tid; i < N / 2; i += 256) tailL[i] = s4[i];
+    }
+  }
+  // plane form: this wave's (row tile, n1 range) slice of the row-pass table is the same for every plane
+  // it will see -- it lives in registers (one 256-byte L2 read per MFMA with a one-step prefetch left the
+  // matrix cores waiting: 883 us for the pair of passes that took 504 + 274 us apart)
+  constexpr int JPD = JP ? JP : 1, KP = 4 / JPD, NS = LB / 2;
+  const int n_jt = (K1 + 15) / 16;
+  const int jt = w % JPD, kp = w / JPD;
+  const int s0 = kp * (NS / KP);
+  float t1r[JP ? NS / KP : 1][2];
+  if (JP) {
+    const int jtc = jt < n_jt ? jt : n_jt - 1;
+    const float* tp = tab1 + ((int64_t)jtc * NS + s0) * 128 + lane;  // [((jt NS + s) 2 + comp) 64 + lane]
+#pragma unroll
+    for (int i = 0; i < NS / KP; ++i) {
+      t1r[i][0] = tp[i * 128];
+      t1r[i][1] = tp[i * 128 + 64];
     }
   }
   // loader: thread (lrow, lc4) brings 16 bytes of lines lrow + 32 m, m = 0..3, per chunk
@@ -526,7 +550,8 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
           tacc = cf_make(0.f, 0.f);
         }
       } else {
-        // ---- the tile's result stays in LDS ...
+        // ---- the tile's result stays in LDS (over the chunk buffer, once every wave is done with it) ...
+        SC_SYNC();
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int f = 32 * ct + col;
@@ -543,31 +568,19 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
             reinterpret_cast<cf32*>(Y)[(32 * w + col) * (SY / 2) + (J - 1)] = cf_add(tacc, tsum[32 * w + col]);
           tacc = cf_make(0.f, 0.f);
         }
-        SC_SYNC();                               // Y is complete; every wave is done with the chunk buffer
+        SC_SYNC();                               // Y is complete
         // ---- ... and is transformed along its 128 rows
-        constexpr int JPD = JP ? JP : 1, KP = 4 / JPD, NS = LB / 2;
-        const int n_jt = (K1 + 15) / 16;
-        const int jt = w % JPD, kp = w / JPD;
-        const int jtc = jt < n_jt ? jt : n_jt - 1;
-        const float* tp = tab1 + ((int64_t)jtc * NS) * 128 + lane;   // [((jt NS + s) 2 + comp) 64 + lane]
         const cf32* yc = reinterpret_cast<const cf32*>(Y) + (col < J ? col : J - 1);
         sc_f32x16 z;
 #pragma unroll
         for (int v = 0; v < 16; ++v) z[v] = 0.f;
-        const int s0 = kp * (NS / KP), s1 = s0 + NS / KP;
-        float a0 = tp[s0 * 128], a1 = tp[s0 * 128 + 64];
-#pragma unroll 2
-        for (int s2 = s0; s2 < s1; ++s2) {
-          const cf32 d = yc[(2 * s2 + half) * (SY / 2)];
-          const int sn = (s2 + 1 < s1) ? s2 + 1 : s2;
-          const float n0 = tp[sn * 128], n1 = tp[sn * 128 + 64];
-          MDFT_MFMA(z, a0, d.x);
-          MDFT_MFMA(z, a1, d.y);
-          a0 = n0;
-          a1 = n1;
+#pragma unroll
+        for (int i = 0; i < NS / KP; ++i) {
+          const cf32 d = yc[(2 * (s0 + i) + half) * (SY / 2)];
+          MDFT_MFMA(z, t1r[i][0], d.x);
+          MDFT_MFMA(z, t1r[i][1], d.y);
         }
         if (KP > 1) {
-          float* red = reinterpret_cast<float*>(dat);
           if (kp > 0) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) red[(((kp - 1) * JPD + jt) * 16 + v) * 64 + lane] = z[v];
@@ -588,7 +601,7 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
             if (jj < K1 && MDFT_STORE_OK(z[v])) zo[(int64_t)jj * J] = cf_make(z[v], z[v + 1]);
           }
         }
-        SC_SYNC();                               // Y and the partial sums may be overwritten again
+        // (the barrier that opens the next chunk frees Y; the partial sums are rewritten a whole tile later)
       }
       c = 0;
       l0 += LB;
