@@ -433,3 +433,45 @@ def test_block_precision_flags_run_in_fp32(prec):
     assert nb(x).dtype == torch.float16
     with pytest.raises(ValueError):
         SpectralConv(4, 4, (8, 8), fno_block_precision="quarter")
+
+
+def test_mode_parallel_layer_on_device_single_rank():
+    """The mode-parallel layer with the engine's stage ops on the GPU (RCCL group of one rank: the all-to-alls
+    degenerate, everything else -- stage plumbing, autograd through both transforms and the contraction --
+    is the multi-GPU code path; the sharding itself is covered by the world-size-2 gloo test)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from neuraloperator_amd import SpectralConv
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dev = torch.device("cuda:0")
+    comm.init(model_parallel_size=1, backend="nccl")
+    try:
+        torch.manual_seed(2)
+        ref = SpectralConv(6, 5, (16, 12)).to(dev)
+        mp_conv = ModeParallelSpectralConv(6, 5, (16, 12)).to(dev)
+        with torch.no_grad():
+            mp_conv.weight.copy_(ref.weight.tensor)
+            mp_conv.bias.copy_(ref.bias)
+        x = torch.randn(4, 6, 32, 24, device=dev, requires_grad=True)
+        xr = x.detach().clone().requires_grad_(True)
+        g = torch.randn(4, 5, 32, 24, device=dev)
+        y, yr = mp_conv(x), ref(xr)
+        y.backward(g)
+        yr.backward(g)
+        mp_conv.reduce_replicated_grads()
+        assert rel_l2(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < TOL
+        assert rel_l2(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < TOL
+        assert rel_l2(mp_conv.weight.grad.cpu().numpy(), ref.weight.tensor.grad.cpu().numpy()) < TOL
+        assert rel_l2(mp_conv.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < TOL
+    finally:
+        comm.cleanup()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
