@@ -34,6 +34,10 @@ WORKLOADS = {
     "darcy_16_m12_c32_b4": (4, 32, (16, 16), (12, 12)),           # configs[0] shape
     "fno3d_128_m32_c32_b8": (8, 32, (128, 128, 128), (32, 32, 32)),  # configs[3] shape
     "fno2d_1024_m256_c128_b4": (4, 128, (1024, 1024), (256, 256)),   # configs[4] shape
+    # not BASELINE configs: common small grids on the size-agnostic path (plane-form passes)
+    "fno2d_64_m32_c64_b64": (64, 64, (64, 64), (32, 32)),
+    "fno2d_128_m32_c64_b32": (32, 64, (128, 128), (32, 32)),
+    "fno3d_64_m16_c32_b8": (8, 32, (64, 64, 64), (16, 16, 16)),
 }
 
 

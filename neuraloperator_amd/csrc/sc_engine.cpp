@@ -532,28 +532,30 @@ static int mdft_lds_tiles_per_block(int64_t lines) {
   return (int)tpb;
 }
 
-template <int CT, bool TAIL, int JP = 0>
+template <int CT, bool TAIL, int JP = 0, int NR = SC_MDFT_LB>
 static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
                                 int J, sc_stream_t st, const float* tab1 = nullptr, int K1 = 0) {
   const int tpb = mdft_lds_tiles_per_block(lines);
   const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
-  SC_LAUNCH((k_mdft_r2c_lds<CT, TAIL, JP>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256),
+  SC_LAUNCH((k_mdft_r2c_lds<CT, TAIL, JP, NR>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256),
             (size_t)(N / 8) * CT * 1024, st, in, (float*)out, tab, tail, lines, N, J, tpb, tab1, K1);
 }
 
-// ---- "plane" form: the last TWO axes in one launch when the second-to-last has exactly 128 rows ----------
+// ---- "plane" form: the last TWO axes in one launch when the second-to-last has 128, 64 or 32 rows --------
+static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32; }
 static bool plane_fwd_ok(const sc_plan* p, int mode) {
   const int L = p->nd - 1;
-  return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_ax_fwd[L - 1] && p->n[L - 1] == SC_MDFT_LB &&
-         p->k[L - 1] <= 64 && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE");
+  return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_ax_fwd[L - 1] && plane_rows_ok(p->n[L - 1]) &&
+         2 * p->k[L - 1] <= p->n[L - 1] && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE");
 }
 static bool plane_inv_ok(const sc_plan* p, int mode) {
   const int L = p->nd - 1;
-  if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_ax_inv[L - 1] && p->n[L - 1] == SC_MDFT_LB &&
-        p->k[L - 1] <= 64 && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE")))
+  if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_ax_inv[L - 1] && plane_rows_ok(p->n[L - 1]) &&
+        2 * p->k[L - 1] <= p->n[L - 1] && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE")))
     return false;
   const int64_t N = p->n[L], J = p->k[L], n_nt = (N + 31) / 32, JS = (J + 1) / 2;
-  const int64_t bytes = (n_nt * JS * 128 + SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * 4 + p->k[L - 1] * J * 8;
+  const int64_t pl = SC_MDFT_LB / p->n[L - 1];
+  const int64_t bytes = (n_nt * JS * 128 + SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * 4 + pl * p->k[L - 1] * J * 8;
   return bytes <= 60 * 1024;
 }
 
@@ -564,9 +566,17 @@ static void dispatch_plane_fwd(const sc_plan* p, int mode, const float* in, cf32
   const float* tab = p->l_r2c[mode];
   const cf32* tail = p->l_r2c_tail[mode];
   const float* t1 = p->m_ax_fwd[L - 1];
-  if (K1 <= 16) launch_mdft_r2c_lds<CT, TAIL, 1>(in, out, tab, tail, lines, N, J, st, t1, K1);
-  else if (K1 <= 32) launch_mdft_r2c_lds<CT, TAIL, 2>(in, out, tab, tail, lines, N, J, st, t1, K1);
-  else launch_mdft_r2c_lds<CT, TAIL, 4>(in, out, tab, tail, lines, N, J, st, t1, K1);
+  const int64_t nr = p->n[L - 1];                      // K1 <= nr / 2 (plane_fwd_ok)
+  if (nr == 128) {
+    if (K1 <= 16) launch_mdft_r2c_lds<CT, TAIL, 1, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
+    else if (K1 <= 32) launch_mdft_r2c_lds<CT, TAIL, 2, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
+    else launch_mdft_r2c_lds<CT, TAIL, 4, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
+  } else if (nr == 64) {
+    if (K1 <= 16) launch_mdft_r2c_lds<CT, TAIL, 1, 64>(in, out, tab, tail, lines, N, J, st, t1, K1);
+    else launch_mdft_r2c_lds<CT, TAIL, 2, 64>(in, out, tab, tail, lines, N, J, st, t1, K1);
+  } else {
+    launch_mdft_r2c_lds<CT, TAIL, 1, 32>(in, out, tab, tail, lines, N, J, st, t1, K1);
+  }
 }
 
 // x (planes x 128 x N real) -> (planes x K1 x J complex): last axis + second-to-last axis
@@ -637,17 +647,18 @@ static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const 
             J, n_nt, lpi, channels);
 }
 
-template <int CT, bool PLANE = false>
+template <int CT, int NR = 0>
 static void launch_mdft_c2r_lds(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
                                 int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
+  constexpr bool PLANE = NR > 0;
   const int tpb = mdft_lds_tiles_per_block(lines);
   const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
   const int n_nt = (N + 31) / 32, JS = (J + 1) / 2;
   const int L = p->nd - 1;
   const int K1 = PLANE ? (int)p->k[L - 1] : 0;
   const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * sizeof(float) +
-                     (size_t)K1 * J * sizeof(cf32);
-  SC_LAUNCH((k_mdft_c2r_lds<CT, PLANE>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
+                     (size_t)(PLANE ? SC_MDFT_LB / NR : 0) * K1 * J * sizeof(cf32);
+  SC_LAUNCH((k_mdft_c2r_lds<CT, NR>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
             (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb,
             PLANE ? (const float*)p->m_ax_inv[L - 1] : (const float*)nullptr, K1);
 }
@@ -658,9 +669,17 @@ static int run_plane_inv(const sc_plan* p, int mode, const cf32* in, float* out,
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
   const int n_nt = (N + 31) / 32;
-  if (n_nt >= 4) launch_mdft_c2r_lds<4, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
-  else if (n_nt >= 2) launch_mdft_c2r_lds<2, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
-  else launch_mdft_c2r_lds<1, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  const int64_t nr = p->n[L - 1];
+#define SC_PLANE_INV(NRV)                                                                                     \
+  do {                                                                                                        \
+    if (n_nt >= 4) launch_mdft_c2r_lds<4, NRV>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);       \
+    else if (n_nt >= 2) launch_mdft_c2r_lds<2, NRV>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);  \
+    else launch_mdft_c2r_lds<1, NRV>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);                 \
+  } while (0)
+  if (nr == 128) SC_PLANE_INV(128);
+  else if (nr == 64) SC_PLANE_INV(64);
+  else SC_PLANE_INV(32);
+#undef SC_PLANE_INV
   return sc_check_launch("k_mdft_c2r_lds<plane>");
 }
 

@@ -398,15 +398,16 @@ SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 
 // dynamic LDS: the table, NG * CT * 1 KB.
 // ------------------------------------------------------------------------------------------
 //
-// JP > 0 ("plane" form, second-to-last axis of exactly 128 rows = one tile): the tile's 128 x J result is
-// not written out but kept in LDS (Y), and the pruned transform along the 128 rows follows at once
-// (the data x table MFMA product of k_mdft_axis, table tab1 in that kernel's layout, from L2):
-//   Z[j1][j2] = sum_n1 T1[j1][n1] Y[n1][j2],  K1 kept rows = n_jt tiles of 16, JP = 1, 2 or 4 >= n_jt.
-// Wave w takes row tile w % JP and the n1 range number w / JP of 4 / JP (its slice of tab1 lives in
-// registers for the whole launch); partial sums meet in LDS; Y lies over the chunk buffer.
-// out is then complex (planes, K1, J).  The 128 x J intermediate (0.57 GB
-// each way on 128^3) never reaches HBM and one launch disappears.
-template <int CT, bool TAIL, int JP = 0>
+// JP > 0 ("plane" form, second-to-last axis of NR = 128, 64 or 32 rows: a tile is 1, 2 or 4 whole planes):
+// the tile's 128 x J result is not written out but kept in LDS (Y, over the chunk buffer), and the pruned
+// transform along the NR rows of each plane follows at once (the data x table MFMA product of k_mdft_axis,
+// table tab1 in that kernel's layout):
+//   Z[j1][j2] = sum_n1 T1[j1][n1] Y[n1][j2],  K1 kept rows = n_jt tiles of 16, JP >= n_jt row tiles at once.
+// A plane belongs to NR / 32 waves; wave wl of them takes row tile wl % JP and the n1 range number wl / JP
+// (its slice of tab1 lives in registers for the whole launch); partial sums of the ranges meet in LDS.
+// out is then complex (planes, K1, J).  The NR x J intermediate (0.57 GB each way on 128^3) never reaches
+// HBM and one launch disappears.
+template <int CT, bool TAIL, int JP = 0, int NR = SC_MDFT_LB>
 #ifndef SC_PLANE_OCC
 #define SC_PLANE_OCC 2
 #endif
@@ -417,7 +418,10 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
   constexpr int LB = SC_MDFT_LB, KC = 32, S4 = 9;            // LDS row = 36 floats = 9 float4
   constexpr int SY = 32 * CT + 8;                            // Y row stride (floats): holds 2J <= 32 CT + 2
   constexpr int DAT4 = (JP && LB * SY > LB * S4 * 4) ? LB * SY / 4 : LB * S4;
-  constexpr int REDF = (JP == 1) ? 3 * 1024 : (JP == 2 ? 2 * 1024 : 1);   // partial-sum tiles of the row pass
+  constexpr int PL = LB / NR, WPP = 4 / PL;                  // planes per tile, waves per plane
+  constexpr int JPD = JP ? JP : 1, KP = (WPP / JPD) ? (WPP / JPD) : 1, NS = NR / 2;
+  static_assert(!JP || JPD * KP == WPP, "row tiles x n1 ranges = waves of a plane");
+  constexpr int REDF = (JP && KP > 1) ? PL * (KP - 1) * JPD * 1024 : 1;   // partial-sum tiles of the row pass
   SC_DYN_SHARED(sc_f4, tabL);
   SC_SHARED sc_f4 dat[DAT4];                                 // chunk buffer; plane form: then the tile result Y
   SC_SHARED sc_f4 tailL[TAIL ? 128 : 1];                     // 256 cf32
@@ -444,9 +448,9 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
   // plane form: this wave's (row tile, n1 range) slice of the row-pass table is the same for every plane
   // it will see -- it lives in registers (one 256-byte L2 read per MFMA with a one-step prefetch left the
   // matrix cores waiting: 883 us for the pair of passes that took 504 + 274 us apart)
-  constexpr int JPD = JP ? JP : 1, KP = 4 / JPD, NS = LB / 2;
   const int n_jt = (K1 + 15) / 16;
-  const int jt = w % JPD, kp = w / JPD;
+  const int pl = w / WPP, wl = w % WPP;
+  const int jt = wl % JPD, kp = wl / JPD;
   const int s0 = kp * (NS / KP);
   float t1r[JP ? NS / KP : 1][2];
   if (JP) {
@@ -576,25 +580,26 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
         for (int v = 0; v < 16; ++v) z[v] = 0.f;
 #pragma unroll
         for (int i = 0; i < NS / KP; ++i) {
-          const cf32 d = yc[(2 * (s0 + i) + half) * (SY / 2)];
+          const cf32 d = yc[(pl * NR + 2 * (s0 + i) + half) * (SY / 2)];
           MDFT_MFMA(z, t1r[i][0], d.x);
           MDFT_MFMA(z, t1r[i][1], d.y);
         }
         if (KP > 1) {
           if (kp > 0) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) red[(((kp - 1) * JPD + jt) * 16 + v) * 64 + lane] = z[v];
+            for (int v = 0; v < 16; ++v) red[(((pl * (KP - 1) + kp - 1) * JPD + jt) * 16 + v) * 64 + lane] = z[v];
           }
           SC_SYNC();
           if (kp == 0) {
 #pragma unroll
             for (int k = 1; k < KP; ++k)
 #pragma unroll
-              for (int v = 0; v < 16; ++v) z[v] += red[(((k - 1) * JPD + jt) * 16 + v) * 64 + lane];
+              for (int v = 0; v < 16; ++v) z[v] += red[(((pl * (KP - 1) + k - 1) * JPD + jt) * 16 + v) * 64 + lane];
           }
         }
-        if (kp == 0 && jt < n_jt && col < J) {
-          cf32* zo = reinterpret_cast<cf32*>(out) + ((l0 / LB) * K1) * J + col;
+        const int64_t plane = (l0 / LB) * PL + pl;
+        if (kp == 0 && jt < n_jt && col < J && plane * NR < lines) {
+          cf32* zo = reinterpret_cast<cf32*>(out) + (plane * K1) * J + col;
 #pragma unroll
           for (int v = 0; v < 16; v += 2) {
             const int jj = 16 * jt + (mdft_row(v, half) >> 1);
@@ -619,18 +624,21 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // A wave's 32 lines must share one bias value (lines_per_image % 32 == 0 when bias != nullptr).
 // ------------------------------------------------------------------------------------------
 //
-// PLANE (second-to-last axis of exactly 128 rows = one tile): `in` is the spectrum BEFORE that axis'
-// zero-padded inverse pass, complex (planes, K1, J).  A plane (K1 x J, a few KB) is copied to LDS, expanded
-// to its 128 rows by the data x table MFMA product of k_mdft_axis (table tabA in that kernel's layout:
-// 8 row tiles of 16 rows, two per wave) straight into the tile buffer, and the last-axis pass follows
-// as before: the 128 x J intermediate never reaches HBM and one launch disappears.
-template <int CT, bool PLANE = false>
+// NR > 0 ("plane" form, second-to-last axis of NR = 128, 64 or 32 rows: a tile is 1, 2 or 4 whole planes):
+// `in` is the spectrum BEFORE that axis' zero-padded inverse pass, complex (planes, K1, J).  The tile's
+// planes (K1 x J each, a few KB) are copied to LDS, expanded to their NR rows by the data x table MFMA
+// product of k_mdft_axis (table tabA in that kernel's layout: NR / 16 row tiles per plane, two per wave)
+// straight into the tile buffer, and the last-axis pass follows as before: the NR x J intermediate never
+// reaches HBM and one launch disappears.
+template <int CT, int NR = 0>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 4 ? 3 : 4))
 k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
                int64_t lines_per_image, int64_t channels, int tiles_per_block,
                const float* __restrict__ tabA, int K1) {
   constexpr int LB = SC_MDFT_LB;
+  constexpr bool PLANE = NR > 0;
+  constexpr int NRD = PLANE ? NR : LB, PL = LB / NRD, WPP = 4 / PL;   // planes per tile, waves per plane
   SC_DYN_SHARED(sc_f4, lds);
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
@@ -639,7 +647,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
   const cf32* tabL = reinterpret_cast<const cf32*>(lds);
   cf32* dat = reinterpret_cast<cf32*>(lds + tab4);
   float* stg = reinterpret_cast<float*>(lds + tab4) + LB * S;   // 4 waves x 2 patches x 8 x 36 floats
-  cf32* Zs = reinterpret_cast<cf32*>(stg + 4 * 2 * 8 * 36);     // PLANE: K1 x J
+  cf32* Zs = reinterpret_cast<cf32*>(stg + 4 * 2 * 8 * 36);     // plane form: PL x K1 x J
   const int64_t n_tiles = (lines + LB - 1) / LB;
   const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
   if (tile0 >= n_tiles) return;
@@ -682,19 +690,22 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
         }
       }
     } else {
-      const cf32* zsrc = in + (l0 / LB) * K1 * J;
-      for (int i = tid; i < K1 * J; i += 256) Zs[i] = zsrc[i];
+      const cf32* zsrc = in + (l0 / NRD) * K1 * J;
+      const int64_t left = (lines - l0) / NRD;                   // planes from this tile to the end
+      const int zvalid = (int)(left < PL ? left : PL) * K1 * J;
+      for (int i = tid; i < PL * K1 * J; i += 256) Zs[i] = zsrc[i < zvalid ? i : zvalid - 1];
       SC_SYNC();
-      // rows 16 jt .. 16 jt + 15 of the plane for jt = w and w + 4:  Y[n1][j2] = sum_j1 T[n1][j1] Z[j1][j2]
+      // rows 16 jt .. 16 jt + 15 of plane pl for jt = wl and wl + WPP:  Y[n1][j2] = sum_j1 T[n1][j1] Z[j1][j2]
+      const int pl = w / WPP, wl = w % WPP;
       const int NSa = (K1 + 1) / 2;
       sc_f32x16 ya[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) ya[t][v] = 0.f;
-      const cf32* zc = Zs + (col < J ? col : J - 1);
-      const float* ta0 = tabA + ((int64_t)w * NSa) * 128 + lane;
-      const float* ta1 = tabA + ((int64_t)(w + 4) * NSa) * 128 + lane;
+      const cf32* zc = Zs + pl * K1 * J + (col < J ? col : J - 1);
+      const float* ta0 = tabA + ((int64_t)wl * NSa) * 128 + lane;
+      const float* ta1 = tabA + ((int64_t)(wl + WPP) * NSa) * 128 + lane;
 #pragma unroll 2
       for (int s2 = 0; s2 < NSa; ++s2) {
         int n = 2 * s2 + half;
@@ -712,7 +723,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int v = 0; v < 16; v += 2) {
-            const int n1 = 16 * (w + 4 * t) + (mdft_row(v, half) >> 1);
+            const int n1 = pl * NRD + 16 * (wl + WPP * t) + (mdft_row(v, half) >> 1);
             dat[n1 * SC2 + col] = cf_make(ya[t][v], ya[t][v + 1]);
           }
       }
