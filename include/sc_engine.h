@@ -114,7 +114,8 @@ int sc_transform_inverse(const sc_plan* plan, int mode, const float* yhat, const
 enum {
   SC_GEMM_FORCE_VALU = 1,    /* never take the matrix-core kernel (debug / A-B)            */
   SC_GEMM_STREAM_C = 2,      /* C is not consumed by the next kernel: non-temporal stores    */
-  SC_GEMM_PAIRED = 4         /* P = 32: two 4-wave workgroups per CU, 5 modes each (A-B; slower from HBM) */
+  SC_GEMM_PAIRED = 4,        /* P = 32: two 4-wave workgroups per CU, 5 modes each (A-B; slower from HBM) */
+  SC_GEMM_WIDE = 8           /* 9 modes per workgroup even for a small mode count (A-B / tests)          */
 };
 /* flags bits 8..23: cap on the number of workgroups of the matrix-core kernel (0 = auto) */
 #define SC_GEMM_GRID(n) (((n) & 0xffff) << 8)

@@ -21,6 +21,7 @@ SC_FREQ_DROPPED = -(1 << 63)
 SC_GEMM_FORCE_VALU = 1
 SC_GEMM_STREAM_C = 2
 SC_GEMM_PAIRED = 4
+SC_GEMM_WIDE = 8
 
 
 def SC_GEMM_GRID(n):

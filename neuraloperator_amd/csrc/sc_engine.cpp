@@ -939,6 +939,13 @@ static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
 //     40-byte segments cost more DRAM/fabric efficiency than the second workgroup's latency hiding buys.
 #define SC_MG_NM_WIDE 9
 #define SC_MG_NM_PAIRED 5
+//   few    (n_modes <= SC_MG_FEW_MAX, e.g. a 64 x 64 grid keeping 32 x 17): 4 modes per workgroup.  With 9
+//     slots a small problem either leaves most CUs idle or, spread over all of them, multiplies stale
+//     slots (the MFMAs of a workgroup always cover all its NM slots): 72 us for 53 MB at 544 modes.
+#define SC_MG_NM_FEW 4
+#ifndef SC_MG_FEW_MAX
+#define SC_MG_FEW_MAX 1152
+#endif
 template <int PT, int NM, int NWV, bool CA, bool CB>
 static void launch_mfma_gemm(const MfmaGemmArgs& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
   SC_LAUNCH((k_modegemm_mfma<PT, 4, NM, CA, CB, NWV>), dim3((unsigned)g.G),
@@ -965,17 +972,21 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
   // contiguous mode ranges of <= NM modes, split evenly over (workgroups per CU) x 256 CUs
   const bool paired = d->P <= 32 && (d->flags & SC_GEMM_PAIRED);
-  const int64_t nmx = paired ? SC_MG_NM_PAIRED : SC_MG_NM_WIDE;
   const int64_t M = d->n_modes;
+  const bool few = !paired && M <= SC_MG_FEW_MAX && !(d->flags & SC_GEMM_WIDE);
+  const int64_t nmx = paired ? SC_MG_NM_PAIRED : (few ? SC_MG_NM_FEW : SC_MG_NM_WIDE);
   int64_t G = (M + nmx - 1) / nmx;
   const int64_t slots = paired ? 512 : 256;
-  if (G < slots) G = M < slots ? M : slots;
+  if (few) G = G < 8 ? G : (G + 7) / 8 * 8;        // keep the ranges full: ceil(M / 4) workgroups
+  else if (G < slots) G = M < slots ? M : slots;
   else G = (G + 7) / 8 * 8;
   if (G > M) G = M;
   const int64_t cap = (d->flags >> 8) & 0xffff;               // SC_GEMM_GRID(n): tests / tuning
   if (cap > 0 && cap < G && cap * nmx >= M) G = cap;
   g.G = (int)G;
   if (paired) dispatch_mfma_gemm<1, SC_MG_NM_PAIRED, 4>(g, d->conj_a, d->conj_b, A, B, C, st);
+  else if (few && d->P <= 32) dispatch_mfma_gemm<1, SC_MG_NM_FEW, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
+  else if (few) dispatch_mfma_gemm<2, SC_MG_NM_FEW, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
   else if (d->P <= 32) dispatch_mfma_gemm<1, SC_MG_NM_WIDE, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
   else dispatch_mfma_gemm<2, SC_MG_NM_WIDE, 8>(g, d->conj_a, d->conj_b, A, B, C, st);
   return sc_check_launch("k_modegemm_mfma");

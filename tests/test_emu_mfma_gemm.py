@@ -49,13 +49,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("shape", [_lib.SC_GEMM_WIDE, 0], ids=["wide9", "few4"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_Ci%d_Co%d_M%d_g%d" % c)
-def test_forward_contraction(lib, case):
+def test_forward_contraction(lib, case, shape):
+    """shape: 9-mode workgroups (forced: the fixtures have few modes) / the 4-mode shape small problems take"""
     B, Ci, Co, M, cap = case
     x = _rand(B, Ci, M, seed=1)
     w = _rand(Ci, Co, M, seed=2)
     y = torch.zeros(B, Co, M, dtype=torch.complex64)
-    run_gemm(lib, x, w, y, flags=_lib.SC_GEMM_GRID(cap), P=B, Q=Co, R=Ci, n_modes=M,
+    run_gemm(lib, x, w, y, flags=shape | _lib.SC_GEMM_GRID(cap), P=B, Q=Co, R=Ci, n_modes=M,
              a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=Co * M, b_sq=M, b_sm=1, c_sp=Co * M, c_sq=M, c_sm=1)
     ref = np.einsum("bim,iom->bom", x.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
     assert rel_l2(y.numpy(), ref) < TOL
@@ -77,7 +79,7 @@ def test_gx_contraction_conj_b_transposed_strides(lib):
     g = _rand(B, Co, M, seed=3)
     w = _rand(Ci, Co, M, seed=4)
     gx = torch.zeros(B, Ci, M, dtype=torch.complex64)
-    run_gemm(lib, g, w, gx, flags=_lib.SC_GEMM_GRID(3), P=B, Q=Ci, R=Co, n_modes=M,
+    run_gemm(lib, g, w, gx, flags=_lib.SC_GEMM_WIDE | _lib.SC_GEMM_GRID(3), P=B, Q=Ci, R=Co, n_modes=M,
              a_sp=Co * M, a_sr=M, a_sm=1, b_sr=M, b_sq=Co * M, b_sm=1, conj_b=1,
              c_sp=Ci * M, c_sq=M, c_sm=1)
     ref = np.einsum("bom,iom->bim", g.numpy().astype(np.complex128), np.conj(w.numpy().astype(np.complex128)))
@@ -89,7 +91,7 @@ def test_gw_contraction_conj_a(lib):
     x = _rand(B, Ci, M, seed=5)
     g = _rand(B, Co, M, seed=6)
     gw = torch.zeros(Ci, Co, M, dtype=torch.complex64)
-    run_gemm(lib, x, g, gw, flags=_lib.SC_GEMM_GRID(2), P=Ci, Q=Co, R=B, n_modes=M,
+    run_gemm(lib, x, g, gw, flags=_lib.SC_GEMM_WIDE | _lib.SC_GEMM_GRID(2), P=Ci, Q=Co, R=B, n_modes=M,
              a_sp=M, a_sr=Ci * M, a_sm=1, conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1,
              c_sp=Co * M, c_sq=M, c_sm=1)
     ref = np.einsum("bim,bom->iom", np.conj(x.numpy().astype(np.complex128)), g.numpy().astype(np.complex128))
@@ -113,7 +115,7 @@ def test_sub_block_index_tables(lib):
     g = _rand(B, Co, M, seed=9)
     x64 = _rand(B, 64, M, seed=10)
     gw = torch.zeros(64, Co, Wm, dtype=torch.complex64)
-    run_gemm(lib, x64, g, gw, flags=_lib.SC_GEMM_GRID(2), P=64, Q=Co, R=B, n_modes=M,
+    run_gemm(lib, x64, g, gw, flags=_lib.SC_GEMM_WIDE | _lib.SC_GEMM_GRID(2), P=64, Q=Co, R=B, n_modes=M,
              a_sp=M, a_sr=64 * M, a_sm=1, conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1,
              c_sp=Co * Wm, c_sq=Wm, c_sm=1, c_idx=idx.data_ptr())
     ref = np.zeros((64, Co, Wm), dtype=np.complex128)
