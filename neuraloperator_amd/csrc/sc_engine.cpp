@@ -173,6 +173,26 @@ static int upload_floats(sc_plan* p, const std::vector<float>& host, float** out
   return 0;
 }
 
+// A-B switches of the size-agnostic passes (measurement only), read from the environment once:
+//   SC_MDFT_TILE=4     4 accumulator tiles per wave instead of 8 (first-generation passes)
+//   SC_MDFT_NOLDS=1    first-generation last-axis passes (operands straight from global memory)
+//   SC_MDFT_NOTAIL=1   the 2^k + 1-th kept column as an MFMA tile instead of a VALU dot product
+//   SC_MDFT_NOPLANE=1  last two axes as separate passes
+struct MdftSwitches {
+  bool tile4, nolds, notail, noplane;
+  MdftSwitches() {
+    const char* t = getenv("SC_MDFT_TILE");
+    tile4 = t && t[0] == '4';
+    nolds = getenv("SC_MDFT_NOLDS") != nullptr;
+    notail = getenv("SC_MDFT_NOTAIL") != nullptr;
+    noplane = getenv("SC_MDFT_NOPLANE") != nullptr;
+  }
+};
+static const MdftSwitches& mdft_switches() {
+  static const MdftSwitches s;
+  return s;
+}
+
 // tables of the matrix-core passes, in MFMA lane order (layouts: sc_kernels_mdft.h)
 static int build_mdft_tables(sc_plan* p) {
   const int L = p->nd - 1;
@@ -508,8 +528,7 @@ static void dispatch_mdft_r2c(const float* in, cf32* out, const float* tab, cons
                               int J, int n_ct, sc_stream_t st) {
   // 8 accumulator tiles per wave by default; SC_MDFT_TILE=4 selects 4-tile waves (2-3 waves per
   // SIMD) for A-B: measured equal on 128^3 (5.38 vs 5.43 ms/step) and slower on 1024^2 (33.1 vs 30.5)
-  const char* tile = getenv("SC_MDFT_TILE");
-  const bool big = !(tile && tile[0] == '4');
+  const bool big = !mdft_switches().tile4;
   if (n_ct == 1) {                       // J = 17 with the tail column on the VALU: no second column tile to pad
     if (big) launch_mdft_r2c<4, 1, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
     else launch_mdft_r2c<2, 1, TAIL>(in, out, tab, tail, lines, N, J, n_ct, st);
@@ -546,12 +565,12 @@ static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32
 static bool plane_fwd_ok(const sc_plan* p, int mode) {
   const int L = p->nd - 1;
   return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_ax_fwd[L - 1] && plane_rows_ok(p->n[L - 1]) &&
-         2 * p->k[L - 1] <= p->n[L - 1] && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE");
+         2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane;
 }
 static bool plane_inv_ok(const sc_plan* p, int mode) {
   const int L = p->nd - 1;
   if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_ax_inv[L - 1] && plane_rows_ok(p->n[L - 1]) &&
-        2 * p->k[L - 1] <= p->n[L - 1] && !getenv("SC_MDFT_NOLDS") && !getenv("SC_MDFT_NOPLANE")))
+        2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane))
     return false;
   const int64_t N = p->n[L], J = p->k[L], n_nt = (N + 31) / 32, JS = (J + 1) / 2;
   const int64_t pl = SC_MDFT_LB / p->n[L - 1];
@@ -595,7 +614,7 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
 static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
-  if (p->mdft && p->l_r2c[mode] && lines < ((int64_t)1 << 36) && !getenv("SC_MDFT_NOLDS")) {
+  if (p->mdft && p->l_r2c[mode] && lines < ((int64_t)1 << 36) && !mdft_switches().nolds) {
     const float* tab = p->l_r2c[mode];
     const cf32* tail = p->l_r2c_tail[mode];
     if (tail) {
@@ -608,8 +627,7 @@ static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64
     return sc_check_launch("k_mdft_r2c_lds");
   }
   if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
-    const char* notail = getenv("SC_MDFT_NOTAIL");
-    if (p->m_r2c_tail[mode] && !notail && 2 * J > 32)
+    if (p->m_r2c_tail[mode] && !mdft_switches().notail && 2 * J > 32)
       dispatch_mdft_r2c<true>(in, out, p->m_r2c[mode], p->m_r2c_tail[mode], lines, N, J, (2 * J - 2) / 32, st);
     else
       dispatch_mdft_r2c<false>(in, out, p->m_r2c[mode], nullptr, lines, N, J, (2 * J + 31) / 32, st);
@@ -688,7 +706,7 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
   if (p->mdft && p->l_c2r[mode] && lines < ((int64_t)1 << 36) && (bias == nullptr || lpi % 32 == 0) &&
-      !getenv("SC_MDFT_NOLDS")) {
+      !mdft_switches().nolds) {
     const int n_nt = (N + 31) / 32;
     if (n_nt >= 4) launch_mdft_c2r_lds<4>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
     else if (n_nt >= 2) launch_mdft_c2r_lds<2>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
@@ -697,8 +715,7 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
   }
   if (p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
     const int n_nt = (N + 31) / 32;
-    const char* tile = getenv("SC_MDFT_TILE");
-    const bool big = !(tile && tile[0] == '4');
+    const bool big = !mdft_switches().tile4;
     const int rt = big ? (n_nt <= 2 ? 4 : (n_nt <= 4 ? 2 : 1)) : (n_nt <= 2 ? 2 : 1);
     if (bias == nullptr || lpi % (32 * rt) == 0) {     // bias must be uniform per wave (32 rt lines)
       if (big) {
@@ -742,13 +759,12 @@ static void launch_mdft_axis(const cf32* in, cf32* out, const float* tab, int64_
 static int run_axis_mdft(const float* tab, const cf32* in, cf32* out, int64_t outer, int N, int J, int64_t inner,
                          sc_stream_t st) {
   const int n_jt = (J + 15) / 16;
-  const char* tile = getenv("SC_MDFT_TILE");
   // column tiles per wave: 4 when that still leaves >= 4 waves per SIMD's worth of waves (4096), fewer for
   // small passes -- the 128^3 first-axis pass (139 k columns) ran 1 wave/SIMD with every table and data
   // load latency exposed: 180 us for 0.18 GB
   const int64_t cols = outer * inner;
   const int ct_max = cols >= (int64_t)4096 * 128 ? 4 : (cols >= (int64_t)4096 * 64 ? 2 : 1);
-  if (tile && tile[0] == '4') {
+  if (mdft_switches().tile4) {
     if (n_jt <= 2) launch_mdft_axis<2, 2>(in, out, tab, outer, N, J, inner, n_jt, st);
     else launch_mdft_axis<4, 1>(in, out, tab, outer, N, J, inner, n_jt, st);
   } else if (ct_max == 1) {
