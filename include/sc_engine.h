@@ -148,6 +148,22 @@ int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
 int sc_bias_grad(const sc_plan* plan, const float* ghat, int64_t batch, int64_t channels,
                  float* gbias, void* stream);
 
+/* ---- fused AdamW step of the spectral weights ("next" row f2 of SURVEY.md section 8) -----------------
+ * One pass over (param, grad, exp_avg, exp_avg_sq) instead of the ~10 elementwise launches of
+ * neuralop/training/adamw.py:155-200 (non-GaLore branch), same arithmetic in the same order:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g conj(g);  p -= step_size m / (sqrt(v) + eps);
+ *   p -= lr weight_decay p        with step_size = lr sqrt(1-b2^t) / (1-b1^t) when correct_bias.
+ * is_complex: the four arrays hold n complex64 values (exp_avg_sq keeps the reference's complex layout,
+ * imaginary part 0); otherwise n floats.  `step` is the 1-based step count AFTER the increment. */
+typedef struct {
+  double lr, beta1, beta2, eps, weight_decay;   /* python floats: 1 - beta is formed in double like upstream */
+  int64_t step;
+  int32_t correct_bias;
+  int32_t reserved;
+} sc_adamw_desc;
+int sc_adamw_step(const sc_adamw_desc* d, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, int is_complex, void* stream);
+
 /* ---- fused dense layer (the reference module's forward / implicit backward) -------------------
  * w: complex (cin, cout, w_extent...) stored weight; the used sub-block starts at w_start[d]
  * in every mode dim and has the plan's `kept` extents (centred block of :465-489).

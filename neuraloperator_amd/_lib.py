@@ -39,6 +39,12 @@ class PlanDesc(Structure):
                 ("freq", POINTER(c_int64) * SC_MAX_DIMS)]
 
 
+class AdamwDesc(Structure):
+    _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
+                ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("step", c_int64),
+                ("correct_bias", c_int32), ("reserved", c_int32)]
+
+
 class ModeGemmDesc(Structure):
     _fields_ = [("P", c_int64), ("Q", c_int64), ("R", c_int64), ("n_modes", c_int64),
                 ("a_sp", c_int64), ("a_sr", c_int64), ("a_sm", c_int64),
@@ -65,7 +71,7 @@ class ScEngineLib:
     # every symbol include/sc_engine.h declares
     SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
                "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
-               "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_bias_grad",
+               "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name"]
 
@@ -103,6 +109,9 @@ class ScEngineLib:
         L.sc_modegemm_uses_matrix_cores.restype = c_int
         L.sc_bias_grad.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
         L.sc_bias_grad.restype = c_int
+        L.sc_adamw_step.argtypes = [POINTER(AdamwDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                    c_int, c_void_p]
+        L.sc_adamw_step.restype = c_int
         L.sc_layer_workspace_bytes.argtypes = [c_void_p, POINTER(LayerDesc)]
         L.sc_layer_workspace_bytes.restype = c_size_t
         L.sc_layer_forward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 7
@@ -189,6 +198,11 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         return bool(self.lib.sc_modegemm_uses_matrix_cores(byref(d)))
+
+    def adamw_step(self, p_ptr, g_ptr, m_ptr, v_ptr, n, is_complex, stream=0, *, lr, beta1, beta2, eps,
+                   weight_decay, correct_bias, step):
+        d = AdamwDesc(lr, beta1, beta2, eps, weight_decay, int(step), int(bool(correct_bias)), 0)
+        self._check(self.lib.sc_adamw_step(byref(d), p_ptr, g_ptr, m_ptr, v_ptr, n, int(bool(is_complex)), stream))
 
     def bias_grad(self, plan, ghat_ptr, batch, channels, gbias_ptr, stream=0):
         self._check(self.lib.sc_bias_grad(plan, ghat_ptr, batch, channels, gbias_ptr, stream))

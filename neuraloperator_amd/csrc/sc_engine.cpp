@@ -1089,6 +1089,43 @@ extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, 
 }
 
 // ------------------------------------------------------------------------------------------
+// fused AdamW step
+// ------------------------------------------------------------------------------------------
+extern "C" int sc_adamw_step(const sc_adamw_desc* d, float* param, const float* grad, float* exp_avg,
+                             float* exp_avg_sq, int64_t n, int is_complex, void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  if (n <= 0) return 0;
+  SC_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "null argument");
+  SC_CHECK_ARG(d->step >= 1, "step counts from 1");
+  AdamwArgs a;
+  a.b1 = (float)d->beta1;
+  a.b2 = (float)d->beta2;
+  a.one_m_b1 = (float)(1.0 - d->beta1);
+  a.one_m_b2 = (float)(1.0 - d->beta2);
+  a.eps = (float)d->eps;
+  double step_size = d->lr;
+  if (d->correct_bias) {                      // adamw.py:176-179, in double like the python arithmetic
+    const double bc1 = 1.0 - std::pow(d->beta1, (double)d->step);
+    const double bc2 = 1.0 - std::pow(d->beta2, (double)d->step);
+    step_size = step_size * std::sqrt(bc2) / bc1;
+  }
+  a.step_size = (float)step_size;
+  a.decay = d->weight_decay > 0.0 ? (float)(d->lr * d->weight_decay) : 0.f;
+  sc_stream_t st = (sc_stream_t)stream;
+  const int64_t pairs = is_complex ? n : n / 2;
+  if (pairs > 0) {
+    int64_t blocks = (pairs + SC_BLOCK - 1) / SC_BLOCK;
+    if (blocks > 8192) blocks = 8192;
+    const int64_t stride = blocks * SC_BLOCK;
+    if (is_complex) SC_LAUNCH((k_adamw<true>), dim3((unsigned)blocks), dim3(SC_BLOCK), 0, st, a, param, grad, exp_avg, exp_avg_sq, pairs, stride);
+    else SC_LAUNCH((k_adamw<false>), dim3((unsigned)blocks), dim3(SC_BLOCK), 0, st, a, param, grad, exp_avg, exp_avg_sq, pairs, stride);
+  }
+  if (!is_complex && (n & 1))
+    SC_LAUNCH(k_adamw_tail, dim3(1), dim3(SC_WAVE), 0, st, a, param, grad, exp_avg, exp_avg_sq, n - 1);
+  return sc_check_launch("k_adamw");
+}
+
+// ------------------------------------------------------------------------------------------
 // fused dense layer
 // ------------------------------------------------------------------------------------------
 static bool layer_full_block(const sc_plan* p, const sc_layer_desc* L) {

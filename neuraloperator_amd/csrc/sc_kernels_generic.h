@@ -378,3 +378,62 @@ k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias, int64_t ba
   }
   if (lane == 0) gbias[c] = part[0];
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Fused AdamW step (neuralop/training/adamw.py:155-200 without the GaLore projection): one read of
+// (p, g, m, v), one write of (p, m, v).  Streaming: 7 arrays of the weight's size cross HBM once.
+// CPX: elements are complex64 -- m and the update are complex, v accumulates g conj(g) = |g|^2 (its
+// imaginary lane only decays, as in the reference's complex exp_avg_sq).
+// ------------------------------------------------------------------------------------------
+struct AdamwArgs {
+  float b1, b2, one_m_b1, one_m_b2, eps, step_size, decay;   // decay = lr * weight_decay (0: none)
+};
+
+template <bool CPX>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_adamw(AdamwArgs a, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+        float* __restrict__ v, int64_t n_pairs, int64_t stride) {
+  // one thread = two floats (one complex value, or two neighbouring real ones); stride = threads in the grid
+  for (int64_t i = (int64_t)SC_BID_X * SC_BLOCK + SC_TID; i < n_pairs; i += stride) {
+    const cf32 gg = reinterpret_cast<const cf32*>(g)[i];
+    cf32 mm = reinterpret_cast<cf32*>(m)[i], vv = reinterpret_cast<cf32*>(v)[i], pp = reinterpret_cast<cf32*>(p)[i];
+    mm.x = a.b1 * mm.x + a.one_m_b1 * gg.x;
+    mm.y = a.b1 * mm.y + a.one_m_b1 * gg.y;
+    float dx, dy;
+    if (CPX) {
+      vv.x = a.b2 * vv.x + a.one_m_b2 * (gg.x * gg.x + gg.y * gg.y);
+      vv.y = a.b2 * vv.y;
+      dx = dy = sqrtf(vv.x) + a.eps;
+    } else {
+      vv.x = a.b2 * vv.x + a.one_m_b2 * (gg.x * gg.x);
+      vv.y = a.b2 * vv.y + a.one_m_b2 * (gg.y * gg.y);
+      dx = sqrtf(vv.x) + a.eps;
+      dy = sqrtf(vv.y) + a.eps;
+    }
+    pp.x -= a.step_size * (mm.x / dx);
+    pp.y -= a.step_size * (mm.y / dy);
+    if (a.decay > 0.f) {
+      pp.x -= a.decay * pp.x;
+      pp.y -= a.decay * pp.y;
+    }
+    reinterpret_cast<cf32*>(m)[i] = mm;
+    reinterpret_cast<cf32*>(v)[i] = vv;
+    reinterpret_cast<cf32*>(p)[i] = pp;
+  }
+}
+
+// odd real element count: the last float on its own
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_WAVE)
+k_adamw_tail(AdamwArgs a, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+             float* __restrict__ v, int64_t idx) {
+  if (SC_TID != 0) return;
+  const float gg = g[idx];
+  const float mm = a.b1 * m[idx] + a.one_m_b1 * gg;
+  const float vv = a.b2 * v[idx] + a.one_m_b2 * gg * gg;
+  float pp = p[idx] - a.step_size * (mm / (sqrtf(vv) + a.eps));
+  if (a.decay > 0.f) pp -= a.decay * pp;
+  m[idx] = mm;
+  v[idx] = vv;
+  p[idx] = pp;
+}

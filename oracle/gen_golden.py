@@ -169,6 +169,40 @@ def gen_transform(ref, name, spatial, output_shape, seed):
     return out
 
 
+# reference AdamW (neuralop/training/adamw.py): name, kwargs, number of steps
+ADAMW_CASES = [
+    ("adamw_default", dict(lr=1e-2), 4),
+    ("adamw_decay_nobias", dict(lr=3e-3, betas=(0.8, 0.95), eps=1e-8, weight_decay=0.1, correct_bias=False), 3),
+]
+
+
+def gen_adamw(name, kw, steps, seed):
+    """A complex (4, 3, 6, 5) and a real (7, 5) [odd element count] parameter, `steps` updates with seeded
+    gradients through the verbatim optimizer; stores every gradient and the parameters / state at the end
+    and after the first step."""
+    adamw = ref_verbatim.load_reference_adamw()
+    torch.manual_seed(seed)
+    pc = torch.nn.Parameter(torch.randn(4, 3, 6, 5, dtype=torch.cfloat))
+    pr = torch.nn.Parameter(torch.randn(7, 5))
+    out = dict(pc0=_np(pc).copy(), pr0=_np(pr).copy(), steps=np.array(steps))   # copies: the optimizer works in place
+    import json
+    out["kwargs"] = np.array(json.dumps(kw))
+    opt = adamw.AdamW([pc, pr], **kw)
+    for t in range(steps):
+        gc, gr = torch.randn_like(pc), torch.randn_like(pr)
+        out[f"gc_{t}"], out[f"gr_{t}"] = _np(gc), _np(gr)
+        pc.grad, pr.grad = gc.clone(), gr.clone()
+        opt.step()
+        if t == 0:
+            out["pc_after1"], out["pr_after1"] = _np(pc).copy(), _np(pr).copy()
+    out["pc"], out["pr"] = _np(pc).copy(), _np(pr).copy()
+    for nm, p in (("c", pc), ("r", pr)):
+        out[f"m_{nm}"] = _np(opt.state[p]["exp_avg"]).copy()
+        out[f"v_{nm}"] = _np(opt.state[p]["exp_avg_sq"]).copy()
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+    return out
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     ref = ref_verbatim.load_reference()
@@ -185,6 +219,9 @@ def main():
     for i, case in enumerate(TRANSFORM_CASES):
         o = gen_transform(ref, *case, seed=4000 + i)
         print(f"{case[0]:32s} t{o['t'].shape}")
+    for i, case in enumerate(ADAMW_CASES):
+        o = gen_adamw(*case, seed=5000 + i)
+        print(f"{case[0]:32s} |pc|={np.abs(o['pc']).mean():.3f} v dtype {o['v_c'].dtype}")
     total = sum(os.path.getsize(os.path.join(GOLDEN_DIR, f)) for f in os.listdir(GOLDEN_DIR))
     print(f"golden dir: {total/1024:.0f} KiB")
 

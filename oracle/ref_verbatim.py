@@ -55,3 +55,24 @@ def load_reference():
     if "neuralop.utils" not in sys.modules:
         _load("neuralop.utils", os.path.join(root, "utils.py"))
     return _load(name, os.path.join(root, "layers", "spectral_convolution.py"))
+
+
+def load_reference_adamw():
+    """The verbatim ``neuralop.training.adamw`` module.  Its Tensor-GaLore projector imports tensorly's
+    decompositions (absent); a placeholder module takes its place -- the non-GaLore branch never touches it."""
+    if not available():
+        raise RuntimeError(f"reference not present under {REFERENCE_ROOT}")
+    name = "neuralop.training.adamw"
+    if name in sys.modules:
+        return sys.modules[name]
+    root = os.path.join(REFERENCE_ROOT, "neuralop")
+    for pkg, sub in (("neuralop", ""), ("neuralop.training", "training")):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(root, sub) if sub else root]
+            sys.modules[pkg] = m
+    if "neuralop.training.tensor_galore_projector" not in sys.modules:
+        stub = types.ModuleType("neuralop.training.tensor_galore_projector")
+        stub.TensorGaLoreProjector = type("TensorGaLoreProjector", (), {})
+        sys.modules["neuralop.training.tensor_galore_projector"] = stub
+    return _load(name, os.path.join(root, "training", "adamw.py"))
