@@ -42,5 +42,5 @@ st = dict(m=torch.zeros_like(p2), v=torch.zeros_like(p2), step=0)
 with torch.no_grad():
     t_ref = timed(lambda: ref_step(p2, g2, st, wd=1e-4))
 mb = w.numel() * 8 / 1e6
-print(f"weight {mb:.1f} MB: fused {t_fused:.1f} us ({7 * mb / t_fused / 1e3:.2f} TB/s over 7 arrays)   "
+print(f"weight {mb:.1f} MB: fused {t_fused:.1f} us ({7 * mb / t_fused:.2f} TB/s over 7 arrays)   "
       f"elementwise chain {t_ref:.1f} us   ({t_ref / t_fused:.1f}x)")
