@@ -665,9 +665,27 @@ static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const 
             J, n_nt, lpi, channels);
 }
 
+#define SC_C2R_NPF 12          // registers per thread holding the next tile's input
+template <int CT, int NR, int NPF>
+static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
+                                    int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st);
+
 template <int CT, int NR = 0>
 static void launch_mdft_c2r_lds(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
                                 int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
+  // next-tile prefetch when a thread's share of a tile's input fits SC_C2R_NPF registers
+  const int L = p->nd - 1;
+  const int64_t per_tile = NR > 0 ? (int64_t)(SC_MDFT_LB / (NR > 0 ? NR : SC_MDFT_LB)) * p->k[L - 1 >= 0 ? L - 1 : 0] * J
+                                  : (int64_t)SC_MDFT_LB * J;
+  if (per_tile <= 256 * SC_C2R_NPF)
+    launch_mdft_c2r_lds_npf<CT, NR, SC_C2R_NPF>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  else
+    launch_mdft_c2r_lds_npf<CT, NR, 0>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+}
+
+template <int CT, int NR, int NPF>
+static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
+                                    int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
   constexpr bool PLANE = NR > 0;
   const int tpb = mdft_lds_tiles_per_block(lines);
   const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
@@ -676,7 +694,7 @@ static void launch_mdft_c2r_lds(const sc_plan* p, int mode, const cf32* in, floa
   const int K1 = PLANE ? (int)p->k[L - 1] : 0;
   const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * sizeof(float) +
                      (size_t)(PLANE ? SC_MDFT_LB / NR : 0) * K1 * J * sizeof(cf32);
-  SC_LAUNCH((k_mdft_c2r_lds<CT, NR>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
+  SC_LAUNCH((k_mdft_c2r_lds<CT, NR, NPF>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
             (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb,
             PLANE ? (const float*)p->m_ax_inv[L - 1] : (const float*)nullptr, K1);
 }

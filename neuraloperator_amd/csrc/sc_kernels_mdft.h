@@ -630,7 +630,10 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // product of k_mdft_axis (table tabA in that kernel's layout: NR / 16 row tiles per plane, two per wave)
 // straight into the tile buffer, and the last-axis pass follows as before: the NR x J intermediate never
 // reaches HBM and one launch disappears.
-template <int CT, int NR = 0>
+// NPF > 0: the NEXT tile's input (its spectrum rows / its planes) is requested into NPF registers per thread
+// before the current tile is multiplied, so its HBM latency hides behind the MFMAs and stores instead of
+// opening every tile (the kernel sat at 36 % matrix-core busy with 46 % of its wave cycles waiting).
+template <int CT, int NR = 0, int NPF = 0>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 4 ? 3 : 4))
 k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
@@ -660,6 +663,30 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
   const int dq = 256 / J, dr = 256 - dq * J;
   const int line_first = tid / J, j_first = tid - line_first * J;
   const int E = LB * J;
+  cf32 pre[NPF ? NPF : 1];
+  auto prefetch = [&](const int ti) {
+    const int64_t l0 = (tile0 + ti) * LB;
+    if (!PLANE) {
+      const int64_t rem = lines - l0;
+      const int Ev = (int)((rem < LB ? rem : LB) * J);
+      const cf32* src = in + l0 * J;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int idx = tid + 256 * u;
+        pre[u] = src[idx < Ev ? idx : Ev - 1];
+      }
+    } else {
+      const cf32* zsrc = in + (l0 / NRD) * K1 * J;
+      const int64_t left = (lines - l0) / NRD;
+      const int zvalid = (int)(left < PL ? left : PL) * K1 * J;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int i = tid + 256 * u;
+        pre[u] = zsrc[i < zvalid ? i : zvalid - 1];
+      }
+    }
+  };
+  if (NPF) prefetch(0);
 #pragma unroll 1
   for (int ti = 0; ti < my_tiles; ++ti) {
     const int64_t l0 = (tile0 + ti) * LB;
@@ -667,7 +694,19 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
     const int Ev = (int)((rem < LB ? rem : LB) * J);             // valid elements (ragged last tile)
     const cf32* src = in + l0 * J;
     SC_SYNC();                                                   // previous tile consumed / table staged
-    if (!PLANE) {
+    if (!PLANE && NPF) {
+      int line = line_first, j = j_first;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        if (tid + 256 * u < E) dat[line * SC2 + j] = pre[u];
+        j += dr;
+        line += dq;
+        if (j >= J) {
+          j -= J;
+          ++line;
+        }
+      }
+    } else if (!PLANE) {
       int line = line_first, j = j_first;
 #pragma unroll 1
       for (int base = tid; base < E; base += 1024) {
@@ -690,11 +729,18 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
         }
       }
     } else {
-      const cf32* zsrc = in + (l0 / NRD) * K1 * J;
-      const int64_t left = (lines - l0) / NRD;                   // planes from this tile to the end
-      const int zvalid = (int)(left < PL ? left : PL) * K1 * J;
-      for (int i = tid; i < PL * K1 * J; i += 256) Zs[i] = zsrc[i < zvalid ? i : zvalid - 1];
+      if (NPF) {
+#pragma unroll
+        for (int u = 0; u < NPF; ++u)
+          if (tid + 256 * u < PL * K1 * J) Zs[tid + 256 * u] = pre[u];
+      } else {
+        const cf32* zsrc = in + (l0 / NRD) * K1 * J;
+        const int64_t left = (lines - l0) / NRD;                 // planes from this tile to the end
+        const int zvalid = (int)(left < PL ? left : PL) * K1 * J;
+        for (int i = tid; i < PL * K1 * J; i += 256) Zs[i] = zsrc[i < zvalid ? i : zvalid - 1];
+      }
       SC_SYNC();
+      if (NPF && ti + 1 < my_tiles) prefetch(ti + 1);
       // rows 16 jt .. 16 jt + 15 of plane pl for jt = wl and wl + WPP:  Y[n1][j2] = sum_j1 T[n1][j1] Z[j1][j2]
       const int pl = w / WPP, wl = w % WPP;
       const int NSa = (K1 + 1) / 2;
@@ -729,6 +775,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
       }
     }
     SC_SYNC();
+    if (!PLANE && NPF && ti + 1 < my_tiles) prefetch(ti + 1);
     const int64_t lw = l0 + 32 * w;
     if (lw >= lines) continue;                                   // wave-uniform; barriers stay matched below
     const float badd = (bias != nullptr) ? bias[(lw / lines_per_image) % channels] : 0.f;
