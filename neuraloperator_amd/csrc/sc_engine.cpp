@@ -574,7 +574,7 @@ static bool plane_inv_ok(const sc_plan* p, int mode) {
     return false;
   const int64_t N = p->n[L], J = p->k[L], n_nt = (N + 31) / 32, JS = (J + 1) / 2;
   const int64_t pl = SC_MDFT_LB / p->n[L - 1];
-  const int64_t bytes = (n_nt * JS * 128 + SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * 4 + pl * p->k[L - 1] * J * 8;
+  const int64_t bytes = (n_nt * JS * 128 + SC_MDFT_LB * p->l_c2r_s + SC_C2R_PATCH_FLOATS) * 4 + pl * p->k[L - 1] * J * 8;
   return bytes <= 60 * 1024;
 }
 
@@ -692,7 +692,7 @@ static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, 
   const int n_nt = (N + 31) / 32, JS = (J + 1) / 2;
   const int L = p->nd - 1;
   const int K1 = PLANE ? (int)p->k[L - 1] : 0;
-  const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + 4 * 2 * 8 * 36) * sizeof(float) +
+  const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + SC_C2R_PATCH_FLOATS) * sizeof(float) +
                      (size_t)(PLANE ? SC_MDFT_LB / NR : 0) * K1 * J * sizeof(cf32);
   SC_LAUNCH((k_mdft_c2r_lds<CT, NR, NPF>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
             (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb,
