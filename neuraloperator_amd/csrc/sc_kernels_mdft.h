@@ -388,11 +388,13 @@ struct alignas(16) sc_f4 {
 SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
 
 #define SC_MDFT_LB 128          // lines per block tile (4 waves x one 32-line MFMA row tile)
-// c2r store patches: 8 rows x 32 floats, row stride 40 floats -- rows u and u + 4 (the two lane halves of one
-// write) land 160 = 32 (mod 64) banks apart, i.e. on disjoint bank halves (stride 36 put them 16 apart: 2-way
-// conflicts on half the banks, 23 % of the plane inverse's LDS cycles)
-#define SC_C2R_PS 40
-#define SC_C2R_PATCH_FLOATS (4 * 2 * 8 * SC_C2R_PS)
+// c2r store patches: 8 rows x 32 floats kept as 4 lines of [row u | row u + 4], line stride 96 floats: the two
+// lane halves of a write (rows u, u + 4) fill the two halves of the 64 banks, and the 16 lanes of a 16-byte
+// read pass (rows 2k, 2k + 1 of one side) land 96 = 32 (mod 64) banks apart -- conflict free both ways.
+// (Plain row strides: 36 -> halves 16 banks apart on the write, 40 -> neighbouring rows 8 banks short on the
+// read; 23-31 % of the plane inverse's LDS cycles were bank conflicts.)
+#define SC_C2R_PL 96
+#define SC_C2R_PATCH_FLOATS (4 * 2 * 4 * SC_C2R_PL)
 
 // ------------------------------------------------------------------------------------------
 // last axis, real -> complex through LDS.  N % 32 == 0, N <= 256, CT column tiles (2J floats <= 32 CT,
@@ -625,7 +627,7 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // last axis, complex -> real through LDS.  One tile = 128 lines x J cf32 (contiguous in memory) copied
 // to rows of S floats (S/2 odd: the 8-byte operand reads of 32 lines hit 32 different bank pairs).
 //   tab [(((nt * JS + t) * 64 + lane) * 2 + comp] : comp 0 multiplies Re(in[l][2t + (lane>>5)]), comp 1 Im
-// dynamic LDS: the table (n_nt * JS * 128 floats), the tile (128 * S floats), 4 x 2 store patches (8 x SC_C2R_PS floats).
+// dynamic LDS: the table (n_nt * JS * 128 floats), the tile (128 * S floats), 4 x 2 store patches.
 // A wave's 32 lines must share one bias value (lines_per_image % 32 == 0 when bias != nullptr).
 // ------------------------------------------------------------------------------------------
 //
@@ -654,7 +656,7 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
   const int tab4 = n_nt * JS * 32;                               // table size in float4
   const cf32* tabL = reinterpret_cast<const cf32*>(lds);
   cf32* dat = reinterpret_cast<cf32*>(lds + tab4);
-  float* stg = reinterpret_cast<float*>(lds + tab4) + LB * S;   // 4 waves x 2 patches x 8 x SC_C2R_PS floats
+  float* stg = reinterpret_cast<float*>(lds + tab4) + LB * S;   // 4 waves x 2 patches (SC_C2R_PATCH_FLOATS)
   cf32* Zs = reinterpret_cast<cf32*>(stg + SC_C2R_PATCH_FLOATS);   // plane form: PL x K1 x J
   const int64_t n_tiles = (lines + LB - 1) / LB;
   const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
@@ -830,18 +832,18 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
       // accumulator registers 4g..4g+3 of the two lane halves are 8 consecutive lines x 32 floats: through a
       // per-wave LDS patch they leave as ONE 16-byte-per-lane store (8 lines x 128 bytes) instead of four
       // dword stores -- a quarter of the store instructions.  N % 4 == 0 (host checks).
-      float* patch = stg + w * (2 * 8 * SC_C2R_PS);
+      float* patch = stg + w * (2 * 4 * SC_C2R_PL);
       const int prow = lane >> 3, pc4 = lane & 7;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         if (nt0 + c >= n_nt) continue;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          float* pb = patch + ((c * 4 + gq) & 1) * (8 * SC_C2R_PS);
+          float* pb = patch + ((c * 4 + gq) & 1) * (4 * SC_C2R_PL);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) pb[(u + 4 * half) * SC_C2R_PS + col] = acc[c][4 * gq + u] + badd;
+          for (int u = 0; u < 4; ++u) pb[u * SC_C2R_PL + 32 * half + col] = acc[c][4 * gq + u] + badd;
           SC_WAVE_SYNC();
-          const sc_f4 o = *reinterpret_cast<const sc_f4*>(pb + prow * SC_C2R_PS + 4 * pc4);
+          const sc_f4 o = *reinterpret_cast<const sc_f4*>(pb + (prow & 3) * SC_C2R_PL + 32 * (prow >> 2) + 4 * pc4);
           const int64_t line = lwe + 8 * gq + prow;
           const int n = 32 * (nt0 + c) + 4 * pc4;
           if (line < lines && n < N && MDFT_STORE_OK(o.x))
