@@ -93,6 +93,8 @@ struct sc_plan {
   int l_r2c_ct = 0;                            // MFMA column tiles (tail column excluded)
   float* l_c2r[2] = {nullptr, nullptr};
   int l_c2r_s = 0;                             // LDS row stride of the c2r tile, floats
+  float* m_pl_fwd = nullptr;                   // plane form: row-pass table of dim nd-2, forward ([jt][n1][64])
+  float* m_pl_inv = nullptr;                   // ... inverse ([row tile][j1][64])
   float* m_ax_fwd[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   float* m_ax_inv[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   // fast path (power-of-two 2-D), see sc_kernels_fft.h
@@ -318,6 +320,31 @@ static int build_mdft_tables(sc_plan* p) {
               h[(size_t)(((jt * NS + sidx) * 2 + comp) * 64 + lane)] = val;
             }
       rc = upload_floats(p, h, dir ? &p->m_ax_inv[d] : &p->m_ax_fwd[d]);
+    }
+  }
+  // plane form (sc_kernels_mdft.h): forward row pass of the second-to-last dim, rows j1 x (Re T | Im T) lanes
+  if (!rc && L >= 1 && (p->n[L - 1] == 128 || p->n[L - 1] == 64 || p->n[L - 1] == 32) && 2 * p->k[L - 1] <= p->n[L - 1]) {
+    const int d = L - 1;
+    const int64_t NR = p->n[d], K1 = p->k[d], JP = (K1 + 31) / 32;
+    std::vector<float> h((size_t)(JP * NR * 64), 0.f);
+    for (int64_t jt = 0; jt < JP; ++jt)
+      for (int64_t n1 = 0; n1 < NR; ++n1)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int64_t j1 = 32 * jt + (lane & 31);
+          if (j1 >= K1) continue;
+          const cf32 tw = axis_tw(p, d, j1, n1, -1.0);
+          h[(size_t)((jt * NR + n1) * 64 + lane)] = (lane >> 5) ? tw.y : tw.x;
+        }
+    rc = upload_floats(p, h, &p->m_pl_fwd);
+    if (!rc) {
+      std::vector<float> hi((size_t)((NR / 32) * K1 * 64), 0.f);
+      for (int64_t rt = 0; rt < NR / 32; ++rt)
+        for (int64_t j1 = 0; j1 < K1; ++j1)
+          for (int lane = 0; lane < 64; ++lane) {
+            const cf32 tw = axis_tw(p, d, j1, 32 * rt + (lane & 31), +1.0);
+            hi[(size_t)((rt * K1 + j1) * 64 + lane)] = (lane >> 5) ? tw.y : tw.x;
+          }
+      rc = upload_floats(p, hi, &p->m_pl_inv);
     }
   }
   if (!rc) p->mdft = true;
@@ -560,22 +587,25 @@ static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, co
             (size_t)(N / 8) * CT * 1024, st, in, (float*)out, tab, tail, lines, N, J, tpb, tab1, K1);
 }
 
+#define SC_C2R_NPF 12          // registers per thread holding the next tile's input (k_mdft_c2r_lds)
 // ---- "plane" form: the last TWO axes in one launch when the second-to-last has 128, 64 or 32 rows --------
 static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32; }
 static bool plane_fwd_ok(const sc_plan* p, int mode) {
   const int L = p->nd - 1;
-  return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_ax_fwd[L - 1] && plane_rows_ok(p->n[L - 1]) &&
+  return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_pl_fwd && plane_rows_ok(p->n[L - 1]) &&
          2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane;
 }
 static bool plane_inv_ok(const sc_plan* p, int mode) {
   const int L = p->nd - 1;
-  if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_ax_inv[L - 1] && plane_rows_ok(p->n[L - 1]) &&
+  if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_pl_inv && plane_rows_ok(p->n[L - 1]) &&
         2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane))
     return false;
   const int64_t N = p->n[L], J = p->k[L], n_nt = (N + 31) / 32, JS = (J + 1) / 2;
   const int64_t pl = SC_MDFT_LB / p->n[L - 1];
   const int64_t bytes = (n_nt * JS * 128 + SC_MDFT_LB * p->l_c2r_s + SC_C2R_PATCH_FLOATS) * 4 + pl * p->k[L - 1] * J * 8;
-  return bytes <= 60 * 1024;
+  const bool atail = J > 1 && (2 * J) % 32 == 2 && 2 * J > 32;
+  const int64_t ca = ((atail ? 2 * J - 2 : 2 * J) + 31) / 32;
+  return bytes <= 60 * 1024 && pl * p->k[L - 1] * J <= 256 * SC_C2R_NPF && ca <= 2;
 }
 
 template <int CT, bool TAIL>
@@ -584,15 +614,13 @@ static void dispatch_plane_fwd(const sc_plan* p, int mode, const float* in, cf32
   const int N = (int)p->n[L], J = (int)p->k[L], K1 = (int)p->k[L - 1];
   const float* tab = p->l_r2c[mode];
   const cf32* tail = p->l_r2c_tail[mode];
-  const float* t1 = p->m_ax_fwd[L - 1];
+  const float* t1 = p->m_pl_fwd;
   const int64_t nr = p->n[L - 1];                      // K1 <= nr / 2 (plane_fwd_ok)
   if (nr == 128) {
-    if (K1 <= 16) launch_mdft_r2c_lds<CT, TAIL, 1, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
-    else if (K1 <= 32) launch_mdft_r2c_lds<CT, TAIL, 2, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
-    else launch_mdft_r2c_lds<CT, TAIL, 4, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
+    if (K1 <= 32) launch_mdft_r2c_lds<CT, TAIL, 1, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
+    else launch_mdft_r2c_lds<CT, TAIL, 2, 128>(in, out, tab, tail, lines, N, J, st, t1, K1);
   } else if (nr == 64) {
-    if (K1 <= 16) launch_mdft_r2c_lds<CT, TAIL, 1, 64>(in, out, tab, tail, lines, N, J, st, t1, K1);
-    else launch_mdft_r2c_lds<CT, TAIL, 2, 64>(in, out, tab, tail, lines, N, J, st, t1, K1);
+    launch_mdft_r2c_lds<CT, TAIL, 1, 64>(in, out, tab, tail, lines, N, J, st, t1, K1);
   } else {
     launch_mdft_r2c_lds<CT, TAIL, 1, 32>(in, out, tab, tail, lines, N, J, st, t1, K1);
   }
@@ -665,8 +693,7 @@ static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const 
             J, n_nt, lpi, channels);
 }
 
-#define SC_C2R_NPF 12          // registers per thread holding the next tile's input
-template <int CT, int NR, int NPF>
+template <int CT, int NR, int NPF, int CA = 1, bool ATAIL = false>
 static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
                                     int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st);
 
@@ -677,13 +704,21 @@ static void launch_mdft_c2r_lds(const sc_plan* p, int mode, const cf32* in, floa
   const int L = p->nd - 1;
   const int64_t per_tile = NR > 0 ? (int64_t)(SC_MDFT_LB / (NR > 0 ? NR : SC_MDFT_LB)) * p->k[L - 1 >= 0 ? L - 1 : 0] * J
                                   : (int64_t)SC_MDFT_LB * J;
-  if (per_tile <= 256 * SC_C2R_NPF)
+  if (NR > 0) {                    // plane form (plane_inv_ok: the planes of a tile fit the prefetch registers)
+    const bool atail = J > 1 && (2 * J) % 32 == 2 && 2 * J > 32;
+    const int ca = ((atail ? 2 * J - 2 : 2 * J) + 31) / 32;
+    if (atail && ca == 1) launch_mdft_c2r_lds_npf<CT, NR, (NR ? SC_C2R_NPF : 0), 1, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else if (atail) launch_mdft_c2r_lds_npf<CT, NR, (NR ? SC_C2R_NPF : 0), 2, true>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else if (ca == 1) launch_mdft_c2r_lds_npf<CT, NR, (NR ? SC_C2R_NPF : 0), 1, false>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else launch_mdft_c2r_lds_npf<CT, NR, (NR ? SC_C2R_NPF : 0), 2, false>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  } else if (per_tile <= 256 * SC_C2R_NPF) {
     launch_mdft_c2r_lds_npf<CT, NR, SC_C2R_NPF>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
-  else
+  } else {
     launch_mdft_c2r_lds_npf<CT, NR, 0>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+  }
 }
 
-template <int CT, int NR, int NPF>
+template <int CT, int NR, int NPF, int CA, bool ATAIL>
 static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
                                     int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
   constexpr bool PLANE = NR > 0;
@@ -694,9 +729,9 @@ static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, 
   const int K1 = PLANE ? (int)p->k[L - 1] : 0;
   const size_t lds = ((size_t)n_nt * JS * 128 + (size_t)SC_MDFT_LB * p->l_c2r_s + SC_C2R_PATCH_FLOATS) * sizeof(float) +
                      (size_t)(PLANE ? SC_MDFT_LB / NR : 0) * K1 * J * sizeof(cf32);
-  SC_LAUNCH((k_mdft_c2r_lds<CT, NR, NPF>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
+  SC_LAUNCH((k_mdft_c2r_lds<CT, NR, NPF, CA, ATAIL>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
             (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb,
-            PLANE ? (const float*)p->m_ax_inv[L - 1] : (const float*)nullptr, K1);
+            PLANE ? (const float*)p->m_pl_inv : (const float*)nullptr, K1);
 }
 
 // (planes x K1 x J complex) -> y (planes x 128 x N real): second-to-last axis + last axis (+ bias)

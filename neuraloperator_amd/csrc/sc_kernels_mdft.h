@@ -407,18 +407,23 @@ SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 
 //
 // JP > 0 ("plane" form, second-to-last axis of NR = 128, 64 or 32 rows: a tile is 1, 2 or 4 whole planes):
 // the tile's 128 x J result is not written out but kept in LDS (Y, over the chunk buffer), and the pruned
-// transform along the NR rows of each plane follows at once (the data x table MFMA product of k_mdft_axis,
-// table tab1 in that kernel's layout):
-//   Z[j1][j2] = sum_n1 T1[j1][n1] Y[n1][j2],  K1 kept rows = n_jt tiles of 16, JP >= n_jt row tiles at once.
-// A plane belongs to NR / 32 waves; wave wl of them takes row tile wl % JP and the n1 range number wl / JP
-// (its slice of tab1 lives in registers for the whole launch); partial sums of the ranges meet in LDS.
+// transform along the NR rows of each plane follows at once as ONE real MFMA product per input row n1:
+//   Z[j1][(j2, c)] = sum_n1 ( Tr[j1][n1] Y[n1][(j2, c)] + Ti[j1][n1] rot(Y)[n1][(j2, c)] ),
+//   rot(Y)[(j2, 0)] = -Im Y[j2], rot(Y)[(j2, 1)] = Re Y[j2]
+// i.e. tile rows = 32 kept rows j1, tile columns = the row's floats exactly as they lie in Y, k = (Re T, Im T)
+// on the two lane halves (table tab1: [(jt * NR + n1) * 64 + lane] = lane < 32 ? Tr : Ti of row 32 jt + lane % 32).
+// With J = 2^k + 1 the 32 CT columns are all real work and the last column is a VALU dot product again; the
+// (row, re/im) x column-index tiling of k_mdft_axis spent half its MFMAs on 15 padding columns of 32.
+// JP = row tiles (K1 <= 32 JP).  A plane belongs to NR / 32 waves; wave wl of them takes row tile wl % JP and
+// the n1 range number wl / JP (its slice of tab1 lives in registers for the whole launch); partial sums of
+// the ranges meet in LDS.
 // out is then complex (planes, K1, J).  The NR x J intermediate (0.57 GB each way on 128^3) never reaches
 // HBM and one launch disappears.
 template <int CT, bool TAIL, int JP = 0, int NR = SC_MDFT_LB>
 #ifndef SC_PLANE_OCC
 #define SC_PLANE_OCC 2
 #endif
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (JP ? ((JP == 4 && CT == 2) ? 1 : ((JP <= 2 && CT == 1) ? SC_PLANE_OCC : 2)) : (CT == 1 ? 4 : 3)))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (JP ? ((JP == 2 || CT == 2) ? 1 : SC_PLANE_OCC) : (CT == 1 ? 4 : 3)))
 k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                const cf32* __restrict__ tail, int64_t lines, int N, int J, int tiles_per_block,
                const float* __restrict__ tab1, int K1) {
@@ -426,14 +431,15 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
   constexpr int SY = 32 * CT + 8;                            // Y row stride (floats): holds 2J <= 32 CT + 2
   constexpr int DAT4 = (JP && LB * SY > LB * S4 * 4) ? LB * SY / 4 : LB * S4;
   constexpr int PL = LB / NR, WPP = 4 / PL;                  // planes per tile, waves per plane
-  constexpr int JPD = JP ? JP : 1, KP = (WPP / JPD) ? (WPP / JPD) : 1, NS = NR / 2;
+  constexpr int JPD = JP ? JP : 1, KP = (WPP / JPD) ? (WPP / JPD) : 1, NS = NR;   // one k-step per input row
   static_assert(!JP || JPD * KP == WPP, "row tiles x n1 ranges = waves of a plane");
-  constexpr int REDF = (JP && KP > 1) ? PL * (KP - 1) * JPD * 1024 : 1;   // partial-sum tiles of the row pass
+  constexpr int REDF = (JP && KP > 1) ? PL * (KP - 1) * JPD * CT * 1024 : 1;   // partial-sum tiles of the row pass
   SC_DYN_SHARED(sc_f4, tabL);
   SC_SHARED sc_f4 dat[DAT4];                                 // chunk buffer; plane form: then the tile result Y
   SC_SHARED sc_f4 tailL[TAIL ? 128 : 1];                     // 256 cf32
   SC_SHARED cf32 tsum[TAIL ? 128 : 1];
   SC_SHARED float red[REDF];
+  SC_SHARED cf32 tred[(JP && TAIL) ? 256 : 1];                // tail column: one partial per lane
   float* Y = reinterpret_cast<float*>(dat);
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
@@ -455,19 +461,14 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
   // plane form: this wave's (row tile, n1 range) slice of the row-pass table is the same for every plane
   // it will see -- it lives in registers (one 256-byte L2 read per MFMA with a one-step prefetch left the
   // matrix cores waiting: 883 us for the pair of passes that took 504 + 274 us apart)
-  const int n_jt = (K1 + 15) / 16;
   const int pl = w / WPP, wl = w % WPP;
   const int jt = wl % JPD, kp = wl / JPD;
   const int s0 = kp * (NS / KP);
-  float t1r[JP ? NS / KP : 1][2];
+  float t1r[JP ? NS / KP : 1];
   if (JP) {
-    const int jtc = jt < n_jt ? jt : n_jt - 1;
-    const float* tp = tab1 + ((int64_t)jtc * NS + s0) * 128 + lane;  // [((jt NS + s) 2 + comp) 64 + lane]
+    const float* tp = tab1 + ((int64_t)jt * NR + s0) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < NS / KP; ++i) {
-      t1r[i][0] = tp[i * 128];
-      t1r[i][1] = tp[i * 128 + 64];
-    }
+    for (int i = 0; i < NS / KP; ++i) t1r[i] = tp[i * 64];
   }
   // loader: thread (lrow, lc4) brings 16 bytes of lines lrow + 32 m, m = 0..3, per chunk
   const int lrow = tid >> 3, lc4 = tid & 7;
@@ -580,37 +581,68 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
           tacc = cf_make(0.f, 0.f);
         }
         SC_SYNC();                               // Y is complete
-        // ---- ... and is transformed along its 128 rows
-        const cf32* yc = reinterpret_cast<const cf32*>(Y) + (col < J ? col : J - 1);
-        sc_f32x16 z;
+        // ---- ... and is transformed along the rows of its planes
+        const float sgn = (half == 0) ? 1.f : ((col & 1) ? 1.f : -1.f);
+        const float* yb = Y + (half == 0 ? col : (col ^ 1));       // rot(Y) for the Im T half
+        const cf32* yt = reinterpret_cast<const cf32*>(Y) + (J - 1);
+        sc_f32x16 z[CT];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) z[v] = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) z[ct][v] = 0.f;
+        cf32 tz = cf_make(0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < NS / KP; ++i) {
-          const cf32 d = yc[(pl * NR + 2 * (s0 + i) + half) * (SY / 2)];
-          MDFT_MFMA(z, t1r[i][0], d.x);
-          MDFT_MFMA(z, t1r[i][1], d.y);
+          const int n1 = pl * NR + s0 + i;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) MDFT_MFMA(z[ct], t1r[i], sgn * yb[n1 * SY + 32 * ct]);
+          if (TAIL) {                                              // (Tr + i Ti) y: this lane holds Tr or Ti
+            const cf32 y = yt[n1 * (SY / 2)];
+            tz.x = fmaf(t1r[i], half ? -y.y : y.x, tz.x);
+            tz.y = fmaf(t1r[i], half ? y.x : y.y, tz.y);
+          }
         }
         if (KP > 1) {
           if (kp > 0) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) red[(((pl * (KP - 1) + kp - 1) * JPD + jt) * 16 + v) * 64 + lane] = z[v];
-          }
-          SC_SYNC();
-          if (kp == 0) {
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int k = 1; k < KP; ++k)
-#pragma unroll
-              for (int v = 0; v < 16; ++v) z[v] += red[(((pl * (KP - 1) + k - 1) * JPD + jt) * 16 + v) * 64 + lane];
+              for (int v = 0; v < 16; ++v)
+                red[((((pl * (KP - 1) + kp - 1) * JPD + jt) * CT + ct) * 16 + v) * 64 + lane] = z[ct][v];
           }
         }
-        const int64_t plane = (l0 / LB) * PL + pl;
-        if (kp == 0 && jt < n_jt && col < J && plane * NR < lines) {
-          cf32* zo = reinterpret_cast<cf32*>(out) + (plane * K1) * J + col;
+        if (TAIL) tred[64 * w + lane] = tz;
+        if (KP > 1 || TAIL) SC_SYNC();
+        if (KP > 1 && kp == 0) {
 #pragma unroll
-          for (int v = 0; v < 16; v += 2) {
-            const int jj = 16 * jt + (mdft_row(v, half) >> 1);
-            if (jj < K1 && MDFT_STORE_OK(z[v])) zo[(int64_t)jj * J] = cf_make(z[v], z[v + 1]);
+          for (int k = 1; k < KP; ++k)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+              for (int v = 0; v < 16; ++v)
+                z[ct][v] += red[((((pl * (KP - 1) + k - 1) * JPD + jt) * CT + ct) * 16 + v) * 64 + lane];
+        }
+        const int64_t plane = (l0 / LB) * PL + pl;
+        if (kp == 0 && plane * NR < lines) {
+          float* zo = out + (plane * K1) * 2 * J;                  // row j1 of the plane = 2J floats
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const int f = 32 * ct + col;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const int j1 = 32 * jt + mdft_row(v, half);
+              if (j1 < K1 && f < fmax && MDFT_STORE_OK(z[ct][v])) zo[(int64_t)j1 * 2 * J + f] = z[ct][v];
+            }
+          }
+          if (TAIL && half == 0) {                                 // both halves of all n1 ranges of row j1
+            const int j1 = 32 * jt + col;
+            cf32 t = cf_make(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+              const int ww = pl * WPP + k * JPD + jt;
+              t = cf_add(t, cf_add(tred[64 * ww + col], tred[64 * ww + 32 + col]));
+            }
+            if (j1 < K1) reinterpret_cast<cf32*>(zo)[(int64_t)j1 * J + (J - 1)] = t;
           }
         }
         // (the barrier that opens the next chunk frees Y; the partial sums are rewritten a whole tile later)
@@ -640,8 +672,12 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // NPF > 0: the NEXT tile's input (its spectrum rows / its planes) is requested into NPF registers per thread
 // before the current tile is multiplied, so its HBM latency hides behind the MFMAs and stores instead of
 // opening every tile (the kernel sat at 36 % matrix-core busy with 46 % of its wave cycles waiting).
-template <int CT, int NR = 0, int NPF = 0>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 4 ? 3 : 4))
+// Plane form row pass (CA column tiles of 32 floats, ATAIL: column J - 1 = 2^k + 1-th on the VALU) -- like the
+// forward one, ONE real MFMA product per kept row j1 with tile rows = 32 output rows n1 (one tile per wave),
+// tile columns = the floats of Z's row as they lie, k = (Re T, Im T) on the two lane halves; table tabA
+// [(rt * K1 + j1) * 64 + lane] = lane < 32 ? Tr : Ti of T[32 rt + lane % 32][j1], this wave's slice in registers.
+template <int CT, int NR = 0, int NPF = 0, int CA = 1, bool ATAIL = false>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (NR == 128 ? 2 : (NR > 0 ? (CA == 2 ? 2 : 3) : (CT == 4 ? 3 : 4))))
 k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
                int64_t lines_per_image, int64_t channels, int tiles_per_block,
@@ -658,6 +694,14 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
   cf32* dat = reinterpret_cast<cf32*>(lds + tab4);
   float* stg = reinterpret_cast<float*>(lds + tab4) + LB * S;   // 4 waves x 2 patches (SC_C2R_PATCH_FLOATS)
   cf32* Zs = reinterpret_cast<cf32*>(stg + SC_C2R_PATCH_FLOATS);   // plane form: PL x K1 x J
+  SC_SHARED cf32 tredA[(PLANE && ATAIL) ? 256 : 1];
+  // plane form: the wave's slice of the row-pass table (its 32 output rows x all kept rows) stays in registers
+  float tar[PLANE ? NRD / 2 : 1];
+  if (PLANE) {
+    const float* ta = tabA + ((int64_t)(w % WPP) * K1) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NRD / 2; ++i) tar[i] = (i < K1) ? ta[i * 64] : 0.f;
+  }
   const int64_t n_tiles = (lines + LB - 1) / LB;
   const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
   if (tile0 >= n_tiles) return;
@@ -748,37 +792,44 @@ k_mdft_c2r_lds(const cf32* __restrict__ in, float* __restrict__ out, const float
       }
       SC_SYNC();
       if (NPF && ti + 1 < my_tiles) prefetch(ti + 1);
-      // rows 16 jt .. 16 jt + 15 of plane pl for jt = wl and wl + WPP:  Y[n1][j2] = sum_j1 T[n1][j1] Z[j1][j2]
+      // rows 32 wl .. 32 wl + 31 of plane pl:  Y[n1][(j2, c)] = sum_j1 ( Tr Z[j1][(j2, c)] + Ti rot(Z)[j1][(j2, c)] )
       const int pl = w / WPP, wl = w % WPP;
-      const int NSa = (K1 + 1) / 2;
-      sc_f32x16 ya[2];
+      const float sgn = (half == 0) ? 1.f : ((col & 1) ? 1.f : -1.f);
+      const float* zb = reinterpret_cast<const float*>(Zs) + pl * K1 * 2 * J + (half == 0 ? col : (col ^ 1));
+      const cf32* zt = Zs + pl * K1 * J + (J - 1);
+      sc_f32x16 ya[CA];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int ca = 0; ca < CA; ++ca)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) ya[t][v] = 0.f;
-      const cf32* zc = Zs + pl * K1 * J + (col < J ? col : J - 1);
-      const float* ta0 = tabA + ((int64_t)wl * NSa) * 128 + lane;
-      const float* ta1 = tabA + ((int64_t)(wl + WPP) * NSa) * 128 + lane;
-#pragma unroll 2
-      for (int s2 = 0; s2 < NSa; ++s2) {
-        int n = 2 * s2 + half;
-        if (n >= K1) n = K1 - 1;                                 // table entry is zero there
-        const cf32 d = zc[n * J];
-        const float a00 = ta0[s2 * 128], a01 = ta0[s2 * 128 + 64];
-        const float a10 = ta1[s2 * 128], a11 = ta1[s2 * 128 + 64];
-        MDFT_MFMA(ya[0], a00, d.x);
-        MDFT_MFMA(ya[0], a01, d.y);
-        MDFT_MFMA(ya[1], a10, d.x);
-        MDFT_MFMA(ya[1], a11, d.y);
-      }
-      if (col < J) {
+        for (int v = 0; v < 16; ++v) ya[ca][v] = 0.f;
+      cf32 ty = cf_make(0.f, 0.f);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int i = 0; i < NRD / 2; ++i) {
+        if (i < K1) {                                            // uniform
 #pragma unroll
-          for (int v = 0; v < 16; v += 2) {
-            const int n1 = pl * NRD + 16 * (wl + WPP * t) + (mdft_row(v, half) >> 1);
-            dat[n1 * SC2 + col] = cf_make(ya[t][v], ya[t][v + 1]);
+          for (int ca = 0; ca < CA; ++ca) MDFT_MFMA(ya[ca], tar[i], sgn * zb[i * 2 * J + 32 * ca]);
+          if (ATAIL) {
+            const cf32 y = zt[i * J];
+            ty.x = fmaf(tar[i], half ? -y.y : y.x, ty.x);
+            ty.y = fmaf(tar[i], half ? y.x : y.y, ty.y);
           }
+        }
+      }
+      float* datf = reinterpret_cast<float*>(dat);
+      const int amax = ATAIL ? 2 * J - 2 : 2 * J;
+#pragma unroll
+      for (int ca = 0; ca < CA; ++ca) {
+        const int f = 32 * ca + col;
+        if (f < amax) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) datf[(pl * NRD + 32 * wl + mdft_row(v, half)) * S + f] = ya[ca][v];
+        }
+      }
+      if (ATAIL) {
+        tredA[64 * w + lane] = ty;
+        SC_WAVE_SYNC();
+        if (half == 0)
+          dat[(pl * NRD + 32 * wl + col) * SC2 + (J - 1)] = cf_add(ty, tredA[64 * w + 32 + col]);
       }
     }
     SC_SYNC();
