@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--workload", default="fno2d_256_m64_c64_b32", choices=sorted(WORKLOADS))
     ap.add_argument("--parallel", default="replicas", choices=["replicas", "modeshard"])
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
+    ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
+                         "bf16 = the bf16-I/O reading of BASELINE configs[1], fused 2-D kernels only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-iters", type=int, default=10)
     ap.add_argument("--cpu-baseline-only", action="store_true",
@@ -56,15 +59,16 @@ def parse():
     return ap.parse_args()
 
 
-def alg_bytes(B, C, spatial, kept):
-    """R, Wb, S and BYTES_ALG = 4R + 3Wb + 9S per fwd+bwd step."""
+def alg_bytes(B, C, spatial, kept, real_bytes=4):
+    """R, Wb, S and BYTES_ALG = 4R + 3Wb + 9S per fwd+bwd step
+    (real_bytes = 2 with bf16 I/O: the 4R term halves, 1592.8 MB at the metric shape)."""
     nsp = 1
     for s in spatial:
         nsp *= s
     mk = 1
     for k in kept:
         mk *= k
-    R = 4 * B * C * nsp
+    R = real_bytes * B * C * nsp
     S = 8 * B * C * mk
     Wb = 8 * C * C * mk
     return R, Wb, S, 4 * R + 3 * Wb + 9 * S
@@ -101,7 +105,7 @@ def device_copy_ceiling(nbytes, iters=10):
     return round(2 * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
 
 
-def stage_profile(B, C, spatial, n_modes, flags, iters):
+def stage_profile(B, C, spatial, n_modes, flags, iters, io="f32"):
     """Time every stage of the layer separately through the C-ABI (events on the launch
     stream) and return {stage: {ms, alg_bytes, GBs}} plus the plan's kernel names."""
     from neuraloperator_amd import _lib
@@ -112,12 +116,13 @@ def stage_profile(B, C, spatial, n_modes, flags, iters):
     dev = torch.device("cuda", torch.cuda.current_device())
     nm = halve_last_mode(n_modes)
     kept, _ = kept_block(spatial, nm, nm)
-    plan = get_plan(dev, spatial, kept, "forward", flags)
+    bf16 = io == "bf16"
+    plan = get_plan(dev, spatial, kept, "forward", flags | (_lib.SC_PLAN_IO_BF16 if bf16 else 0))
     mk = 1
     for k in kept:
         mk *= k
-    R, Wb, S, _ = alg_bytes(B, C, spatial, kept)
-    x = torch.randn(B, C, *spatial, device=dev)
+    R, Wb, S, _ = alg_bytes(B, C, spatial, kept, 2 if bf16 else 4)
+    x = torch.randn(B, C, *spatial, device=dev).to(torch.bfloat16 if bf16 else torch.float32)
     y = torch.empty_like(x)
     xh = torch.randn(B, C, mk, 2, device=dev)
     yh = torch.randn(B, C, mk, 2, device=dev)
@@ -274,8 +279,14 @@ def main():
         scaling = "weak"
         global_batch = B * world
         par = f"dp{world}-replicas" if world > 1 else "single"
-    x = torch.randn(b_local, C, *spatial, device=dev, requires_grad=True)
-    g = torch.randn(b_local, C, *spatial, device=dev)
+    io_dtype = torch.bfloat16 if args.io == "bf16" else torch.float32
+    x = torch.randn(b_local, C, *spatial, device=dev).to(io_dtype).requires_grad_(True)
+    g = torch.randn(b_local, C, *spatial, device=dev).to(io_dtype)
+    if args.io == "bf16":
+        from neuraloperator_amd import engine
+        kept_chk, _ = kept_block(spatial, halve_last_mode(n_modes), halve_last_mode(n_modes))
+        if engine.get_plan_bf16_io(dev, list(spatial), kept_chk, "forward", flags) is None:
+            raise SystemExit(f"--io bf16: {args.workload} does not run on the fused 2-D kernels (no bf16 I/O there)")
 
     def step():
         x.grad = None
@@ -309,8 +320,8 @@ def main():
     if rank == 0:
         nm = halve_last_mode(n_modes)
         kept, _ = kept_block(spatial, nm, nm)
-        R, Wb, S, total = alg_bytes(b_local, C, spatial, kept)
-        stages, names = stage_profile(b_local, C, spatial, n_modes, flags, args.stage_iters)
+        R, Wb, S, total = alg_bytes(b_local, C, spatial, kept, 2 if args.io == "bf16" else 4)
+        stages, names = stage_profile(b_local, C, spatial, n_modes, flags, args.stage_iters, args.io)
         dom = max(stages, key=lambda k: stages[k]["ms"])
         kern = names["fwd"] if dom in ("fwd_transform", "adj_c2r_transform") else \
             names["inv"] if dom in ("inv_transform", "adj_r2c_transform") else "k_modegemm"
@@ -318,7 +329,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                tkey = args.workload + ("_bf16io" if args.io == "bf16" else "")
+                traffic = json.load(open(tpath)).get(tkey, {}).get(dom)
             except Exception:
                 traffic = None
         roof = {"bound": "hbm", "kernel": kern, "stage": dom,
@@ -337,12 +349,14 @@ def main():
             "config": {"workload": args.workload, "B_per_gpu": b_local, "global_batch": global_batch,
                        "channels": C, "grid": list(spatial), "n_modes": list(n_modes), "kept": kept,
                        "parallelism": par, "engine_path": "fused-fft" if names["fast"] else "generic-dft",
+                       "real_tensor_io": args.io,
                        "weights": "dense complex64, random init"},
             "roofline": roof,
             "step_roofline": {"alg_bytes_per_step": total, "achieved_GBs": round(step_gbs, 1),
                               "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_measured_copy": round(step_gbs / copy_gbs, 4),
-                              "formula": "4R+3Wb+9S (SURVEY.md 8d)"},
+                              "formula": "4R+3Wb+9S (SURVEY.md 8d)" +
+                                         (", R at 2 bytes per value" if args.io == "bf16" else "")},
             "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:

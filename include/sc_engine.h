@@ -10,8 +10,8 @@
  * Conventions
  *   - plain pointers + sizes, no torch types.  All data pointers are DEVICE pointers
  *     owned by the caller (PyTorch's allocator); the plan owns only its twiddle tables.
- *   - real tensors: float32, contiguous (B, C, d1..dN).  complex tensors: interleaved
- *     (re, im) float32 pairs (== torch.complex64 memory).
+ *   - real tensors: float32 (bfloat16 storage with SC_PLAN_IO_BF16), contiguous (B, C, d1..dN).
+ *     complex tensors: interleaved (re, im) float32 pairs (== torch.complex64 memory).
  *   - truncated spectra are stored (B, C, k1..kN) with the mode dims in WEIGHT order:
  *     non-last dim row r  <->  signed frequency r - floor(k/2) (fftshift order, even k
  *     keeps -k/2 .. k/2-1), last dim column c <-> frequency c.
@@ -75,9 +75,16 @@ enum {
   SC_PLAN_FORCE_GENERIC = 1, /* never take the power-of-two fast kernels (debug / A-B)     */
   SC_PLAN_FFT_GEN2 = 2,      /* fast path on the generation-2 fused kernels (A-B)           */
   SC_PLAN_NO_MDFT = 4,       /* generic passes on the VALU kernels instead of the matrix cores (A-B) */
-  SC_PLAN_COMPLEX = 8        /* complex_data=True (:439-441, 536-538): x and y are complex (n_images,
+  SC_PLAN_COMPLEX = 8,       /* complex_data=True (:439-441, 536-538): x and y are complex (n_images,
                                 d1..dN), every dim is a complex-to-complex pass, bias must be NULL
                                 (the host adds the real bias); transforms only, no sc_layer_*      */
+  SC_PLAN_IO_BF16 = 16       /* the REAL tensors (x, y, gy, gx) are bfloat16 in memory -- the `float*`
+                                arguments that carry them then point at 2-byte elements; spectra,
+                                weights, bias and every arithmetic step stay float32 and y / gx are
+                                rounded to nearest even on the store (BASELINE configs[1] "bf16": the
+                                reference has no bf16 spectral path, torch.fft rejects the dtype, so this
+                                is y = bf16(layer(fp32(x)))).  Fused 2-D kernels only: sc_plan_create
+                                fails for shapes that take the size-agnostic passes (the host converts) */
 };
 
 /* ---- plan ------------------------------------------------------------------------------ */

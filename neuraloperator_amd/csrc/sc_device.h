@@ -130,6 +130,32 @@ struct sc_int {
   static constexpr int value = N;
 };
 
+// --------------------------------------------------------------------------- bfloat16 storage
+// (SC_PLAN_IO_BF16: real tensors cross HBM as bfloat16, all arithmetic stays fp32)
+struct sc_bf16 {
+  uint16_t v;
+};
+#ifndef SC_EMU
+SC_DEVICE float sc_bits_to_f32(const uint32_t u) { return __uint_as_float(u); }
+// round to nearest even, NaN -> quiet NaN: v_cvt_pk_bf16_f32 (same results as torch's float -> bfloat16)
+SC_DEVICE uint16_t sc_f32_to_bf16_bits(const float f) {
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+#else
+inline float sc_bits_to_f32(const uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+inline uint16_t sc_f32_to_bf16_bits(const float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;            // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                // round to nearest even
+  return (uint16_t)(u >> 16);
+}
+#endif
+
 // --------------------------------------------------------------------------- complex helpers
 struct cf32 {
   float x, y;

@@ -488,6 +488,9 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     std::string why;
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
+  if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
+    rc = sc_fail("sc_engine: SC_PLAN_IO_BF16 is implemented on the fused 2-D kernels (generation 3) only: "
+                 "width 256, height 64..512, kept block <= 64 x 33, no frequency maps");
   if (!rc && !p->fast && !(desc->flags & SC_PLAN_NO_MDFT)) rc = build_mdft_tables(p);
   if (rc) {
     sc_plan_destroy(p);
@@ -858,6 +861,8 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
   if (p->fast) {
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
+    if (p->d.flags & SC_PLAN_IO_BF16)
+      return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
     return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
   }
   const int L = p->nd - 1;
@@ -917,6 +922,9 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
                            &g_last_error);
+    if (p->d.flags & SC_PLAN_IO_BF16)
+      return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
+                          &g_last_error);
     return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
   }
   const int L = p->nd - 1;

@@ -56,6 +56,33 @@ struct F3Lds {
   static_assert(total * (H <= 256 ? 4 : 3) <= 160 * 1024, "4 workgroups per CU (3 at H = 512)");
 };
 
+// ---- real-tensor I/O of the fused kernels: float32, or bfloat16 storage (SC_PLAN_IO_BF16: the spectral
+//      arithmetic stays fp32, only x / y / gy / gx cross HBM as 2-byte values -- BASELINE configs[1] "bf16").
+//      A lane owns points lam + 32 j of a row.  bf16: lanes 2l and 2l+1 read the SAME aligned dword (one
+//      64-byte piece per half-wave and instruction) and keep their half; stores are 2-byte, 64 contiguous
+//      bytes per half-wave, rounded to nearest even by v_cvt_pk_bf16_f32.
+SC_DEVICE float f3_load(const float* row, const int lam, const int j) {
+#ifdef SC_F3_PLAIN_IO
+  return row[lam + 32 * j];
+#else
+  return SC_LOAD_STREAM(&row[lam + 32 * j]);             // read once: keep it out of the caches the
+#endif                                                   // spectra and weights live in
+}
+SC_DEVICE float f3_load(const sc_bf16* row, const int lam, const int j) {
+  const uint32_t u = SC_LOAD_STREAM(reinterpret_cast<const uint32_t*>(row) + (lam >> 1) + 16 * j);
+  return sc_bits_to_f32((u << ((lam & 1) ? 0 : 16)) & 0xffff0000u);
+}
+SC_DEVICE void f3_store(float* row, const int lam, const int j, const float v) {
+#ifdef SC_F3_PLAIN_IO
+  row[lam + 32 * j] = v;
+#else
+  SC_STORE_STREAM(&row[lam + 32 * j], v);
+#endif
+}
+SC_DEVICE void f3_store(sc_bf16* row, const int lam, const int j, const float v) {
+  SC_STORE_STREAM(&row[lam + 32 * j].v, sc_f32_to_bf16_bits(v));
+}
+
 // 8-point DFT, natural order in and out: b[k] = sum_n a[n] w8^(nk), w8 = exp(DIR 2 pi i / 8)
 template <int DIR>
 SC_HD void dft8(const cf32 (&a)[8], cf32 (&b)[8]) {
@@ -95,9 +122,9 @@ SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
 #ifndef SC_F3_FWD_OCC
 #define SC_F3_FWD_OCC 3
 #endif
-template <int H>
+template <int H, typename IO>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? SC_F3_FWD_OCC : 3))
-k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
+k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
              const cf32* __restrict__ tabH, int Mx, int My, float s_dc, float s_other) {
   constexpr int P = H / 64;
   typedef F3Lds<H> L;
@@ -113,7 +140,7 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
   const int lane = tid & 63, hs = lane >> 5, lam = lane & 31;
   const int hw = w * 2 + hs;                           // half-wave = row-pair slot of a round
   const int64_t img = SC_BID_X;
-  const float* xi = x + img * (int64_t)H * SC_F2D_W;
+  const IO* xi = x + img * (int64_t)H * SC_F2D_W;
 
   for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
   if (tid < 64) {
@@ -188,20 +215,15 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
   auto prefetch = [&](const int t, cf32 (&q)[8]) {        // t = 4 a + r
     if (t < 4 * P) {
       const int a = t >> 2, p = (t & 3) * 8 + hw;
-      const float* ra = xi + (int64_t)(P * (2 * p) + a) * SC_F2D_W + lam;
-      const float* rb = ra + P * SC_F2D_W;
+      const IO* ra = xi + (int64_t)(P * (2 * p) + a) * SC_F2D_W;
+      const IO* rb = ra + P * SC_F2D_W;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
 #ifdef SC_F3_ABL_NOLOAD
         q[j] = cf_make((float)(lam + j + t), (float)(lam - j));
 #else
-#ifdef SC_F3_PLAIN_IO
-        q[j].x = ra[32 * j];
-        q[j].y = rb[32 * j];
-#else
-        q[j].x = SC_LOAD_STREAM(&ra[32 * j]);          // read once: keep it out of the caches the
-        q[j].y = SC_LOAD_STREAM(&rb[32 * j]);          // spectra and weights live in
-#endif
+        q[j].x = f3_load(ra, lam, j);
+        q[j].y = f3_load(rb, lam, j);
 #endif
       }
     }
@@ -303,9 +325,9 @@ k_fft2d_fwd3(const float* __restrict__ x, cf32* __restrict__ xhat, const cf32* _
 // ------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------
-template <int H>
+template <int H, typename IO>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? 4 : 3))
-k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* __restrict__ bias,
+k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
              int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
              float s_dc, float s_other) {
   constexpr int P = H / 64;
@@ -323,7 +345,7 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
   const int lane = tid & 63, hs = lane >> 5, lam = lane & 31;
   const int hw = w * 2 + hs;
   const int64_t img = SC_BID_X;
-  float* yo = y + img * (int64_t)H * SC_F2D_W;
+  IO* yo = y + img * (int64_t)H * SC_F2D_W;
   const cf32* src = yhat + img * (int64_t)Mx * My;
 
   for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
@@ -453,17 +475,12 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
       }
       SC_WAVE_SYNC();                                   // xb is rewritten by the next round
       dft8<+1>(v, o);                                    // over k1 -> n1 : z[32 n1 + lam]
-      float* ra = yo + (int64_t)(P * (2 * p) + a) * SC_F2D_W + lam;
-      float* rb = yo + (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W + lam;
+      IO* ra = yo + (int64_t)(P * (2 * p) + a) * SC_F2D_W;
+      IO* rb = yo + (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W;
 #pragma unroll
       for (int n1 = 0; n1 < 8; ++n1) {
-#ifdef SC_F3_PLAIN_IO
-        ra[32 * n1] = o[n1].x;
-        rb[32 * n1] = o[n1].y;
-#else
-        SC_STORE_STREAM(&ra[32 * n1], o[n1].x);
-        SC_STORE_STREAM(&rb[32 * n1], o[n1].y);
-#endif
+        f3_store(ra, lam, n1, o[n1].x);
+        f3_store(rb, lam, n1, o[n1].y);
       }
     }
     SC_SYNC();                                          // T is rewritten by the next group
@@ -473,29 +490,31 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, float* __restrict__ y, const float* 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int H>
-static void fft3_launch_fwd(const Fft2dPlan* fp, const float* x, cf32* xhat, int64_t n_images, float s_dc,
+template <int H, typename IO>
+static void fft3_launch_fwd(const Fft2dPlan* fp, const IO* x, cf32* xhat, int64_t n_images, float s_dc,
                             float s_other, sc_stream_t st) {
-  SC_LAUNCH((k_fft2d_fwd3<H>), dim3((unsigned)n_images), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
+  SC_LAUNCH((k_fft2d_fwd3<H, IO>), dim3((unsigned)n_images), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
             (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
 }
 
-template <int H>
-static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, float* y, const float* bias, int channels,
+template <int H, typename IO>
+static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const float* bias, int channels,
                             int64_t n_images, float s_dc, float s_other, sc_stream_t st) {
-  SC_LAUNCH((k_fft2d_inv3<H>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels,
+  SC_LAUNCH((k_fft2d_inv3<H, IO>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels,
             (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
 }
 
-static inline int fft3_forward(const Fft2dPlan* fp, int mode, const float* x, cf32* xhat, int64_t n_images,
+// x / y: float32, or bfloat16 storage when the plan carries SC_PLAN_IO_BF16 (IO = sc_bf16)
+template <typename IO>
+static inline int fft3_forward(const Fft2dPlan* fp, int mode, const IO* x, cf32* xhat, int64_t n_images,
                                sc_stream_t st, std::string* err) {
   const float s_dc = (mode == 0) ? fp->sf : fp->si;
   const float s_other = (mode == 0) ? fp->sf : 2.f * fp->si;
   switch (fp->H) {
-    case 64: fft3_launch_fwd<64>(fp, x, xhat, n_images, s_dc, s_other, st); break;
-    case 128: fft3_launch_fwd<128>(fp, x, xhat, n_images, s_dc, s_other, st); break;
-    case 256: fft3_launch_fwd<256>(fp, x, xhat, n_images, s_dc, s_other, st); break;
-    case 512: fft3_launch_fwd<512>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 64: fft3_launch_fwd<64, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 128: fft3_launch_fwd<128, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 256: fft3_launch_fwd<256, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 512: fft3_launch_fwd<512, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {
@@ -505,15 +524,16 @@ static inline int fft3_forward(const Fft2dPlan* fp, int mode, const float* x, cf
   return 0;
 }
 
+template <typename IO>
 static inline int fft3_inverse(const Fft2dPlan* fp, int mode, const cf32* yhat, const float* bias,
-                               int64_t channels, float* y, int64_t n_images, sc_stream_t st, std::string* err) {
+                               int64_t channels, IO* y, int64_t n_images, sc_stream_t st, std::string* err) {
   const float s_dc = (mode == 0) ? fp->si : fp->sf;
   const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
   switch (fp->H) {
-    case 64: fft3_launch_inv<64>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 128: fft3_launch_inv<128>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 256: fft3_launch_inv<256>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 512: fft3_launch_inv<512>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 64: fft3_launch_inv<64, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 128: fft3_launch_inv<128, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 256: fft3_launch_inv<256, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 512: fft3_launch_inv<512, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {

@@ -12,8 +12,10 @@ from . import _lib
 from .modes import kept_block
 
 SC_PLAN_COMPLEX = _lib.SC_PLAN_COMPLEX
+SC_PLAN_IO_BF16 = _lib.SC_PLAN_IO_BF16
 _PLAN_LOCK = threading.Lock()
 _PLANS = {}
+_NO_BF16_IO = set()       # (spatial, kept, norm, flags) the engine has no bfloat16-I/O kernels for
 
 
 def _require_gpu(t, what="input"):
@@ -46,6 +48,19 @@ def get_plan(device, spatial, kept, fft_norm="forward", flags=0, freq=None, real
     return plan
 
 
+def get_plan_bf16_io(device, spatial, kept, fft_norm, flags):
+    """Plan whose real tensors are bfloat16 in memory (SC_PLAN_IO_BF16), or None where the engine only has
+    float32 I/O for the shape (everything off the fused 2-D kernels): the caller then converts."""
+    key = (tuple(int(s) for s in spatial), tuple(int(k) for k in kept), fft_norm, flags)
+    if key in _NO_BF16_IO:
+        return None
+    try:
+        return get_plan(device, spatial, kept, fft_norm, flags | SC_PLAN_IO_BF16)
+    except _lib.EngineError:
+        _NO_BF16_IO.add(key)
+        return None
+
+
 @atexit.register
 def _destroy_plans():
     # device memory is reclaimed with the process; only drop the handles
@@ -73,8 +88,6 @@ class SpectralConvDenseFn(torch.autograd.Function):
         _require_gpu(weight, "weight")
         lib = _lib.get_lib()
         x = x.contiguous()
-        if x.dtype != torch.float32:
-            x = x.float()
         w = weight.detach()
         if w.dtype != torch.complex64:
             w = w.to(torch.complex64)
@@ -85,11 +98,17 @@ class SpectralConvDenseFn(torch.autograd.Function):
             raise ValueError(f"input has {cin} channels, weight expects {w.shape[0]}")
         spatial = list(x.shape[2:])
         kept, w_start = kept_block(spatial, n_modes_attr, max_n_modes_attr)
-        plan = get_plan(x.device, spatial, kept, fft_norm, flags)
+        # bfloat16 activations: the fused kernels read / write them as they are (fp32 arithmetic, y and
+        # gx rounded once on the store); other shapes and dtypes are converted to float32 here
+        plan = get_plan_bf16_io(x.device, spatial, kept, fft_norm, flags) if x.dtype == torch.bfloat16 else None
+        io_dtype = torch.bfloat16 if plan is not None else torch.float32
+        if plan is None:
+            x = x.float()
+            plan = get_plan(x.device, spatial, kept, fft_norm, flags)
         L = lib.layer_desc(b, cin, cout, list(w.shape[2:]), w_start)
         with torch.cuda.device(x.device):
             ws = _ws(lib.layer_workspace_bytes(plan, L), x.device)
-            y = torch.empty((b, cout, *spatial), dtype=torch.float32, device=x.device)
+            y = torch.empty((b, cout, *spatial), dtype=io_dtype, device=x.device)
             xhat = torch.empty((b, cin, *kept, 2), dtype=torch.float32, device=x.device)
             bias_flat = None
             if bias is not None:
@@ -99,6 +118,7 @@ class SpectralConvDenseFn(torch.autograd.Function):
                               y.data_ptr(), xhat.data_ptr(), ws.data_ptr(), _stream())
         ctx.save_for_backward(xhat, w)
         ctx.plan, ctx.L = plan, L
+        ctx.io_dtype = io_dtype
         ctx.x_shape = tuple(x.shape)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.w_shape = tuple(weight.shape)
@@ -110,12 +130,12 @@ class SpectralConvDenseFn(torch.autograd.Function):
         xhat, w = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         gy = gy.contiguous()
-        if gy.dtype != torch.float32:
-            gy = gy.float()
+        if gy.dtype != ctx.io_dtype:
+            gy = gy.to(ctx.io_dtype)
         dev = gy.device
         with torch.cuda.device(dev):
             ws = _ws(lib.layer_workspace_bytes(ctx.plan, ctx.L), dev)
-            gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if need_x else None
+            gx = torch.empty(ctx.x_shape, dtype=ctx.io_dtype, device=dev) if need_x else None
             gw = None
             if need_w:
                 full = all(ctx.L.w_start[d] == 0 for d in range(len(ctx.w_shape) - 2)) and \

@@ -203,6 +203,11 @@ class SpectralConv(BaseSpectralConv):
         if self.fno_block_precision in ("half", "mixed") and not self.complex_data:
             y = self._forward_full(x.float(), spatial, out_shape)
             return y if self.bias is not None else y.half()      # half + fp32 bias promotes to fp32 upstream
+        if x.dtype == torch.bfloat16:
+            # bfloat16 activations (BASELINE configs[1] "bf16"; torch.fft has no bfloat16, so upstream has no
+            # behaviour to match): y = bf16(layer(fp32(x))).  On the fused 2-D kernels x / y / their gradients
+            # cross HBM as bfloat16 (SC_PLAN_IO_BF16); every other route converts around the fp32 engine.
+            return self._forward_full(x, spatial, out_shape).to(torch.bfloat16)
         return self._forward_full(x, spatial, out_shape)
 
     def _forward_full(self, x, spatial, out_shape):

@@ -58,7 +58,8 @@ def layer_fwd_bwd(lib, x, w, bias, g, n_modes_attr, max_n_modes_attr, flags=0, f
         w = w.contiguous()
         g = g.contiguous()
         wv = torch.view_as_real(w)
-        y = torch.empty(b, cout, *spatial, dtype=torch.float32, device=dev)
+        # SC_PLAN_IO_BF16: x and g are bfloat16 tensors, y and gx come back as bfloat16
+        y = torch.empty(b, cout, *spatial, dtype=x.dtype, device=dev)
         xhat = torch.empty(b, cin, *kept, 2, dtype=torch.float32, device=dev)
         bias_flat = None if bias is None else bias.reshape(-1).contiguous()
         st = _stream(dev)

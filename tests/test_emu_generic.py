@@ -81,6 +81,52 @@ def test_fused_fft_path_matches_oracle(lib, case, gen):
     assert rel_l2(xh.numpy(), xk) < TOL
 
 
+def bf16_checks(y, y_ref32, what):
+    """y: bfloat16 result; y_ref32: the fp32 oracle result on the same (bf16-valued) inputs.  The engine rounds
+    its fp32 result once (nearest even), so it sits within half a bf16 ulp (2^-9 relative) of the fp32 oracle
+    plus fp32 round-off, and agrees bit for bit with the rounded oracle except where the two fp32 values
+    straddle a rounding boundary."""
+    assert y.dtype == torch.bfloat16, what
+    yf = y.float()
+    err = (yf - y_ref32).abs()
+    bound = y_ref32.abs() * 2.0 ** -8 + 1e-5 * y_ref32.abs().max()
+    assert bool((err <= bound).all()), f"{what}: {float((err - bound).max())} past one bf16 ulp"
+    same = (y.view(torch.int16) == y_ref32.bfloat16().view(torch.int16)).float().mean().item()
+    assert same > 0.98, f"{what}: only {same:.4f} of the values equal the rounded oracle bit for bit"
+
+
+@pytest.mark.parametrize("case", [(1, 2, 2, 256, (64, 64)), (1, 1, 2, 64, (20, 16)), (2, 1, 1, 128, (5, 7))],
+                         ids=lambda c: f"H{c[3]}_m{c[4][0]}x{c[4][1]}")
+def test_fused_fft_bf16_io_matches_oracle(lib, case):
+    """SC_PLAN_IO_BF16: x / gy read as bfloat16, y / gx stored as bfloat16 (nearest even), arithmetic and
+    the fp32 outputs (saved spectrum, gW, gbias) as in the fp32 path on the same input values."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode, kept_block
+
+    b, ci, co, H, modes = case
+    torch.manual_seed(12)
+    nm = halve_last_mode(modes)
+    kept, _ = kept_block([H, 256], nm, nm)
+    with pytest.raises(_lib.EngineError):             # size-agnostic passes have no bf16 I/O: the host converts
+        lib.plan_create([48, 40], [8, 5], flags=_lib.SC_PLAN_IO_BF16)
+    with pytest.raises(_lib.EngineError):
+        lib.plan_create([H, 256], kept, flags=_lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_FFT_GEN2)
+    x = torch.randn(b, ci, H, 256).bfloat16()
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.5)
+    bias = torch.randn(co, 1, 1)
+    g = torch.randn(b, co, H, 256).bfloat16()
+    xc, wc, bc = x.float().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g.float())
+    y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=_lib.SC_PLAN_IO_BF16)
+    bf16_checks(y, yo.detach(), "y")
+    bf16_checks(gx, xc.grad, "gx")
+    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+    _, xk = so.forward_np64(x.float().numpy(), w.numpy(), bias.numpy(), nm, nm)
+    assert rel_l2(xh.numpy(), xk) < TOL
+
+
 def test_emu_library_exports_and_errors(lib):
     for s in _lib.ScEngineLib.SYMBOLS:
         assert hasattr(lib.lib, s)

@@ -55,6 +55,81 @@ ORACLE_CASES = [
 ]
 
 
+def _bf16_checks(y, y_ref32, what):
+    """bfloat16 result against the fp32 oracle on the same (bf16-valued) inputs: the engine rounds its fp32
+    result once (nearest even), so it is within one bf16 ulp of the oracle and bit-identical to the rounded
+    oracle except where the two fp32 values straddle a rounding boundary."""
+    assert y.dtype == torch.bfloat16, what
+    y, y_ref32 = y.cpu(), y_ref32.cpu()
+    err = (y.float() - y_ref32).abs()
+    bound = y_ref32.abs() * 2.0 ** -8 + 1e-5 * y_ref32.abs().max()
+    assert bool((err <= bound).all()), f"{what}: {float((err - bound).max())} past one bf16 ulp"
+    same = (y.view(torch.int16) == y_ref32.bfloat16().view(torch.int16)).float().mean().item()
+    assert same > 0.98, f"{what}: only {same:.4f} of the values equal the rounded oracle bit for bit"
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 256, (64, 64)), (3, 4, 6, 64, (20, 16)), (2, 8, 8, 512, (64, 64)),
+                                  (32, 64, 64, 128, (32, 32))],
+                         ids=lambda c: f"H{c[3]}_m{c[4][0]}_c{c[1]}")
+def test_bf16_io_vs_oracle(lib, case):
+    """SC_PLAN_IO_BF16 through the C-ABI (BASELINE configs[1] "bf16"): x / gy are bfloat16 in HBM, y / gx are
+    stored as bfloat16, spectra / weights / their gradients and all arithmetic stay fp32."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd import _lib
+    from neuraloperator_amd.modes import halve_last_mode
+
+    b, ci, co, H, modes = case
+    torch.manual_seed(77)
+    nm = halve_last_mode(modes)
+    std = (2 / (ci + co)) ** 0.5
+    x = torch.randn(b, ci, H, 256).bfloat16()
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, std)
+    bias = std * torch.randn(co, 1, 1)
+    g = torch.randn(b, co, H, 256).bfloat16()
+    xc, wc, bc = x.float().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g.float())
+    dev = torch.device("cuda:0")
+    y, gx, gw, gb, xh = layer_fwd_bwd(lib, x.to(dev), w.to(dev), bias.to(dev), g.to(dev), nm, nm,
+                                      flags=_lib.SC_PLAN_IO_BF16)
+    _bf16_checks(y, yo.detach(), "y")
+    _bf16_checks(gx, xc.grad, "gx")
+    assert rel_l2(gw.cpu().numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.cpu().numpy(), bc.grad.numpy()) < TOL
+    # and the fp32-I/O kernels on the same values give the same fp32 spectrum bit for bit (same arithmetic)
+    _, _, _, _, xh32 = layer_fwd_bwd(lib, x.float().to(dev), w.to(dev), bias.to(dev), g.float().to(dev), nm, nm)
+    assert torch.equal(xh, xh32)
+
+
+def test_module_bf16_activations():
+    """bfloat16 in -> bfloat16 out through the drop-in module: native bf16 I/O on the fused kernels, conversion
+    around the fp32 engine everywhere else; gradients arrive in the dtypes autograd expects."""
+    from neuraloperator_amd import SpectralConv, engine
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    for spatial, modes, native in [((64, 256), (16, 16), True), ((48, 40), (12, 12), False)]:
+        conv = SpectralConv(6, 5, modes).to(dev)
+        x = torch.randn(2, 6, *spatial, device=dev).bfloat16().requires_grad_(True)
+        g = torch.randn(2, 5, *spatial, device=dev).bfloat16()
+        y = conv(x)
+        assert y.dtype == torch.bfloat16
+        y.backward(g)
+        assert x.grad.dtype == torch.bfloat16 and conv.weight.tensor.grad.dtype == torch.complex64
+        gw, gb = conv.weight.tensor.grad.clone(), conv.bias.grad.clone()
+        kept = [modes[0], modes[1] // 2 + 1]
+        assert (engine.get_plan_bf16_io(dev, list(spatial), kept, "forward", 0) is not None) == native
+        # the same module on the fp32 copies of the same values
+        conv.zero_grad()
+        x32 = x.detach().float().requires_grad_(True)
+        y32 = conv(x32)
+        y32.backward(g.float())
+        _bf16_checks(y.detach(), y32.detach(), "y")
+        _bf16_checks(x.grad, x32.grad, "gx")
+        assert rel_l2(gw.cpu().numpy(), conv.weight.tensor.grad.cpu().numpy()) < TOL
+        assert rel_l2(gb.cpu().numpy(), conv.bias.grad.cpu().numpy()) < TOL
+
+
 @pytest.mark.parametrize("flags", [0, 1, 5], ids=["default", "force_generic", "force_generic_valu"])
 @pytest.mark.parametrize("case", ORACLE_CASES, ids=lambda c: "x".join(map(str, c[3])) + f"_m{c[4][0]}_c{c[1]}")
 def test_vs_oracle(lib, case, flags):
