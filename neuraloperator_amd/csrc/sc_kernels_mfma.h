@@ -37,6 +37,9 @@
 #include "sc_device.h"
 
 #define SC_MG_RC 8
+#ifndef SC_MG_PF
+#define SC_MG_PF 1      // stages of operand loads in flight (1 or 2), see k_modegemm_mfma
+#endif
 
 #ifndef SC_EMU
 typedef float sc_f32x16 __attribute__((ext_vector_type(16)));
@@ -166,29 +169,34 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
     return b < 0 ? 0 : b;
   };
 
-  cf32 ra[K::HL][K::NPA], rb[K::HL][K::NPB];
+  // operand registers of the stages in flight: SC_MG_PF = 2 keeps TWO stages' loads outstanding (stage k + 2 is
+  // requested before stage k feeds the matrix cores), so a stage's HBM round trip -- about as long as a stage's
+  // MFMAs at the metric shape -- is covered by two compute phases instead of one
+  cf32 ra0[K::HL][K::NPA], rb0[K::HL][K::NPB];
+#if SC_MG_PF == 2
+  cf32 ra1[K::HL][K::NPA], rb1[K::HL][K::NPB];
+#endif
 
   // every load address stays inside the operand (no exec-masked loads); r values past g.R are zeroed
   // when the stage is committed to LDS
-  auto issue = [&](const int r0) {
+  auto issue = [&](const int r0, cf32 (&ra)[K::HL][K::NPA], cf32 (&rb)[K::HL][K::NPB]) {
 #pragma unroll
     for (int h = 0; h < K::HL; ++h) {
       int r = r0 + w + K::NW * h;                                       // uniform
       r = r < g.R ? r : g.R - 1;
       const cf32* ar = A + (int64_t)r * g.a_sr + la;
       const cf32* br = B + (int64_t)r * g.b_sr + lb;
+      // no branches around the loads (a group past the last one re-reads the last rows): with loads in
+      // conditional blocks the compiler cannot count the younger loads in flight and every wait for a
+      // stage's registers becomes s_waitcnt vmcnt(0), i.e. also waits for the stage requested after it
 #pragma unroll
-      for (int pg = 0; pg < K::NPA; ++pg) {
-        if (pg < npa) ra[h][pg] = ar[(int64_t)group_base(pg, g.P) * g.a_sp];   // uniform branch
-      }
+      for (int pg = 0; pg < K::NPA; ++pg) ra[h][pg] = ar[(int64_t)group_base(pg, g.P) * g.a_sp];
 #pragma unroll
-      for (int qg = 0; qg < K::NPB; ++qg) {
-        if (qg < npb) rb[h][qg] = br[(int64_t)group_base(qg, g.Q) * g.b_sq];
-      }
+      for (int qg = 0; qg < K::NPB; ++qg) rb[h][qg] = br[(int64_t)group_base(qg, g.Q) * g.b_sq];
     }
   };
 
-  auto commit = [&](float* st, const int r0) {
+  auto commit = [&](float* st, const int r0, const cf32 (&ra)[K::HL][K::NPA], const cf32 (&rb)[K::HL][K::NPB]) {
 #pragma unroll
     for (int h = 0; h < K::HL; ++h) {
       const int rr = w + K::NW * h;
@@ -265,19 +273,7 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
 #ifndef SC_EMU
   long long dbg_t0 = 0, dbg_w0 = 0;
 #endif
-  issue(0);
-  commit(lds, 0);
-  SC_SYNC();
-#ifndef SC_EMU
-  if (g.dbg & 8) { dbg_t0 = clock64(); dbg_w0 = wall_clock64(); }
-#endif
-#pragma unroll 1
-  for (int ck = 0; ck < nck; ++ck) {
-    float* cur = lds + (ck & 1) * K::STAGE;
-    float* nxt = lds + ((ck + 1) & 1) * K::STAGE;
-    const bool more = ck + 1 < nck;
-    if (more && !(g.dbg & 4)) issue((ck + 1) * RC);
-    if (!(g.dbg & 1)) compute(cur);
+  auto pin_acc = [&]() {
 #ifndef SC_EMU
     if constexpr (K::NW == 4) {
       // 256-thread shape: hipcc puts the accumulators in AGPRs but carries them across the loop
@@ -288,10 +284,54 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
         for (int u = 0; u < QW; ++u) asm volatile("" : "+a"(acc[j][u]));
     }
 #endif
+  };
+  const bool ld = !(g.dbg & 4);
+  issue(0, ra0, rb0);
+#if SC_MG_PF == 2
+  if (nck > 1 && ld) issue(RC, ra1, rb1);
+#endif
+  commit(lds, 0, ra0, rb0);
+  SC_SYNC();
+#ifndef SC_EMU
+  if (g.dbg & 8) { dbg_t0 = clock64(); dbg_w0 = wall_clock64(); }
+#endif
+#if SC_MG_PF == 2
+  // two stages per trip so that the register sets alternate statically: even stages come from set 0 / LDS
+  // buffer 0, odd ones from set 1 / buffer 1
+  float* const l0 = lds;
+  float* const l1 = lds + K::STAGE;
+#pragma unroll 1
+  for (int ck = 0; ck < nck; ck += 2) {
+    if (ck + 2 < nck && ld) issue((ck + 2) * RC, ra0, rb0);
+    if (!(g.dbg & 1)) compute(l0);
+    pin_acc();
+    if (!(g.dbg & 8)) {
+      if (ck + 1 < nck) commit(l1, (ck + 1) * RC, ra1, rb1);
+      SC_SYNC();
+    }
+    if (ck + 1 >= nck) break;
+    if (ck + 3 < nck && ld) issue((ck + 3) * RC, ra1, rb1);
+    if (!(g.dbg & 1)) compute(l1);
+    pin_acc();
+    if (!(g.dbg & 8)) {
+      if (ck + 2 < nck) commit(l0, (ck + 2) * RC, ra0, rb0);
+      SC_SYNC();
+    }
+  }
+#else
+#pragma unroll 1
+  for (int ck = 0; ck < nck; ++ck) {
+    float* cur = lds + (ck & 1) * K::STAGE;
+    float* nxt = lds + ((ck + 1) & 1) * K::STAGE;
+    const bool more = ck + 1 < nck;
+    if (more && ld) issue((ck + 1) * RC, ra0, rb0);
+    if (!(g.dbg & 1)) compute(cur);
+    pin_acc();
     if (g.dbg & 8) continue;
-    if (more) commit(nxt, (ck + 1) * RC);
+    if (more) commit(nxt, (ck + 1) * RC, ra0, rb0);
     SC_SYNC();
   }
+#endif
 
   // ---- C: a lane owns column n = (q, d) and 16 rows of its tile, i.e. 4-byte pieces M*8 bytes
   //      apart.  Eight rows at a time are transposed through the tile's LDS patch (the stage
