@@ -1,4 +1,5 @@
-"""Launch the fused FFT transforms a few times (for rocprofv3 --pmc / --kernel-trace)."""
+"""Launch the fused FFT transforms a few times (for rocprofv3 --pmc / --kernel-trace).
+Usage: python scripts/fft_one.py [bf16]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,8 +8,9 @@ from neuraloperator_amd.engine import get_plan
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
 B, C, H = 32, 64, 256
-plan = get_plan(dev, [H, 256], [64, 33], "forward", 0)
-x = torch.randn(B, C, H, 256, device=dev); y = torch.empty_like(x)
+bf16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"          # SC_PLAN_IO_BF16: real tensors as bfloat16
+plan = get_plan(dev, [H, 256], [64, 33], "forward", _lib.SC_PLAN_IO_BF16 if bf16 else 0)
+x = torch.randn(B, C, H, 256, device=dev).to(torch.bfloat16 if bf16 else torch.float32); y = torch.empty_like(x)
 xh = torch.randn(B, C, 64 * 33, 2, device=dev)
 bias = torch.randn(C, device=dev)
 st = torch.cuda.current_stream().cuda_stream
