@@ -206,6 +206,17 @@ inline cf32 cf_mul_tw(const cf32 a, const float c, const float ns, const float s
   return cf_make(a.x * c + a.y * ns, a.y * c + a.x * s);
 }
 #endif
+// a * (c + i s) with the twiddle held as the plain pair t = (c, s): the sign of the cross term is an operand
+// modifier of v_pk_fma_f32, so no third register is needed (A-B: SC_F3_TW1_CS)
+#ifndef SC_EMU
+SC_DEVICE cf32 cf_mul_cs(const cf32 a, const cf32 t) {
+  const sc_f2 av = {a.x, a.y}, ayx = {a.y, a.x}, cc = {t.x, t.x}, nb = {-t.y, t.y};
+  const sc_f2 r = __builtin_elementwise_fma(ayx, nb, av * cc);
+  return cf_make(r.x, r.y);
+}
+#else
+inline cf32 cf_mul_cs(const cf32 a, const cf32 t) { return cf_make(a.x * t.x - a.y * t.y, a.y * t.x + a.x * t.y); }
+#endif
 struct ctw3 {   // register-resident twiddle
   float c, ns, s;
 };
@@ -227,6 +238,32 @@ SC_HD ctw4 ctw4_make(const cf32 t) {
   r.s = t.y;
   return r;
 }
+// a + (DIR i) b and a - (DIR i) b in ONE packed instruction each: fma(swap(b), (-/+1, +/-1), a).  Multiplying by +-1
+// is exact, so the bits equal those of the add / subtract pair; written as separate per-lane add and subtract the
+// compiler emits two packed adds plus two register moves to re-pair the halves (10 v_mov per 8-point DFT).
+#ifndef SC_EMU
+template <int DIR>
+SC_HD cf32 cf_add_rot(const cf32 a, const cf32 b) {              // a + w b, w = DIR i
+  const sc_f2 av = {a.x, a.y}, byx = {b.y, b.x}, k = {DIR < 0 ? 1.f : -1.f, DIR < 0 ? -1.f : 1.f};
+  const sc_f2 r = __builtin_elementwise_fma(byx, k, av);
+  return cf_make(r.x, r.y);
+}
+template <int DIR>
+SC_HD cf32 cf_sub_rot(const cf32 a, const cf32 b) {              // a - w b
+  const sc_f2 av = {a.x, a.y}, byx = {b.y, b.x}, k = {DIR < 0 ? -1.f : 1.f, DIR < 0 ? 1.f : -1.f};
+  const sc_f2 r = __builtin_elementwise_fma(byx, k, av);
+  return cf_make(r.x, r.y);
+}
+#else
+template <int DIR>
+inline cf32 cf_add_rot(const cf32 a, const cf32 b) {
+  return DIR < 0 ? cf_make(a.x + b.y, a.y - b.x) : cf_make(a.x - b.y, a.y + b.x);
+}
+template <int DIR>
+inline cf32 cf_sub_rot(const cf32 a, const cf32 b) {
+  return DIR < 0 ? cf_make(a.x - b.y, a.y + b.x) : cf_make(a.x + b.y, a.y - b.x);
+}
+#endif
 SC_HD cf32 cf_add(const cf32 a, const cf32 b) { return cf_make(a.x + b.x, a.y + b.y); }
 SC_HD cf32 cf_sub(const cf32 a, const cf32 b) { return cf_make(a.x - b.x, a.y - b.y); }
 SC_HD cf32 cf_conj(const cf32 a) { return cf_make(a.x, -a.y); }

@@ -50,11 +50,11 @@ SC_HD cf32 rot90(const cf32 a) {
 template <int DIR>
 SC_HD void radix4(cf32& a0, cf32& a1, cf32& a2, cf32& a3) {
   const cf32 t0 = cf_add(a0, a2), t1 = cf_sub(a0, a2);
-  const cf32 t2 = cf_add(a1, a3), t3 = rot90<DIR>(cf_sub(a1, a3));
+  const cf32 t2 = cf_add(a1, a3), d = cf_sub(a1, a3);
   a0 = cf_add(t0, t2);
   a2 = cf_sub(t0, t2);
-  a1 = cf_add(t1, t3);
-  a3 = cf_sub(t1, t3);
+  a1 = cf_add_rot<DIR>(t1, d);                           // t1 +- (DIR i) d
+  a3 = cf_sub_rot<DIR>(t1, d);
 }
 
 // a * exp(DIR * 2 pi i M / 16), M compile-time
@@ -106,7 +106,7 @@ SC_HD void fft16(cf32 (&v)[16], cf32 (&o)[16]) {
 
 SC_HD cf32 cf_scale(const cf32 a, const float s) { return cf_make(a.x * s, a.y * s); }
 // a + i*b
-SC_HD cf32 cf_add_i(const cf32 a, const cf32 b) { return cf_make(a.x - b.y, a.y + b.x); }
+SC_HD cf32 cf_add_i(const cf32 a, const cf32 b) { return cf_add_rot<+1>(a, b); }
 // conj(a) + i*conj(b)
 SC_HD cf32 cf_conj_add_i(const cf32 a, const cf32 b) { return cf_make(a.x + b.y, b.x - a.y); }
 

@@ -91,17 +91,16 @@ SC_HD void dft8(const cf32 (&a)[8], cf32 (&b)[8]) {
   radix4<DIR>(e0, e1, e2, e3);
   radix4<DIR>(o0, o1, o2, o3);
   constexpr float r = 0.70710678118654752440f;
-  const cf32 t1 = DIR < 0 ? cf_make((o1.x + o1.y) * r, (o1.y - o1.x) * r)
-                          : cf_make((o1.x - o1.y) * r, (o1.y + o1.x) * r);
-  const cf32 t2 = rot90<DIR>(o2);
-  const cf32 t3 = DIR < 0 ? cf_make((o3.y - o3.x) * r, (-o3.x - o3.y) * r)
-                          : cf_make((-o3.x - o3.y) * r, (o3.x - o3.y) * r);
+  // t1 = w8 o1 = (o1 + (DIR i) o1) r,  t3 = w8^3 o3 = -(o3 - (DIR i) o3) r  (same roundings as the
+  // component formulas: one add, one multiply per part)
+  const cf32 t1 = cf_scale(cf_add_rot<DIR>(o1, o1), r);
+  const cf32 t3 = cf_scale(cf_sub_rot<DIR>(o3, o3), -r);
   b[0] = cf_add(e0, o0);
   b[4] = cf_sub(e0, o0);
   b[1] = cf_add(e1, t1);
   b[5] = cf_sub(e1, t1);
-  b[2] = cf_add(e2, t2);
-  b[6] = cf_sub(e2, t2);
+  b[2] = cf_add_rot<DIR>(e2, o2);
+  b[6] = cf_sub_rot<DIR>(e2, o2);
   b[3] = cf_add(e3, t3);
   b[7] = cf_sub(e3, t3);
 }
@@ -119,11 +118,22 @@ SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// occupancy of the forward kernel: 4 workgroups per CU (128 VGPRs) with a ONE-round-deep row prefetch and the
+// first-stage twiddles as (c, s) pairs.  Measured (profiles/r01_fft_gen3_ablation.txt, session 3): once the
+// packed butterflies stopped wasting VALU slots on register moves the kernel became latency-bound, and a fourth
+// resident workgroup hides more of the LDS / HBM latency than the second prefetch round did (124.6-126.3 ->
+// 116.4-120.4 us).  A-B: -DSC_F3_FWD_OCC=3 -DSC_F3_PF_DEPTH=2 -DSC_F3_TW1_LEGACY.
 #ifndef SC_F3_FWD_OCC
-#define SC_F3_FWD_OCC 3
+#define SC_F3_FWD_OCC 4
+#endif
+#ifndef SC_F3_PF_DEPTH
+#define SC_F3_PF_DEPTH 1
+#endif
+#ifndef SC_F3_TW1_LEGACY
+#define SC_F3_TW1_CS 1
 #endif
 template <int H, typename IO>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? SC_F3_FWD_OCC : 3))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && sizeof(IO) == 4 ? SC_F3_FWD_OCC : 3))   // bf16 loads need 4 more VGPRs
 k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
              const cf32* __restrict__ tabH, int Mx, int My, float s_dc, float s_other) {
   constexpr int P = H / 64;
@@ -155,9 +165,15 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 
   // ---- row phase roles and per-lane twiddles
   const int k1l = lam >> 2, n4 = lam & 3;             // after the transpose: lane = (k1, n4)
+#ifdef SC_F3_TW1_CS
+  cf32 tw1[8];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) tw1[k] = tabW[(lam * k) & 255];               // w256^(n2 k1) as (c, s)
+#else
   ctw3 tw1[8];
 #pragma unroll
   for (int k = 1; k < 8; ++k) tw1[k] = ctw3_make(tabW[(lam * k) & 255]);    // w256^(n2 k1)
+#endif
   const ctw4* tw2 = tw2t + n4;                           // LDS table [k3][n4]: four adjacent 16-B slots per read
   cf32* xb = xch + hw * 8 * SC_F3_XRS;
 
@@ -208,10 +224,11 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
   };
 
   SC_SYNC();
-  // software prefetch, two rounds deep: a round of this kernel is short (~1 us), shorter than the
-  // loaded HBM latency, so the values of round t + 2 are requested while round t is transformed
-  // (two register sets, rounds alternate between them)
-  cf32 pz[2][8];                                         // .x = row A, .y = row B of the pair
+  // software prefetch, SC_F3_PF_DEPTH rounds deep: the values of round t + depth are requested while round t
+  // is transformed (depth register sets, rounds alternate between them).  A round is short (~1 us), about the
+  // loaded HBM latency: depth 2 covers it alone at 3 workgroups per CU, depth 1 relies on the other resident
+  // workgroups (4 per CU) and frees the 16 registers that make the fourth one fit
+  cf32 pz[SC_F3_PF_DEPTH][8];                            // .x = row A, .y = row B of the pair
   auto prefetch = [&](const int t, cf32 (&q)[8]) {        // t = 4 a + r
     if (t < 4 * P) {
       const int a = t >> 2, p = (t & 3) * 8 + hw;
@@ -229,7 +246,9 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     }
   };
   prefetch(0, pz[0]);
+#if SC_F3_PF_DEPTH == 2
   prefetch(1, pz[1]);
+#endif
 
 #pragma unroll 1
   for (int a = 0; a < P; ++a) {
@@ -238,15 +257,19 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     for (int r = 0; r < 4; ++r) {
       const int p = r * 8 + hw;
       cf32 v[8], o[8];
-      dft8<-1>(pz[r & 1], o);                            // over n1 (n = 32 n1 + lam) -> k1
-      prefetch(4 * a + r + 2, pz[r & 1]);                // refill the consumed register set
+      dft8<-1>(pz[r % SC_F3_PF_DEPTH], o);               // over n1 (n = 32 n1 + lam) -> k1
+      prefetch(4 * a + r + SC_F3_PF_DEPTH, pz[r % SC_F3_PF_DEPTH]);   // refill the consumed register set
 #ifdef SC_F3_ABL_NOROW
       if (o[0].x == 1234.5f) T[tid] = o[1];
       continue;
 #endif
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1)
+#ifdef SC_F3_TW1_CS
+        xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul_cs(o[k1], tw1[k1]);
+#else
         xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul_tw(o[k1], tw1[k1].c, tw1[k1].ns, tw1[k1].s);
+#endif
       SC_WAVE_SYNC();
 #pragma unroll
       for (int n3 = 0; n3 < 8; ++n3) v[n3] = xb[k1l * SC_F3_XRS + 4 * n3 + n4];
