@@ -264,8 +264,23 @@ inline cf32 cf_sub_rot(const cf32 a, const cf32 b) {
   return DIR < 0 ? cf_make(a.x - b.y, a.y + b.x) : cf_make(a.x + b.y, a.y - b.x);
 }
 #endif
+#ifndef SC_EMU
+// explicit packed forms: the natural (re, im) pair is the vector -- left to the SLP vectoriser, freshly loaded
+// values get paired ACROSS complex numbers and every first-stage butterfly pays register moves
+SC_HD cf32 cf_add(const cf32 a, const cf32 b) {
+  const sc_f2 av = {a.x, a.y}, bv = {b.x, b.y};
+  const sc_f2 r = av + bv;
+  return cf_make(r.x, r.y);
+}
+SC_HD cf32 cf_sub(const cf32 a, const cf32 b) {
+  const sc_f2 av = {a.x, a.y}, bv = {b.x, b.y};
+  const sc_f2 r = av - bv;
+  return cf_make(r.x, r.y);
+}
+#else
 SC_HD cf32 cf_add(const cf32 a, const cf32 b) { return cf_make(a.x + b.x, a.y + b.y); }
 SC_HD cf32 cf_sub(const cf32 a, const cf32 b) { return cf_make(a.x - b.x, a.y - b.y); }
+#endif
 SC_HD cf32 cf_conj(const cf32 a) { return cf_make(a.x, -a.y); }
 // multiply by -i  /  +i
 SC_HD cf32 cf_mul_mi(const cf32 a) { return cf_make(a.y, -a.x); }
