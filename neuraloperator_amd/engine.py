@@ -433,3 +433,13 @@ class EngineOps:
 
     def inverse_transform(self, yhat, bias, spatial, freq=None, real_col=0):
         return TransformInverseFn.apply(yhat, bias, list(spatial), self.fft_norm, self.flags, freq, real_col)
+
+    # one complex axis of a separable transform (the sharded dim of mpu.SpatialParallelSpectralConv):
+    # x (B, L, n) complex -> (B, L, k) with kept row r reading FFT index rows[r], and its zero-padded inverse;
+    # 1-d complex plans with an explicit frequency map (sc_plan_desc.freq)
+    def forward_axis(self, x, k, rows):
+        return TransformForwardFn.apply(x, [int(k)], self.fft_norm, self.flags | SC_PLAN_COMPLEX, [list(rows)])
+
+    def inverse_axis(self, xhat, n, rows):
+        return TransformInverseFn.apply(xhat, None, [int(n)], self.fft_norm, self.flags | SC_PLAN_COMPLEX,
+                                        [list(rows)], 0)

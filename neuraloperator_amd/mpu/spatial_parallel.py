@@ -1,0 +1,162 @@
+"""Spatially decomposed ("pencil") SpectralConv: ONE sample spans the model-parallel group.
+
+SURVEY.md section 8, "next" row f3: for B < P, or for single samples too large for one GPU (1024^2, 128^3+), the
+batch cannot be sharded -- the grid is.  New functionality on the reference's mpu API shape (the reference
+only has the unused building blocks, neuralop/mpu/helpers.py:28-99).  Layout per rank p of P:
+
+    activations   row-sharded      x_p   (B, Cin, d1/P, d2..dN)         rows [p d1/P, (p+1) d1/P) of dim 1
+    weights       column-sharded   W_p   (Cin, Cout, k1, k2p/P, k3..kN)  second mode dim, padded to k2p = P ceil(k2/P)
+
+    x_p --pruned rFFT over d2..dN (local rows)--> (B, Cin, d1/P, k2, ..)
+        --pad k2 -> k2p, all-to-all (split k2p, cat rows)--> (B, Cin, d1, k2p/P, ..)
+        --pruned complex DFT over d1 (centred rows)--> (B, Cin, k1, k2p/P, ..)
+        --contract with W_p--> (B, Cout, k1, k2p/P, ..)
+        --zero-padded inverse DFT over d1--> (B, Cout, d1, k2p/P, ..)
+        --all-to-all (split rows, cat k2p), drop the padding--> (B, Cout, d1/P, k2, ..)
+        --zero-padded C2R over d2..dN (+ bias)--> y_p (B, Cout, d1/P, d2..dN)
+
+Every local stage is an engine transform over fewer dims (a (N-1)-d real plan with the local rows folded into the
+channel count, and a 1-d complex plan with an explicit centred frequency map -- include/sc_engine.h,
+sc_plan_desc.freq); the separable N-d transform of spectral_convolution.py:443-449 / :531-559 is the product of
+the two.  One all-to-all each way moves the truncated spectrum only (k2/d2 of the data); the backward is the
+same pipeline mirrored.  Each rank sees the whole batch for its mode columns: gW needs no all-reduce; the bias
+gradient is summed over the group (every rank saw different rows).
+"""
+import torch
+from torch import nn
+
+from ..modes import halve_last_mode, kept_block
+from ..spectral_conv import BaseSpectralConv
+from . import comm
+from .mappings import all_to_all
+
+
+def centred_rows(k, n):
+    """FFT index on an n-point grid of kept row r: signed frequency r - k//2 (spectral_convolution.py:502-512)."""
+    return [(r - k // 2) % n for r in range(k)]
+
+
+class SpatialParallelSpectralConv(BaseSpectralConv):
+    """Dense-weight SpectralConv on a grid whose FIRST spatial dim is sharded across the model-parallel group.
+
+    Constructor arguments follow SpectralConv; ``n_modes`` is fixed at construction.  ``ops`` (tests only)
+    replaces the local stages (forward_transform / inverse_transform / contract / forward_axis / inverse_axis)."""
+
+    def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
+                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, **unused):
+        super().__init__(device=device)
+        for k in ("complex_data", "separable"):
+            if unused.get(k):
+                raise NotImplementedError(f"{k}=True is not supported by the spatially decomposed layer")
+        if unused.get("factorization") not in (None, "Dense", "dense"):
+            raise NotImplementedError("spatially decomposed layer: dense weights only")
+        if fft_norm != "forward":
+            raise NotImplementedError("spatially decomposed layer: fft_norm='forward' (the reference default)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._n_modes = halve_last_mode(n_modes)
+        self.max_n_modes = list(self._n_modes)
+        self.order = len(self._n_modes)
+        if self.order < 2:
+            raise NotImplementedError("a spatial decomposition needs >= 2 spatial dims (dim 0 is sharded)")
+        self.fft_norm = fft_norm
+        self.group = group
+        self.P = comm.get_model_parallel_size() if group is None else torch.distributed.get_world_size(group)
+        self.rank = comm.get_model_parallel_rank() if group is None else torch.distributed.get_rank(group)
+        k2 = self._n_modes[1]
+        self.k2_pad = -(-k2 // self.P) * self.P                      # columns after padding
+        self.k2_loc = self.k2_pad // self.P                          # columns this rank contracts
+        if init_std == "auto":
+            init_std = (2 / (in_channels + out_channels)) ** 0.5
+        w = torch.empty(in_channels, out_channels, self._n_modes[0], self.k2_loc, *self._n_modes[2:],
+                        dtype=torch.cfloat, device=device)
+        w.normal_(0, init_std)
+        lo = self.rank * self.k2_loc
+        if lo + self.k2_loc > k2:                                    # inert padding columns of the last rank(s)
+            with torch.no_grad():
+                w[:, :, :, max(k2 - lo, 0):] = 0
+        self.weight = nn.Parameter(w)
+        self.weight.mode_sharded = True
+        self.bias = nn.Parameter(init_std * torch.randn(out_channels, *(1,) * self.order, device=device)) \
+            if bias else None
+        if ops is None:
+            from ..engine import EngineOps
+            ops = EngineOps(fft_norm, engine_flags)
+        self.ops = ops
+
+    @property
+    def n_modes(self):
+        return self._n_modes
+
+    @n_modes.setter
+    def n_modes(self, value):
+        raise NotImplementedError("the spatially decomposed layer fixes n_modes at construction (shard layout)")
+
+    def transform(self, x, output_shape=None):
+        if output_shape is not None:
+            raise NotImplementedError("resolution change is not supported by the spatially decomposed layer")
+        return x
+
+    def forward(self, x, output_shape=None):
+        if output_shape is not None:
+            raise NotImplementedError("resolution change is not supported by the spatially decomposed layer")
+        if x.ndim != self.order + 2:
+            raise ValueError(f"expected a (B, C, {self.order} spatial dims) input, got {tuple(x.shape)}")
+        b, c, h_loc = x.shape[:3]
+        rest = list(x.shape[3:])
+        d1 = h_loc * self.P
+        kept, _ = kept_block([d1] + rest, self._n_modes, self.max_n_modes)
+        if kept != list(self._n_modes):
+            raise ValueError(f"grid {[d1] + rest} is too small for n_modes {self._n_modes}")
+        k1, k2 = kept[0], kept[1]
+        co = self.out_channels
+        # 1. local rows: pruned real transform over d2..dN (rows folded into the channel count)
+        xh = self.ops.forward_transform(x.reshape(b, c * h_loc, *rest), kept[1:])
+        xh = xh.reshape(b, c, h_loc, *kept[1:])
+        # 2. exchange: every rank gets ALL rows of its k2p / P columns
+        if self.k2_pad != k2:
+            xh = _pad_dim(xh, 3, self.k2_pad - k2)
+        xh = all_to_all(xh, split_dim=3, cat_dim=2, group=self.group)          # (B, Cin, d1, k2p/P, ..)
+        # 3. pruned complex DFT over d1 (moved last: the engine's 1-d plans run over the contiguous dim)
+        xt = xh.movedim(2, -1).contiguous()
+        lead = xt.shape[:-1]
+        xa = self.ops.forward_axis(xt.reshape(b, -1, d1), k1, centred_rows(k1, d1))
+        xa = xa.reshape(*lead, k1).movedim(-1, 2).contiguous()                   # (B, Cin, k1, k2p/P, ..)
+        # 4. contraction with this rank's mode columns
+        yh = self.ops.contract(xa, self.weight)                                 # (B, Cout, k1, k2p/P, ..)
+        # 5. zero-padded inverse DFT over d1
+        yt = yh.movedim(2, -1).contiguous()
+        lead = yt.shape[:-1]
+        ya = self.ops.inverse_axis(yt.reshape(b, -1, k1), d1, centred_rows(k1, d1))
+        ya = ya.reshape(*lead, d1).movedim(-1, 2).contiguous()                   # (B, Cout, d1, k2p/P, ..)
+        # 6. exchange back: local rows, all columns; drop the padding
+        ya = all_to_all(ya, split_dim=2, cat_dim=3, group=self.group)          # (B, Cout, d1/P, k2p, ..)
+        if self.k2_pad != k2:
+            ya = ya.narrow(3, 0, k2)
+        # 7. zero-padded C2R over d2..dN on the local rows, bias per (channel, row) image
+        bias = None
+        if self.bias is not None:
+            bias = self.bias.reshape(co, 1).expand(co, h_loc).reshape(co * h_loc, *(1,) * len(rest))
+        y = self.ops.inverse_transform(ya.reshape(b, co * h_loc, *kept[1:]).contiguous(), bias, rest)
+        return y.reshape(b, co, h_loc, *rest)
+
+    # ---- helpers for the training loop -----------------------------------------------------------
+    def reduce_replicated_grads(self):
+        """Sum the bias gradient over the model-parallel group (every rank saw different rows)."""
+        if self.P > 1 and self.bias is not None and self.bias.grad is not None:
+            torch.distributed.all_reduce(self.bias.grad, group=self.group if self.group is not None
+                                         else comm.get_model_parallel_group())
+
+    @staticmethod
+    def shard_dense_weight(full_weight, rank, world):
+        """Columns (second mode dim, zero-padded to a multiple of ``world``) of a full weight that ``rank`` owns."""
+        k2 = full_weight.shape[3]
+        loc = -(-k2 // world)
+        w = _pad_dim(full_weight, 3, loc * world - k2) if loc * world != k2 else full_weight
+        return w.narrow(3, rank * loc, loc).contiguous()
+
+
+def _pad_dim(t, dim, n):
+    """zero-pad ``n`` entries at the end of ``dim`` (autograd: the gradient of the padding is dropped)."""
+    shape = list(t.shape)
+    shape[dim] = n
+    return torch.cat([t, torch.zeros(shape, dtype=t.dtype, device=t.device)], dim=dim)

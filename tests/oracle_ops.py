@@ -41,3 +41,14 @@ class OracleOps:
             cur = z.index_add(2 + d, idx[d], cur)
         y = torch.fft.irfftn(cur, s=list(spatial), dim=list(range(-nd, 0)), norm="forward")
         return y + bias if bias is not None else y
+
+    # one complex axis (last dim) with an explicit row -> FFT index map; norm="forward" like the layer
+    def forward_axis(self, x, k, rows):
+        ix = torch.as_tensor(list(rows))
+        assert len(rows) == k
+        return torch.fft.fft(x, dim=-1, norm="forward").index_select(-1, ix)
+
+    def inverse_axis(self, xhat, n, rows):
+        ix = torch.as_tensor(list(rows))
+        z = torch.zeros(*xhat.shape[:-1], n, dtype=xhat.dtype)
+        return torch.fft.ifft(z.index_add(-1, ix, xhat), dim=-1, norm="forward")

@@ -83,3 +83,47 @@ def test_frequency_map_validation(lib):
         lib.plan_create([8, 8], [4, 3], freq=[[0, 1], None])                # wrong length
     p = lib.plan_create([8, 8], [4, 3], freq=[[6, 7, 0, None], None])       # a dropped row is fine
     lib.plan_destroy(p)
+
+
+@pytest.mark.parametrize("passes", ["mdft", "valu"])
+@pytest.mark.parametrize("n,k,lines", [(16, 8, 5), (12, 5, 3), (64, 32, 9), (10, 10, 2)])
+def test_one_complex_axis_with_centred_rows(lib, n, k, lines, passes):
+    """The sharded-dim pass of mpu.SpatialParallelSpectralConv (EngineOps.forward_axis / inverse_axis): a 1-d
+    complex plan whose kept row r reads / lands at FFT index (r - k//2) mod n, forward scaled by 1/n
+    (fft_norm="forward"), inverse zero-padded and unscaled -- and the SC_FWD_ADJ / SC_INV_ADJ pair autograd uses."""
+    from neuraloperator_amd.mpu.spatial_parallel import centred_rows
+    torch.manual_seed(n + k)
+    rows = centred_rows(k, n)
+    flags = _lib.SC_PLAN_COMPLEX | (_lib.SC_PLAN_NO_MDFT if passes == "valu" else 0)
+    plan = lib.plan_create([n], [k], flags=flags, freq=[rows])
+    try:
+        b = 2
+        x = torch.randn(b, lines, n, dtype=torch.cfloat)
+        xh = torch.empty(b, lines, k, dtype=torch.cfloat)
+        ws = torch.empty(max(lib.plan_workspace_bytes(plan, b * lines), 256), dtype=torch.uint8)
+        ix = torch.as_tensor(rows)
+        lib.transform_forward(plan, _lib.SC_FWD_SCALED, torch.view_as_real(x).data_ptr(),
+                              torch.view_as_real(xh).data_ptr(), b * lines, ws.data_ptr(), 0)
+        ref = torch.fft.fft(x, dim=-1, norm="forward").index_select(-1, ix)
+        assert rel_l2(xh.numpy(), ref.numpy()) < TOL
+        yh = torch.randn(b, lines, k, dtype=torch.cfloat)
+        y = torch.empty(b, lines, n, dtype=torch.cfloat)
+        lib.transform_inverse(plan, _lib.SC_INV_PADDED, torch.view_as_real(yh).data_ptr(), 0, lines,
+                              torch.view_as_real(y).data_ptr(), b * lines, ws.data_ptr(), 0)
+        z = torch.zeros(b, lines, n, dtype=torch.cfloat).index_add(-1, ix, yh)
+        assert rel_l2(y.numpy(), torch.fft.ifft(z, dim=-1, norm="forward").numpy()) < TOL
+        # adjoints (what TransformForwardFn / TransformInverseFn launch in backward): <A x, v> = <x, A^H v>
+        gx = torch.empty_like(x)
+        lib.transform_inverse(plan, _lib.SC_INV_ADJ_R2C, torch.view_as_real(yh).data_ptr(), 0, lines,
+                              torch.view_as_real(gx).data_ptr(), b * lines, ws.data_ptr(), 0)
+        lhs = torch.sum(torch.conj(yh) * ref)
+        rhs = torch.sum(torch.conj(gx) * x)
+        assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+        gh = torch.empty_like(yh)
+        lib.transform_forward(plan, _lib.SC_FWD_ADJ_C2R, torch.view_as_real(x).data_ptr(),
+                              torch.view_as_real(gh).data_ptr(), b * lines, ws.data_ptr(), 0)
+        lhs = torch.sum(torch.conj(x) * torch.fft.ifft(z, dim=-1, norm="forward"))
+        rhs = torch.sum(torch.conj(gh) * yh)
+        assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+    finally:
+        lib.plan_destroy(plan)

@@ -552,6 +552,35 @@ def test_mode_parallel_layer_on_device_single_rank():
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("spatial,modes", [((32, 24), (16, 12)), ((12, 16, 20), (6, 8, 8)), ((64, 256), (16, 16))])
+def test_spatial_parallel_layer_on_device_single_rank(spatial, modes):
+    """The spatially decomposed layer with the engine's stage ops on the GPU, one rank (no process
+    group: the all-to-alls degenerate): the (N-1)-d real plans with the rows folded into the channel count, the 1-d
+    complex axis plans with the centred frequency map, the contraction and autograd through all of them against
+    the plain layer.  Row sharding / padding / exchange: world-size-2 gloo test."""
+    from neuraloperator_amd import SpectralConv
+    from neuraloperator_amd.mpu import SpatialParallelSpectralConv
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    ref = SpectralConv(6, 5, modes).to(dev)
+    sp = SpatialParallelSpectralConv(6, 5, modes).to(dev)
+    assert sp.P == 1
+    with torch.no_grad():
+        sp.weight.copy_(ref.weight.tensor)
+        sp.bias.copy_(ref.bias)
+    x = torch.randn(3, 6, *spatial, device=dev, requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    g = torch.randn(3, 5, *spatial, device=dev)
+    y, yr = sp(x), ref(xr)
+    y.backward(g)
+    yr.backward(g)
+    assert rel_l2(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < TOL
+    assert rel_l2(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < TOL
+    assert rel_l2(sp.weight.grad.cpu().numpy(), ref.weight.tensor.grad.cpu().numpy()) < TOL
+    assert rel_l2(sp.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < TOL
+
+
 @pytest.mark.parametrize("name", golden_names("adamw_"))
 def test_optimizer_matches_reference_trajectory(name):
     """neuraloperator_amd.AdamW (one fused launch per parameter) against the verbatim reference optimizer's
