@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fno2d_256_m64_c64_b32", choices=sorted(WORKLOADS))
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "modeshard"])
+    ap.add_argument("--parallel", default="replicas", choices=["replicas", "modeshard", "pencil"],
+                    help="N > 1: replicas = data-parallel copies (default, no data-path collective); modeshard = "
+                         "mode-parallel layer (batch-sharded activations); pencil = spatially decomposed layer "
+                         "(every sample spans all ranks: rows of the first grid dim sharded)")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
                     help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
@@ -286,6 +289,16 @@ def main():
         scaling = "strong" if B % world == 0 else "weak"
         global_batch = b_local * world
         par = f"modeshard{world}"
+    elif args.parallel == "pencil" and world > 1:
+        from neuraloperator_amd.mpu import SpatialParallelSpectralConv, comm
+        if spatial[0] % world:
+            raise SystemExit(f"--parallel pencil: grid rows {spatial[0]} not divisible by {world} ranks")
+        comm.init(model_parallel_size=world)
+        conv = SpatialParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        b_local = B
+        scaling = "strong"                     # the same B samples, each spread over all ranks
+        global_batch = B
+        par = f"pencil{world}"
     else:
         conv = SpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
         b_local = B
@@ -293,8 +306,11 @@ def main():
         global_batch = B * world
         par = f"dp{world}-replicas" if world > 1 else "single"
     io_dtype = torch.bfloat16 if args.io == "bf16" else torch.float32
-    x = torch.randn(b_local, C, *spatial, device=dev).to(io_dtype).requires_grad_(True)
-    g = torch.randn(b_local, C, *spatial, device=dev).to(io_dtype)
+    local_spatial = list(spatial)
+    if par.startswith("pencil"):
+        local_spatial[0] = spatial[0] // world
+    x = torch.randn(b_local, C, *local_spatial, device=dev).to(io_dtype).requires_grad_(True)
+    g = torch.randn(b_local, C, *local_spatial, device=dev).to(io_dtype)
     if args.io == "bf16":
         from neuraloperator_amd import engine
         kept_chk, _ = kept_block(spatial, halve_last_mode(n_modes), halve_last_mode(n_modes))
