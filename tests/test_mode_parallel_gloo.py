@@ -118,3 +118,62 @@ def test_single_process_fallback_getters():
     from neuraloperator_amd.mpu import comm
     assert comm.get_world_size() == 1 and comm.get_model_parallel_size() == 1
     assert comm.get_model_parallel_rank() == 0 and comm.get_data_parallel_rank() == 0
+
+
+def _hybrid_worker(rank, world, port, ret):
+    """4 ranks = 2 data-parallel replicas of a 2-rank mode-parallel group (contiguous model groups {0,1}, {2,3};
+    strided data groups {0,2}, {1,3} -- reference comm.py:104-198): each replica sees half of the batch, the
+    sharded weight gradient is summed over the DATA-parallel group only (never over the model group), the bias
+    gradient over both."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleOps
+
+    mp_size = 2
+    comm.init(model_parallel_size=mp_size, backend="gloo")
+    assert comm.get_model_parallel_size() == 2 and comm.get_data_parallel_size() == 2
+    mp_rank, dp_rank = comm.get_model_parallel_rank(), comm.get_data_parallel_rank()
+    assert (mp_rank, dp_rank) == (rank % 2, rank // 2)
+    spatial, modes = (8, 10), (4, 6)
+    nm = halve_last_mode(modes)
+    B, ci, co = 8, 2, 3                      # global batch: 2 replicas x 2 model ranks x 2 samples
+    torch.manual_seed(0)
+    x = torch.randn(B, ci, *spatial)
+    g = torch.randn(B, co, *spatial)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
+    bias = torch.randn(co, 1, 1)
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleOps(nm))
+    with torch.no_grad():
+        conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, mp_rank, mp_size))
+        conv.bias.copy_(bias)
+    per = B // world
+    lo = (dp_rank * mp_size + mp_rank) * per
+    xs = x[lo:lo + per].clone().requires_grad_(True)
+    conv(xs).backward(g[lo:lo + per])
+    conv.reduce_replicated_grads()                                   # bias: over the model group
+    dist_group = comm.get_data_parallel_group()
+    dist.all_reduce(conv.weight.grad, group=dist_group)              # sharded weight: data-parallel group only
+    dist.all_reduce(conv.bias.grad, group=dist_group)
+    xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    so.forward_torch(xf, wf, bf, nm, nm).backward(g)
+    rows = nm[0] // mp_size
+    ret[rank] = dict(
+        gx=so.rel_l2(xs.grad.numpy(), xf.grad[lo:lo + per].numpy()),
+        gw=so.rel_l2(conv.weight.grad.numpy(), wf.grad[:, :, mp_rank * rows:(mp_rank + 1) * rows].numpy()),
+        gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()))
+    comm.cleanup()
+
+
+def test_hybrid_data_and_mode_parallel_groups():
+    world = 4
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_hybrid_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank, errs in ret.items():
+        for k, v in errs.items():
+            assert np.isfinite(v) and v < 1e-5, (rank, k, v)
