@@ -122,7 +122,8 @@ enum {
   SC_GEMM_FORCE_VALU = 1,    /* never take the matrix-core kernel (debug / A-B)            */
   SC_GEMM_STREAM_C = 2,      /* C is not consumed by the next kernel: non-temporal stores    */
   SC_GEMM_PAIRED = 4,        /* P = 32: two 4-wave workgroups per CU, 5 modes each (A-B; slower from HBM) */
-  SC_GEMM_WIDE = 8           /* 9 modes per workgroup even for a small mode count (A-B / tests)          */
+  SC_GEMM_WIDE = 8,          /* 9 modes per workgroup even for a small mode count (A-B / tests)          */
+  SC_GEMM_NO_STREAM = 16     /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
 };
 /* flags bits 8..23: cap on the number of workgroups of the matrix-core kernel (0 = auto) */
 #define SC_GEMM_GRID(n) (((n) & 0xffff) << 8)
@@ -147,8 +148,12 @@ int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float
  * p*c_sp + q*c_sq) must be zeroed by the caller; c_sm / c_idx / accumulate are ignored. */
 int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                      void* stream);
-/* 1 if this call runs on the MFMA kernel (k_modegemm_mfma), 0 for the VALU kernel */
+/* 1 if this call runs on a matrix-core kernel, 0 for the VALU kernel */
 int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
+/* which kernel a call with 16-byte aligned operands takes: 0 k_modegemm (VALU), 1 k_modegemm_mfma (register-staged
+ * matrix-core kernel: sub-blocks through index tables, ragged ranks, factor operands), 2 k_modegemm_s8 (LDS-DMA
+ * streamed matrix-core kernel: plain contiguous-mode operands, mode count a multiple of 8) */
+int sc_modegemm_path(const sc_modegemm_desc* d);
 
 /* gbias[c] = sum_b Re(ghat[b, c, dc]) -- the bias gradient read off the DC coefficient of
  * the already-computed SC_FWD_ADJ_C2R spectrum (autograd of :567-568). */

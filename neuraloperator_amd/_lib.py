@@ -23,6 +23,7 @@ SC_GEMM_FORCE_VALU = 1
 SC_GEMM_STREAM_C = 2
 SC_GEMM_PAIRED = 4
 SC_GEMM_WIDE = 8
+SC_GEMM_NO_STREAM = 16
 
 
 def SC_GEMM_GRID(n):
@@ -72,7 +73,7 @@ class ScEngineLib:
     # every symbol include/sc_engine.h declares
     SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
                "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
-               "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_bias_grad", "sc_adamw_step",
+               "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name"]
 
@@ -108,6 +109,8 @@ class ScEngineLib:
         L.sc_modegemm_msum.restype = c_int
         L.sc_modegemm_uses_matrix_cores.argtypes = [POINTER(ModeGemmDesc)]
         L.sc_modegemm_uses_matrix_cores.restype = c_int
+        L.sc_modegemm_path.argtypes = [POINTER(ModeGemmDesc)]
+        L.sc_modegemm_path.restype = c_int
         L.sc_bias_grad.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
         L.sc_bias_grad.restype = c_int
         L.sc_adamw_step.argtypes = [POINTER(AdamwDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
@@ -199,6 +202,13 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         return bool(self.lib.sc_modegemm_uses_matrix_cores(byref(d)))
+
+    def modegemm_path(self, **kw):
+        """0 VALU kernel, 1 k_modegemm_mfma, 2 k_modegemm_s8 (for 16-byte aligned operands)."""
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return int(self.lib.sc_modegemm_path(byref(d)))
 
     def adamw_step(self, p_ptr, g_ptr, m_ptr, v_ptr, n, is_complex, stream=0, *, lr, beta1, beta2, eps,
                    weight_decay, correct_bias, step):

@@ -54,6 +54,24 @@ SC_DEVICE int sc_opaque(int x) {
 #define SC_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; \
   type* name = reinterpret_cast<type*>(name##_raw)
 
+
+// ---- LDS-DMA pipeline vocabulary (sc_kernels_gemm8.h) ---------------------------------------------------------
+// 16 bytes per lane straight from global memory into LDS, no VGPR round trip: the wave writes ONE contiguous 1 KiB
+// piece at the wave-uniform LDS address `lbase` (lane l lands at lbase + 16 l); the global source is per lane.
+// hipcc neither counts these operations nor orders ds_reads behind them: the kernel waits with its own counted
+// s_waitcnt vmcnt(N) and a raw s_barrier (cdna_hip_programming.md 5, "Pipelining across barriers").
+#define SC_GLDS16(gptr, lbase)                                                                   \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
+                                   (__attribute__((address_space(3))) void*)(lbase), 16, 0, 0)
+template <int N>
+SC_DEVICE void sc_wait_vmcnt() {        // at most N of this wave's vector-memory operations still in flight
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define SC_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// s_barrier without the vmcnt(0) drain __syncthreads() carries while an LDS-DMA is outstanding
+#define SC_BARRIER_RAW() __builtin_amdgcn_s_barrier()
+typedef float sc_f4 __attribute__((ext_vector_type(4)));
+
 typedef hipStream_t sc_stream_t;
 
 #define SC_LAUNCH(kernel, grid, block, shmem, stream, ...) \
@@ -101,6 +119,19 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_LOAD_STREAM(ptr) (*(ptr))
 inline int sc_opaque(int x) { return x; }
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)
+
+
+struct alignas(16) sc_f4 {
+  float x, y, z, w;
+};
+// LDS-DMA emulated as a synchronous copy by the lane's own thread; the waits are no-ops, the raw barrier is the
+// workgroup barrier -- ordering bugs that depend on a MISSING wait are therefore invisible here (the GPU tier
+// and the counted-wait arithmetic in the kernel comments cover those), index maths and buffer rotation are not
+#define SC_GLDS16(gptr, lbase) std::memcpy(reinterpret_cast<unsigned char*>(lbase) + 16 * (SC_TID & 63), (gptr), 16)
+template <int N>
+inline void sc_wait_vmcnt() {}
+#define SC_WAIT_LGKM0() do { } while (0)
+#define SC_BARRIER_RAW() scemu::barrier()
 
 typedef void* sc_stream_t;
 

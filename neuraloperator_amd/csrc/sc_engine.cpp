@@ -19,6 +19,7 @@
 #include "sc_kernels_fft.h"
 #include "sc_kernels_fft3.h"
 #include "sc_kernels_mfma.h"
+#include "sc_kernels_gemm8.h"
 #include "sc_kernels_mdft.h"
 
 // ------------------------------------------------------------------------------------------
@@ -1069,6 +1070,66 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   return sc_check_launch("k_modegemm_mfma");
 }
 
+// ---- streamed matrix-core path (sc_kernels_gemm8.h): plain contiguous-mode operands, 8 modes per workgroup ------
+#ifndef SC_G8_DEPTH
+#define SC_G8_DEPTH 6          // ring stages of 12 KiB: 72 KiB of LDS -> two workgroups per CU
+#endif
+static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
+  if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM)) return false;
+  if (d->accumulate || d->b_idx || d->c_idx) return false;
+  if (d->a_sm != 1 || d->b_sm != 1 || d->c_sm != 1) return false;
+  if (d->n_modes % 8 != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
+  // 16-byte granules: every row / column of every operand must start on an even complex element
+  if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
+  // tiles are 32 rows x 64 columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as 36
+  // stay on the 64-row tiles of k_modegemm_mfma)
+  const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + 63) / 64 * 64;
+  if (4 * d->P < 3 * Pp || 4 * d->Q < 3 * Qp) return false;
+  if (d->R < 4) return false;
+  if (Pp / 32 * (Qp / 64) * (d->n_modes / 8) >= ((int64_t)1 << 30)) return false;
+  return true;
+}
+
+template <bool CA, bool CB>
+static void launch_gemm8(const Gemm8Args& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  SC_LAUNCH((k_modegemm_s8<SC_G8_DEPTH, CA, CB>), dim3((unsigned)g.G), dim3(256), 0, st, g, A, B, C);
+}
+
+static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  Gemm8Args g;
+  g.P = (int)d->P; g.Q = (int)d->Q; g.R = (int)d->R;
+  g.n_mg = (int)(d->n_modes / 8);
+  g.n_pb = (int)((d->P + 31) / 32);
+  g.n_qb = (int)((d->Q + 63) / 64);
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr;
+  g.b_sr = d->b_sr; g.b_sq = d->b_sq;
+  g.c_sp = d->c_sp; g.c_sq = d->c_sq;
+  g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
+  // tiles per workgroup: a launch that would need between one and two rounds of the 512 resident workgroups (two
+  // per CU) runs its tiles back to back inside fewer workgroups instead of queueing a short second round; the
+  // grid is a multiple of 8 whenever possible so that the XCD-aware unit mapping applies
+  const int64_t nblk = (int64_t)g.n_pb * g.n_qb;
+  int64_t bpw = 1;
+  if (g.n_mg <= 512 && g.n_mg * nblk > 512) {
+    bpw = nblk;
+    for (int64_t b = 1; b <= nblk; ++b)
+      if (g.n_mg * ((nblk + b - 1) / b) <= 512) {
+        bpw = b;
+        break;
+      }
+  }
+  const int64_t cap = (d->flags >> 8) & 0xffff;               // SC_GEMM_GRID(n) doubles as "tiles per workgroup" (tests)
+  if (cap > 0 && cap <= nblk) bpw = cap;
+  g.bpw = (int)bpw;
+  g.G = (int)(g.n_mg * ((nblk + bpw - 1) / bpw));
+  if (!d->conj_a && !d->conj_b) launch_gemm8<false, false>(g, A, B, C, st);
+  else if (d->conj_a && !d->conj_b) launch_gemm8<true, false>(g, A, B, C, st);
+  else if (!d->conj_a && d->conj_b) launch_gemm8<false, true>(g, A, B, C, st);
+  else launch_gemm8<true, true>(g, A, B, C, st);
+  return sc_check_launch("k_modegemm_s8");
+}
+
 extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                            void* stream) {
   SC_CHECK_ARG(d && A && B && C, "null argument");
@@ -1088,6 +1149,7 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   const cf32* a = (const cf32*)A;
   const cf32* b = (const cf32*)B;
   cf32* c = (cf32*)C;
+  if (gemm8_eligible(d, A, B, C)) return run_gemm8(d, a, b, c, st);
   if (!(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d))
     return run_mfma_gemm(d, a, b, c, st);
   if (g.Q > 4) return dispatch_modegemm_conj<4, 8>(g, d->conj_a, d->conj_b, a, b, c, st);
@@ -1135,9 +1197,13 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
   return sc_check_launch("k_modegemm_msum");
 }
 
-extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) {
-  return d && !(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d) ? 1 : 0;
+extern "C" int sc_modegemm_path(const sc_modegemm_desc* d) {
+  if (!d) return 0;
+  if (gemm8_eligible(d, nullptr, nullptr, nullptr)) return 2;
+  return !(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d) ? 1 : 0;
 }
+
+extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) { return sc_modegemm_path(d) ? 1 : 0; }
 
 extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,
                             float* gbias, void* stream) {

@@ -378,13 +378,6 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
 // from LDS (padded rows: conflict-free).  One 32-line row tile per wave and <= 64 accumulator
 // registers: 3-4 blocks per CU hide each other's barriers and memory latency.
 // ==========================================================================================
-#ifndef SC_EMU
-typedef float sc_f4 __attribute__((ext_vector_type(4)));
-#else
-struct alignas(16) sc_f4 {
-  float x, y, z, w;
-};
-#endif
 SC_HD float sc_f4_at(const sc_f4& v, const int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
 
 #define SC_MDFT_LB 128          // lines per block tile (4 waves x one 32-line MFMA row tile)

@@ -49,6 +49,10 @@ SC_DEVICE void sc_mfma_32x32x2(sc_f32x16& acc, const float a, const float b) {
 SC_DEVICE float sc_xor_sign(const float v, const uint32_t mask) {
   return __uint_as_float(__float_as_uint(v) ^ mask);
 }
+// bitwise (mask ? hi : lo): one v_bfi_b32
+SC_DEVICE float sc_bitsel(const uint32_t mask, const float hi, const float lo) {
+  return __uint_as_float((__float_as_uint(hi) & mask) | (__float_as_uint(lo) & ~mask));
+}
 #else
 struct sc_f32x16 {
   float v[16];
@@ -73,6 +77,15 @@ inline void sc_mfma_32x32x2(sc_f32x16& acc, const float a, const float b) {
     acc[v] = c;
   }
   scemu::wave_barrier();
+}
+inline float sc_bitsel(const uint32_t mask, const float hi, const float lo) {
+  uint32_t a, b;
+  std::memcpy(&a, &hi, 4);
+  std::memcpy(&b, &lo, 4);
+  a = (a & mask) | (b & ~mask);
+  float r;
+  std::memcpy(&r, &a, 4);
+  return r;
 }
 inline float sc_xor_sign(const float v, const uint32_t mask) {
   uint32_t u;

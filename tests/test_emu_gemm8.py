@@ -1,0 +1,117 @@
+"""CPU tier: the LDS-DMA streamed matrix-core mode GEMM (sc_kernels_gemm8.h, k_modegemm_s8) in host emulation --
+MFMA replaced by its documented lane / register map, LDS-DMA by a synchronous copy; unit decoding, the source-side
+bank swizzle, ring rotation, operand sign masks, the patch epilogue and the clamping of ragged rows / columns / r
+are the product source -- against a numpy complex128 einsum.  Covers the layer's three contractions (forward, gX
+with conj(B) and transposed strides, gW with conj(A)), odd / short / long r loops (shorter and longer than the
+ring), several row / column blocks per workgroup and per launch, hidden = 128."""
+import numpy as np
+import pytest
+import torch
+
+from engine_runner import emu_lib, rel_l2
+from neuraloperator_amd import _lib
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def _rand(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.complex(torch.randn(*shape, generator=g), torch.randn(*shape, generator=g))
+
+
+def run(lib, a, b, c, flags=0, expect=2, **kw):
+    assert lib.modegemm_path(flags=flags, **kw) == expect, "test must exercise the intended kernel"
+    lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                 torch.view_as_real(c).data_ptr(), 0, flags=flags, **kw)
+    return c
+
+
+# (B, Ci, Co, M, tiles per workgroup (0 = auto))
+FWD = [
+    (32, 64, 64, 16, 0),     # the metric tile: two mode groups, 32 stages (ring wraps five times)
+    (32, 6, 64, 8, 0),       # r loop shorter than the ring (3 stages)
+    (32, 7, 64, 8, 0),       # odd r: the clamped duplicate of the last pair contributes nothing
+    (28, 20, 52, 8, 0),      # ragged rows and columns inside one tile
+    (64, 16, 128, 8, 0),     # 2 row blocks x 2 column blocks, one tile per workgroup
+    (64, 16, 128, 8, 4),     # ... all four tiles in one workgroup, back to back
+    (56, 12, 64, 24, 2),     # second row block ragged (24 of 32 rows), two tiles per workgroup, 3 mode groups
+]
+
+
+@pytest.mark.parametrize("case", FWD, ids=lambda c: "B%d_Ci%d_Co%d_M%d_t%d" % c)
+def test_forward(lib, case):
+    B, Ci, Co, M, bpw = case
+    x, w = _rand(B, Ci, M, seed=1), _rand(Ci, Co, M, seed=2)
+    y = torch.full((B, Co, M), float("nan"), dtype=torch.complex64)
+    kw = dict(P=B, Q=Co, R=Ci, n_modes=M, a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=Co * M, b_sq=M, b_sm=1,
+              c_sp=Co * M, c_sq=M, c_sm=1)
+    run(lib, x, w, y, flags=_lib.SC_GEMM_GRID(bpw), **kw)
+    ref = np.einsum("bim,iom->bom", x.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
+    assert rel_l2(y.numpy(), ref) < TOL
+    # and the generation-1 kernels on the same call agree
+    y1 = torch.zeros_like(y)
+    flags = _lib.SC_GEMM_NO_STREAM
+    run(lib, x, w, y1, flags=flags, expect=lib.modegemm_path(flags=flags, **kw), **kw)
+    assert rel_l2(y1.numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (32, 128, 128, 8), (30, 48, 70, 8)])
+def test_gx_conj_b_transposed(lib, dims):
+    """gxhat[b,i,m] = sum_o ghat[b,o,m] conj(W[i,o,m]): B operand read through transposed strides"""
+    B, Ci, Co, M = dims
+    g, w = _rand(B, Co, M, seed=3), _rand(Ci, Co, M, seed=4)
+    gx = torch.full((B, Ci, M), float("nan"), dtype=torch.complex64)
+    run(lib, g, w, gx, P=B, Q=Ci, R=Co, n_modes=M, a_sp=Co * M, a_sr=M, a_sm=1, b_sr=M, b_sq=Co * M, b_sm=1,
+        conj_b=1, c_sp=Ci * M, c_sq=M, c_sm=1)
+    ref = np.einsum("bom,iom->bim", g.numpy().astype(np.complex128), np.conj(w.numpy().astype(np.complex128)))
+    assert rel_l2(gx.numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (4, 128, 128, 8), (9, 56, 64, 8)])
+def test_gw_conj_a(lib, dims):
+    """gW[i,o,m] = sum_b conj(xhat[b,i,m]) ghat[b,o,m]: P = Ci (two row blocks at 64 -> both in one workgroup at
+    the metric shape's mode count), streaming stores"""
+    B, Ci, Co, M = dims
+    x, g = _rand(B, Ci, M, seed=5), _rand(B, Co, M, seed=6)
+    gw = torch.full((Ci, Co, M), float("nan"), dtype=torch.complex64)
+    run(lib, x, g, gw, flags=_lib.SC_GEMM_STREAM_C, P=Ci, Q=Co, R=B, n_modes=M, a_sp=M, a_sr=Ci * M, a_sm=1,
+        conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1, c_sp=Co * M, c_sq=M, c_sm=1)
+    ref = np.einsum("bim,bom->iom", np.conj(x.numpy().astype(np.complex128)), g.numpy().astype(np.complex128))
+    assert rel_l2(gw.numpy(), ref) < TOL
+
+
+def test_both_conjugates_and_padded_rows(lib):
+    """conj(A) conj(B) (no layer call uses it, the C-ABI offers it); operands embedded in wider rows (strides larger
+    than the extents, as a mode-sharded or padded caller would pass)"""
+    P, Q, R, M, MS = 32, 64, 10, 8, 24
+    a, b = _rand(P, R, MS, seed=7), _rand(R, Q, MS, seed=8)
+    c = torch.zeros(P, Q, MS, dtype=torch.complex64)
+    off = 8                                  # modes 8..15 of rows that hold 24
+    av, bv, cv = (torch.view_as_real(t).reshape(-1)[2 * off:] for t in (a, b, c))
+    kw = dict(P=P, Q=Q, R=R, n_modes=M, a_sp=R * MS, a_sr=MS, a_sm=1, b_sr=Q * MS, b_sq=MS, b_sm=1,
+              c_sp=Q * MS, c_sq=MS, c_sm=1, conj_a=1, conj_b=1)
+    assert lib.modegemm_path(**kw) == 2
+    lib.modegemm(av.data_ptr(), bv.data_ptr(), cv.data_ptr(), 0, **kw)
+    ref = np.einsum("prm,rqm->pqm", np.conj(a.numpy()[:, :, off:off + M].astype(np.complex128)),
+                    np.conj(b.numpy()[:, :, off:off + M].astype(np.complex128)))
+    assert rel_l2(c.numpy()[:, :, off:off + M], ref) < TOL
+    assert not c.numpy()[:, :, :off].any() and not c.numpy()[:, :, off + M:].any()      # nothing outside the block
+
+
+def test_eligibility(lib):
+    base = dict(P=32, Q=64, R=64, n_modes=2112, a_sp=64 * 2112, a_sr=2112, a_sm=1, b_sr=64 * 2112, b_sq=2112,
+                b_sm=1, c_sp=64 * 2112, c_sq=2112, c_sm=1)
+    assert lib.modegemm_path(**base) == 2
+    assert lib.modegemm_path(**dict(base, flags=_lib.SC_GEMM_NO_STREAM)) == 1
+    assert lib.modegemm_path(**dict(base, flags=_lib.SC_GEMM_FORCE_VALU)) == 0
+    assert lib.modegemm_path(**dict(base, n_modes=2110)) == 1            # not a multiple of 8
+    assert lib.modegemm_path(**dict(base, a_sr=2111)) == 1               # rows not 16-byte aligned
+    assert lib.modegemm_path(**dict(base, accumulate=1)) == 0
+    assert lib.modegemm_path(**dict(base, Q=36)) == 1                    # ragged Tucker rank: 64-row tiles of gen 1
+    assert lib.modegemm_path(**dict(base, P=4, Q=128)) == 0              # 4 rows: neither matrix-core kernel
+    assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4)) == 2       # hidden 128 weight gradient
