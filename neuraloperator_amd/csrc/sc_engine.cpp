@@ -1070,9 +1070,14 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   return sc_check_launch("k_modegemm_mfma");
 }
 
-// ---- streamed matrix-core path (sc_kernels_gemm8.h): plain contiguous-mode operands, 8 modes per workgroup ------
+// ---- streamed matrix-core path (sc_kernels_gemm8.h): plain contiguous-mode operands ------------------------------
+//   mode count % 16 == 0: 16 modes per workgroup (128-byte segments), 8 waves, 32 x 32 tiles, ring of 16 KiB stages
+//   mode count %  8 == 0:  8 modes per workgroup ( 64-byte segments), 4 waves, 32 x 64 tiles, ring of 12 KiB stages
 #ifndef SC_G8_DEPTH
-#define SC_G8_DEPTH 6          // ring stages of 12 KiB: 72 KiB of LDS -> two workgroups per CU
+#define SC_G8_DEPTH 4          // GS = 8: 64 KiB of LDS -> two workgroups per CU
+#endif
+#ifndef SC_G8_DEPTH4
+#define SC_G8_DEPTH4 6         // GS = 4: 72 KiB
 #endif
 static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
   if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM)) return false;
@@ -1082,33 +1087,52 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   // 16-byte granules: every row / column of every operand must start on an even complex element
   if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
-  // tiles are 32 rows x 64 columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as 36
-  // stay on the 64-row tiles of k_modegemm_mfma)
-  const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + 63) / 64 * 64;
+  // tiles are 32 rows x 32 (64) columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as
+  // 36 stay on the 64-row tiles of k_modegemm_mfma)
+#ifdef SC_G8_FORCE64
+  const int64_t cols = 64;
+#else
+  const int64_t cols = d->n_modes % 16 == 0 ? 32 : 64;
+#endif
+  const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + cols - 1) / cols * cols;
   if (4 * d->P < 3 * Pp || 4 * d->Q < 3 * Qp) return false;
   if (d->R < 4) return false;
-  if (Pp / 32 * (Qp / 64) * (d->n_modes / 8) >= ((int64_t)1 << 30)) return false;
+  if (Pp / 32 * (Qp / cols) * (d->n_modes / 8) >= ((int64_t)1 << 30)) return false;
   return true;
 }
 
-template <bool CA, bool CB>
+template <int GS, int QT, int D, bool CA, bool CB>
 static void launch_gemm8(const Gemm8Args& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  SC_LAUNCH((k_modegemm_s8<SC_G8_DEPTH, CA, CB>), dim3((unsigned)g.G), dim3(256), 0, st, g, A, B, C);
+  SC_LAUNCH((k_modegemm_dma<GS, QT, D, CA, CB>), dim3((unsigned)g.G), dim3((Gemm8Cfg<GS, QT>::THREADS)), 0, st, g, A,
+            B, C);
+}
+
+template <int GS, int QT, int D>
+static void dispatch_gemm8(const Gemm8Args& g, int ca, int cb, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  if (!ca && !cb) launch_gemm8<GS, QT, D, false, false>(g, A, B, C, st);
+  else if (ca && !cb) launch_gemm8<GS, QT, D, true, false>(g, A, B, C, st);
+  else if (!ca && cb) launch_gemm8<GS, QT, D, false, true>(g, A, B, C, st);
+  else launch_gemm8<GS, QT, D, true, true>(g, A, B, C, st);
 }
 
 static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+#ifdef SC_G8_FORCE64             // measurement builds only: 64-byte segments also where whole lines are possible
+  const bool wide = false;
+#else
+  const bool wide = d->n_modes % 16 == 0;                     // whole cache lines per segment
+#endif
+  const int64_t cols = wide ? 32 : 64, modes = wide ? 16 : 8;
   Gemm8Args g;
   g.P = (int)d->P; g.Q = (int)d->Q; g.R = (int)d->R;
-  g.n_mg = (int)(d->n_modes / 8);
+  g.n_mg = (int)(d->n_modes / modes);
   g.n_pb = (int)((d->P + 31) / 32);
-  g.n_qb = (int)((d->Q + 63) / 64);
+  g.n_qb = (int)((d->Q + cols - 1) / cols);
   g.a_sp = d->a_sp; g.a_sr = d->a_sr;
   g.b_sr = d->b_sr; g.b_sq = d->b_sq;
   g.c_sp = d->c_sp; g.c_sq = d->c_sq;
   g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
   // tiles per workgroup: a launch that would need between one and two rounds of the 512 resident workgroups (two
-  // per CU) runs its tiles back to back inside fewer workgroups instead of queueing a short second round; the
-  // grid is a multiple of 8 whenever possible so that the XCD-aware unit mapping applies
+  // per CU) runs its tiles back to back inside fewer workgroups instead of queueing a short second round
   const int64_t nblk = (int64_t)g.n_pb * g.n_qb;
   int64_t bpw = 1;
   if (g.n_mg <= 512 && g.n_mg * nblk > 512) {
@@ -1123,11 +1147,9 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   if (cap > 0 && cap <= nblk) bpw = cap;
   g.bpw = (int)bpw;
   g.G = (int)(g.n_mg * ((nblk + bpw - 1) / bpw));
-  if (!d->conj_a && !d->conj_b) launch_gemm8<false, false>(g, A, B, C, st);
-  else if (d->conj_a && !d->conj_b) launch_gemm8<true, false>(g, A, B, C, st);
-  else if (!d->conj_a && d->conj_b) launch_gemm8<false, true>(g, A, B, C, st);
-  else launch_gemm8<true, true>(g, A, B, C, st);
-  return sc_check_launch("k_modegemm_s8");
+  if (wide) dispatch_gemm8<8, 2, SC_G8_DEPTH>(g, d->conj_a, d->conj_b, A, B, C, st);
+  else dispatch_gemm8<4, 4, SC_G8_DEPTH4>(g, d->conj_a, d->conj_b, A, B, C, st);
+  return sc_check_launch("k_modegemm_dma");
 }
 
 extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,

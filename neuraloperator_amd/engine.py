@@ -443,3 +443,104 @@ class EngineOps:
     def inverse_axis(self, xhat, n, rows):
         return TransformInverseFn.apply(xhat, None, [int(n)], self.fft_norm, self.flags | SC_PLAN_COMPLEX,
                                         [list(rows)], 0)
+
+
+class EngineRawOps:
+    """The local stages of a spectral layer and their adjoints as plain calls (no autograd): what a hand-scheduled
+    pipeline (mpu.ModeParallelSpectralConv: transform chunk j+1 while chunk j is on the wire) is built from.
+    ``out`` = a contiguous slice of a preallocated result the call writes into (no concatenation copies of the
+    0.5 GB real tensors).  Real data, unchanged grid."""
+
+    def __init__(self, fft_norm="forward", flags=0):
+        self.fft_norm, self.flags = fft_norm, flags
+
+    def _plan(self, dev, spatial, kept):
+        return get_plan(dev, spatial, kept, self.fft_norm, self.flags)
+
+    @staticmethod
+    def _out(out, shape, dev):
+        if out is None:
+            return torch.empty(shape, dtype=torch.float32, device=dev)
+        if tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError(f"out must be a contiguous float32 tensor of shape {tuple(shape)}")
+        return out
+
+    def fwd(self, x, kept):                                   # SC_FWD_SCALED
+        _require_gpu(x)
+        lib = _lib.get_lib()
+        x = x.contiguous().float()
+        n, c = x.shape[:2]
+        plan = self._plan(x.device, list(x.shape[2:]), kept)
+        with torch.cuda.device(x.device):
+            ws = _ws(lib.plan_workspace_bytes(plan, n * c), x.device)
+            xh = torch.empty((n, c, *kept, 2), dtype=torch.float32, device=x.device)
+            lib.transform_forward(plan, _lib.SC_FWD_SCALED, x.data_ptr(), xh.data_ptr(), n * c, ws.data_ptr(), _stream())
+        return torch.view_as_complex(xh)
+
+    def fwd_adjoint(self, gxhat, spatial, out=None):          # SC_INV_ADJ_R2C
+        lib = _lib.get_lib()
+        g = _cview(gxhat)
+        n, c = g.shape[:2]
+        kept = list(g.shape[2:-1])
+        plan = self._plan(g.device, list(spatial), kept)
+        with torch.cuda.device(g.device):
+            gx = self._out(out, (n, c, *spatial), g.device)
+            ws = _ws(lib.plan_workspace_bytes(plan, n * c), g.device)
+            lib.transform_inverse(plan, _lib.SC_INV_ADJ_R2C, g.data_ptr(), 0, c, gx.data_ptr(), n * c, ws.data_ptr(),
+                                  _stream())
+        return gx
+
+    def inv(self, yhat, bias, spatial, out=None):             # SC_INV_PADDED (+ bias)
+        lib = _lib.get_lib()
+        yh = _cview(yhat)
+        n, c = yh.shape[:2]
+        kept = list(yh.shape[2:-1])
+        plan = self._plan(yh.device, list(spatial), kept)
+        with torch.cuda.device(yh.device):
+            y = self._out(out, (n, c, *spatial), yh.device)
+            ws = _ws(lib.plan_workspace_bytes(plan, n * c), yh.device)
+            bflat = None if bias is None else bias.detach().reshape(-1).float().contiguous()
+            lib.transform_inverse(plan, _lib.SC_INV_PADDED, yh.data_ptr(), 0 if bflat is None else bflat.data_ptr(), c,
+                                  y.data_ptr(), n * c, ws.data_ptr(), _stream())
+        return y
+
+    def inv_adjoint(self, gy, kept, want_bias=False):         # SC_FWD_ADJ_C2R (+ bias gradient off the DC row)
+        lib = _lib.get_lib()
+        gy = gy.contiguous().float()
+        n, c = gy.shape[:2]
+        plan = self._plan(gy.device, list(gy.shape[2:]), kept)
+        with torch.cuda.device(gy.device):
+            ws = _ws(lib.plan_workspace_bytes(plan, n * c), gy.device)
+            gh = torch.empty((n, c, *kept, 2), dtype=torch.float32, device=gy.device)
+            lib.transform_forward(plan, _lib.SC_FWD_ADJ_C2R, gy.data_ptr(), gh.data_ptr(), n * c, ws.data_ptr(), _stream())
+            gb = None
+            if want_bias:
+                gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+                lib.bias_grad(plan, gh.data_ptr(), n, c, gb.data_ptr(), _stream())
+        return torch.view_as_complex(gh), gb
+
+    @staticmethod
+    def contract(xhat, w):
+        b, ci = xhat.shape[:2]
+        co = w.shape[1]
+        mk = xhat[0, 0].numel()
+        yhat = torch.empty((b, co, *xhat.shape[2:]), dtype=torch.complex64, device=xhat.device)
+        modegemm(xhat, w, P=b, Q=co, R=ci, n_modes=mk, a_strides=(ci * mk, mk, 1), b_strides=(co * mk, mk, 1),
+                 out=yhat, c_strides=(co * mk, mk, 1))
+        return yhat
+
+    @staticmethod
+    def contract_bwd(xhat, w, ghat, need_x=True, need_w=True):
+        b, ci = xhat.shape[:2]
+        co = w.shape[1]
+        mk = xhat[0, 0].numel()
+        gx = gw = None
+        if need_x:
+            gx = torch.empty_like(xhat)
+            modegemm(ghat, w, P=b, Q=ci, R=co, n_modes=mk, a_strides=(co * mk, mk, 1), b_strides=(mk, co * mk, 1),
+                     conj_b=True, out=gx, c_strides=(ci * mk, mk, 1))
+        if need_w:
+            gw = torch.empty_like(w)
+            modegemm(xhat, ghat, P=ci, Q=co, R=b, n_modes=mk, a_strides=(mk, ci * mk, 1), conj_a=True,
+                     b_strides=(co * mk, mk, 1), out=gw, c_strides=(co * mk, mk, 1))
+        return gx, gw

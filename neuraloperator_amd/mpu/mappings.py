@@ -17,23 +17,41 @@ def _size(group):
     return dist.get_world_size(group=group) if dist.is_initialized() else 1
 
 
+# traffic counter (bench.py reports it): payload bytes this rank has handed to all_to_all_single
+A2A_STATS = {"calls": 0, "bytes": 0}
+
+
+def _a2a_issue(x, split_dim, group):
+    """Start the exchange of ``x`` split into P chunks along split_dim (chunk p goes to rank p).  Returns
+    (recv, work, send): recv is [P, *chunk shape] (real view of complex data), rank-major, valid once work is waited
+    for.  ONE copy at most: the send buffer is the chunk-major permutation of x (a view when split_dim == 0)."""
+    p = _size(group)
+    if x.shape[split_dim] % p != 0:
+        raise ValueError(f"dim {split_dim} of size {x.shape[split_dim]} not divisible by {p} ranks")
+    xr = torch.view_as_real(x) if x.is_complex() else x
+    send = xr.unflatten(split_dim, (p, xr.shape[split_dim] // p)).movedim(split_dim, 0).contiguous()
+    recv = torch.empty_like(send)
+    work = dist.all_to_all_single(recv, send, group=group, async_op=True)
+    A2A_STATS["calls"] += 1
+    A2A_STATS["bytes"] += send.numel() * send.element_size()
+    return recv, work, send
+
+
+def _a2a_finish(recv, cat_dim, is_complex):
+    """[P, chunk...] -> the chunks concatenated along cat_dim in rank order (a view when cat_dim == 0)."""
+    out = recv.movedim(0, cat_dim).flatten(cat_dim, cat_dim + 1)
+    out = out.contiguous()
+    return torch.view_as_complex(out) if is_complex else out
+
+
 def _all_to_all(x, split_dim, cat_dim, group):
     """Split ``x`` into P chunks along split_dim, send chunk p to rank p, concatenate what
     arrives (in rank order) along cat_dim."""
-    p = _size(group)
-    if p == 1:
+    if _size(group) == 1:
         return x
-    if x.shape[split_dim] % p != 0:
-        raise ValueError(f"dim {split_dim} of size {x.shape[split_dim]} not divisible by {p} ranks")
-    is_c = x.is_complex()
-    xr = torch.view_as_real(x) if is_c else x
-    # [P][..chunk..] contiguous send buffer
-    chunks = xr.chunk(p, dim=split_dim)
-    send = torch.stack(chunks, dim=0).contiguous()
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    out = torch.cat(list(recv.unbind(0)), dim=cat_dim)
-    return torch.view_as_complex(out.contiguous()) if is_c else out
+    recv, work, _send = _a2a_issue(x, split_dim, group)
+    work.wait()
+    return _a2a_finish(recv, cat_dim, x.is_complex())
 
 
 class _AllToAll(torch.autograd.Function):

@@ -5,33 +5,209 @@ no mode-parallel conv, its ``_transpose`` all-to-all helper, mpu/helpers.py:81-9
 code).  Layout per rank p of P:
 
     activations   batch-sharded   x_p   (B/P, Cin, d1..dN)            (like data parallel)
-    weights       mode-sharded    W_p   (Cin, Cout, k1/P, k2..kN)     rows [p*k1/P, (p+1)*k1/P)
+    weights       mode-sharded    W_p   (Cin, Cout, rows, k2..kN)     rows [p*rows, (p+1)*rows), rows = ceil(k1/P)
 
     x_p --pruned rFFT--> xhat_p (B/P, Cin, k1, ..) --all-to-all(split k1, cat batch)-->
-    (B, Cin, k1/P, ..) --contract with W_p--> (B, Cout, k1/P, ..)
+    (B, Cin, rows, ..) --contract with W_p--> (B, Cout, rows, ..)
     --all-to-all(split batch, cat k1)--> (B/P, Cout, k1, ..) --zero-padded inverse--> y_p
 
 Each rank sees the whole batch for its modes, so gW needs NO all-reduce (a dense layer's
 69 MB weight gradient would be ring-bound on xGMI); the bias is replicated and its gradient
 is summed over the group.  The backward is the same pipeline mirrored (2 more all-to-alls).
+
+One autograd Function runs the whole pipeline (``_ModeParallelFn``) so that the exchange can be scheduled by hand:
+the local batch (or, for one sample per rank, the channels) is cut into a few chunks, chunk j's all-to-all is
+enqueued (RCCL runs it on the process group's own stream) as soon as its transform is launched, and the
+transform of chunk j+1 runs meanwhile; on the way back every chunk's inverse transform starts when ITS exchange
+has landed.  Per exchange one S-sized copy (the chunk-major send permutation one way, the mode-major receive
+permutation the other); the R-sized real tensors are written in place (``out=`` slices).  When k1 is not a
+multiple of P the mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
 """
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from ..modes import halve_last_mode, kept_block
 from ..spectral_conv import BaseSpectralConv
 from . import comm
-from .mappings import all_to_all
+from .mappings import A2A_STATS
+
+
+def _bounds(ext, n):
+    return [((ext * i) // n, (ext * (i + 1)) // n) for i in range(n)]
+
+
+class _Exchange:
+    """the two all-to-alls of one direction of the pipeline, chunk by chunk (plain tensors, no autograd)"""
+
+    def __init__(self, group, P, rows, k1):
+        self.group, self.P, self.rows, self.k1 = group, P, rows, k1
+
+    def _a2a(self, recv, send):
+        A2A_STATS["calls"] += 1
+        A2A_STATS["bytes"] += send.numel() * send.element_size()
+        return dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+
+    # (n, C, k1, rest) complex  ->  this rank's rows of every rank's chunk: recv [P, n, C, rows, rest, 2]
+    def modes_out(self, xh, recv):
+        P, rows, k1 = self.P, self.rows, self.k1
+        xr = torch.view_as_real(xh)
+        n, c = xr.shape[:2]
+        if rows * P == k1:
+            send = xr.unflatten(2, (P, rows)).movedim(2, 0).contiguous()
+        else:                                           # zero-padded rows on the wire
+            send = xr.new_zeros((P, n, c, rows, *xr.shape[3:]))
+            for p in range(P):
+                r = min(rows, k1 - p * rows)
+                if r > 0:
+                    send[p, :, :, :r] = xr[:, :, p * rows:p * rows + r]
+        return self._a2a(recv, send), send
+
+    # send [P, n, C, rows, rest, 2] (rank-major rows of the contraction result) -> recv of the same shape
+    def batch_out(self, send, recv):
+        return self._a2a(recv, send), send
+
+    # recv [P, n, C, rows, rest, 2] -> (n, C, k1, rest) complex
+    def modes_in(self, recv):
+        out = recv.movedim(0, 2).flatten(2, 3)
+        if self.rows * self.P != self.k1:
+            out = out[:, :, :self.k1]
+        return torch.view_as_complex(out.contiguous())
+
+
+class _ModeParallelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        ops, P, rows = layer.ops, layer.P, layer.rows
+        spatial = list(x.shape[2:])
+        kept = list(layer._n_modes)
+        b, ci = x.shape[:2]
+        co = weight.shape[1]
+        rest = kept[1:]
+        w = weight.detach().contiguous()
+        ex = _Exchange(layer._group(), P, rows, kept[0])
+        by_batch = b >= 2 or P == 1
+        chunks = _bounds(b, min(layer.comm_chunks, b)) if by_batch else _bounds(ci, min(layer.comm_chunks, ci))
+        ctx.cfg = (layer, spatial, kept, b, ci, co, by_batch)
+        dev = x.device
+
+        # ---- forward transform + exchange (split modes, cat batch)
+        xd = x.detach()
+        if by_batch:
+            xhat_all = torch.empty((P * b, ci, rows, *rest, 2), dtype=torch.float32, device=dev)
+        else:
+            xhat_all = torch.empty((P, ci, rows, *rest, 2), dtype=torch.float32, device=dev)
+        pend = []
+        for (c0, c1) in chunks:
+            xh = ops.fwd(xd[c0:c1] if by_batch else xd[:, c0:c1], kept)
+            if by_batch:
+                recv = xhat_all[P * c0:P * c1].view(P, c1 - c0, ci, rows, *rest, 2)
+            else:
+                recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
+            pend.append((ex.modes_out(xh, recv), recv, c0, c1))
+        for (work, _send), recv, c0, c1 in pend:
+            work.wait()
+            if not by_batch:
+                xhat_all[:, c0:c1] = recv[:, 0]
+        xhat_all = torch.view_as_complex(xhat_all)
+
+        # ---- contraction on this rank's mode rows, whole batch
+        yhat_all = ops.contract(xhat_all, w).contiguous()
+
+        # ---- exchange back (split batch, cat modes) + zero-padded inverse
+        y = torch.empty((b, co, *spatial), dtype=torch.float32, device=dev)
+        yr = torch.view_as_real(yhat_all)
+        ochunks = chunks if by_batch else _bounds(co, min(layer.comm_chunks, co))
+        pend = []
+        for (c0, c1) in ochunks:
+            if by_batch:
+                send = yr[P * c0:P * c1].view(P, c1 - c0, co, rows, *rest, 2)
+            else:
+                send = yr[:, c0:c1].contiguous().view(P, 1, c1 - c0, rows, *rest, 2)
+            recv = torch.empty_like(send)
+            pend.append((ex.batch_out(send, recv), recv, c0, c1))
+        bflat = None if bias is None else bias.detach().reshape(-1)
+        for (work, _send), recv, c0, c1 in pend:
+            work.wait()
+            yh = ex.modes_in(recv)
+            if by_batch:
+                ops.inv(yh, bflat, spatial, out=y[c0:c1])
+            else:
+                ops.inv(yh, None if bflat is None else bflat[c0:c1], spatial, out=y[:, c0:c1])
+        ctx.save_for_backward(xhat_all, w)
+        ctx.has_bias = bias is not None
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        layer, spatial, kept, b, ci, co, by_batch = ctx.cfg
+        ops, P, rows = layer.ops, layer.P, layer.rows
+        xhat_all, w = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        rest = kept[1:]
+        ex = _Exchange(layer._group(), P, rows, kept[0])
+        dev = gy.device
+        gy = gy.contiguous()
+        chunks = _bounds(b, min(layer.comm_chunks, b)) if by_batch else _bounds(co, min(layer.comm_chunks, co))
+
+        # ---- adjoint of the inverse transform (+ bias gradient) + exchange (split modes, cat batch)
+        if by_batch:
+            ghat_all = torch.empty((P * b, co, rows, *rest, 2), dtype=torch.float32, device=dev)
+        else:
+            ghat_all = torch.empty((P, co, rows, *rest, 2), dtype=torch.float32, device=dev)
+        want_b = need_b and ctx.has_bias
+        gb_parts, pend = [], []
+        for (c0, c1) in chunks:
+            gh, gb = ops.inv_adjoint(gy[c0:c1] if by_batch else gy[:, c0:c1], kept, want_bias=want_b)
+            gb_parts.append(gb)
+            if by_batch:
+                recv = ghat_all[P * c0:P * c1].view(P, c1 - c0, co, rows, *rest, 2)
+            else:
+                recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
+            pend.append((ex.modes_out(gh, recv), recv, c0, c1))
+        for (work, _send), recv, c0, c1 in pend:
+            work.wait()
+            if not by_batch:
+                ghat_all[:, c0:c1] = recv[:, 0]
+        ghat_all = torch.view_as_complex(ghat_all)
+        gbias = None
+        if want_b:
+            gbias = (torch.stack(gb_parts).sum(0) if by_batch else torch.cat(gb_parts)).reshape(ctx.bias_shape)
+
+        # ---- the two gradient contractions on this rank's mode rows (gW is complete: no all-reduce)
+        gxhat_all, gw = ops.contract_bwd(xhat_all, w, ghat_all, need_x, need_w)
+
+        # ---- exchange back + adjoint of the forward transform
+        gx = None
+        if need_x:
+            gx = torch.empty((b, ci, *spatial), dtype=torch.float32, device=dev)
+            gr = torch.view_as_real(gxhat_all.contiguous())
+            ichunks = chunks if by_batch else _bounds(ci, min(layer.comm_chunks, ci))
+            pend = []
+            for (c0, c1) in ichunks:
+                if by_batch:
+                    send = gr[P * c0:P * c1].view(P, c1 - c0, ci, rows, *rest, 2)
+                else:
+                    send = gr[:, c0:c1].contiguous().view(P, 1, c1 - c0, rows, *rest, 2)
+                recv = torch.empty_like(send)
+                pend.append((ex.batch_out(send, recv), recv, c0, c1))
+            for (work, _send), recv, c0, c1 in pend:
+                work.wait()
+                gxh = ex.modes_in(recv)
+                ops.fwd_adjoint(gxh, spatial, out=gx[c0:c1] if by_batch else gx[:, c0:c1])
+        return gx, gw, gbias, None
 
 
 class ModeParallelSpectralConv(BaseSpectralConv):
     """Dense-weight SpectralConv whose first mode dim is sharded across the model-parallel group.
 
     Constructor arguments follow SpectralConv; ``n_modes`` is fixed at construction (the
-    shard layout depends on it).  ``ops`` (tests only) replaces the three local stages."""
+    shard layout depends on it).  ``ops`` (tests only) replaces the local stages (an object with the
+    interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in."""
 
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
-                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, **unused):
+                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=4, **unused):
         super().__init__(device=device)
         for k in ("complex_data", "separable"):
             if unused.get(k):
@@ -46,23 +222,29 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             raise NotImplementedError("mode sharding needs >= 2 spatial dims (dim 0 is sharded)")
         self.fft_norm = fft_norm
         self.group = group
-        self.P = comm.get_model_parallel_size() if group is None else torch.distributed.get_world_size(group)
-        self.rank = comm.get_model_parallel_rank() if group is None else torch.distributed.get_rank(group)
-        if self._n_modes[0] % self.P != 0:
-            raise ValueError(f"n_modes[0]={self._n_modes[0]} must be divisible by the {self.P} model-parallel ranks")
+        self.comm_chunks = max(1, int(comm_chunks))
+        self.P = comm.get_model_parallel_size() if group is None else dist.get_world_size(group)
+        self.rank = comm.get_model_parallel_rank() if group is None else dist.get_rank(group)
+        # rows of the first mode dim per rank; k1 not divisible by P: the last rank(s) carry zero rows
+        self.rows = -(-self._n_modes[0] // self.P)
         if init_std == "auto":
             init_std = (2 / (in_channels + out_channels)) ** 0.5
-        rows = self._n_modes[0] // self.P
-        w = torch.empty(in_channels, out_channels, rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
+        w = torch.empty(in_channels, out_channels, self.rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
         w.normal_(0, init_std)
+        live = min(self.rows, max(0, self._n_modes[0] - self.rank * self.rows))
+        with torch.no_grad():
+            w[:, :, live:] = 0
         self.weight = nn.Parameter(w)
         self.weight.mode_sharded = True          # exclude from data-parallel all-reduce within the group
         self.bias = nn.Parameter(init_std * torch.randn(out_channels, *(1,) * self.order, device=device)) \
             if bias else None
         if ops is None:
-            from ..engine import EngineOps
-            ops = EngineOps(fft_norm, engine_flags)
+            from ..engine import EngineRawOps
+            ops = EngineRawOps(fft_norm, engine_flags)
         self.ops = ops
+
+    def _group(self):
+        return self.group if self.group is not None else comm.get_model_parallel_group()
 
     @property
     def n_modes(self):
@@ -84,22 +266,55 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         kept, _ = kept_block(spatial, self._n_modes, self.max_n_modes)
         if kept != list(self._n_modes):
             raise ValueError(f"grid {spatial} is too small for n_modes {self._n_modes} in the mode-parallel layer")
-        xhat = self.ops.forward_transform(x, kept)                    # (B/P, Cin, k1, ..)
-        xhat = all_to_all(xhat, split_dim=2, cat_dim=0, group=self.group)   # (B, Cin, k1/P, ..)
-        yhat = self.ops.contract(xhat, self.weight)                   # (B, Cout, k1/P, ..)
-        yhat = all_to_all(yhat, split_dim=0, cat_dim=2, group=self.group)   # (B/P, Cout, k1, ..)
-        return self.ops.inverse_transform(yhat, self.bias, spatial)
+        if x.shape[1] != self.in_channels:
+            raise ValueError(f"input has {x.shape[1]} channels, the layer expects {self.in_channels}")
+        if self.P == 1 and not dist.is_initialized():
+            return _single_rank(self, x, spatial)
+        return _ModeParallelFn.apply(x, self.weight, self.bias, self)
 
     # ---- helpers for the training loop -----------------------------------------------------------
     def reduce_replicated_grads(self):
         """Sum the gradients of the replicated parameters (bias) over the model-parallel group
         (every rank saw a different batch shard).  The sharded weight needs nothing."""
         if self.P > 1 and self.bias is not None and self.bias.grad is not None:
-            torch.distributed.all_reduce(self.bias.grad, group=self.group if self.group is not None
-                                         else comm.get_model_parallel_group())
+            dist.all_reduce(self.bias.grad, group=self._group())
 
     @staticmethod
     def shard_dense_weight(full_weight, rank, world):
-        """Rows of a full (Cin, Cout, k1, ..) weight that rank ``rank`` owns."""
-        rows = full_weight.shape[2] // world
-        return full_weight[:, :, rank * rows:(rank + 1) * rows].contiguous()
+        """Rows of a full (Cin, Cout, k1, ..) weight that rank ``rank`` owns (zero rows past k1)."""
+        k1 = full_weight.shape[2]
+        rows = -(-k1 // world)
+        out = full_weight.new_zeros((*full_weight.shape[:2], rows, *full_weight.shape[3:]))
+        live = min(rows, max(0, k1 - rank * rows))
+        if live > 0:
+            out[:, :, :live] = full_weight[:, :, rank * rows:rank * rows + live]
+        return out
+
+
+class _SingleRankFn(torch.autograd.Function):
+    """P = 1 without a process group: the same stages, nothing on the wire"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        ops = layer.ops
+        spatial, kept = list(x.shape[2:]), list(layer._n_modes)
+        w = weight.detach().contiguous()
+        xhat = ops.fwd(x.detach(), kept)
+        y = ops.inv(ops.contract(xhat, w), None if bias is None else bias.detach().reshape(-1), spatial)
+        ctx.save_for_backward(xhat, w)
+        ctx.cfg = (layer, spatial, kept, None if bias is None else tuple(bias.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        layer, spatial, kept, bshape = ctx.cfg
+        xhat, w = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        gh, gb = layer.ops.inv_adjoint(gy.contiguous(), kept, want_bias=need_b and bshape is not None)
+        gxh, gw = layer.ops.contract_bwd(xhat, w, gh, need_x, need_w)
+        gx = layer.ops.fwd_adjoint(gxh, spatial) if need_x else None
+        return gx, gw, None if gb is None else gb.reshape(bshape), None
+
+
+def _single_rank(layer, x, spatial):
+    return _SingleRankFn.apply(x, layer.weight, layer.bias, layer)

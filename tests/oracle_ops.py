@@ -52,3 +52,48 @@ class OracleOps:
         ix = torch.as_tensor(list(rows))
         z = torch.zeros(*xhat.shape[:-1], n, dtype=xhat.dtype)
         return torch.fft.ifft(z.index_add(-1, ix, xhat), dim=-1, norm="forward")
+
+
+class OracleRawOps:
+    """The interface of neuraloperator_amd.engine.EngineRawOps (plain calls: the stages and their adjoints, ``out=``
+    slices) on the CPU: the stages are OracleOps', every adjoint is torch autograd's vector-Jacobian product of the
+    corresponding (linear) stage.  Injected into mpu.ModeParallelSpectralConv by the gloo tests."""
+
+    def __init__(self, n_modes_attr):
+        self.o = OracleOps(n_modes_attr)
+
+    @staticmethod
+    def _ret(val, out):
+        if out is None:
+            return val
+        assert out.is_contiguous() and tuple(out.shape) == tuple(val.shape)
+        out.copy_(val)
+        return out
+
+    def fwd(self, x, kept):
+        return self.o.forward_transform(x, kept)
+
+    def fwd_adjoint(self, gxhat, spatial, out=None):
+        n, c = gxhat.shape[:2]
+        x0 = torch.zeros(n, c, *spatial, requires_grad=True)
+        (gx,) = torch.autograd.grad(self.o.forward_transform(x0, list(gxhat.shape[2:])), x0, gxhat)
+        return self._ret(gx, out)
+
+    def inv(self, yhat, bias, spatial, out=None):
+        b = None if bias is None else bias.reshape(-1, *(1,) * len(spatial))
+        return self._ret(self.o.inverse_transform(yhat, b, spatial), out)
+
+    def inv_adjoint(self, gy, kept, want_bias=False):
+        n, c = gy.shape[:2]
+        z0 = torch.zeros(n, c, *kept, dtype=torch.cfloat, requires_grad=True)
+        (gh,) = torch.autograd.grad(self.o.inverse_transform(z0, None, list(gy.shape[2:])), z0, gy)
+        gb = gy.sum(dim=[0] + list(range(2, gy.ndim))) if want_bias else None
+        return gh, gb
+
+    def contract(self, xhat, w):
+        return so.contract_dense(xhat, w)
+
+    def contract_bwd(self, xhat, w, ghat, need_x=True, need_w=True):
+        xr, wr = xhat.detach().requires_grad_(True), w.detach().requires_grad_(True)
+        gx, gw = torch.autograd.grad(so.contract_dense(xr, wr), (xr, wr), ghat)
+        return (gx if need_x else None), (gw if need_w else None)

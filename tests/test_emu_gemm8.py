@@ -1,4 +1,4 @@
-"""CPU tier: the LDS-DMA streamed matrix-core mode GEMM (sc_kernels_gemm8.h, k_modegemm_s8) in host emulation --
+"""CPU tier: the LDS-DMA streamed matrix-core mode GEMM (sc_kernels_gemm8.h, k_modegemm_dma) in host emulation --
 MFMA replaced by its documented lane / register map, LDS-DMA by a synchronous copy; unit decoding, the source-side
 bank swizzle, ring rotation, operand sign masks, the patch epilogue and the clamping of ragged rows / columns / r
 are the product source -- against a numpy complex128 einsum.  Covers the layer's three contractions (forward, gX
@@ -40,6 +40,12 @@ FWD = [
     (64, 16, 128, 8, 0),     # 2 row blocks x 2 column blocks, one tile per workgroup
     (64, 16, 128, 8, 4),     # ... all four tiles in one workgroup, back to back
     (56, 12, 64, 24, 2),     # second row block ragged (24 of 32 rows), two tiles per workgroup, 3 mode groups
+    # mode counts that are multiples of 16: 128-byte segments, 8 waves, 32 x 32 tiles
+    (32, 64, 64, 32, 0),     # the metric tile: two mode groups x two column blocks
+    (28, 7, 52, 16, 0),      # ragged rows / columns (second column block 20 of 32), odd r
+    (64, 16, 128, 16, 0),    # 2 row blocks x 4 column blocks
+    (64, 16, 128, 16, 8),    # ... all eight tiles in one workgroup
+    (56, 12, 64, 48, 2),     # ragged second row block, two tiles per workgroup, 3 mode groups
 ]
 
 
@@ -60,7 +66,7 @@ def test_forward(lib, case):
     assert rel_l2(y1.numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (32, 128, 128, 8), (30, 48, 70, 8)])
+@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (32, 128, 128, 8), (30, 48, 70, 8), (32, 128, 128, 16), (30, 48, 70, 32)])
 def test_gx_conj_b_transposed(lib, dims):
     """gxhat[b,i,m] = sum_o ghat[b,o,m] conj(W[i,o,m]): B operand read through transposed strides"""
     B, Ci, Co, M = dims
@@ -72,7 +78,7 @@ def test_gx_conj_b_transposed(lib, dims):
     assert rel_l2(gx.numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (4, 128, 128, 8), (9, 56, 64, 8)])
+@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (4, 128, 128, 8), (9, 56, 64, 8), (4, 128, 128, 16), (9, 56, 64, 32)])
 def test_gw_conj_a(lib, dims):
     """gW[i,o,m] = sum_b conj(xhat[b,i,m]) ghat[b,o,m]: P = Ci (two row blocks at 64 -> both in one workgroup at
     the metric shape's mode count), streaming stores"""

@@ -25,31 +25,30 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, spatial, modes, ret):
+def _worker(rank, world, port, spatial, modes, ret, bl=2, chunks=4):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     from neuraloperator_amd.modes import halve_last_mode
     from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
     from oracle import spectral_oracle as so
-    from oracle_ops import OracleOps
+    from oracle_ops import OracleRawOps
 
     comm.init(model_parallel_size=world, backend="gloo")
     assert comm.get_model_parallel_size() == world and comm.get_model_parallel_rank() == rank
     assert comm.get_data_parallel_size() == 1
     nm = halve_last_mode(modes)
-    B, ci, co = 2 * world, 3, 4
+    B, ci, co = bl * world, 3, 4
     torch.manual_seed(0)                      # identical full tensors on every rank
     x = torch.randn(B, ci, *spatial)
     g = torch.randn(B, co, *spatial)
     w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
     bias = torch.randn(co, *(1,) * len(spatial))
 
-    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleOps(nm))
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=chunks)
     with torch.no_grad():
         conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, rank, world))
         conv.bias.copy_(bias)
-    bl = B // world
     xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
     y = conv(xs)
     y.backward(g[rank * bl:(rank + 1) * bl])
@@ -58,24 +57,31 @@ def _worker(rank, world, port, spatial, modes, ret):
     xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     yf = so.forward_torch(xf, wf, bf, nm, nm)
     yf.backward(g)
-    rows = nm[0] // world
+    rows = -(-nm[0] // world)                 # the last rank's shard may end in zero-padding rows
+    live = min(rows, nm[0] - rank * rows)
+    assert not conv.weight.grad[:, :, live:].abs().max() > 0 if live < rows else True
     errs = dict(
         y=so.rel_l2(y.detach().numpy(), yf.detach()[rank * bl:(rank + 1) * bl].numpy()),
         gx=so.rel_l2(xs.grad.numpy(), xf.grad[rank * bl:(rank + 1) * bl].numpy()),
-        gw=so.rel_l2(conv.weight.grad.numpy(), wf.grad[:, :, rank * rows:(rank + 1) * rows].numpy()),
+        gw=so.rel_l2(conv.weight.grad[:, :, :live].numpy(), wf.grad[:, :, rank * rows:rank * rows + live].numpy()),
         gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()),
     )
     ret[rank] = errs
     comm.cleanup()
 
 
-@pytest.mark.parametrize("spatial,modes", [((16, 12), (8, 6)), ((8, 8, 6), (4, 4, 4))])
-def test_mode_parallel_matches_single_process(spatial, modes):
+@pytest.mark.parametrize("spatial,modes,bl,chunks", [
+    ((16, 12), (8, 6), 2, 4),          # even split, the local batch pipelined in two chunks
+    ((8, 8, 6), (4, 4, 4), 2, 1),      # 3-d, one exchange per direction
+    ((16, 12), (5, 6), 3, 2),          # 5 mode rows over 2 ranks: zero-padded rows on the wire, ragged batch chunks
+    ((16, 12), (7, 6), 1, 2),          # one sample per rank: the exchange is pipelined over channel chunks
+])
+def test_mode_parallel_matches_single_process(spatial, modes, bl, chunks):
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, spatial, modes, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, spatial, modes, ret, bl, chunks), nprocs=world, join=True)
     assert len(ret) == world
     for rank, errs in ret.items():
         for k, v in errs.items():
@@ -146,7 +152,7 @@ def _hybrid_worker(rank, world, port, ret):
     g = torch.randn(B, co, *spatial)
     w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
     bias = torch.randn(co, 1, 1)
-    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleOps(nm))
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=chunks)
     with torch.no_grad():
         conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, mp_rank, mp_size))
         conv.bias.copy_(bias)
