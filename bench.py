@@ -6,10 +6,13 @@
 
 A "step" = one forward + backward of ONE SpectralConv layer (grads for x, W, bias) over one
 batch of synthetic fields already resident in HBM.  Default workload = BASELINE configs[1]:
-B=32, C=64, 256x256, n_modes=(64,64) -> kept 64x33, fp32.  With N > 1 every rank runs the
-same per-GPU batch (data-parallel replicas, weak scaling; the layer itself has no
-cross-rank exchange in that mode) unless --parallel modeshard is given, which runs the
-mode-parallel layer (RCCL all-to-all, neuraloperator_amd/mpu).
+B=32, C=64, 256x256, n_modes=(64,64) -> kept 64x33, fp32.  With N > 1 the default is the MODE-PARALLEL layer
+(neuraloperator_amd/mpu: activations batch-sharded, B=32 per GPU -> weak scaling; weights sharded over the first
+mode dim; RCCL all-to-all each way, pipelined in chunks) on the same workload, so that `value` measures the same
+metric at every N; the line also carries `extra.dp_allreduce` (data-parallel replicas WITH the gradient
+all-reduce of the 69 MB dense weight, what mode sharding avoids) and `extra.fno3d_modeshard` (BASELINE
+configs[3]: 128^3, B=8 in total, strong scaling; its single-GPU number is `extra.fno3d_single` of the N=1 line).
+--parallel replicas | modeshard | pencil selects one explicitly.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
 kernel, timed live with events on the launch stream) and, at N=1, `cpu_baseline` (the
@@ -47,10 +50,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fno2d_256_m64_c64_b32", choices=sorted(WORKLOADS))
-    ap.add_argument("--parallel", default="replicas", choices=["replicas", "modeshard", "pencil"],
-                    help="N > 1: replicas = data-parallel copies (default, no data-path collective); modeshard = "
-                         "mode-parallel layer (batch-sharded activations); pencil = spatially decomposed layer "
-                         "(every sample spans all ranks: rows of the first grid dim sharded)")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "modeshard", "pencil"],
+                    help="N > 1: auto = modeshard; replicas = data-parallel copies with the gradient all-reduce; "
+                         "modeshard = mode-parallel layer (batch-sharded activations, mode-sharded weights); pencil = "
+                         "spatially decomposed layer (every sample spans all ranks: rows of the first grid dim sharded)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra.* measurements")
+    ap.add_argument("--no-gpu-reference", action="store_true", help="skip gpu_reference_baseline")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
                     help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
@@ -186,43 +191,63 @@ def stage_profile(B, C, spatial, n_modes, flags, iters, io="f32"):
     return out, names
 
 
-def cpu_baseline(C, spatial, n_modes, budget_s=12.0):
-    """Reference CPU path (oracle/spectral_oracle.forward_torch: the op-for-op torch
-    restatement of neuralop SpectralConv.forward, autograd backward) on the host cores.
-    Bounded sample: the batch is chosen from a B=1 probe so that the timed part is ~budget_s."""
+def cpu_baseline(C, spatial, n_modes, budget_s=10.0):
+    """The reference's CPU path on the host cores of this box, fwd + autograd bwd of one SpectralConv layer.
+
+    kind "reference": the VERBATIM module (oracle/ref_verbatim.py imports neuralop/layers/spectral_convolution.py from
+    /root/reference through stubs of its absent third-party packages) -- possible only where the reference tree
+    exists (the build container).  kind "port": oracle/spectral_oracle.forward_torch, the op-for-op torch
+    restatement (rel-L2 0.0 against the verbatim module, tests/test_oracle_vs_reference.py) -- what runs on the GPU
+    box, where /root/reference does not exist.  Timed at all cores and at 32 threads (torch's intra-op pool does
+    not scale past that on this op chain); the better one is `value`, `cores` = its thread count."""
     from oracle import spectral_oracle as so
     from neuraloperator_amd.modes import halve_last_mode
 
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)           # torch's intra-op pool stops scaling well beyond this
-    torch.set_num_threads(threads)
     nm = halve_last_mode(n_modes)
     std = (2 / (2 * C)) ** 0.5
     torch.manual_seed(0)
+    kind, ref_conv = "port", None
+    try:
+        from oracle import ref_verbatim
+        if ref_verbatim.available():
+            mod = ref_verbatim.load_reference()
+            ref_conv = mod.SpectralConv(C, C, tuple(n_modes))
+            kind = "reference"
+    except Exception:
+        ref_conv = None
     w = torch.empty(C, C, *nm, dtype=torch.cfloat).normal_(0, std).requires_grad_(True)
     bias = (std * torch.randn(C, *(1,) * len(spatial))).requires_grad_(True)
-
-    def make(b):
-        return (torch.randn(b, C, *spatial, requires_grad=True), torch.randn(b, C, *spatial))
-
-    def step(x, g):
-        x.grad = w.grad = bias.grad = None
-        y = so.forward_torch(x, w, bias, nm, nm)
-        y.backward(g)
-
     b = 8                               # bounded sample of the B=32 workload (same C, grid, modes)
-    x, g = make(b)
-    step(x, g)                          # warm-up (thread pool, FFT plans, allocator)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 5):
-        step(x, g)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(b / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"B={b} of the same (C={C}, {'x'.join(map(str, spatial))}, modes {list(n_modes)}) "
-                      f"workload, {n} timed fwd+bwd steps, torch {torch.__version__} CPU fp32 "
-                      f"({threads} threads of {cores} cores), oracle.forward_torch"}
+    x = torch.randn(b, C, *spatial, requires_grad=True)
+    g = torch.randn(b, C, *spatial)
+
+    def step():
+        x.grad = None
+        if ref_conv is not None:
+            ref_conv.zero_grad(set_to_none=True)
+            ref_conv(x).backward(g)
+        else:
+            w.grad = bias.grad = None
+            so.forward_torch(x, w, bias, nm, nm).backward(g)
+
+    results = {}
+    for threads in sorted({cores, min(cores, 32)}, reverse=True):
+        torch.set_num_threads(threads)
+        step()                          # warm-up (thread pool, FFT plans, allocator)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < budget_s / 2 and n < 4):
+            step()
+            n += 1
+        results[threads] = (b * n / (time.perf_counter() - t0), n)
+    best = max(results, key=lambda t: results[t][0])
+    what = "verbatim neuralop SpectralConv (oracle/ref_verbatim)" if kind == "reference" else "oracle.forward_torch"
+    return {"value": round(results[best][0], 3), "unit": "samples/s", "cores": best, "kind": kind,
+            "sample": f"B={b} of the same (C={C}, {'x'.join(map(str, spatial))}, modes {list(n_modes)}) workload, "
+                      f"{results[best][1]} timed fwd+bwd steps, torch {torch.__version__} CPU fp32, {what}; "
+                      + ", ".join(f"{t} threads: {results[t][0]:.2f} samples/s" for t in sorted(results))
+                      + f" ({cores} cores)"}
 
 
 def cpu_baseline_subprocess(workload, timeout_s=240):
@@ -241,6 +266,122 @@ def cpu_baseline_subprocess(workload, timeout_s=240):
                 "sample": f"cpu baseline exceeded {timeout_s}s and was cut off"}
 
 
+def gpu_reference_baseline(B, C, spatial, n_modes, dev, steps=5):
+    """The "before" number of SURVEY.md 8(d): the reference's own op chain (rfftn -> fftshift -> slice -> einsum ->
+    zero-filled full spectrum -> ifftshift -> ifftn + irfft -> + bias, autograd backward) run through PyTorch-ROCm
+    on this MI355X (hipFFT + ATen), same B / shapes / fp32.  oracle.forward_torch is that chain op for op (and the
+    verbatim module itself where /root/reference exists)."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+
+    nm = halve_last_mode(n_modes)
+    std = (2 / (2 * C)) ** 0.5
+    try:
+        w = torch.empty(C, C, *nm, dtype=torch.cfloat, device=dev).normal_(0, std).requires_grad_(True)
+        bias = (std * torch.randn(C, *(1,) * len(spatial), device=dev)).requires_grad_(True)
+        x = torch.randn(B, C, *spatial, device=dev, requires_grad=True)
+        g = torch.randn(B, C, *spatial, device=dev)
+
+        def fwd(x_, w_, b_):
+            # forward_torch allocates its zero spectrum on the CPU by default: run it under the device context
+            with torch.device(dev):
+                return so.forward_torch(x_, w_, b_, nm, nm)
+
+        def step():
+            x.grad = w.grad = bias.grad = None
+            fwd(x, w, bias).backward(g)
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        return {"value": round(B / (ms / 1e3), 2), "unit": "samples/s", "ms_per_step": round(ms, 3),
+                "what": f"reference op chain (oracle.forward_torch = spectral_convolution.py:417-570 op for op) on "
+                        f"PyTorch-ROCm {torch.__version__}: hipFFT + ATen einsum, autograd backward, B={B}, fp32"}
+    except Exception as e:                      # never let the baseline leg kill the bench line
+        return {"value": None, "unit": "samples/s", "what": f"failed: {type(e).__name__}: {str(e)[:160]}"}
+    finally:
+        torch.cuda.empty_cache()
+
+
+def timed_steps(step, steps, warmup, dist, dev, share):
+    """W untimed steps, then K steps between barrier + synchronize on both sides; max over ranks (ms per step)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt / steps * 1e3
+
+
+def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed):
+    """(step fn, per-GPU batch, global batch, scaling, parallelism tag, conv) of one measurement."""
+    from neuraloperator_amd import SpectralConv
+
+    B, C, spatial, n_modes = WORKLOADS[workload]
+    torch.manual_seed(seed)
+    local_spatial = list(spatial)
+    post = None
+    if parallel == "modeshard" and world > 1:
+        from neuraloperator_amd.mpu import ModeParallelSpectralConv
+        conv = ModeParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        if workload == "fno2d_256_m64_c64_b32":
+            b_local, scaling = B, "weak"                 # the metric workload: B = 32 per GPU at every N
+        else:
+            if B % world:
+                return None
+            b_local, scaling = B // world, "strong"      # configs[3]: the same 8 samples over N GPUs
+        global_batch, par = b_local * world, f"modeshard{world}"
+        post = conv.reduce_replicated_grads
+    elif parallel == "pencil" and world > 1:
+        from neuraloperator_amd.mpu import SpatialParallelSpectralConv
+        if spatial[0] % world:
+            raise SystemExit(f"--parallel pencil: grid rows {spatial[0]} not divisible by {world} ranks")
+        conv = SpatialParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        b_local, scaling, global_batch, par = B, "strong", B, f"pencil{world}"
+        local_spatial[0] = spatial[0] // world
+    else:
+        conv = SpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        b_local, scaling, global_batch = B, "weak", B * world
+        par = f"dp{world}-allreduce" if world > 1 else "single"
+        if world > 1:
+            def post():                                  # data parallel: the dense weight's gradient crosses xGMI
+                for prm in conv.parameters():
+                    if prm.grad is not None:
+                        gr = torch.view_as_real(prm.grad) if prm.grad.is_complex() else prm.grad
+                        dist.all_reduce(gr)
+    x = torch.randn(b_local, C, *local_spatial, device=dev).to(io_dtype).requires_grad_(True)
+    g = torch.randn(b_local, C, *local_spatial, device=dev).to(io_dtype)
+
+    def step():
+        x.grad = None
+        for prm in conv.parameters():
+            prm.grad = None
+        y = conv(x)
+        y.backward(g)
+        if post is not None:
+            post()
+
+    return step, b_local, global_batch, scaling, par, conv
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -257,9 +398,10 @@ def main():
     os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
-    # SC_BENCH_SHARE_GPU=1 (tests on a 1-GPU box only): every rank uses cuda:0 and the control collectives run
-    # over gloo -- exercises the launch contract (torchrun env, barriers, max-over-ranks, rank-0 line) without
-    # N devices.  Never set by the driver: the real runs are one rank per GPU over RCCL.
+    # SC_BENCH_SHARE_GPU=1 (tests on a 1-GPU box only): every rank uses cuda:0 and all collectives run over gloo
+    # (RCCL refuses two ranks on one device) -- exercises the launch contract (torchrun env, barriers,
+    # max-over-ranks, rank-0 line) and the multi-rank data path without N devices.  Never set by the driver: the
+    # real runs are one rank per GPU over RCCL.
     share = os.environ.get("SC_BENCH_SHARE_GPU") == "1"
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
@@ -272,88 +414,70 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from neuraloperator_amd.mpu import comm
+        comm.init(model_parallel_size=world)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    from neuraloperator_amd import SpectralConv, _lib
+    from neuraloperator_amd import _lib
     from neuraloperator_amd.modes import halve_last_mode, kept_block
+    from neuraloperator_amd.mpu import mappings
 
     B, C, spatial, n_modes = WORKLOADS[args.workload]
     flags = _lib.SC_PLAN_FORCE_GENERIC if args.force_generic else 0
-    torch.manual_seed(1234 + rank)
-    if args.parallel == "modeshard" and world > 1:
-        from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
-        comm.init(model_parallel_size=world)
-        conv = ModeParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
-        b_local = B // world if B % world == 0 else B
-        scaling = "strong" if B % world == 0 else "weak"
-        global_batch = b_local * world
-        par = f"modeshard{world}"
-    elif args.parallel == "pencil" and world > 1:
-        from neuraloperator_amd.mpu import SpatialParallelSpectralConv, comm
-        if spatial[0] % world:
-            raise SystemExit(f"--parallel pencil: grid rows {spatial[0]} not divisible by {world} ranks")
-        comm.init(model_parallel_size=world)
-        conv = SpatialParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
-        b_local = B
-        scaling = "strong"                     # the same B samples, each spread over all ranks
-        global_batch = B
-        par = f"pencil{world}"
-    else:
-        conv = SpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
-        b_local = B
-        scaling = "weak"
-        global_batch = B * world
-        par = f"dp{world}-replicas" if world > 1 else "single"
     io_dtype = torch.bfloat16 if args.io == "bf16" else torch.float32
-    local_spatial = list(spatial)
-    if par.startswith("pencil"):
-        local_spatial[0] = spatial[0] // world
-    x = torch.randn(b_local, C, *local_spatial, device=dev).to(io_dtype).requires_grad_(True)
-    g = torch.randn(b_local, C, *local_spatial, device=dev).to(io_dtype)
+    parallel = args.parallel
+    if parallel == "auto":
+        parallel = "modeshard" if world > 1 else "replicas"
+    if share and parallel != "replicas" and args.io == "f32":
+        pass                                             # gloo moves CUDA tensors through the host: slow but correct
     if args.io == "bf16":
         from neuraloperator_amd import engine
         kept_chk, _ = kept_block(spatial, halve_last_mode(n_modes), halve_last_mode(n_modes))
         if engine.get_plan_bf16_io(dev, list(spatial), kept_chk, "forward", flags) is None:
             raise SystemExit(f"--io bf16: {args.workload} does not run on the fused 2-D kernels (no bf16 I/O there)")
 
-    def step():
-        x.grad = None
-        for prm in conv.parameters():
-            prm.grad = None
-        y = conv(x)
-        y.backward(g)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms = dt / args.steps * 1e3
+    case = build_case(parallel, args.workload, world, dev, flags, io_dtype, dist, 1234 + rank)
+    if case is None:
+        raise SystemExit(f"{args.workload}: batch {B} not divisible by {world} ranks for the strong-scaling run")
+    step, b_local, global_batch, scaling, par, conv = case
+    mappings.A2A_STATS.update(calls=0, bytes=0)
+    ms = timed_steps(step, args.steps, args.warmup, dist, dev, share)
     value = global_batch / (ms / 1e3)
+    a2a = dict(mappings.A2A_STATS)
+    n_timed = args.steps + args.warmup
+    del step, conv, case
+    torch.cuda.empty_cache()
 
-    out = None
+    # ---- extra measurements (same launch, fewer steps): see the module docstring
+    extra = {}
+    if not args.no_extras and args.workload == "fno2d_256_m64_c64_b32" and args.io == "f32":
+        todo = [("fno3d_single", "replicas", "fno3d_128_m32_c32_b8")] if world == 1 else \
+            [("dp_allreduce", "replicas", args.workload), ("fno3d_modeshard", "modeshard", "fno3d_128_m32_c32_b8")]
+        for name, par_x, wl in todo:
+            if par_x == parallel and wl == args.workload:
+                continue
+            c = build_case(par_x, wl, world, dev, flags, io_dtype, dist, 99 + rank)
+            if c is None:
+                extra[name] = {"value": None, "note": f"batch of {wl} not divisible by {world} ranks"}
+                continue
+            st_x, bl_x, gb_x, sc_x, tag_x, conv_x = c
+            ms_x = timed_steps(st_x, 10, 3, dist, dev, share)
+            extra[name] = {"workload": wl, "parallelism": tag_x, "scaling": sc_x, "B_per_gpu": bl_x,
+                           "global_batch": gb_x, "ms_per_step": round(ms_x, 4),
+                           "value": round(gb_x / (ms_x / 1e3), 2), "unit": "samples/s", "steps": 10, "warmup": 3}
+            del st_x, conv_x, c
+            torch.cuda.empty_cache()
+
     if rank == 0:
         nm = halve_last_mode(n_modes)
         kept, _ = kept_block(spatial, nm, nm)
         R, Wb, S, total = alg_bytes(b_local, C, spatial, kept, 2 if args.io == "bf16" else 4)
-        stages, names = stage_profile(b_local, C, spatial, n_modes, flags, args.stage_iters, args.io)
+        stages, names = stage_profile(B if par.startswith(("modeshard", "pencil")) else b_local, C, spatial, n_modes,
+                                      flags, args.stage_iters, args.io)
         dom = max(stages, key=lambda k: stages[k]["ms"])
         kern = names["fwd"] if dom in ("fwd_transform", "adj_c2r_transform") else \
-            names["inv"] if dom in ("inv_transform", "adj_r2c_transform") else "k_modegemm"
+            names["inv"] if dom in ("inv_transform", "adj_r2c_transform") else "k_modegemm_dma"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(tpath):
@@ -365,6 +489,8 @@ def main():
         roof = {"bound": "hbm", "kernel": kern, "stage": dom,
                 "achieved": stages[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(stages[dom]["GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "kernel, gfx950 corrections applied; not re-measured by this run)",
                 "alg_bytes_per_launch": stages[dom]["alg_bytes"], "ms_per_launch": stages[dom]["ms"]}
         step_gbs = total / ms / 1e6
         copy_gbs = device_copy_ceiling(R)
@@ -384,10 +510,18 @@ def main():
             "step_roofline": {"alg_bytes_per_step": total, "achieved_GBs": round(step_gbs, 1),
                               "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_measured_copy": round(step_gbs / copy_gbs, 4),
-                              "formula": "4R+3Wb+9S (SURVEY.md 8d)" +
+                              "formula": "4R+3Wb+9S (SURVEY.md 8d), per GPU" +
                                          (", R at 2 bytes per value" if args.io == "bf16" else "")},
             "stages": stages,
         }
+        if world > 1:
+            out["collectives"] = {"backend": "gloo (SC_BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL over xGMI)",
+                                  "all_to_all_calls_per_step": round(a2a["calls"] / n_timed, 2),
+                                  "all_to_all_bytes_per_step_per_rank": int(a2a["bytes"] / n_timed)}
+        if extra:
+            out["extra"] = extra
+        if world == 1 and not args.no_gpu_reference and args.io == "f32":
+            out["gpu_reference_baseline"] = gpu_reference_baseline(b_local, C, spatial, n_modes, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
         sys.stdout.flush()

@@ -138,6 +138,12 @@ typedef struct {
   int32_t flags;            /* SC_GEMM_* bits                                               */
   const int32_t* b_idx;     /* optional device table [n_modes], NULL -> m*b_sm              */
   const int32_t* c_idx;     /* optional device table [n_modes], NULL -> m*c_sm              */
+  /* tiled ("mode-group-major") operands, engine-private layouts only: with a_sg != 0 mode m of A lives at element
+   * offset (m / 16) * a_sg + (m % 16) (+ p*a_sp + r*a_sr), i.e. the 16 modes of a group stay contiguous and the
+   * groups are a_sg apart -- e.g. [group][p][r][16] with a_sg = P*R*16, a_sp = R*16, a_sr = 16 makes everything one
+   * workgroup of k_modegemm_dma reads one contiguous block.  Same for b_sg / c_sg.  0 = plain (m * sm).  Needs
+   * n_modes % 16 == 0, sm == 1 and no index table; only k_modegemm_dma takes it (sc_modegemm fails otherwise). */
+  int64_t a_sg, b_sg, c_sg;
 } sc_modegemm_desc;
 
 int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,

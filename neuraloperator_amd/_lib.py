@@ -54,7 +54,8 @@ class ModeGemmDesc(Structure):
                 ("c_sp", c_int64), ("c_sq", c_int64), ("c_sm", c_int64),
                 ("conj_a", c_int32), ("conj_b", c_int32),
                 ("accumulate", c_int32), ("flags", c_int32),
-                ("b_idx", c_void_p), ("c_idx", c_void_p)]
+                ("b_idx", c_void_p), ("c_idx", c_void_p),
+                ("a_sg", c_int64), ("b_sg", c_int64), ("c_sg", c_int64)]
 
 
 class LayerDesc(Structure):
@@ -64,6 +65,26 @@ class LayerDesc(Structure):
 
 class EngineError(RuntimeError):
     pass
+
+
+class PlanHandle:
+    """Owner of one sc_plan*.  ctypes passes ``_as_parameter_``; the plan (its device twiddle / index tables) is
+    released by plan_destroy() or when the last reference goes away -- the plan cache of engine.py only drops ITS
+    reference on eviction, autograd contexts that still hold the plan keep it alive."""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._as_parameter_ = lib, ptr
+
+    def destroy(self):
+        ptr, self._as_parameter_ = self._as_parameter_, None
+        if ptr is not None and self._lib is not None:
+            try:
+                self._lib.sc_plan_destroy(ptr)
+            except Exception:            # interpreter shutdown
+                pass
+
+    def __del__(self):
+        self.destroy()
 
 
 class ScEngineLib:
@@ -161,10 +182,10 @@ class ScEngineLib:
                 d.freq[i] = ctypes.cast(arr, POINTER(c_int64))
         h = c_void_p()
         self._check(self.lib.sc_plan_create(byref(h), byref(d)))
-        return h
+        return PlanHandle(self.lib, h)
 
     def plan_destroy(self, plan):
-        self.lib.sc_plan_destroy(plan)
+        plan.destroy()
 
     def plan_workspace_bytes(self, plan, n_images):
         return int(self.lib.sc_plan_workspace_bytes(plan, n_images))

@@ -1084,6 +1084,8 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   if (d->accumulate || d->b_idx || d->c_idx) return false;
   if (d->a_sm != 1 || d->b_sm != 1 || d->c_sm != 1) return false;
   if (d->n_modes % 8 != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
+  if ((d->a_sg || d->b_sg || d->c_sg) && d->n_modes % 16 != 0) return false;        // tiled operands: groups of 16
+  if ((d->a_sg | d->b_sg | d->c_sg) & 1) return false;
   // 16-byte granules: every row / column of every operand must start on an even complex element
   if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
@@ -1130,6 +1132,9 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   g.a_sp = d->a_sp; g.a_sr = d->a_sr;
   g.b_sr = d->b_sr; g.b_sq = d->b_sq;
   g.c_sp = d->c_sp; g.c_sq = d->c_sq;
+  g.a_sg = d->a_sg ? d->a_sg : modes;
+  g.b_sg = d->b_sg ? d->b_sg : modes;
+  g.c_sg = d->c_sg ? d->c_sg : modes;
   g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
   // tiles per workgroup: a launch that would need between one and two rounds of the 512 resident workgroups (two
   // per CU) runs its tiles back to back inside fewer workgroups instead of queueing a short second round
@@ -1172,6 +1177,9 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   const cf32* b = (const cf32*)B;
   cf32* c = (cf32*)C;
   if (gemm8_eligible(d, A, B, C)) return run_gemm8(d, a, b, c, st);
+  SC_CHECK_ARG(!(d->a_sg || d->b_sg || d->c_sg),
+               "tiled operands (a_sg / b_sg / c_sg) need the streamed matrix-core kernel: n_modes % 16 == 0, unit mode "
+               "strides, no index tables, 16-byte aligned rows, near-full 32 x 32 tiles");
   if (!(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d))
     return run_mfma_gemm(d, a, b, c, st);
   if (g.Q > 4) return dispatch_modegemm_conj<4, 8>(g, d->conj_a, d->conj_b, a, b, c, st);

@@ -44,6 +44,8 @@ struct Gemm8Args {
   int n_mg, n_pb, n_qb, bpw;   // mode groups of 2 GS, row blocks of 32, column blocks of 16 QT, tiles per workgroup
   int G;                       // grid size = n_mg * ceil(n_pb * n_qb / bpw)
   int64_t a_sp, a_sr, b_sr, b_sq, c_sp, c_sq;   // complex elements; the mode stride of all three is 1
+  int64_t a_sg, b_sg, c_sg;    // element offset from one mode group to the next (2 GS for plain arrays; anything for a
+                               // group-major "tiled spectrum": [group][row][col][2 GS modes])
   int stream_c;                // 1: C is not read by the next kernel -> non-temporal stores
 };
 
@@ -108,7 +110,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
   int gid = SC_BID_X;
   if ((g.G & 7) == 0) gid = (gid & 7) * (g.G >> 3) + (gid >> 3);
   const int mg = gid / chunks, ch = gid - mg * chunks;
-  const int64_t m0 = (int64_t)mg * K::MODES;
+  const int64_t mA = (int64_t)mg * g.a_sg, mB = (int64_t)mg * g.b_sg, mC = (int64_t)mg * g.c_sg;
 
   // ---- loader role: lane = (segment ls of the piece, slot ltq); it fetches granule ltq ^ f(row or column).
   //      This wave's pieces of every stage: piece w is an A piece (r0 + ra_k, rows ra_g SP ..), pieces
@@ -137,7 +139,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
     // multiplied by zero below)
     int prow = p0 + rowA;
     prow = prow < g.P ? prow : g.P - 1;
-    const cf32* srcA = A + (int64_t)prow * g.a_sp + m0 + 2 * lgrA;
+    const cf32* srcA = A + (int64_t)prow * g.a_sp + mA + 2 * lgrA;
     const cf32* srcB[NBW];
     int rb_k[NBW];
 #pragma unroll
@@ -147,7 +149,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
       const int colB = (kb % BPR) * K::SP + ls;
       int qcol = q0 + colB;
       qcol = qcol < g.Q ? qcol : g.Q - 1;
-      srcB[j] = B + (int64_t)qcol * g.b_sq + m0 + 2 * (ltq ^ ((colB >> K::SH) & (GS - 1)));
+      srcB[j] = B + (int64_t)qcol * g.b_sq + mB + 2 * (ltq ^ ((colB >> K::SH) & (GS - 1)));
     }
     auto issue = [&](const int st, const int buf) {
       sc_f4* sb = lds + buf * K::STAGE_G;
@@ -294,7 +296,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
           if (g.P < 0)
 #endif
           if (full || (prow_ < g.P && qc < g.Q))
-            sc_store16(C + (int64_t)prow_ * g.c_sp + (int64_t)qc * g.c_sq + m0 + 2 * gr, val[e], g.stream_c);
+            sc_store16(C + (int64_t)prow_ * g.c_sp + (int64_t)qc * g.c_sq + mC + 2 * gr, val[e], g.stream_c);
         }
       }
     }

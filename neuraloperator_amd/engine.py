@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams, autograd graph); every arithme
 of the hot path runs in libsc_engine.so (hand-written HIP, include/sc_engine.h).
 """
 import atexit
+import collections
 import threading
 
 import torch
@@ -14,8 +15,10 @@ from .modes import kept_block
 SC_PLAN_COMPLEX = _lib.SC_PLAN_COMPLEX
 SC_PLAN_IO_BF16 = _lib.SC_PLAN_IO_BF16
 _PLAN_LOCK = threading.Lock()
-_PLANS = {}
-_NO_BF16_IO = set()       # (spatial, kept, norm, flags) the engine has no bfloat16-I/O kernels for
+_PLANS = collections.OrderedDict()     # least recently used first
+MAX_CACHED_PLANS = 64                  # variable-resolution / incremental-mode training creates a plan per
+                                       # (grid, kept modes, frequency map): evicted plans free their device tables
+_NO_BF16_IO = set()       # (device, spatial, kept, norm, flags) the engine has no bfloat16-I/O kernels for
 
 
 def _require_gpu(t, what="input"):
@@ -45,18 +48,24 @@ def get_plan(device, spatial, kept, fft_norm="forward", flags=0, freq=None, real
                 plan = lib.plan_create(key[1], key[2], fft_norm=fft_norm, flags=flags, freq=freq,
                                        real_col=real_col)
             _PLANS[key] = plan
+            while len(_PLANS) > MAX_CACHED_PLANS:
+                _PLANS.popitem(last=False)      # the handle frees the plan once nothing else references it
+        else:
+            _PLANS.move_to_end(key)
     return plan
 
 
 def get_plan_bf16_io(device, spatial, kept, fft_norm, flags):
     """Plan whose real tensors are bfloat16 in memory (SC_PLAN_IO_BF16), or None where the engine only has
     float32 I/O for the shape (everything off the fused 2-D kernels): the caller then converts."""
-    key = (tuple(int(s) for s in spatial), tuple(int(k) for k in kept), fft_norm, flags)
+    key = (device.index, tuple(int(s) for s in spatial), tuple(int(k) for k in kept), fft_norm, flags)
     if key in _NO_BF16_IO:
         return None
     try:
         return get_plan(device, spatial, kept, fft_norm, flags | SC_PLAN_IO_BF16)
-    except _lib.EngineError:
+    except _lib.EngineError as e:
+        if "SC_PLAN_IO_BF16 is implemented" not in str(e):
+            raise                       # out of memory, HIP errors, ...: not a property of the shape
         _NO_BF16_IO.add(key)
         return None
 

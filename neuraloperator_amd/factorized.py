@@ -5,8 +5,10 @@ The reference keeps its weight in a ``tltorch.FactorizedTensor``
 third-party class.  These containers give the drop-in module the same surface the
 reference's consumers touch:
 
-* state-dict names ``weight.tensor`` (Dense), ``weight.core`` + ``weight.factors.{i}``
-  (Tucker), ``weight.weights`` + ``weight.factors.{i}`` (CP), ``weight.factors.{i}`` (TT)
+* state-dict names ``weight.tensor`` (Dense), ``weight.core`` + ``weight.factors.factor_{i}``
+  (Tucker), ``weight.weights`` + ``weight.factors.factor_{i}`` (CP), ``weight.factors.factor_{i}`` (TT) --
+  tltorch's FactorList naming; checkpoints that store complex parameters as real (..., 2)
+  views, or that use ``factors.{i}`` (this package, round 1), load as well
 * ``.shape``, ``.name``, ``.normal_()``, ``.to_tensor()``, ``w[slices]`` (factor-row slicing
   for Tucker/CP), and use as a tensor in torch functions (``torch.zeros_like(w)``,
   ``w += ...``) as neuralop/training/incremental.py:215-238 does.
@@ -38,8 +40,10 @@ def tucker_rank(shape: Sequence[int], rank, fixed_modes: Optional[List[int]] = N
     n_fixed = int(np.prod([shape[i] for i in fixed])) if fixed else 1
     n_param = int(np.prod(comp)) * n_fixed
     sq = sum(s * s for s in comp)
+    sq_fixed = sum(shape[i] ** 2 for i in fixed)          # factors of the fixed modes: full-rank squares
     n = len(comp)
-    frac = brentq(lambda x: n_param * x ** n + sq * x - rank * n_param, 0.0, max(rank, 1.0))
+    # tensorly.validate_tucker_rank: n_param x^n + (sum of squared compressed sizes) x + (fixed factors) x = rank n_param
+    frac = brentq(lambda x: n_param * x ** n + sq * x + sq_fixed * x - rank * n_param, 0.0, max(rank, 1.0))
     comp_r = [max(int(round(s * frac)), 1) for s in comp]
     out, j = [], 0
     for i, s in enumerate(shape):
@@ -84,10 +88,66 @@ def tt_rank(shape: Sequence[int], rank) -> List[int]:
     return [1] + [max(int(round(d * frac)), 1) for d in avg] + [1]
 
 
+def _as_param_dtype(value, param):
+    """checkpoint tensor -> something ``param.copy_`` accepts: complex parameters may have been stored as real
+    (..., 2) views"""
+    if torch.is_tensor(value) and param.is_complex() and not value.is_complex() and value.shape[-1:] == (2,) \
+            and tuple(value.shape[:-1]) == tuple(param.shape):
+        return torch.view_as_complex(value.contiguous())
+    return value
+
+
+class FactorList(nn.Module):
+    """List of factor parameters registered as ``factor_0, factor_1, ...`` (tltorch.FactorList: the state-dict names
+    of a reference TFNO checkpoint are ``...weight.factors.factor_{i}``)."""
+
+    def __init__(self, factors=()):
+        super().__init__()
+        self._n = 0
+        for f in factors:
+            self.append(f)
+
+    def append(self, f):
+        self.register_parameter(f"factor_{self._n}", f if isinstance(f, nn.Parameter) else nn.Parameter(f))
+        self._n += 1
+        return self
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return getattr(self, f"factor_{i}")
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for i in range(self._n):
+            new, old = f"{prefix}factor_{i}", f"{prefix}{i}"
+            if new not in state_dict and old in state_dict:        # nn.ParameterList naming
+                state_dict[new] = state_dict.pop(old)
+            if new in state_dict:
+                state_dict[new] = _as_param_dtype(state_dict[new], self[i])
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
 class SpectralWeight(nn.Module):
     """Base container.  Sub-classes: DenseWeight, TuckerWeight, CPWeight, TTWeight."""
 
     name = "Base"
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for pname, prm in self._parameters.items():
+            key = prefix + pname
+            if prm is not None and key in state_dict:
+                state_dict[key] = _as_param_dtype(state_dict[key], prm)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     @staticmethod
     def new(shape, rank=1.0, factorization="Dense", fixed_rank_modes=None,
@@ -179,7 +239,7 @@ class TuckerWeight(SpectralWeight):
         super().__init__()
         if as_parameters:
             self.core = nn.Parameter(core)
-            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+            self.factors = FactorList(factors)
         else:  # a sliced view: shares storage with the parent's parameters
             self.core = core
             self.factors = list(factors)
@@ -220,7 +280,7 @@ class CPWeight(SpectralWeight):
         super().__init__()
         if as_parameters:
             self.weights = nn.Parameter(weights)
-            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+            self.factors = FactorList(factors)
         else:
             self.weights = weights
             self.factors = list(factors)
@@ -262,7 +322,7 @@ class TTWeight(SpectralWeight):
     def __init__(self, factors, as_parameters=True):
         super().__init__()
         if as_parameters:
-            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+            self.factors = FactorList(factors)
         else:
             self.factors = list(factors)
 

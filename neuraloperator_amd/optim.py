@@ -6,7 +6,11 @@ metric layer that is 7 arrays across HBM once instead of ~30.
 Same constructor arguments, state-dict layout (``step``, ``exp_avg``, ``exp_avg_sq`` -- complex for complex
 parameters, exactly like the reference's ``torch.zeros_like(grad)`` state) and arithmetic order as the
 reference's non-GaLore branch.  Tensor-GaLore projection (``galore_params``) is not on the engine and raises.
-Parameters must live on the GPU (the engine has no CPU path)."""
+The fused launch takes contiguous fp32 / complex64 parameters on the GPU -- the spectral weights and everything
+else an FNO holds by default; any other parameter of the model (CPU, bf16 / fp16 / fp64, channels_last views) is
+updated with the same formulas as elementwise torch operations, so one optimizer serves a whole model and a step
+never stops half way."""
+import math
 from typing import Callable, Iterable, Tuple
 
 import torch
@@ -47,16 +51,15 @@ class AdamW(Optimizer):
                 grad = p.grad
                 if grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
-                if not p.is_cuda:
-                    raise RuntimeError("neuraloperator_amd.optim.AdamW: parameters must be on the GPU (no CPU path)")
                 cplx = torch.is_complex(p)
-                if p.dtype not in (torch.float32, torch.complex64) or not p.is_contiguous():
-                    raise RuntimeError(f"AdamW on the engine needs contiguous fp32 / complex64 parameters, got "
-                                       f"{p.dtype}, contiguous={p.is_contiguous()}")
-                grad = grad.to(p.dtype).contiguous()
+                fused = p.is_cuda and p.dtype in (torch.float32, torch.complex64) and p.is_contiguous()
                 state = self.state[p]
                 if "step" not in state:
                     state["step"] = 0
+                if not fused:
+                    self._elementwise_update(p, grad, state, group)
+                    continue
+                grad = grad.to(p.dtype).contiguous()
                 if "exp_avg" not in state:
                     state["exp_avg"] = torch.zeros_like(grad)
                     state["exp_avg_sq"] = torch.zeros_like(grad)
@@ -70,3 +73,21 @@ class AdamW(Optimizer):
                                    weight_decay=group["weight_decay"], correct_bias=group["correct_bias"],
                                    step=state["step"])
         return loss
+
+    @staticmethod
+    def _elementwise_update(p, grad, state, group):
+        """The same update (adamw.py:155-200) as torch operations, for parameters the fused launch does not take."""
+        if "exp_avg" not in state:
+            state["exp_avg"] = torch.zeros_like(grad)
+            state["exp_avg_sq"] = torch.zeros_like(grad)
+        m, v = state["exp_avg"], state["exp_avg_sq"]
+        beta1, beta2 = group["betas"]
+        state["step"] += 1
+        m.mul_(beta1).add_(grad, alpha=1.0 - beta1)
+        v.mul_(beta2).addcmul_(grad, grad.conj() if torch.is_complex(grad) else grad, value=1.0 - beta2)
+        step_size = group["lr"]
+        if group["correct_bias"]:
+            step_size *= math.sqrt(1.0 - beta2 ** state["step"]) / (1.0 - beta1 ** state["step"])
+        p.add_(m / v.sqrt().add_(group["eps"]), alpha=-step_size)
+        if group["weight_decay"] > 0.0:
+            p.add_(p, alpha=-group["lr"] * group["weight_decay"])

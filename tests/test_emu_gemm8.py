@@ -121,3 +121,36 @@ def test_eligibility(lib):
     assert lib.modegemm_path(**dict(base, Q=36)) == 1                    # ragged Tucker rank: 64-row tiles of gen 1
     assert lib.modegemm_path(**dict(base, P=4, Q=128)) == 0              # 4 rows: neither matrix-core kernel
     assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4)) == 2       # hidden 128 weight gradient
+
+
+@pytest.mark.parametrize("layout", ["AC", "B", "ABC"])
+def test_tiled_operands(lib, layout):
+    """mode-group-major ("tiled spectrum") operands: [group][row][col][16 modes] through a_sg / b_sg / c_sg"""
+    B, Ci, Co, M = 32, 12, 64, 48
+    G = M // 16
+    x, w = _rand(B, Ci, M, seed=11), _rand(Ci, Co, M, seed=12)
+
+    def tile(t):                                  # (P, Q, M) -> (G, P, Q, 16) contiguous
+        p, q, _ = t.shape
+        return t.reshape(p, q, G, 16).permute(2, 0, 1, 3).contiguous()
+
+    def untile(t, p, q):
+        return t.reshape(G, p, q, 16).permute(1, 2, 0, 3).reshape(p, q, M)
+
+    a = tile(x) if "A" in layout else x
+    b = tile(w) if "B" in layout else w
+    c = torch.full((B, Co, M), float("nan"), dtype=torch.complex64)
+    if "C" in layout:
+        c = tile(c)
+    kw = dict(P=B, Q=Co, R=Ci, n_modes=M, a_sm=1, b_sm=1, c_sm=1)
+    kw.update(dict(a_sg=B * Ci * 16, a_sp=Ci * 16, a_sr=16) if "A" in layout else dict(a_sp=Ci * M, a_sr=M))
+    kw.update(dict(b_sg=Ci * Co * 16, b_sr=Co * 16, b_sq=16) if "B" in layout else dict(b_sr=Co * M, b_sq=M))
+    kw.update(dict(c_sg=B * Co * 16, c_sp=Co * 16, c_sq=16) if "C" in layout else dict(c_sp=Co * M, c_sq=M))
+    run(lib, a, b, c, **kw)
+    got = untile(c, B, Co) if "C" in layout else c
+    ref = np.einsum("bim,iom->bom", x.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
+    assert rel_l2(got.numpy(), ref) < TOL
+    # tiled operands on a call the streamed kernel does not take fail loudly (no silent mis-addressing)
+    with pytest.raises(_lib.EngineError):
+        lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                     torch.view_as_real(c).data_ptr(), 0, **dict(kw, a_sg=16, flags=_lib.SC_GEMM_NO_STREAM))

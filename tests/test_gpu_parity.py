@@ -422,7 +422,9 @@ def test_module_variants_match_golden(name):
         kw["rank"] = [int(g[f"param_{i}"].shape[0]) for i in range(n_par)] + [1]
     conv = SpectralConv(ci, co, tuple(int(v) for v in g["ctor_n_modes"]), **kw).to(dev)
     assert list(conv.n_modes) == [int(v) for v in g["n_modes_attr"]]
-    params = dict(conv.weight.named_parameters())
+    # the fixtures name factor parameters after the stub's nn.ParameterList ("factors.0"); the module registers them
+    # under tltorch's FactorList names ("factors.factor_0")
+    params = {k.replace("factors.factor_", "factors."): v for k, v in conv.weight.named_parameters()}
     assert len(params) == n_par
     with torch.no_grad():
         for i in range(n_par):
