@@ -1071,31 +1071,49 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 }
 
 // ---- streamed matrix-core path (sc_kernels_gemm8.h): plain contiguous-mode operands ------------------------------
-//   mode count % 16 == 0: 16 modes per workgroup (128-byte segments), 8 waves, 32 x 32 tiles, ring of 16 KiB stages
-//   mode count %  8 == 0:  8 modes per workgroup ( 64-byte segments), 4 waves, 32 x 64 tiles, ring of 12 KiB stages
-#ifndef SC_G8_DEPTH
-#define SC_G8_DEPTH 4          // GS = 8: 64 KiB of LDS -> two workgroups per CU
+// Shapes of the kernel (modes per workgroup x tile, waves).  Measured (profiles/r02_gemm_dma_diag_grid_layout.txt):
+// ONE workgroup needs ~33 us for its 32 stages whatever the layout or segment size -- every stage is wait + issue +
+// MFMA in lock step behind its barrier (matrix pipe 45 % busy) -- so the launch is as fast as the number of
+// INDEPENDENT workgroups a CU holds: small workgroups, several per CU.
+//   0 (default)  8 modes x 32 x 32, 4 waves, 2 r pairs per stage:  528 workgroups at the metric shape, 3 per CU
+//   1           16 modes x 32 x 32, 8 waves (128-byte segments):   264 workgroups, 2 per CU
+//   2            8 modes x 32 x 64, 4 waves:                       264 workgroups, 2 per CU
+#ifndef SC_G8_VARIANT
+#define SC_G8_VARIANT 0
 #endif
-#ifndef SC_G8_DEPTH4
-#define SC_G8_DEPTH4 6         // GS = 4: 72 KiB
+#if SC_G8_VARIANT == 1
+#define SC_G8_CFG 8, 2, 1, 4
+#define SC_G8_MODES 16
+#define SC_G8_COLS 32
+#elif SC_G8_VARIANT == 2
+#define SC_G8_CFG 4, 4, 1, 6
+#define SC_G8_MODES 8
+#define SC_G8_COLS 64
+#elif SC_G8_VARIANT == 3
+#define SC_G8_CFG 4, 2, 1, 6
+#define SC_G8_MODES 8
+#define SC_G8_COLS 32
+#else
+#define SC_G8_CFG 4, 2, 2, 3
+#define SC_G8_MODES 8
+#define SC_G8_COLS 32
+#endif
+#ifndef SC_G8_RESIDENT
+#define SC_G8_RESIDENT 768     // workgroups the chip holds at once (3 per CU)
 #endif
 static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
   if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM)) return false;
   if (d->accumulate || d->b_idx || d->c_idx) return false;
   if (d->a_sm != 1 || d->b_sm != 1 || d->c_sm != 1) return false;
-  if (d->n_modes % 8 != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
+  if (d->n_modes % SC_G8_MODES != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
   if ((d->a_sg || d->b_sg || d->c_sg) && d->n_modes % 16 != 0) return false;        // tiled operands: groups of 16
   if ((d->a_sg | d->b_sg | d->c_sg) & 1) return false;
   // 16-byte granules: every row / column of every operand must start on an even complex element
   if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
-  // tiles are 32 rows x 32 (64) columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as
+  // tiles are 32 rows x SC_G8_COLS columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as
   // 36 stay on the 64-row tiles of k_modegemm_mfma)
-#ifdef SC_G8_FORCE64
-  const int64_t cols = 64;
-#else
-  const int64_t cols = d->n_modes % 16 == 0 ? 32 : 64;
-#endif
+  const int64_t cols = SC_G8_COLS;
   const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + cols - 1) / cols * cols;
   if (4 * d->P < 3 * Pp || 4 * d->Q < 3 * Qp) return false;
   if (d->R < 4) return false;
@@ -1103,27 +1121,22 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   return true;
 }
 
-template <int GS, int QT, int D, bool CA, bool CB>
+template <int GS, int QT, int SUB, int D, bool CA, bool CB>
 static void launch_gemm8(const Gemm8Args& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  SC_LAUNCH((k_modegemm_dma<GS, QT, D, CA, CB>), dim3((unsigned)g.G), dim3((Gemm8Cfg<GS, QT>::THREADS)), 0, st, g, A,
-            B, C);
+  SC_LAUNCH((k_modegemm_dma<GS, QT, SUB, D, CA, CB>), dim3((unsigned)g.G), dim3((Gemm8Cfg<GS, QT, SUB>::THREADS)), 0,
+            st, g, A, B, C);
 }
 
-template <int GS, int QT, int D>
+template <int GS, int QT, int SUB, int D>
 static void dispatch_gemm8(const Gemm8Args& g, int ca, int cb, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  if (!ca && !cb) launch_gemm8<GS, QT, D, false, false>(g, A, B, C, st);
-  else if (ca && !cb) launch_gemm8<GS, QT, D, true, false>(g, A, B, C, st);
-  else if (!ca && cb) launch_gemm8<GS, QT, D, false, true>(g, A, B, C, st);
-  else launch_gemm8<GS, QT, D, true, true>(g, A, B, C, st);
+  if (!ca && !cb) launch_gemm8<GS, QT, SUB, D, false, false>(g, A, B, C, st);
+  else if (ca && !cb) launch_gemm8<GS, QT, SUB, D, true, false>(g, A, B, C, st);
+  else if (!ca && cb) launch_gemm8<GS, QT, SUB, D, false, true>(g, A, B, C, st);
+  else launch_gemm8<GS, QT, SUB, D, true, true>(g, A, B, C, st);
 }
 
 static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-#ifdef SC_G8_FORCE64             // measurement builds only: 64-byte segments also where whole lines are possible
-  const bool wide = false;
-#else
-  const bool wide = d->n_modes % 16 == 0;                     // whole cache lines per segment
-#endif
-  const int64_t cols = wide ? 32 : 64, modes = wide ? 16 : 8;
+  const int64_t cols = SC_G8_COLS, modes = SC_G8_MODES;
   Gemm8Args g;
   g.P = (int)d->P; g.Q = (int)d->Q; g.R = (int)d->R;
   g.n_mg = (int)(d->n_modes / modes);
@@ -1132,18 +1145,18 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   g.a_sp = d->a_sp; g.a_sr = d->a_sr;
   g.b_sr = d->b_sr; g.b_sq = d->b_sq;
   g.c_sp = d->c_sp; g.c_sq = d->c_sq;
-  g.a_sg = d->a_sg ? d->a_sg : modes;
-  g.b_sg = d->b_sg ? d->b_sg : modes;
-  g.c_sg = d->c_sg ? d->c_sg : modes;
+  g.a_sg = d->a_sg ? d->a_sg : 16;                            // groups of 16 modes (plain arrays: 16 apart)
+  g.b_sg = d->b_sg ? d->b_sg : 16;
+  g.c_sg = d->c_sg ? d->c_sg : 16;
   g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
-  // tiles per workgroup: a launch that would need between one and two rounds of the 512 resident workgroups (two
-  // per CU) runs its tiles back to back inside fewer workgroups instead of queueing a short second round
+  // tiles per workgroup: a launch a little larger than what the chip holds at once runs its tiles back to back
+  // inside fewer workgroups instead of queueing a short second round
   const int64_t nblk = (int64_t)g.n_pb * g.n_qb;
   int64_t bpw = 1;
-  if (g.n_mg <= 512 && g.n_mg * nblk > 512) {
+  if (g.n_mg <= SC_G8_RESIDENT && g.n_mg * nblk > SC_G8_RESIDENT) {
     bpw = nblk;
     for (int64_t b = 1; b <= nblk; ++b)
-      if (g.n_mg * ((nblk + b - 1) / b) <= 512) {
+      if (g.n_mg * ((nblk + b - 1) / b) <= SC_G8_RESIDENT) {
         bpw = b;
         break;
       }
@@ -1152,8 +1165,7 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   if (cap > 0 && cap <= nblk) bpw = cap;
   g.bpw = (int)bpw;
   g.G = (int)(g.n_mg * ((nblk + bpw - 1) / bpw));
-  if (wide) dispatch_gemm8<8, 2, SC_G8_DEPTH>(g, d->conj_a, d->conj_b, A, B, C, st);
-  else dispatch_gemm8<4, 4, SC_G8_DEPTH4>(g, d->conj_a, d->conj_b, A, B, C, st);
+  dispatch_gemm8<SC_G8_CFG>(g, d->conj_a, d->conj_b, A, B, C, st);
   return sc_check_launch("k_modegemm_dma");
 }
 

@@ -19,9 +19,9 @@
 //    Cache, independent of the ring depth, and the MFMA time ADDS to it -- the CU's memory path is limited in
 //    requests, not bytes, and a wave that cannot issue its next LDS-DMA cannot issue its MFMAs either.  Hence whole
 //    lines per request and twice the waves (GS of them: two per SIMD and workgroup, two workgroups per CU);
-//  * a stage = 2 values of r: A 2 x 32 rows + B 2 x 16 QT columns; D stages form a ring, D - 1 of them are in
-//    flight while one feeds the matrix cores; the only synchronisation is ONE raw s_barrier per stage behind a
-//    COUNTED s_waitcnt vmcnt (loads of later stages stay in flight across it);
+//  * a stage = SUB pairs of r values: per pair A 2 x 32 rows + B 2 x 16 QT columns; D stages form a ring, D - 2
+//    of them are in flight while one feeds the matrix cores; the only synchronisation is ONE raw s_barrier per stage
+//    behind a COUNTED s_waitcnt vmcnt (loads of later stages stay in flight across it);
 //  * the LDS image of a piece is lane-linear (hardware), so the bank swizzle is applied to the SOURCE address:
 //    granule t of segment s lands in slot t ^ f(s), f(s) = (s / (16 / GS)) mod GS; with it the ds_read_b128
 //    operand fetches (32 rows or columns, stride 16 GS bytes) are conflict free (cdna_hip_programming.md 5.4 rule 21);
@@ -44,12 +44,12 @@ struct Gemm8Args {
   int n_mg, n_pb, n_qb, bpw;   // mode groups of 2 GS, row blocks of 32, column blocks of 16 QT, tiles per workgroup
   int G;                       // grid size = n_mg * ceil(n_pb * n_qb / bpw)
   int64_t a_sp, a_sr, b_sr, b_sq, c_sp, c_sq;   // complex elements; the mode stride of all three is 1
-  int64_t a_sg, b_sg, c_sg;    // element offset from one mode group to the next (2 GS for plain arrays; anything for a
-                               // group-major "tiled spectrum": [group][row][col][2 GS modes])
+  int64_t a_sg, b_sg, c_sg;    // element offset from one group of 16 modes to the next (16 for plain arrays; anything
+                               // for a group-major "tiled spectrum": [group][row][col][16 modes])
   int stream_c;                // 1: C is not read by the next kernel -> non-temporal stores
 };
 
-template <int GS, int QT>
+template <int GS, int QT, int SUB = 1>
 struct Gemm8Cfg {
   static constexpr int NW = GS;                        // waves = granules of a segment (mode pairs of the unit)
   static constexpr int THREADS = 64 * NW;
@@ -59,9 +59,10 @@ struct Gemm8Cfg {
   static constexpr int SH = (GS == 4) ? 2 : 1;         // log2(16 / GS)
   static constexpr int A_G = 2 * 32 * GS;              // granules of a stage: A [kk][32 rows][GS]
   static constexpr int B_G = 2 * COLS * GS;            //                      B [kk][COLS][GS]
-  static constexpr int STAGE_G = A_G + B_G;
-  static constexpr int NPA = A_G / 64, NPB = B_G / 64; // pieces per stage
-  static constexpr int PPW = (NPA + NPB) / NW;         // pieces per wave and stage
+  static constexpr int SUB_G = A_G + B_G;              // granules of one r pair
+  static constexpr int STAGE_G = SUB * SUB_G;          // a stage = SUB r pairs (one barrier per stage)
+  static constexpr int NPA = A_G / 64, NPB = B_G / 64; // pieces per r pair
+  static constexpr int PPW = SUB * (NPA + NPB) / NW;   // pieces per wave and stage
   static constexpr int RP = 2048 / (16 * GS);          // rows of an epilogue patch (2048 granules = 32 KiB)
   static constexpr int EPW = 32 / GS;                  // patch stores per wave
   static_assert(GS == 4 || GS == 8, "64- or 128-byte segments");
@@ -94,10 +95,10 @@ SC_DEVICE void g8_wait_stage(const int rem) {
   }
 }
 
-template <int GS, int QT, int D, bool CA, bool CB>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT>::THREADS), (GS == 8 ? 4 : 2))
+template <int GS, int QT, int SUB, int D, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
 k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
-  typedef Gemm8Cfg<GS, QT> K;
+  typedef Gemm8Cfg<GS, QT, SUB> K;
   SC_SHARED __attribute__((aligned(16))) sc_f4 lds[D * K::STAGE_G];
   static_assert(D * K::STAGE_G >= 2048, "the epilogue patch (32 KiB) lives in the ring");
 
@@ -110,14 +111,17 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
   int gid = SC_BID_X;
   if ((g.G & 7) == 0) gid = (gid & 7) * (g.G >> 3) + (gid >> 3);
   const int mg = gid / chunks, ch = gid - mg * chunks;
-  const int64_t mA = (int64_t)mg * g.a_sg, mB = (int64_t)mg * g.b_sg, mC = (int64_t)mg * g.c_sg;
+  constexpr int GPG = 16 / K::MODES;                           // workgroups per group of 16 modes
+  const int64_t mlo = (int64_t)(mg % GPG) * K::MODES;
+  const int64_t mA = (int64_t)(mg / GPG) * g.a_sg + mlo, mB = (int64_t)(mg / GPG) * g.b_sg + mlo,
+                mC = (int64_t)(mg / GPG) * g.c_sg + mlo;
 
   // ---- loader role: lane = (segment ls of the piece, slot ltq); it fetches granule ltq ^ f(row or column).
   //      This wave's pieces of every stage: piece w is an A piece (r0 + ra_k, rows ra_g SP ..), pieces
   //      NPA + w + NW j are B pieces (r0 + rb_k, columns rb_g SP ..)
   const int ls = lane / GS, ltq = lane % GS;
   constexpr int APR = 32 / K::SP, BPR = K::COLS / K::SP;       // pieces per r
-  constexpr int NBW = K::PPW - 1;                              // B pieces per wave
+  constexpr int NBW = K::NPB / K::NW;                          // B pieces per wave and r pair
   const int ra_k = w / APR, ra_g = w % APR;
   const int rowA = ra_g * K::SP + ls;                          // row inside the tile
   const int lgrA = ltq ^ ((rowA >> K::SH) & (GS - 1));
@@ -128,7 +132,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
   const uint32_t m_re = (CB && d) ? 0x80000000u : 0u;        // B'[(r,re)][(q,1)] = Im B  (conj: -Im B)
   const uint32_t m_im = (!CB && !d) ? 0x80000000u : 0u;      // B'[(r,im)][(q,0)] = -Im B (conj: +Im B)
   const uint32_t dsel = d ? 0xffffffffu : 0u;
-  const int NS = (g.R + 1) >> 1;
+  const int NS = (g.R + 2 * SUB - 1) / (2 * SUB);            // stages of 2 SUB values of r
 
   const int b_end = (ch + 1) * g.bpw < nblk ? (ch + 1) * g.bpw : nblk;
 #pragma unroll 1
@@ -151,27 +155,43 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
       qcol = qcol < g.Q ? qcol : g.Q - 1;
       srcB[j] = B + (int64_t)qcol * g.b_sq + mB + 2 * (ltq ^ ((colB >> K::SH) & (GS - 1)));
     }
-    auto issue = [&](const int st, const int buf) {
-      sc_f4* sb = lds + buf * K::STAGE_G;
-      int ra = 2 * st + ra_k;
-      ra = ra < g.R ? ra : g.R - 1;
-      SC_GLDS16(srcA + (int64_t)ra * g.a_sr, sb + w * 64);
+    // stages are requested in order, so the sources are running pointers (r values past the end re-read the last
+    // one: only the final r pair of an odd R, multiplied by zero below, or whole r pairs past NS * 2 SUB > R)
+    const int64_t stepA = 2 * g.a_sr, stepB = 2 * g.b_sr;
+    const cf32* pA = srcA + (int64_t)ra_k * g.a_sr;
+    const cf32* pB[NBW];
 #pragma unroll
-      for (int j = 0; j < NBW; ++j) {
-        int rb = 2 * st + rb_k[j];
-        rb = rb < g.R ? rb : g.R - 1;
-        SC_GLDS16(srcB[j] + (int64_t)rb * g.b_sr, sb + K::A_G + (w + K::NW * j) * 64);
+    for (int j = 0; j < NBW; ++j) pB[j] = srcB[j] + (int64_t)rb_k[j] * g.b_sr;
+    int r_next = 0;                                       // first r of the next r pair to request
+    auto issue = [&](const int buf) {
+      sc_f4* sb = lds + buf * K::STAGE_G;
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int64_t backA = (r_next + ra_k < g.R) ? 0 : (int64_t)(r_next + ra_k - (g.R - 1)) * g.a_sr;
+        SC_GLDS16(pA - backA, sb + sub * K::SUB_G + w * 64);
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+          const int64_t backB = (r_next + rb_k[j] < g.R) ? 0 : (int64_t)(r_next + rb_k[j] - (g.R - 1)) * g.b_sr;
+          SC_GLDS16(pB[j] - backB, sb + sub * K::SUB_G + K::A_G + (w + K::NW * j) * 64);
+        }
+        pA += stepA;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) pB[j] += stepB;
+        r_next += 2;
       }
     };
     struct Ops {                 // MFMA operands of one stage: (Re, Im) of both modes for this lane's row / columns
       sc_f4 a;
       sc_f4 b[QT];
     };
-    auto fetch = [&](const int buf, Ops& o) {
-      const sc_f4* sb = lds + buf * K::STAGE_G;
-      o.a = sb[a_g];
+    auto fetch = [&](const int buf, Ops (&o)[SUB]) {
 #pragma unroll
-      for (int u = 0; u < QT; ++u) o.b[u] = sb[b_g + u * 16 * GS];
+      for (int sub = 0; sub < SUB; ++sub) {
+        const sc_f4* sb = lds + buf * K::STAGE_G + sub * K::SUB_G;
+        o[sub].a = sb[a_g];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[sub].b[u] = sb[b_g + u * 16 * GS];
+      }
     };
 
     sc_f32x16 acc[2][QT];
@@ -189,8 +209,8 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
       float ar[2], ai[2], br[2][QT], bm[2][QT];
     };
     auto bsel = [&](const float hi, const float lo) { return sc_bitsel(dsel, hi, lo); };      // d ? hi : lo
-    auto prep = [&](const Ops& o, const int st, Prep& q) {
-      const float keep = (2 * st + kk < g.R) ? 1.f : 0.f;     // odd R: the clamped duplicate contributes 0
+    auto prep = [&](const Ops& o, const int r0, Prep& q) {
+      const float keep = (r0 + kk < g.R) ? 1.f : 0.f;         // r values past the end: the duplicate contributes 0
       q.ar[0] = o.a.x * keep;
       q.ai[0] = (CA ? -o.a.y : o.a.y) * keep;
       q.ar[1] = o.a.z * keep;
@@ -225,35 +245,28 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
       SC_SCHED_BARRIER();
     };
 
-    // ---- prologue: fill the ring, take stage 0
+    // ---- prologue: D - 1 stages in flight
     sc_wait_vmcnt<0>();                 // stores of the previous tile's epilogue are counted by vmcnt too
-    const int npro = NS < D ? NS : D;
-    for (int st = 0; st < npro; ++st) issue(st, st);
-    g8_wait_stage<D, K::PPW>(npro - 1);
-    SC_BARRIER_RAW();
-    Ops o0, o1;
-    fetch(0, o0);
-    // one stage: publish stage st + 1 (counted wait + barrier), refill the buffer stage st lived in, fetch the
-    // operands of stage st + 1 while the matrix cores work on stage st
-    auto step = [&](const int st, const Ops& cur, Ops& nxt) {
-      Prep q;
-      if (st + 1 < NS) {
-        g8_wait_stage<D, K::PPW>((NS - 2 - st) < (D - 2) ? (NS - 2 - st) : (D - 2));
-        SC_WAIT_LGKM0();                // this wave's reads of stage st have landed in registers
-        SC_BARRIER_RAW();               // ... so have everybody's: its buffer is free, stage st + 1 is complete
-        if (st + D < NS) issue(st + D, st % D);
-        prep(cur, st, q);               // before the next fetch: the compiler's own wait for `cur` must not
-        SC_SCHED_BARRIER();             // also wait for the reads issued below
-        fetch((st + 1) % D, nxt);
-      } else {
-        prep(cur, st, q);
-      }
-      fire(q);
-    };
+    const int npro = NS < D - 1 ? NS : D - 1;
+    for (int st = 0; st < npro; ++st) issue(st);
+    // one stage: counted wait for stage st + barrier (publishes it; everybody has finished READING stage st - 1, so
+    // its buffer is refilled with stage st + D - 1), then fetch / prepare / multiply r pair by r pair.  No operand
+    // double-buffering in registers: the latencies exposed after the barrier are covered by the OTHER workgroups of
+    // the CU (measured: one workgroup alone is latency-bound whatever it does; fewer registers = more of them)
 #pragma unroll 1
-    for (int st = 0; st < NS; st += 2) {
-      step(st, o0, o1);
-      if (st + 1 < NS) step(st + 1, o1, o0);
+    for (int st = 0; st < NS; ++st) {
+      g8_wait_stage<D, K::PPW>((NS - 1 - st) < (D - 2) ? (NS - 1 - st) : (D - 2));
+      SC_WAIT_LGKM0();
+      SC_BARRIER_RAW();
+      if (st + D - 1 < NS) issue((st + D - 1) % D);
+      Ops o[SUB];
+      fetch(st % D, o);
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        Prep q;
+        prep(o[sub], 2 * (st * SUB + sub), q);
+        fire(q);
+      }
     }
 
     // ---- C: per (16-column tile, RP rows) the waves fill a [RP rows][16 cols][GS slots] granule patch (each wave

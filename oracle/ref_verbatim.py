@@ -76,3 +76,19 @@ def load_reference_adamw():
         stub.TensorGaLoreProjector = type("TensorGaLoreProjector", (), {})
         sys.modules["neuralop.training.tensor_galore_projector"] = stub
     return _load(name, os.path.join(root, "training", "adamw.py"))
+
+
+def load_reference_fno():
+    """The verbatim ``neuralop.models.fno`` module (FNO / TFNO built from the reference's own FNOBlocks, ChannelMLP,
+    skip connections, embeddings ...): the real caller of the ``conv_module`` plug-in
+    (neuralop/layers/fno_block.py:210-240).  Bare package objects keep the reference's ``__init__`` files (wandb,
+    zencfg, h5py ...) from running; every module is imported from where it lies."""
+    import importlib
+
+    load_reference()                                   # tensorly / tltorch stubs, neuralop, neuralop.layers, utils
+    root = os.path.join(REFERENCE_ROOT, "neuralop")
+    if "neuralop.models" not in sys.modules:
+        m = types.ModuleType("neuralop.models")
+        m.__path__ = [os.path.join(root, "models")]
+        sys.modules["neuralop.models"] = m
+    return importlib.import_module("neuralop.models.fno")

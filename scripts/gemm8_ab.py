@@ -1,7 +1,7 @@
 """A-B of the layer's three contractions between kernels / engine builds on one box, interleaved:
     python scripts/gemm8_ab.py [lib.so ...]
 For every library: the streamed kernel (k_modegemm_s8, flags 0) and generation 1 (SC_GEMM_NO_STREAM) at the layer's
-own strides; us per launch warm (back to back) and cold (after a 600 MB fill, the cache state inside a step)."""
+own strides; us per launch warm (back to back) and cold (after READING 600 MB: caches evicted, nothing dirty)."""
 import os
 import sys
 
@@ -14,14 +14,15 @@ paths = sys.argv[1:] or [_lib.DEFAULT_LIB]
 libs = [(os.path.basename(p).replace("libsc_engine", "").replace(".so", "") or "prod", _lib.ScEngineLib(p)) for p in paths]
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
-junk = torch.empty(600 * 1024 * 1024 // 4, device=dev)
+junk = torch.empty(600 * 1024 * 1024 // 4, device=dev).normal_()
+sink = torch.zeros(1, device=dev)
 
 
 def timed(fn, cold, n=12):
     tot = []
     for _ in range(n):
         if cold:
-            junk.fill_(1.0)
+            sink.add_(junk.sum())        # clean eviction: a 600 MB fill would leave dirty lines the timed kernel pays for
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
