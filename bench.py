@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra.* measurements")
     ap.add_argument("--no-gpu-reference", action="store_true", help="skip gpu_reference_baseline")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
+    ap.add_argument("--plan-flags", type=int, default=0, help="A/B: extra SC_PLAN_* bits (32 = SC_PLAN_SINGLE_QUEUE)")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
                     help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
                          "bf16 = the bf16-I/O reading of BASELINE configs[1], fused 2-D kernels only")
@@ -424,7 +425,7 @@ def main():
     from neuraloperator_amd.mpu import mappings
 
     B, C, spatial, n_modes = WORKLOADS[args.workload]
-    flags = _lib.SC_PLAN_FORCE_GENERIC if args.force_generic else 0
+    flags = (_lib.SC_PLAN_FORCE_GENERIC if args.force_generic else 0) | args.plan_flags
     io_dtype = torch.bfloat16 if args.io == "bf16" else torch.float32
     parallel = args.parallel
     if parallel == "auto":

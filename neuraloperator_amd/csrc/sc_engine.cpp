@@ -100,6 +100,7 @@ struct sc_plan {
   float* m_ax_inv[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   // fast path (power-of-two 2-D), see sc_kernels_fft.h
   Fft2dPlan fft2d;
+  mutable Fft3Queues queues;   // side stream + fork / join events of the two-queue transform launches
   bool fast = false;
   // weight sub-block index tables (device), keyed by (w_extent, w_start)
   std::mutex idx_mu;
@@ -487,7 +488,10 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   }
   if (!rc && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !p->custom_map && !p->cplx) {
     std::string why;
-    if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
+    if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) {
+      p->fast = true;
+      fft3_queues_init(&p->queues, !(desc->flags & (SC_PLAN_FFT_GEN2 | SC_PLAN_SINGLE_QUEUE)));
+    }
   }
   if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
     rc = sc_fail("sc_engine: SC_PLAN_IO_BF16 is implemented on the fused 2-D kernels (generation 3) only: "
@@ -504,6 +508,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
 extern "C" void sc_plan_destroy(sc_plan* p) {
   if (!p) return;
 
+  fft3_queues_destroy(&p->queues);
   for (void* q : p->owned) (void)hipFree(q);
   for (auto& kv : p->idx_cache) (void)hipFree(kv.second);
   delete p;
@@ -863,8 +868,8 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
     if (p->d.flags & SC_PLAN_IO_BF16)
-      return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
-    return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
+      return fft3_forward(&p->fft2d, &p->queues, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
+    return fft3_forward(&p->fft2d, &p->queues, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
   }
   const int L = p->nd - 1;
   int64_t lines = n_images;
@@ -924,9 +929,9 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
       return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
                            &g_last_error);
     if (p->d.flags & SC_PLAN_IO_BF16)
-      return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
+      return fft3_inverse(&p->fft2d, &p->queues, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
                           &g_last_error);
-    return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
+    return fft3_inverse(&p->fft2d, &p->queues, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
   }
   const int L = p->nd - 1;
   int64_t lpi = 1;
@@ -1082,19 +1087,27 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 #define SC_G8_VARIANT 0
 #endif
 #if SC_G8_VARIANT == 1
-#define SC_G8_CFG 8, 2, 1, 4
+#define SC_G8_CFG 8, 2, 1, 4, false
 #define SC_G8_MODES 16
 #define SC_G8_COLS 32
 #elif SC_G8_VARIANT == 2
-#define SC_G8_CFG 4, 4, 1, 6
+#define SC_G8_CFG 4, 4, 1, 6, false
 #define SC_G8_MODES 8
 #define SC_G8_COLS 64
 #elif SC_G8_VARIANT == 3
-#define SC_G8_CFG 4, 2, 1, 6
+#define SC_G8_CFG 4, 2, 1, 6, false
 #define SC_G8_MODES 8
 #define SC_G8_COLS 32
+#elif SC_G8_VARIANT == 4
+#define SC_G8_CFG 4, 2, 2, 3, true
+#define SC_G8_MODES 8
+#define SC_G8_COLS 32
+#elif SC_G8_VARIANT == 5
+#define SC_G8_CFG 8, 2, 1, 4, true
+#define SC_G8_MODES 16
+#define SC_G8_COLS 32
 #else
-#define SC_G8_CFG 4, 2, 2, 3
+#define SC_G8_CFG 4, 2, 2, 3, false
 #define SC_G8_MODES 8
 #define SC_G8_COLS 32
 #endif
@@ -1121,18 +1134,18 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   return true;
 }
 
-template <int GS, int QT, int SUB, int D, bool CA, bool CB>
+template <int GS, int QT, int SUB, int D, bool IL, bool CA, bool CB>
 static void launch_gemm8(const Gemm8Args& g, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  SC_LAUNCH((k_modegemm_dma<GS, QT, SUB, D, CA, CB>), dim3((unsigned)g.G), dim3((Gemm8Cfg<GS, QT, SUB>::THREADS)), 0,
-            st, g, A, B, C);
+  SC_LAUNCH((k_modegemm_dma<GS, QT, SUB, D, IL, CA, CB>), dim3((unsigned)g.G), dim3((Gemm8Cfg<GS, QT, SUB>::THREADS)),
+            0, st, g, A, B, C);
 }
 
-template <int GS, int QT, int SUB, int D>
+template <int GS, int QT, int SUB, int D, bool IL>
 static void dispatch_gemm8(const Gemm8Args& g, int ca, int cb, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  if (!ca && !cb) launch_gemm8<GS, QT, SUB, D, false, false>(g, A, B, C, st);
-  else if (ca && !cb) launch_gemm8<GS, QT, SUB, D, true, false>(g, A, B, C, st);
-  else if (!ca && cb) launch_gemm8<GS, QT, SUB, D, false, true>(g, A, B, C, st);
-  else launch_gemm8<GS, QT, SUB, D, true, true>(g, A, B, C, st);
+  if (!ca && !cb) launch_gemm8<GS, QT, SUB, D, IL, false, false>(g, A, B, C, st);
+  else if (ca && !cb) launch_gemm8<GS, QT, SUB, D, IL, true, false>(g, A, B, C, st);
+  else if (!ca && cb) launch_gemm8<GS, QT, SUB, D, IL, false, true>(g, A, B, C, st);
+  else launch_gemm8<GS, QT, SUB, D, IL, true, true>(g, A, B, C, st);
 }
 
 static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {

@@ -79,23 +79,20 @@ SC_DEVICE void sc_store16(cf32* dst, const sc_f4 v, const int stream) {
 inline void sc_store16(cf32* dst, const sc_f4 v, const int) { std::memcpy(dst, &v, 16); }
 #endif
 
-// `rem` stages were requested after the one needed now (PPW LDS-DMA instructions per wave and stage)
-template <int D, int PPW>
-SC_DEVICE void g8_wait_stage(const int rem) {
-  static_assert(D >= 2 && D <= 8 && PPW * 7 <= 63, "ring depth");
-  switch (rem < D - 1 ? rem : D - 1) {
-    case 0: sc_wait_vmcnt<0>(); break;
-    case 1: sc_wait_vmcnt<PPW>(); break;
-    case 2: sc_wait_vmcnt<2 * PPW>(); break;
-    case 3: sc_wait_vmcnt<3 * PPW>(); break;
-    case 4: sc_wait_vmcnt<4 * PPW>(); break;
-    case 5: sc_wait_vmcnt<5 * PPW>(); break;
-    case 6: sc_wait_vmcnt<6 * PPW>(); break;
-    default: sc_wait_vmcnt<7 * PPW>(); break;
-  }
+// wait until the stage needed now has landed: in the steady state exactly NEWER stages (PPW LDS-DMA instructions
+// per wave each) were requested after it and stay in flight; near the end of the r loop fewer exist and the wave
+// simply drains its queue
+template <int NEWER, int PPW>
+SC_DEVICE void g8_wait_stage(const int newer_issued) {
+  static_assert(NEWER >= 0 && NEWER * PPW <= 63, "vmcnt range");
+  if (newer_issued >= NEWER) sc_wait_vmcnt<NEWER * PPW>();
+  else sc_wait_vmcnt<0>();
 }
 
-template <int GS, int QT, int SUB, int D, bool CA, bool CB>
+// IL: software-pipelined stage -- the next stage's LDS-DMA requests, operand fetches and operand preparation are
+// issued BETWEEN this stage's MFMAs (a v_mfma_f32_32x32x2_f32 occupies the matrix pipe for 64 cycles, during which
+// the wave may issue other instructions), operands double-buffered in registers
+template <int GS, int QT, int SUB, int D, bool IL, bool CA, bool CB>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
 k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
   typedef Gemm8Cfg<GS, QT, SUB> K;
@@ -163,22 +160,27 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
 #pragma unroll
     for (int j = 0; j < NBW; ++j) pB[j] = srcB[j] + (int64_t)rb_k[j] * g.b_sr;
     int r_next = 0;                                       // first r of the next r pair to request
-    auto issue = [&](const int buf) {
+    // piece pc of a stage: r pair sub = pc / (1 + NBW); its A piece first, then its NBW B pieces
+    auto issue_piece = [&](const int buf, const int pc) {
       sc_f4* sb = lds + buf * K::STAGE_G;
-#pragma unroll
-      for (int sub = 0; sub < SUB; ++sub) {
+      const int sub = pc / (1 + NBW), e = pc % (1 + NBW);
+      if (e == 0) {
         const int64_t backA = (r_next + ra_k < g.R) ? 0 : (int64_t)(r_next + ra_k - (g.R - 1)) * g.a_sr;
         SC_GLDS16(pA - backA, sb + sub * K::SUB_G + w * 64);
+        pA += stepA;
+      }
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) {
+      for (int j = 0; j < NBW; ++j)
+        if (e == 1 + j) {
           const int64_t backB = (r_next + rb_k[j] < g.R) ? 0 : (int64_t)(r_next + rb_k[j] - (g.R - 1)) * g.b_sr;
           SC_GLDS16(pB[j] - backB, sb + sub * K::SUB_G + K::A_G + (w + K::NW * j) * 64);
+          pB[j] += stepB;
         }
-        pA += stepA;
+      if (e == NBW) r_next += 2;
+    };
+    auto issue = [&](const int buf) {
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) pB[j] += stepB;
-        r_next += 2;
-      }
+      for (int pc = 0; pc < K::PPW; ++pc) issue_piece(buf, pc);
     };
     struct Ops {                 // MFMA operands of one stage: (Re, Im) of both modes for this lane's row / columns
       sc_f4 a;
@@ -245,6 +247,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
       SC_SCHED_BARRIER();
     };
 
+    if constexpr (!IL) {
     // ---- prologue: D - 1 stages in flight
     sc_wait_vmcnt<0>();                 // stores of the previous tile's epilogue are counted by vmcnt too
     const int npro = NS < D - 1 ? NS : D - 1;
@@ -255,7 +258,7 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
     // the CU (measured: one workgroup alone is latency-bound whatever it does; fewer registers = more of them)
 #pragma unroll 1
     for (int st = 0; st < NS; ++st) {
-      g8_wait_stage<D, K::PPW>((NS - 1 - st) < (D - 2) ? (NS - 1 - st) : (D - 2));
+      g8_wait_stage<D - 2, K::PPW>(NS - 1 - st);
       SC_WAIT_LGKM0();
       SC_BARRIER_RAW();
       if (st + D - 1 < NS) issue((st + D - 1) % D);
@@ -267,6 +270,61 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
         prep(o[sub], 2 * (st * SUB + sub), q);
         fire(q);
       }
+    }
+    } else {
+    // ---- software-pipelined form: D stages requested ahead, operands of the next stage prepared during this one
+    sc_wait_vmcnt<0>();
+    const int npro = NS < D ? NS : D;
+    for (int st = 0; st < npro; ++st) issue(st);
+    g8_wait_stage<D - 1, K::PPW>(npro - 1);
+    SC_BARRIER_RAW();
+    Prep q0[SUB], q1[SUB];
+    {
+      Ops o[SUB];
+      fetch(0, o);
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) prep(o[sub], 2 * sub, q0[sub]);
+    }
+    constexpr int NM = SUB * 4 * QT;                       // MFMAs of a stage
+    constexpr int NF = SUB * (1 + QT);                     // operand fetches of a stage
+    static_assert(K::PPW + NF + SUB <= NM, "one filler per MFMA");
+    auto stage = [&](const int st, const Prep (&qc)[SUB], Prep (&qn)[SUB]) {
+      const bool more = st + 1 < NS;
+      if (more) {
+        g8_wait_stage<D - 2, K::PPW>(NS - 2 - st);
+        SC_WAIT_LGKM0();                // this wave's fetches of stage st are in registers
+        SC_BARRIER_RAW();               // ... everybody's: buffer st % D is free, stage st + 1 is complete
+      }
+      const bool refill = st + D < NS;
+      const sc_f4* sbn = lds + ((st + 1) % D) * K::STAGE_G;
+      Ops on[SUB];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        // MFMA m: r pair, re / im part, column tile, mode -- consecutive MFMAs write different accumulators
+        const int sub = m / (4 * QT), part = (m / (2 * QT)) & 1, u = (m >> 1) % QT, j = m & 1;
+        sc_mfma_32x32x2(acc[j][u], part ? qc[sub].ai[j] : qc[sub].ar[j], part ? qc[sub].bm[j][u] : qc[sub].br[j][u]);
+        SC_SCHED_BARRIER();
+        // filler m: one piece of work for the NEXT stages, issued while the matrix pipe is busy
+        if (m < K::PPW) {
+          if (refill) issue_piece(st % D, m);
+        } else if (m < K::PPW + NF) {
+          const int f = m - K::PPW, fs = f / (1 + QT), fe = f % (1 + QT);
+          if (more) {
+            if (fe == 0) on[fs].a = sbn[fs * K::SUB_G + a_g];
+            else on[fs].b[fe - 1] = sbn[fs * K::SUB_G + b_g + (fe - 1) * 16 * GS];
+          }
+        } else if (m < K::PPW + NF + SUB) {
+          const int ps = m - K::PPW - NF;
+          if (more) prep(on[ps], 2 * ((st + 1) * SUB + ps), qn[ps]);
+        }
+        SC_SCHED_BARRIER();
+      }
+    };
+#pragma unroll 1
+    for (int st = 0; st < NS; st += 2) {
+      stage(st, q0, q1);
+      if (st + 1 < NS) stage(st + 1, q1, q0);
+    }
     }
 
     // ---- C: per (16-column tile, RP rows) the waves fill a [RP rows][16 cols][GS slots] granule patch (each wave

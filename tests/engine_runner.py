@@ -22,7 +22,10 @@ EMU_LIB = os.path.join(EMU_DIR, "libsc_engine_emu.so")
 
 
 def emu_lib():
-    """Build (if stale) and load the host-emulation library.  TEST ONLY."""
+    """Build (if stale) and load the host-emulation library.  TEST ONLY.
+    SC_EMU_LIB=<path> loads a prebuilt variant instead (kernel shape A-B builds: g++ ... -DSC_G8_VARIANT=n)."""
+    if os.environ.get("SC_EMU_LIB"):
+        return _lib.ScEngineLib(os.environ["SC_EMU_LIB"])
     srcs = [os.path.join(ROOT, "neuraloperator_amd", "csrc", f)
             for f in os.listdir(os.path.join(ROOT, "neuraloperator_amd", "csrc"))
             if f.endswith((".h", ".cpp"))]
