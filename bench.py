@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra.* measurements")
     ap.add_argument("--no-gpu-reference", action="store_true", help="skip gpu_reference_baseline")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
-    ap.add_argument("--plan-flags", type=int, default=0, help="A/B: extra SC_PLAN_* bits (32 = SC_PLAN_SINGLE_QUEUE)")
+    ap.add_argument("--plan-flags", type=int, default=0, help="A/B: extra SC_PLAN_* bits OR-ed into the plan flags")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
                     help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
                          "bf16 = the bf16-I/O reading of BASELINE configs[1], fused 2-D kernels only")

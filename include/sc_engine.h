@@ -78,10 +78,6 @@ enum {
   SC_PLAN_COMPLEX = 8,       /* complex_data=True (:439-441, 536-538): x and y are complex (n_images,
                                 d1..dN), every dim is a complex-to-complex pass, bias must be NULL
                                 (the host adds the real bias); transforms only, no sc_layer_*      */
-  SC_PLAN_SINGLE_QUEUE = 32, /* fused 2-D kernels: always ONE launch per transform (A-B).  By default a transform over
-                                >= 1024 images is enqueued as two halves, the second on a side stream the plan owns,
-                                joined back in stream order: two free-running queues keep the load-heavy and the
-                                load-free phases of the workgroups from lining up (13-20 % per transform) */
   SC_PLAN_IO_BF16 = 16       /* the REAL tensors (x, y, gy, gx) are bfloat16 in memory -- the `float*`
                                 arguments that carry them then point at 2-byte elements; spectra,
                                 weights, bias and every arithmetic step stay float32 and y / gx are

@@ -4,8 +4,10 @@ The product loads exactly one library: ``neuraloperator_amd/libsc_engine.so``, t
 gfx950 build of ``csrc/sc_engine.cpp``.  If it is missing the import of the engine raises --
 there is no CPU or PyTorch fallback for the hot path.
 """
+import atexit
 import ctypes
 import os
+import sys
 from ctypes import (POINTER, Structure, byref, c_char_p, c_int, c_int32, c_int64, c_size_t,
                     c_void_p)
 
@@ -18,7 +20,6 @@ SC_PLAN_FFT_GEN2 = 2
 SC_PLAN_NO_MDFT = 4
 SC_PLAN_COMPLEX = 8
 SC_PLAN_IO_BF16 = 16
-SC_PLAN_SINGLE_QUEUE = 32
 SC_FREQ_DROPPED = -(1 << 63)
 SC_GEMM_FORCE_VALU = 1
 SC_GEMM_STREAM_C = 2
@@ -68,6 +69,15 @@ class EngineError(RuntimeError):
     pass
 
 
+_SHUTDOWN = False          # set at interpreter exit: device memory goes with the process, the HIP runtime may be gone
+
+
+@atexit.register
+def _mark_shutdown():
+    global _SHUTDOWN
+    _SHUTDOWN = True
+
+
 class PlanHandle:
     """Owner of one sc_plan*.  ctypes passes ``_as_parameter_``; the plan (its device twiddle / index tables) is
     released by plan_destroy() or when the last reference goes away -- the plan cache of engine.py only drops ITS
@@ -78,7 +88,7 @@ class PlanHandle:
 
     def destroy(self):
         ptr, self._as_parameter_ = self._as_parameter_, None
-        if ptr is not None and self._lib is not None:
+        if ptr is not None and self._lib is not None and not _SHUTDOWN and not sys.is_finalizing():
             try:
                 self._lib.sc_plan_destroy(ptr)
             except Exception:            # interpreter shutdown

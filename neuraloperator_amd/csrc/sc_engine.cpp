@@ -100,7 +100,6 @@ struct sc_plan {
   float* m_ax_inv[SC_MAX_DIMS] = {nullptr, nullptr, nullptr, nullptr};
   // fast path (power-of-two 2-D), see sc_kernels_fft.h
   Fft2dPlan fft2d;
-  mutable Fft3Queues queues;   // side stream + fork / join events of the two-queue transform launches
   bool fast = false;
   // weight sub-block index tables (device), keyed by (w_extent, w_start)
   std::mutex idx_mu;
@@ -177,25 +176,35 @@ static int upload_floats(sc_plan* p, const std::vector<float>& host, float** out
   return 0;
 }
 
-// A-B switches of the size-agnostic passes (measurement only), read from the environment once:
-//   SC_MDFT_TILE=4     4 accumulator tiles per wave instead of 8 (first-generation passes)
-//   SC_MDFT_NOLDS=1    first-generation last-axis passes (operands straight from global memory)
-//   SC_MDFT_NOTAIL=1   the 2^k + 1-th kept column as an MFMA tile instead of a VALU dot product
-//   SC_MDFT_NOPLANE=1  last two axes as separate passes
+// A-B switches of the size-agnostic passes: COMPILE-TIME only (measurement builds, scripts/build_variants.py);
+// the product library is built without any of them.
+//   -DSC_MDFT_TILE4    4 accumulator tiles per wave instead of 8 (first-generation passes)
+//   -DSC_MDFT_NOLDS    first-generation last-axis passes (operands straight from global memory)
+//   -DSC_MDFT_NOTAIL   the 2^k + 1-th kept column as an MFMA tile instead of a VALU dot product
+//   -DSC_MDFT_NOPLANE  last two axes as separate passes
 struct MdftSwitches {
-  bool tile4, nolds, notail, noplane;
-  MdftSwitches() {
-    const char* t = getenv("SC_MDFT_TILE");
-    tile4 = t && t[0] == '4';
-    nolds = getenv("SC_MDFT_NOLDS") != nullptr;
-    notail = getenv("SC_MDFT_NOTAIL") != nullptr;
-    noplane = getenv("SC_MDFT_NOPLANE") != nullptr;
-  }
+#ifdef SC_MDFT_TILE4
+  static constexpr bool tile4 = true;
+#else
+  static constexpr bool tile4 = false;
+#endif
+#ifdef SC_MDFT_NOLDS
+  static constexpr bool nolds = true;
+#else
+  static constexpr bool nolds = false;
+#endif
+#ifdef SC_MDFT_NOTAIL
+  static constexpr bool notail = true;
+#else
+  static constexpr bool notail = false;
+#endif
+#ifdef SC_MDFT_NOPLANE
+  static constexpr bool noplane = true;
+#else
+  static constexpr bool noplane = false;
+#endif
 };
-static const MdftSwitches& mdft_switches() {
-  static const MdftSwitches s;
-  return s;
-}
+static constexpr MdftSwitches mdft_switches() { return MdftSwitches(); }
 
 // tables of the matrix-core passes, in MFMA lane order (layouts: sc_kernels_mdft.h)
 static int build_mdft_tables(sc_plan* p) {
@@ -488,10 +497,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   }
   if (!rc && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !p->custom_map && !p->cplx) {
     std::string why;
-    if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) {
-      p->fast = true;
-      fft3_queues_init(&p->queues, !(desc->flags & (SC_PLAN_FFT_GEN2 | SC_PLAN_SINGLE_QUEUE)));
-    }
+    if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
   if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
     rc = sc_fail("sc_engine: SC_PLAN_IO_BF16 is implemented on the fused 2-D kernels (generation 3) only: "
@@ -508,7 +514,6 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
 extern "C" void sc_plan_destroy(sc_plan* p) {
   if (!p) return;
 
-  fft3_queues_destroy(&p->queues);
   for (void* q : p->owned) (void)hipFree(q);
   for (auto& kv : p->idx_cache) (void)hipFree(kv.second);
   delete p;
@@ -868,8 +873,8 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
     if (p->d.flags & SC_PLAN_IO_BF16)
-      return fft3_forward(&p->fft2d, &p->queues, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
-    return fft3_forward(&p->fft2d, &p->queues, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
+      return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
+    return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
   }
   const int L = p->nd - 1;
   int64_t lines = n_images;
@@ -929,9 +934,9 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
       return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
                            &g_last_error);
     if (p->d.flags & SC_PLAN_IO_BF16)
-      return fft3_inverse(&p->fft2d, &p->queues, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
+      return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
                           &g_last_error);
-    return fft3_inverse(&p->fft2d, &p->queues, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
+    return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
   }
   const int L = p->nd - 1;
   int64_t lpi = 1;
@@ -1051,7 +1056,6 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.b_sm = d->b_sm;
   g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
   g.b_idx = d->b_idx; g.c_idx = d->c_idx;
-  g.dbg = (d->flags >> 24) & 0xf;
   g.stream_c = (d->flags & SC_GEMM_STREAM_C) ? 1 : 0;
   // contiguous mode ranges of <= NM modes, split evenly over (workgroups per CU) x 256 CUs
   const bool paired = d->P <= 32 && (d->flags & SC_GEMM_PAIRED);
@@ -1076,57 +1080,31 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 }
 
 // ---- streamed matrix-core path (sc_kernels_gemm8.h): plain contiguous-mode operands ------------------------------
-// Shapes of the kernel (modes per workgroup x tile, waves).  Measured (profiles/r02_gemm_dma_diag_grid_layout.txt):
-// ONE workgroup needs ~33 us for its 32 stages whatever the layout or segment size -- every stage is wait + issue +
-// MFMA in lock step behind its barrier (matrix pipe 45 % busy) -- so the launch is as fast as the number of
-// INDEPENDENT workgroups a CU holds: small workgroups, several per CU.
-//   0 (default)  8 modes x 32 x 32, 4 waves, 2 r pairs per stage:  528 workgroups at the metric shape, 3 per CU
-//   1           16 modes x 32 x 32, 8 waves (128-byte segments):   264 workgroups, 2 per CU
-//   2            8 modes x 32 x 64, 4 waves:                       264 workgroups, 2 per CU
-#ifndef SC_G8_VARIANT
-#define SC_G8_VARIANT 0
-#endif
-#if SC_G8_VARIANT == 1
-#define SC_G8_CFG 8, 2, 1, 4, false
-#define SC_G8_MODES 16
-#define SC_G8_COLS 32
-#elif SC_G8_VARIANT == 2
-#define SC_G8_CFG 4, 4, 1, 6, false
-#define SC_G8_MODES 8
-#define SC_G8_COLS 64
-#elif SC_G8_VARIANT == 3
-#define SC_G8_CFG 4, 2, 1, 6, false
-#define SC_G8_MODES 8
-#define SC_G8_COLS 32
-#elif SC_G8_VARIANT == 4
-#define SC_G8_CFG 4, 2, 2, 3, true
-#define SC_G8_MODES 8
-#define SC_G8_COLS 32
-#elif SC_G8_VARIANT == 5
-#define SC_G8_CFG 8, 2, 1, 4, true
-#define SC_G8_MODES 16
-#define SC_G8_COLS 32
-#else
-#define SC_G8_CFG 4, 2, 2, 3, false
-#define SC_G8_MODES 8
-#define SC_G8_COLS 32
-#endif
-#ifndef SC_G8_RESIDENT
-#define SC_G8_RESIDENT 768     // workgroups the chip holds at once (3 per CU)
-#endif
+// Two shapes of the kernel are built into the library (profiles/r02_gemm_dma_v3_shapes_ab.txt):
+//   narrow   8 modes x 32 x 32 tiles, 4 waves, 2 r pairs per stage, plain stage loop: 528 workgroups for the forward
+//            / gX contraction of the metric shape (45 us; 16 modes x 8 waves: 54 us)
+//   wide    16 modes x 32 x 32 tiles, 8 waves, 128-byte segments, software-pipelined stage: calls with >= 4 tiles per
+//            mode group (the weight gradient: 46.6 against 51.2 us; hidden 128: 131 / 173 / 146 against 150 / 224 / 149 us,
+//            and the store-dominated hidden-128 weight gradient of the 1024^2 config 1.38 against 2.1 ms)
+// Measured (profiles/r02_gemm_dma_diag_grid_layout.txt): ONE workgroup needs ~33 us for its stages whatever the
+// operand layout, segment size, ring depth or instruction order -- so a launch is as fast as its busiest CU.
+#define SC_G8_NARROW 4, 2, 2, 3, false
+#define SC_G8_WIDE 8, 2, 1, 4, true
+// workgroups the chip holds at once: narrow 3 per CU (48 KiB of LDS each), wide 2 per CU (64 KiB)
+#define SC_G8_RESIDENT(wide) ((wide) ? 512 : 768)
 static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
   if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM)) return false;
   if (d->accumulate || d->b_idx || d->c_idx) return false;
   if (d->a_sm != 1 || d->b_sm != 1 || d->c_sm != 1) return false;
-  if (d->n_modes % SC_G8_MODES != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
+  if (d->n_modes % 8 != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
   if ((d->a_sg || d->b_sg || d->c_sg) && d->n_modes % 16 != 0) return false;        // tiled operands: groups of 16
   if ((d->a_sg | d->b_sg | d->c_sg) & 1) return false;
   // 16-byte granules: every row / column of every operand must start on an even complex element
   if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
-  // tiles are 32 rows x SC_G8_COLS columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as
+  // tiles are 32 rows x 32 columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as
   // 36 stay on the 64-row tiles of k_modegemm_mfma)
-  const int64_t cols = SC_G8_COLS;
+  const int64_t cols = 32;
   const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + cols - 1) / cols * cols;
   if (4 * d->P < 3 * Pp || 4 * d->Q < 3 * Qp) return false;
   if (d->R < 4) return false;
@@ -1149,7 +1127,16 @@ static void dispatch_gemm8(const Gemm8Args& g, int ca, int cb, const cf32* A, co
 }
 
 static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  const int64_t cols = SC_G8_COLS, modes = SC_G8_MODES;
+  const int64_t cols = 32;
+  const int64_t tiles = ((d->P + 31) / 32) * ((d->Q + cols - 1) / cols);
+#if defined(SC_G8_FORCE_NARROW)          // measurement builds only
+  const bool wide = false;
+#elif defined(SC_G8_FORCE_WIDE)
+  const bool wide = d->n_modes % 16 == 0;
+#else
+  const bool wide = d->n_modes % 16 == 0 && tiles >= 4;
+#endif
+  const int64_t modes = wide ? 16 : 8;
   Gemm8Args g;
   g.P = (int)d->P; g.Q = (int)d->Q; g.R = (int)d->R;
   g.n_mg = (int)(d->n_modes / modes);
@@ -1166,10 +1153,10 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   // inside fewer workgroups instead of queueing a short second round
   const int64_t nblk = (int64_t)g.n_pb * g.n_qb;
   int64_t bpw = 1;
-  if (g.n_mg <= SC_G8_RESIDENT && g.n_mg * nblk > SC_G8_RESIDENT) {
+  if (g.n_mg <= SC_G8_RESIDENT(wide) && g.n_mg * nblk > SC_G8_RESIDENT(wide)) {
     bpw = nblk;
     for (int64_t b = 1; b <= nblk; ++b)
-      if (g.n_mg * ((nblk + b - 1) / b) <= SC_G8_RESIDENT) {
+      if (g.n_mg * ((nblk + b - 1) / b) <= SC_G8_RESIDENT(wide)) {
         bpw = b;
         break;
       }
@@ -1178,7 +1165,8 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   if (cap > 0 && cap <= nblk) bpw = cap;
   g.bpw = (int)bpw;
   g.G = (int)(g.n_mg * ((nblk + bpw - 1) / bpw));
-  dispatch_gemm8<SC_G8_CFG>(g, d->conj_a, d->conj_b, A, B, C, st);
+  if (wide) dispatch_gemm8<SC_G8_WIDE>(g, d->conj_a, d->conj_b, A, B, C, st);
+  else dispatch_gemm8<SC_G8_NARROW>(g, d->conj_a, d->conj_b, A, B, C, st);
   return sc_check_launch("k_modegemm_dma");
 }
 

@@ -351,7 +351,7 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 template <int H, typename IO>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? 4 : 3))
 k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
-             int channels, int chan0, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
+             int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
              float s_dc, float s_other) {
   constexpr int P = H / 64;
   typedef F3Lds<H> L;
@@ -381,7 +381,7 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
   }
   cf32* IN = T;
   for (int i = tid; i < Mx * My; i += 256) IN[i] = src[i];
-  const float badd = (bias != nullptr) ? bias[(img + chan0) % channels] : 0.f;   // chan0: channel of image 0 of this launch
+  const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
 
   const int k1l = lam >> 2, n4 = lam & 3;
   ctw3 tw1c[8];
@@ -513,100 +513,31 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-// ---- two hardware queues per transform ----------------------------------------------------------------------------
-// The workgroups of ONE launch start in lock step and keep their load-heavy row phases and load-free column phases
-// aligned; the same images launched as two halves on two queues run 13-20 % faster (profiles/r01_stream_overlap.txt:
-// fwd 2 x 1024 images 102 us against 117-125 us for one launch of 2048).  A plan therefore owns a side stream and a
-// fork / join event pair; a transform over >= SC_F3_SPLIT_MIN images enqueues its second half there.  The fork / join
-// is stream-ordered (hipEventRecord / hipStreamWaitEvent only), so the call still never blocks the host and still
-// records into a HIP graph.
-#ifndef SC_F3_SPLIT_MIN
-#define SC_F3_SPLIT_MIN 1024
-#endif
-struct Fft3Queues {
-#ifndef SC_EMU
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  std::mutex mu;                       // one fork / join at a time per plan (calls from several host threads)
-#endif
-  bool enabled = false;
-};
-
-static inline void fft3_queues_init(Fft3Queues* q, bool enable) {
-#ifndef SC_EMU
-  if (!enable) return;
-  if (hipStreamCreateWithFlags(&q->side, hipStreamNonBlocking) != hipSuccess) return;
-  if (hipEventCreateWithFlags(&q->fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&q->join, hipEventDisableTiming) != hipSuccess)
-    return;
-  q->enabled = true;
-#else
-  (void)q; (void)enable;
-#endif
-}
-
-static inline void fft3_queues_destroy(Fft3Queues* q) {
-#ifndef SC_EMU
-  if (q->fork) (void)hipEventDestroy(q->fork);
-  if (q->join) (void)hipEventDestroy(q->join);
-  if (q->side) (void)hipStreamDestroy(q->side);
-  q->side = nullptr; q->fork = q->join = nullptr;
-#endif
-  q->enabled = false;
-}
-
-// run launch(first image, image count, stream) once, or as two halves on two queues
-template <typename F>
-static inline void fft3_split_launch(Fft3Queues* q, int64_t n_images, sc_stream_t st, F launch) {
-#ifndef SC_EMU
-  if (q && q->enabled && n_images >= SC_F3_SPLIT_MIN) {
-    std::lock_guard<std::mutex> lock(q->mu);
-    const int64_t n0 = (n_images / 2 + 63) / 64 * 64;           // whole channel groups where possible
-    if (hipEventRecord(q->fork, st) == hipSuccess && hipStreamWaitEvent(q->side, q->fork, 0) == hipSuccess) {
-      launch((int64_t)0, n0, st);
-      launch(n0, n_images - n0, q->side);
-      if (hipEventRecord(q->join, q->side) == hipSuccess && hipStreamWaitEvent(st, q->join, 0) == hipSuccess) return;
-      (void)hipStreamSynchronize(q->side);                      // could not join in stream order: join on the host
-      return;
-    }
-  }
-#else
-  (void)q;
-#endif
-  launch((int64_t)0, n_images, st);
-}
-
 template <int H, typename IO>
-static void fft3_launch_fwd(const Fft2dPlan* fp, Fft3Queues* q, const IO* x, cf32* xhat, int64_t n_images, float s_dc,
+static void fft3_launch_fwd(const Fft2dPlan* fp, const IO* x, cf32* xhat, int64_t n_images, float s_dc,
                             float s_other, sc_stream_t st) {
-  fft3_split_launch(q, n_images, st, [&](int64_t i0, int64_t n, sc_stream_t s) {
-    SC_LAUNCH((k_fft2d_fwd3<H, IO>), dim3((unsigned)n), dim3(256), 0, s, x + i0 * (int64_t)H * SC_F2D_W,
-              xhat + i0 * (int64_t)fp->Mx * fp->My, (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc,
-              s_other);
-  });
+  SC_LAUNCH((k_fft2d_fwd3<H, IO>), dim3((unsigned)n_images), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
+            (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
 }
 
 template <int H, typename IO>
-static void fft3_launch_inv(const Fft2dPlan* fp, Fft3Queues* q, const cf32* yhat, IO* y, const float* bias, int channels,
+static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const float* bias, int channels,
                             int64_t n_images, float s_dc, float s_other, sc_stream_t st) {
-  fft3_split_launch(q, n_images, st, [&](int64_t i0, int64_t n, sc_stream_t s) {
-    SC_LAUNCH((k_fft2d_inv3<H, IO>), dim3((unsigned)n), dim3(256), 0, s, yhat + i0 * (int64_t)fp->Mx * fp->My,
-              y + i0 * (int64_t)H * SC_F2D_W, bias, channels, (int)(i0 % channels), (const cf32*)fp->tabW,
-              (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
-  });
+  SC_LAUNCH((k_fft2d_inv3<H, IO>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels,
+            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
 }
 
 // x / y: float32, or bfloat16 storage when the plan carries SC_PLAN_IO_BF16 (IO = sc_bf16)
 template <typename IO>
-static inline int fft3_forward(const Fft2dPlan* fp, Fft3Queues* q, int mode, const IO* x, cf32* xhat, int64_t n_images,
+static inline int fft3_forward(const Fft2dPlan* fp, int mode, const IO* x, cf32* xhat, int64_t n_images,
                                sc_stream_t st, std::string* err) {
   const float s_dc = (mode == 0) ? fp->sf : fp->si;
   const float s_other = (mode == 0) ? fp->sf : 2.f * fp->si;
   switch (fp->H) {
-    case 64: fft3_launch_fwd<64, IO>(fp, q, x, xhat, n_images, s_dc, s_other, st); break;
-    case 128: fft3_launch_fwd<128, IO>(fp, q, x, xhat, n_images, s_dc, s_other, st); break;
-    case 256: fft3_launch_fwd<256, IO>(fp, q, x, xhat, n_images, s_dc, s_other, st); break;
-    case 512: fft3_launch_fwd<512, IO>(fp, q, x, xhat, n_images, s_dc, s_other, st); break;
+    case 64: fft3_launch_fwd<64, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 128: fft3_launch_fwd<128, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 256: fft3_launch_fwd<256, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 512: fft3_launch_fwd<512, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {
@@ -617,15 +548,15 @@ static inline int fft3_forward(const Fft2dPlan* fp, Fft3Queues* q, int mode, con
 }
 
 template <typename IO>
-static inline int fft3_inverse(const Fft2dPlan* fp, Fft3Queues* q, int mode, const cf32* yhat, const float* bias,
+static inline int fft3_inverse(const Fft2dPlan* fp, int mode, const cf32* yhat, const float* bias,
                                int64_t channels, IO* y, int64_t n_images, sc_stream_t st, std::string* err) {
   const float s_dc = (mode == 0) ? fp->si : fp->sf;
   const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
   switch (fp->H) {
-    case 64: fft3_launch_inv<64, IO>(fp, q, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 128: fft3_launch_inv<128, IO>(fp, q, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 256: fft3_launch_inv<256, IO>(fp, q, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 512: fft3_launch_inv<512, IO>(fp, q, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 64: fft3_launch_inv<64, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 128: fft3_launch_inv<128, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 256: fft3_launch_inv<256, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 512: fft3_launch_inv<512, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {

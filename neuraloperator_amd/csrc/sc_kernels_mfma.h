@@ -37,6 +37,9 @@
 #include "sc_device.h"
 
 #define SC_MG_RC 8
+#ifndef SC_MG_ABLATE
+#define SC_MG_ABLATE 0
+#endif
 #ifndef SC_MG_PF
 #define SC_MG_PF 1      // stages of operand loads in flight (1 or 2), see k_modegemm_mfma
 #endif
@@ -112,7 +115,8 @@ struct MfmaGemmArgs {
   int64_t c_sp, c_sq, c_sm;
   const int32_t* b_idx;
   const int32_t* c_idx;
-  int dbg;             // ablation bits (bench only): 1 skip MFMA, 2 skip C stores, 4 skip operand loads
+  // (ablation of the kernel's phases is a COMPILE-TIME switch of measurement builds: -DSC_MG_ABLATE=bits with
+  //  1 skip MFMA, 2 skip C stores, 4 skip operand loads; the product library is built without it)
   int stream_c;        // 1: C is not read by the next kernel -> non-temporal stores
 };
 
@@ -283,9 +287,7 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   };
 
   const int nck = (g.R + RC - 1) / RC;
-#ifndef SC_EMU
-  long long dbg_t0 = 0, dbg_w0 = 0;
-#endif
+  constexpr int dbg = SC_MG_ABLATE;
   auto pin_acc = [&]() {
 #ifndef SC_EMU
     if constexpr (K::NW == 4) {
@@ -298,16 +300,13 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
     }
 #endif
   };
-  const bool ld = !(g.dbg & 4);
+  constexpr bool ld = !(dbg & 4);
   issue(0, ra0, rb0);
 #if SC_MG_PF == 2
   if (nck > 1 && ld) issue(RC, ra1, rb1);
 #endif
   commit(lds, 0, ra0, rb0);
   SC_SYNC();
-#ifndef SC_EMU
-  if (g.dbg & 8) { dbg_t0 = clock64(); dbg_w0 = wall_clock64(); }
-#endif
 #if SC_MG_PF == 2
   // two stages per trip so that the register sets alternate statically: even stages come from set 0 / LDS
   // buffer 0, odd ones from set 1 / buffer 1
@@ -316,20 +315,16 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
 #pragma unroll 1
   for (int ck = 0; ck < nck; ck += 2) {
     if (ck + 2 < nck && ld) issue((ck + 2) * RC, ra0, rb0);
-    if (!(g.dbg & 1)) compute(l0);
+    if (!(dbg & 1)) compute(l0);
     pin_acc();
-    if (!(g.dbg & 8)) {
-      if (ck + 1 < nck) commit(l1, (ck + 1) * RC, ra1, rb1);
-      SC_SYNC();
-    }
+    if (ck + 1 < nck) commit(l1, (ck + 1) * RC, ra1, rb1);
+    SC_SYNC();
     if (ck + 1 >= nck) break;
     if (ck + 3 < nck && ld) issue((ck + 3) * RC, ra1, rb1);
-    if (!(g.dbg & 1)) compute(l1);
+    if (!(dbg & 1)) compute(l1);
     pin_acc();
-    if (!(g.dbg & 8)) {
-      if (ck + 2 < nck) commit(l0, (ck + 2) * RC, ra0, rb0);
-      SC_SYNC();
-    }
+    if (ck + 2 < nck) commit(l0, (ck + 2) * RC, ra0, rb0);
+    SC_SYNC();
   }
 #else
 #pragma unroll 1
@@ -338,9 +333,8 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
     float* nxt = lds + ((ck + 1) & 1) * K::STAGE;
     const bool more = ck + 1 < nck;
     if (more && ld) issue((ck + 1) * RC, ra0, rb0);
-    if (!(g.dbg & 1)) compute(cur);
+    if (!(dbg & 1)) compute(cur);
     pin_acc();
-    if (g.dbg & 8) continue;
     if (more) commit(nxt, (ck + 1) * RC, ra0, rb0);
     SC_SYNC();
   }
@@ -351,13 +345,7 @@ k_modegemm_mfma(MfmaGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   //      buffers are free after the last barrier) into (row, column, mode) order and leave as
   //      nm*8-byte segments -- the same access shape as the operand loads.  The waves sharing a
   //      tile fill the patch together and split the segment stores.
-#ifndef SC_EMU
-  if ((g.dbg & 8) && tid == 0 && SC_BID_X < 8) {   // bench only: cycles of the bare MFMA loop
-    reinterpret_cast<long long*>(C)[2 * SC_BID_X] = clock64() - dbg_t0;
-    reinterpret_cast<long long*>(C)[2 * SC_BID_X + 1] = wall_clock64() - dbg_w0;
-  }
-#endif
-  if (g.dbg & 2) {
+  if (dbg & 2) {
     if (acc[0][0][0] != 12345.678f) return;
   }
   constexpr int NST = (128 + K::SPI_MIN - 1) / K::SPI_MIN;

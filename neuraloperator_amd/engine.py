@@ -72,7 +72,9 @@ def get_plan_bf16_io(device, spatial, kept, fft_norm, flags):
 
 @atexit.register
 def _destroy_plans():
-    # device memory is reclaimed with the process; only drop the handles
+    # device memory is reclaimed with the process: the handles are dropped without calling into the library
+    # (_lib marks the shutdown first: atexit handlers run in reverse order of registration, _lib is imported earlier)
+    _lib._SHUTDOWN = True
     _PLANS.clear()
 
 

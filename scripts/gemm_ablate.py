@@ -1,41 +1,41 @@
-"""Time the three layer contractions through the C-ABI, warm and cold (a 600 MB write between
-launches), with the MFMA kernel's ablation bits.  Usage: python scripts/gemm_ablate.py"""
-import os, sys
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from neuraloperator_amd import _lib
+"""Phase ablation of the generation-1 matrix-core contraction (k_modegemm_mfma).  The switches are COMPILE-TIME
+(-DSC_MG_ABLATE=bits: 1 skip MFMA, 2 skip C stores, 4 skip operand loads), so build the variants first:
+    python scripts/build_variants.py g1_nomfma=SC_MG_ABLATE=1 g1_nostore=SC_MG_ABLATE=2 g1_noload=SC_MG_ABLATE=4 \\
+        g1_loadsonly=SC_MG_ABLATE=3 g1_mfmaonly=SC_MG_ABLATE=6
+    python scripts/gemm_ablate.py neuraloperator_amd/libsc_engine.so neuraloperator_amd/libsc_engine_g1_*.so
+(us per launch of the forward contraction at the metric shape, generation 1 forced with SC_GEMM_NO_STREAM;
+round-1 numbers: profiles/r01_mfma_gemm_ablation.txt)."""
+import os
+import sys
 
-lib = _lib.get_lib()
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuraloperator_amd import _lib  # noqa: E402
+
 dev = torch.device("cuda:0")
+st = torch.cuda.current_stream().cuda_stream
 B, C, M = 32, 64, 2112
 xh = torch.randn(B, C, M, 2, device=dev)
-gh = torch.randn(B, C, M, 2, device=dev)
 w = torch.randn(C, C, M, 2, device=dev)
-out_s = torch.empty(B, C, M, 2, device=dev)
-out_w = torch.empty(C, C, M, 2, device=dev)
-junk = torch.empty(600 * 1024 * 1024 // 4, device=dev)
-st = torch.cuda.current_stream().cuda_stream
-kws = {
-    "fwd": (xh, w, out_s, dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1, b_sr=C * M, b_sq=M, b_sm=1, c_sp=C * M, c_sq=M, c_sm=1)),
-    "gx": (gh, w, out_s, dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1, b_sr=M, b_sq=C * M, b_sm=1, conj_b=1, c_sp=C * M, c_sq=M, c_sm=1)),
-    "gw": (xh, gh, out_w, dict(P=C, Q=C, R=B, n_modes=M, a_sp=M, a_sr=C * M, a_sm=1, conj_a=1, b_sr=C * M, b_sq=M, b_sm=1, c_sp=C * M, c_sq=M, c_sm=1)),
-}
-
-def t(fn, cold, iters=10):
-    fn(); torch.cuda.synchronize()
-    tot = 0.0
-    for _ in range(iters):
-        if cold:
-            junk.fill_(1.0)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        tot += e0.elapsed_time(e1)
-    return tot / iters * 1e3
-
-variants = [("full", 0), ("no-mfma", 1 << 24), ("no-store", 2 << 24), ("no-load", 4 << 24),
-            ("no-mfma no-store", 3 << 24), ("loads only(no mfma/store)", 3 << 24), ("mfma only", 6 << 24), ("mfma only, no commit/barrier", 14 << 24),
-            ("paired (2 WG/CU, 5 modes)", _lib.SC_GEMM_PAIRED), ("VALU kernel", _lib.SC_GEMM_FORCE_VALU)]
-for name, (a, b, c, kw) in list(kws.items()):
-    for vn, fl in variants:
-        fn = lambda: lib.modegemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), st, flags=fl, **kw)
-        print(f"{name:4s} {vn:28s} warm {t(fn, False):8.1f} us   cold {t(fn, True):8.1f} us", flush=True)
+out = torch.empty(B, C, M, 2, device=dev)
+junk = torch.empty(600 * 1024 * 1024 // 4, device=dev).normal_()
+kw = dict(flags=_lib.SC_GEMM_NO_STREAM, P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1, b_sr=C * M, b_sq=M,
+          b_sm=1, c_sp=C * M, c_sq=M, c_sm=1)
+for path in sys.argv[1:] or [_lib.DEFAULT_LIB]:
+    lib = _lib.ScEngineLib(path)
+    fn = lambda: lib.modegemm(xh.data_ptr(), w.data_ptr(), out.data_ptr(), st, **kw)
+    res = {}
+    for cold in (False, True):
+        ts = []
+        for _ in range(12):
+            if cold:
+                junk.sum()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        res["cold" if cold else "warm"] = sorted(ts)[len(ts) // 2]
+    print(f"{os.path.basename(path):40s} warm {res['warm']:6.1f} us   cold {res['cold']:6.1f} us", flush=True)

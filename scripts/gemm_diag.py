@@ -56,7 +56,7 @@ def run(tag, B, C, M, layout, flags=0):
           " | ".join(f"{m} {v:6.1f} us {nbytes / v / 1e6:5.2f} TB/s" for m, v in t.items()), flush=True)
 
 
-for M in (528, 1056, 2112, 4224, 8448):
+for M in (1024, 2048, 2112, 3072, 4096, 8448):
     run(f"plain M={M}", 32, 64, M, "")
 for lay in ("", "AC", "B", "ABC"):
     run(f"M=2112 tiled[{lay or '-'}]", 32, 64, 2112, lay)

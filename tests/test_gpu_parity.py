@@ -611,46 +611,6 @@ def test_optimizer_matches_reference_trajectory(name):
         AdamW([pc], galore_params=[pr])
 
 
-def test_two_queue_transforms_match_single_queue_and_capture():
-    """>= 1024 images on the fused 2-D kernels: a transform is enqueued as two halves on two hardware queues (fork /
-    join in stream order inside the engine).  Same bits as the single launch (SC_PLAN_SINGLE_QUEUE), the bias of the
-    second half starts at the right channel, and the step still records into a HIP graph."""
-    from neuraloperator_amd import SpectralConv, _lib
-    dev = torch.device("cuda:0")
-    torch.manual_seed(8)
-    conv2 = SpectralConv(24, 40, (16, 16)).to(dev)                       # 16 x 24 = 384 / 16 x 40 = 640 images: one queue
-    conv = SpectralConv(72, 88, (16, 16)).to(dev)                        # 16 x 72 = 1152, 16 x 88 = 1408: two queues
-    single = SpectralConv(72, 88, (16, 16), engine_flags=_lib.SC_PLAN_SINGLE_QUEUE).to(dev)
-    single.load_state_dict(conv.state_dict())
-    x = torch.randn(16, 72, 64, 256, device=dev, requires_grad=True)
-    g = torch.randn(16, 88, 64, 256, device=dev)
-
-    def step(m):
-        y = m(x)
-        return (y,) + torch.autograd.grad(y, (x, m.weight.tensor, m.bias), g)
-
-    a, b = step(conv), step(single)
-    for t, u in zip(a, b):
-        assert torch.equal(t, u)
-    assert conv2(torch.randn(16, 24, 64, 256, device=dev)).shape == (16, 40, 64, 256)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        step(conv)
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = step(conv)
-    with torch.no_grad():
-        x.copy_(torch.randn_like(x))
-    graph.replay()
-    torch.cuda.synchronize()
-    want = step(single)
-    for t, u in zip(out, want):
-        assert torch.equal(t, u)
-
-
 def test_layer_step_is_graph_capturable():
     """A whole forward+backward of the layer records into a HIP graph (torch.cuda.CUDAGraph) and replays:
     every C-ABI call only enqueues work on the stream it is given -- no synchronisation, no allocation of
