@@ -205,6 +205,27 @@ int sc_layer_backward(const sc_plan* plan, const sc_layer_desc* L, const float* 
                       const float* xhat_saved, const float* w, float* gx, float* gw,
                       float* gbias, void* workspace, void* stream);
 
+/* ---- block epilogue (first "next" row f1 of SURVEY.md section 8) ---------------------------------------------------
+ * The FNO block computes act(conv(x) + skip(x)) around the spectral convolution (neuralop/layers/fno_block.py:392-414:
+ * x_fno + x_skip_fno, then the non-linearity) -- three more passes over tensors of the activation's size.  With an
+ * epilogue the inverse transform adds `skip` (same shape and storage type as y) and applies the activation while it
+ * stores:  y = act(irfft(...) + bias + skip).  preact (optional, same shape) receives the value before the
+ * activation, which the backward of the activation needs.  On the fused 2-D kernels this happens in the store path of
+ * the inverse transform (one extra read of the activation's size); other shapes run one streaming pass after it. */
+enum { SC_ACT_NONE = 0, SC_ACT_GELU = 1 };     /* GELU: exact (erf), torch.nn.functional.gelu's default */
+typedef struct {
+  const float* skip;        /* device, (n_images, d1..dN); NULL = no epilogue at all          */
+  float* preact;            /* device, optional                                                 */
+  int32_t act;              /* SC_ACT_*                                                         */
+  int32_t reserved;
+} sc_epilogue;
+
+int sc_transform_inverse_ex(const sc_plan* plan, int mode, const float* yhat, const float* bias, int64_t channels,
+                            const sc_epilogue* ep, float* y, int64_t n_images, void* workspace, void* stream);
+int sc_layer_forward_ex(const sc_plan* plan, const sc_layer_desc* L, const float* x, const float* w,
+                        const float* bias, const sc_epilogue* ep, float* y, float* xhat_saved, void* workspace,
+                        void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 const char* sc_last_error(void);
 const char* sc_version(void);

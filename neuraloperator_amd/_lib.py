@@ -65,6 +65,13 @@ class LayerDesc(Structure):
                 ("w_extent", c_int64 * SC_MAX_DIMS), ("w_start", c_int64 * SC_MAX_DIMS)]
 
 
+class Epilogue(Structure):
+    _fields_ = [("skip", c_void_p), ("preact", c_void_p), ("act", c_int32), ("reserved", c_int32)]
+
+
+SC_ACT_NONE, SC_ACT_GELU = 0, 1
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -107,7 +114,8 @@ class ScEngineLib:
                "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
                "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
-               "sc_last_error", "sc_version", "sc_plan_kernel_name"]
+               "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
+               "sc_layer_forward_ex"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -152,6 +160,12 @@ class ScEngineLib:
         L.sc_layer_workspace_bytes.restype = c_size_t
         L.sc_layer_forward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 7
         L.sc_layer_forward.restype = c_int
+        L.sc_transform_inverse_ex.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int64, POINTER(Epilogue),
+                                              c_void_p, c_int64, c_void_p, c_void_p]
+        L.sc_transform_inverse_ex.restype = c_int
+        L.sc_layer_forward_ex.argtypes = [c_void_p, POINTER(LayerDesc), c_void_p, c_void_p, c_void_p,
+                                          POINTER(Epilogue), c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sc_layer_forward_ex.restype = c_int
         L.sc_layer_backward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 8
         L.sc_layer_backward.restype = c_int
         L.sc_last_error.restype = c_char_p
@@ -266,6 +280,17 @@ class ScEngineLib:
     def layer_forward(self, plan, L, x, w, bias, y, xhat_saved, ws, stream=0):
         self._check(self.lib.sc_layer_forward(plan, byref(L), x, w, bias, y, xhat_saved, ws,
                                               stream))
+
+    def layer_forward_ex(self, plan, L, x, w, bias, skip, preact, act, y, xhat_saved, ws, stream=0):
+        """forward with the block epilogue y = act(layer(x) + skip) (include/sc_engine.h, sc_epilogue)"""
+        ep = Epilogue(skip, preact, act, 0)
+        self._check(self.lib.sc_layer_forward_ex(plan, byref(L), x, w, bias, byref(ep), y, xhat_saved, ws, stream))
+
+    def transform_inverse_ex(self, plan, mode, yhat_ptr, bias_ptr, channels, skip, preact, act, y_ptr, n_images,
+                             ws_ptr, stream=0):
+        ep = Epilogue(skip, preact, act, 0)
+        self._check(self.lib.sc_transform_inverse_ex(plan, mode, yhat_ptr, bias_ptr, channels, byref(ep), y_ptr,
+                                                     n_images, ws_ptr, stream))
 
     def layer_backward(self, plan, L, gy, xhat_saved, w, gx, gw, gbias, ws, stream=0):
         self._check(self.lib.sc_layer_backward(plan, byref(L), gy, xhat_saved, w, gx, gw,

@@ -920,23 +920,53 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
   return 0;
 }
 
+static int run_epilogue_pass(const sc_plan* p, const sc_epilogue* ep, float* y, int64_t n_images, sc_stream_t st) {
+  const int64_t n = n_images * p->ntot;
+  int64_t blocks = (n + SC_BLOCK - 1) / SC_BLOCK;
+  if (blocks > 16384) blocks = 16384;
+  SC_LAUNCH(k_epilogue, dim3((unsigned)blocks), dim3(SC_BLOCK), 0, st, y, ep->skip, ep->preact, (int)ep->act, n,
+            blocks * SC_BLOCK);
+  return sc_check_launch("k_epilogue");
+}
+
 extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yhat, const float* bias,
                                     int64_t channels, float* y, int64_t n_images, void* workspace,
                                     void* stream) {
+  return sc_transform_inverse_ex(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream);
+}
+
+extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* yhat, const float* bias,
+                                       int64_t channels, const sc_epilogue* ep, float* y, int64_t n_images,
+                                       void* workspace, void* stream) {
   SC_CHECK_ARG(p, "null argument");
+  if (ep && !ep->skip) ep = nullptr;
+  if (ep) {
+    SC_CHECK_ARG(ep->act == SC_ACT_NONE || ep->act == SC_ACT_GELU, "unknown activation");
+    SC_CHECK_ARG(!p->cplx, "complex-data plans take no epilogue");
+    SC_CHECK_ARG(mode == SC_INV_PADDED, "the epilogue belongs to the forward inverse transform (SC_INV_PADDED)");
+  }
+  const int epi = ep ? (ep->act == SC_ACT_GELU ? 2 : 1) : 0;
   SC_CHECK_ARG(mode == SC_INV_PADDED || mode == SC_INV_ADJ_R2C, "bad inverse mode");
   if (n_images <= 0) return 0;
   SC_CHECK_ARG(yhat && y, "null argument");
   if (channels <= 0) channels = 1;
   sc_stream_t st = (sc_stream_t)stream;
   if (p->fast) {
-    if (p->d.flags & SC_PLAN_FFT_GEN2)
-      return fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
-                           &g_last_error);
+    if (p->d.flags & SC_PLAN_FFT_GEN2) {
+      int rc2 = fft2d_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st,
+                              &g_last_error);
+      return (rc2 || !ep) ? rc2 : run_epilogue_pass(p, ep, y, n_images, st);
+    }
     if (p->d.flags & SC_PLAN_IO_BF16)
       return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
-                          &g_last_error);
-    return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error);
+                          &g_last_error, epi, ep ? (const sc_bf16*)ep->skip : nullptr,
+                          ep ? (sc_bf16*)ep->preact : nullptr);
+    return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error, epi,
+                        ep ? ep->skip : nullptr, ep ? ep->preact : nullptr);
+  }
+  if (ep) {                                  // size-agnostic passes: the plain transform, then one streaming pass
+    int rc2 = sc_transform_inverse_ex(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream);
+    return rc2 ? rc2 : run_epilogue_pass(p, ep, y, n_images, st);
   }
   const int L = p->nd - 1;
   int64_t lpi = 1;
@@ -1083,9 +1113,11 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 // Two shapes of the kernel are built into the library (profiles/r02_gemm_dma_v3_shapes_ab.txt):
 //   narrow   8 modes x 32 x 32 tiles, 4 waves, 2 r pairs per stage, plain stage loop: 528 workgroups for the forward
 //            / gX contraction of the metric shape (45 us; 16 modes x 8 waves: 54 us)
-//   wide    16 modes x 32 x 32 tiles, 8 waves, 128-byte segments, software-pipelined stage: calls with >= 4 tiles per
-//            mode group (the weight gradient: 46.6 against 51.2 us; hidden 128: 131 / 173 / 146 against 150 / 224 / 149 us,
-//            and the store-dominated hidden-128 weight gradient of the 1024^2 config 1.38 against 2.1 ms)
+//   wide    16 modes x 32 x 32 tiles, 8 waves, 128-byte segments, software-pipelined stage: calls with >= 8 tiles per
+//            mode group (hidden 128: weight gradient 173 against 224 us, and the store-dominated weight gradient of
+//            the 1024^2 config 1.38 against 2.1 ms).  The metric shape's weight gradient (4 tiles) measures 46.6
+//            against 51.2 us stand-alone but 63.9 against 53.5 us INSIDE a step (profiles/r02_gpu6_kernel_stats.txt:
+//            its operands come from HBM there) and stays on the narrow shape
 // Measured (profiles/r02_gemm_dma_diag_grid_layout.txt): ONE workgroup needs ~33 us for its stages whatever the
 // operand layout, segment size, ring depth or instruction order -- so a launch is as fast as its busiest CU.
 #define SC_G8_NARROW 4, 2, 2, 3, false
@@ -1134,7 +1166,7 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
 #elif defined(SC_G8_FORCE_WIDE)
   const bool wide = d->n_modes % 16 == 0;
 #else
-  const bool wide = d->n_modes % 16 == 0 && tiles >= 4;
+  const bool wide = d->n_modes % 16 == 0 && tiles >= 8;
 #endif
   const int64_t modes = wide ? 16 : 8;
   Gemm8Args g;
@@ -1363,6 +1395,12 @@ static int64_t weight_slab(const sc_plan* p, const sc_layer_desc* L) {
 extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const float* x, const float* w,
                                 const float* bias, float* y, float* xhat_saved, void* workspace,
                                 void* stream) {
+  return sc_layer_forward_ex(p, L, x, w, bias, nullptr, y, xhat_saved, workspace, stream);
+}
+
+extern "C" int sc_layer_forward_ex(const sc_plan* p, const sc_layer_desc* L, const float* x, const float* w,
+                                   const float* bias, const sc_epilogue* ep, float* y, float* xhat_saved,
+                                   void* workspace, void* stream) {
   SC_CHECK_ARG(p && L, "null argument");
   SC_CHECK_ARG(!p->cplx, "complex-data plans: call the transform / contraction stages (no fused layer)");
   const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
@@ -1388,7 +1426,7 @@ extern "C" int sc_layer_forward(const sc_plan* p, const sc_layer_desc* L, const 
   g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
   rc = sc_modegemm(&g, xhat_saved, w, yhat, stream);
   if (rc) return rc;
-  return sc_transform_inverse(p, SC_INV_PADDED, yhat, bias, Co, y, B * Co, ws, stream);
+  return sc_transform_inverse_ex(p, SC_INV_PADDED, yhat, bias, Co, ep, y, B * Co, ws, stream);
 }
 
 extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const float* gy,

@@ -83,6 +83,22 @@ SC_DEVICE void f3_store(sc_bf16* row, const int lam, const int j, const float v)
   SC_STORE_STREAM(&row[lam + 32 * j].v, sc_f32_to_bf16_bits(v));
 }
 
+// ---- block epilogue fused into the inverse transform's store path (the FNO block computes
+//      act(conv(x) + skip(x)), neuralop/layers/fno_block.py:392-414, as three more R-sized passes):
+//      EPI 0: y = v;  EPI 1: y = v + skip;  EPI 2: y = gelu(v + skip) with the pre-activation optionally saved for
+//      the backward pass.  gelu = torch's default (exact, erf based).
+SC_DEVICE float sc_gelu(const float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+template <int EPI, typename IO>
+SC_DEVICE void f3_store_epi(IO* row, const IO* srow, IO* prow, const int lam, const int j, float v) {
+  if (EPI >= 1) v += f3_load(srow, lam, j);
+  if (EPI == 2) {
+    if (prow != nullptr) f3_store(prow, lam, j, v);
+    v = sc_gelu(v);
+  }
+  f3_store(row, lam, j, v);
+}
+
 // 8-point DFT, natural order in and out: b[k] = sum_n a[n] w8^(nk), w8 = exp(DIR 2 pi i / 8)
 template <int DIR>
 SC_HD void dft8(const cf32 (&a)[8], cf32 (&b)[8]) {
@@ -348,11 +364,11 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 // ------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------
-template <int H, typename IO>
+template <int H, typename IO, int EPI = 0>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? 4 : 3))
 k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
              int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
-             float s_dc, float s_other) {
+             float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact) {
   constexpr int P = H / 64;
   typedef F3Lds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
@@ -498,12 +514,26 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
       }
       SC_WAVE_SYNC();                                   // xb is rewritten by the next round
       dft8<+1>(v, o);                                    // over k1 -> n1 : z[32 n1 + lam]
-      IO* ra = yo + (int64_t)(P * (2 * p) + a) * SC_F2D_W;
-      IO* rb = yo + (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W;
+      const int64_t oa = (int64_t)(P * (2 * p) + a) * SC_F2D_W, ob = (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W;
+      IO* ra = yo + oa;
+      IO* rb = yo + ob;
+      if (EPI == 0) {
 #pragma unroll
-      for (int n1 = 0; n1 < 8; ++n1) {
-        f3_store(ra, lam, n1, o[n1].x);
-        f3_store(rb, lam, n1, o[n1].y);
+        for (int n1 = 0; n1 < 8; ++n1) {
+          f3_store(ra, lam, n1, o[n1].x);
+          f3_store(rb, lam, n1, o[n1].y);
+        }
+      } else {
+        const int64_t io = img * (int64_t)H * SC_F2D_W;
+        const IO* sa = skip + io + oa;
+        const IO* sb = skip + io + ob;
+        IO* pa = preact ? preact + io + oa : nullptr;
+        IO* pb = preact ? preact + io + ob : nullptr;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+          f3_store_epi<EPI>(ra, sa, pa, lam, n1, o[n1].x);
+          f3_store_epi<EPI>(rb, sb, pb, lam, n1, o[n1].y);
+        }
       }
     }
     SC_SYNC();                                          // T is rewritten by the next group
@@ -522,9 +552,15 @@ static void fft3_launch_fwd(const Fft2dPlan* fp, const IO* x, cf32* xhat, int64_
 
 template <int H, typename IO>
 static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const float* bias, int channels,
-                            int64_t n_images, float s_dc, float s_other, sc_stream_t st) {
-  SC_LAUNCH((k_fft2d_inv3<H, IO>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels,
-            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
+                            int64_t n_images, float s_dc, float s_other, sc_stream_t st, int epi = 0,
+                            const IO* skip = nullptr, IO* preact = nullptr) {
+#define SC_F3_INV(E)                                                                                        \
+  SC_LAUNCH((k_fft2d_inv3<H, IO, E>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels, \
+            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, skip, preact)
+  if (epi == 2) SC_F3_INV(2);
+  else if (epi == 1) SC_F3_INV(1);
+  else SC_F3_INV(0);
+#undef SC_F3_INV
 }
 
 // x / y: float32, or bfloat16 storage when the plan carries SC_PLAN_IO_BF16 (IO = sc_bf16)
@@ -549,14 +585,15 @@ static inline int fft3_forward(const Fft2dPlan* fp, int mode, const IO* x, cf32*
 
 template <typename IO>
 static inline int fft3_inverse(const Fft2dPlan* fp, int mode, const cf32* yhat, const float* bias,
-                               int64_t channels, IO* y, int64_t n_images, sc_stream_t st, std::string* err) {
+                               int64_t channels, IO* y, int64_t n_images, sc_stream_t st, std::string* err,
+                               int epi = 0, const IO* skip = nullptr, IO* preact = nullptr) {
   const float s_dc = (mode == 0) ? fp->si : fp->sf;
   const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
   switch (fp->H) {
-    case 64: fft3_launch_inv<64, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 128: fft3_launch_inv<128, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 256: fft3_launch_inv<256, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
-    case 512: fft3_launch_inv<512, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st); break;
+    case 64: fft3_launch_inv<64, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
+    case 128: fft3_launch_inv<128, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
+    case 256: fft3_launch_inv<256, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
+    case 512: fft3_launch_inv<512, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {

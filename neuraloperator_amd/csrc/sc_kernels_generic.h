@@ -381,6 +381,24 @@ k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias, int64_t ba
 
 
 // ------------------------------------------------------------------------------------------
+// Block epilogue as its own pass, for the shapes whose inverse transform does not carry it in its store path
+// (everything off the fused 2-D kernels): y = act(y + skip), pre-activation optionally saved (SURVEY.md 8 row f1;
+// neuralop/layers/fno_block.py:392-414).  Streaming, 16 bytes per lane.
+// ------------------------------------------------------------------------------------------
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_epilogue(float* __restrict__ y, const float* __restrict__ skip, float* __restrict__ preact, int act,
+           int64_t n, int64_t stride) {
+  for (int64_t i = (int64_t)SC_BID_X * SC_BLOCK + SC_TID; i < n; i += stride) {
+    float v = y[i] + skip[i];
+    if (act == 1) {
+      if (preact != nullptr) preact[i] = v;
+      v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    }
+    y[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused AdamW step (neuralop/training/adamw.py:155-200 without the GaLore projection): one read of
 // (p, g, m, v), one write of (p, m, v).  Streaming: 7 arrays of the weight's size cross HBM once.
 // CPX: elements are complex64 -- m and the update are complex, v accumulates g conj(g) = |g|^2 (its

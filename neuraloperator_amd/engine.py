@@ -166,6 +166,77 @@ class SpectralConvDenseFn(torch.autograd.Function):
         return gx, gw_c, gb_r, None, None, None, None
 
 
+class FourierLayerFn(torch.autograd.Function):
+    """out = act(spectral_conv(x) + skip): the Fourier layer of an FNO block (neuralop/layers/fno_block.py:392-414:
+    ``x_fno + x_skip_fno`` followed by the non-linearity) with the addition and the activation done in the store
+    path of the inverse transform -- ``sc_layer_forward_ex``.  ``act``: "gelu" (exact, torch's
+    default) or None.  Backward: the activation's derivative is one elementwise pass over the saved pre-activation
+    (ATen's gelu_backward), its result is both the skip branch's gradient and the input of ``sc_layer_backward``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, skip, act, n_modes_attr, max_n_modes_attr, fft_norm, flags):
+        _require_gpu(x)
+        _require_gpu(weight, "weight")
+        lib = _lib.get_lib()
+        if act not in (None, "gelu"):
+            raise ValueError(f"activation {act!r}: the fused epilogue knows 'gelu' and None")
+        x = x.contiguous().float()
+        skip = skip.contiguous().float()
+        w = weight.detach().to(torch.complex64).contiguous()
+        b, cin = x.shape[:2]
+        cout = w.shape[1]
+        spatial = list(x.shape[2:])
+        if tuple(skip.shape) != (b, cout, *spatial):
+            raise ValueError(f"skip has shape {tuple(skip.shape)}, the layer's output is {(b, cout, *spatial)}")
+        kept, w_start = kept_block(spatial, n_modes_attr, max_n_modes_attr)
+        plan = get_plan(x.device, spatial, kept, fft_norm, flags)
+        L = lib.layer_desc(b, cin, cout, list(w.shape[2:]), w_start)
+        need_pre = act == "gelu" and any(ctx.needs_input_grad[:4])
+        with torch.cuda.device(x.device):
+            ws = _ws(lib.layer_workspace_bytes(plan, L), x.device)
+            y = torch.empty((b, cout, *spatial), dtype=torch.float32, device=x.device)
+            pre = torch.empty_like(y) if need_pre else None
+            xhat = torch.empty((b, cin, *kept, 2), dtype=torch.float32, device=x.device)
+            bias_flat = None if bias is None else bias.detach().reshape(-1).float().contiguous()
+            lib.layer_forward_ex(plan, L, x.data_ptr(), torch.view_as_real(w).data_ptr(),
+                                 0 if bias_flat is None else bias_flat.data_ptr(), skip.data_ptr(),
+                                 0 if pre is None else pre.data_ptr(),
+                                 _lib.SC_ACT_GELU if act == "gelu" else _lib.SC_ACT_NONE,
+                                 y.data_ptr(), xhat.data_ptr(), ws.data_ptr(), _stream())
+        ctx.save_for_backward(xhat, w, pre)
+        ctx.plan, ctx.L, ctx.act = plan, L, act
+        ctx.x_shape, ctx.w_shape = tuple(x.shape), tuple(weight.shape)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.get_lib()
+        xhat, w, pre = ctx.saved_tensors
+        need_x, need_w, need_b, need_s = ctx.needs_input_grad[:4]
+        gz = gout.contiguous().float()
+        if ctx.act == "gelu":
+            gz = torch.ops.aten.gelu_backward(gz, pre)              # host glue: one elementwise pass
+        dev = gz.device
+        gx = gw = gb = None
+        if need_x or need_w or (need_b and ctx.bias_shape is not None):
+            with torch.cuda.device(dev):
+                ws = _ws(lib.layer_workspace_bytes(ctx.plan, ctx.L), dev)
+                gx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if need_x else None
+                if need_w:
+                    full = all(ctx.L.w_start[d] == 0 for d in range(len(ctx.w_shape) - 2)) and \
+                        tuple(xhat.shape[2:-1]) == tuple(ctx.w_shape[2:])
+                    gw = (torch.empty if full else torch.zeros)((*ctx.w_shape, 2), dtype=torch.float32, device=dev)
+                if need_b and ctx.bias_shape is not None:
+                    gb = torch.empty(ctx.L.cout, dtype=torch.float32, device=dev)
+                lib.layer_backward(ctx.plan, ctx.L, gz.data_ptr(), xhat.data_ptr(), torch.view_as_real(w).data_ptr(),
+                                   0 if gx is None else gx.data_ptr(), 0 if gw is None else gw.data_ptr(),
+                                   0 if gb is None else gb.data_ptr(), ws.data_ptr(), _stream())
+        return (gx, None if gw is None else torch.view_as_complex(gw),
+                None if gb is None else gb.reshape(ctx.bias_shape), gz if need_s else None,
+                None, None, None, None, None)
+
+
 class TransformForwardFn(torch.autograd.Function):
     """x (B, C, d1..dN) real -> truncated spectrum (B, C, k1..kN) complex (weight order).
     forward = SC_FWD_SCALED, backward = its adjoint SC_INV_ADJ_R2C."""

@@ -210,6 +210,21 @@ class SpectralConv(BaseSpectralConv):
             return self._forward_full(x, spatial, out_shape).to(torch.bfloat16)
         return self._forward_full(x, spatial, out_shape)
 
+    def forward_fused(self, x, skip, activation="gelu"):
+        """``activation(self(x) + skip)`` -- the Fourier layer of an FNO block (fno_block.py:392-414) -- with the
+        addition and the activation inside the inverse transform's store path (three R-sized
+        elementwise passes less per layer).  Dense weights, real data, unchanged grid; every other configuration
+        takes the unfused composition of the same operations."""
+        spatial = list(x.shape[2:])
+        dense = isinstance(self.weight, DenseWeight) and not self.separable and not self.complex_data
+        if dense and self.resolution_scaling_factor is None and x.dtype == torch.float32 and \
+                self.fno_block_precision == "full":
+            return engine.FourierLayerFn.apply(x, self._dense_weight(), self.bias, skip, activation,
+                                               list(self.n_modes), list(self.max_n_modes), self.fft_norm,
+                                               self.engine_flags)
+        y = self(x) + skip
+        return torch.nn.functional.gelu(y) if activation == "gelu" else y
+
     def _forward_full(self, x, spatial, out_shape):
         if self.complex_data or out_shape != spatial:
             return self._forward_staged(x, spatial, out_shape)

@@ -194,6 +194,29 @@ def _as_slices(idx, n):
     return idx
 
 
+class FactorList(nn.Module):
+    """tltorch.FactorList: the factors of a decomposition as parameters named factor_0, factor_1, ... (state-dict
+    keys ``...factors.factor_{i}``)"""
+
+    def __init__(self, factors=()):
+        super().__init__()
+        self._n = 0
+        for f in factors:
+            self.register_parameter(f"factor_{self._n}", f if isinstance(f, nn.Parameter) else nn.Parameter(f))
+            self._n += 1
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        return getattr(self, f"factor_{i % self._n}")
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
 class TuckerTensor(FactorizedTensor):
     name = "Tucker"
 
@@ -201,7 +224,7 @@ class TuckerTensor(FactorizedTensor):
         super().__init__()
         if _param:
             self.core = nn.Parameter(core)
-            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+            self.factors = FactorList(factors)
         else:
             self.core = core
             self.factors = list(factors)
@@ -242,7 +265,7 @@ class CPTensor(FactorizedTensor):
         super().__init__()
         if _param:
             self.weights = nn.Parameter(weights)
-            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+            self.factors = FactorList(factors)
         else:
             self.weights = weights
             self.factors = list(factors)
@@ -281,7 +304,7 @@ class TTTensor(FactorizedTensor):
     def __init__(self, factors, _param=True):
         super().__init__()
         if _param:
-            self.factors = nn.ParameterList([nn.Parameter(f) for f in factors])
+            self.factors = FactorList(factors)
         else:
             self.factors = list(factors)
 

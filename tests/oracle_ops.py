@@ -75,8 +75,9 @@ class OracleRawOps:
 
     def fwd_adjoint(self, gxhat, spatial, out=None):
         n, c = gxhat.shape[:2]
-        x0 = torch.zeros(n, c, *spatial, requires_grad=True)
-        (gx,) = torch.autograd.grad(self.o.forward_transform(x0, list(gxhat.shape[2:])), x0, gxhat)
+        with torch.enable_grad():          # called from inside a Function's backward, where grad mode is off
+            x0 = torch.zeros(n, c, *spatial, requires_grad=True)
+            (gx,) = torch.autograd.grad(self.o.forward_transform(x0, list(gxhat.shape[2:])), x0, gxhat)
         return self._ret(gx, out)
 
     def inv(self, yhat, bias, spatial, out=None):
@@ -85,8 +86,9 @@ class OracleRawOps:
 
     def inv_adjoint(self, gy, kept, want_bias=False):
         n, c = gy.shape[:2]
-        z0 = torch.zeros(n, c, *kept, dtype=torch.cfloat, requires_grad=True)
-        (gh,) = torch.autograd.grad(self.o.inverse_transform(z0, None, list(gy.shape[2:])), z0, gy)
+        with torch.enable_grad():
+            z0 = torch.zeros(n, c, *kept, dtype=torch.cfloat, requires_grad=True)
+            (gh,) = torch.autograd.grad(self.o.inverse_transform(z0, None, list(gy.shape[2:])), z0, gy)
         gb = gy.sum(dim=[0] + list(range(2, gy.ndim))) if want_bias else None
         return gh, gb
 
@@ -94,6 +96,7 @@ class OracleRawOps:
         return so.contract_dense(xhat, w)
 
     def contract_bwd(self, xhat, w, ghat, need_x=True, need_w=True):
-        xr, wr = xhat.detach().requires_grad_(True), w.detach().requires_grad_(True)
-        gx, gw = torch.autograd.grad(so.contract_dense(xr, wr), (xr, wr), ghat)
+        with torch.enable_grad():
+            xr, wr = xhat.detach().requires_grad_(True), w.detach().requires_grad_(True)
+            gx, gw = torch.autograd.grad(so.contract_dense(xr, wr), (xr, wr), ghat)
         return (gx if need_x else None), (gw if need_w else None)

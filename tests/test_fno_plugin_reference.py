@@ -54,10 +54,7 @@ def compare(ref, ours, x, y, tag):
         out_o = ours(x)
         (out_o - y).pow(2).mean().backward()
     assert rel(out_o, out_r) < TOL, (tag, "forward", rel(out_o, out_r))
-    # (the third-party stub behind the reference registers factors as "factors.{i}", the module -- like tltorch
-    # itself -- as "factors.factor_{i}"; load_state_dict accepts both)
-    pr = dict(ref.named_parameters())
-    po = {k.replace("factors.factor_", "factors."): v for k, v in ours.named_parameters()}
+    pr, po = dict(ref.named_parameters()), dict(ours.named_parameters())
     assert pr.keys() == po.keys()
     for k in pr:
         assert po[k].grad is not None, (tag, k)

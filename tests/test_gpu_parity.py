@@ -647,3 +647,40 @@ def test_layer_step_is_graph_capturable():
     for a, b in zip(got, want):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
     assert rel_l2(got[0].cpu().numpy(), ref[0].cpu().numpy()) > 1e-3    # it really recomputed on the new input
+
+
+@pytest.mark.parametrize("spatial,modes", [((128, 256), (32, 32)), ((24, 20), (8, 8)), ((8, 6, 10), (4, 4, 4))])
+def test_fourier_layer_fused_epilogue(spatial, modes):
+    """SURVEY.md 8 row f1, first step: out = gelu(conv(x) + skip) with the addition and the activation in the store
+    path of the inverse transform (fused 2-D kernels) / one streaming pass behind it (other shapes), against the CPU
+    oracle composition (reference: neuralop/layers/fno_block.py:392-414) -- output and the gradients of x, skip,
+    weight and bias -- and against the module's own unfused composition."""
+    from neuraloperator_amd import SpectralConv
+    from oracle import spectral_oracle as so
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    conv = SpectralConv(6, 5, modes).to(dev)
+    x = torch.randn(3, 6, *spatial)
+    skip = torch.randn(3, 5, *spatial)
+    g = torch.randn(3, 5, *spatial)
+    xd, sd = x.to(dev).requires_grad_(True), skip.to(dev).requires_grad_(True)
+    out = conv.forward_fused(xd, sd, "gelu")
+    out.backward(g.to(dev))
+    got = dict(out=out.detach(), gx=xd.grad, gskip=sd.grad, gw=conv.weight.tensor.grad.clone(),
+               gb=conv.bias.grad.clone())
+    xr, sr = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    wr = conv.weight.tensor.detach().cpu().requires_grad_(True)
+    br = conv.bias.detach().cpu().requires_grad_(True)
+    ref = torch.nn.functional.gelu(so.forward_torch(xr, wr, br, conv.n_modes, conv.max_n_modes) + sr)
+    ref.backward(g)
+    want = dict(out=ref.detach(), gx=xr.grad, gskip=sr.grad, gw=wr.grad, gb=br.grad)
+    for k in got:
+        assert rel_l2(got[k].cpu().numpy(), want[k].numpy()) < TOL, k
+    conv.zero_grad()
+    x2, s2 = x.to(dev).requires_grad_(True), skip.to(dev).requires_grad_(True)
+    torch.nn.functional.gelu(conv(x2) + s2).backward(g.to(dev))
+    assert rel_l2(xd.grad.cpu().numpy(), x2.grad.cpu().numpy()) < TOL
+    # no activation: plain sum
+    y_lin = conv.forward_fused(xd.detach(), sd.detach(), None)
+    assert rel_l2(y_lin.cpu().numpy(), (conv(xd.detach()) + sd.detach()).cpu().numpy()) < TOL

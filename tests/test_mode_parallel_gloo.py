@@ -137,7 +137,7 @@ def _hybrid_worker(rank, world, port, ret):
     from neuraloperator_amd.modes import halve_last_mode
     from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
     from oracle import spectral_oracle as so
-    from oracle_ops import OracleOps
+    from oracle_ops import OracleRawOps
 
     mp_size = 2
     comm.init(model_parallel_size=mp_size, backend="gloo")
@@ -152,7 +152,7 @@ def _hybrid_worker(rank, world, port, ret):
     g = torch.randn(B, co, *spatial)
     w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
     bias = torch.randn(co, 1, 1)
-    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=chunks)
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=2)
     with torch.no_grad():
         conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, mp_rank, mp_size))
         conv.bias.copy_(bias)

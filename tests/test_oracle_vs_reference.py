@@ -101,7 +101,8 @@ def test_variant_branches_match_verbatim(spatial, nm, kw):
 @pytest.mark.parametrize("sep", [False, True])
 def test_state_dict_layout_is_the_reference_containers(fac, sep):
     """Checkpoints move between the reference module and the drop-in: same parameter names and shapes
-    (weight.tensor | weight.core + weight.factors.i | weight.weights + weight.factors.i, bias).  TT ranks are
+    (weight.tensor | weight.core + weight.factors.factor_i | weight.weights + weight.factors.factor_i, bias: tltorch's
+    FactorList naming).  TT ranks are
     passed explicitly (the rank RULE is tensorly's and unpinned)."""
     from neuraloperator_amd import SpectralConv
     ref = ref_verbatim.load_reference()
