@@ -86,12 +86,32 @@ SC_DEVICE void f3_store(sc_bf16* row, const int lam, const int j, const float v)
 // ---- block epilogue fused into the inverse transform's store path (the FNO block computes
 //      act(conv(x) + skip(x)), neuralop/layers/fno_block.py:392-414, as three more R-sized passes):
 //      EPI 0: y = v;  EPI 1: y = v + skip;  EPI 2: y = gelu(v + skip) with the pre-activation optionally saved for
-//      the backward pass.  gelu = torch's default (exact, erf based).
-SC_DEVICE float sc_gelu(const float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+//      the backward pass.  gelu = torch's default form 0.5 v (1 + erf(v / sqrt 2)).  The inverse kernel is VALU /
+//      LDS-issue bound, so the library erff (~40 instructions; measured: the fused inverse 113 -> 570 us, no faster
+//      than the three elementwise passes it replaces) is replaced by the 5-term rational approximation of
+//      Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in erf, i.e. fp32 round-off class for the activation; 14
+//      instructions with v_rcp_f32 / v_exp_f32).
+SC_DEVICE float sc_erf_fast(const float x) {
+  const float ax = fabsf(x);
+#ifndef SC_EMU
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-ax * ax);
+#else
+  const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
+  const float e = expf(-ax * ax);
+#endif
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float r = fmaf(-p * t, e, 1.f);
+  return copysignf(r, x);
+}
+SC_DEVICE float sc_gelu(const float v) { return 0.5f * v * (1.f + sc_erf_fast(v * 0.70710678118654752440f)); }
 
 template <int EPI, typename IO>
-SC_DEVICE void f3_store_epi(IO* row, const IO* srow, IO* prow, const int lam, const int j, float v) {
-  if (EPI >= 1) v += f3_load(srow, lam, j);
+SC_DEVICE void f3_store_epi(IO* row, const float sk, IO* prow, const int lam, const int j, float v) {
+  if (EPI >= 1) v += sk;
   if (EPI == 2) {
     if (prow != nullptr) f3_store(prow, lam, j, v);
     v = sc_gelu(v);
@@ -365,7 +385,7 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 // inverse
 // ------------------------------------------------------------------------------------------
 template <int H, typename IO, int EPI = 0>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? 4 : 3))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && EPI == 0 ? 4 : 3))
 k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
              int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
              float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact) {
@@ -476,6 +496,19 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
       const int p = r * 8 + hw;
+      // block epilogue: the round's 16 skip values are requested here and consumed ~1 us later, after the row
+      // transforms (requested next to the stores, every load waits for the store in front of it: vmcnt is in order)
+      cf32 sk[8];
+      if (EPI >= 1) {
+        const int64_t io = img * (int64_t)H * SC_F2D_W;
+        const IO* sa = skip + io + (int64_t)(P * (2 * p) + a) * SC_F2D_W;
+        const IO* sb = skip + io + (int64_t)(P * (2 * p + 1) + a) * SC_F2D_W;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+          sk[n1].x = f3_load(sa, lam, n1);
+          sk[n1].y = f3_load(sb, lam, n1);
+        }
+      }
       {
         // lane j builds Z[j] (k1 = j & 7, k3 = j >> 3) and Z[j - 32] (k3 + 4); lane 0 also Z[+32]
         const cf32* ta = T + (2 * p) * L::URS;
@@ -525,14 +558,12 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
         }
       } else {
         const int64_t io = img * (int64_t)H * SC_F2D_W;
-        const IO* sa = skip + io + oa;
-        const IO* sb = skip + io + ob;
         IO* pa = preact ? preact + io + oa : nullptr;
         IO* pb = preact ? preact + io + ob : nullptr;
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
-          f3_store_epi<EPI>(ra, sa, pa, lam, n1, o[n1].x);
-          f3_store_epi<EPI>(rb, sb, pb, lam, n1, o[n1].y);
+          f3_store_epi<EPI>(ra, sk[n1].x, pa, lam, n1, o[n1].x);
+          f3_store_epi<EPI>(rb, sk[n1].y, pb, lam, n1, o[n1].y);
         }
       }
     }
