@@ -682,5 +682,6 @@ def test_fourier_layer_fused_epilogue(spatial, modes):
     torch.nn.functional.gelu(conv(x2) + s2).backward(g.to(dev))
     assert rel_l2(xd.grad.cpu().numpy(), x2.grad.cpu().numpy()) < TOL
     # no activation: plain sum
-    y_lin = conv.forward_fused(xd.detach(), sd.detach(), None)
-    assert rel_l2(y_lin.cpu().numpy(), (conv(xd.detach()) + sd.detach()).cpu().numpy()) < TOL
+    with torch.no_grad():
+        y_lin = conv.forward_fused(xd.detach(), sd.detach(), None)
+        assert rel_l2(y_lin.cpu().numpy(), (conv(xd.detach()) + sd.detach()).cpu().numpy()) < TOL
