@@ -21,6 +21,7 @@
 #include "sc_kernels_mfma.h"
 #include "sc_kernels_gemm8.h"
 #include "sc_kernels_mdft.h"
+#include "sc_kernels_fft2p.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -101,6 +102,14 @@ struct sc_plan {
   // fast path (power-of-two 2-D), see sc_kernels_fft.h
   Fft2dPlan fft2d;
   bool fast = false;
+  // two-pass factorised route for large power-of-two 2-D grids (sc_kernels_fft2p.h)
+  bool f2p = false;
+  int f2p_p[2] = {0, 0};        // points per lane of a line along dim 0 / dim 1 (N = 32 P)
+  int f2p_k2[2] = {0, 0};       // range of the pruned 32-point stage: kept rows / kept columns
+  int f2p_ncb = 0;              // panel blocks of 8 kept columns
+  cf32* f2p_tw[2] = {nullptr, nullptr};
+  float* f2p_cs_fwd[2] = {nullptr, nullptr};   // [SC_FWD_SCALED], [SC_FWD_ADJ_C2R]
+  float* f2p_cs_inv[2] = {nullptr, nullptr};   // [SC_INV_PADDED], [SC_INV_ADJ_R2C]
   // weight sub-block index tables (device), keyed by (w_extent, w_start)
   std::mutex idx_mu;
   std::map<IdxKey, int32_t*> idx_cache;
@@ -362,6 +371,131 @@ static int build_mdft_tables(sc_plan* p) {
   return rc;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// two-pass factorised route (sc_kernels_fft2p.h): eligibility, tables, launches
+// ------------------------------------------------------------------------------------------
+#ifndef SC_F2P_CHUNK_MB
+#define SC_F2P_CHUNK_MB 96      // panel bytes in flight between the two passes (Infinity Cache: 256 MB)
+#endif
+
+static int f2p_pow2_at_least(int64_t v) {
+  int r = 1;
+  while (r < v) r *= 2;
+  return r;
+}
+
+static int f2p_plan_init(sc_plan* p) {
+  if (p->nd != 2 || p->cplx || p->custom_map || p->d.real_col) return 0;
+  for (int d = 0; d < 2; ++d)
+    if (p->n[d] != 512 && p->n[d] != 1024) return 0;
+  const int P0 = (int)(p->n[0] / 32), P1 = (int)(p->n[1] / 32);
+  const int64_t K0 = p->k[0], J = p->k[1];
+  if (J > p->n[1] / 2) return 0;                          // kept columns stay below the Nyquist column
+  const int k2r = f2p_pow2_at_least((((K0 + 1) / 2) + P0 - 1) / P0);
+  const int k2c = f2p_pow2_at_least(J > 1 ? (J - 1 + P1 - 1) / P1 : 1);
+  if (k2r > 8 || k2c > 8) return 0;
+  p->f2p_p[0] = P0;
+  p->f2p_p[1] = P1;
+  p->f2p_k2[0] = k2r;
+  p->f2p_k2[1] = k2c;
+  p->f2p_ncb = (int)((J + SC_F2P_CB - 1) / SC_F2P_CB);
+  for (int d = 0; d < 2; ++d) {
+    const int P = p->f2p_p[d];
+    const int64_t N = p->n[d];
+    std::vector<cf32> h((size_t)P * 32);
+    for (int k1 = 0; k1 < P; ++k1)
+      for (int t = 0; t < 32; ++t) h[(size_t)k1 * 32 + t] = twiddle(k1, t, N, -1.0, 1.0);
+    DeviceTable dt;
+    int rc = upload_table(p, h, P, 32, &dt);
+    if (rc) return rc;
+    p->f2p_tw[d] = dt.ptr;
+  }
+  for (int v = 0; v < 2; ++v) {
+    std::vector<float> f((size_t)J), g((size_t)J);
+    for (int64_t k = 0; k < J; ++k) {
+      const double wf = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(k, p->n[1]);
+      const double wi = (v == SC_INV_PADDED) ? p->si * col_weight(k, p->n[1]) : p->sf;
+      f[(size_t)k] = (float)(0.5 * wf);
+      g[(size_t)k] = (float)(k == 0 ? wi : 0.5 * wi);
+    }
+    int rc = upload_floats(p, f, &p->f2p_cs_fwd[v]);
+    if (!rc) rc = upload_floats(p, g, &p->f2p_cs_inv[v]);
+    if (rc) return rc;
+  }
+  p->f2p = true;
+  return 0;
+}
+
+static int64_t f2p_panel_elems_per_image(const sc_plan* p) { return (int64_t)p->f2p_ncb * p->n[0] * SC_F2P_CB; }
+static int64_t f2p_chunk_images(const sc_plan* p, int64_t n_images) {
+  int64_t c = ((int64_t)SC_F2P_CHUNK_MB << 20) / (f2p_panel_elems_per_image(p) * (int64_t)sizeof(cf32));
+  if (c < 1) c = 1;
+  return c < n_images ? c : n_images;
+}
+
+template <typename F>
+static bool f2p_dispatch(int P, int K2, F&& f) {
+  switch (P * 100 + K2) {
+    case 3201: f(sc_int<32>(), sc_int<1>()); return true;
+    case 3202: f(sc_int<32>(), sc_int<2>()); return true;
+    case 3204: f(sc_int<32>(), sc_int<4>()); return true;
+    case 3208: f(sc_int<32>(), sc_int<8>()); return true;
+    case 1601: f(sc_int<16>(), sc_int<1>()); return true;
+    case 1602: f(sc_int<16>(), sc_int<2>()); return true;
+    case 1604: f(sc_int<16>(), sc_int<4>()); return true;
+    case 1608: f(sc_int<16>(), sc_int<8>()); return true;
+    default: return false;
+  }
+}
+
+static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, int64_t n_images, void* workspace,
+                       sc_stream_t st) {
+  SC_CHECK_ARG(workspace, "workspace required");
+  cf32* panel = (cf32*)workspace;
+  const int N0 = (int)p->n[0], J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
+  const int64_t chunk = f2p_chunk_images(p, n_images);
+  for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
+    const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
+    const float* xs = x + i0 * p->ntot;
+    bool ok = f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
+      SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / 16)), dim3(256), 0, st,
+                xs, panel, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_fwd[mode], N0, J, NCB);
+    });
+    cf32* dst = xhat + i0 * p->modes;
+    ok = ok && f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
+      SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * NCB)), dim3(256), 0, st,
+                (const cf32*)panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0);
+    });
+    if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
+  }
+  return sc_check_launch("k_f2p_r2c / k_f2p_col_fwd");
+}
+
+static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float* bias, int64_t channels, float* y,
+                       int64_t n_images, void* workspace, sc_stream_t st) {
+  SC_CHECK_ARG(workspace, "workspace required");
+  cf32* panel = (cf32*)workspace;
+  const int N0 = (int)p->n[0], J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
+  const int64_t chunk = f2p_chunk_images(p, n_images);
+  for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
+    const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
+    const cf32* src = yhat + i0 * p->modes;
+    bool ok = f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
+      SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * NCB)), dim3(256), 0, st,
+                src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0);
+    });
+    float* ys = y + i0 * p->ntot;
+    ok = ok && f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
+      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / 16)), dim3(256), 0, st,
+                (const cf32*)panel, ys, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_inv[mode], bias,
+                (int)channels, (int)(i0 % channels), N0, J, NCB);
+    });
+    if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
+  }
+  return sc_check_launch("k_f2p_col_inv / k_f2p_c2r");
+}
+
 extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   SC_CHECK_ARG(out && desc, "null argument");
   SC_CHECK_ARG(desc->ndim >= 1 && desc->ndim <= SC_MAX_DIMS, "ndim must be 1..4");
@@ -499,10 +633,11 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     std::string why;
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
+  if (!rc && !p->fast && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !(desc->flags & SC_PLAN_IO_BF16)) rc = f2p_plan_init(p);
   if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
     rc = sc_fail("sc_engine: SC_PLAN_IO_BF16 is implemented on the fused 2-D kernels (generation 3) only: "
                  "width 256, height 64..512, kept block <= 64 x 33, no frequency maps");
-  if (!rc && !p->fast && !(desc->flags & SC_PLAN_NO_MDFT)) rc = build_mdft_tables(p);
+  if (!rc && !p->fast && !p->f2p && !(desc->flags & SC_PLAN_NO_MDFT)) rc = build_mdft_tables(p);
   if (rc) {
     sc_plan_destroy(p);
     return rc;
@@ -539,6 +674,7 @@ static void generic_ws_sizes(const sc_plan* p, int64_t n_images, int64_t* s1, in
 extern "C" size_t sc_plan_workspace_bytes(const sc_plan* p, int64_t n_images) {
   if (!p) return 0;
   if (p->fast) return fft2d_workspace_bytes(&p->fft2d, n_images);
+  if (p->f2p) return (size_t)(f2p_chunk_images(p, n_images) * f2p_panel_elems_per_image(p)) * sizeof(cf32) + 256;
   int64_t s1, s2;
   generic_ws_sizes(p, n_images, &s1, &s2);
   return (size_t)(s1 + s2) * sizeof(cf32) + 256;
@@ -876,6 +1012,7 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
       return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
     return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
   }
+  if (p->f2p) return f2p_forward(p, mode, x, (cf32*)xhat, n_images, workspace, st);
   const int L = p->nd - 1;
   int64_t lines = n_images;
   for (int d = 0; d < L; ++d) lines *= p->n[d];
@@ -968,6 +1105,7 @@ extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* 
     int rc2 = sc_transform_inverse_ex(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream);
     return rc2 ? rc2 : run_epilogue_pass(p, ep, y, n_images, st);
   }
+  if (p->f2p) return f2p_inverse(p, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st);
   const int L = p->nd - 1;
   int64_t lpi = 1;
   for (int d = 0; d < L; ++d) lpi *= p->n[d];
@@ -1505,6 +1643,7 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
     return which == 0 ? "k_fft2d_fwd3" : "k_fft2d_inv3";
   }
   if (p->cplx) return "k_axis_pass";
+  if (p->f2p) return which == 0 ? "k_f2p_r2c" : "k_f2p_c2r";
   if (p->mdft) {
     if (which == 0 && plane_fwd_ok(p, 0)) return "k_mdft_r2c_lds<plane>";
     if (which == 1 && plane_inv_ok(p, 0)) return "k_mdft_c2r_lds<plane>";

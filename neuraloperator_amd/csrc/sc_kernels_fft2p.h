@@ -1,0 +1,381 @@
+// sc_kernels_fft2p.h -- factorised (O(N log N)) transforms for LARGE power-of-two 2-D grids, in two passes.
+//
+// The fused kernels of sc_kernels_fft3.h keep one image per workgroup (width 256, kept block <= 64 x 33); a
+// 1024 x 1024 image is 4 MB and its kept columns after the row transforms (1024 x 129 complex) are 1 MB, so nothing
+// fits a CU's LDS and the size-agnostic direct-DFT passes that served these grids are matrix-pipe bound (129 flop
+// per byte: 5.3-5.9 ms per transform at 1024^2 / modes 256, B x C = 512, for 2.3 GB of algorithmic traffic).  Here
+// each axis is a REAL Cooley-Tukey factorisation N = P x 32 on the vector ALUs -- a radix-P codelet in registers,
+// one LDS exchange, a 32-point codelet pruned to (forward) / fed from (inverse) the kept modes only -- and the two
+// axes are two launches with an engine-private intermediate that is written and read exactly once:
+//
+//   forward  (rfft2 restricted to the kept block, spectral_convolution.py:443-449 + :500-519)
+//     k_f2p_r2c      x[img][n0][N1] real          -> panel[img][cb][n0][8]   (kept columns of every row)
+//     k_f2p_col_fwd  panel[img][cb][N0][8]        -> xhat[img][K0][J]        (kept rows of every kept column)
+//   inverse  (irfft2 of the zero-padded block, :531-568)
+//     k_f2p_col_inv  yhat[img][K0][J]             -> panel[img][cb][N0][8]
+//     k_f2p_c2r      panel[img][cb][n0][8]        -> y[img][n0][N1] real (+ bias)
+//
+// panel layout: the kept columns in blocks of 8 (cb = column / 8), row-major inside a block: a row transform
+// stores 64-byte pieces (its two packed rows are neighbours: 128 contiguous bytes), a column transform reads and
+// writes ONE contiguous N0 x 64 B region.  The host runs the two passes over chunks of images sized so that a
+// chunk's panel (1.1 MB per image at J = 129) stays in the 256 MB Infinity Cache between its writer and its reader.
+//
+// A line of N = 32 P points is owned by 32 lanes ("t"), P points each (n = t + 32 j):
+//     X[k1 + P k2] = sum_t w32^(t k2) [ w_N^(t k1) ( sum_j w_P^(j k1) x[t + 32 j] ) ]
+//   stage 1  radix-P over j in registers                       (lane t, all k1)
+//   twiddle  w_N^(t k1), LDS table [k1][t]
+//   exchange E[k1][t]  (row stride 33 complex: both sides conflict-free)
+//   stage 2  32-point DFT over t by lane k1, only the k2 that hold kept modes: |k| <= P K2
+// Row passes pack two real rows as one complex line (z = a + i b) and split A[k], B[k] from Z[k], Z[-k] on the
+// way out (in: build Z from A, B), so a half-wave moves 2 x 4 KB rows per round with 128-byte coalesced accesses.
+// The inverse kernels are the exact transposes (zero-padded 32-point stage first).
+//
+// Scope (sc_engine.cpp: f2p_eligible): 2 dims, both sizes in {512, 1024}, default centred frequency maps, real
+// data, kept columns below the Nyquist column; everything else stays on the size-agnostic passes.
+#pragma once
+#include "sc_kernels_fft3.h"
+
+#define SC_F2P_RS 33                  // exchange row stride (complex)
+#define SC_F2P_CB 8                   // kept columns per panel block
+#define SC_F2P_CS (32 * SC_F2P_RS + 4)  // per-column exchange stride of the column kernels (= 4 mod 32: reads conflict-free)
+
+template <int I, int N, typename F>
+SC_HD void sc_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(sc_int<I>());
+    sc_static_for<I + 1, N>(f);
+  }
+}
+
+// cos(pi m / 16), sin(pi m / 16): the 32nd roots of unity
+constexpr float f2p_cos16(int m) {
+  constexpr float Q[9] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                          0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                          0.19509032201612826785f, 0.f};
+  m &= 31;
+  if (m > 16) m = 32 - m;
+  return m > 8 ? -Q[16 - m] : Q[m];
+}
+constexpr float f2p_sin16(int m) { return f2p_cos16(m - 8); }
+
+// a * exp(DIR 2 pi i M / 32), M compile-time
+template <int DIR, int M>
+SC_HD cf32 mul_w32(const cf32 a) {
+  constexpr int m = ((M % 32) + 32) % 32;
+  if constexpr (m == 0) {
+    return a;
+  } else if constexpr (m == 8) {
+    return rot90<DIR>(a);
+  } else if constexpr (m == 16) {
+    return cf_make(-a.x, -a.y);
+  } else if constexpr (m == 24) {
+    return rot90<-DIR>(a);
+  } else {
+    constexpr float c = f2p_cos16(m), s = (DIR < 0) ? -f2p_sin16(m) : f2p_sin16(m);
+    return cf_mul_tw(a, c, -s, s);
+  }
+}
+
+// 32-point DFT, natural order in and out: b[k] = sum_j a[j] w32^(jk), w32 = exp(DIR 2 pi i / 32)
+// (j = j1 + 4 j2, k = k2 + 8 k1: four 8-point DFTs over j2, twiddle w32^(j1 k2), eight radix-4 over j1)
+template <int DIR>
+SC_HD void dft32(const cf32 (&a)[32], cf32 (&b)[32]) {
+  cf32 c[4][8];
+#pragma unroll
+  for (int j1 = 0; j1 < 4; ++j1) {
+    cf32 in[8];
+#pragma unroll
+    for (int j2 = 0; j2 < 8; ++j2) in[j2] = a[j1 + 4 * j2];
+    dft8<DIR>(in, c[j1]);
+  }
+  sc_static_for<0, 8>([&](auto k2t) {
+    constexpr int k2 = decltype(k2t)::value;
+    cf32 t0 = c[0][k2];
+    cf32 t1 = mul_w32<DIR, k2>(c[1][k2]);
+    cf32 t2 = mul_w32<DIR, 2 * k2>(c[2][k2]);
+    cf32 t3 = mul_w32<DIR, 3 * k2>(c[3][k2]);
+    radix4<DIR>(t0, t1, t2, t3);
+    b[k2] = t0;
+    b[k2 + 8] = t1;
+    b[k2 + 16] = t2;
+    b[k2 + 24] = t3;
+  });
+}
+
+// stage-1 codelet of a line: P points per lane
+template <int P, int DIR>
+SC_HD void f2p_dftP(cf32 (&a)[P], cf32 (&b)[P]) {
+  if constexpr (P == 32) {
+    dft32<DIR>(a, b);
+  } else {
+    static_assert(P == 16, "lines of 512 or 1024 points");
+    fft16<DIR>(a, b);
+  }
+}
+
+// 32-point DFT over t, only outputs k2 = -K2 .. K2-1 (and +K2 when TOP): out[k2 + K2]
+//   sum_t w32^(t k2) y[t],  t = s1 + 4 s2:  sum_s1 w32^(s1 k2) D_s1[k2 mod 8],  D_s1 = 8-point DFT over s2
+template <int DIR, int K2, bool TOP>
+SC_HD void dft32_kept(const cf32 (&y)[32], cf32 (&out)[2 * K2 + 1]) {
+  cf32 D[4][8];
+#pragma unroll
+  for (int s1 = 0; s1 < 4; ++s1) {
+    cf32 in[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) in[s2] = y[s1 + 4 * s2];
+    dft8<DIR>(in, D[s1]);
+  }
+  sc_static_for<0, 2 * K2 + (TOP ? 1 : 0)>([&](auto it) {
+    constexpr int k2 = decltype(it)::value - K2;
+    constexpr int r = k2 & 7;
+    const cf32 e = cf_add(D[0][r], mul_w32<DIR, 2 * k2>(D[2][r]));
+    const cf32 o = cf_add(mul_w32<DIR, k2>(D[1][r]), mul_w32<DIR, 3 * k2>(D[3][r]));
+    out[k2 + K2] = cf_add(e, o);
+  });
+  if constexpr (!TOP) out[2 * K2] = cf_make(0.f, 0.f);
+}
+
+// the transpose: g[t] = sum_{k2 = -K2 .. K2-1 (+K2 when TOP)} w32^(t k2) in[k2 + K2], all 32 t
+template <int DIR, int K2, bool TOP>
+SC_HD void dft32_padded(const cf32 (&in)[2 * K2 + 1], cf32 (&g)[32]) {
+  constexpr int NIN = 2 * K2 + (TOP ? 1 : 0);
+  sc_static_for<0, 4>([&](auto s1t) {
+    constexpr int s1 = decltype(s1t)::value;
+    cf32 e[8], o[8];
+    if constexpr (NIN < 8) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) e[r] = cf_make(0.f, 0.f);
+    }
+    sc_static_for<0, NIN>([&](auto it) {
+      constexpr int i = decltype(it)::value;
+      constexpr int k2 = i - K2;
+      constexpr int r = k2 & 7;
+      const cf32 term = mul_w32<DIR, s1 * k2>(in[i]);
+      if constexpr (i < 8) e[r] = term;
+      else e[r] = cf_add(e[r], term);
+    });
+    dft8<DIR>(e, o);
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) g[s1 + 4 * s2] = o[s2];
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 1 forward: real rows -> kept columns of the panel.  One half-wave per packed row pair, 8 pairs per workgroup.
+// ------------------------------------------------------------------------------------------
+template <int P, int K2>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __restrict__ twN,
+          const float* __restrict__ cs, int N0, int J, int NCB) {
+  constexpr int N = 32 * P, KOFF = P * K2;
+  SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
+  SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
+  const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
+  for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
+  const int64_t pair = (int64_t)SC_BID_X * 8 + hw;
+  const int64_t rA = 2 * pair;
+  const int64_t img = rA / N0;
+  const int n = (int)(rA - img * N0);
+  const float* xa = x + rA * N + t;
+  cf32 z[P], u[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    z[j].x = SC_LOAD_STREAM(xa + 32 * j);
+    z[j].y = SC_LOAD_STREAM(xa + N + 32 * j);
+  }
+  SC_SYNC();                                             // twiddle table
+  cf32* E = Eall[hw];
+  f2p_dftP<P, -1>(z, u);                                 // over j -> k1
+  E[t] = u[0];
+#pragma unroll
+  for (int k1 = 1; k1 < P; ++k1) E[k1 * SC_F2P_RS + t] = cf_mul_cs(u[k1], tw[k1 * 32 + t]);
+  SC_WAVE_SYNC();
+  cf32 y[32], Zk[2 * K2 + 1];
+  const int L = t < P ? t : 0;                           // lane L plays k1 = L (lanes >= P idle at P = 16)
+#pragma unroll
+  for (int q = 0; q < 32; ++q) y[q] = E[L * SC_F2P_RS + q];
+  SC_WAVE_SYNC();
+  dft32_kept<-1, K2, true>(y, Zk);                       // Z[L + P k2], k2 = -K2 .. K2
+  if (t < P) {
+#pragma unroll
+    for (int i = 0; i < 2 * K2; ++i) E[KOFF + t + P * (i - K2)] = Zk[i];
+    if (t == 0) E[2 * KOFF] = Zk[2 * K2];
+  }
+  SC_WAVE_SYNC();
+  cf32* dst = panel + ((img * NCB) * (int64_t)N0 + n) * SC_F2P_CB;
+  constexpr int NI = (KOFF + 32) / 32;                   // k = t + 32 i <= KOFF
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = t + 32 * i;
+    if (k < J) {
+      const cf32 zk = E[KOFF + k], zm = E[KOFF - k];
+      const float s = cs[k];                             // 0.5 x norm x column weight
+      // A = (Z[k] + conj Z[-k]) / 2,  B = -i (Z[k] - conj Z[-k]) / 2
+      const cf32 A = cf_make(s * (zk.x + zm.x), s * (zk.y - zm.y));
+      const cf32 B = cf_make(s * (zk.y + zm.y), s * (zm.x - zk.x));
+      cf32* d = dst + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
+      d[0] = A;
+      d[SC_F2P_CB] = B;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2 forward: one panel block (N0 rows x 8 columns) per workgroup -> the kept rows of its columns.
+// thread = (column c = tid & 7, slot s = tid >> 3): slot s is lane t = s of the column's line in stage 1 and
+// k1 = s in stage 2.
+// ------------------------------------------------------------------------------------------
+template <int P, int K2>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_f2p_col_fwd(const cf32* __restrict__ panel, cf32* __restrict__ xhat, const cf32* __restrict__ twN, int NCB, int J,
+              int K0) {
+  constexpr int N0 = 32 * P;
+  SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
+  SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_F2P_CS];
+  const int tid = SC_TID, c = tid & 7, s = tid >> 3;
+  for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
+  const int64_t blk = SC_BID_X;
+  const int cb = (int)(blk % NCB);
+  const int64_t img = blk / NCB;
+  const int col = cb * SC_F2P_CB + c;
+  const bool live = col < J;
+  const cf32* src = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
+  cf32 z[P], u[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) z[j] = live ? src[(int64_t)32 * j * SC_F2P_CB] : cf_make(0.f, 0.f);
+  SC_SYNC();
+  f2p_dftP<P, -1>(z, u);
+  cf32* Ec = E + c * SC_F2P_CS;
+  Ec[s] = u[0];
+#pragma unroll
+  for (int k1 = 1; k1 < P; ++k1) Ec[k1 * SC_F2P_RS + s] = cf_mul_cs(u[k1], tw[k1 * 32 + s]);
+  SC_SYNC();
+  if (s < P) {
+    cf32 y[32], X[2 * K2 + 1];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) y[q] = Ec[s * SC_F2P_RS + q];
+    dft32_kept<-1, K2, false>(y, X);
+    if (live) {
+      cf32* dst = xhat + img * (int64_t)K0 * J + col;
+#pragma unroll
+      for (int i = 0; i < 2 * K2; ++i) {
+        const int row = s + P * (i - K2) + K0 / 2;
+        if (row >= 0 && row < K0) dst[(int64_t)row * J] = X[i];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2 inverse: kept rows of 8 columns -> full columns of the panel block (zero padded in frequency)
+// ------------------------------------------------------------------------------------------
+template <int P, int K2>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf32* __restrict__ twN, int NCB, int J,
+              int K0) {
+  constexpr int N0 = 32 * P;
+  SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
+  SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_F2P_CS];
+  const int tid = SC_TID, c = tid & 7, s = tid >> 3;
+  for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
+  const int64_t blk = SC_BID_X;
+  const int cb = (int)(blk % NCB);
+  const int64_t img = blk / NCB;
+  const int col = cb * SC_F2P_CB + c;
+  const bool live = col < J;
+  cf32 in[2 * K2 + 1];
+  {
+    const cf32* src = yhat + img * (int64_t)K0 * J + col;
+#pragma unroll
+    for (int i = 0; i < 2 * K2; ++i) {
+      const int row = s + P * (i - K2) + K0 / 2;
+      in[i] = (live && s < P && row >= 0 && row < K0) ? src[(int64_t)row * J] : cf_make(0.f, 0.f);
+    }
+    in[2 * K2] = cf_make(0.f, 0.f);
+  }
+  SC_SYNC();
+  cf32* Ec = E + c * SC_F2P_CS;
+  if (s < P) {
+    cf32 g[32];
+    dft32_padded<+1, K2, false>(in, g);
+    Ec[s * SC_F2P_RS] = g[0];
+#pragma unroll
+    for (int q = 1; q < 32; ++q) Ec[s * SC_F2P_RS + q] = cf_mul_cs(g[q], cf_conj(tw[s * 32 + q]));
+  }
+  SC_SYNC();
+  cf32 u[P], z[P];
+#pragma unroll
+  for (int k1 = 0; k1 < P; ++k1) u[k1] = Ec[k1 * SC_F2P_RS + s];
+  f2p_dftP<P, +1>(u, z);                                 // over k1 -> j : line point n = s + 32 j
+  if (live) {
+    cf32* dst = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
+#pragma unroll
+    for (int j = 0; j < P; ++j) dst[(int64_t)32 * j * SC_F2P_CB] = z[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 1 inverse: kept columns of two panel rows -> two real rows (+ bias)
+// ------------------------------------------------------------------------------------------
+template <int P, int K2>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ twN,
+          const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J, int NCB) {
+  constexpr int N = 32 * P, KOFF = P * K2;
+  SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
+  SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
+  const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
+  for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
+  const int64_t pair = (int64_t)SC_BID_X * 8 + hw;
+  const int64_t rA = 2 * pair;
+  const int64_t img = rA / N0;
+  const int n = (int)(rA - img * N0);
+  cf32* E = Eall[hw];
+  const cf32* src = panel + ((img * NCB) * (int64_t)N0 + n) * SC_F2P_CB;
+  constexpr int NI = (KOFF + 32) / 32;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k = t + 32 * i;
+    if (k <= KOFF) {
+      cf32 zp = cf_make(0.f, 0.f), zm = zp;
+      if (k < J) {
+        const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
+        const cf32 A = a[0], B = a[SC_F2P_CB];
+        const float s = cs[k];                           // norm x column weight (x 1/2 for k > 0)
+        // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B)
+        zp = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
+        zm = cf_make(s * (A.x + B.y), s * (B.x - A.y));
+      }
+      E[KOFF + k] = zp;
+      if (k > 0) E[KOFF - k] = zm;
+    }
+  }
+  SC_SYNC();                                             // twiddle table, and the half-wave's Z
+  cf32 in[2 * K2 + 1];
+  const int L = t < P ? t : 0;
+#pragma unroll
+  for (int i = 0; i < 2 * K2; ++i) in[i] = E[KOFF + L + P * (i - K2)];
+  in[2 * K2] = (t == 0) ? E[2 * KOFF] : cf_make(0.f, 0.f);
+  SC_WAVE_SYNC();
+  {
+    cf32 g[32];
+    dft32_padded<+1, K2, true>(in, g);
+    if (t < P) {
+      E[t * SC_F2P_RS] = g[0];
+#pragma unroll
+      for (int q = 1; q < 32; ++q) E[t * SC_F2P_RS + q] = cf_mul_cs(g[q], cf_conj(tw[t * 32 + q]));
+    }
+  }
+  SC_WAVE_SYNC();
+  cf32 u[P], z[P];
+#pragma unroll
+  for (int k1 = 0; k1 < P; ++k1) u[k1] = E[k1 * SC_F2P_RS + t];
+  f2p_dftP<P, +1>(u, z);                                 // z[j] = a[t + 32 j] + i b[t + 32 j]
+  const float bv = bias ? bias[(img + img0) % channels] : 0.f;   // img0: first image of this chunk
+  float* ya = y + rA * N + t;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    SC_STORE_STREAM(ya + 32 * j, z[j].x + bv);
+    SC_STORE_STREAM(ya + N + 32 * j, z[j].y + bv);
+  }
+}

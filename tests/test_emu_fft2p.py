@@ -1,0 +1,127 @@
+"""CPU tier: the two-pass factorised transforms for large power-of-two grids (sc_kernels_fft2p.h) in host emulation:
+all four transform modes through the C-ABI against numpy's FFT of the same definition (rfft2 restricted to the kept
+block / irfft2 of the zero-padded block, spectral_convolution.py:443-449, 500-519, 531-568, and their adjoints) and
+against the size-agnostic direct-DFT route of the same library (SC_PLAN_FORCE_GENERIC)."""
+import numpy as np
+import pytest
+import torch
+
+from neuraloperator_amd import _lib
+from engine_runner import emu_lib, rel_l2
+
+TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def _ref_forward(x, kept, scale, weighted):
+    """kept block of the centred spectrum: rows f = r - K0/2, columns 0..J-1; `weighted` = adjoint of irfft2."""
+    K0, J = kept
+    N0, N1 = x.shape[-2:]
+    full = np.fft.fft(np.fft.rfft(x.astype(np.float64), axis=-1)[..., :J], axis=-2)
+    rows = [(r - K0 // 2) % N0 for r in range(K0)]
+    out = full[..., rows, :] * scale
+    if weighted:
+        w = np.full(J, 2.0)
+        w[0] = 1.0
+        out = out * w
+    return out
+
+
+def _ref_inverse(yhat, spatial, scale, weighted, bias=None):
+    K0, J = yhat.shape[-2:]
+    N0, N1 = spatial
+    n_img = yhat.shape[0]
+    spec = np.zeros((n_img, N0, J), dtype=np.complex128)
+    for r in range(K0):
+        spec[:, (r - K0 // 2) % N0, :] = yhat[:, r, :]
+    cols = np.fft.ifft(spec, axis=-2) * N0                      # unnormalised inverse over rows
+    w = np.full(J, 2.0 if weighted else 1.0)
+    w[0] = 1.0
+    n = np.arange(N1)
+    # y[n] = Re sum_j w_j cols[j] e^{+2 pi i j n / N1}: irfft semantics (weighted) or the adjoint of the pruned rfft
+    ph = np.exp(2j * np.pi * np.outer(np.arange(J), n) / N1)
+    y = np.real(np.einsum("brj,jn->brn", cols * w, ph)) * scale
+    if bias is not None:
+        y = y + bias[:, None, None]
+    return y
+
+
+CASES = [
+    # spatial, kept, images
+    ((1024, 1024), (256, 129), 1),      # BASELINE configs[4]
+    ((1024, 512), (64, 33), 2),
+    ((512, 1024), (31, 17), 2),         # odd kept rows, ragged columns
+    ((512, 512), (256, 120), 1),        # half of the rows, widest column range the codelets cover
+    ((1024, 1024), (2, 1), 1),
+]
+
+
+@pytest.mark.parametrize("spatial,kept,n_img", CASES, ids=[f"{s[0]}x{s[1]}_k{k[0]}x{k[1]}" for s, k, _ in CASES])
+def test_two_pass_transforms(lib, spatial, kept, n_img):
+    rng = np.random.default_rng(5)
+    N0, N1 = spatial
+    K0, J = kept
+    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+    try:
+        assert lib.plan_kernel_name(plan, 0) == "k_f2p_r2c", "the large power-of-two grid takes the two-pass route"
+        ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8)
+        x = torch.from_numpy(rng.standard_normal((n_img, N0, N1)).astype(np.float32))
+        ntot = N0 * N1
+        for mode, scale, weighted in ((_lib.SC_FWD_SCALED, 1.0 / ntot, False), (_lib.SC_FWD_ADJ_C2R, 1.0, True)):
+            xhat = torch.full((n_img, K0, J), float("nan"), dtype=torch.complex64)
+            lib.transform_forward(plan, mode, x.data_ptr(), torch.view_as_real(xhat).data_ptr(), n_img, ws.data_ptr(), 0)
+            ref = _ref_forward(x.numpy(), kept, scale, weighted)
+            assert rel_l2(xhat.numpy(), ref) < TOL, f"forward mode {mode}"
+        yh = (rng.standard_normal((n_img, K0, J)) + 1j * rng.standard_normal((n_img, K0, J))).astype(np.complex64)
+        yhat = torch.from_numpy(yh)
+        channels = n_img
+        bias = torch.from_numpy(rng.standard_normal(channels).astype(np.float32))
+        for mode, scale, weighted, b in ((_lib.SC_INV_PADDED, 1.0, True, bias), (_lib.SC_INV_ADJ_R2C, 1.0 / ntot, False, None)):
+            y = torch.full((n_img, N0, N1), float("nan"), dtype=torch.float32)
+            lib.transform_inverse(plan, mode, torch.view_as_real(yhat).data_ptr(), 0 if b is None else b.data_ptr(),
+                                  channels, y.data_ptr(), n_img, ws.data_ptr(), 0)
+            ref = _ref_inverse(yh, spatial, scale, weighted, None if b is None else b.numpy().astype(np.float64))
+            assert rel_l2(y.numpy(), ref) < TOL, f"inverse mode {mode}"
+    finally:
+        lib.plan_destroy(plan)
+
+
+def test_two_pass_matches_size_agnostic_route(lib):
+    """Same plan description on the direct-DFT passes (SC_PLAN_FORCE_GENERIC): the two routes are interchangeable."""
+    rng = np.random.default_rng(6)
+    spatial, kept, n_img = (512, 1024), (40, 65), 3
+    x = torch.from_numpy(rng.standard_normal((n_img, *spatial)).astype(np.float32))
+    yhat = torch.from_numpy((rng.standard_normal((n_img, *kept)) + 1j * rng.standard_normal((n_img, *kept))).astype(np.complex64))
+    bias = torch.from_numpy(rng.standard_normal(3).astype(np.float32))
+    res = {}
+    for tag, flags in (("f2p", 0), ("generic", _lib.SC_PLAN_FORCE_GENERIC)):
+        plan = lib.plan_create(list(spatial), list(kept), fft_norm="ortho", flags=flags)
+        try:
+            ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8)
+            xhat = torch.empty((n_img, *kept), dtype=torch.complex64)
+            lib.transform_forward(plan, _lib.SC_FWD_SCALED, x.data_ptr(), torch.view_as_real(xhat).data_ptr(), n_img, ws.data_ptr(), 0)
+            y = torch.empty((n_img, *spatial), dtype=torch.float32)
+            lib.transform_inverse(plan, _lib.SC_INV_PADDED, torch.view_as_real(yhat).data_ptr(), bias.data_ptr(), 3,
+                                  y.data_ptr(), n_img, ws.data_ptr(), 0)
+            res[tag] = (xhat.numpy().copy(), y.numpy().copy(), lib.plan_kernel_name(plan, 0))
+        finally:
+            lib.plan_destroy(plan)
+    assert res["f2p"][2] == "k_f2p_r2c" and res["generic"][2] != "k_f2p_r2c"
+    assert rel_l2(res["f2p"][0], res["generic"][0]) < TOL
+    assert rel_l2(res["f2p"][1], res["generic"][1]) < TOL
+
+
+def test_two_pass_scope(lib):
+    """Outside the route's scope the plan stays on the size-agnostic passes (and still works)."""
+    for spatial, kept in (((1024, 1024), (256, 513)),     # Nyquist column kept
+                          ((2048, 1024), (64, 33)),       # line length without a codelet
+                          ((1024, 256), (64, 33))):
+        plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+        try:
+            assert lib.plan_kernel_name(plan, 0) != "k_f2p_r2c"
+        finally:
+            lib.plan_destroy(plan)
