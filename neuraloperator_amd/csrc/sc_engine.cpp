@@ -22,6 +22,7 @@
 #include "sc_kernels_gemm8.h"
 #include "sc_kernels_mdft.h"
 #include "sc_kernels_fft2p.h"
+#include "sc_kernels_plane.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -110,6 +111,11 @@ struct sc_plan {
   cf32* f2p_tw[2] = {nullptr, nullptr};
   float* f2p_cs_fwd[2] = {nullptr, nullptr};   // [SC_FWD_SCALED], [SC_FWD_ADJ_C2R]
   float* f2p_cs_inv[2] = {nullptr, nullptr};   // [SC_INV_PADDED], [SC_INV_ADJ_R2C]
+  // factorised last-two-axes kernels for 128 x 128 planes (sc_kernels_plane.h)
+  bool pl128 = false;
+  cf32* pl_tab128 = nullptr;
+  float* pl_cs_fwd[2] = {nullptr, nullptr};
+  float* pl_cs_inv[2] = {nullptr, nullptr};
   // weight sub-block index tables (device), keyed by (w_extent, w_start)
   std::mutex idx_mu;
   std::map<IdxKey, int32_t*> idx_cache;
@@ -376,13 +382,35 @@ static int build_mdft_tables(sc_plan* p) {
 // two-pass factorised route (sc_kernels_fft2p.h): eligibility, tables, launches
 // ------------------------------------------------------------------------------------------
 #ifndef SC_F2P_CHUNK_MB
-#define SC_F2P_CHUNK_MB 96      // panel bytes in flight between the two passes (Infinity Cache: 256 MB)
+#define SC_F2P_CHUNK_MB 192     // panel bytes in flight between the two passes (Infinity Cache: 256 MB); measured
+                                // 32 / 96 / 192 / unchunked: 0.84 / 0.74 / 0.70 / 0.73 ms forward, 1.45 / 1.02 / 0.94 / 1.07 ms inverse
+                                // (profiles/r02_f2p_1024_time.txt)
 #endif
 
 static int f2p_pow2_at_least(int64_t v) {
   int r = 1;
   while (r < v) r *= 2;
   return r;
+}
+
+// per-column factors of the packed-row FFT kernels (sc_kernels_fft2p.h, sc_kernels_plane.h): norm x C2R column
+// weight, x 1/2 for the split of a packed pair (forward: every column; inverse: every column but k = 0)
+static int fft_col_scales(sc_plan* p, float** fwd, float** inv) {
+  const int L = p->nd - 1;
+  const int64_t J = p->k[L];
+  for (int v = 0; v < 2; ++v) {
+    std::vector<float> f((size_t)J), g((size_t)J);
+    for (int64_t k = 0; k < J; ++k) {
+      const double wf = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(k, p->n[L]);
+      const double wi = (v == SC_INV_PADDED) ? p->si * col_weight(k, p->n[L]) : p->sf;
+      f[(size_t)k] = (float)(0.5 * wf);
+      g[(size_t)k] = (float)(k == 0 ? wi : 0.5 * wi);
+    }
+    int rc = upload_floats(p, f, &fwd[v]);
+    if (!rc) rc = upload_floats(p, g, &inv[v]);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 static int f2p_plan_init(sc_plan* p) {
@@ -411,19 +439,24 @@ static int f2p_plan_init(sc_plan* p) {
     if (rc) return rc;
     p->f2p_tw[d] = dt.ptr;
   }
-  for (int v = 0; v < 2; ++v) {
-    std::vector<float> f((size_t)J), g((size_t)J);
-    for (int64_t k = 0; k < J; ++k) {
-      const double wf = (v == SC_FWD_SCALED) ? p->sf : p->si * col_weight(k, p->n[1]);
-      const double wi = (v == SC_INV_PADDED) ? p->si * col_weight(k, p->n[1]) : p->sf;
-      f[(size_t)k] = (float)(0.5 * wf);
-      g[(size_t)k] = (float)(k == 0 ? wi : 0.5 * wi);
-    }
-    int rc = upload_floats(p, f, &p->f2p_cs_fwd[v]);
-    if (!rc) rc = upload_floats(p, g, &p->f2p_cs_inv[v]);
-    if (rc) return rc;
-  }
+  int rc = fft_col_scales(p, p->f2p_cs_fwd, p->f2p_cs_inv);
+  if (rc) return rc;
   p->f2p = true;
+  return 0;
+}
+
+static int pl128_plan_init(sc_plan* p) {
+  const int L = p->nd - 1;
+  if (p->nd < 2 || p->cplx || p->custom_map || p->d.real_col) return 0;
+  if (p->n[L] != SC_PL_N || p->n[L - 1] != SC_PL_N || p->k[L] > SC_PL_JMAX || p->k[L - 1] > SC_PL_KMAX) return 0;
+  std::vector<cf32> h(128);
+  for (int m = 0; m < 128; ++m) h[(size_t)m] = twiddle(m, 1, 128, -1.0, 1.0);
+  DeviceTable dt;
+  int rc = upload_table(p, h, 1, 128, &dt);
+  if (!rc) rc = fft_col_scales(p, p->pl_cs_fwd, p->pl_cs_inv);
+  if (rc) return rc;
+  p->pl_tab128 = dt.ptr;
+  p->pl128 = true;
   return 0;
 }
 
@@ -634,6 +667,8 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
   if (!rc && !p->fast && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !(desc->flags & SC_PLAN_IO_BF16)) rc = f2p_plan_init(p);
+  if (!rc && !p->fast && !p->f2p && !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT)))
+    rc = pl128_plan_init(p);
   if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
     rc = sc_fail("sc_engine: SC_PLAN_IO_BF16 is implemented on the fused 2-D kernels (generation 3) only: "
                  "width 256, height 64..512, kept block <= 64 x 33, no frequency maps");
@@ -741,11 +776,13 @@ static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, co
 // ---- "plane" form: the last TWO axes in one launch when the second-to-last has 128, 64 or 32 rows --------
 static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32; }
 static bool plane_fwd_ok(const sc_plan* p, int mode) {
+  if (p->pl128) return true;
   const int L = p->nd - 1;
   return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_pl_fwd && plane_rows_ok(p->n[L - 1]) &&
          2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane;
 }
 static bool plane_inv_ok(const sc_plan* p, int mode) {
+  if (p->pl128) return true;
   const int L = p->nd - 1;
   if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_pl_inv && plane_rows_ok(p->n[L - 1]) &&
         2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane))
@@ -778,6 +815,12 @@ static void dispatch_plane_fwd(const sc_plan* p, int mode, const float* in, cf32
 
 // x (planes x 128 x N real) -> (planes x K1 x J complex): last axis + second-to-last axis
 static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
+  if (p->pl128) {
+    const int L = p->nd - 1;
+    SC_LAUNCH(k_pl128_fwd, dim3((unsigned)(lines / SC_PL_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
+              (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L]);
+    return sc_check_launch("k_pl128_fwd");
+  }
   const bool tail = p->l_r2c_tail[mode] != nullptr;
   if (tail) {
     if (p->l_r2c_ct == 1) dispatch_plane_fwd<1, true>(p, mode, in, out, lines, st);
@@ -888,6 +931,11 @@ static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, 
 static int run_plane_inv(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
                          int64_t lpi, int64_t channels, sc_stream_t st) {
   const int L = p->nd - 1;
+  if (p->pl128) {
+    SC_LAUNCH(k_pl128_inv, dim3((unsigned)(lines / SC_PL_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
+              (const float*)p->pl_cs_inv[mode], bias, lpi / SC_PL_N, (int)channels, (int)p->k[L - 1], (int)p->k[L]);
+    return sc_check_launch("k_pl128_inv");
+  }
   const int N = (int)p->n[L], J = (int)p->k[L];
   const int n_nt = (N + 31) / 32;
   const int64_t nr = p->n[L - 1];
@@ -1644,6 +1692,7 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   }
   if (p->cplx) return "k_axis_pass";
   if (p->f2p) return which == 0 ? "k_f2p_r2c" : "k_f2p_c2r";
+  if (p->pl128) return which == 0 ? "k_pl128_fwd" : "k_pl128_inv";
   if (p->mdft) {
     if (which == 0 && plane_fwd_ok(p, 0)) return "k_mdft_r2c_lds<plane>";
     if (which == 1 && plane_inv_ok(p, 0)) return "k_mdft_c2r_lds<plane>";

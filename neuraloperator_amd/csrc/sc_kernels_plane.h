@@ -1,0 +1,249 @@
+// sc_kernels_plane.h -- factorised transforms of the LAST TWO axes for 128 x 128 planes, one launch each way.
+//
+// FNO3d 128^3 (BASELINE configs[3]) and 2-D 128 x 128 grids: a plane is 64 KB of real data and its kept block
+// (<= 32 rows x 17 columns) 4 KB, so -- unlike the large grids of sc_kernels_fft2p.h -- both axes fit one
+// workgroup's LDS and the plane crosses HBM once.  The direct-DFT plane kernels of sc_kernels_mdft.h that served
+// these shapes spend 0.65-0.8 ms per launch at B x C = 256 volumes (2.15 GB: 2.5-3.0 TB/s) on the matrix pipe; here
+// every line is a Cooley-Tukey factorisation on the vector ALUs, as in the other FFT kernels of the engine:
+//
+//   rows     128 real points x 2 rows packed as one complex line, 16 lanes x 8 points (n = t + 16 j):
+//              radix-8 over j in registers, twiddle w128^(t k1), exchange, 16-point DFT over t by lane k1 (< 8),
+//              of which only k = k1 + 8 k2, |k| <= 16 is used; Z[k], Z[-k] -> A[k], B[k] -> tile T[row][k]
+//   columns  128 complex points, 8 lanes x 16 points (n = t + 8 j): radix-16 over j, twiddle, exchange, 8-point DFT
+//              over t (two k1 per lane) of which k = k1 + 16 k2, k2 in {-1, 0} are the 32 centred rows
+//   forward  k_pl128_fwd   x[plane][128][128] real -> out[plane][K0][J]   (rfft2 restricted to the kept block)
+//   inverse  k_pl128_inv   in[plane][K0][J]        -> y[plane][128][128] real (+ bias): the exact transpose
+// For 3-D data the first axis stays a size-agnostic axis pass over the (small) plane results.
+// Reference lines: spectral_convolution.py:443-449, 500-519 (forward), :531-568 (inverse).
+#pragma once
+#include "sc_kernels_fft2p.h"
+
+#define SC_PL_N 128
+#define SC_PL_RS 20          // tile row stride (complex): column-phase reads conflict-free
+#define SC_PL_ES 17          // row-phase exchange stride (per k1)
+#define SC_PL_JMAX 17
+#define SC_PL_KMAX 32
+
+struct PlLds {
+  static constexpr int T_c = SC_PL_N * SC_PL_RS;                 // 2560 complex
+  static constexpr int E_c = 16 * 8 * SC_PL_ES;                  // row exchange, 16 groups: 2176
+  static constexpr int Z_c = 16 * 34;                            // row-phase Z[-16..16] per group
+  static constexpr int E2_c = 17 * 148;                          // column exchange, 17 groups of 16 x 9 (+4): 2516
+  static constexpr int IO_c = SC_PL_KMAX * SC_PL_JMAX;           // kept block staged for one contiguous copy
+  static constexpr int off_T = 0;
+  static constexpr int off_E = off_T + T_c;
+  static constexpr int off_Z = off_E + (E_c > E2_c ? E_c : E2_c);
+  static constexpr int off_IO = off_Z + Z_c;
+  static constexpr int total_c = off_IO + IO_c;                  // 6164 complex = 49 KB: 3 workgroups per CU
+};
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 3)
+k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __restrict__ tab128,
+            const float* __restrict__ cs, int K0, int J) {
+  SC_SHARED __attribute__((aligned(16))) cf32 lds[PlLds::total_c];
+  cf32* T = lds + PlLds::off_T;
+  const int tid = SC_TID;
+  const int64_t plane = SC_BID_X;
+  const float* xp = x + plane * (int64_t)(SC_PL_N * SC_PL_N);
+  // ---------------- rows: 4 rounds of 16 packed row pairs ----------------
+  {
+    const int g = tid >> 4, t = tid & 15, L = t & 7;
+    cf32* E = lds + PlLds::off_E + g * (8 * SC_PL_ES);
+    cf32* Zs = lds + PlLds::off_Z + g * 34;
+    cf32 tw1[8];
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = tab128[(t * k1) & 127];
+    cf32 pf[8];
+    auto prefetch = [&](const int r) {
+      const float* ra = xp + (2 * (g + 16 * r)) * SC_PL_N + t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pf[j].x = SC_LOAD_STREAM(ra + 16 * j);
+        pf[j].y = SC_LOAD_STREAM(ra + SC_PL_N + 16 * j);
+      }
+    };
+    prefetch(0);
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int p = g + 16 * r;
+      cf32 u[8];
+      dft8<-1>(pf, u);                                   // over j -> k1
+      if (r < 3) prefetch(r + 1);
+      E[t] = u[0];
+#pragma unroll
+      for (int k1 = 1; k1 < 8; ++k1) E[k1 * SC_PL_ES + t] = cf_mul_cs(u[k1], tw1[k1]);
+      SC_WAVE_SYNC();
+      cf32 y[16], o[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) y[q] = E[L * SC_PL_ES + q];
+      fft16<-1>(y, o);                                   // over t -> k2: Z[L + 8 k2]
+      if (t < 8) {
+        Zs[16 + t] = o[0];
+        Zs[24 + t] = o[1];
+        Zs[8 + t] = o[15];
+        Zs[t] = o[14];
+        if (t == 0) Zs[32] = o[2];
+      }
+      SC_WAVE_SYNC();
+      {
+        // A = (Z[k] + conj Z[-k]) / 2, B = -i (Z[k] - conj Z[-k]) / 2 (the 1/2 rides on the column scale)
+        const cf32 zk = Zs[16 + t], zm = Zs[16 - t];
+        T[(2 * p) * SC_PL_RS + t] = cf_make(zk.x + zm.x, zk.y - zm.y);
+        T[(2 * p + 1) * SC_PL_RS + t] = cf_make(zk.y + zm.y, zm.x - zk.x);
+        if (t == 0) {
+          const cf32 zt = Zs[32], zb = Zs[0];
+          T[(2 * p) * SC_PL_RS + 16] = cf_make(zt.x + zb.x, zt.y - zb.y);
+          T[(2 * p + 1) * SC_PL_RS + 16] = cf_make(zt.y + zb.y, zb.x - zt.x);
+        }
+      }
+    }
+  }
+  SC_SYNC();
+  // ---------------- columns: 8 lanes per kept column ----------------
+  cf32* OUT = lds + PlLds::off_IO;
+  {
+    const int c = tid >> 3, t = tid & 7;
+    const bool act = c < SC_PL_JMAX;                     // waves 0, 1 and the first group of wave 2
+    cf32* E2 = lds + PlLds::off_E + (act ? c : 0) * 148;
+    if (act) {
+      cf32 v[16], u[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = T[(t + 8 * j) * SC_PL_RS + c];
+      fft16<-1>(v, u);                                   // over j -> k1
+      E2[t] = u[0];
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], tab128[(t * k1) & 127]);
+    }
+    SC_WAVE_SYNC();
+    if (act) {
+      const float s = (c < J) ? cs[c] : 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k1 = t + 8 * h;
+        cf32 y[8], o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[q] = E2[k1 * 9 + q];
+        dft8<-1>(y, o);                                  // over t -> k2: k = k1 + 16 k2; kept: k2 = 0 and k2 = -1
+        const int rp = k1 + K0 / 2, rn = k1 - 16 + K0 / 2;
+        if (c < J) {
+          if (rp < K0) OUT[rp * J + c] = cf_scale(o[0], s);
+          if (rn >= 0) OUT[rn * J + c] = cf_scale(o[7], s);
+        }
+      }
+    }
+  }
+  SC_SYNC();
+  cf32* dst = out + plane * (int64_t)K0 * J;
+  for (int i = tid; i < K0 * J; i += 256) dst[i] = OUT[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse
+// ------------------------------------------------------------------------------------------
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 3)
+k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __restrict__ tab128,
+            const float* __restrict__ cs, const float* __restrict__ bias, int64_t planes_per_image, int channels,
+            int K0, int J) {
+  SC_SHARED __attribute__((aligned(16))) cf32 lds[PlLds::total_c];
+  cf32* T = lds + PlLds::off_T;
+  cf32* IN = lds + PlLds::off_IO;
+  const int tid = SC_TID;
+  const int64_t plane = SC_BID_X;
+  {
+    const cf32* src = in + plane * (int64_t)K0 * J;
+    for (int i = tid; i < K0 * J; i += 256) IN[i] = src[i];
+  }
+  SC_SYNC();
+  // ---------------- columns: kept rows -> all 128 rows of the tile ----------------
+  {
+    const int c = tid >> 3, t = tid & 7;
+    const bool act = c < SC_PL_JMAX;
+    cf32* E2 = lds + PlLds::off_E + (act ? c : 0) * 148;
+    if (act) {
+      const float s = (c < J) ? cs[c] : 0.f;             // norm x column weight (x 1/2 for c > 0)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k1 = t + 8 * h;
+        const int rp = k1 + K0 / 2, rn = k1 - 16 + K0 / 2;
+        const cf32 x0 = (c < J && rp < K0) ? cf_scale(IN[rp * J + c], s) : cf_make(0.f, 0.f);
+        const cf32 xm = (c < J && rn >= 0) ? cf_scale(IN[rn * J + c], s) : cf_make(0.f, 0.f);
+        // g[q] = X[k1] + w8^(-q) X[k1 - 16],  w8 = exp(+2 pi i / 8);  then the twiddle conj(w128^(q k1))
+        cf32 e[8], o[8];
+        e[0] = x0;
+#pragma unroll
+        for (int q = 1; q < 7; ++q) e[q] = cf_make(0.f, 0.f);
+        e[7] = xm;
+        dft8<+1>(e, o);
+        E2[k1 * 9] = o[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) E2[k1 * 9 + q] = cf_mul_cs(o[q], cf_conj(tab128[(q * k1) & 127]));
+      }
+    }
+    SC_WAVE_SYNC();
+    if (act) {
+      cf32 u[16], v[16];
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) u[k1] = E2[k1 * 9 + t];
+      fft16<+1>(u, v);                                   // over k1 -> j: row n = t + 8 j
+#pragma unroll
+      for (int j = 0; j < 16; ++j) T[(t + 8 * j) * SC_PL_RS + c] = v[j];
+    }
+  }
+  SC_SYNC();
+  // ---------------- rows ----------------
+  {
+    const int g = tid >> 4, t = tid & 15, L = t & 7;
+    cf32* E = lds + PlLds::off_E + g * (8 * SC_PL_ES);
+    cf32* Zs = lds + PlLds::off_Z + g * 34;
+    cf32 tw2[16];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tw2[q] = cf_conj(tab128[(q * L) & 127]);
+    const float bv = bias ? bias[(plane / planes_per_image) % channels] : 0.f;
+    float* yp = y + plane * (int64_t)(SC_PL_N * SC_PL_N);
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int p = g + 16 * r;
+      {
+        // Z[k] = A + i B, Z[-k] = conj A + i conj B; k = 0: (Re A, Re B)
+        const cf32 A = T[(2 * p) * SC_PL_RS + t], B = T[(2 * p + 1) * SC_PL_RS + t];
+        Zs[16 + t] = (t == 0) ? cf_make(A.x, B.x) : cf_make(A.x - B.y, A.y + B.x);
+        if (t > 0) Zs[16 - t] = cf_make(A.x + B.y, B.x - A.y);
+        if (t == 0) {
+          const cf32 At = T[(2 * p) * SC_PL_RS + 16], Bt = T[(2 * p + 1) * SC_PL_RS + 16];
+          Zs[32] = cf_make(At.x - Bt.y, At.y + Bt.x);
+          Zs[0] = cf_make(At.x + Bt.y, Bt.x - At.y);
+        }
+      }
+      SC_WAVE_SYNC();
+      cf32 e[16], o[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) e[q] = cf_make(0.f, 0.f);
+      e[0] = Zs[16 + L];
+      e[1] = Zs[24 + L];
+      e[15] = Zs[8 + L];
+      e[14] = Zs[L];
+      e[2] = (L == 0) ? Zs[32] : cf_make(0.f, 0.f);
+      fft16<+1>(e, o);                                   // zero-padded 16-point stage: g[q], q = t index of the line
+      if (t < 8) {
+        E[t * SC_PL_ES] = o[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) E[t * SC_PL_ES + q] = cf_mul_cs(o[q], tw2[q]);
+      }
+      SC_WAVE_SYNC();
+      cf32 u[8], z[8];
+#pragma unroll
+      for (int k1 = 0; k1 < 8; ++k1) u[k1] = E[k1 * SC_PL_ES + t];
+      dft8<+1>(u, z);                                    // over k1 -> j: z[j] = a[t + 16 j] + i b[t + 16 j]
+      float* ra = yp + (2 * p) * SC_PL_N + t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        SC_STORE_STREAM(ra + 16 * j, z[j].x + bv);
+        SC_STORE_STREAM(ra + SC_PL_N + 16 * j, z[j].y + bv);
+      }
+      SC_WAVE_SYNC();                                    // Zs / E are rewritten by the next round
+    }
+  }
+}

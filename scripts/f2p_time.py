@@ -58,7 +58,7 @@ for path in libs:
             err = ((a[k] - b[k]).norm() / b[k].norm()).item()
             print(f"agreement {na} vs {nb} {k}: rel-L2 {err:.2e}")
         _, tg, _ = run(lib, _lib.SC_PLAN_FORCE_GENERIC, x, yh, bias, NIMG, 3)
-        print("direct-DFT route  :", "  ".join(f"{k} {v:.3f} ms ({alg / v:.0f} GB/s)" for k, v in tg.items()))
+        print("direct-DFT route  :", "  ".join(f"{k} {v:.3f} ms ({alg / v * 1e3:.0f} GB/s)" for k, v in tg.items()))
         base = True
     _, t, nm = run(lib, 0, x, yh, bias, NIMG, 10)
-    print(f"{os.path.basename(path)} [{nm}]:", "  ".join(f"{k} {v:.3f} ms ({alg / v:.0f} GB/s)" for k, v in t.items()))
+    print(f"{os.path.basename(path)} [{nm}]:", "  ".join(f"{k} {v:.3f} ms ({alg / v * 1e3:.0f} GB/s)" for k, v in t.items()))
