@@ -1007,6 +1007,18 @@ static void launch_mdft_axis(const cf32* in, cf32* out, const float* tab, int64_
             inner, n_jt);
 }
 
+// 128-point first-axis lines over the plane results (sc_kernels_plane.h)
+static bool ax128_ok(const sc_plan* p, int d) {
+  return p->pl128 && d < p->nd - 2 && p->n[d] == SC_PL_N && p->k[d] <= SC_PL_KMAX;
+}
+static int run_ax128(const sc_plan* p, int dir, const cf32* in, cf32* out, int64_t outer, int K, int64_t inner,
+                     sc_stream_t st) {
+  const dim3 grid((unsigned)((inner + 31) / 32), (unsigned)outer);
+  if (dir < 0) SC_LAUNCH((k_ax128<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
+  else SC_LAUNCH((k_ax128<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
+  return sc_check_launch("k_ax128");
+}
+
 static int run_axis_mdft(const float* tab, const cf32* in, cf32* out, int64_t outer, int N, int J, int64_t inner,
                          sc_stream_t st) {
   const int n_jt = (J + 15) / 16;
@@ -1094,7 +1106,9 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
     int64_t outer = n_images;
     for (int e = 0; e < d; ++e) outer *= p->n[e];
     cf32* dst = (d == 0) ? (cf32*)xhat : (cur == bufA ? bufB : bufA);
-    if (p->mdft && p->m_ax_fwd[d])
+    if (ax128_ok(p, d) && outer <= 65535)
+      rc = run_ax128(p, -1, cur, dst, outer, (int)p->k[d], inner, st);
+    else if (p->mdft && p->m_ax_fwd[d])
       rc = run_axis_mdft(p->m_ax_fwd[d], cur, dst, outer, (int)p->n[d], (int)p->k[d], inner, st);
     else
       rc = run_axis(p->ax_fwd_jt[d], cur, dst, p->ax_fwd[d], outer, (int)p->n[d], (int)p->k[d], inner, st);
@@ -1183,7 +1197,9 @@ extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* 
     const int remaining = L - 1 - d;  // passes after this one
     cf32* dst = (remaining % 2 == 0) ? bufA : bufB;
     int rc;
-    if (p->mdft && p->m_ax_inv[d])
+    if (ax128_ok(p, d) && outer <= 65535)
+      rc = run_ax128(p, +1, cur, dst, outer, (int)p->k[d], inner, st);
+    else if (p->mdft && p->m_ax_inv[d])
       rc = run_axis_mdft(p->m_ax_inv[d], cur, dst, outer, (int)p->k[d], (int)p->n[d], inner, st);
     else
       rc = run_axis(p->ax_inv_jt[d], cur, dst, p->ax_inv[d], outer, (int)p->k[d], (int)p->n[d], inner, st);

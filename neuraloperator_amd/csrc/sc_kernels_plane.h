@@ -247,3 +247,71 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// first axis of 3-D data: 128-point lines with an inner stride (the plane results), kept rows <= 32, centred.
+//   forward  in[o][128][inner] -> out[o][K][inner];   inverse  in[o][K][inner] -> out[o][128][inner]
+// Same line as the column phase above (8 lanes x 16 points, two kept k2 per k1), fed from global memory: a wave
+// owns 8 neighbouring inner positions (lane = (t, c): 64 contiguous bytes per row and instruction), a workgroup 32.
+// The size-agnostic matrix-core pass it replaces took 80-94 us per launch for 0.18 GB at FNO3d 128^3
+// (profiles/r02_fno3d_128_plane_fft_kernel_stats.txt).
+// ------------------------------------------------------------------------------------------
+template <int DIR>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
+k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ tab128, int64_t inner, int K) {
+  SC_SHARED __attribute__((aligned(16))) cf32 lds[4 * 8 * 148];
+  const int tid = SC_TID, w = tid >> 6, lane = tid & 63, c = lane & 7, t = lane >> 3;
+  const int64_t o = SC_BID_Y;
+  const int64_t col = ((int64_t)SC_BID_X * 4 + w) * 8 + c;
+  const bool live = col < inner;
+  cf32* E2 = lds + (w * 8 + c) * 148;
+  if (DIR < 0) {
+    const cf32* src = in + (o * SC_PL_N + t) * inner + col;
+    cf32 v[16], u[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = live ? src[(int64_t)8 * j * inner] : cf_make(0.f, 0.f);
+    fft16<-1>(v, u);
+    E2[t] = u[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], tab128[(t * k1) & 127]);
+    SC_WAVE_SYNC();
+    cf32* dst = out + o * K * inner + col;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k1 = t + 8 * h;
+      cf32 y[8], r[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] = E2[k1 * 9 + q];
+      dft8<-1>(y, r);
+      const int rp = k1 + K / 2, rn = k1 - 16 + K / 2;
+      if (live && rp < K) dst[(int64_t)rp * inner] = r[0];
+      if (live && rn >= 0) dst[(int64_t)rn * inner] = r[7];
+    }
+  } else {
+    const cf32* src = in + o * K * inner + col;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k1 = t + 8 * h;
+      const int rp = k1 + K / 2, rn = k1 - 16 + K / 2;
+      cf32 e[8], g[8];
+      e[0] = (live && rp < K) ? src[(int64_t)rp * inner] : cf_make(0.f, 0.f);
+#pragma unroll
+      for (int q = 1; q < 7; ++q) e[q] = cf_make(0.f, 0.f);
+      e[7] = (live && rn >= 0) ? src[(int64_t)rn * inner] : cf_make(0.f, 0.f);
+      dft8<+1>(e, g);
+      E2[k1 * 9] = g[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) E2[k1 * 9 + q] = cf_mul_cs(g[q], cf_conj(tab128[(q * k1) & 127]));
+    }
+    SC_WAVE_SYNC();
+    cf32 u[16], v[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) u[k1] = E2[k1 * 9 + t];
+    fft16<+1>(u, v);
+    if (live) {
+      cf32* dst = out + (o * SC_PL_N + t) * inner + col;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dst[(int64_t)8 * j * inner] = v[j];
+    }
+  }
+}

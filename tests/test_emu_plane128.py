@@ -62,6 +62,7 @@ CASES = [
     ((128, 128), (21, 9), 2),           # odd kept rows, fewer columns
     ((6, 128, 128), (4, 32, 17), 2),    # 3-D: planes + axis pass over the first dim (FNO3d 128^3 shape family)
     ((128, 128), (1, 1), 1),
+    ((128, 128, 128), (21, 32, 17), 1),  # first axis on the 128-point line kernel as well (k_ax128)
 ]
 
 
