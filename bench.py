@@ -193,6 +193,15 @@ def stage_profile(B, C, spatial, n_modes, flags, iters, io="f32"):
     return out, names
 
 
+def engine_path(names):
+    """Which transform kernels the plan of this workload runs (sc_plan_kernel_name): the fused one-image-per-workgroup
+    FFT (256-wide grids), the two-pass factorised FFT (512 / 1024 per axis), the factorised plane kernels (128 x 128
+    last two axes) or the size-agnostic direct-DFT passes."""
+    if names["fast"]:
+        return "fused-fft"
+    return {"k_f2p_r2c": "two-pass-fft", "k_pl128_fwd": "plane-fft"}.get(names["fwd"], "generic-dft")
+
+
 def cpu_baseline(C, spatial, n_modes, threads, budget_s=10.0):
     """The reference's CPU path on the host cores of this box, fwd + autograd bwd of one SpectralConv layer, with
     ``threads`` torch threads.
@@ -519,7 +528,7 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "B_per_gpu": b_local, "global_batch": global_batch,
                        "channels": C, "grid": list(spatial), "n_modes": list(n_modes), "kept": kept,
-                       "parallelism": par, "engine_path": "fused-fft" if names["fast"] else "generic-dft",
+                       "parallelism": par, "engine_path": engine_path(names),
                        "real_tensor_io": args.io,
                        "weights": "dense complex64, random init"},
             "roofline": roof,
