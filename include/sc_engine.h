@@ -123,7 +123,11 @@ enum {
   SC_GEMM_STREAM_C = 2,      /* C is not consumed by the next kernel: non-temporal stores    */
   SC_GEMM_PAIRED = 4,        /* P = 32: two 4-wave workgroups per CU, 5 modes each (A-B; slower from HBM) */
   SC_GEMM_WIDE = 8,          /* 9 modes per workgroup even for a small mode count (A-B / tests)          */
-  SC_GEMM_NO_STREAM = 16     /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
+  SC_GEMM_NO_STREAM = 16,    /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
+  SC_GEMM_F16 = 32           /* the reference's complex-half contraction (fno_block_precision "half" / "mixed",
+                              * einsum_utils.py:10-36): operands rounded to float16, four real products summed in
+                              * fp32 and rounded to float16, re = t00 - t11, im = t10 + t01 rounded to float16;
+                              * fp32 storage throughout.  Plain C = opA(A) opB(B) launches (no accumulate) */
 };
 /* flags bits 8..23: cap on the number of workgroups of the matrix-core kernel (0 = auto) */
 #define SC_GEMM_GRID(n) (((n) & 0xffff) << 8)
@@ -160,6 +164,11 @@ int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
  * matrix-core kernel: sub-blocks through index tables, ragged ranks, factor operands), 2 k_modegemm_s8 (LDS-DMA
  * streamed matrix-core kernel: plain contiguous-mode operands, mode count a multiple of 8) */
 int sc_modegemm_path(const sc_modegemm_desc* d);
+
+/* out[i] = float16(in[i]) (round to nearest even), kept in fp32 storage; in == out allowed.  The cast points of
+ * fno_block_precision "half" / "mixed" (spectral_convolution.py:436-437 x.half(), :451-454 x.chalf(), and the
+ * float16 result of the inverse transform). */
+int sc_round_f16(const float* in, float* out, int64_t n, void* stream);
 
 /* gbias[c] = sum_b Re(ghat[b, c, dc]) -- the bias gradient read off the DC coefficient of
  * the already-computed SC_FWD_ADJ_C2R spectrum (autograd of :567-568). */

@@ -26,6 +26,7 @@ SC_GEMM_STREAM_C = 2
 SC_GEMM_PAIRED = 4
 SC_GEMM_WIDE = 8
 SC_GEMM_NO_STREAM = 16
+SC_GEMM_F16 = 32
 
 
 def SC_GEMM_GRID(n):
@@ -115,7 +116,7 @@ class ScEngineLib:
                "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
-               "sc_layer_forward_ex"]
+               "sc_layer_forward_ex", "sc_round_f16"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -168,6 +169,8 @@ class ScEngineLib:
         L.sc_layer_forward_ex.restype = c_int
         L.sc_layer_backward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 8
         L.sc_layer_backward.restype = c_int
+        L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+        L.sc_round_f16.restype = c_int
         L.sc_last_error.restype = c_char_p
         L.sc_version.restype = c_char_p
         L.sc_plan_kernel_name.argtypes = [c_void_p, c_int]
@@ -236,6 +239,10 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    def round_f16(self, in_ptr, out_ptr, n, stream=0):
+        """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""
+        self._check(self.lib.sc_round_f16(in_ptr, out_ptr, n, stream))
 
     def modegemm_msum(self, a_ptr, b_ptr, c_ptr, stream=0, **kw):
         d = ModeGemmDesc()

@@ -187,6 +187,39 @@ inline uint16_t sc_f32_to_bf16_bits(const float f) {
 }
 #endif
 
+// --------------------------------------------------------------------------- float16 rounding
+// (fno_block_precision = "half" / "mixed": values are ROUNDED to float16 where the reference holds them in
+// float16 / complex32 -- spectral_convolution.py:436-459, einsum_utils.py:10-36 -- and kept in fp32 storage)
+#ifndef SC_EMU
+SC_DEVICE float sc_round_f16(const float f) { return (float)(_Float16)f; }      // v_cvt_f16_f32, nearest even
+#else
+inline float sc_round_f16(const float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint32_t sign = u & 0x80000000u;
+  uint32_t a = u & 0x7fffffffu;
+  float r;
+  if (a >= 0x7f800000u) {                                   // inf / nan
+    r = f;
+    return r;
+  }
+  if (a >= 0x477ff000u) {                                   // >= 65520: rounds to infinity
+    a = 0x7f800000u;
+  } else if (a >= 0x38800000u) {                            // normal half: keep 10 mantissa bits
+    a += 0xfffu + ((a >> 13) & 1u);
+    a &= ~0x1fffu;
+  } else {                                                  // subnormal half: multiples of 2^-24
+    float m;
+    std::memcpy(&m, &a, 4);
+    const float q = std::nearbyint(m * 16777216.f) / 16777216.f;   // default rounding mode: nearest even
+    std::memcpy(&a, &q, 4);
+  }
+  a |= sign;
+  std::memcpy(&r, &a, 4);
+  return r;
+}
+#endif
+
 // --------------------------------------------------------------------------- complex helpers
 struct cf32 {
   float x, y;

@@ -1327,7 +1327,7 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 // workgroups the chip holds at once: narrow 3 per CU (48 KiB of LDS each), wide 2 per CU (64 KiB)
 #define SC_G8_RESIDENT(wide) ((wide) ? 512 : 768)
 static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
-  if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM)) return false;
+  if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM | SC_GEMM_F16)) return false;
   if (d->accumulate || d->b_idx || d->c_idx) return false;
   if (d->a_sm != 1 || d->b_sm != 1 || d->c_sm != 1) return false;
   if (d->n_modes % 8 != 0 || d->n_modes >= ((int64_t)1 << 31)) return false;
@@ -1423,6 +1423,19 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   const cf32* a = (const cf32*)A;
   const cf32* b = (const cf32*)B;
   cf32* c = (cf32*)C;
+  if (d->flags & SC_GEMM_F16) {
+    SC_CHECK_ARG(!d->accumulate && !(d->a_sg || d->b_sg || d->c_sg), "SC_GEMM_F16: plain C = A B launches only");
+    g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
+    g.n_pg = (int)((g.P + 15) / 16);
+    g.n_qt = (int)((g.Q + 3) / 4);
+    g.per_xcd = 0;
+    const dim3 grid((unsigned)((int64_t)g.n_mt * g.n_pg * g.n_qt));
+    if (d->conj_a && d->conj_b) SC_LAUNCH((k_modegemm_f16<true, true>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
+    else if (d->conj_a) SC_LAUNCH((k_modegemm_f16<true, false>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
+    else if (d->conj_b) SC_LAUNCH((k_modegemm_f16<false, true>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
+    else SC_LAUNCH((k_modegemm_f16<false, false>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
+    return sc_check_launch("k_modegemm_f16");
+  }
   if (gemm8_eligible(d, A, B, C)) return run_gemm8(d, a, b, c, st);
   SC_CHECK_ARG(!(d->a_sg || d->b_sg || d->c_sg),
                "tiled operands (a_sg / b_sg / c_sg) need the streamed matrix-core kernel: n_modes % 16 == 0, unit mode "
@@ -1472,6 +1485,15 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
   else if (!d->conj_a && d->conj_b) launch_msum<false, true>(g, a, b, c, st);
   else launch_msum<true, true>(g, a, b, c, st);
   return sc_check_launch("k_modegemm_msum");
+}
+
+extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  SC_CHECK_ARG(in && out, "null argument");
+  int64_t blocks = (n + SC_BLOCK - 1) / SC_BLOCK;
+  if (blocks > 16384) blocks = 16384;
+  SC_LAUNCH(k_round_f16, dim3((unsigned)blocks), dim3(SC_BLOCK), 0, (sc_stream_t)stream, in, out, n, blocks * SC_BLOCK);
+  return sc_check_launch("k_round_f16");
 }
 
 extern "C" int sc_modegemm_path(const sc_modegemm_desc* d) {

@@ -275,6 +275,85 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// The contraction with the reference's complex-half semantics (fno_block_precision "half" / "mixed":
+// einsum_utils.py:10-36 einsum_complexhalf_two_input).  The reference views both operands as real, casts them to
+// float16, evaluates FOUR real einsums t[x][y] = sum_r a_x b_y (x, y in {re, im}; float16 results of fp32 sums) and
+// combines re = t00 - t11, im = t10 + t01 in float16.  Same roundings here, at the same points: operands rounded
+// to float16 as they are loaded, four fp32 accumulators, each rounded once, the two combinations rounded once more.
+// C holds float16-representable values in fp32 storage.  (Conjugation is exact in any precision.)
+// ------------------------------------------------------------------------------------------
+template <bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_modegemm_f16(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+  constexpr int PT = 4, QT = 4;
+  const int tid = SC_TID;
+  const int lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int item = SC_BID_X;
+  if (item >= g.n_mt * g.n_pg * g.n_qt) return;
+  const int mt = item / (g.n_pg * g.n_qt);
+  const int rem = item - mt * (g.n_pg * g.n_qt);
+  const int qt = rem / g.n_pg, pg = rem - qt * g.n_pg;
+  const int64_t m = (int64_t)mt * SC_WAVE + lane;
+  const int64_t p0 = ((int64_t)pg * 4 + w) * PT;
+  const int64_t q0 = (int64_t)qt * QT;
+  if (p0 >= g.P) return;
+  const bool active = m < g.M;
+  const int64_t mm = active ? m : g.M - 1;
+  const int64_t la = mm * g.a_sm;
+  const int64_t lb = g.b_idx ? (int64_t)g.b_idx[mm] : mm * g.b_sm;
+  const int64_t lc = g.c_idx ? (int64_t)g.c_idx[mm] : mm * g.c_sm;
+  float rr[PT][QT], ii[PT][QT], ri[PT][QT], ir[PT][QT];
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) rr[pp][qq] = ii[pp][qq] = ri[pp][qq] = ir[pp][qq] = 0.f;
+  for (int64_t r = 0; r < g.R; ++r) {
+    cf32 a[PT], b[QT];
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp) {
+      const int64_t p = (p0 + pp < g.P) ? (p0 + pp) : (g.P - 1);
+      const cf32 v = A[p * g.a_sp + r * g.a_sr + la];
+      a[pp] = cf_make(sc_round_f16(v.x), sc_round_f16(CA ? -v.y : v.y));
+    }
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      const int64_t q = (q0 + qq < g.Q) ? (q0 + qq) : (g.Q - 1);
+      const cf32 v = B[r * g.b_sr + q * g.b_sq + lb];
+      b[qq] = cf_make(sc_round_f16(v.x), sc_round_f16(CB ? -v.y : v.y));
+    }
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) {
+        rr[pp][qq] = fmaf(a[pp].x, b[qq].x, rr[pp][qq]);
+        ii[pp][qq] = fmaf(a[pp].y, b[qq].y, ii[pp][qq]);
+        ri[pp][qq] = fmaf(a[pp].x, b[qq].y, ri[pp][qq]);
+        ir[pp][qq] = fmaf(a[pp].y, b[qq].x, ir[pp][qq]);
+      }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp) {
+    if (p0 + pp >= g.P) continue;
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      if (q0 + qq >= g.Q) continue;
+      cf32 v;
+      v.x = sc_round_f16(sc_round_f16(rr[pp][qq]) - sc_round_f16(ii[pp][qq]));
+      v.y = sc_round_f16(sc_round_f16(ir[pp][qq]) + sc_round_f16(ri[pp][qq]));
+      C[(p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq + lc] = v;
+    }
+  }
+}
+
+// out[i] = float16(in[i]) kept in fp32 storage (in == out allowed)
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_round_f16(const float* __restrict__ in, float* __restrict__ out, int64_t n, int64_t stride) {
+  for (int64_t i = (int64_t)SC_BID_X * SC_BLOCK + SC_TID; i < n; i += stride) out[i] = sc_round_f16(in[i]);
+}
+
+// ------------------------------------------------------------------------------------------
 // Mode-summed complex GEMM:  C[p,q] += sum_m sum_r opA(A[p,r,m]) * opB(B[r,q,m])
 // the gradient of a mode-INDEPENDENT operand (Tucker / CP factor matrices, spectral_convolution.py
 // :55-103): same lanes-are-modes tiles as k_modegemm; a workgroup walks every per_xcd-th mode tile

@@ -409,7 +409,7 @@ def _strides3(t, lead):
     return int(t.stride(0)), int(t.stride(1)), 0
 
 
-def _raw_mode_gemm(a, b, n_modes, conj_a, conj_b, reduce_modes=False):
+def _raw_mode_gemm(a, b, n_modes, conj_a, conj_b, reduce_modes=False, flags=0):
     """a: [P, R, M] or [P, R]; b: [R, Q, M] or [R, Q]; complex64 CUDA tensors/views (any strides).
     Returns C[P, Q, M] (or C[P, Q] = sum over modes when reduce_modes)."""
     lib = _lib.get_lib()
@@ -433,7 +433,7 @@ def _raw_mode_gemm(a, b, n_modes, conj_a, conj_b, reduce_modes=False):
         if P and Q and n_modes:
             fn(a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream(), P=P, Q=Q, R=R, n_modes=n_modes,
                a_sp=a_sp, a_sr=a_sr, a_sm=a_sm, b_sr=b_sr, b_sq=b_sq, b_sm=b_sm,
-               conj_a=int(conj_a), conj_b=int(conj_b), **c)
+               conj_a=int(conj_a), conj_b=int(conj_b), flags=int(flags), **c)
     return out
 
 
@@ -445,7 +445,7 @@ class ModeGemmFn(torch.autograd.Function):
     (spectral_convolution.py:55-103) and of their autograd."""
 
     @staticmethod
-    def forward(ctx, a, b, n_modes, conj_a, conj_b):
+    def forward(ctx, a, b, n_modes, conj_a, conj_b, flags=0):
         _require_gpu(a, "A")
         _require_gpu(b, "B")
         a = a if a.dtype == torch.complex64 else a.to(torch.complex64)
@@ -454,7 +454,10 @@ class ModeGemmFn(torch.autograd.Function):
             raise ValueError(f"inner extents differ: A {tuple(a.shape)} B {tuple(b.shape)}")
         ctx.save_for_backward(a, b)
         ctx.cfg = (int(n_modes), bool(conj_a), bool(conj_b))
-        return _raw_mode_gemm(a, b, int(n_modes), conj_a, conj_b)
+        ctx.flags = int(flags)                # SC_GEMM_F16: the complex-half contraction, forward AND gradients
+        if ctx.flags & _lib.SC_GEMM_F16 and (a.dim() != 3 or b.dim() != 3):
+            raise ValueError("SC_GEMM_F16 contracts two per-mode operands (the dense equation)")
+        return _raw_mode_gemm(a, b, int(n_modes), conj_a, conj_b, flags=ctx.flags)
 
     @staticmethod
     def backward(ctx, gc):
@@ -474,7 +477,7 @@ class ModeGemmFn(torch.autograd.Function):
                 bm = b.permute(1, 2, 0).reshape(Q * M, R)                              # [QM, R], mode independent
                 ga = _raw_mode_gemm(gt, bm, P, ca, cbx).reshape(R, P).t()
             else:
-                ga = _raw_mode_gemm(gc, b.transpose(0, 1), M, ca, cbx, reduce_modes=(a.dim() == 2))
+                ga = _raw_mode_gemm(gc, b.transpose(0, 1), M, ca, cbx, reduce_modes=(a.dim() == 2), flags=ctx.flags)
         if ctx.needs_input_grad[1]:
             # grad_b = sum_p conj(opA(A)) * gC; conj_b: grad_B = conj(grad_b) = sum_p opA(A) * conj(gC)
             cax = ca if cb else not ca
@@ -493,12 +496,35 @@ class ModeGemmFn(torch.autograd.Function):
                 g2 = gc.permute(1, 0, 2).reshape(1, Q, P * M)                           # [1, Q, (p m)] (copy)
                 gb = _raw_mode_gemm(a2, g2, P * M, cax, cb, reduce_modes=True)
             else:
-                gb = _raw_mode_gemm(a.transpose(0, 1), gc, M, cax, cb, reduce_modes=(b.dim() == 2))
-        return ga, gb, None, None, None
+                gb = _raw_mode_gemm(a.transpose(0, 1), gc, M, cax, cb, reduce_modes=(b.dim() == 2), flags=ctx.flags)
+        return ga, gb, None, None, None, None
 
 
-def mode_gemm(a, b, n_modes, conj_a=False, conj_b=False):
-    return ModeGemmFn.apply(a, b, n_modes, conj_a, conj_b)
+def mode_gemm(a, b, n_modes, conj_a=False, conj_b=False, flags=0):
+    return ModeGemmFn.apply(a, b, n_modes, conj_a, conj_b, flags)
+
+
+class RoundF16Fn(torch.autograd.Function):
+    """``t.half()`` of the reference's half / mixed precision modes (spectral_convolution.py:436-437 and the float16
+    result of the inverse transform of a complex32 spectrum) with the values kept in fp32 storage: sc_round_f16.
+    The cast's autograd is a cast back, i.e. the gradient passes through."""
+
+    @staticmethod
+    def forward(ctx, t):
+        _require_gpu(t, "t")
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        with torch.cuda.device(t.device):
+            _lib.get_lib().round_f16(t.data_ptr(), out.data_ptr(), t.numel(), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_f16(t):
+    return RoundF16Fn.apply(t)
 
 
 class EngineOps:

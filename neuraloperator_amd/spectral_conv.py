@@ -11,17 +11,17 @@ All arithmetic of the layer is in libsc_engine.so; this file is argument checkin
 autograd plumbing.  Dense / Tucker / CP / TT weights, separable weights, complex data and
 resolution-changing layers (``resolution_scaling_factor`` / ``output_shape``, with the reference's
 end-padding behaviour) all run on the engine -- there is no silent PyTorch fallback.
-``fno_block_precision="half"/"mixed"`` (fp16 FFT / chalf einsum upstream, :436-459) are accepted and
-computed with the engine's fp32 spectral arithmetic, i.e. at least the reference's precision; the result
-has the dtype the reference returns (fp32 with a bias, fp16 without).  That pair is "parity unpinned":
-the reference's fp16 path does not run on its CPU backend, so no golden vectors exist for it.
+``fno_block_precision="half"/"mixed"`` (:436-459): values are rounded to float16 at the reference's cast points and
+the contraction follows ``einsum_complexhalf`` (einsum_utils.py:10-36) -- pinned against the verbatim function; the two
+transforms compute in fp32 (the reference's float16 FFT has no CPU backend to pin against).  The result has the dtype
+the reference returns (fp32 with a bias, fp16 without).
 """
 from typing import List, Optional, Tuple, Union
 
 import torch
 from torch import nn
 
-from . import engine
+from . import _lib, engine
 from .factorized import CPWeight, DenseWeight, SpectralWeight, TTWeight, TuckerWeight
 from . import modes
 from .modes import halve_last_mode, kept_block
@@ -201,7 +201,9 @@ class SpectralConv(BaseSpectralConv):
             out_shape = list(output_shape)
         out_shape = [int(v) for v in out_shape]
         if self.fno_block_precision in ("half", "mixed") and not self.complex_data:
-            y = self._forward_full(x.float(), spatial, out_shape)
+            if x.is_cuda and not self.separable and out_shape == spatial:
+                return self._forward_half(x.float(), spatial)
+            y = self._forward_full(x.float(), spatial, out_shape)    # separable / resized: fp32 arithmetic
             return y if self.bias is not None else y.half()      # half + fp32 bias promotes to fp32 upstream
         if x.dtype == torch.bfloat16:
             # bfloat16 activations (BASELINE configs[1] "bf16"; torch.fft has no bfloat16, so upstream has no
@@ -224,6 +226,28 @@ class SpectralConv(BaseSpectralConv):
                                                self.engine_flags)
         y = self(x) + skip
         return torch.nn.functional.gelu(y) if activation == "gelu" else y
+
+    def _forward_half(self, x, spatial):
+        """``fno_block_precision`` "half" / "mixed" (spectral_convolution.py:436-459): the reference casts x to
+        float16 ("half"), the spectrum to complex32 (both) and contracts with ``einsum_complexhalf``
+        (einsum_utils.py:10-36); the inverse transform of the complex32 spectrum returns float16.  Here every one of
+        those values is ROUNDED to float16 at the same point and kept in fp32 storage: the contraction reproduces the
+        reference's four-real-product arithmetic (SC_GEMM_F16, pinned against the verbatim einsum on the CPU), the two
+        transforms compute in fp32 (the reference's float16 FFT arithmetic is the backend's; it has no CPU
+        implementation to pin against).  Factorized weights contract through their dense block."""
+        kept, wsl = self._used_block(spatial)
+        w = self._block_dense(wsl, kept)
+        ops = engine.EngineOps(self.fft_norm, self.engine_flags)
+        if self.fno_block_precision == "half":
+            x = engine.round_f16(x)                                                   # :436-437
+        xhat = ops.forward_transform(x, kept)
+        b, ci = int(xhat.shape[0]), int(xhat.shape[1])
+        co, m = int(w.shape[1]), 1
+        for k in kept:
+            m *= int(k)
+        yhat = engine.mode_gemm(xhat.reshape(b, ci, m), w.reshape(ci, co, m), m, flags=_lib.SC_GEMM_F16)
+        y = engine.round_f16(ops.inverse_transform(yhat.reshape(b, co, *kept), None, spatial))
+        return y + self.bias if self.bias is not None else y.half()
 
     def _forward_full(self, x, spatial, out_shape):
         if self.complex_data or out_shape != spatial:

@@ -159,6 +159,35 @@ def gen_variant(ref, name, kw, b, ci, co, spatial, n_modes, output_shape, seed):
     return out
 
 
+# fno_block_precision "half" / "mixed": name, precision, B, Cin, Cout, spatial, n_modes
+HALF_CASES = [
+    ("half_2d", "half", 2, 6, 5, (16, 16), (8, 8)),
+    ("mixed_2d", "mixed", 2, 6, 5, (16, 16), (8, 8)),
+    ("mixed_3d", "mixed", 1, 4, 4, (8, 8, 8), (4, 4, 4)),
+]
+
+
+def gen_half(name, precision, b, ci, co, spatial, n_modes, seed):
+    """The verbatim module cannot run these modes on the CPU (no float16 FFT in MKL), so the fixture comes from the
+    oracle's restatement (oracle.spectral_oracle.forward_half_torch) whose contraction -- the part with a defined
+    arithmetic -- is pinned against the verbatim ``einsum_complexhalf`` in tests/test_oracle_vs_reference.py.
+    Gradients: torch autograd through the restatement (casts pass the gradient through, the float16 einsum
+    differentiates in float16)."""
+    from . import spectral_oracle as so
+    torch.manual_seed(seed)
+    nm = so.halve_last(list(n_modes))
+    w = (torch.randn(ci, co, *nm, dtype=torch.cfloat) * 0.5).requires_grad_(True)
+    bias = (torch.randn(co, *([1] * len(spatial))) * 0.3).requires_grad_(True)
+    x = torch.randn(b, ci, *spatial, requires_grad=True)
+    y = so.forward_half_torch(x, w, bias, nm, precision=precision)
+    g = torch.randn_like(y)
+    y.backward(g)
+    out = dict(x=_np(x), w=_np(w), bias=_np(bias), g=_np(g), y=_np(y), gx=_np(x.grad), gw=_np(w.grad),
+               gbias=_np(bias.grad), ctor_n_modes=np.array(n_modes), precision=np.array(precision))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+    return out
+
+
 def gen_transform(ref, name, spatial, output_shape, seed):
     torch.manual_seed(seed)
     conv = ref.SpectralConv(2, 2, tuple(4 for _ in spatial))
@@ -219,6 +248,9 @@ def main():
     for i, case in enumerate(TRANSFORM_CASES):
         o = gen_transform(ref, *case, seed=4000 + i)
         print(f"{case[0]:32s} t{o['t'].shape}")
+    for i, case in enumerate(HALF_CASES):
+        o = gen_half(*case, seed=6000 + i)
+        print(f"{case[0]:32s} y{o['y'].shape} |y|={np.abs(o['y']).mean():.3f}")
     for i, case in enumerate(ADAMW_CASES):
         o = gen_adamw(*case, seed=5000 + i)
         print(f"{case[0]:32s} |pc|={np.abs(o['pc']).mean():.3f} v dtype {o['v_c'].dtype}")

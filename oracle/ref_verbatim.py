@@ -92,3 +92,19 @@ def load_reference_fno():
         m.__path__ = [os.path.join(root, "models")]
         sys.modules["neuralop.models"] = m
     return importlib.import_module("neuralop.models.fno")
+
+
+def load_reference_patching():
+    """The verbatim ``neuralop.training.patching`` (MultigridPatching2D, make_patches) with the verbatim
+    ``neuralop.mpu`` modules it imports (comm, mappings, helpers)."""
+    import importlib
+
+    if not available():
+        raise RuntimeError(f"reference not present under {REFERENCE_ROOT}")
+    root = os.path.join(REFERENCE_ROOT, "neuralop")
+    for pkg, sub in (("neuralop", ""), ("neuralop.training", "training"), ("neuralop.mpu", "mpu")):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(root, sub) if sub else root]
+            sys.modules[pkg] = m
+    return importlib.import_module("neuralop.training.patching")

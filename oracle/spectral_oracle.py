@@ -236,6 +236,37 @@ def forward_torch(x, weight, bias, n_modes_h, max_n_modes=None, fft_norm="forwar
 
 
 # --------------------------------------------------------------------------
+# fno_block_precision = "half" / "mixed" (spectral_convolution.py:436-459, einsum_utils.py:10-36)
+# --------------------------------------------------------------------------
+def contract_dense_chalf(x, w):
+    """The dense contraction as ``einsum_complexhalf_two_input`` evaluates it (einsum_utils.py:10-36): both operands
+    viewed as real and cast to float16, ONE real einsum with the two real/imaginary axes kept apart
+    (tmp[x][y] = sum_i a_x b_y, a float16 result), re = tmp00 - tmp11, im = tmp10 + tmp01 in float16.
+    Returns complex64 holding float16-representable values (complex32 has no FFT on the CPU)."""
+    nd = x.ndim - 2
+    m = "cdef"[:nd]
+    a = torch.view_as_real(x.to(torch.complex64)).half()
+    b = torch.view_as_real(w.to(torch.complex64)).half()
+    tmp = torch.einsum(f"ab{m}x,bz{m}y->xyaz{m}", a, b)                          # :30-32
+    res = torch.stack([tmp[0, 0] - tmp[1, 1], tmp[1, 0] + tmp[0, 1]], dim=-1)    # :33-35
+    return torch.view_as_complex(res.float())
+
+
+def forward_half_torch(x, weight, bias, n_modes_h, max_n_modes=None, fft_norm="forward", precision="mixed"):
+    """Real data, unchanged grid, dense weight block.  The cast points of the reference -- x.half() for "half"
+    (:436-437), x.chalf() before the contraction (:451-454, inside contract_dense_chalf here), the complex32
+    ``out_fft`` (:455-462) whose inverse transform returns float16 -- with every value ROUNDED to float16 at that
+    point and carried in fp32, and the two transforms evaluated in fp32: torch has no float16 FFT on the CPU, the
+    reference's float16 FFT arithmetic is whatever the GPU backend does and cannot be pinned here."""
+    assert precision in ("half", "mixed")
+    if precision == "half":
+        x = x.half().float()
+    y = forward_torch(x, weight, None, n_modes_h, max_n_modes, fft_norm, contract=contract_dense_chalf)
+    y = y.half().float()
+    return y + bias if bias is not None else y.half()
+
+
+# --------------------------------------------------------------------------
 # numpy float64 "kept-rows" formulation
 # --------------------------------------------------------------------------
 def _kept_index(spatial, freqs):

@@ -117,3 +117,22 @@ def test_state_dict_layout_is_the_reference_containers(fac, sep):
         assert tuple(rs[k].shape) == tuple(ms[k].shape) and rs[k].dtype == ms[k].dtype, k
     mine.load_state_dict(rs)
     assert so.rel_l2(mine.weight.to_tensor().detach().numpy(), rconv.weight.to_tensor().detach().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 4, 8, 5), (3, 6, 6, 12)], ids=str)
+def test_chalf_contraction_matches_verbatim_einsum_complexhalf(shape):
+    """fno_block_precision half / mixed: oracle.contract_dense_chalf == the verbatim einsum_complexhalf
+    (einsum_utils.py:10-83) on the dense equation the module builds (:21-46), bit for bit."""
+    import sys
+    ref_verbatim.load_reference()
+    eu = sys.modules["neuralop.layers.einsum_utils"]
+    b, ci, co = shape[:3]
+    modes = shape[3:]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, ci, *modes, dtype=torch.complex64, generator=g)
+    w = torch.randn(ci, co, *modes, dtype=torch.complex64, generator=g)
+    m = "cd"[:len(modes)]
+    want = eu.einsum_complexhalf(f"ab{m},be{m}->ae{m}", x.chalf(), w.chalf())        # the module's call (:42-44)
+    got = so.contract_dense_chalf(x, w)
+    assert want.dtype == torch.complex32
+    assert torch.equal(torch.view_as_real(want).float(), torch.view_as_real(got))
