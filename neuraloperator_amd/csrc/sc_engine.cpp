@@ -492,7 +492,8 @@ static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, i
     const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
     const float* xs = x + i0 * p->ntot;
     bool ok = f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / 16)), dim3(256), 0, st,
+      SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / (16 * SC_F2P_R2C_ITER))),
+                dim3(256), 0, st,
                 xs, panel, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_fwd[mode], N0, J, NCB);
     });
     cf32* dst = xhat + i0 * p->modes;
@@ -520,7 +521,8 @@ static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float
     });
     float* ys = y + i0 * p->ntot;
     ok = ok && f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / 16)), dim3(256), 0, st,
+      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / (16 * SC_F2P_C2R_ITER))),
+                dim3(256), 0, st,
                 (const cf32*)panel, ys, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_inv[mode], bias,
                 (int)channels, (int)(i0 % channels), N0, J, NCB);
     });

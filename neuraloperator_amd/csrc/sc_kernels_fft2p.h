@@ -161,62 +161,77 @@ SC_HD void dft32_padded(const cf32 (&in)[2 * K2 + 1], cf32 (&g)[32]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 1 forward: real rows -> kept columns of the panel.  One half-wave per packed row pair, 8 pairs per workgroup.
+// pass 1 forward: real rows -> kept columns of the panel.  One half-wave per packed row pair, 8 pairs per workgroup
+// and round, SC_F2P_R2C_ITER rounds per workgroup: the rows of the next round are requested as soon as the first
+// stage has consumed the current ones (the occupancy of this kernel is set by its LDS, so the 64 extra registers
+// of the prefetch cost nothing).
 // ------------------------------------------------------------------------------------------
+#ifndef SC_F2P_R2C_ITER
+#define SC_F2P_R2C_ITER 2
+#endif
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __restrict__ twN,
           const float* __restrict__ cs, int N0, int J, int NCB) {
   constexpr int N = 32 * P, KOFF = P * K2;
+  constexpr int NI = (KOFF + 32) / 32;                   // k = t + 32 i <= KOFF
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
   const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
-  const int64_t pair = (int64_t)SC_BID_X * 8 + hw;
-  const int64_t rA = 2 * pair;
-  const int64_t img = rA / N0;
-  const int n = (int)(rA - img * N0);
-  const float* xa = x + rA * N + t;
   cf32 z[P], u[P];
+  auto fetch = [&](const int it) {
+    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_R2C_ITER + it) * 8 + hw);
+    const float* xa = x + rA * N + t;
 #pragma unroll
-  for (int j = 0; j < P; ++j) {
-    z[j].x = SC_LOAD_STREAM(xa + 32 * j);
-    z[j].y = SC_LOAD_STREAM(xa + N + 32 * j);
-  }
+    for (int j = 0; j < P; ++j) {
+      z[j].x = SC_LOAD_STREAM(xa + 32 * j);
+      z[j].y = SC_LOAD_STREAM(xa + N + 32 * j);
+    }
+  };
+  fetch(0);
+  float sc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) sc[i] = (t + 32 * i < J) ? cs[t + 32 * i] : 0.f;   // 0.5 x norm x column weight
   SC_SYNC();                                             // twiddle table
   cf32* E = Eall[hw];
-  f2p_dftP<P, -1>(z, u);                                 // over j -> k1
-  E[t] = u[0];
+#pragma unroll 1
+  for (int it = 0; it < SC_F2P_R2C_ITER; ++it) {
+    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_R2C_ITER + it) * 8 + hw);
+    const int64_t img = rA / N0;
+    const int n = (int)(rA - img * N0);
+    f2p_dftP<P, -1>(z, u);                               // over j -> k1
+    if (it + 1 < SC_F2P_R2C_ITER) fetch(it + 1);
+    E[t] = u[0];
 #pragma unroll
-  for (int k1 = 1; k1 < P; ++k1) E[k1 * SC_F2P_RS + t] = cf_mul_cs(u[k1], tw[k1 * 32 + t]);
-  SC_WAVE_SYNC();
-  cf32 y[32], Zk[2 * K2 + 1];
-  const int L = t < P ? t : 0;                           // lane L plays k1 = L (lanes >= P idle at P = 16)
+    for (int k1 = 1; k1 < P; ++k1) E[k1 * SC_F2P_RS + t] = cf_mul_cs(u[k1], tw[k1 * 32 + t]);
+    SC_WAVE_SYNC();
+    cf32 y[32], Zk[2 * K2 + 1];
+    const int L = t < P ? t : 0;                         // lane L plays k1 = L (lanes >= P idle at P = 16)
 #pragma unroll
-  for (int q = 0; q < 32; ++q) y[q] = E[L * SC_F2P_RS + q];
-  SC_WAVE_SYNC();
-  dft32_kept<-1, K2, true>(y, Zk);                       // Z[L + P k2], k2 = -K2 .. K2
-  if (t < P) {
+    for (int q = 0; q < 32; ++q) y[q] = E[L * SC_F2P_RS + q];
+    SC_WAVE_SYNC();
+    dft32_kept<-1, K2, true>(y, Zk);                     // Z[L + P k2], k2 = -K2 .. K2
+    if (t < P) {
 #pragma unroll
-    for (int i = 0; i < 2 * K2; ++i) E[KOFF + t + P * (i - K2)] = Zk[i];
-    if (t == 0) E[2 * KOFF] = Zk[2 * K2];
-  }
-  SC_WAVE_SYNC();
-  cf32* dst = panel + ((img * NCB) * (int64_t)N0 + n) * SC_F2P_CB;
-  constexpr int NI = (KOFF + 32) / 32;                   // k = t + 32 i <= KOFF
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int k = t + 32 * i;
-    if (k < J) {
-      const cf32 zk = E[KOFF + k], zm = E[KOFF - k];
-      const float s = cs[k];                             // 0.5 x norm x column weight
-      // A = (Z[k] + conj Z[-k]) / 2,  B = -i (Z[k] - conj Z[-k]) / 2
-      const cf32 A = cf_make(s * (zk.x + zm.x), s * (zk.y - zm.y));
-      const cf32 B = cf_make(s * (zk.y + zm.y), s * (zm.x - zk.x));
-      cf32* d = dst + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
-      d[0] = A;
-      d[SC_F2P_CB] = B;
+      for (int i = 0; i < 2 * K2; ++i) E[KOFF + t + P * (i - K2)] = Zk[i];
+      if (t == 0) E[2 * KOFF] = Zk[2 * K2];
     }
+    SC_WAVE_SYNC();
+    cf32* dst = panel + ((img * NCB) * (int64_t)N0 + n) * SC_F2P_CB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = t + 32 * i;
+      if (k < J) {
+        const cf32 zk = E[KOFF + k], zm = E[KOFF - k];
+        const float s = sc[i];
+        // A = (Z[k] + conj Z[-k]) / 2,  B = -i (Z[k] - conj Z[-k]) / 2
+        cf32* d = dst + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
+        d[0] = cf_make(s * (zk.x + zm.x), s * (zk.y - zm.y));
+        d[SC_F2P_CB] = cf_make(s * (zk.y + zm.y), s * (zm.x - zk.x));
+      }
+    }
+    SC_WAVE_SYNC();                                      // E is rewritten by the next round
   }
 }
 
@@ -315,67 +330,90 @@ k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf3
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 1 inverse: kept columns of two panel rows -> two real rows (+ bias)
+// pass 1 inverse: kept columns of two panel rows -> two real rows (+ bias).  A half-wave transforms SC_F2P_C2R_ITER
+// packed row pairs in a row and requests the (few) panel values of the next pair before it transforms the current
+// one, so only the first pair of a workgroup waits for memory.
 // ------------------------------------------------------------------------------------------
+#ifndef SC_F2P_C2R_ITER
+#define SC_F2P_C2R_ITER 4
+#endif
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ twN,
           const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J, int NCB) {
   constexpr int N = 32 * P, KOFF = P * K2;
+  constexpr int NI = (KOFF + 32) / 32;
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
   const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
-  const int64_t pair = (int64_t)SC_BID_X * 8 + hw;
-  const int64_t rA = 2 * pair;
-  const int64_t img = rA / N0;
-  const int n = (int)(rA - img * N0);
   cf32* E = Eall[hw];
-  const cf32* src = panel + ((img * NCB) * (int64_t)N0 + n) * SC_F2P_CB;
-  constexpr int NI = (KOFF + 32) / 32;
+  float sc[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int k = t + 32 * i;
-    if (k <= KOFF) {
-      cf32 zp = cf_make(0.f, 0.f), zm = zp;
+  for (int i = 0; i < NI; ++i) sc[i] = (t + 32 * i < J) ? cs[t + 32 * i] : 0.f;   // norm x column weight (x 1/2, k > 0)
+  cf32 pa[NI], pb[NI];
+  auto fetch = [&](const int it) {
+    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_C2R_ITER + it) * 8 + hw);
+    const int64_t img = rA / N0;
+    const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = t + 32 * i;
       if (k < J) {
         const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
-        const cf32 A = a[0], B = a[SC_F2P_CB];
-        const float s = cs[k];                           // norm x column weight (x 1/2 for k > 0)
-        // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B)
-        zp = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
-        zm = cf_make(s * (A.x + B.y), s * (B.x - A.y));
+        pa[i] = a[0];
+        pb[i] = a[SC_F2P_CB];
+      } else {
+        pa[i] = pb[i] = cf_make(0.f, 0.f);
       }
-      E[KOFF + k] = zp;
-      if (k > 0) E[KOFF - k] = zm;
     }
-  }
-  SC_SYNC();                                             // twiddle table, and the half-wave's Z
-  cf32 in[2 * K2 + 1];
-  const int L = t < P ? t : 0;
+  };
+  fetch(0);
+  SC_SYNC();                                             // twiddle table
+#pragma unroll 1
+  for (int it = 0; it < SC_F2P_C2R_ITER; ++it) {
+    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_C2R_ITER + it) * 8 + hw);
+    const int64_t img = rA / N0;
 #pragma unroll
-  for (int i = 0; i < 2 * K2; ++i) in[i] = E[KOFF + L + P * (i - K2)];
-  in[2 * K2] = (t == 0) ? E[2 * KOFF] : cf_make(0.f, 0.f);
-  SC_WAVE_SYNC();
-  {
-    cf32 g[32];
-    dft32_padded<+1, K2, true>(in, g);
-    if (t < P) {
-      E[t * SC_F2P_RS] = g[0];
-#pragma unroll
-      for (int q = 1; q < 32; ++q) E[t * SC_F2P_RS + q] = cf_mul_cs(g[q], cf_conj(tw[t * 32 + q]));
+    for (int i = 0; i < NI; ++i) {
+      const int k = t + 32 * i;
+      if (k <= KOFF) {
+        const cf32 A = pa[i], B = pb[i];
+        const float s = sc[i];
+        // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B)
+        E[KOFF + k] = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
+        if (k > 0) E[KOFF - k] = cf_make(s * (A.x + B.y), s * (B.x - A.y));
+      }
     }
-  }
-  SC_WAVE_SYNC();
-  cf32 u[P], z[P];
+    if (it + 1 < SC_F2P_C2R_ITER) fetch(it + 1);
+    SC_WAVE_SYNC();
+    cf32 in[2 * K2 + 1];
+    const int L = t < P ? t : 0;
 #pragma unroll
-  for (int k1 = 0; k1 < P; ++k1) u[k1] = E[k1 * SC_F2P_RS + t];
-  f2p_dftP<P, +1>(u, z);                                 // z[j] = a[t + 32 j] + i b[t + 32 j]
-  const float bv = bias ? bias[(img + img0) % channels] : 0.f;   // img0: first image of this chunk
-  float* ya = y + rA * N + t;
+    for (int i = 0; i < 2 * K2; ++i) in[i] = E[KOFF + L + P * (i - K2)];
+    in[2 * K2] = (t == 0) ? E[2 * KOFF] : cf_make(0.f, 0.f);
+    SC_WAVE_SYNC();
+    {
+      cf32 g[32];
+      dft32_padded<+1, K2, true>(in, g);
+      if (t < P) {
+        E[t * SC_F2P_RS] = g[0];
 #pragma unroll
-  for (int j = 0; j < P; ++j) {
-    SC_STORE_STREAM(ya + 32 * j, z[j].x + bv);
-    SC_STORE_STREAM(ya + N + 32 * j, z[j].y + bv);
+        for (int q = 1; q < 32; ++q) E[t * SC_F2P_RS + q] = cf_mul_cs(g[q], cf_conj(tw[t * 32 + q]));
+      }
+    }
+    SC_WAVE_SYNC();
+    cf32 u[P], z[P];
+#pragma unroll
+    for (int k1 = 0; k1 < P; ++k1) u[k1] = E[k1 * SC_F2P_RS + t];
+    SC_WAVE_SYNC();                                      // E is rewritten by the next pair's Z
+    f2p_dftP<P, +1>(u, z);                               // z[j] = a[t + 32 j] + i b[t + 32 j]
+    const float bv = bias ? bias[(img + img0) % channels] : 0.f;   // img0: first image of this chunk
+    float* ya = y + rA * N + t;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      SC_STORE_STREAM(ya + 32 * j, z[j].x + bv);
+      SC_STORE_STREAM(ya + N + 32 * j, z[j].y + bv);
+    }
   }
 }

@@ -12,12 +12,17 @@ from neuraloperator_amd import _lib  # noqa: E402
 
 lib = _lib.get_lib()
 dev = torch.device("cuda:0")
-B, C, H = 32, 64, 256
+# LAYER_SHAPE = "B,C,spatial...,modes..." (default: the metric shape 32,64,256,256,64,64)
+shape = [int(v) for v in os.environ.get("LAYER_SHAPE", "32,64,256,256,64,64").split(",")]
+B, C = shape[:2]
+nd = (len(shape) - 2) // 2
+spatial, modes = shape[2:2 + nd], shape[2 + nd:]
+kept = modes[:-1] + [modes[-1] // 2 + 1]
 torch.manual_seed(0)
-x = torch.randn(B, C, H, 256, device=dev)
-g = torch.randn(B, C, H, 256, device=dev)
-w = torch.randn(C, C, 64, 33, dtype=torch.cfloat, device=dev)
-bias = torch.randn(C, 1, 1, device=dev)
-for _ in range(5):
-    layer_fwd_bwd(lib, x, w, bias, g, [64, 33], [64, 33])
+x = torch.randn(B, C, *spatial, device=dev)
+g = torch.randn(B, C, *spatial, device=dev)
+w = torch.randn(C, C, *kept, dtype=torch.cfloat, device=dev)
+bias = torch.randn(C, *([1] * nd), device=dev)
+for _ in range(int(os.environ.get("LAYER_REPS", 5))):
+    layer_fwd_bwd(lib, x, w, bias, g, kept, kept)
 torch.cuda.synchronize()
