@@ -490,6 +490,8 @@ static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, i
   const int64_t chunk = f2p_chunk_images(p, n_images);
   for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
     const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
+    const int64_t n_blk = ni * NCB;
+    const int per_xcd = (int)((n_blk + 7) / 8);
     const float* xs = x + i0 * p->ntot;
     bool ok = f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
       SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / (16 * SC_F2P_R2C_ITER))),
@@ -498,8 +500,8 @@ static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, i
     });
     cf32* dst = xhat + i0 * p->modes;
     ok = ok && f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * NCB)), dim3(256), 0, st,
-                (const cf32*)panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0);
+      SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * per_xcd)), dim3(256), 0, st,
+                (const cf32*)panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, per_xcd);
     });
     if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
   }
@@ -514,10 +516,12 @@ static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float
   const int64_t chunk = f2p_chunk_images(p, n_images);
   for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
     const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
+    const int64_t n_blk = ni * NCB;
+    const int per_xcd = (int)((n_blk + 7) / 8);
     const cf32* src = yhat + i0 * p->modes;
     bool ok = f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * NCB)), dim3(256), 0, st,
-                src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0);
+      SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * per_xcd)), dim3(256), 0, st,
+                src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, per_xcd);
     });
     float* ys = y + i0 * p->ntot;
     ok = ok && f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
@@ -1222,6 +1226,12 @@ static void launch_modegemm(const ModeGemmArgs& g0, const cf32* A, const cf32* B
   g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
   g.n_pg = (int)((g.P + 4 * PT - 1) / (4 * PT));
   g.n_qt = (int)((g.Q + QT - 1) / QT);
+#ifndef SC_MG_NO_WAVE_MODES
+  g.wave_modes = (g.P <= PT && g.n_mt >= 64) ? 1 : 0;
+#else
+  g.wave_modes = 0;
+#endif
+  if (g.wave_modes) g.n_mt = (g.n_mt + 3) / 4;
   const int64_t total = (int64_t)g.n_mt * g.n_pg * g.n_qt;
   g.per_xcd = (int)((total + 7) / 8);
   dim3 grid((unsigned)(8 * g.per_xcd));
@@ -1419,6 +1429,7 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
   g.b_idx = d->b_idx; g.c_idx = d->c_idx;
   g.accumulate = d->accumulate;
+  g.wave_modes = 0;
   SC_CHECK_ARG(((g.M + 63) / 64) * ((g.P + 15) / 16) * ((g.Q + 3) / 4) < ((int64_t)1 << 30),
                "problem too large for one launch grid");
   sc_stream_t st = (sc_stream_t)stream;

@@ -39,6 +39,16 @@
 #define SC_F2P_CB 8                   // kept columns per panel block
 #define SC_F2P_CS (32 * SC_F2P_RS + 4)  // per-column exchange stride of the column kernels (= 4 mod 32: reads conflict-free)
 
+// workgroup -> panel block, XCD-aware (A-B: -DSC_F2P_NO_XCD_MAP = launch order)
+SC_DEVICE int64_t f2p_block(const int per_xcd) {
+#ifdef SC_F2P_NO_XCD_MAP
+  (void)per_xcd;
+  return SC_BID_X;
+#else
+  return (int64_t)(SC_BID_X & 7) * per_xcd + (SC_BID_X >> 3);
+#endif
+}
+
 template <int I, int N, typename F>
 SC_HD void sc_static_for(F&& f) {
   if constexpr (I < N) {
@@ -166,8 +176,10 @@ SC_HD void dft32_padded(const cf32 (&in)[2 * K2 + 1], cf32 (&g)[32]) {
 // stage has consumed the current ones (the occupancy of this kernel is set by its LDS, so the 64 extra registers
 // of the prefetch cost nothing).
 // ------------------------------------------------------------------------------------------
+// (measured, profiles/r02_f2p_round_loop_ab.txt: 1 / 2 / 4 rounds -> 0.652-0.654 / 0.656-0.689 / 0.666 ms per forward
+// transform at 1024^2: nothing to gain, the default stays 1)
 #ifndef SC_F2P_R2C_ITER
-#define SC_F2P_R2C_ITER 2
+#define SC_F2P_R2C_ITER 1
 #endif
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
@@ -243,13 +255,16 @@ k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __r
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_col_fwd(const cf32* __restrict__ panel, cf32* __restrict__ xhat, const cf32* __restrict__ twN, int NCB, int J,
-              int K0) {
+              int K0, int64_t n_blk, int per_xcd) {
   constexpr int N0 = 32 * P;
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_F2P_CS];
   const int tid = SC_TID, c = tid & 7, s = tid >> 3;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
-  const int64_t blk = SC_BID_X;
+  // consecutive panel blocks (the column blocks of one image) on ONE XCD: their 64-byte output pieces share
+  // 128-byte lines, which then merge in that XCD's L2 (the dispatcher places workgroup b on XCD b % 8)
+  const int64_t blk = f2p_block(per_xcd);
+  if (blk >= n_blk) return;
   const int cb = (int)(blk % NCB);
   const int64_t img = blk / NCB;
   const int col = cb * SC_F2P_CB + c;
@@ -287,13 +302,16 @@ k_f2p_col_fwd(const cf32* __restrict__ panel, cf32* __restrict__ xhat, const cf3
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf32* __restrict__ twN, int NCB, int J,
-              int K0) {
+              int K0, int64_t n_blk, int per_xcd) {
   constexpr int N0 = 32 * P;
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_F2P_CS];
   const int tid = SC_TID, c = tid & 7, s = tid >> 3;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
-  const int64_t blk = SC_BID_X;
+  // consecutive panel blocks on ONE XCD (see k_f2p_col_fwd): the 64-byte pieces of the kept rows that neighbouring
+  // column blocks read share 128-byte lines -- fetched once per XCD instead of once per block (126 MB per chunk for 45 MB of kept rows before, profiles/r02_pmc_traffic_raw_fno2d_1024.txt)
+  const int64_t blk = f2p_block(per_xcd);
+  if (blk >= n_blk) return;
   const int cb = (int)(blk % NCB);
   const int64_t img = blk / NCB;
   const int col = cb * SC_F2P_CB + c;
@@ -334,8 +352,10 @@ k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf3
 // packed row pairs in a row and requests the (few) panel values of the next pair before it transforms the current
 // one, so only the first pair of a workgroup waits for memory.
 // ------------------------------------------------------------------------------------------
+// (measured, profiles/r02_f2p_round_loop_ab.txt: 1 / 4 / 8 pairs per half-wave -> 0.913-0.920 / 0.911-0.926 / 0.910 ms
+// per inverse transform at 1024^2 -- the other resident workgroup already covers the wait; the default stays 1)
 #ifndef SC_F2P_C2R_ITER
-#define SC_F2P_C2R_ITER 4
+#define SC_F2P_C2R_ITER 1
 #endif
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)

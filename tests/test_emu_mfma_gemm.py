@@ -162,3 +162,24 @@ def test_mode_independent_factor_on_matrix_cores(lib):
              a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=F, b_sq=1, b_sm=0, c_sp=F * M, c_sq=M, c_sm=1)
     ref = np.einsum("bim,if->bfm", x.numpy().astype(np.complex128), u.numpy().astype(np.complex128))
     assert rel_l2(z.numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("conj_b", [0, 1])
+def test_few_rows_many_modes_valu_mapping(lib, conj_b):
+    """P <= 4 rows and >= 64 mode tiles (a batch of 4 at 1024^2: weight streaming): the four waves of a workgroup take
+    neighbouring mode tiles instead of p groups.  Mode count not a multiple of 256 (ragged last workgroup and wave),
+    transposed B strides as in the gX contraction."""
+    P, R, Q, M = 3, 6, 10, 64 * 66 + 37
+    a = _rand(P, R, M, seed=41)
+    w = _rand(Q, R, M, seed=42) if conj_b else _rand(R, Q, M, seed=42)
+    c = torch.full((P, Q, M), float("nan"), dtype=torch.complex64)
+    kw = dict(P=P, Q=Q, R=R, n_modes=M, a_sp=R * M, a_sr=M, a_sm=1, c_sp=Q * M, c_sq=M, c_sm=1, conj_b=conj_b)
+    if conj_b:
+        kw.update(b_sr=M, b_sq=R * M, b_sm=1)           # B[r][q] = conj(w[q][r])
+    else:
+        kw.update(b_sr=Q * M, b_sq=M, b_sm=1)
+    assert not lib.modegemm_uses_matrix_cores(**kw)
+    lib.modegemm(_c(a).data_ptr(), _c(w).data_ptr(), torch.view_as_real(c).data_ptr(), 0, **kw)
+    ref = np.einsum("prm,qrm->pqm", a.numpy().astype(np.complex128), np.conj(w.numpy().astype(np.complex128))) if conj_b \
+        else np.einsum("prm,rqm->pqm", a.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
+    assert rel_l2(c.numpy(), ref) < TOL
