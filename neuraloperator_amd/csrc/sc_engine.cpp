@@ -1226,12 +1226,9 @@ static void launch_modegemm(const ModeGemmArgs& g0, const cf32* A, const cf32* B
   g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
   g.n_pg = (int)((g.P + 4 * PT - 1) / (4 * PT));
   g.n_qt = (int)((g.Q + QT - 1) / QT);
-#ifndef SC_MG_NO_WAVE_MODES
-  g.wave_modes = (g.P <= PT && g.n_mt >= 64) ? 1 : 0;
-#else
-  g.wave_modes = 0;
-#endif
-  if (g.wave_modes) g.n_mt = (g.n_mt + 3) / 4;
+  // (the four waves of a workgroup over four neighbouring mode tiles instead of p groups when P <= PT -- 2 KB
+  // contiguous per operand row for the weight-streaming launches at B = 4 -- changed nothing:
+  // profiles/r02_valu_contraction_wave_modes_ab.txt)
   const int64_t total = (int64_t)g.n_mt * g.n_pg * g.n_qt;
   g.per_xcd = (int)((total + 7) / 8);
   dim3 grid((unsigned)(8 * g.per_xcd));
@@ -1429,7 +1426,6 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
   g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = d->c_sm;
   g.b_idx = d->b_idx; g.c_idx = d->c_idx;
   g.accumulate = d->accumulate;
-  g.wave_modes = 0;
   SC_CHECK_ARG(((g.M + 63) / 64) * ((g.P + 15) / 16) * ((g.Q + 3) / 4) < ((int64_t)1 << 30),
                "problem too large for one launch grid");
   sc_stream_t st = (sc_stream_t)stream;

@@ -39,7 +39,8 @@
 #define SC_F2P_CB 8                   // kept columns per panel block
 #define SC_F2P_CS (32 * SC_F2P_RS + 4)  // per-column exchange stride of the column kernels (= 4 mod 32: reads conflict-free)
 
-// workgroup -> panel block, XCD-aware (A-B: -DSC_F2P_NO_XCD_MAP = launch order)
+// workgroup -> panel block, XCD-aware (A-B: -DSC_F2P_NO_XCD_MAP = launch order; measured equal within the run-to-run
+// spread, profiles/r02_f2p_xcd_map_ab.txt)
 SC_DEVICE int64_t f2p_block(const int per_xcd) {
 #ifdef SC_F2P_NO_XCD_MAP
   (void)per_xcd;

@@ -188,10 +188,6 @@ struct ModeGemmArgs {
   int accumulate;
   // launch geometry: 1-D grid of 8 * per_xcd blocks, work item = (mode tile, p group, q tile)
   int n_mt, n_pg, n_qt, per_xcd;
-  // few rows (P <= PT: one p group, e.g. a batch of 4 at 1024^2): the four waves of a workgroup take four
-  // NEIGHBOURING mode tiles instead of four p groups (three of which would be empty), so a workgroup streams 2 KB
-  // contiguous per (r, q) operand row instead of 512 B
-  int wave_modes;
 };
 
 template <int PT, int QT, bool CA, bool CB>
@@ -211,10 +207,10 @@ k_modegemm(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ 
   const int mt = item / (g.n_pg * g.n_qt);
   const int rem = item - mt * (g.n_pg * g.n_qt);
   const int qt = rem / g.n_pg, pg = rem - qt * g.n_pg;
-  const int64_t m = g.wave_modes ? ((int64_t)mt * 4 + w) * SC_WAVE + lane : (int64_t)mt * SC_WAVE + lane;
-  const int64_t p0 = g.wave_modes ? 0 : ((int64_t)pg * 4 + w) * PT;   // wave-uniform
+  const int64_t m = (int64_t)mt * SC_WAVE + lane;
+  const int64_t p0 = ((int64_t)pg * 4 + w) * PT;            // wave-uniform
   const int64_t q0 = (int64_t)qt * QT;                      // wave-uniform
-  if (p0 >= g.P || (g.wave_modes && ((int64_t)mt * 4 + w) * SC_WAVE >= g.M)) return;  // whole wave idle (no barriers here)
+  if (p0 >= g.P) return;  // whole wave idle (no barriers in this kernel)
   const bool active = m < g.M;
   const int64_t mm = active ? m : g.M - 1;
   // per-lane part of every address: one 32-bit element offset per operand; everything else is

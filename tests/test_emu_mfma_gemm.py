@@ -166,9 +166,8 @@ def test_mode_independent_factor_on_matrix_cores(lib):
 
 @pytest.mark.parametrize("conj_b", [0, 1])
 def test_few_rows_many_modes_valu_mapping(lib, conj_b):
-    """P <= 4 rows and >= 64 mode tiles (a batch of 4 at 1024^2: weight streaming): the four waves of a workgroup take
-    neighbouring mode tiles instead of p groups.  Mode count not a multiple of 256 (ragged last workgroup and wave),
-    transposed B strides as in the gX contraction."""
+    """P <= 4 rows and many mode tiles on the VALU kernel (a batch of 4 at 1024^2: weight streaming): one p group,
+    three of the four waves idle.  Mode count not a multiple of 64, transposed B strides as in the gX contraction."""
     P, R, Q, M = 3, 6, 10, 64 * 66 + 37
     a = _rand(P, R, M, seed=41)
     w = _rand(Q, R, M, seed=42) if conj_b else _rand(R, Q, M, seed=42)
