@@ -652,3 +652,16 @@ class EngineRawOps:
             modegemm(xhat, ghat, P=ci, Q=co, R=b, n_modes=mk, a_strides=(mk, ci * mk, 1), conj_a=True,
                      b_strides=(co * mk, mk, 1), out=gw, c_strides=(co * mk, mk, 1))
         return gx, gw
+
+
+    def tucker_dense(self, core, factors):
+        """Dense (Cin, Cout, modes...) block of a Tucker weight on the engine, with autograd to the core and every
+        factor (the chain of sc_modegemm launches of SpectralConv._tucker_dense)."""
+        from types import SimpleNamespace
+        from .spectral_conv import SpectralConv
+        kept = [int(f.shape[0]) for f in factors[2:]]
+        t3 = SpectralConv._tucker_core_times_modes(SimpleNamespace(core=core, factors=list(factors)), kept)
+        m = int(t3.shape[2])
+        w1 = mode_gemm(factors[0], t3, m)
+        w = mode_gemm(w1, factors[1].transpose(0, 1), m)
+        return w.reshape(w.shape[0], w.shape[1], *kept)

@@ -23,6 +23,8 @@ has landed.  Per exchange one S-sized copy (the chunk-major send permutation one
 permutation the other); the R-sized real tensors are written in place (``out=`` slices).  When k1 is not a
 multiple of P the mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
 """
+import math
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -200,20 +202,30 @@ class _ModeParallelFn(torch.autograd.Function):
 
 
 class ModeParallelSpectralConv(BaseSpectralConv):
-    """Dense-weight SpectralConv whose first mode dim is sharded across the model-parallel group.
+    """SpectralConv whose first mode dim is sharded across the model-parallel group.
 
     Constructor arguments follow SpectralConv; ``n_modes`` is fixed at construction (the
     shard layout depends on it).  ``ops`` (tests only) replaces the local stages (an object with the
-    interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in."""
+    interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in.
+
+    Weights: dense (``weight``: this rank's mode rows of the (Cin, Cout, modes...) tensor), or
+    ``factorization="tucker"`` (TFNO, spectral_convolution.py:76-103): the core and the factors of the channel and
+    unsharded mode dims are REPLICATED, the factor of the first mode dim is sharded by rows like the dense weight;
+    a rank contracts with the dense block rebuilt from its shard (1 / P of the reconstruction work), the gradients
+    of the replicated parameters are partial sums over this rank's modes and are summed over the group by
+    ``reduce_replicated_grads``."""
 
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
-                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=4, **unused):
+                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=4,
+                 factorization=None, rank=0.5, **unused):
         super().__init__(device=device)
         for k in ("complex_data", "separable"):
             if unused.get(k):
                 raise NotImplementedError(f"{k}=True is not supported by the mode-parallel layer")
-        if unused.get("factorization") not in (None, "Dense", "dense"):
-            raise NotImplementedError("mode-parallel layer: dense weights only")
+        fac = (factorization or "dense").lower()
+        if fac not in ("dense", "tucker"):
+            raise NotImplementedError("mode-parallel layer: dense or Tucker weights")
+        self.factorization = fac
         self.in_channels, self.out_channels = in_channels, out_channels
         self._n_modes = halve_last_mode(n_modes)
         self.max_n_modes = list(self._n_modes)
@@ -229,13 +241,28 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         self.rows = -(-self._n_modes[0] // self.P)
         if init_std == "auto":
             init_std = (2 / (in_channels + out_channels)) ** 0.5
-        w = torch.empty(in_channels, out_channels, self.rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
-        w.normal_(0, init_std)
         live = min(self.rows, max(0, self._n_modes[0] - self.rank * self.rows))
-        with torch.no_grad():
-            w[:, :, live:] = 0
-        self.weight = nn.Parameter(w)
-        self.weight.mode_sharded = True          # exclude from data-parallel all-reduce within the group
+        if fac == "dense":
+            w = torch.empty(in_channels, out_channels, self.rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
+            w.normal_(0, init_std)
+            with torch.no_grad():
+                w[:, :, live:] = 0
+            self.weight = nn.Parameter(w)
+            self.weight.mode_sharded = True          # exclude from data-parallel all-reduce within the group
+        else:
+            from ..factorized import tucker_rank
+            full_shape = [in_channels, out_channels, *self._n_modes]
+            ranks = tucker_rank(full_shape, rank)
+            std_f = (init_std / math.prod(math.sqrt(r) for r in ranks)) ** (1.0 / (len(full_shape) + 1))
+            self.weight = None
+            self.core = nn.Parameter(torch.empty(*ranks, dtype=torch.cfloat, device=device).normal_(0, std_f))
+            sizes = [in_channels, out_channels, self.rows, *self._n_modes[1:]]
+            self.factors = nn.ParameterList(
+                [nn.Parameter(torch.empty(n, r, dtype=torch.cfloat, device=device).normal_(0, std_f))
+                 for n, r in zip(sizes, ranks)])
+            with torch.no_grad():
+                self.factors[2][live:] = 0
+            self.factors[2].mode_sharded = True
         self.bias = nn.Parameter(init_std * torch.randn(out_channels, *(1,) * self.order, device=device)) \
             if bias else None
         if ops is None:
@@ -268,16 +295,46 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             raise ValueError(f"grid {spatial} is too small for n_modes {self._n_modes} in the mode-parallel layer")
         if x.shape[1] != self.in_channels:
             raise ValueError(f"input has {x.shape[1]} channels, the layer expects {self.in_channels}")
+        w = self.weight if self.factorization == "dense" else self.ops.tucker_dense(self.core, list(self.factors))
         if self.P == 1 and not dist.is_initialized():
-            return _single_rank(self, x, spatial)
-        return _ModeParallelFn.apply(x, self.weight, self.bias, self)
+            return _single_rank(self, x, spatial, w)
+        return _ModeParallelFn.apply(x, w, self.bias, self)
 
     # ---- helpers for the training loop -----------------------------------------------------------
+    def replicated_parameters(self):
+        ps = [] if self.bias is None else [self.bias]
+        if self.factorization == "tucker":
+            ps += [self.core] + [f for i, f in enumerate(self.factors) if i != 2]
+        return ps
+
     def reduce_replicated_grads(self):
-        """Sum the gradients of the replicated parameters (bias) over the model-parallel group
-        (every rank saw a different batch shard).  The sharded weight needs nothing."""
-        if self.P > 1 and self.bias is not None and self.bias.grad is not None:
-            dist.all_reduce(self.bias.grad, group=self._group())
+        """Sum the gradients of the replicated parameters over the model-parallel group: the bias (every rank saw a
+        different batch shard) and, for Tucker weights, the core and the unsharded factors (every rank contracted
+        different modes).  The sharded weight / factor rows need nothing."""
+        if self.P > 1:
+            for q in self.replicated_parameters():
+                if q.grad is not None:
+                    g = torch.view_as_real(q.grad) if q.grad.is_complex() else q.grad
+                    dist.all_reduce(g, group=self._group())
+
+    def sync_replicated_parameters(self, src=0):
+        """Broadcast the replicated parameters from group rank ``src`` (after a per-rank random init)."""
+        if self.P > 1:
+            grp = self._group()
+            for q in self.replicated_parameters():
+                t = torch.view_as_real(q.data) if q.is_complex() else q.data
+                dist.broadcast(t, dist.get_global_rank(grp, src) if grp is not None else src, group=grp)
+
+    @staticmethod
+    def shard_tucker_factor(full_factor, rank, world):
+        """Rows of the first-mode-dim factor (k1, r) that rank ``rank`` owns (zero rows past k1)."""
+        k1 = full_factor.shape[0]
+        rows = -(-k1 // world)
+        out = full_factor.new_zeros((rows, full_factor.shape[1]))
+        live = min(rows, max(0, k1 - rank * rows))
+        if live > 0:
+            out[:live] = full_factor[rank * rows:rank * rows + live]
+        return out
 
     @staticmethod
     def shard_dense_weight(full_weight, rank, world):
@@ -316,5 +373,5 @@ class _SingleRankFn(torch.autograd.Function):
         return gx, gw, None if gb is None else gb.reshape(bshape), None
 
 
-def _single_rank(layer, x, spatial):
-    return _SingleRankFn.apply(x, layer.weight, layer.bias, layer)
+def _single_rank(layer, x, spatial, w):
+    return _SingleRankFn.apply(x, w, layer.bias, layer)

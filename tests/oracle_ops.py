@@ -28,6 +28,9 @@ class OracleOps:
     def contract(self, xhat, w):
         return so.contract_dense(xhat, w)
 
+    def tucker_dense(self, core, factors):
+        return so.reconstruct_tucker(core, list(factors))
+
     def inverse_transform(self, yhat, bias, spatial):
         nd = len(spatial)
         full_shape = list(yhat.shape[:2]) + list(spatial[:-1]) + [spatial[-1] // 2 + 1]
@@ -94,6 +97,9 @@ class OracleRawOps:
 
     def contract(self, xhat, w):
         return so.contract_dense(xhat, w)
+
+    def tucker_dense(self, core, factors):
+        return so.reconstruct_tucker(core, list(factors))
 
     def contract_bwd(self, xhat, w, ghat, need_x=True, need_w=True):
         with torch.enable_grad():

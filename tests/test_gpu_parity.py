@@ -561,6 +561,28 @@ def test_mode_parallel_layer_on_device_single_rank():
         assert rel_l2(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < TOL
         assert rel_l2(mp_conv.weight.grad.cpu().numpy(), ref.weight.tensor.grad.cpu().numpy()) < TOL
         assert rel_l2(mp_conv.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < TOL
+        # TFNO weights in the same layer: replicated core / factors, the first mode dim's factor sharded (here: whole)
+        tref = SpectralConv(6, 5, (16, 12), factorization="tucker", rank=0.5, implementation="factorized").to(dev)
+        tmp = ModeParallelSpectralConv(6, 5, (16, 12), factorization="tucker", rank=0.5).to(dev)
+        assert tuple(tmp.core.shape) == tuple(tref.weight.core.shape)
+        with torch.no_grad():
+            for q in list(tref.weight.parameters()):
+                q.mul_(8.0)                                        # O(1) outputs
+            tmp.core.copy_(tref.weight.core)
+            for f, fr in zip(tmp.factors, tref.weight.factors):
+                f.copy_(fr)
+            tmp.bias.copy_(tref.bias)
+        x2 = x.detach().clone().requires_grad_(True)
+        x3 = x.detach().clone().requires_grad_(True)
+        y2, y3 = tmp(x2), tref(x3)
+        y2.backward(g)
+        y3.backward(g)
+        tmp.reduce_replicated_grads()
+        assert rel_l2(y2.detach().cpu().numpy(), y3.detach().cpu().numpy()) < TOL
+        assert rel_l2(x2.grad.cpu().numpy(), x3.grad.cpu().numpy()) < TOL
+        assert rel_l2(tmp.core.grad.cpu().numpy(), tref.weight.core.grad.cpu().numpy()) < TOL
+        for f, fr in zip(tmp.factors, tref.weight.factors):
+            assert rel_l2(f.grad.cpu().numpy(), fr.grad.cpu().numpy()) < TOL
     finally:
         comm.cleanup()
         if dist.is_initialized():

@@ -183,3 +183,76 @@ def test_hybrid_data_and_mode_parallel_groups():
     for rank, errs in ret.items():
         for k, v in errs.items():
             assert np.isfinite(v) and v < 1e-5, (rank, k, v)
+
+
+def _tucker_worker(rank, world, port, spatial, modes, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleRawOps
+
+    comm.init(model_parallel_size=world, backend="gloo")
+    nm = halve_last_mode(modes)
+    bl, ci, co = 2, 4, 3
+    B = bl * world
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=2, factorization="tucker", rank=0.6)
+    ranks = list(conv.core.shape)
+    torch.manual_seed(0)                      # identical full tensors on every rank
+    x = torch.randn(B, ci, *spatial)
+    g = torch.randn(B, co, *spatial)
+    core = torch.randn(*ranks, dtype=torch.cfloat) * 0.5
+    full_f = [torch.randn(n, r, dtype=torch.cfloat) * 0.7 for n, r in zip([ci, co, *nm], ranks)]
+    bias = torch.randn(co, *(1,) * len(spatial))
+    with torch.no_grad():
+        conv.core.copy_(core if rank == 0 else torch.zeros_like(core))       # rank 0 holds the values ...
+        for i, f in enumerate(full_f):
+            if i == 2:
+                conv.factors[2].copy_(ModeParallelSpectralConv.shard_tucker_factor(f, rank, world))
+            else:
+                conv.factors[i].copy_(f if rank == 0 else torch.zeros_like(f))
+        conv.bias.copy_(bias if rank == 0 else torch.zeros_like(bias))
+    conv.sync_replicated_parameters(src=0)                                     # ... and broadcasts them
+    xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
+    y = conv(xs)
+    y.backward(g[rank * bl:(rank + 1) * bl])
+    conv.reduce_replicated_grads()
+
+    xf = x.clone().requires_grad_(True)
+    cf = core.clone().requires_grad_(True)
+    ff = [f.clone().requires_grad_(True) for f in full_f]
+    bf = bias.clone().requires_grad_(True)
+    yf = so.forward_torch(xf, so.reconstruct_tucker(cf, ff), bf, nm, nm)
+    yf.backward(g)
+    rows = -(-nm[0] // world)
+    live = min(rows, nm[0] - rank * rows)
+    errs = dict(
+        y=so.rel_l2(y.detach().numpy(), yf.detach()[rank * bl:(rank + 1) * bl].numpy()),
+        gx=so.rel_l2(xs.grad.numpy(), xf.grad[rank * bl:(rank + 1) * bl].numpy()),
+        gcore=so.rel_l2(conv.core.grad.numpy(), cf.grad.numpy()),
+        gbias=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()),
+        gshard=so.rel_l2(conv.factors[2].grad[:live].numpy(), ff[2].grad[rank * rows:rank * rows + live].numpy()),
+    )
+    for i in (0, 1, 3):
+        errs[f"gfactor{i}"] = so.rel_l2(conv.factors[i].grad.numpy(), ff[i].grad.numpy())
+    if live < rows:
+        errs["pad_rows_zero"] = float(conv.factors[2].grad[live:].abs().max())
+    ret[rank] = errs
+    comm.cleanup()
+
+
+@pytest.mark.parametrize("spatial,modes", [((16, 12), (8, 6)), ((16, 12), (5, 6))], ids=["even", "padded_rows"])
+def test_mode_parallel_tucker_matches_single_process(spatial, modes):
+    """TFNO weights in the mode-parallel layer: replicated core / channel / unsharded mode factors, the first mode
+    dim's factor sharded by rows; output, input gradient and every parameter gradient (replicated ones after
+    reduce_replicated_grads) equal the single-process oracle with the reconstructed dense weight."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tucker_worker, args=(world, _free_port(), spatial, modes, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank, errs in ret.items():
+        for k, v in errs.items():
+            assert np.isfinite(v) and v < 2e-5, (rank, k, v)
