@@ -1459,15 +1459,20 @@ template <bool CA, bool CB>
 static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
   ModeGemmArgs g = g0;
   g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
-  g.n_pg = (int)((g.P + 4 * 2 - 1) / (4 * 2));
-  g.n_qt = (int)((g.Q + 4 - 1) / 4);
+  // 4 x 8 outputs per wave (12 operand loads per 32 products) when the problem still yields enough workgroups,
+  // 2 x 4 for small outputs
+  const bool wide = g.P >= 16 && g.Q >= 8;
+  const int PT = wide ? 4 : 2, QT = wide ? 8 : 4;
+  g.n_pg = (int)((g.P + 4 * PT - 1) / (4 * PT));
+  g.n_qt = (int)((g.Q + QT - 1) / QT);
   // mode splits: enough workgroups to fill the chip (~4096), as few atomic adds per output as that allows
   int64_t splits = 4096 / ((int64_t)g.n_pg * g.n_qt);
   if (splits < 1) splits = 1;
   if (splits > g.n_mt) splits = g.n_mt;
   g.per_xcd = (int)splits;
   const int64_t total = splits * g.n_pg * g.n_qt;
-  SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
+  if (wide) SC_LAUNCH((k_modegemm_msum<4, 8, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
+  else SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
 }
 
 /* C[p,q] += sum_m sum_r opA(A[p,r,m]) opB(B[r,q,m]); C (strides c_sp, c_sq) zeroed by the caller */

@@ -365,7 +365,7 @@ template <int PT, int QT, bool CA, bool CB>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
 k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
                 cf32* __restrict__ C) {
-  SC_SHARED cf32 red[4][SC_WAVE];
+  SC_SHARED float red[4 * 32 * 65];
   const int tid = SC_TID;
   const int lane = tid & 63;
   const int w = SC_UNIFORM(tid >> 6);
@@ -406,34 +406,40 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
         for (int qq = 0; qq < QT; ++qq) cf_mac(acc[pp][qq], a[pp], b[qq]);
     }
   }
-  // wave reduction through LDS (one value at a time: these launches are small)
+  // wave reduction, transposed: the 2 PT QT partial sums of every lane go to LDS as [value][lane] (row stride 65:
+  // conflict-free both ways), lane v then adds the 64 partials of value v and issues ONE atomic.  (The first version
+  // reduced one value at a time through a 6-level tree with three wave syncs per level -- 144 sync rounds for 8
+  // values; with one mode tile per workgroup that cost more than the accumulation: 82 us for the 64 x 36 factor
+  // gradients of TFNO rank 0.1, profiles/r02_tfno_kernel_stats.txt.)
+  constexpr int NV = 2 * PT * QT;                             // floats per lane
+  static_assert(NV % 32 == 0 || NV <= 32, "values are reduced 32 at a time");
+  float* rw = red + w * (32 * 65);
 #pragma unroll
-  for (int pp = 0; pp < PT; ++pp)
+  for (int h0 = 0; h0 < NV; h0 += 32) {
 #pragma unroll
-    for (int qq = 0; qq < QT; ++qq) {
-      red[w][lane] = acc[pp][qq];
-      SC_WAVE_SYNC();
-#pragma unroll
-      for (int off = SC_WAVE / 2; off > 0; off >>= 1) {
-        cf32 o = cf_make(0.f, 0.f);
-        if (lane < off) o = red[w][lane + off];
-        SC_WAVE_SYNC();
-        if (lane < off) red[w][lane] = cf_add(red[w][lane], o);
-        SC_WAVE_SYNC();
-      }
-      if (lane == 0 && wave_on && p0 + pp < g.P && q0 + qq < g.Q) {
-        cf32* dst = C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq;
-        const cf32 v = red[w][0];
+    for (int v = 0; v < 32 && h0 + v < NV; ++v) {
+      const int i = (h0 + v) >> 1;                            // acc index: pp = i / QT, qq = i % QT
+      const cf32 c = acc[i / QT][i % QT];
+      rw[v * 65 + lane] = ((h0 + v) & 1) ? c.y : c.x;
+    }
+    SC_WAVE_SYNC();
+    if (lane < 32 && h0 + lane < NV) {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int l = 0; l < SC_WAVE; ++l) sum += rw[lane * 65 + l];
+      const int i = (h0 + lane) >> 1;
+      const int pp = i / QT, qq = i % QT;
+      if (wave_on && p0 + pp < g.P && q0 + qq < g.Q) {
+        float* dst = reinterpret_cast<float*>(C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq) + ((h0 + lane) & 1);
 #ifndef SC_EMU
-        atomicAdd(&dst->x, v.x);
-        atomicAdd(&dst->y, v.y);
+        atomicAdd(dst, sum);
 #else
-        dst->x += v.x;    // emulated workgroups run one after another, waves own different p
-        dst->y += v.y;
+        *dst += sum;      // emulated workgroups run one after another, waves own different p
 #endif
       }
-      SC_WAVE_SYNC();
     }
+    SC_WAVE_SYNC();
+  }
 }
 
 // gbias[c] = sum_b Re(ghat[(b*channels + c) * modes_per_image + dc])
