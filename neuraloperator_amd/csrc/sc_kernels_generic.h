@@ -386,7 +386,8 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
     if (m >= g.M) continue;
     const uint32_t la = (uint32_t)(m * g.a_sm);
     const uint32_t lb = g.b_idx ? (uint32_t)g.b_idx[m] : (uint32_t)(m * g.b_sm);
-    for (int64_t r = 0; r < g.R; ++r) {
+#pragma unroll 2
+    for (int64_t r = 0; r < g.R; ++r) {                       // two steps of operand loads in flight
       cf32 a[PT], b[QT];
 #pragma unroll
       for (int pp = 0; pp < PT; ++pp) {

@@ -5,7 +5,9 @@ metric layer that is 7 arrays across HBM once instead of ~30.
 
 Same constructor arguments, state-dict layout (``step``, ``exp_avg``, ``exp_avg_sq`` -- complex for complex
 parameters, exactly like the reference's ``torch.zeros_like(grad)`` state) and arithmetic order as the
-reference's non-GaLore branch.  Tensor-GaLore projection (``galore_params``) is not on the engine and raises.
+reference.  Tensor-GaLore (``galore_params``, adamw.py:94-111, 139-153, 183-185): those parameters form their own
+group, their gradient is projected onto a Tucker subspace (neuraloperator_amd.galore.TensorGaLoreProjector), the moments
+live in the low-rank space and the normalised update is projected back before it is applied.
 The fused launch takes contiguous fp32 / complex64 parameters on the GPU -- the spectral weights and everything
 else an FNO holds by default; any other parameter of the model (CPU, bf16 / fp16 / fp64, channels_last views) is
 updated with the same formulas as elementwise torch operations, so one optimizer serves a whole model and a step
@@ -22,9 +24,8 @@ from . import _lib
 class AdamW(Optimizer):
     def __init__(self, params: Iterable, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-6, weight_decay: float = 0.0, correct_bias: bool = True,
-                 galore_params=None, **galore_kwargs):
-        if galore_params is not None:
-            raise NotImplementedError("Tensor-GaLore projection (galore_params) is not on the MI355X engine")
+                 galore_params=None, galore_rank=1.0, galore_update_proj_gap: int = 50, galore_scale: float = 1.0,
+                 activation_checkpoint: bool = False, warm_restart: bool = True):
         if lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr} - should be >= 0.0")            # adamw.py:73-80
         if not 0.0 <= betas[0] < 1.0:
@@ -35,6 +36,14 @@ class AdamW(Optimizer):
             raise ValueError(f"Invalid epsilon value: {eps} - should be >= 0.0")
         defaults = {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay, "correct_bias": correct_bias}
         super().__init__(params, defaults)
+        if galore_params is not None:                                                         # adamw.py:94-106
+            self.add_param_group({"params": galore_params, "rank": galore_rank, "lr": lr, "betas": betas, "eps": eps,
+                                  "weight_decay": weight_decay, "correct_bias": correct_bias, "galore": True})
+        self.galore_rank = galore_rank
+        self.activation_checkpoint = activation_checkpoint
+        self.warm_restart = warm_restart
+        self.galore_update_proj_gap = galore_update_proj_gap
+        self.galore_scale = galore_scale
 
     @torch.no_grad()
     def step(self, closure: Callable = None):
@@ -56,6 +65,9 @@ class AdamW(Optimizer):
                 state = self.state[p]
                 if "step" not in state:
                     state["step"] = 0
+                if group.get("galore", False):
+                    self._galore_update(p, grad, state, group)
+                    continue
                 if not fused:
                     self._elementwise_update(p, grad, state, group)
                     continue
@@ -73,6 +85,30 @@ class AdamW(Optimizer):
                                    weight_decay=group["weight_decay"], correct_bias=group["correct_bias"],
                                    step=state["step"])
         return loss
+
+    def _galore_update(self, p, grad, state, group):
+        """adamw.py:139-196 with ``group["galore"]``: project, Adam moments in the low-rank space, project back."""
+        from .galore import TensorGaLoreProjector
+        if "projector" not in state:
+            state["projector"] = TensorGaLoreProjector(
+                rank=self.galore_rank, update_proj_gap=self.galore_update_proj_gap, scale=self.galore_scale,
+                activation_checkpoint=self.activation_checkpoint, warm_restart=self.warm_restart)
+        proj = state["projector"]
+        g = proj.project(grad, state["step"])
+        if "exp_avg" not in state:
+            state["exp_avg"] = torch.zeros_like(g)
+            state["exp_avg_sq"] = torch.zeros_like(g)
+        m, v = state["exp_avg"], state["exp_avg_sq"]
+        beta1, beta2 = group["betas"]
+        state["step"] += 1
+        m.mul_(beta1).add_(g, alpha=1.0 - beta1)
+        v.mul_(beta2).addcmul_(g, g.conj() if torch.is_complex(g) else g, value=1.0 - beta2)
+        step_size = group["lr"]
+        if group["correct_bias"]:
+            step_size *= math.sqrt(1.0 - beta2 ** state["step"]) / (1.0 - beta1 ** state["step"])
+        p.add_(proj.project_back(m / v.sqrt().add_(group["eps"])), alpha=-step_size)
+        if group["weight_decay"] > 0.0:
+            p.add_(p, alpha=-group["lr"] * group["weight_decay"])
 
     @staticmethod
     def _elementwise_update(p, grad, state, group):

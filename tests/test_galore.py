@@ -1,0 +1,93 @@
+"""Tensor-GaLore: the projector (neuraloperator_amd.galore) and the GaLore branch of
+neuraloperator_amd.AdamW.
+
+* decomposition: orthonormal factors, exact at full rank, the planted subspaces of an exactly low-rank complex tensor;
+* mode products: ``transpose=True`` is the adjoint;
+* optimizer: the VERBATIM reference AdamW (training/adamw.py, GaLore branch :139-196) driving this repo's projector
+  against neuraloperator_amd.AdamW -- same parameter trajectory and state, bit for bit on the CPU.
+tensorly's own ``tucker`` is absent (un-vendored third party): the decomposition is pinned by its defining properties."""
+import pytest
+import torch
+
+from neuraloperator_amd import AdamW, galore
+from oracle import ref_verbatim
+
+
+def _orth(n, r, g, cplx=True):
+    a = torch.randn(n, r, generator=g, dtype=torch.float64)
+    if cplx:
+        a = torch.complex(a, torch.randn(n, r, generator=g, dtype=torch.float64))
+    q, _ = torch.linalg.qr(a)
+    return q
+
+
+def test_hooi_properties():
+    g = torch.Generator().manual_seed(0)
+    shape, ranks = (8, 7, 6, 5), (3, 4, 2, 3)
+    fs = [_orth(n, r, g) for n, r in zip(shape, ranks)]
+    core = torch.complex(torch.randn(*ranks, generator=g, dtype=torch.float64), torch.randn(*ranks, generator=g, dtype=torch.float64))
+    t = galore.multi_mode_dot(core, fs)
+    c, us = galore.tucker_hooi(t, list(ranks))
+    for u, f in zip(us, fs):
+        eye = torch.eye(u.shape[1], dtype=u.dtype)
+        assert torch.allclose(u.conj().T @ u, eye, atol=1e-10)                        # orthonormal columns
+        assert torch.allclose(u @ u.conj().T, f @ f.conj().T, atol=1e-8)              # the planted subspace
+    assert torch.allclose(galore.multi_mode_dot(c, us), t, atol=1e-8)
+    # full rank: exact for any tensor
+    x = torch.randn(4, 5, 3, generator=g)
+    c, us = galore.tucker_hooi(x, [4, 5, 3])
+    assert torch.allclose(galore.multi_mode_dot(c, us), x, atol=1e-5)
+    # float rank follows the parameter-fraction rule of the weight containers
+    _, us = galore.tucker_hooi(torch.randn(16, 16, 8, 5, generator=g), 0.25)
+    from neuraloperator_amd.factorized import tucker_rank
+    assert [u.shape[1] for u in us] == tucker_rank([16, 16, 8, 5], 0.25)
+
+
+def test_mode_products_adjoint():
+    g = torch.Generator().manual_seed(1)
+    a = torch.complex(torch.randn(6, 5, 4, generator=g), torch.randn(6, 5, 4, generator=g))
+    us = [torch.complex(torch.randn(n, r, generator=g), torch.randn(n, r, generator=g)) for n, r in ((6, 2), (5, 3), (4, 4))]
+    b = torch.complex(torch.randn(2, 3, 4, generator=g), torch.randn(2, 3, 4, generator=g))
+    lhs = torch.vdot(galore.multi_mode_dot(a, us, transpose=True).flatten(), b.flatten())
+    rhs = torch.vdot(a.flatten(), galore.multi_mode_dot(b, us).flatten())
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.skipif(not ref_verbatim.available(), reason="verbatim reference not present")
+@pytest.mark.parametrize("rank,kw", [(0.4, {}), ([3, 3, 4, 2], dict(weight_decay=0.05, correct_bias=False, galore_scale=0.5))])
+def test_adamw_galore_branch_matches_verbatim_optimizer(rank, kw):
+    mod = ref_verbatim.load_reference_adamw()
+    saved = mod.TensorGaLoreProjector
+    mod.TensorGaLoreProjector = galore.TensorGaLoreProjector          # the verbatim optimizer drives this repo's projector
+    try:
+        g = torch.Generator().manual_seed(2)
+        w0 = torch.complex(torch.randn(6, 5, 8, 5, generator=g), torch.randn(6, 5, 8, 5, generator=g))
+        b0 = torch.randn(5, generator=g)
+        grads = [(torch.complex(torch.randn(6, 5, 8, 5, generator=g), torch.randn(6, 5, 8, 5, generator=g)),
+                  torch.randn(5, generator=g)) for _ in range(4)]
+        out = []
+        for cls in (mod.AdamW, AdamW):
+            w, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+            opt = cls([b], lr=1e-2, galore_params=[w], galore_rank=rank, **kw)
+            for gw, gb in grads:
+                w.grad, b.grad = gw.clone(), gb.clone()
+                opt.step()
+            st = opt.state[w]
+            out.append((w.detach().clone(), b.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"]))
+        (w1, b1, m1, v1, s1), (w2, b2, m2, v2, s2) = out
+        assert s1 == s2 == 4 and m1.shape == m2.shape and m1.shape != w0.shape          # moments live in the low-rank space
+        assert torch.equal(w1, w2) and torch.equal(b1, b2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+    finally:
+        mod.TensorGaLoreProjector = saved
+
+
+def test_full_rank_projection_is_the_identity():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 5, generator=g)
+    p = galore.TensorGaLoreProjector(rank=[4, 3, 5], scale=2.0)
+    low = p.project(x, 0)
+    assert low.shape == x.shape and torch.allclose(p.project_back(low), 2.0 * x, atol=1e-5)
+    # the subspace is computed once (step 0) and kept, as upstream
+    u0 = [f.clone() for f in p.proj_tensor]
+    p.project(torch.randn(4, 3, 5, generator=g), 200)
+    assert all(torch.equal(a, b) for a, b in zip(u0, p.proj_tensor))

@@ -644,8 +644,17 @@ def test_optimizer_matches_reference_trajectory(name):
     assert rel_l2(opt.state[pc]["exp_avg_sq"].cpu().numpy(), g["v_c"]) < tol
     assert rel_l2(opt.state[pr]["exp_avg_sq"].cpu().numpy(), g["v_r"]) < tol
     assert opt.state[pc]["exp_avg_sq"].dtype == torch.complex64 and opt.state[pc]["step"] == int(g["steps"])
-    with pytest.raises(NotImplementedError):
-        AdamW([pc], galore_params=[pr])
+    # Tensor-GaLore group (adamw.py:94-111, 139-196) on the device: low-rank moments, finite update, subspace kept
+    wg = torch.nn.Parameter(torch.randn(8, 8, 12, 7, dtype=torch.cfloat, device=dev))
+    w_before = wg.detach().clone()
+    go = AdamW([pr], galore_params=[wg], galore_rank=0.25, lr=1e-2)
+    for _ in range(2):
+        wg.grad = torch.randn_like(wg)
+        pr.grad = torch.randn_like(pr)
+        go.step()
+    st = go.state[wg]
+    assert st["exp_avg"].shape != wg.shape and st["exp_avg"].is_cuda and st["step"] == 2
+    assert torch.isfinite(torch.view_as_real(wg.detach())).all() and not torch.equal(wg.detach(), w_before)
 
 
 def test_layer_step_is_graph_capturable():
