@@ -175,6 +175,33 @@ int sc_round_f16(const float* in, float* out, int64_t n, void* stream);
 int sc_bias_grad(const sc_plan* plan, const float* ghat, int64_t batch, int64_t channels,
                  float* gbias, void* stream);
 
+/* ---- pointwise half of an FNO block in one pass ("next" row f1 of SURVEY.md section 8) -------------------
+ *   out = act( W2 gelu(W1 x + b1) + b2 + gate (.) skip_src )
+ * replaces ChannelMLP.forward (neuralop/layers/channel_mlp.py:82-119: two Conv1d with kernel size 1 and a GELU),
+ * the soft-gating skip (neuralop/layers/skip_connections.py:53-130: per-channel weight times the block input) and
+ * the closing non-linearity of FNOBlocks.forward_with_postactivation (neuralop/layers/fno_block.py:399-412).
+ * x (batch, c_in, spatial), skip_src / out (batch, c_out, spatial) contiguous float32; w1 (c_hid, c_in), w2 (c_out,
+ * c_hid) row-major (= Conv1d weights with the trailing 1 dropped); b1, b2, skip_src + gate optional (null).
+ * Channel counts: multiples of 32 with (c_in, c_hid, c_out) / 32 in {(1,1,1), (2,1,2), (2,2,2), (4,2,4)};
+ * spatial a multiple of 32. */
+typedef struct sc_pmlp_desc {
+  int64_t batch, c_in, c_hid, c_out, spatial;
+  int32_t act;               /* SC_ACT_NONE / SC_ACT_GELU on the result */
+  int32_t reserved;
+} sc_pmlp_desc;
+int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1, const float* w2,
+                             const float* b2, const float* skip_src, const float* gate, float* out, void* stream);
+/* gradient of the above with respect to everything: nothing but the forward's INPUTS is needed (h and the
+ * pre-activations are recomputed inside the tile).  gx (batch, c_in, spatial), gskip_src (batch, c_out, spatial; with a
+ * gate), gw1 / gw2 like w1 / w2, gb1 / gb2 / ggate (null when the forward had none) are all overwritten.  workspace:
+ * sc_pointwise_mlp_workspace_bytes(d) bytes (operand tables + one partial sum per workgroup; the partials are added
+ * in a fixed order: results are bit-reproducible). */
+size_t sc_pointwise_mlp_workspace_bytes(const sc_pmlp_desc* d);
+int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1, const float* w2,
+                              const float* b2, const float* skip_src, const float* gate, const float* gout, float* gx,
+                              float* gw1, float* gb1, float* gw2, float* gb2, float* gskip_src, float* ggate,
+                              void* workspace, void* stream);
+
 /* ---- fused AdamW step of the spectral weights ("next" row f2 of SURVEY.md section 8) -----------------
  * One pass over (param, grad, exp_avg, exp_avg_sq) instead of the ~10 elementwise launches of
  * neuralop/training/adamw.py:155-200 (non-GaLore branch), same arithmetic in the same order:

@@ -73,6 +73,11 @@ class Epilogue(Structure):
 SC_ACT_NONE, SC_ACT_GELU = 0, 1
 
 
+class PmlpDesc(Structure):
+    _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_hid", c_int64), ("c_out", c_int64), ("spatial", c_int64),
+                ("act", c_int32), ("reserved", c_int32)]
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -116,7 +121,8 @@ class ScEngineLib:
                "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
-               "sc_layer_forward_ex", "sc_round_f16"]
+               "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
+               "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -169,6 +175,12 @@ class ScEngineLib:
         L.sc_layer_forward_ex.restype = c_int
         L.sc_layer_backward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 8
         L.sc_layer_backward.restype = c_int
+        L.sc_pointwise_mlp_forward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 9
+        L.sc_pointwise_mlp_forward.restype = c_int
+        L.sc_pointwise_mlp_workspace_bytes.argtypes = [POINTER(PmlpDesc)]
+        L.sc_pointwise_mlp_workspace_bytes.restype = c_size_t
+        L.sc_pointwise_mlp_backward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 17
+        L.sc_pointwise_mlp_backward.restype = c_int
         L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.sc_round_f16.restype = c_int
         L.sc_last_error.restype = c_char_p
@@ -239,6 +251,20 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    def pointwise_mlp_forward(self, batch, c_in, c_hid, c_out, spatial, act, x, w1, b1, w2, b2, skip, gate, out, stream=0):
+        d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
+        self._check(self.lib.sc_pointwise_mlp_forward(byref(d), x, w1, b1, w2, b2, skip, gate, out, stream))
+
+    def pointwise_mlp_workspace_bytes(self, batch, c_in, c_hid, c_out, spatial, act):
+        d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
+        return int(self.lib.sc_pointwise_mlp_workspace_bytes(byref(d)))
+
+    def pointwise_mlp_backward(self, batch, c_in, c_hid, c_out, spatial, act, x, w1, b1, w2, b2, skip, gate, gout,
+                               gx, gw1, gb1, gw2, gb2, gskip, ggate, ws, stream=0):
+        d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
+        self._check(self.lib.sc_pointwise_mlp_backward(byref(d), x, w1, b1, w2, b2, skip, gate, gout, gx, gw1, gb1, gw2,
+                                                       gb2, gskip, ggate, ws, stream))
 
     def round_f16(self, in_ptr, out_ptr, n, stream=0):
         """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""

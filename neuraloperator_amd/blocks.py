@@ -1,0 +1,132 @@
+"""The rest of an FNO block on the engine: what FNOBlocks.forward_with_postactivation
+(/root/reference/neuralop/layers/fno_block.py:377-414) does around the spectral convolution.
+
+    x_skip_fno = fno_skips[i](x)                      1 x 1 linear skip (skip_connections.py:119-169)
+    x          = gelu(convs[i](x) + x_skip_fno)       -> SpectralConv.forward_fused: add + GELU in the inverse
+                                                         transform's store path (sc_layer_forward_ex)
+    x          = channel_mlp[i](x) + gate * x_in      -> fused_channel_mlp: both 1 x 1 convolutions, the GELU between
+    x          = gelu(x)            (not the last block)   them, the soft-gating skip and the closing GELU in ONE pass
+                                                         over the tensor (sc_pointwise_mlp_forward / _backward)
+
+``fused_block_forward(blocks, x, index)`` runs exactly that on the parameters of an ``FNOBlocks``-shaped module (the
+verbatim reference class, built with ``conv_module=neuraloperator_amd.SpectralConv``): same result as
+``blocks(x, index)``; configurations outside its scope (normalisation layers, pre-activation, tanh stabiliser, a
+resolution change, other skip types) take the module's own forward."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .engine import _require_gpu, _stream
+
+
+class PointwiseMLPFn(torch.autograd.Function):
+    """out = act(W2 gelu(W1 x + b1) + b2 + gate * skip_src) and all of its gradients, one pass each way
+    (sc_kernels_pmlp.h); saves only its inputs."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, skip_src, gate, act):
+        _require_gpu(x, "x")
+        shape = x.shape
+        b, ci = int(shape[0]), int(shape[1])
+        s = 1
+        for v in shape[2:]:
+            s *= int(v)
+        ch, co = int(w1.shape[0]), int(w2.shape[0])
+        xc = x.contiguous()
+        w1c, w2c = w1.reshape(ch, ci).contiguous(), w2.reshape(co, ch).contiguous()
+        b1c = None if b1 is None else b1.contiguous()
+        b2c = None if b2 is None else b2.contiguous()
+        skc = None if skip_src is None else skip_src.contiguous()
+        gtc = None if gate is None else gate.reshape(co).contiguous()
+        out = torch.empty((b, co, *shape[2:]), dtype=torch.float32, device=x.device)
+        p = lambda t: 0 if t is None else t.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.get_lib().pointwise_mlp_forward(b, ci, ch, co, s, act, p(xc), p(w1c), p(b1c), p(w2c), p(b2c), p(skc),
+                                                 p(gtc), p(out), _stream())
+        ctx.save_for_backward(xc, w1c, b1c, w2c, b2c, skc, gtc)
+        ctx.cfg = (b, ci, ch, co, s, act, tuple(w1.shape), tuple(w2.shape), None if gate is None else tuple(gate.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, w1c, b1c, w2c, b2c, skc, gtc = ctx.saved_tensors
+        b, ci, ch, co, s, act, w1_shape, w2_shape, gate_shape = ctx.cfg
+        lib = _lib.get_lib()
+        dev = xc.device
+        gout = gout.contiguous()
+        gx = torch.empty_like(xc)
+        gw1, gw2 = torch.empty_like(w1c), torch.empty_like(w2c)
+        gb1 = None if b1c is None else torch.empty_like(b1c)
+        gb2 = None if b2c is None else torch.empty_like(b2c)
+        gsk = None if skc is None else torch.empty_like(skc)
+        ggt = None if gtc is None else torch.empty_like(gtc)
+        ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, ci, ch, co, s, act), dtype=torch.uint8, device=dev)
+        p = lambda t: 0 if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            lib.pointwise_mlp_backward(b, ci, ch, co, s, act, p(xc), p(w1c), p(b1c), p(w2c), p(b2c), p(skc), p(gtc),
+                                       p(gout), p(gx), p(gw1), p(gb1), p(gw2), p(gb2), p(gsk), p(ggt), p(ws), _stream())
+        return (gx, gw1.reshape(w1_shape), gb1, gw2.reshape(w2_shape), gb2, gsk,
+                None if ggt is None else ggt.reshape(gate_shape), None)
+
+
+_SHAPES = {(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)}
+
+
+def _on_engine(t):
+    return t.is_cuda
+
+
+def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=None):
+    """``act(conv1x1(gelu(conv1x1(x, w1, b1)), w2, b2) + gate * skip_src)``: w1 / w2 are Conv1d weights
+    (out, in[, 1]); gate a per-channel weight of any broadcastable shape with ``out`` elements; activation None or
+    "gelu".  One engine pass when the channel counts have a kernel and the pixel count is a multiple of 32, the plain
+    composition of the same operations otherwise."""
+    ci, ch, co = int(x.shape[1]), int(w1.shape[0]), int(w2.shape[0])
+    s = x[0, 0].numel()
+    fits = _on_engine(x) and x.dtype == torch.float32 and (ci, ch, co) in _SHAPES and s % 32 == 0 and \
+        (skip_src is None) == (gate is None)
+    if fits:
+        act = _lib.SC_ACT_GELU if activation == "gelu" else _lib.SC_ACT_NONE
+        return PointwiseMLPFn.apply(x, w1, b1, w2, b2, skip_src, gate, act)
+    shape = x.shape
+    h = F.gelu(F.conv1d(x.reshape(shape[0], ci, -1), w1.reshape(ch, ci, 1), b1))
+    z = F.conv1d(h, w2.reshape(co, ch, 1), b2).reshape(shape[0], co, *shape[2:])
+    if skip_src is not None:
+        z = z + gate.reshape(1, co, *(1,) * (x.ndim - 2)) * skip_src
+    return F.gelu(z) if activation == "gelu" else z
+
+
+def _block_in_scope(blocks, index, output_shape):
+    if output_shape is not None or getattr(blocks, "preactivation", False) or getattr(blocks, "norm", None) is not None:
+        return False
+    if getattr(blocks, "stabilizer", None) is not None or getattr(blocks, "complex_data", False):
+        return False
+    conv = blocks.convs[index]
+    if not hasattr(conv, "forward_fused") or getattr(conv, "resolution_scaling_factor", None) is not None:
+        return False
+    if not getattr(blocks, "use_channel_mlp", False) or blocks.fno_skips is None or blocks.channel_mlp_skips is None:
+        return False
+    mlp, gskip, fskip = blocks.channel_mlp[index], blocks.channel_mlp_skips[index], blocks.fno_skips[index]
+    if len(getattr(mlp, "fcs", ())) != 2 or getattr(mlp, "dropout", None) is not None:
+        return False
+    if type(gskip).__name__ != "SoftGating" or getattr(gskip, "bias", None) is not None:
+        return False
+    if type(fskip).__name__ != "Flattened1dConv":
+        return False
+    act = getattr(blocks, "non_linearity", None)
+    return act is F.gelu and getattr(mlp, "non_linearity", None) is F.gelu
+
+
+def fused_block_forward(blocks, x, index=0, output_shape=None):
+    """FNOBlocks.forward_with_postactivation (fno_block.py:377-414) for block ``index`` in two engine passes + the 1 x 1
+    skip convolution (a plain library GEMM); the module's own forward outside the scope described in the module
+    docstring."""
+    if not _block_in_scope(blocks, index, output_shape):
+        return blocks(x, index, output_shape=output_shape)
+    last = index >= blocks.n_layers - 1
+    x_skip_fno = blocks.fno_skips[index](x)                                   # 1 x 1 convolution, no bias by default
+    conv = blocks.convs[index]
+    y = conv.forward_fused(x, x_skip_fno, activation=None if last else "gelu")
+    fc1, fc2 = blocks.channel_mlp[index].fcs
+    return fused_channel_mlp(y, fc1.weight, fc1.bias, fc2.weight, fc2.bias, skip_src=x,
+                             gate=blocks.channel_mlp_skips[index].weight, activation=None if last else "gelu")

@@ -46,6 +46,12 @@ SC_DEVICE int sc_opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// the same for a wave-uniform value (stays in an SGPR): loop-invariant address terms derived from it are recomputed
+// where they are used instead of being hoisted into dozens of live registers
+SC_DEVICE int sc_opaque_s(int x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
 // streaming (non-temporal) access to the 0.5 GB real tensors: a plain store leaves up to 256 MB of
 // dirty Infinity-Cache lines whose write-back the NEXT kernel pays for (+57 us on a 537 MB reader,
 // profiles/r01_writeback_ubench.txt); nt stores drain to HBM while the producing kernel computes
@@ -71,6 +77,9 @@ SC_DEVICE void sc_wait_vmcnt() {        // at most N of this wave's vector-memor
 // s_barrier without the vmcnt(0) drain __syncthreads() carries while an LDS-DMA is outstanding
 #define SC_BARRIER_RAW() __builtin_amdgcn_s_barrier()
 typedef float sc_f4 __attribute__((ext_vector_type(4)));
+
+// float add into LDS shared by the waves of a workgroup: ds_add_f32 (no return value)
+#define SC_LDS_ADD(ptr, val) atomicAdd((ptr), (val))
 
 typedef hipStream_t sc_stream_t;
 
@@ -118,6 +127,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_STORE_STREAM(ptr, val) (*(ptr) = (val))
 #define SC_LOAD_STREAM(ptr) (*(ptr))
 inline int sc_opaque(int x) { return x; }
+inline int sc_opaque_s(int x) { return x; }
 #define SC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(scemu::g_dyn_shared)
 
 
@@ -134,6 +144,19 @@ inline void sc_wait_vmcnt() {}
 #define SC_BARRIER_RAW() scemu::barrier()
 
 typedef void* sc_stream_t;
+
+// emulated lanes are free-running threads: a compare-exchange loop stands in for ds_add_f32
+inline void sc_emu_lds_add(float* p, const float v) {
+  uint32_t* u = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED), nw;
+  do {
+    float f;
+    std::memcpy(&f, &old, 4);
+    f += v;
+    std::memcpy(&nw, &f, 4);
+  } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
+#define SC_LDS_ADD(ptr, val) sc_emu_lds_add((ptr), (val))
 
 // capture the arguments by value in a lambda and hand it to the thread pool
 #define SC_LAUNCH(kernel, grid, block, shmem, stream, ...)                          \

@@ -23,6 +23,7 @@
 #include "sc_kernels_mdft.h"
 #include "sc_kernels_fft2p.h"
 #include "sc_kernels_plane.h"
+#include "sc_kernels_pmlp.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -1499,6 +1500,128 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
   else if (!d->conj_a && d->conj_b) launch_msum<false, true>(g, a, b, c, st);
   else launch_msum<true, true>(g, a, b, c, st);
   return sc_check_launch("k_modegemm_msum");
+}
+
+// ------------------------------------------------------------------------------------------
+// pointwise MLP of an FNO block (sc_kernels_pmlp.h)
+// ------------------------------------------------------------------------------------------
+template <int CI, int CH, int CO>
+static void launch_pmlp_fwd(const PmlpArgs& g, bool gate, int act, sc_stream_t st) {
+  const dim3 grid((unsigned)g.n_wg), block(256);
+  if (gate && act) SC_LAUNCH((k_pmlp_fwd<CI, CH, CO, true, 1>), grid, block, 0, st, g);
+  else if (gate) SC_LAUNCH((k_pmlp_fwd<CI, CH, CO, true, 0>), grid, block, 0, st, g);
+  else if (act) SC_LAUNCH((k_pmlp_fwd<CI, CH, CO, false, 1>), grid, block, 0, st, g);
+  else SC_LAUNCH((k_pmlp_fwd<CI, CH, CO, false, 0>), grid, block, 0, st, g);
+}
+
+static int pmlp_shape_id(const sc_pmlp_desc* d) {
+  if (d->c_in % 32 || d->c_hid % 32 || d->c_out % 32) return 0;
+  return (int)(d->c_in / 32) * 100 + (int)(d->c_hid / 32) * 10 + (int)(d->c_out / 32);
+}
+
+extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1,
+                                        const float* w2, const float* b2, const float* skip_src, const float* gate,
+                                        float* out, void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  if (d->batch <= 0 || d->spatial <= 0) return 0;
+  SC_CHECK_ARG(x && w1 && w2 && out, "null argument");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU, "unknown activation");
+  SC_CHECK_ARG((skip_src == nullptr) == (gate == nullptr), "skip_src and gate come together");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
+  PmlpArgs g;
+  g.x = x; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.out = out;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  const int64_t wgs = (g.n_tiles + 3) / 4;
+  g.n_wg = (int)(wgs < 2048 ? wgs : 2048);                  // persistent: the weight tables are built once per workgroup
+  sc_stream_t st = (sc_stream_t)stream;
+  switch (pmlp_shape_id(d)) {
+    case 111: launch_pmlp_fwd<1, 1, 1>(g, gate != nullptr, d->act, st); break;
+    case 212: launch_pmlp_fwd<2, 1, 2>(g, gate != nullptr, d->act, st); break;
+    case 222: launch_pmlp_fwd<2, 2, 2>(g, gate != nullptr, d->act, st); break;
+    case 424: launch_pmlp_fwd<4, 2, 4>(g, gate != nullptr, d->act, st); break;
+    default:
+      return sc_fail("sc_engine: pointwise MLP: channel counts (c_in, c_hid, c_out) must be one of (32,32,32), "
+                     "(64,32,64), (64,64,64), (128,64,128)");
+  }
+  return sc_check_launch("k_pmlp_fwd");
+}
+
+static int pmlp_bwd_wgs(const sc_pmlp_desc* d) {
+  const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
+  return (int)(wgs < 512 ? wgs : 512);
+}
+
+template <int CI, int CH, int CO>
+static size_t pmlp_ws_floats(int n_wg) {
+  typedef PmlpDims<CI, CH, CO> D;
+  return (size_t)D::nTab + (size_t)n_wg * D::NP;
+}
+
+extern "C" size_t sc_pointwise_mlp_workspace_bytes(const sc_pmlp_desc* d) {
+  if (!d || d->batch <= 0 || d->spatial <= 0) return 0;
+  const int n_wg = pmlp_bwd_wgs(d);
+  size_t f = 0;
+  switch (pmlp_shape_id(d)) {
+    case 111: f = pmlp_ws_floats<1, 1, 1>(n_wg); break;
+    case 212: f = pmlp_ws_floats<2, 1, 2>(n_wg); break;
+    case 222: f = pmlp_ws_floats<2, 2, 2>(n_wg); break;
+    case 424: f = pmlp_ws_floats<4, 2, 4>(n_wg); break;
+    default: return 0;
+  }
+  return f * sizeof(float) + 256;
+}
+
+template <int CI, int CH, int CO>
+static void launch_pmlp_bwd(PmlpBwdArgs g, const float* w1, const float* w2, float* ws, bool gate, int act, float* gw1,
+                            float* gb1, float* gw2, float* gb2, float* ggate, sc_stream_t st) {
+  typedef PmlpDims<CI, CH, CO> D;
+  float* tab = ws;
+  g.tab = tab;
+  g.partial = ws + D::nTab;
+  SC_LAUNCH((k_pmlp_prep<CI, CH, CO>), dim3(64), dim3(256), 0, st, w1, w2, tab);
+  const dim3 grid((unsigned)g.n_wg), block(256);
+  if (gate && act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 1>), grid, block, 0, st, g);
+  else if (gate) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 0>), grid, block, 0, st, g);
+  else if (act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, false, 1>), grid, block, 0, st, g);
+  else SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, false, 0>), grid, block, 0, st, g);
+  SC_LAUNCH(k_pmlp_reduce, dim3((unsigned)((D::NP + 255) / 256)), dim3(256), 0, st, (const float*)g.partial, g.n_wg, (int)D::NP,
+            (int)D::oW1, (int)D::oB1, (int)D::oB2, (int)D::oG, gw2, gw1, gb1, gb2, gate ? ggate : (float*)nullptr);
+}
+
+extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1,
+                                         const float* w2, const float* b2, const float* skip_src, const float* gate,
+                                         const float* gout, float* gx, float* gw1, float* gb1, float* gw2, float* gb2,
+                                         float* gskip_src, float* ggate, void* workspace, void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise MLP backward: empty input");
+  SC_CHECK_ARG(x && w1 && w2 && gout && gx && gw1 && gw2 && workspace, "null argument");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU, "unknown activation");
+  SC_CHECK_ARG((skip_src == nullptr) == (gate == nullptr), "skip_src and gate come together");
+  SC_CHECK_ARG(!gate || (gskip_src && ggate), "a gated forward needs gskip_src and ggate");
+  SC_CHECK_ARG((b1 != nullptr || gb1 == nullptr) && (b2 != nullptr || gb2 == nullptr), "bias gradient without a bias");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
+  PmlpBwdArgs g;
+  g.x = x; g.b1 = b1; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.gout = gout; g.gx = gx; g.gskip = gskip_src;
+  g.tab = nullptr; g.partial = nullptr;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  g.n_wg = pmlp_bwd_wgs(d);
+  sc_stream_t st = (sc_stream_t)stream;
+  float* ws = (float*)workspace;
+  const bool gt = gate != nullptr;
+  switch (pmlp_shape_id(d)) {
+    case 111: launch_pmlp_bwd<1, 1, 1>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 212: launch_pmlp_bwd<2, 1, 2>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 222: launch_pmlp_bwd<2, 2, 2>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 424: launch_pmlp_bwd<4, 2, 4>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    default:
+      return sc_fail("sc_engine: pointwise MLP: channel counts (c_in, c_hid, c_out) must be one of (32,32,32), "
+                     "(64,32,64), (64,64,64), (128,64,128)");
+  }
+  return sc_check_launch("k_pmlp_bwd");
 }
 
 extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream) {

@@ -1,0 +1,439 @@
+// sc_kernels_pmlp.h -- the pointwise half of an FNO block in one pass:
+//
+//     out = act( W2 gelu(W1 y + b1) + b2 + gate (.) skip_src )
+//
+// i.e. the block's ChannelMLP (two 1 x 1 convolutions with a GELU in between, channel_mlp.py:60-119), its soft-gating
+// skip connection (skip_connections.py:53-130) and the block's closing non-linearity (fno_block.py:399-412), which
+// the reference runs as ~10 tensor-sized elementwise / conv1d passes.  Here a wave owns a tile of 32 pixels of one
+// sample for all channels and never leaves its registers between the two products:
+//
+//   GEMM 1  H[hid][px] = W1[hid][c] X[c][px]      exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the B operand X[c = 2 t + k][px]
+//           comes straight from global memory (per channel row 32 consecutive pixels: one 128-byte segment per half-wave)
+//   GELU    on the accumulator registers
+//   GEMM 2  Z[out][px] = W2[out][hid] H[hid][px]  the accumulator of GEMM 1 IS the B operand: lane (px, k) of an
+//           accumulator holds rows (v & 3) + 8 (v >> 2) + 4 k, so step v contracts the row pair (row(v, 0), row(v, 1)) and
+//           the A operand (W2) is pre-arranged in that order -- the hidden activations never touch LDS or memory
+//   epilogue + b2 + gate[c] skip_src[c][px], activation, store (same 128-byte segments)
+//
+// Weights live in LDS in MFMA lane order (one conflict-free ds_read_b32 per MFMA).  Memory traffic: y and skip_src read
+// once, out written once (3 tensor passes); matrix work 2 x 32 MFMAs per 32-pixel tile at 64 -> 32 -> 64 channels, far
+// under the time the 24 KB of the tile need to cross HBM.
+#pragma once
+#include "sc_kernels_mfma.h"
+#include "sc_kernels_fft3.h"      // sc_gelu
+
+// accumulator register v of a lane in half `half` holds this row of the 32 x 32 tile
+SC_HD int pmlp_row(const int v, const int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
+
+// d/dx gelu(x) = Phi(x) + x phi(x)
+SC_DEVICE float sc_gelu_grad(const float x) {
+  const float cdf = 0.5f * (1.f + sc_erf_fast(x * 0.70710678118654752440f));
+#ifndef SC_EMU
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+#else
+  const float pdf = 0.39894228040143267794f * std::exp(-0.5f * x * x);
+#endif
+  return cdf + x * pdf;
+}
+
+struct PmlpArgs {
+  const float* x;         // (batch, 32 CI, spatial)
+  const float* w1;        // (32 CH, 32 CI)
+  const float* b1;        // (32 CH) or null
+  const float* w2;        // (32 CO, 32 CH)
+  const float* b2;        // (32 CO) or null
+  const float* skip;      // (batch, 32 CO, spatial) when GATE
+  const float* gate;      // (32 CO) when GATE
+  float* out;             // (batch, 32 CO, spatial)
+  int64_t n_tiles, spatial;
+  int tiles_per_sample, n_wg;
+};
+
+template <int CI, int CH, int CO, bool GATE, int ACT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_pmlp_fwd(PmlpArgs g) {
+  constexpr int C_IN = 32 * CI, C_HID = 32 * CH, C_OUT = 32 * CO, S1 = 16 * CI;
+  SC_SHARED float A1[CH * S1 * 64];
+  SC_SHARED float A2[CO * CH * 16 * 64];
+  SC_SHARED float B1[C_HID], B2[C_OUT], GT[C_OUT];
+  const int tid = SC_TID, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = SC_UNIFORM(tid >> 6);
+  for (int i = tid; i < CH * S1 * 64; i += 256) {
+    const int l = i & 63, s = (i >> 6) % S1, hm = (i >> 6) / S1;
+    A1[i] = g.w1[(32 * hm + (l & 31)) * C_IN + 2 * s + (l >> 5)];
+  }
+  for (int i = tid; i < CO * CH * 16 * 64; i += 256) {
+    const int l = i & 63, v = (i >> 6) & 15, hm = ((i >> 10) % CH), om = (i >> 10) / CH;
+    A2[i] = g.w2[(32 * om + (l & 31)) * C_HID + 32 * hm + pmlp_row(v, l >> 5)];
+  }
+  for (int i = tid; i < C_HID; i += 256) B1[i] = g.b1 ? g.b1[i] : 0.f;
+  for (int i = tid; i < C_OUT; i += 256) {
+    B2[i] = g.b2 ? g.b2[i] : 0.f;
+    GT[i] = GATE ? g.gate[i] : 0.f;
+  }
+  SC_SYNC();
+  // addressing: a wave-uniform base (sample, first pixel of the tile, channel row of the step) + ONE 32-bit lane offset
+  // per operand layout, so the ~100 loads / stores of a tile share two address registers
+  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
+  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+#pragma unroll 1
+  for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
+    const int64_t b = tile / g.tiles_per_sample;
+    const int64_t px0 = (tile - b * g.tiles_per_sample) * 32;
+    const int64_t sp = sc_opaque_s((int)g.spatial);        // row offsets k * sp: computed at their use, not hoisted
+    const float* xs = g.x + b * C_IN * sp + px0;
+    const float* ss = GATE ? g.skip + b * C_OUT * sp + px0 : nullptr;
+    float* os = g.out + b * C_OUT * sp + px0;
+    const int hq = sc_opaque(half);                        // bias / gate reads are loop invariant: keep them in the loop
+    float xr[CI * 16];
+#pragma unroll
+    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+    SC_SCHED_BARRIER();
+    sc_f32x16 acc1[CH];
+#pragma unroll
+    for (int hm = 0; hm < CH; ++hm) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc1[hm][v] = 0.f;
+#pragma unroll
+      for (int s0 = 0; s0 < S1; s0 += 8) {                 // 8 table reads, 8 MFMAs: bounded live ranges
+#pragma unroll
+        for (int s = s0; s < s0 + 8; ++s) sc_mfma_32x32x2(acc1[hm], A1[(hm * S1 + s) * 64 + lane], xr[s]);
+        SC_SCHED_BARRIER();
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        acc1[hm][v] = sc_gelu(acc1[hm][v] + B1[32 * hm + pmlp_row(v, hq)]);
+        if ((v & 3) == 3) SC_SCHED_BARRIER();              // four evaluations in flight, not sixteen
+      }
+    }
+#pragma unroll
+    for (int om = 0; om < CO; ++om) {
+      float sk[16];
+      if (GATE) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+      }
+      sc_f32x16 acc2;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc2[v] = 0.f;
+#pragma unroll
+      for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc2, A2[((om * CH + hm) * 16 + v) * 64 + lane], acc1[hm][v]);
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int r = 32 * om + pmlp_row(v, hq);
+        float val = acc2[v] + B2[r];
+        if (GATE) val = fmaf(GT[r], sk[v], val);
+        if (ACT == 1) val = sc_gelu(val);
+        SC_STORE_STREAM(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, val);
+        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: everything recomputed from x (and skip_src) inside the tile -- nothing but x is saved by the forward.
+//   gz  = gout (.) act'(z_pre)                     gskip = gate (.) gz,  ggate += sum_px gz (.) skip,  gb2 += sum_px gz
+//   gh  = W2^T gz,  ghp = gh (.) gelu'(h_pre)      gb1 += sum_px ghp
+//   gx  = W1^T ghp
+//   gW2 += gz h^T,  gW1 += ghp x^T                 contraction over the 32 pixels of the tile: the operands are transposed
+//                                                  through a per-wave LDS scratch (32 x 33 floats each)
+// A operands (W1, W2, W2^T, W1^T in MFMA lane order, the latter three in the accumulator row order) are prepared once
+// by k_pmlp_prep in the workspace and read with one coalesced 256-byte load per MFMA (L1 / L2 resident); the weight
+// gradients of a tile (one fresh 32 x 32 accumulator per weight tile) are added into ONE LDS image per workgroup
+// (ds_add_f32 -- register-resident accumulators over the whole tile loop cost 64+ registers and sent the kernel to
+// scratch), written as one partial per workgroup; k_pmlp_reduce adds the partials in a fixed order.
+// ------------------------------------------------------------------------------------------
+template <int CI, int CH, int CO>
+struct PmlpDims {
+  static constexpr int C_IN = 32 * CI, C_HID = 32 * CH, C_OUT = 32 * CO, S1 = 16 * CI;
+  static constexpr int nA1 = CH * S1 * 64, nA2 = CO * CH * 16 * 64, nA3 = CH * CO * 16 * 64, nA4 = CI * CH * 16 * 64;
+  static constexpr int oA1 = 0, oA2 = oA1 + nA1, oA3 = oA2 + nA2, oA4 = oA3 + nA3, nTab = oA4 + nA4;
+  // one partial: gw2 | gw1 | gb1 | gb2 | ggate
+  static constexpr int oW2 = 0, oW1 = oW2 + C_OUT * C_HID, oB1 = oW1 + C_HID * C_IN, oB2 = oB1 + C_HID, oG = oB2 + C_OUT,
+                       NP = oG + C_OUT;
+};
+
+template <int CI, int CH, int CO>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+k_pmlp_prep(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ tab) {
+  typedef PmlpDims<CI, CH, CO> D;
+  const int stride = 256 * 64;
+  for (int i = SC_BID_X * 256 + SC_TID; i < D::nTab; i += stride) {
+    const int l = i & 63, m = l & 31, kk = l >> 5;
+    float val;
+    if (i < D::oA2) {
+      const int j = (i - D::oA1) >> 6, s = j % D::S1, hm = j / D::S1;
+      val = w1[(32 * hm + m) * D::C_IN + 2 * s + kk];
+    } else if (i < D::oA3) {
+      const int j = (i - D::oA2) >> 6, v = j & 15, hm = (j >> 4) % CH, om = (j >> 4) / CH;
+      val = w2[(32 * om + m) * D::C_HID + 32 * hm + pmlp_row(v, kk)];
+    } else if (i < D::oA4) {
+      const int j = (i - D::oA3) >> 6, v = j & 15, om = (j >> 4) % CO, hm = (j >> 4) / CO;
+      val = w2[(32 * om + pmlp_row(v, kk)) * D::C_HID + 32 * hm + m];
+    } else {
+      const int j = (i - D::oA4) >> 6, v = j & 15, hm = (j >> 4) % CH, ci = (j >> 4) / CH;
+      val = w1[(32 * hm + pmlp_row(v, kk)) * D::C_IN + 32 * ci + m];
+    }
+    tab[i] = val;
+  }
+}
+
+struct PmlpBwdArgs {
+  const float* x;
+  const float* b1;
+  const float* b2;
+  const float* skip;
+  const float* gate;
+  const float* gout;
+  const float* tab;        // A operands (k_pmlp_prep)
+  float* gx;
+  float* gskip;
+  float* partial;          // [n_wg][NP]
+  int64_t n_tiles, spatial;
+  int tiles_per_sample, n_wg;
+};
+
+template <int CI, int CH, int CO, bool GATE, int ACT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_pmlp_bwd(PmlpBwdArgs g) {
+  typedef PmlpDims<CI, CH, CO> D;
+  constexpr int S1 = D::S1, TS = 32 * 33;
+  SC_SHARED float scr[4 * (1 + CH) * TS];                 // per wave: T_A and one T_B per hidden tile (h)
+  SC_SHARED float red[D::NP];
+  SC_SHARED float B1[D::C_HID], B2[D::C_OUT], GT[D::C_OUT];
+  const int tid = SC_TID, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = SC_UNIFORM(tid >> 6);
+  float* TA = scr + w * (1 + CH) * TS;
+  float* TH = TA + TS;                                    // h tiles, transposed: TH[hm][row][px]
+  const float* A1 = g.tab + D::oA1;
+  const float* A2 = g.tab + D::oA2;
+  const float* A3 = g.tab + D::oA3;
+  const float* A4 = g.tab + D::oA4;
+  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
+  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+  float sB2[CO], sG[CO], sB1[CH];                          // row sums (bias / gate gradients): half a row per lane
+#pragma unroll
+  for (int om = 0; om < CO; ++om) sB2[om] = sG[om] = 0.f;
+#pragma unroll
+  for (int hm = 0; hm < CH; ++hm) sB1[hm] = 0.f;
+  for (int i = tid; i < D::NP; i += 256) red[i] = 0.f;
+  for (int i = tid; i < D::C_HID; i += 256) B1[i] = g.b1 ? g.b1[i] : 0.f;
+  for (int i = tid; i < D::C_OUT; i += 256) {
+    B2[i] = g.b2 ? g.b2[i] : 0.f;
+    GT[i] = GATE ? g.gate[i] : 0.f;
+  }
+  SC_SYNC();
+#pragma unroll 1
+  for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
+    const int64_t b = tile / g.tiles_per_sample;
+    const int64_t px0 = (tile - b * g.tiles_per_sample) * 32;
+    const int64_t sp = sc_opaque_s((int)g.spatial);        // row offsets k * sp: computed at their use, not hoisted
+    const float* xs = g.x + b * D::C_IN * sp + px0;
+    const float* gs = g.gout + b * D::C_OUT * sp + px0;
+    const float* ss = GATE ? g.skip + b * D::C_OUT * sp + px0 : nullptr;
+    float* gks = GATE ? g.gskip + b * D::C_OUT * sp + px0 : nullptr;
+    float* gxs = g.gx + b * D::C_IN * sp + px0;
+    // ---- A: recompute h_pre and h; h also goes to LDS transposed (operand of the W2 gradient)
+    // (the operand tables are loop invariant: without an opaque lane offset per phase the compiler hoists all ~130
+    // table loads out of the tile loop and the kernel lives in scratch)
+    float hp[CH][16], h[CH][16];
+    {
+      const int ln1 = sc_opaque(lane), hq1 = sc_opaque(half);
+      float xr[CI * 16];
+#pragma unroll
+      for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int hm = 0; hm < CH; ++hm) {
+        sc_f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int s0 = 0; s0 < S1; s0 += 8) {
+#pragma unroll
+          for (int s = s0; s < s0 + 8; ++s) sc_mfma_32x32x2(acc, A1[(hm * S1 + s) * 64 + ln1], xr[s]);
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          hp[hm][v] = acc[v] + B1[32 * hm + pmlp_row(v, hq1)];
+          h[hm][v] = sc_gelu(hp[hm][v]);
+          TH[hm * TS + pmlp_row(v, half) * 33 + n] = h[hm][v];
+        }
+        SC_SCHED_BARRIER();
+      }
+    }
+    // ---- B: one output tile at a time: gz, gskip, ggate / gb2 sums, gW2 += gz h^T, gh += W2^T gz
+    sc_f32x16 gh[CH];
+#pragma unroll
+    for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) gh[hm][v] = 0.f;
+#pragma unroll
+    for (int om = 0; om < CO; ++om) {
+      const int ln2 = sc_opaque(lane), hq2 = sc_opaque(half);
+      float gz[16], sk[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
+        gz[v] = SC_LOAD_STREAM(gs + ro);
+        sk[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+      }
+      if (ACT == 1) {
+        sc_f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+          for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+            for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, A2[((om * CH + hm) * 16 + v) * 64 + ln2], h[hm][v]);
+            SC_SCHED_BARRIER();
+          }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int r = 32 * om + pmlp_row(v, hq2);
+          float z = acc[v] + B2[r];
+          if (GATE) z = fmaf(GT[r], sk[v], z);
+          gz[v] *= sc_gelu_grad(z);
+        }
+      }
+      if (GATE) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int r = 32 * om + pmlp_row(v, hq2);
+          SC_STORE_STREAM(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[r] * gz[v]);
+          TA[pmlp_row(v, half) * 33 + n] = gz[v] * sk[v];
+        }
+        SC_WAVE_SYNC();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sG[om] += TA[n * 33 + 2 * t + half];     // row sums: lane (row, half of the pixels)
+        SC_WAVE_SYNC();
+      }
+      SC_SCHED_BARRIER();
+      // transposed gz: T[row][px]; lane (m, kk) reads T[m][2 t + kk] as the A operand of step t
+#pragma unroll
+      for (int v = 0; v < 16; ++v) TA[pmlp_row(v, half) * 33 + n] = gz[v];
+      SC_WAVE_SYNC();
+#pragma unroll
+      for (int hm = 0; hm < CH; ++hm) {
+        sc_f32x16 dw;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) dw[v] = 0.f;
+#pragma unroll
+        for (int t0 = 0; t0 < 16; t0 += 8) {
+#pragma unroll
+          for (int t = t0; t < t0 + 8; ++t) {
+            const float a = TA[n * 33 + 2 * t + half];
+            sc_mfma_32x32x2(dw, a, TH[hm * TS + n * 33 + 2 * t + half]);
+            if (hm == 0) sB2[om] += a;
+          }
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) SC_LDS_ADD(&red[D::oW2 + (32 * om + pmlp_row(v, half)) * D::C_HID + 32 * hm + n], dw[v]);
+        SC_SCHED_BARRIER();
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(gh[hm], A3[((hm * CO + om) * 16 + v) * 64 + ln2], gz[v]);
+          SC_SCHED_BARRIER();
+        }
+      }
+      SC_WAVE_SYNC();                                      // T_A is rewritten by the next tile
+    }
+    // ---- C: ghp = gh * gelu'(h_pre)
+    float ghp[CH][16];
+#pragma unroll
+    for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) ghp[hm][v] = gh[hm][v] * sc_gelu_grad(hp[hm][v]);
+    SC_SCHED_BARRIER();
+    // ---- D: gx = W1^T ghp
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+      const int ln4 = sc_opaque(lane);
+      sc_f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+      for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, A4[((ci * CH + hm) * 16 + v) * 64 + ln4], ghp[hm][v]);
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) SC_STORE_STREAM(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
+      SC_SCHED_BARRIER();
+    }
+    // ---- E: gW1 += ghp x^T over the pixels: ghp transposed in T_A, the x tile (re-read: L2 resident) in the first
+    //         T_H buffer as X[c][px]
+#pragma unroll
+    for (int hm = 0; hm < CH; ++hm) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) TA[pmlp_row(v, half) * 33 + n] = ghp[hm][v];
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) {
+        const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);   // a second read of x, not phase A's values kept alive
+        SC_WAVE_SYNC();                                    // readers of the previous X tile (and of h, first round)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) TH[(2 * t + half) * 33 + n] = xs[(int64_t)(32 * ci + 2 * t) * sp + lo_e];
+        SC_WAVE_SYNC();
+        sc_f32x16 dw;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) dw[v] = 0.f;
+#pragma unroll
+        for (int t0 = 0; t0 < 16; t0 += 8) {
+#pragma unroll
+          for (int t = t0; t < t0 + 8; ++t) {
+            const float a = TA[n * 33 + 2 * t + half];
+            sc_mfma_32x32x2(dw, a, TH[n * 33 + 2 * t + half]);
+            if (ci == 0) sB1[hm] += a;
+          }
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) SC_LDS_ADD(&red[D::oW1 + (32 * hm + pmlp_row(v, half)) * D::C_IN + 32 * ci + n], dw[v]);
+        SC_SCHED_BARRIER();
+      }
+      SC_WAVE_SYNC();
+    }
+  }
+  // ---- row sums: the two halves of a row live in lanes n and n + 32
+#pragma unroll
+  for (int om = 0; om < CO; ++om) {
+    SC_LDS_ADD(&red[D::oB2 + 32 * om + n], sB2[om]);
+    SC_LDS_ADD(&red[D::oG + 32 * om + n], sG[om]);
+  }
+#pragma unroll
+  for (int hm = 0; hm < CH; ++hm) SC_LDS_ADD(&red[D::oB1 + 32 * hm + n], sB1[hm]);
+  SC_SYNC();
+  float* dst = g.partial + (int64_t)SC_BID_X * D::NP;
+  for (int i = tid; i < D::NP; i += 256) dst[i] = red[i];
+}
+
+// sums[i] = sum_wg partial[wg][i] (wg ascending), scattered to the five gradient tensors (null = not wanted)
+SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+k_pmlp_reduce(const float* __restrict__ partial, int n_wg, int np, int o_w1, int o_b1, int o_b2, int o_g,
+              float* __restrict__ gw2, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gb2,
+              float* __restrict__ ggate) {
+  const int i = SC_BID_X * 256 + SC_TID;
+  if (i >= np) return;
+  float s = 0.f;
+  for (int k = 0; k < n_wg; ++k) s += partial[(int64_t)k * np + i];
+  if (i < o_w1) gw2[i] = s;
+  else if (i < o_b1) gw1[i - o_w1] = s;
+  else if (i < o_b2) { if (gb1) gb1[i - o_b1] = s; }
+  else if (i < o_g) { if (gb2) gb2[i - o_b2] = s; }
+  else if (ggate) ggate[i - o_g] = s;
+}

@@ -14,14 +14,17 @@ from engine_runner import emu_lib
 
 @contextlib.contextmanager
 def engine_on_emulation():
-    from neuraloperator_amd import _lib, engine
+    from neuraloperator_amd import _lib, blocks, engine
 
     saved = (_lib._LIB, engine._require_gpu, engine._stream, torch.cuda.device, torch.cuda.current_device,
-             dict(engine._PLANS))
+             dict(engine._PLANS), blocks._require_gpu, blocks._stream, blocks._on_engine)
     engine._PLANS.clear()
     _lib._LIB = emu_lib()
     engine._require_gpu = lambda *a, **k: None
     engine._stream = lambda: 0
+    blocks._require_gpu = lambda *a, **k: None
+    blocks._stream = lambda: 0
+    blocks._on_engine = lambda t: True
     torch.cuda.device = lambda *a, **k: contextlib.nullcontext()
     torch.cuda.current_device = lambda: 0
     try:
@@ -30,3 +33,4 @@ def engine_on_emulation():
         engine._PLANS.clear()                       # emulation plans must never reach the product library
         _lib._LIB, engine._require_gpu, engine._stream, torch.cuda.device, torch.cuda.current_device = saved[:5]
         engine._PLANS.update(saved[5])
+        blocks._require_gpu, blocks._stream, blocks._on_engine = saved[6:9]

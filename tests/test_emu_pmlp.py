@@ -1,0 +1,100 @@
+"""CPU tier: the pointwise half of an FNO block in one pass (sc_kernels_pmlp.h) in host
+emulation against the same computation in torch: out = act(W2 gelu(W1 x + b1) + b2 + gate * skip) -- the reference's
+ChannelMLP (channel_mlp.py:82-119) + soft-gating skip (skip_connections.py:53-130) + closing non-linearity
+(fno_block.py:399-412)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from engine_runner import emu_lib, rel_l2
+from neuraloperator_amd import _lib
+
+TOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def _ref(x, w1, b1, w2, b2, skip, gate, act):
+    h = F.gelu(torch.einsum("hc,bcs->bhs", w1.double(), x.double()) + (0 if b1 is None else b1.double()[None, :, None]))
+    z = torch.einsum("oh,bhs->bos", w2.double(), h) + (0 if b2 is None else b2.double()[None, :, None])
+    if skip is not None:
+        z = z + gate.double()[None, :, None] * skip.double()
+    return F.gelu(z) if act else z
+
+
+@pytest.mark.parametrize("chans", [(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)], ids=str)
+@pytest.mark.parametrize("gate,act,bias", [(True, 1, True), (False, 0, True), (True, 0, False)])
+def test_pointwise_mlp_forward(lib, chans, gate, act, bias):
+    ci, ch, co = chans
+    g = torch.Generator().manual_seed(ci + ch + act)
+    B, S = 3, 96                                        # 9 tiles of 32 pixels: more tiles than one wave round
+    x = torch.randn(B, ci, S, generator=g)
+    w1 = torch.randn(ch, ci, generator=g) / ci ** 0.5
+    w2 = torch.randn(co, ch, generator=g) / ch ** 0.5
+    b1 = torch.randn(ch, generator=g) if bias else None
+    b2 = torch.randn(co, generator=g) if bias else None
+    skip = torch.randn(B, co, S, generator=g) if gate else None
+    gt = torch.randn(co, generator=g) if gate else None
+    out = torch.full((B, co, S), float("nan"))
+    p = lambda t: 0 if t is None else t.data_ptr()
+    lib.pointwise_mlp_forward(B, ci, ch, co, S, act, p(x), p(w1), p(b1), p(w2), p(b2), p(skip), p(gt), p(out), 0)
+    assert rel_l2(out.numpy(), _ref(x, w1, b1, w2, b2, skip, gt, act).numpy()) < TOL
+
+
+def test_pointwise_mlp_argument_checks(lib):
+    x = torch.zeros(1, 64, 32)
+    w1, w2, out = torch.zeros(32, 64), torch.zeros(64, 32), torch.zeros(1, 64, 32)
+    with pytest.raises(_lib.EngineError):                # 48 channels: no kernel
+        lib.pointwise_mlp_forward(1, 48, 32, 48, 32, 0, x.data_ptr(), w1.data_ptr(), 0, w2.data_ptr(), 0, 0, 0, out.data_ptr(), 0)
+    with pytest.raises(_lib.EngineError):                # spatial not a multiple of 32
+        lib.pointwise_mlp_forward(1, 64, 32, 64, 40, 0, x.data_ptr(), w1.data_ptr(), 0, w2.data_ptr(), 0, 0, 0, out.data_ptr(), 0)
+    with pytest.raises(_lib.EngineError):                # a gate without its source
+        lib.pointwise_mlp_forward(1, 64, 32, 64, 32, 0, x.data_ptr(), w1.data_ptr(), 0, w2.data_ptr(), 0, 0, w1.data_ptr(), out.data_ptr(), 0)
+
+
+BWD_CASES = [((64, 32, 64), True, 1, True), ((64, 32, 64), False, 0, True), ((64, 32, 64), True, 0, False),
+             ((64, 32, 64), False, 1, False), ((32, 32, 32), True, 1, True), ((64, 64, 64), True, 1, False),
+             ((128, 64, 128), True, 1, True)]
+
+
+@pytest.mark.parametrize("chans,gate,act,bias", BWD_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}_g{int(g)}a{a}b{int(b)}" for c, g, a, b in BWD_CASES])
+def test_pointwise_mlp_backward(lib, chans, gate, act, bias):
+    """Every gradient of the fused pass (recomputation inside the tile, pixel contraction of the weight gradients
+    through the LDS transposes, fixed-order reduction of the per-workgroup partials) against torch autograd of the
+    float64 composition."""
+    ci, ch, co = chans
+    g = torch.Generator().manual_seed(7 * ci + ch + 3 * act)
+    B, S = 2, 96                                        # 6 tiles: 2 workgroups, the last with two idle waves
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    x, gout = mk(B, ci, S), mk(B, co, S)
+    w1, w2 = mk(ch, ci, sc=ci ** -0.5), mk(co, ch, sc=ch ** -0.5)
+    b1, b2 = (mk(ch), mk(co)) if bias else (None, None)
+    skip, gt = (mk(B, co, S), mk(co)) if gate else (None, None)
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, w1, b1, w2, b2, skip, gt)]
+    xd, w1d, b1d, w2d, b2d, skd, gtd = leaves
+    h = F.gelu(torch.einsum("hc,bcs->bhs", w1d, xd) + (0 if b1d is None else b1d[None, :, None]))
+    z = torch.einsum("oh,bhs->bos", w2d, h) + (0 if b2d is None else b2d[None, :, None])
+    if gate:
+        z = z + gtd[None, :, None] * skd
+    out = F.gelu(z) if act else z
+    out.backward(gout.double())
+    gx, gw1, gw2 = torch.full_like(x, float("nan")), torch.full_like(w1, float("nan")), torch.full_like(w2, float("nan"))
+    gb1 = torch.full((ch,), float("nan")) if bias else None
+    gb2 = torch.full((co,), float("nan")) if bias else None
+    gsk = torch.full((B, co, S), float("nan")) if gate else None
+    ggt = torch.full((co,), float("nan")) if gate else None
+    ws = torch.empty(lib.pointwise_mlp_workspace_bytes(B, ci, ch, co, S, act), dtype=torch.uint8)
+    p = lambda t: 0 if t is None else t.data_ptr()
+    lib.pointwise_mlp_backward(B, ci, ch, co, S, act, p(x), p(w1), p(b1), p(w2), p(b2), p(skip), p(gt), p(gout),
+                               p(gx), p(gw1), p(gb1), p(gw2), p(gb2), p(gsk), p(ggt), p(ws), 0)
+    tol = 1e-5
+    assert rel_l2(gx.numpy(), xd.grad.numpy()) < tol
+    assert rel_l2(gw1.numpy(), w1d.grad.numpy()) < tol
+    assert rel_l2(gw2.numpy(), w2d.grad.numpy()) < tol
+    if bias:
+        assert rel_l2(gb1.numpy(), b1d.grad.numpy()) < tol and rel_l2(gb2.numpy(), b2d.grad.numpy()) < tol
+    if gate:
+        assert rel_l2(gsk.numpy(), skd.grad.numpy()) < tol and rel_l2(ggt.numpy(), gtd.grad.numpy()) < tol

@@ -1,0 +1,62 @@
+"""a whole FNO block through the two fused engine passes
+(neuraloperator_amd.blocks.fused_block_forward) against the VERBATIM reference FNOBlocks.forward
+(neuralop/layers/fno_block.py:377-414) on the same module -- output, input gradient and every parameter gradient,
+first and last block (the last one has no closing activation).  CPU tier: engine in host emulation."""
+import pytest
+import torch
+
+from emu_engine import engine_on_emulation
+from engine_runner import rel_l2
+from oracle import ref_verbatim
+
+pytestmark = pytest.mark.skipif(not ref_verbatim.available(), reason="verbatim reference not present")
+
+
+def _blocks(hidden, n_modes, n_layers=2):
+    import importlib
+    from neuraloperator_amd import SpectralConv
+    ref_verbatim.load_reference_fno()
+    fb = importlib.import_module("neuralop.layers.fno_block")
+    torch.manual_seed(0)
+    return fb.FNOBlocks(hidden, hidden, n_modes=n_modes, n_layers=n_layers, conv_module=SpectralConv)
+
+
+@pytest.mark.parametrize("index", [0, 1], ids=["first", "last"])
+def test_fused_block_matches_verbatim_fnoblocks(index):
+    from neuraloperator_amd import blocks as nb
+    blk = _blocks(64, (8, 8))
+    with torch.no_grad():
+        for q in blk.parameters():
+            if q.is_complex():
+                q.mul_(4.0)                                  # spectral weights at O(1) so the Fourier branch matters
+        blk.channel_mlp_skips[index].weight.copy_(torch.randn_like(blk.channel_mlp_skips[index].weight))
+    x = torch.randn(2, 64, 16, 16)
+    g = torch.randn(2, 64, 16, 16)
+    res = []
+    with engine_on_emulation():
+        assert nb._block_in_scope(blk, index, None)
+        for fn in (lambda t: blk(t, index), lambda t: nb.fused_block_forward(blk, t, index)):
+            blk.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            y = fn(xi)
+            y.backward(g)
+            res.append((y.detach(), xi.grad.clone(), {n: q.grad.clone() for n, q in blk.named_parameters() if q.grad is not None}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert rel_l2(y1.numpy(), y0.numpy()) < 1e-5 and rel_l2(gx1.numpy(), gx0.numpy()) < 1e-5
+    assert set(gp0) == set(gp1) and len(gp0) >= 7
+    for n in gp0:
+        a, b = gp1[n], gp0[n]
+        a, b = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
+        assert rel_l2(a.numpy(), b.numpy()) < 2e-5, n
+
+
+def test_out_of_scope_blocks_take_the_module_forward():
+    from neuraloperator_amd import blocks as nb
+    blk = _blocks(32, (4, 4))                                # 32 -> 16 -> 32 channels: no kernel for the MLP
+    x = torch.randn(1, 32, 8, 8)
+    with engine_on_emulation():
+        assert nb._block_in_scope(blk, 0, None)              # in scope as a block ...
+        y0 = blk(x, 0)
+        y1 = nb.fused_block_forward(blk, x, 0)               # ... the MLP part falls back to the composition
+    assert rel_l2(y1.detach().numpy(), y0.detach().numpy()) < 1e-5
+    assert not nb._block_in_scope(blk, 0, (16, 16))          # a resolution change is out of scope
