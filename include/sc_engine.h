@@ -195,7 +195,8 @@ int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, const float*
  * pre-activations are recomputed inside the tile).  gx (batch, c_in, spatial), gskip_src (batch, c_out, spatial; with a
  * gate), gw1 / gw2 like w1 / w2, gb1 / gb2 / ggate (null when the forward had none) are all overwritten.  workspace:
  * sc_pointwise_mlp_workspace_bytes(d) bytes (operand tables + one partial sum per workgroup; the partials are added
- * in a fixed order: results are bit-reproducible). */
+ * in a fixed order; inside a workgroup the waves add with LDS atomics).  Shapes: (32,32,32), (64,32,64), (64,64,64) --
+ * (128,64,128) has the forward pass only. */
 size_t sc_pointwise_mlp_workspace_bytes(const sc_pmlp_desc* d);
 int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1, const float* w2,
                               const float* b2, const float* skip_src, const float* gate, const float* gout, float* gx,

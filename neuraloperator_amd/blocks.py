@@ -70,6 +70,7 @@ class PointwiseMLPFn(torch.autograd.Function):
 
 
 _SHAPES = {(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)}
+_SHAPES_BWD = {(32, 32, 32), (64, 32, 64), (64, 64, 64)}      # (128, 64, 128): forward kernel only
 
 
 def _on_engine(t):
@@ -83,8 +84,10 @@ def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=No
     composition of the same operations otherwise."""
     ci, ch, co = int(x.shape[1]), int(w1.shape[0]), int(w2.shape[0])
     s = x[0, 0].numel()
-    fits = _on_engine(x) and x.dtype == torch.float32 and (ci, ch, co) in _SHAPES and s % 32 == 0 and \
-        (skip_src is None) == (gate is None)
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                   for t in (x, w1, b1, w2, b2, skip_src, gate))
+    fits = _on_engine(x) and x.dtype == torch.float32 and s % 32 == 0 and (skip_src is None) == (gate is None) and \
+        (ci, ch, co) in (_SHAPES_BWD if needs_grad else _SHAPES)
     if fits:
         act = _lib.SC_ACT_GELU if activation == "gelu" else _lib.SC_ACT_NONE
         return PointwiseMLPFn.apply(x, w1, b1, w2, b2, skip_src, gate, act)

@@ -1548,15 +1548,19 @@ extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, c
   return sc_check_launch("k_pmlp_fwd");
 }
 
+#define SC_PMLP_RED_GROUPS 16
+// waves per workgroup of the backward kernel: 8 while the operand tables + scratch fit LDS, 4 for 64 hidden channels
+static int pmlp_bwd_waves(const sc_pmlp_desc* d) { return d->c_hid > 32 ? 4 : 8; }
 static int pmlp_bwd_wgs(const sc_pmlp_desc* d) {
-  const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
-  return (int)(wgs < 512 ? wgs : 512);
+  const int nw = pmlp_bwd_waves(d);
+  const int64_t wgs = (d->batch * (d->spatial / 32) + nw - 1) / nw;
+  return (int)(wgs < 256 ? wgs : 256);                      // one workgroup per CU
 }
 
 template <int CI, int CH, int CO>
 static size_t pmlp_ws_floats(int n_wg) {
   typedef PmlpDims<CI, CH, CO> D;
-  return (size_t)D::nTab + (size_t)n_wg * D::NP;
+  return (size_t)(n_wg + SC_PMLP_RED_GROUPS) * D::NP;       // one partial per workgroup + the first reduction stage
 }
 
 extern "C" size_t sc_pointwise_mlp_workspace_bytes(const sc_pmlp_desc* d) {
@@ -1567,27 +1571,28 @@ extern "C" size_t sc_pointwise_mlp_workspace_bytes(const sc_pmlp_desc* d) {
     case 111: f = pmlp_ws_floats<1, 1, 1>(n_wg); break;
     case 212: f = pmlp_ws_floats<2, 1, 2>(n_wg); break;
     case 222: f = pmlp_ws_floats<2, 2, 2>(n_wg); break;
-    case 424: f = pmlp_ws_floats<4, 2, 4>(n_wg); break;
-    default: return 0;
+    default: return 0;                                      // (128, 64, 128): forward kernel only
   }
   return f * sizeof(float) + 256;
 }
 
-template <int CI, int CH, int CO>
-static void launch_pmlp_bwd(PmlpBwdArgs g, const float* w1, const float* w2, float* ws, bool gate, int act, float* gw1,
-                            float* gb1, float* gw2, float* gb2, float* ggate, sc_stream_t st) {
+template <int CI, int CH, int CO, int NW>
+static void launch_pmlp_bwd(PmlpBwdArgs g, float* ws, bool gate, int act, float* gw1, float* gb1, float* gw2, float* gb2,
+                            float* ggate, sc_stream_t st) {
   typedef PmlpDims<CI, CH, CO> D;
-  float* tab = ws;
-  g.tab = tab;
-  g.partial = ws + D::nTab;
-  SC_LAUNCH((k_pmlp_prep<CI, CH, CO>), dim3(64), dim3(256), 0, st, w1, w2, tab);
-  const dim3 grid((unsigned)g.n_wg), block(256);
-  if (gate && act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 1>), grid, block, 0, st, g);
-  else if (gate) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 0>), grid, block, 0, st, g);
-  else if (act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, false, 1>), grid, block, 0, st, g);
-  else SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, false, 0>), grid, block, 0, st, g);
-  SC_LAUNCH(k_pmlp_reduce, dim3((unsigned)((D::NP + 255) / 256)), dim3(256), 0, st, (const float*)g.partial, g.n_wg, (int)D::NP,
-            (int)D::oW1, (int)D::oB1, (int)D::oB2, (int)D::oG, gw2, gw1, gb1, gb2, gate ? ggate : (float*)nullptr);
+  g.partial = ws;
+  float* stage = ws + (size_t)g.n_wg * D::NP;
+  const dim3 grid((unsigned)g.n_wg), block(64 * NW);
+  if (gate && act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 1, NW>), grid, block, 0, st, g);
+  else if (gate) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 0, NW>), grid, block, 0, st, g);
+  else if (act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, false, 1, NW>), grid, block, 0, st, g);
+  else SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, false, 0, NW>), grid, block, 0, st, g);
+  const unsigned nb = (unsigned)((D::NP + 255) / 256);
+  const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
+  SC_LAUNCH(k_pmlp_reduce1, dim3(nb, (unsigned)groups), dim3(256), 0, st, (const float*)g.partial, g.n_wg, groups, (int)D::NP,
+            stage);
+  SC_LAUNCH(k_pmlp_reduce, dim3(nb), dim3(256), 0, st, (const float*)stage, groups, (int)D::NP, (int)D::oW1, (int)D::oB1,
+            (int)D::oB2, (int)D::oG, gw2, gw1, gb1, gb2, gate ? ggate : (float*)nullptr);
 }
 
 extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1,
@@ -1604,7 +1609,7 @@ extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, 
   SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
   PmlpBwdArgs g;
   g.x = x; g.b1 = b1; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.gout = gout; g.gx = gx; g.gskip = gskip_src;
-  g.tab = nullptr; g.partial = nullptr;
+  g.w1 = w1; g.w2 = w2; g.partial = nullptr;
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
@@ -1613,13 +1618,13 @@ extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, 
   float* ws = (float*)workspace;
   const bool gt = gate != nullptr;
   switch (pmlp_shape_id(d)) {
-    case 111: launch_pmlp_bwd<1, 1, 1>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
-    case 212: launch_pmlp_bwd<2, 1, 2>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
-    case 222: launch_pmlp_bwd<2, 2, 2>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
-    case 424: launch_pmlp_bwd<4, 2, 4>(g, w1, w2, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 111: launch_pmlp_bwd<1, 1, 1, 8>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 212: launch_pmlp_bwd<2, 1, 2, 8>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 222: launch_pmlp_bwd<2, 2, 2, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
     default:
-      return sc_fail("sc_engine: pointwise MLP: channel counts (c_in, c_hid, c_out) must be one of (32,32,32), "
-                     "(64,32,64), (64,64,64), (128,64,128)");
+      return sc_fail("sc_engine: pointwise MLP backward: channel counts (c_in, c_hid, c_out) must be one of (32,32,32), "
+                     "(64,32,64), (64,64,64); (128,64,128) has the forward pass only (operand tables + gradient image "
+                     "exceed a CU's LDS)");
   }
   return sc_check_launch("k_pmlp_bwd");
 }

@@ -160,31 +160,6 @@ struct PmlpDims {
                        NP = oG + C_OUT;
 };
 
-template <int CI, int CH, int CO>
-SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
-k_pmlp_prep(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ tab) {
-  typedef PmlpDims<CI, CH, CO> D;
-  const int stride = 256 * 64;
-  for (int i = SC_BID_X * 256 + SC_TID; i < D::nTab; i += stride) {
-    const int l = i & 63, m = l & 31, kk = l >> 5;
-    float val;
-    if (i < D::oA2) {
-      const int j = (i - D::oA1) >> 6, s = j % D::S1, hm = j / D::S1;
-      val = w1[(32 * hm + m) * D::C_IN + 2 * s + kk];
-    } else if (i < D::oA3) {
-      const int j = (i - D::oA2) >> 6, v = j & 15, hm = (j >> 4) % CH, om = (j >> 4) / CH;
-      val = w2[(32 * om + m) * D::C_HID + 32 * hm + pmlp_row(v, kk)];
-    } else if (i < D::oA4) {
-      const int j = (i - D::oA3) >> 6, v = j & 15, om = (j >> 4) % CO, hm = (j >> 4) / CO;
-      val = w2[(32 * om + pmlp_row(v, kk)) * D::C_HID + 32 * hm + m];
-    } else {
-      const int j = (i - D::oA4) >> 6, v = j & 15, hm = (j >> 4) % CH, ci = (j >> 4) / CH;
-      val = w1[(32 * hm + pmlp_row(v, kk)) * D::C_IN + 32 * ci + m];
-    }
-    tab[i] = val;
-  }
-}
-
 struct PmlpBwdArgs {
   const float* x;
   const float* b1;
@@ -192,7 +167,8 @@ struct PmlpBwdArgs {
   const float* skip;
   const float* gate;
   const float* gout;
-  const float* tab;        // A operands (k_pmlp_prep)
+  const float* w1;
+  const float* w2;
   float* gx;
   float* gskip;
   float* partial;          // [n_wg][NP]
@@ -200,22 +176,45 @@ struct PmlpBwdArgs {
   int tiles_per_sample, n_wg;
 };
 
-template <int CI, int CH, int CO, bool GATE, int ACT>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+template <int CI, int CH, int CO, bool GATE, int ACT, int NW>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(64 * NW, 1)
 k_pmlp_bwd(PmlpBwdArgs g) {
   typedef PmlpDims<CI, CH, CO> D;
-  constexpr int S1 = D::S1, TS = 32 * 33;
-  SC_SHARED float scr[4 * (1 + CH) * TS];                 // per wave: T_A and one T_B per hidden tile (h)
+  constexpr int S1 = D::S1, TS = 32 * 33, NT = 64 * NW;
+  static_assert((D::nTab + NW * (1 + CH) * TS + D::NP + D::C_HID + 2 * D::C_OUT) * 4 <= 160 * 1024, "LDS budget");
+  // one workgroup of NW (8, or 4 for the larger tables) waves per CU: the four operand tables (W1, W2, W2^T, W1^T in MFMA lane order) live in LDS once
+  // for all of them (read from the workspace they cost an L2 round trip per group of MFMAs: 1.7 ms per launch at the
+  // metric shape, profiles/r02_block_kernel_stats_v1.txt)
+  SC_SHARED float tabs[D::nTab];
+  SC_SHARED float scr[NW * (1 + CH) * TS];                // per wave: T_A and one T_B per hidden tile (h)
   SC_SHARED float red[D::NP];
   SC_SHARED float B1[D::C_HID], B2[D::C_OUT], GT[D::C_OUT];
   const int tid = SC_TID, lane = tid & 63, n = lane & 31, half = lane >> 5;
   const int w = SC_UNIFORM(tid >> 6);
   float* TA = scr + w * (1 + CH) * TS;
   float* TH = TA + TS;                                    // h tiles, transposed: TH[hm][row][px]
-  const float* A1 = g.tab + D::oA1;
-  const float* A2 = g.tab + D::oA2;
-  const float* A3 = g.tab + D::oA3;
-  const float* A4 = g.tab + D::oA4;
+  const float* A1 = tabs + D::oA1;
+  const float* A2 = tabs + D::oA2;
+  const float* A3 = tabs + D::oA3;
+  const float* A4 = tabs + D::oA4;
+  for (int i = tid; i < D::nTab; i += NT) {
+    const int l = i & 63, m = l & 31, kk = l >> 5;
+    float val;
+    if (i < D::oA2) {
+      const int j = (i - D::oA1) >> 6, s = j % D::S1, hm = j / D::S1;
+      val = g.w1[(32 * hm + m) * D::C_IN + 2 * s + kk];
+    } else if (i < D::oA3) {
+      const int j = (i - D::oA2) >> 6, v = j & 15, hm = (j >> 4) % CH, om = (j >> 4) / CH;
+      val = g.w2[(32 * om + m) * D::C_HID + 32 * hm + pmlp_row(v, kk)];
+    } else if (i < D::oA4) {
+      const int j = (i - D::oA3) >> 6, v = j & 15, om = (j >> 4) % CO, hm = (j >> 4) / CO;
+      val = g.w2[(32 * om + pmlp_row(v, kk)) * D::C_HID + 32 * hm + m];
+    } else {
+      const int j = (i - D::oA4) >> 6, v = j & 15, hm = (j >> 4) % CH, ci = (j >> 4) / CH;
+      val = g.w1[(32 * hm + pmlp_row(v, kk)) * D::C_IN + 32 * ci + m];
+    }
+    tabs[i] = val;
+  }
   const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
   const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
   float sB2[CO], sG[CO], sB1[CH];                          // row sums (bias / gate gradients): half a row per lane
@@ -223,15 +222,15 @@ k_pmlp_bwd(PmlpBwdArgs g) {
   for (int om = 0; om < CO; ++om) sB2[om] = sG[om] = 0.f;
 #pragma unroll
   for (int hm = 0; hm < CH; ++hm) sB1[hm] = 0.f;
-  for (int i = tid; i < D::NP; i += 256) red[i] = 0.f;
-  for (int i = tid; i < D::C_HID; i += 256) B1[i] = g.b1 ? g.b1[i] : 0.f;
-  for (int i = tid; i < D::C_OUT; i += 256) {
+  for (int i = tid; i < D::NP; i += NT) red[i] = 0.f;
+  for (int i = tid; i < D::C_HID; i += NT) B1[i] = g.b1 ? g.b1[i] : 0.f;
+  for (int i = tid; i < D::C_OUT; i += NT) {
     B2[i] = g.b2 ? g.b2[i] : 0.f;
     GT[i] = GATE ? g.gate[i] : 0.f;
   }
   SC_SYNC();
 #pragma unroll 1
-  for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
+  for (int64_t tile = (int64_t)SC_BID_X * NW + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * NW) {
     const int64_t b = tile / g.tiles_per_sample;
     const int64_t px0 = (tile - b * g.tiles_per_sample) * 32;
     const int64_t sp = sc_opaque_s((int)g.spatial);        // row offsets k * sp: computed at their use, not hoisted
@@ -419,10 +418,20 @@ k_pmlp_bwd(PmlpBwdArgs g) {
   for (int hm = 0; hm < CH; ++hm) SC_LDS_ADD(&red[D::oB1 + 32 * hm + n], sB1[hm]);
   SC_SYNC();
   float* dst = g.partial + (int64_t)SC_BID_X * D::NP;
-  for (int i = tid; i < D::NP; i += 256) dst[i] = red[i];
+  for (int i = tid; i < D::NP; i += NT) dst[i] = red[i];
 }
 
-// sums[i] = sum_wg partial[wg][i] (wg ascending), scattered to the five gradient tensors (null = not wanted)
+// stage 1: out[y][i] = sum_{k = y, y + groups, ...} in[k][i]   (grid: ceil(np / 256) x groups)
+SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+k_pmlp_reduce1(const float* __restrict__ in, int n_in, int groups, int np, float* __restrict__ out) {
+  const int i = SC_BID_X * 256 + SC_TID, y = SC_BID_Y;
+  if (i >= np) return;
+  float s = 0.f;
+  for (int k = y; k < n_in; k += groups) s += in[(int64_t)k * np + i];
+  out[(int64_t)y * np + i] = s;
+}
+
+// stage 2: sums[i] = sum_y in[y][i] (y ascending), scattered to the five gradient tensors (null = not wanted)
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_pmlp_reduce(const float* __restrict__ partial, int n_wg, int np, int o_w1, int o_b1, int o_b2, int o_g,
               float* __restrict__ gw2, float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gb2,

@@ -735,6 +735,7 @@ def test_fourier_layer_fused_epilogue(spatial, modes):
 
 @pytest.mark.parametrize("chans", [(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)], ids=str)
 def test_pointwise_mlp_pass(chans):
+    # (128, 64, 128) has the forward kernel only: with gradients it takes the composition, checked like the others
     """sc_pointwise_mlp_forward / _backward (ChannelMLP + soft-gating skip + closing GELU in one
     pass) through neuraloperator_amd.blocks.fused_channel_mlp against torch autograd of the float64 composition."""
     import torch.nn.functional as F
@@ -751,6 +752,9 @@ def test_pointwise_mlp_pass(chans):
     ref = F.gelu(F.conv1d(h, w2d, b2d).reshape(3, co, 24, 40) + gtd * skd)
     ref.backward(go.double())
     dl = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2, sk, gt)]
+    with torch.no_grad():                                      # inference: every shape has the forward kernel
+        out_ng = fused_channel_mlp(dl[0], dl[1], dl[2], dl[3], dl[4], skip_src=dl[5], gate=dl[6], activation="gelu")
+    assert rel_l2(out_ng.cpu().numpy(), ref.detach().numpy()) < TOL
     out = fused_channel_mlp(dl[0], dl[1], dl[2], dl[3], dl[4], skip_src=dl[5], gate=dl[6], activation="gelu")
     out.backward(go.to(dev))
     assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
