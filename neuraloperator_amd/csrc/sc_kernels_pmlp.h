@@ -22,6 +22,30 @@
 #include "sc_kernels_mfma.h"
 #include "sc_kernels_fft3.h"      // sc_gelu
 
+// measurement builds only (scripts/pmlp_ablate.py): take one resource out of the backward pass to see what it costs
+#ifdef SC_PMLP_ABL_NOMFMA
+#define PMLP_MFMA(acc, a, b) ((acc)[0] = fmaf((a), (b), (acc)[0]))
+#else
+#define PMLP_MFMA(acc, a, b) sc_mfma_32x32x2((acc), (a), (b))
+#endif
+#ifdef SC_PMLP_ABL_NOATOMIC
+#define PMLP_LDS_ADD(ptr, val) do { if ((val) == 12345.678f) *(ptr) = (val); } while (0)
+#else
+#define PMLP_LDS_ADD(ptr, val) SC_LDS_ADD((ptr), (val))
+#endif
+#ifdef SC_PMLP_ABL_NOGELU
+#define PMLP_GELU(x) ((x) * 0.5f)
+#define PMLP_GELU_GRAD(x) ((x) * 0.25f + 0.5f)
+#else
+#define PMLP_GELU(x) sc_gelu(x)
+#define PMLP_GELU_GRAD(x) sc_gelu_grad(x)
+#endif
+#ifdef SC_PMLP_ABL_NOSTORE
+#define PMLP_STORE(ptr, val) do { if ((val) == 12345.678f) SC_STORE_STREAM((ptr), (val)); } while (0)
+#else
+#define PMLP_STORE(ptr, val) SC_STORE_STREAM((ptr), (val))
+#endif
+
 // accumulator register v of a lane in half `half` holds this row of the 32 x 32 tile
 SC_HD int pmlp_row(const int v, const int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
 
@@ -242,12 +266,21 @@ k_pmlp_bwd(PmlpBwdArgs g) {
     // ---- A: recompute h_pre and h; h also goes to LDS transposed (operand of the W2 gradient)
     // (the operand tables are loop invariant: without an opaque lane offset per phase the compiler hoists all ~130
     // table loads out of the tile loop and the kernel lives in scratch)
-    float hp[CH][16], h[CH][16];
+    float hp[CH][16], h[CH][16], gzn[16], skn[16];
     {
       const int ln1 = sc_opaque(lane), hq1 = sc_opaque(half);
       float xr[CI * 16];
 #pragma unroll
       for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+      // software pipeline over the tile: the gout / skip rows of output tile om + 1 are requested before tile om is
+      // worked on (tile 0 here, next to x), the x rows of phase E before phase D -- one exposed memory latency per
+      // pixel tile instead of one per phase
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t ro = (int64_t)pmlp_row(v, 0) * sp + lo_c;
+        gzn[v] = SC_LOAD_STREAM(gs + ro);
+        skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+      }
       SC_SCHED_BARRIER();
 #pragma unroll
       for (int hm = 0; hm < CH; ++hm) {
@@ -257,13 +290,13 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
         for (int s0 = 0; s0 < S1; s0 += 8) {
 #pragma unroll
-          for (int s = s0; s < s0 + 8; ++s) sc_mfma_32x32x2(acc, A1[(hm * S1 + s) * 64 + ln1], xr[s]);
+          for (int s = s0; s < s0 + 8; ++s) PMLP_MFMA(acc, A1[(hm * S1 + s) * 64 + ln1], xr[s]);
           SC_SCHED_BARRIER();
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           hp[hm][v] = acc[v] + B1[32 * hm + pmlp_row(v, hq1)];
-          h[hm][v] = sc_gelu(hp[hm][v]);
+          h[hm][v] = PMLP_GELU(hp[hm][v]);
           TH[hm * TS + pmlp_row(v, half) * 33 + n] = h[hm][v];
         }
         SC_SCHED_BARRIER();
@@ -281,10 +314,18 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       float gz[16], sk[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
-        gz[v] = SC_LOAD_STREAM(gs + ro);
-        sk[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+        gz[v] = gzn[v];
+        sk[v] = skn[v];
       }
+      if (om + 1 < CO) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int64_t ro = (int64_t)(32 * (om + 1) + pmlp_row(v, 0)) * sp + lo_c;
+          gzn[v] = SC_LOAD_STREAM(gs + ro);
+          skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+        }
+      }
+      SC_SCHED_BARRIER();
       if (ACT == 1) {
         sc_f32x16 acc;
 #pragma unroll
@@ -294,7 +335,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
           for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
-            for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, A2[((om * CH + hm) * 16 + v) * 64 + ln2], h[hm][v]);
+            for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(acc, A2[((om * CH + hm) * 16 + v) * 64 + ln2], h[hm][v]);
             SC_SCHED_BARRIER();
           }
 #pragma unroll
@@ -302,14 +343,14 @@ k_pmlp_bwd(PmlpBwdArgs g) {
           const int r = 32 * om + pmlp_row(v, hq2);
           float z = acc[v] + B2[r];
           if (GATE) z = fmaf(GT[r], sk[v], z);
-          gz[v] *= sc_gelu_grad(z);
+          gz[v] *= PMLP_GELU_GRAD(z);
         }
       }
       if (GATE) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const int r = 32 * om + pmlp_row(v, hq2);
-          SC_STORE_STREAM(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[r] * gz[v]);
+          PMLP_STORE(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[r] * gz[v]);
           TA[pmlp_row(v, half) * 33 + n] = gz[v] * sk[v];
         }
         SC_WAVE_SYNC();
@@ -332,18 +373,18 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
           for (int t = t0; t < t0 + 8; ++t) {
             const float a = TA[n * 33 + 2 * t + half];
-            sc_mfma_32x32x2(dw, a, TH[hm * TS + n * 33 + 2 * t + half]);
+            PMLP_MFMA(dw, a, TH[hm * TS + n * 33 + 2 * t + half]);
             if (hm == 0) sB2[om] += a;
           }
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) SC_LDS_ADD(&red[D::oW2 + (32 * om + pmlp_row(v, half)) * D::C_HID + 32 * hm + n], dw[v]);
+        for (int v = 0; v < 16; ++v) PMLP_LDS_ADD(&red[D::oW2 + (32 * om + pmlp_row(v, half)) * D::C_HID + 32 * hm + n], dw[v]);
         SC_SCHED_BARRIER();
 #pragma unroll
         for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
-          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(gh[hm], A3[((hm * CO + om) * 16 + v) * 64 + ln2], gz[v]);
+          for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(gh[hm], A3[((hm * CO + om) * 16 + v) * 64 + ln2], gz[v]);
           SC_SCHED_BARRIER();
         }
       }
@@ -354,7 +395,14 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
     for (int hm = 0; hm < CH; ++hm)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) ghp[hm][v] = gh[hm][v] * sc_gelu_grad(hp[hm][v]);
+      for (int v = 0; v < 16; ++v) ghp[hm][v] = gh[hm][v] * PMLP_GELU_GRAD(hp[hm][v]);
+    SC_SCHED_BARRIER();
+    float xe[16];
+    {
+      const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);     // a second read of x (L2), not phase A's values kept alive
+#pragma unroll
+      for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(2 * t) * sp + lo_e];
+    }
     SC_SCHED_BARRIER();
     // ---- D: gx = W1^T ghp
 #pragma unroll
@@ -368,11 +416,11 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
         for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
-          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, A4[((ci * CH + hm) * 16 + v) * 64 + ln4], ghp[hm][v]);
+          for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(acc, A4[((ci * CH + hm) * 16 + v) * 64 + ln4], ghp[hm][v]);
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) SC_STORE_STREAM(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
+      for (int v = 0; v < 16; ++v) PMLP_STORE(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
       SC_SCHED_BARRIER();
     }
     // ---- E: gW1 += ghp x^T over the pixels: ghp transposed in T_A, the x tile (re-read: L2 resident) in the first
@@ -383,10 +431,15 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       for (int v = 0; v < 16; ++v) TA[pmlp_row(v, half) * 33 + n] = ghp[hm][v];
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
-        const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);   // a second read of x, not phase A's values kept alive
         SC_WAVE_SYNC();                                    // readers of the previous X tile (and of h, first round)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) TH[(2 * t + half) * 33 + n] = xs[(int64_t)(32 * ci + 2 * t) * sp + lo_e];
+        for (int t = 0; t < 16; ++t) TH[(2 * t + half) * 33 + n] = xe[t];
+        if (ci + 1 < CI || hm + 1 < CH) {                  // next x rows while this tile's products run
+          const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);
+          const int cn = (ci + 1 < CI) ? ci + 1 : 0;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(32 * cn + 2 * t) * sp + lo_e];
+        }
         SC_WAVE_SYNC();
         sc_f32x16 dw;
 #pragma unroll
@@ -396,13 +449,13 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
           for (int t = t0; t < t0 + 8; ++t) {
             const float a = TA[n * 33 + 2 * t + half];
-            sc_mfma_32x32x2(dw, a, TH[n * 33 + 2 * t + half]);
+            PMLP_MFMA(dw, a, TH[n * 33 + 2 * t + half]);
             if (ci == 0) sB1[hm] += a;
           }
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) SC_LDS_ADD(&red[D::oW1 + (32 * hm + pmlp_row(v, half)) * D::C_IN + 32 * ci + n], dw[v]);
+        for (int v = 0; v < 16; ++v) PMLP_LDS_ADD(&red[D::oW1 + (32 * hm + pmlp_row(v, half)) * D::C_IN + 32 * ci + n], dw[v]);
         SC_SCHED_BARRIER();
       }
       SC_WAVE_SYNC();
