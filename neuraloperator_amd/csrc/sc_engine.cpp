@@ -1549,8 +1549,8 @@ extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, c
 }
 
 #define SC_PMLP_RED_GROUPS 16
-// waves per workgroup of the backward kernel: 8 while the operand tables + scratch fit LDS, 4 for 64 hidden channels
-static int pmlp_bwd_waves(const sc_pmlp_desc* d) { return d->c_hid > 32 ? 4 : 8; }
+// waves per workgroup of the backward kernel: one per SIMD (its register file holds the weight-gradient accumulators)
+static int pmlp_bwd_waves(const sc_pmlp_desc*) { return 4; }
 static int pmlp_bwd_wgs(const sc_pmlp_desc* d) {
   const int nw = pmlp_bwd_waves(d);
   const int64_t wgs = (d->batch * (d->spatial / 32) + nw - 1) / nw;
@@ -1618,8 +1618,8 @@ extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, 
   float* ws = (float*)workspace;
   const bool gt = gate != nullptr;
   switch (pmlp_shape_id(d)) {
-    case 111: launch_pmlp_bwd<1, 1, 1, 8>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
-    case 212: launch_pmlp_bwd<2, 1, 2, 8>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 111: launch_pmlp_bwd<1, 1, 1, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 212: launch_pmlp_bwd<2, 1, 2, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
     case 222: launch_pmlp_bwd<2, 2, 2, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
     default:
       return sc_fail("sc_engine: pointwise MLP backward: channel counts (c_in, c_hid, c_out) must be one of (32,32,32), "

@@ -169,10 +169,9 @@ k_pmlp_fwd(PmlpArgs g) {
 //   gW2 += gz h^T,  gW1 += ghp x^T                 contraction over the 32 pixels of the tile: the operands are transposed
 //                                                  through a per-wave LDS scratch (32 x 33 floats each)
 // A operands (W1, W2, W2^T, W1^T in MFMA lane order, the latter three in the accumulator row order) are prepared once
-// by k_pmlp_prep in the workspace and read with one coalesced 256-byte load per MFMA (L1 / L2 resident); the weight
-// gradients of a tile (one fresh 32 x 32 accumulator per weight tile) are added into ONE LDS image per workgroup
-// (ds_add_f32 -- register-resident accumulators over the whole tile loop cost 64+ registers and sent the kernel to
-// scratch), written as one partial per workgroup; k_pmlp_reduce adds the partials in a fixed order.
+// live in LDS; the weight gradients accumulate in MFMA accumulators over all tiles of a wave, are summed over the waves
+// of the workgroup in LDS (fixed order) and leave as ONE partial per workgroup; two reduction stages add the partials
+// in a fixed order (bit-reproducible).
 // ------------------------------------------------------------------------------------------
 template <int CI, int CH, int CO>
 struct PmlpDims {
@@ -241,6 +240,22 @@ k_pmlp_bwd(PmlpBwdArgs g) {
   }
   const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
   const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+  // weight-gradient tiles: MFMA accumulators that live across the whole tile loop (one wave per SIMD: the register file
+  // has room; adding every tile's contribution into a shared LDS image with ds_add_f32 cost 0.85 of 1.8 ms,
+  // profiles/r02_pmlp_ablation.txt)
+  sc_f32x16 aW2[CO][CH], aW1[CH][CI];
+#pragma unroll
+  for (int om = 0; om < CO; ++om)
+#pragma unroll
+    for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) aW2[om][hm][v] = 0.f;
+#pragma unroll
+  for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) aW1[hm][ci][v] = 0.f;
   float sB2[CO], sG[CO], sB1[CH];                          // row sums (bias / gate gradients): half a row per lane
 #pragma unroll
   for (int om = 0; om < CO; ++om) sB2[om] = sG[om] = 0.f;
@@ -365,22 +380,16 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       SC_WAVE_SYNC();
 #pragma unroll
       for (int hm = 0; hm < CH; ++hm) {
-        sc_f32x16 dw;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) dw[v] = 0.f;
 #pragma unroll
         for (int t0 = 0; t0 < 16; t0 += 8) {
 #pragma unroll
           for (int t = t0; t < t0 + 8; ++t) {
             const float a = TA[n * 33 + 2 * t + half];
-            PMLP_MFMA(dw, a, TH[hm * TS + n * 33 + 2 * t + half]);
+            PMLP_MFMA(aW2[om][hm], a, TH[hm * TS + n * 33 + 2 * t + half]);
             if (hm == 0) sB2[om] += a;
           }
           SC_SCHED_BARRIER();
         }
-#pragma unroll
-        for (int v = 0; v < 16; ++v) PMLP_LDS_ADD(&red[D::oW2 + (32 * om + pmlp_row(v, half)) * D::C_HID + 32 * hm + n], dw[v]);
-        SC_SCHED_BARRIER();
 #pragma unroll
         for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
@@ -441,35 +450,53 @@ k_pmlp_bwd(PmlpBwdArgs g) {
           for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(32 * cn + 2 * t) * sp + lo_e];
         }
         SC_WAVE_SYNC();
-        sc_f32x16 dw;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) dw[v] = 0.f;
 #pragma unroll
         for (int t0 = 0; t0 < 16; t0 += 8) {
 #pragma unroll
           for (int t = t0; t < t0 + 8; ++t) {
             const float a = TA[n * 33 + 2 * t + half];
-            PMLP_MFMA(dw, a, TH[n * 33 + 2 * t + half]);
+            PMLP_MFMA(aW1[hm][ci], a, TH[n * 33 + 2 * t + half]);
             if (ci == 0) sB1[hm] += a;
           }
           SC_SCHED_BARRIER();
         }
-#pragma unroll
-        for (int v = 0; v < 16; ++v) PMLP_LDS_ADD(&red[D::oW1 + (32 * hm + pmlp_row(v, half)) * D::C_IN + 32 * ci + n], dw[v]);
-        SC_SCHED_BARRIER();
       }
       SC_WAVE_SYNC();
     }
   }
-  // ---- row sums: the two halves of a row live in lanes n and n + 32
+  // ---- one partial per workgroup: the waves add their sums into the LDS image one after the other (fixed order);
+  //      the two halves of a row sum live in lanes n and n + 32
+  for (int turn = 0; turn < NW; ++turn) {
+    if (w == turn) {
 #pragma unroll
-  for (int om = 0; om < CO; ++om) {
-    SC_LDS_ADD(&red[D::oB2 + 32 * om + n], sB2[om]);
-    SC_LDS_ADD(&red[D::oG + 32 * om + n], sG[om]);
+      for (int om = 0; om < CO; ++om)
+#pragma unroll
+        for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            red[D::oW2 + (32 * om + pmlp_row(v, half)) * D::C_HID + 32 * hm + n] += aW2[om][hm][v];
+#pragma unroll
+      for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            red[D::oW1 + (32 * hm + pmlp_row(v, half)) * D::C_IN + 32 * ci + n] += aW1[hm][ci][v];
+      for (int hh = 0; hh < 2; ++hh) {
+        if (half == hh) {
+#pragma unroll
+          for (int om = 0; om < CO; ++om) {
+            red[D::oB2 + 32 * om + n] += sB2[om];
+            red[D::oG + 32 * om + n] += sG[om];
+          }
+#pragma unroll
+          for (int hm = 0; hm < CH; ++hm) red[D::oB1 + 32 * hm + n] += sB1[hm];
+        }
+        SC_WAVE_SYNC();
+      }
+    }
+    SC_SYNC();
   }
-#pragma unroll
-  for (int hm = 0; hm < CH; ++hm) SC_LDS_ADD(&red[D::oB1 + 32 * hm + n], sB1[hm]);
-  SC_SYNC();
   float* dst = g.partial + (int64_t)SC_BID_X * D::NP;
   for (int i = tid; i < D::NP; i += NT) dst[i] = red[i];
 }
