@@ -203,6 +203,20 @@ int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float
                               float* gw1, float* gb1, float* gw2, float* gb2, float* gskip_src, float* ggate,
                               void* workspace, void* stream);
 
+/* 1 x 1 linear map over the channels in one pass each way: out = W x (+ bias) -- the block's linear skip
+ * (neuralop/layers/skip_connections.py:119-169: Flattened1dConv = Conv1d with kernel size 1 on the flattened grid).
+ * x (batch, c_in, spatial), out (batch, c_out, spatial), w (c_out, c_in) row-major, bias (c_out) or null.
+ * c_in = c_out in {32, 64, 128} forward, {32, 64} backward; spatial a multiple of 32.  Backward: gx, gw (and gbias
+ * when not null) are overwritten; workspace sc_pointwise_linear_workspace_bytes(d) bytes. */
+typedef struct sc_plin_desc {
+  int64_t batch, c_in, c_out, spatial;
+} sc_plin_desc;
+int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x, const float* w, const float* bias, float* out,
+                                void* stream);
+size_t sc_pointwise_linear_workspace_bytes(const sc_plin_desc* d);
+int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* x, const float* w, const float* gout, float* gx,
+                                 float* gw, float* gbias, void* workspace, void* stream);
+
 /* ---- fused AdamW step of the spectral weights ("next" row f2 of SURVEY.md section 8) -----------------
  * One pass over (param, grad, exp_avg, exp_avg_sq) instead of the ~10 elementwise launches of
  * neuralop/training/adamw.py:155-200 (non-GaLore branch), same arithmetic in the same order:

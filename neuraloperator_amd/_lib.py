@@ -73,6 +73,10 @@ class Epilogue(Structure):
 SC_ACT_NONE, SC_ACT_GELU = 0, 1
 
 
+class PlinDesc(Structure):
+    _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("spatial", c_int64)]
+
+
 class PmlpDesc(Structure):
     _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_hid", c_int64), ("c_out", c_int64), ("spatial", c_int64),
                 ("act", c_int32), ("reserved", c_int32)]
@@ -122,7 +126,8 @@ class ScEngineLib:
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
                "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
-               "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes"]
+               "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes", "sc_pointwise_linear_forward",
+               "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -181,6 +186,12 @@ class ScEngineLib:
         L.sc_pointwise_mlp_workspace_bytes.restype = c_size_t
         L.sc_pointwise_mlp_backward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 17
         L.sc_pointwise_mlp_backward.restype = c_int
+        L.sc_pointwise_linear_forward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 5
+        L.sc_pointwise_linear_forward.restype = c_int
+        L.sc_pointwise_linear_workspace_bytes.argtypes = [POINTER(PlinDesc)]
+        L.sc_pointwise_linear_workspace_bytes.restype = c_size_t
+        L.sc_pointwise_linear_backward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 8
+        L.sc_pointwise_linear_backward.restype = c_int
         L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.sc_round_f16.restype = c_int
         L.sc_last_error.restype = c_char_p
@@ -265,6 +276,18 @@ class ScEngineLib:
         d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
         self._check(self.lib.sc_pointwise_mlp_backward(byref(d), x, w1, b1, w2, b2, skip, gate, gout, gx, gw1, gb1, gw2,
                                                        gb2, gskip, ggate, ws, stream))
+
+    def pointwise_linear_forward(self, batch, c_in, c_out, spatial, x, w, bias, out, stream=0):
+        d = PlinDesc(batch, c_in, c_out, spatial)
+        self._check(self.lib.sc_pointwise_linear_forward(byref(d), x, w, bias, out, stream))
+
+    def pointwise_linear_workspace_bytes(self, batch, c_in, c_out, spatial):
+        d = PlinDesc(batch, c_in, c_out, spatial)
+        return int(self.lib.sc_pointwise_linear_workspace_bytes(byref(d)))
+
+    def pointwise_linear_backward(self, batch, c_in, c_out, spatial, x, w, gout, gx, gw, gbias, ws, stream=0):
+        d = PlinDesc(batch, c_in, c_out, spatial)
+        self._check(self.lib.sc_pointwise_linear_backward(byref(d), x, w, gout, gx, gw, gbias, ws, stream))
 
     def round_f16(self, in_ptr, out_ptr, n, stream=0):
         """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""

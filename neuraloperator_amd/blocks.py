@@ -1,14 +1,14 @@
 """The rest of an FNO block on the engine: what FNOBlocks.forward_with_postactivation
 (/root/reference/neuralop/layers/fno_block.py:377-414) does around the spectral convolution.
 
-    x_skip_fno = fno_skips[i](x)                      1 x 1 linear skip (skip_connections.py:119-169)
+    x_skip_fno = fno_skips[i](x)                      1 x 1 linear skip (skip_connections.py:119-169) -> fused_linear
     x          = gelu(convs[i](x) + x_skip_fno)       -> SpectralConv.forward_fused: add + GELU in the inverse
                                                          transform's store path (sc_layer_forward_ex)
     x          = channel_mlp[i](x) + gate * x_in      -> fused_channel_mlp: both 1 x 1 convolutions, the GELU between
     x          = gelu(x)            (not the last block)   them, the soft-gating skip and the closing GELU in ONE pass
                                                          over the tensor (sc_pointwise_mlp_forward / _backward)
 
-``fused_block_forward(blocks, x, index)`` runs exactly that on the parameters of an ``FNOBlocks``-shaped module (the
+``fused_block_forward(blocks, x, index)`` runs exactly that (three engine passes forward) on the parameters of an ``FNOBlocks``-shaped module (the
 verbatim reference class, built with ``conv_module=neuraloperator_amd.SpectralConv``): same result as
 ``blocks(x, index)``; configurations outside its scope (normalisation layers, pre-activation, tanh stabiliser, a
 resolution change, other skip types) take the module's own forward."""
@@ -69,6 +69,56 @@ class PointwiseMLPFn(torch.autograd.Function):
                 None if ggt is None else ggt.reshape(gate_shape), None)
 
 
+class PointwiseLinearFn(torch.autograd.Function):
+    """out = conv1x1(x, w, bias) (the block's linear skip, skip_connections.py:119-169) and its gradients, one pass
+    each way (k_plin_fwd / k_plin_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _require_gpu(x, "x")
+        shape = x.shape
+        b, ci, co = int(shape[0]), int(shape[1]), int(w.shape[0])
+        s = 1
+        for v in shape[2:]:
+            s *= int(v)
+        xc, wc = x.contiguous(), w.reshape(co, ci).contiguous()
+        bc = None if bias is None else bias.contiguous()
+        out = torch.empty((b, co, *shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.get_lib().pointwise_linear_forward(b, ci, co, s, xc.data_ptr(), wc.data_ptr(),
+                                                    0 if bc is None else bc.data_ptr(), out.data_ptr(), _stream())
+        ctx.save_for_backward(xc, wc)
+        ctx.cfg = (b, ci, co, s, tuple(w.shape), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, wc = ctx.saved_tensors
+        b, ci, co, s, w_shape, has_bias = ctx.cfg
+        lib = _lib.get_lib()
+        gout = gout.contiguous()
+        gx, gw = torch.empty_like(xc), torch.empty_like(wc)
+        gb = torch.empty(co, dtype=torch.float32, device=xc.device) if has_bias else None
+        ws = torch.empty(lib.pointwise_linear_workspace_bytes(b, ci, co, s), dtype=torch.uint8, device=xc.device)
+        with torch.cuda.device(xc.device):
+            lib.pointwise_linear_backward(b, ci, co, s, xc.data_ptr(), wc.data_ptr(), gout.data_ptr(), gx.data_ptr(),
+                                          gw.data_ptr(), 0 if gb is None else gb.data_ptr(), ws.data_ptr(), _stream())
+        return gx, gw.reshape(w_shape), gb
+
+
+def fused_linear(x, w, bias=None):
+    """1 x 1 convolution over the channels: the engine pass for 32 / 64 (with gradients) or 32 / 64 / 128 (inference)
+    equal input / output channels and a pixel count that is a multiple of 32, ``F.conv1d`` otherwise."""
+    ci, co = int(x.shape[1]), int(w.shape[0])
+    s = x[0, 0].numel()
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, bias))
+    ok = (32, 64) if needs_grad else (32, 64, 128)
+    if _on_engine(x) and x.dtype == torch.float32 and ci == co and ci in ok and s % 32 == 0:
+        return PointwiseLinearFn.apply(x, w, bias)
+    shape = x.shape
+    return F.conv1d(x.reshape(shape[0], ci, -1), w.reshape(co, ci, 1), bias).reshape(shape[0], co, *shape[2:])
+
+
 _SHAPES = {(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)}
 _SHAPES_BWD = {(32, 32, 32), (64, 32, 64), (64, 64, 64)}      # (128, 64, 128): forward kernel only
 
@@ -127,7 +177,8 @@ def fused_block_forward(blocks, x, index=0, output_shape=None):
     if not _block_in_scope(blocks, index, output_shape):
         return blocks(x, index, output_shape=output_shape)
     last = index >= blocks.n_layers - 1
-    x_skip_fno = blocks.fno_skips[index](x)                                   # 1 x 1 convolution, no bias by default
+    lin = blocks.fno_skips[index].conv                                        # 1 x 1 convolution, no bias by default
+    x_skip_fno = fused_linear(x, lin.weight, lin.bias)
     conv = blocks.convs[index]
     y = conv.forward_fused(x, x_skip_fno, activation=None if last else "gelu")
     fc1, fc2 = blocks.channel_mlp[index].fcs

@@ -1629,6 +1629,81 @@ extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, 
   return sc_check_launch("k_pmlp_bwd");
 }
 
+// ---- 1 x 1 linear map (the block's linear skip)
+static int plin_shape_id(const sc_plin_desc* d) {
+  if (d->c_in % 32 || d->c_out % 32) return 0;
+  return (int)(d->c_in / 32) * 10 + (int)(d->c_out / 32);
+}
+static int plin_bwd_wgs(const sc_plin_desc* d) {
+  const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
+  return (int)(wgs < 512 ? wgs : 512);
+}
+
+extern "C" int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x, const float* w, const float* bias,
+                                           float* out, void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  if (d->batch <= 0 || d->spatial <= 0) return 0;
+  SC_CHECK_ARG(x && w && out, "null argument");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  PlinArgs g;
+  g.x = x; g.w = w; g.bias = bias; g.gout = nullptr; g.out = out; g.partial = nullptr;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  const int64_t wgs = (g.n_tiles + 3) / 4;
+  g.n_wg = (int)(wgs < 2048 ? wgs : 2048);
+  sc_stream_t st = (sc_stream_t)stream;
+  const dim3 grid((unsigned)g.n_wg), block(256);
+  switch (plin_shape_id(d)) {
+    case 11: SC_LAUNCH((k_plin_fwd<1, 1>), grid, block, 0, st, g); break;
+    case 22: SC_LAUNCH((k_plin_fwd<2, 2>), grid, block, 0, st, g); break;
+    case 44: SC_LAUNCH((k_plin_fwd<4, 4>), grid, block, 0, st, g); break;
+    default: return sc_fail("sc_engine: pointwise linear map: c_in = c_out must be 32, 64 or 128");
+  }
+  return sc_check_launch("k_plin_fwd");
+}
+
+extern "C" size_t sc_pointwise_linear_workspace_bytes(const sc_plin_desc* d) {
+  if (!d || d->batch <= 0 || d->spatial <= 0) return 0;
+  const int id = plin_shape_id(d);
+  if (id != 11 && id != 22) return 0;
+  const size_t np = (size_t)d->c_out * d->c_in + d->c_out;
+  return (size_t)(plin_bwd_wgs(d) + SC_PMLP_RED_GROUPS) * np * sizeof(float) + 256;
+}
+
+template <int CI, int CO>
+static void launch_plin_bwd(PlinArgs g, float* ws, float* gw, float* gb, sc_stream_t st) {
+  constexpr int NPW = 32 * CO * 32 * CI, NP = NPW + 32 * CO;
+  g.partial = ws;
+  float* stage = ws + (size_t)g.n_wg * NP;
+  SC_LAUNCH((k_plin_bwd<CI, CO>), dim3((unsigned)g.n_wg), dim3(256), 0, st, g);
+  const unsigned nb = (unsigned)((NP + 255) / 256);
+  const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
+  SC_LAUNCH(k_pmlp_reduce1, dim3(nb, (unsigned)groups), dim3(256), 0, st, (const float*)g.partial, g.n_wg, groups, (int)NP, stage);
+  SC_LAUNCH(k_plin_reduce, dim3(nb), dim3(256), 0, st, (const float*)stage, groups, (int)NP, (int)NPW, gw, gb);
+}
+
+extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* x, const float* w, const float* gout,
+                                            float* gx, float* gw, float* gbias, void* workspace, void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise linear map backward: empty input");
+  SC_CHECK_ARG(x && w && gout && gx && gw && workspace, "null argument");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  PlinArgs g;
+  g.x = x; g.w = w; g.bias = nullptr; g.gout = gout; g.out = gx; g.partial = nullptr;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  g.n_wg = plin_bwd_wgs(d);
+  sc_stream_t st = (sc_stream_t)stream;
+  switch (plin_shape_id(d)) {
+    case 11: launch_plin_bwd<1, 1>(g, (float*)workspace, gw, gbias, st); break;
+    case 22: launch_plin_bwd<2, 2>(g, (float*)workspace, gw, gbias, st); break;
+    default: return sc_fail("sc_engine: pointwise linear map backward: c_in = c_out must be 32 or 64");
+  }
+  return sc_check_launch("k_plin_bwd");
+}
+
 extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream) {
   if (n <= 0) return 0;
   SC_CHECK_ARG(in && out, "null argument");

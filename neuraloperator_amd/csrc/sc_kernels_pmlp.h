@@ -526,3 +526,191 @@ k_pmlp_reduce(const float* __restrict__ partial, int n_wg, int np, int o_w1, int
   else if (i < o_g) { if (gb2) gb2[i - o_b2] = s; }
   else if (ggate) ggate[i - o_g] = s;
 }
+
+// ------------------------------------------------------------------------------------------
+// 1 x 1 linear map over the channels (the block's linear skip, skip_connections.py:119-169: Conv1d with kernel size 1
+// on the flattened grid): out = W x (+ b), one pass; backward gx = W^T g, gW = g x^T, gb = sum g, one pass.
+// Same tiles, operand layouts and reduction as the MLP pass above (GEMM 1 only / GEMM 4 + the weight-gradient
+// products only).
+// ------------------------------------------------------------------------------------------
+struct PlinArgs {
+  const float* x;          // (batch, 32 CI, spatial)
+  const float* w;          // (32 CO, 32 CI)
+  const float* bias;       // (32 CO) or null
+  const float* gout;       // backward: (batch, 32 CO, spatial)
+  float* out;              // forward: (batch, 32 CO, spatial); backward: gx (batch, 32 CI, spatial)
+  float* partial;          // backward: [n_wg][32 CO * 32 CI + 32 CO]
+  int64_t n_tiles, spatial;
+  int tiles_per_sample, n_wg;
+};
+
+template <int CI, int CO>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_plin_fwd(PlinArgs g) {
+  constexpr int C_IN = 32 * CI, C_OUT = 32 * CO, S1 = 16 * CI;
+  SC_SHARED float A[CO * S1 * 64];
+  SC_SHARED float Bv[C_OUT];
+  const int tid = SC_TID, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = SC_UNIFORM(tid >> 6);
+  for (int i = tid; i < CO * S1 * 64; i += 256) {
+    const int l = i & 63, s = (i >> 6) % S1, om = (i >> 6) / S1;
+    A[i] = g.w[(32 * om + (l & 31)) * C_IN + 2 * s + (l >> 5)];
+  }
+  for (int i = tid; i < C_OUT; i += 256) Bv[i] = g.bias ? g.bias[i] : 0.f;
+  SC_SYNC();
+  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
+  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
+#pragma unroll 1
+  for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
+    const int64_t b = tile / g.tiles_per_sample;
+    const int64_t px0 = (tile - b * g.tiles_per_sample) * 32;
+    const int64_t sp = sc_opaque_s((int)g.spatial);
+    const int hq = sc_opaque(half);
+    const float* xs = g.x + b * C_IN * sp + px0;
+    float* os = g.out + b * C_OUT * sp + px0;
+    float xr[CI * 16];
+#pragma unroll
+    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+    SC_SCHED_BARRIER();
+#pragma unroll
+    for (int om = 0; om < CO; ++om) {
+      sc_f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+      for (int s0 = 0; s0 < S1; s0 += 8) {
+#pragma unroll
+        for (int s = s0; s < s0 + 8; ++s) sc_mfma_32x32x2(acc, A[(om * S1 + s) * 64 + lane], xr[s]);
+        SC_SCHED_BARRIER();
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        SC_STORE_STREAM(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, acc[v] + Bv[32 * om + pmlp_row(v, hq)]);
+      SC_SCHED_BARRIER();
+    }
+  }
+}
+
+template <int CI, int CO>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_plin_bwd(PlinArgs g) {
+  constexpr int C_IN = 32 * CI, C_OUT = 32 * CO, TS = 32 * 33, NW = 4, NT = 256, NPW = C_OUT * C_IN, NP = NPW + C_OUT;
+  SC_SHARED float AT[CI * CO * 16 * 64];                  // W^T as the A operand, K in accumulator row order
+  SC_SHARED float scr[NW * 2 * TS];
+  SC_SHARED float red[NP];
+  const int tid = SC_TID, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = SC_UNIFORM(tid >> 6);
+  float* TA = scr + w * 2 * TS;
+  float* TB = TA + TS;
+  for (int i = tid; i < CI * CO * 16 * 64; i += NT) {
+    const int l = i & 63, v = (i >> 6) & 15, om = (i >> 10) % CO, ci = (i >> 10) / CO;
+    AT[i] = g.w[(32 * om + pmlp_row(v, l >> 5)) * C_IN + 32 * ci + (l & 31)];
+  }
+  for (int i = tid; i < NP; i += NT) red[i] = 0.f;
+  SC_SYNC();
+  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
+  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
+  sc_f32x16 aW[CO][CI];
+  float sB[CO];
+#pragma unroll
+  for (int om = 0; om < CO; ++om) {
+    sB[om] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) aW[om][ci][v] = 0.f;
+  }
+#pragma unroll 1
+  for (int64_t tile = (int64_t)SC_BID_X * NW + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * NW) {
+    const int64_t b = tile / g.tiles_per_sample;
+    const int64_t px0 = (tile - b * g.tiles_per_sample) * 32;
+    const int64_t sp = sc_opaque_s((int)g.spatial);
+    const int ln = sc_opaque(lane);
+    const float* xs = g.x + b * C_IN * sp + px0;
+    const float* gs = g.gout + b * C_OUT * sp + px0;
+    float* gxs = g.out + b * C_IN * sp + px0;
+    float gz[CO][16];
+#pragma unroll
+    for (int om = 0; om < CO; ++om)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+    SC_SCHED_BARRIER();
+    // gx = W^T g
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+      sc_f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+      for (int om = 0; om < CO; ++om)
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, AT[((ci * CO + om) * 16 + v) * 64 + ln], gz[om][v]);
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) SC_STORE_STREAM(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
+      SC_SCHED_BARRIER();
+    }
+    // gW += g x^T over the pixels of the tile (operands transposed through LDS), gb += row sums of g
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+      float xe[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(xs + (int64_t)(32 * ci + 2 * t) * sp + lo_b);
+      SC_WAVE_SYNC();
+#pragma unroll
+      for (int t = 0; t < 16; ++t) TB[(2 * t + half) * 33 + n] = xe[t];
+#pragma unroll
+      for (int om = 0; om < CO; ++om) {
+        SC_WAVE_SYNC();
+#pragma unroll
+        for (int v = 0; v < 16; ++v) TA[pmlp_row(v, half) * 33 + n] = gz[om][v];
+        SC_WAVE_SYNC();
+#pragma unroll
+        for (int t0 = 0; t0 < 16; t0 += 8) {
+#pragma unroll
+          for (int t = t0; t < t0 + 8; ++t) {
+            const float a = TA[n * 33 + 2 * t + half];
+            sc_mfma_32x32x2(aW[om][ci], a, TB[n * 33 + 2 * t + half]);
+            if (ci == 0) sB[om] += a;
+          }
+          SC_SCHED_BARRIER();
+        }
+      }
+    }
+    SC_WAVE_SYNC();
+  }
+  for (int turn = 0; turn < NW; ++turn) {
+    if (w == turn) {
+#pragma unroll
+      for (int om = 0; om < CO; ++om)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) red[(32 * om + pmlp_row(v, half)) * C_IN + 32 * ci + n] += aW[om][ci][v];
+      for (int hh = 0; hh < 2; ++hh) {
+        if (half == hh) {
+#pragma unroll
+          for (int om = 0; om < CO; ++om) red[NPW + 32 * om + n] += sB[om];
+        }
+        SC_WAVE_SYNC();
+      }
+    }
+    SC_SYNC();
+  }
+  float* dst = g.partial + (int64_t)SC_BID_X * NP;
+  for (int i = tid; i < NP; i += NT) dst[i] = red[i];
+}
+
+// stage 2 for the linear map: gw | gb
+SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+k_plin_reduce(const float* __restrict__ partial, int n, int np, int o_b, float* __restrict__ gw, float* __restrict__ gb) {
+  const int i = SC_BID_X * 256 + SC_TID;
+  if (i >= np) return;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += partial[(int64_t)k * np + i];
+  if (i < o_b) gw[i] = s;
+  else if (gb) gb[i - o_b] = s;
+}

@@ -103,3 +103,32 @@ def test_pointwise_mlp_backward(lib, chans, gate, act, bias):
         assert rel_l2(gb1.numpy(), b1d.grad.numpy()) < tol and rel_l2(gb2.numpy(), b2d.grad.numpy()) < tol
     if gate:
         assert rel_l2(gsk.numpy(), skd.grad.numpy()) < tol and rel_l2(ggt.numpy(), gtd.grad.numpy()) < tol
+
+
+@pytest.mark.parametrize("c", [32, 64, 128])
+@pytest.mark.parametrize("bias", [True, False])
+def test_pointwise_linear(lib, c, bias):
+    """The block's 1 x 1 linear skip in one pass each way against torch (float64)."""
+    g = torch.Generator().manual_seed(c + bias)
+    B, S = 2, 96
+    x, go = torch.randn(B, c, S, generator=g), torch.randn(B, c, S, generator=g)
+    w = torch.randn(c, c, generator=g) / c ** 0.5
+    b = torch.randn(c, generator=g) if bias else None
+    p = lambda t: 0 if t is None else t.data_ptr()
+    out = torch.full((B, c, S), float("nan"))
+    lib.pointwise_linear_forward(B, c, c, S, p(x), p(w), p(b), p(out), 0)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = None if b is None else b.double().requires_grad_(True)
+    ref = torch.einsum("oc,bcs->bos", wd, xd) + (0 if bd is None else bd[None, :, None])
+    assert rel_l2(out.numpy(), ref.detach().numpy()) < TOL
+    if c == 128:
+        assert lib.pointwise_linear_workspace_bytes(B, c, c, S) == 0        # forward only at 128 channels
+        return
+    ref.backward(go.double())
+    gx, gw = torch.full_like(x, float("nan")), torch.full_like(w, float("nan"))
+    gb = torch.full((c,), float("nan")) if bias else None
+    ws = torch.empty(lib.pointwise_linear_workspace_bytes(B, c, c, S), dtype=torch.uint8)
+    lib.pointwise_linear_backward(B, c, c, S, p(x), p(w), p(go), p(gx), p(gw), p(gb), p(ws), 0)
+    assert rel_l2(gx.numpy(), xd.grad.numpy()) < 1e-5 and rel_l2(gw.numpy(), wd.grad.numpy()) < 1e-5
+    if bias:
+        assert rel_l2(gb.numpy(), bd.grad.numpy()) < 1e-5

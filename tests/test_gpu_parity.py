@@ -792,3 +792,22 @@ def test_fused_block_forward_matches_op_sequence():
             a, b = gp1[n], gp0[n]
             a, b = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, n
+
+
+@pytest.mark.parametrize("c", [32, 64])
+def test_pointwise_linear_pass(c):
+    """The block's 1 x 1 linear skip (k_plin_fwd / k_plin_bwd) through blocks.fused_linear against torch float64."""
+    from neuraloperator_amd.blocks import fused_linear
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(c)
+    x, go = torch.randn(3, c, 24, 40, generator=g), torch.randn(3, c, 24, 40, generator=g)
+    w, b = torch.randn(c, c, 1, generator=g) / c ** 0.5, torch.randn(c, generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.conv1d(xd.reshape(3, c, -1), wd, bd).reshape(3, c, 24, 40)
+    ref.backward(go.double())
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    out = fused_linear(xg, wg, bg)
+    out.backward(go.to(dev))
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+    for a, r in ((xg, xd), (wg, wd), (bg, bd)):
+        assert rel_l2(a.grad.cpu().numpy(), r.grad.numpy()) < TOL
