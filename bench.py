@@ -12,6 +12,8 @@ mode dim; RCCL all-to-all each way, pipelined in chunks) on the same workload, s
 metric at every N; the line also carries `extra.dp_allreduce` (data-parallel replicas WITH the gradient
 all-reduce of the 69 MB dense weight, what mode sharding avoids) and `extra.fno3d_modeshard` (BASELINE
 configs[3]: 128^3, B=8 in total, strong scaling; its single-GPU number is `extra.fno3d_single` of the N=1 line).
+The N=1 line also carries `extra.fno_block`: one whole FNO block forward + backward at the metric
+shape, the reference's op sequence around the engine's convolution against the engine's fused passes.
 --parallel replicas | modeshard | pencil selects one explicitly.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
@@ -191,6 +193,78 @@ def stage_profile(B, C, spatial, n_modes, flags, iters, io="f32"):
     names = {"fwd": lib.plan_kernel_name(plan, 0), "inv": lib.plan_kernel_name(plan, 1),
              "fast": lib.plan_is_fast(plan)}
     return out, names
+
+
+def block_extra(B, C, spatial, n_modes, dev):
+    """one whole FNO block (fno_block.py:377-414, default configuration: linear skip, spectral
+    convolution, GELU, ChannelMLP with expansion 0.5, soft-gating skip, GELU) forward + backward at the metric shape --
+    the reference's op sequence with the engine's convolution inside (what a user of the conv_module plug-in runs)
+    against the engine's three fused passes (neuraloperator_amd.blocks.fused_block_forward)."""
+    import torch.nn.functional as F
+    from torch import nn
+    from neuraloperator_amd import SpectralConv, blocks as nb
+
+    class Skip(nn.Module):                                   # skip_connections.py:119-169
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv1d(C, C, 1, bias=False)
+
+        def forward(self, x):
+            return self.conv(x.reshape(x.shape[0], C, -1)).reshape(x.shape)
+    Skip.__name__ = "Flattened1dConv"
+
+    class Gate(nn.Module):                                   # skip_connections.py:53-117
+        def __init__(self):
+            super().__init__()
+            self.weight, self.bias = nn.Parameter(torch.ones(1, C, *(1,) * len(spatial))), None
+
+        def forward(self, x):
+            return self.weight * x
+    Gate.__name__ = "SoftGating"
+
+    class MLP(nn.Module):                                    # channel_mlp.py:60-119
+        def __init__(self):
+            super().__init__()
+            self.fcs = nn.ModuleList([nn.Conv1d(C, C // 2, 1), nn.Conv1d(C // 2, C, 1)])
+            self.non_linearity, self.dropout = F.gelu, None
+
+        def forward(self, x):
+            return self.fcs[1](F.gelu(self.fcs[0](x.reshape(x.shape[0], C, -1)))).reshape(x.shape)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.n_layers, self.non_linearity = 2, F.gelu
+            self.preactivation, self.norm, self.stabilizer, self.complex_data, self.use_channel_mlp = False, None, None, False, True
+            self.convs = nn.ModuleList([SpectralConv(C, C, n_modes)])
+            self.fno_skips, self.channel_mlp, self.channel_mlp_skips = nn.ModuleList([Skip()]), nn.ModuleList([MLP()]), nn.ModuleList([Gate()])
+
+        def forward(self, x, index=0, output_shape=None):
+            y = F.gelu(self.convs[0](x) + self.fno_skips[0](x))
+            return F.gelu(self.channel_mlp[0](y) + self.channel_mlp_skips[0](x))
+
+    torch.manual_seed(7)
+    blk = Block().to(dev)
+    x = torch.randn(B, C, *spatial, device=dev, requires_grad=True)
+    g = torch.randn(B, C, *spatial, device=dev)
+    out = {"workload": f"one FNO block, B={B} C={C} {'x'.join(map(str, spatial))} modes {list(n_modes)}, forward + backward",
+           "in_scope": bool(nb._block_in_scope(blk, 0, None))}
+    for tag, fn in (("reference_op_sequence_ms", lambda t: blk(t, 0)), ("fused_ms", lambda t: nb.fused_block_forward(blk, t, 0))):
+        def step():
+            blk.zero_grad(set_to_none=True)
+            x.grad = None
+            fn(x).backward(g)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        out[tag] = round(e0.elapsed_time(e1) / 5, 4)
+    return out
 
 
 def engine_path(names):
@@ -492,6 +566,9 @@ def main():
                            "global_batch": gb_x, "ms_per_step": round(ms_x, 4),
                            "value": round(gb_x / (ms_x / 1e3), 2), "unit": "samples/s", "steps": 10, "warmup": 3}
             del st_x, conv_x, c
+            torch.cuda.empty_cache()
+        if world == 1:
+            extra["fno_block"] = block_extra(B, C, spatial, n_modes, dev)
             torch.cuda.empty_cache()
 
     if rank == 0:
