@@ -207,15 +207,18 @@ int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float
  * (neuralop/layers/skip_connections.py:119-169: Flattened1dConv = Conv1d with kernel size 1 on the flattened grid).
  * x (batch, c_in, spatial), out (batch, c_out, spatial), w (c_out, c_in) row-major, bias (c_out) or null.
  * c_in = c_out in {32, 64, 128} forward, {32, 64} backward; spatial a multiple of 32.  Backward: gx, gw (and gbias
- * when not null) are overwritten; workspace sc_pointwise_linear_workspace_bytes(d) bytes. */
+ * when not null) are overwritten; gx_addend (optional, like gx): gx = W^T gout + gx_addend -- the gradient another
+ * branch of the block sends to the same input, added in the store path instead of by a separate pass; workspace
+ * sc_pointwise_linear_workspace_bytes(d) bytes. */
 typedef struct sc_plin_desc {
   int64_t batch, c_in, c_out, spatial;
 } sc_plin_desc;
 int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x, const float* w, const float* bias, float* out,
                                 void* stream);
 size_t sc_pointwise_linear_workspace_bytes(const sc_plin_desc* d);
-int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* x, const float* w, const float* gout, float* gx,
-                                 float* gw, float* gbias, void* workspace, void* stream);
+int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* x, const float* w, const float* gout,
+                                 const float* gx_addend, float* gx, float* gw, float* gbias, void* workspace,
+                                 void* stream);
 
 /* ---- fused AdamW step of the spectral weights ("next" row f2 of SURVEY.md section 8) -----------------
  * One pass over (param, grad, exp_avg, exp_avg_sq) instead of the ~10 elementwise launches of
@@ -255,6 +258,11 @@ int sc_layer_forward(const sc_plan* plan, const sc_layer_desc* L, const float* x
 int sc_layer_backward(const sc_plan* plan, const sc_layer_desc* L, const float* gy,
                       const float* xhat_saved, const float* w, float* gx, float* gw,
                       float* gbias, void* workspace, void* stream);
+/* sc_layer_backward with gx = (gradient through the layer) + gx_addend (optional; same shape as gx): the gradient the
+ * other branches of an FNO block send to the layer's input, added in the store path of the last transform. */
+int sc_layer_backward_ex(const sc_plan* plan, const sc_layer_desc* layer, const float* gy,
+                         const float* xhat_saved, const float* w, float* gx, float* gw, float* gbias,
+                         const float* gx_addend, void* workspace, void* stream);
 
 /* ---- block epilogue (first "next" row f1 of SURVEY.md section 8) ---------------------------------------------------
  * The FNO block computes act(conv(x) + skip(x)) around the spectral convolution (neuralop/layers/fno_block.py:392-414:

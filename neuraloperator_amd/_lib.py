@@ -127,7 +127,7 @@ class ScEngineLib:
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
                "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
                "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes", "sc_pointwise_linear_forward",
-               "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes"]
+               "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -179,6 +179,8 @@ class ScEngineLib:
                                           POINTER(Epilogue), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_layer_forward_ex.restype = c_int
         L.sc_layer_backward.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 8
+        L.sc_layer_backward_ex.argtypes = [c_void_p, POINTER(LayerDesc)] + [c_void_p] * 9
+        L.sc_layer_backward_ex.restype = c_int
         L.sc_layer_backward.restype = c_int
         L.sc_pointwise_mlp_forward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 9
         L.sc_pointwise_mlp_forward.restype = c_int
@@ -190,7 +192,7 @@ class ScEngineLib:
         L.sc_pointwise_linear_forward.restype = c_int
         L.sc_pointwise_linear_workspace_bytes.argtypes = [POINTER(PlinDesc)]
         L.sc_pointwise_linear_workspace_bytes.restype = c_size_t
-        L.sc_pointwise_linear_backward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 8
+        L.sc_pointwise_linear_backward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 9
         L.sc_pointwise_linear_backward.restype = c_int
         L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.sc_round_f16.restype = c_int
@@ -285,9 +287,9 @@ class ScEngineLib:
         d = PlinDesc(batch, c_in, c_out, spatial)
         return int(self.lib.sc_pointwise_linear_workspace_bytes(byref(d)))
 
-    def pointwise_linear_backward(self, batch, c_in, c_out, spatial, x, w, gout, gx, gw, gbias, ws, stream=0):
+    def pointwise_linear_backward(self, batch, c_in, c_out, spatial, x, w, gout, gx, gw, gbias, ws, stream=0, addend=0):
         d = PlinDesc(batch, c_in, c_out, spatial)
-        self._check(self.lib.sc_pointwise_linear_backward(byref(d), x, w, gout, gx, gw, gbias, ws, stream))
+        self._check(self.lib.sc_pointwise_linear_backward(byref(d), x, w, gout, addend, gx, gw, gbias, ws, stream))
 
     def round_f16(self, in_ptr, out_ptr, n, stream=0):
         """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""
@@ -351,6 +353,9 @@ class ScEngineLib:
     def layer_backward(self, plan, L, gy, xhat_saved, w, gx, gw, gbias, ws, stream=0):
         self._check(self.lib.sc_layer_backward(plan, byref(L), gy, xhat_saved, w, gx, gw,
                                                gbias, ws, stream))
+
+    def layer_backward_ex(self, plan, L, gy, xhat_saved, w, gx, gw, gbias, gx_addend, ws, stream=0):
+        self._check(self.lib.sc_layer_backward_ex(plan, byref(L), gy, xhat_saved, w, gx, gw, gbias, gx_addend, ws, stream))
 
 
 _LIB = None

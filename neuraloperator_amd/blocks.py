@@ -149,6 +149,94 @@ def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=No
     return F.gelu(z) if activation == "gelu" else z
 
 
+class FusedBlockFn(torch.autograd.Function):
+    """One default FNO block as ONE autograd node: linear skip -> Fourier layer with the add + GELU epilogue ->
+    pointwise MLP pass.  The block input feeds three branches; as separate nodes autograd adds their three gradients
+    with two tensor-sized passes (6 tensor reads / writes).  Here the backward chains them through the store paths:
+    the MLP pass' skip gradient is the addend of the linear skip's backward, whose result is the addend of the last
+    transform of the spectral convolution's backward (sc_pointwise_linear_backward / sc_layer_backward_ex)."""
+
+    @staticmethod
+    def forward(ctx, x, cw, cb, lw, lb, w1, b1, w2, b2, gate, last, n_modes_attr, max_n_modes_attr, fft_norm, flags):
+        from . import engine
+        from .modes import kept_block
+        _require_gpu(x, "x")
+        lib = _lib.get_lib()
+        dev = x.device
+        x = x.contiguous().float()
+        b, c = int(x.shape[0]), int(x.shape[1])
+        spatial = [int(v) for v in x.shape[2:]]
+        s = 1
+        for v in spatial:
+            s *= v
+        ch = int(w1.shape[0])
+        act = _lib.SC_ACT_NONE if last else _lib.SC_ACT_GELU
+        p = lambda t: 0 if t is None else t.data_ptr()
+        lwc, w1c, w2c = lw.detach().reshape(c, c).contiguous(), w1.detach().reshape(ch, c).contiguous(), w2.detach().reshape(c, ch).contiguous()
+        lbc = None if lb is None else lb.detach().contiguous()
+        b1c, b2c = (None if t is None else t.detach().contiguous() for t in (b1, b2))
+        gtc = gate.detach().reshape(c).contiguous()
+        cwc = cw.detach().to(torch.complex64).contiguous()
+        cbf = None if cb is None else cb.detach().reshape(-1).float().contiguous()
+        kept, w_start = kept_block(spatial, n_modes_attr, max_n_modes_attr)
+        plan = engine.get_plan(dev, spatial, kept, fft_norm, flags)
+        L = lib.layer_desc(b, c, c, list(cwc.shape[2:]), w_start)
+        with torch.cuda.device(dev):
+            st = _stream()
+            skip = torch.empty_like(x)
+            lib.pointwise_linear_forward(b, c, c, s, p(x), p(lwc), p(lbc), p(skip), st)
+            ws = engine._ws(lib.layer_workspace_bytes(plan, L), dev)
+            y = torch.empty_like(x)
+            pre = None if last else torch.empty_like(x)
+            xhat = torch.empty((b, c, *kept, 2), dtype=torch.float32, device=dev)
+            lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), p(skip), p(pre), act, p(y), p(xhat),
+                                 p(ws), st)
+            out = torch.empty_like(x)
+            lib.pointwise_mlp_forward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(out), st)
+        ctx.save_for_backward(x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc)
+        ctx.cfg = (plan, L, b, c, ch, s, act, tuple(cw.shape), None if cb is None else tuple(cb.shape), tuple(lw.shape),
+                   lb is not None, tuple(w1.shape), tuple(w2.shape), tuple(gate.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from . import engine
+        x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc = ctx.saved_tensors
+        plan, L, b, c, ch, s, act, cw_shape, cb_shape, lw_shape, has_lb, w1_shape, w2_shape, gate_shape = ctx.cfg
+        lib = _lib.get_lib()
+        dev = x.device
+        p = lambda t: 0 if t is None else t.data_ptr()
+        gout = gout.contiguous().float()
+        with torch.cuda.device(dev):
+            st = _stream()
+            # pointwise MLP pass: gy, and the soft-gating branch's gradient of the block input (acc)
+            gy, acc = torch.empty_like(x), torch.empty_like(x)
+            gw1, gw2 = torch.empty_like(w1c), torch.empty_like(w2c)
+            gb1 = None if b1c is None else torch.empty_like(b1c)
+            gb2 = None if b2c is None else torch.empty_like(b2c)
+            ggt = torch.empty_like(gtc)
+            ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, c, ch, c, s, act), dtype=torch.uint8, device=dev)
+            lib.pointwise_mlp_backward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(gout), p(gy),
+                                       p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(ws), st)
+            gz = torch.ops.aten.gelu_backward(gy, pre) if pre is not None else gy
+            # linear skip: W^T gz + acc
+            acc2, glw = torch.empty_like(x), torch.empty_like(lwc)
+            glb = torch.empty(c, dtype=torch.float32, device=dev) if has_lb else None
+            ws2 = torch.empty(lib.pointwise_linear_workspace_bytes(b, c, c, s), dtype=torch.uint8, device=dev)
+            lib.pointwise_linear_backward(b, c, c, s, p(x), p(lwc), p(gz), p(acc2), p(glw), p(glb), p(ws2), st, addend=p(acc))
+            # spectral convolution: its input gradient + acc2 in the store path of the last transform
+            gx = torch.empty_like(x)
+            full = all(L.w_start[d] == 0 for d in range(len(cw_shape) - 2)) and tuple(xhat.shape[2:-1]) == tuple(cw_shape[2:])
+            gcw = (torch.empty if full else torch.zeros)((*cw_shape, 2), dtype=torch.float32, device=dev)
+            gcb = None if cb_shape is None else torch.empty(c, dtype=torch.float32, device=dev)
+            ws3 = engine._ws(lib.layer_workspace_bytes(plan, L), dev)
+            lib.layer_backward_ex(plan, L, p(gz), p(xhat), torch.view_as_real(cwc).data_ptr(), p(gx), p(gcw), p(gcb), p(acc2),
+                                  p(ws3), st)
+        return (gx, torch.view_as_complex(gcw), None if gcb is None else gcb.reshape(cb_shape), glw.reshape(lw_shape), glb,
+                gw1.reshape(w1_shape), gb1, gw2.reshape(w2_shape), gb2, ggt.reshape(gate_shape),
+                None, None, None, None, None)
+
+
 def _block_in_scope(blocks, index, output_shape):
     if output_shape is not None or getattr(blocks, "preactivation", False) or getattr(blocks, "norm", None) is not None:
         return False
@@ -177,10 +265,20 @@ def fused_block_forward(blocks, x, index=0, output_shape=None):
     if not _block_in_scope(blocks, index, output_shape):
         return blocks(x, index, output_shape=output_shape)
     last = index >= blocks.n_layers - 1
-    lin = blocks.fno_skips[index].conv                                        # 1 x 1 convolution, no bias by default
-    x_skip_fno = fused_linear(x, lin.weight, lin.bias)
     conv = blocks.convs[index]
-    y = conv.forward_fused(x, x_skip_fno, activation=None if last else "gelu")
     fc1, fc2 = blocks.channel_mlp[index].fcs
+    lin = blocks.fno_skips[index].conv
+    c, ch = int(x.shape[1]), int(fc1.weight.shape[0])
+    from .factorized import DenseWeight
+    one_node = _on_engine(x) and x.dtype == torch.float32 and x[0, 0].numel() % 32 == 0 and \
+        (c, ch, c) in _SHAPES_BWD and c in (32, 64) and int(lin.weight.shape[0]) == c and \
+        isinstance(conv.weight, DenseWeight) and not conv.separable and conv.fno_block_precision == "full" and \
+        conv.in_channels == conv.out_channels == c
+    if one_node:
+        return FusedBlockFn.apply(x, conv.weight.tensor, conv.bias, lin.weight, lin.bias, fc1.weight, fc1.bias, fc2.weight,
+                                  fc2.bias, blocks.channel_mlp_skips[index].weight, last, list(conv.n_modes),
+                                  list(conv.max_n_modes), conv.fft_norm, conv.engine_flags)                                        # 1 x 1 convolution, no bias by default
+    x_skip_fno = fused_linear(x, lin.weight, lin.bias)
+    y = conv.forward_fused(x, x_skip_fno, activation=None if last else "gelu")
     return fused_channel_mlp(y, fc1.weight, fc1.bias, fc2.weight, fc2.bias, skip_src=x,
                              gate=blocks.channel_mlp_skips[index].weight, activation=None if last else "gelu")

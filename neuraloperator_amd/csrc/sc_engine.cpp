@@ -1149,7 +1149,8 @@ extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* 
   if (ep) {
     SC_CHECK_ARG(ep->act == SC_ACT_NONE || ep->act == SC_ACT_GELU, "unknown activation");
     SC_CHECK_ARG(!p->cplx, "complex-data plans take no epilogue");
-    SC_CHECK_ARG(mode == SC_INV_PADDED, "the epilogue belongs to the forward inverse transform (SC_INV_PADDED)");
+    SC_CHECK_ARG(mode == SC_INV_PADDED || ep->act == SC_ACT_NONE,
+                 "an activation in the epilogue belongs to the forward inverse transform (SC_INV_PADDED)");
   }
   const int epi = ep ? (ep->act == SC_ACT_GELU ? 2 : 1) : 0;
   SC_CHECK_ARG(mode == SC_INV_PADDED || mode == SC_INV_ADJ_R2C, "bad inverse mode");
@@ -1646,7 +1647,7 @@ extern "C" int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x
   SC_CHECK_ARG(x && w && out, "null argument");
   SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
   PlinArgs g;
-  g.x = x; g.w = w; g.bias = bias; g.gout = nullptr; g.out = out; g.partial = nullptr;
+  g.x = x; g.w = w; g.bias = bias; g.gout = nullptr; g.addend = nullptr; g.out = out; g.partial = nullptr;
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
@@ -1684,13 +1685,14 @@ static void launch_plin_bwd(PlinArgs g, float* ws, float* gw, float* gb, sc_stre
 }
 
 extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* x, const float* w, const float* gout,
-                                            float* gx, float* gw, float* gbias, void* workspace, void* stream) {
+                                            const float* gx_addend, float* gx, float* gw, float* gbias, void* workspace,
+                                            void* stream) {
   SC_CHECK_ARG(d, "null argument");
   SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise linear map backward: empty input");
   SC_CHECK_ARG(x && w && gout && gx && gw && workspace, "null argument");
   SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
   PlinArgs g;
-  g.x = x; g.w = w; g.bias = nullptr; g.gout = gout; g.out = gx; g.partial = nullptr;
+  g.x = x; g.w = w; g.bias = nullptr; g.gout = gout; g.addend = gx_addend; g.out = gx; g.partial = nullptr;
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
@@ -1873,6 +1875,12 @@ extern "C" int sc_layer_forward_ex(const sc_plan* p, const sc_layer_desc* L, con
 extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const float* gy,
                                  const float* xhat_saved, const float* w, float* gx, float* gw,
                                  float* gbias, void* workspace, void* stream) {
+  return sc_layer_backward_ex(p, L, gy, xhat_saved, w, gx, gw, gbias, nullptr, workspace, stream);
+}
+
+extern "C" int sc_layer_backward_ex(const sc_plan* p, const sc_layer_desc* L, const float* gy,
+                                    const float* xhat_saved, const float* w, float* gx, float* gw,
+                                    float* gbias, const float* gx_addend, void* workspace, void* stream) {
   SC_CHECK_ARG(p && L, "null argument");
   SC_CHECK_ARG(!p->cplx, "complex-data plans: call the transform / contraction stages (no fused layer)");
   const int64_t B = L->batch, Ci = L->cin, Co = L->cout, Mk = p->modes;
@@ -1922,7 +1930,9 @@ extern "C" int sc_layer_backward(const sc_plan* p, const sc_layer_desc* L, const
     g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
     rc = sc_modegemm(&g, ghat, w, gxhat, stream);
     if (rc) return rc;
-    rc = sc_transform_inverse(p, SC_INV_ADJ_R2C, gxhat, nullptr, Ci, gx, B * Ci, ws, stream);
+    sc_epilogue ep;
+    ep.skip = gx_addend; ep.preact = nullptr; ep.act = SC_ACT_NONE; ep.reserved = 0;
+    rc = sc_transform_inverse_ex(p, SC_INV_ADJ_R2C, gxhat, nullptr, Ci, gx_addend ? &ep : nullptr, gx, B * Ci, ws, stream);
     if (rc) return rc;
   }
   return 0;

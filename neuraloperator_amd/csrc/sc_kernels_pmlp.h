@@ -538,6 +538,7 @@ struct PlinArgs {
   const float* w;          // (32 CO, 32 CI)
   const float* bias;       // (32 CO) or null
   const float* gout;       // backward: (batch, 32 CO, spatial)
+  const float* addend;     // backward, optional: gx = W^T g + addend (another branch's gradient of the same input)
   float* out;              // forward: (batch, 32 CO, spatial); backward: gx (batch, 32 CI, spatial)
   float* partial;          // backward: [n_wg][32 CO * 32 CI + 32 CO]
   int64_t n_tiles, spatial;
@@ -629,6 +630,7 @@ k_plin_bwd(PlinArgs g) {
     const float* xs = g.x + b * C_IN * sp + px0;
     const float* gs = g.gout + b * C_OUT * sp + px0;
     float* gxs = g.out + b * C_IN * sp + px0;
+    const float* ads = g.addend ? g.addend + b * C_IN * sp + px0 : nullptr;
     float gz[CO][16];
 #pragma unroll
     for (int om = 0; om < CO; ++om)
@@ -649,6 +651,10 @@ k_plin_bwd(PlinArgs g) {
           for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, AT[((ci * CO + om) * 16 + v) * 64 + ln], gz[om][v]);
           SC_SCHED_BARRIER();
         }
+      if (ads) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += SC_LOAD_STREAM(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) SC_STORE_STREAM(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
       SC_SCHED_BARRIER();

@@ -129,6 +129,10 @@ def test_pointwise_linear(lib, c, bias):
     gb = torch.full((c,), float("nan")) if bias else None
     ws = torch.empty(lib.pointwise_linear_workspace_bytes(B, c, c, S), dtype=torch.uint8)
     lib.pointwise_linear_backward(B, c, c, S, p(x), p(w), p(go), p(gx), p(gw), p(gb), p(ws), 0)
+    add = torch.randn(B, c, S, generator=g)                                    # gx = W^T g + addend in the store path
+    gx2 = torch.full_like(x, float("nan"))
+    lib.pointwise_linear_backward(B, c, c, S, p(x), p(w), p(go), p(gx2), p(gw), p(gb), p(ws), 0, addend=p(add))
+    assert rel_l2(gx2.numpy(), (xd.grad + add.double()).numpy()) < 1e-5
     assert rel_l2(gx.numpy(), xd.grad.numpy()) < 1e-5 and rel_l2(gw.numpy(), wd.grad.numpy()) < 1e-5
     if bias:
         assert rel_l2(gb.numpy(), bd.grad.numpy()) < 1e-5
