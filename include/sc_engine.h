@@ -202,6 +202,12 @@ int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float
                               const float* b2, const float* skip_src, const float* gate, const float* gout, float* gx,
                               float* gw1, float* gb1, float* gw2, float* gb2, float* gskip_src, float* ggate,
                               void* workspace, void* stream);
+/* the same with x_pre (optional, like x): x = gelu(x_pre) came out of sc_layer_forward_ex; gx is then the gradient with
+ * respect to x_pre -- the GELU backward of the Fourier layer in this pass' store path instead of a pass of its own. */
+int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* x, const float* x_pre, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, const float* skip_src,
+                                 const float* gate, const float* gout, float* gx, float* gw1, float* gb1, float* gw2,
+                                 float* gb2, float* gskip_src, float* ggate, void* workspace, void* stream);
 
 /* 1 x 1 linear map over the channels in one pass each way: out = W x (+ bias) -- the block's linear skip
  * (neuralop/layers/skip_connections.py:119-169: Flattened1dConv = Conv1d with kernel size 1 on the flattened grid).

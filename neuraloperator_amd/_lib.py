@@ -127,7 +127,8 @@ class ScEngineLib:
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
                "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
                "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes", "sc_pointwise_linear_forward",
-               "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex"]
+               "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex",
+               "sc_pointwise_mlp_backward_ex"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -188,6 +189,8 @@ class ScEngineLib:
         L.sc_pointwise_mlp_workspace_bytes.restype = c_size_t
         L.sc_pointwise_mlp_backward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 17
         L.sc_pointwise_mlp_backward.restype = c_int
+        L.sc_pointwise_mlp_backward_ex.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 18
+        L.sc_pointwise_mlp_backward_ex.restype = c_int
         L.sc_pointwise_linear_forward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 5
         L.sc_pointwise_linear_forward.restype = c_int
         L.sc_pointwise_linear_workspace_bytes.argtypes = [POINTER(PlinDesc)]
@@ -274,10 +277,10 @@ class ScEngineLib:
         return int(self.lib.sc_pointwise_mlp_workspace_bytes(byref(d)))
 
     def pointwise_mlp_backward(self, batch, c_in, c_hid, c_out, spatial, act, x, w1, b1, w2, b2, skip, gate, gout,
-                               gx, gw1, gb1, gw2, gb2, gskip, ggate, ws, stream=0):
+                               gx, gw1, gb1, gw2, gb2, gskip, ggate, ws, stream=0, x_pre=0):
         d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
-        self._check(self.lib.sc_pointwise_mlp_backward(byref(d), x, w1, b1, w2, b2, skip, gate, gout, gx, gw1, gb1, gw2,
-                                                       gb2, gskip, ggate, ws, stream))
+        self._check(self.lib.sc_pointwise_mlp_backward_ex(byref(d), x, x_pre, w1, b1, w2, b2, skip, gate, gout, gx, gw1,
+                                                          gb1, gw2, gb2, gskip, ggate, ws, stream))
 
     def pointwise_linear_forward(self, batch, c_in, c_out, spatial, x, w, bias, out, stream=0):
         d = PlinDesc(batch, c_in, c_out, spatial)

@@ -216,9 +216,10 @@ class FusedBlockFn(torch.autograd.Function):
             gb2 = None if b2c is None else torch.empty_like(b2c)
             ggt = torch.empty_like(gtc)
             ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, c, ch, c, s, act), dtype=torch.uint8, device=dev)
+            # (with the Fourier layer's pre-activation the pass returns the gradient THROUGH its GELU: gy is gz)
             lib.pointwise_mlp_backward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(gout), p(gy),
-                                       p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(ws), st)
-            gz = torch.ops.aten.gelu_backward(gy, pre) if pre is not None else gy
+                                       p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(ws), st, x_pre=p(pre))
+            gz = gy
             # linear skip: W^T gz + acc
             acc2, glw = torch.empty_like(x), torch.empty_like(lwc)
             glb = torch.empty(c, dtype=torch.float32, device=dev) if has_lb else None

@@ -1600,6 +1600,15 @@ extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, 
                                          const float* w2, const float* b2, const float* skip_src, const float* gate,
                                          const float* gout, float* gx, float* gw1, float* gb1, float* gw2, float* gb2,
                                          float* gskip_src, float* ggate, void* workspace, void* stream) {
+  return sc_pointwise_mlp_backward_ex(d, x, nullptr, w1, b1, w2, b2, skip_src, gate, gout, gx, gw1, gb1, gw2, gb2, gskip_src,
+                                      ggate, workspace, stream);
+}
+
+extern "C" int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* x, const float* x_pre, const float* w1,
+                                            const float* b1, const float* w2, const float* b2, const float* skip_src,
+                                            const float* gate, const float* gout, float* gx, float* gw1, float* gb1,
+                                            float* gw2, float* gb2, float* gskip_src, float* ggate, void* workspace,
+                                            void* stream) {
   SC_CHECK_ARG(d, "null argument");
   SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise MLP backward: empty input");
   SC_CHECK_ARG(x && w1 && w2 && gout && gx && gw1 && gw2 && workspace, "null argument");
@@ -1610,7 +1619,7 @@ extern "C" int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, 
   SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
   PmlpBwdArgs g;
   g.x = x; g.b1 = b1; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.gout = gout; g.gx = gx; g.gskip = gskip_src;
-  g.w1 = w1; g.w2 = w2; g.partial = nullptr;
+  g.w1 = w1; g.w2 = w2; g.x_pre = x_pre; g.partial = nullptr;
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;

@@ -192,6 +192,8 @@ struct PmlpBwdArgs {
   const float* gout;
   const float* w1;
   const float* w2;
+  const float* x_pre;      // optional: x = gelu(x_pre) was produced by the previous fused pass; gx is then the gradient
+                           // with respect to x_pre (the gelu backward of the Fourier layer folded into this store path)
   float* gx;
   float* gskip;
   float* partial;          // [n_wg][NP]
@@ -428,6 +430,17 @@ k_pmlp_bwd(PmlpBwdArgs g) {
           for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(acc, A4[((ci * CH + hm) * 16 + v) * 64 + ln4], ghp[hm][v]);
           SC_SCHED_BARRIER();
         }
+      if (g.x_pre) {
+        const float* ps = g.x_pre + b * D::C_IN * sp + px0;
+        float pv[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) pv[v] = SC_LOAD_STREAM(ps + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          acc[v] *= PMLP_GELU_GRAD(pv[v]);
+          if ((v & 3) == 3) SC_SCHED_BARRIER();
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) PMLP_STORE(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
       SC_SCHED_BARRIER();
