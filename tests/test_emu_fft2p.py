@@ -125,3 +125,39 @@ def test_two_pass_scope(lib):
             assert lib.plan_kernel_name(plan, 0) != "k_f2p_r2c"
         finally:
             lib.plan_destroy(plan)
+
+
+def test_two_pass_chunking_and_bias_offsets(tmp_path):
+    """The host runs the two passes over chunks of images (192 MB of panel in the product); a build with a 1 MB chunk
+    makes 8 images of 512 x 512 take two chunks here: the second chunk's bias index starts at (first image of the
+    chunk) mod channels, and the results equal the one-chunk run of the product-sized build."""
+    import os
+    import subprocess
+    from engine_runner import EMU_DIR, ROOT
+    out = os.path.join(str(tmp_path), "libsc_engine_emu_chunk1.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DSC_EMU=1", "-DSC_F2P_CHUNK_MB=1",
+                           "-x", "c++", os.path.join(ROOT, "neuraloperator_amd", "csrc", "sc_engine.cpp"),
+                           os.path.join(EMU_DIR, "sc_emu_runtime.cpp"), "-o", out])
+    small = _lib.ScEngineLib(out)
+    big = emu_lib()
+    rng = np.random.default_rng(8)
+    spatial, kept, n_img, channels = (512, 512), (16, 33), 8, 4
+    x = torch.from_numpy(rng.standard_normal((n_img, *spatial)).astype(np.float32))
+    yhat = torch.from_numpy((rng.standard_normal((n_img, *kept)) + 1j * rng.standard_normal((n_img, *kept))).astype(np.complex64))
+    bias = torch.from_numpy(rng.standard_normal(channels).astype(np.float32))
+    res = []
+    for lib in (small, big):
+        plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+        try:
+            nbytes = lib.plan_workspace_bytes(plan, n_img)
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8)
+            xhat = torch.empty((n_img, *kept), dtype=torch.complex64)
+            lib.transform_forward(plan, _lib.SC_FWD_SCALED, x.data_ptr(), torch.view_as_real(xhat).data_ptr(), n_img, ws.data_ptr(), 0)
+            y = torch.empty((n_img, *spatial), dtype=torch.float32)
+            lib.transform_inverse(plan, _lib.SC_INV_PADDED, torch.view_as_real(yhat).data_ptr(), bias.data_ptr(), channels,
+                                  y.data_ptr(), n_img, ws.data_ptr(), 0)
+            res.append((xhat.numpy().copy(), y.numpy().copy(), nbytes))
+        finally:
+            lib.plan_destroy(plan)
+    assert res[0][2] < res[1][2], "the small-chunk build asks for a smaller panel workspace"
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
