@@ -8,5 +8,6 @@ from .spectral_conv import BaseSpectralConv, SpectralConv  # noqa: F401
 from .factorized import CPWeight, DenseWeight, SpectralWeight, TTWeight, TuckerWeight  # noqa: F401
 from .optim import AdamW  # noqa: F401
 from .galore import TensorGaLoreProjector  # noqa: F401
+from .spherical import SHT, SphericalConv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -811,3 +811,31 @@ def test_pointwise_linear_pass(c):
     assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
     for a, r in ((xg, xd), (wg, wd), (bg, bd)):
         assert rel_l2(a.grad.cpu().numpy(), r.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("grid", ["equiangular", "legendre-gauss"])
+def test_spherical_conv_on_device(grid):
+    """SphericalConv (last item) on the GPU against the float64 restatement of its definition
+    (tests/test_spherical.py; torch_harmonics itself is absent: parity with it is unpinned)."""
+    from neuraloperator_amd import SphericalConv
+    from test_spherical import _ref_isht, _ref_sht
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    conv = SphericalConv(4, 5, (12, 24), factorization=None, sht_grids=grid).to(dev)
+    with torch.no_grad():
+        conv.weight.tensor.mul_(3.0)
+    x = torch.randn(2, 4, 25, 48)
+    g = torch.randn(2, 5, 25, 48)
+    xi = x.to(dev).requires_grad_(True)
+    y = conv(xi)
+    y.backward(g.to(dev))
+    xd = x.double().requires_grad_(True)
+    w = conv.weight.tensor.detach().cpu().to(torch.complex128).requires_grad_(True)
+    b = conv.bias.detach().cpu().double().requires_grad_(True)
+    yh = torch.einsum("bilm,iol->bolm", _ref_sht(xd, 12, 12, "ortho", grid), w)
+    yr = _ref_isht(yh, 25, 48, "ortho", grid) + b
+    yr.backward(g.double())
+    assert rel_l2(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL
+    assert rel_l2(xi.grad.cpu().numpy(), xd.grad.numpy()) < TOL
+    assert rel_l2(torch.view_as_real(conv.weight.tensor.grad).cpu().numpy(), torch.view_as_real(w.grad).numpy()) < 2e-5
+    assert rel_l2(conv.bias.grad.cpu().numpy(), b.grad.numpy()) < TOL

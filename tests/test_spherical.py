@@ -1,0 +1,109 @@
+"""SURVEY section 8 row f4 (last item): SphericalConv on the engine (neuraloperator_amd/spherical.py).
+
+torch_harmonics (the reference's transform library) is absent, so nothing here compares with it: the Legendre tables are
+pinned against scipy's associated Legendre functions, the quadrature rules by exactness, the transforms by round trips of
+band-limited fields and against a float64 torch restatement of their definition (which also provides the autograd
+reference for the layer).  Engine in host emulation."""
+import math
+
+import numpy as np
+import pytest
+import torch
+from scipy.special import gammaln, lpmv
+
+from emu_engine import engine_on_emulation
+from engine_runner import rel_l2
+from neuraloperator_amd import spherical as sp
+
+
+def test_legendre_table_matches_scipy():
+    theta = np.linspace(0.05, math.pi - 0.05, 23)
+    mmax, lmax = 9, 14
+    tab = sp.legendre_table(mmax, lmax, theta)
+    for m in range(mmax):
+        for l in range(lmax):
+            if l < m:
+                assert np.all(tab[m, l] == 0)
+                continue
+            nrm = math.sqrt((2 * l + 1) / (4 * math.pi) * math.exp(gammaln(l - m + 1) - gammaln(l + m + 1)))
+            assert np.allclose(tab[m, l], nrm * lpmv(m, l, np.cos(theta)), rtol=1e-10, atol=1e-12), (m, l)
+    assert np.allclose(sp.legendre_table(3, 5, theta, "four-pi")[1, 3], tab[1, 3] * math.sqrt(4 * math.pi))
+    assert np.allclose(sp.legendre_table(3, 5, theta, "schmidt", inverse=True)[1, 3], tab[1, 3] / math.sqrt(4 * math.pi / 7))
+
+
+@pytest.mark.parametrize("n", [9, 16, 33])
+def test_clenshaw_curtis_is_exact_below_degree_n(n):
+    x, w = sp.clenshaw_curtis(n)
+    assert np.all(np.diff(x) > 0) and abs(w.sum() - 2.0) < 1e-13
+    for p in range(n):
+        assert abs(np.sum(w * x ** p) - (0.0 if p % 2 else 2.0 / (p + 1))) < 1e-12, p
+
+
+def _ref_sht(x, lmax, mmax, norm, grid):
+    nlat, nlon = x.shape[-2:]
+    theta, w = sp.quadrature(nlat, grid)
+    tab = torch.from_numpy(sp.legendre_table(mmax, lmax, theta, norm) * w[None, None, :])
+    xh = 2 * math.pi * torch.fft.rfft(x.double(), dim=-1, norm="forward")[..., :mmax]
+    return torch.einsum("...km,mlk->...lm", xh, tab.to(torch.complex128))
+
+
+def _ref_isht(c, nlat, nlon, norm, grid):
+    lmax, mmax = c.shape[-2:]
+    theta, _ = sp.quadrature(nlat, grid)
+    tab = torch.from_numpy(sp.legendre_table(mmax, lmax, theta, norm, inverse=True)).to(torch.complex128)
+    xh = torch.einsum("...lm,mlk->...km", c.to(torch.complex128), tab)
+    full = torch.zeros(*xh.shape[:-1], nlon // 2 + 1, dtype=torch.complex128)
+    full[..., :mmax] = xh
+    return torch.fft.irfft(full, n=nlon, dim=-1, norm="forward")
+
+
+@pytest.mark.parametrize("grid,nlat,nlon,lmax,mmax", [("equiangular", 17, 32, 8, 8), ("legendre-gauss", 12, 24, 12, 10)])
+def test_transforms_match_definition_and_round_trip(grid, nlat, nlon, lmax, mmax):
+    g = torch.Generator().manual_seed(5)
+    c = torch.complex(torch.randn(2, 3, lmax, mmax, generator=g), torch.randn(2, 3, lmax, mmax, generator=g))
+    for m in range(mmax):
+        c[..., :m, m] = 0                                   # l >= m
+    c[..., 0] = c[..., 0].real.to(torch.complex64)          # m = 0 coefficients of a real field are real
+    with engine_on_emulation():
+        h = sp.SHT()
+        x = h.isht(c, s=(nlat, nlon), grid=grid)
+        c2 = h.sht(x, s=(lmax, mmax), grid=grid)
+    assert rel_l2(x.numpy(), _ref_isht(c, nlat, nlon, "ortho", grid).numpy()) < 2e-6
+    assert rel_l2(c2.numpy(), _ref_sht(x, lmax, mmax, "ortho", grid).numpy()) < 2e-6
+    assert rel_l2(c2.numpy(), c.numpy()) < 1e-5             # a band-limited field survives analysis after synthesis
+
+
+@pytest.mark.parametrize("fac", [None, "tucker"])
+def test_spherical_conv_forward_backward(fac):
+    from neuraloperator_amd.spherical import SphericalConv
+    torch.manual_seed(1)
+    conv = SphericalConv(3, 4, (8, 16), factorization=fac, rank=0.6)
+    with torch.no_grad():
+        for q in conv.weight.parameters():
+            q.mul_(3.0)
+    x = torch.randn(2, 3, 17, 32)
+    g = torch.randn(2, 4, 17, 32)
+    with engine_on_emulation():
+        xi = x.clone().requires_grad_(True)
+        y = conv(xi)
+        y.backward(g)
+        gw = [q.grad.clone() for q in conv.weight.parameters()]
+        gb, gx = conv.bias.grad.clone(), xi.grad.clone()
+    # float64 restatement with torch autograd
+    conv.zero_grad(set_to_none=True)
+    xd = x.double().requires_grad_(True)
+    w = conv._dense_weight().to(torch.complex128)
+    c = _ref_sht(xd, 8, 8, "ortho", "equiangular")
+    yh = torch.einsum("bilm,iol->bolm", c, w)
+    yr = _ref_isht(yh, 17, 32, "ortho", "equiangular") + conv.bias.double()
+    yr.backward(g.double())
+    assert rel_l2(y.detach().numpy(), yr.detach().numpy()) < 1e-5
+    assert rel_l2(gx.numpy(), xd.grad.numpy()) < 1e-5
+    assert rel_l2(gb.numpy(), conv.bias.grad.numpy()) < 1e-5
+    for a, q in zip(gw, conv.weight.parameters()):
+        assert rel_l2(torch.view_as_real(a).numpy(), torch.view_as_real(q.grad).numpy()) < 2e-5
+    # the skip-path transform: identity on the same grid, resampling otherwise
+    assert conv.transform(x) is x
+    with engine_on_emulation():
+        t = conv.transform(x, output_shape=(9, 16))
+    assert tuple(t.shape) == (2, 3, 9, 16)
