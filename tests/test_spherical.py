@@ -107,3 +107,26 @@ def test_spherical_conv_forward_backward(fac):
     with engine_on_emulation():
         t = conv.transform(x, output_shape=(9, 16))
     assert tuple(t.shape) == (2, 3, 9, 16)
+
+
+def test_verbatim_fno_drives_the_spherical_plugin():
+    """The reference builds the SFNO as ``FNO(..., conv_module=SphericalConv)`` (models/sfno.py:7-9).  The verbatim
+    FNO constructs and trains through this repo's SphericalConv with exactly the keyword set FNOBlocks passes
+    (fno_block.py:212-237); its own SphericalConv cannot be imported here (torch_harmonics), so there is nothing to
+    compare the numbers with -- this pins the plug-in surface."""
+    from oracle import ref_verbatim
+    if not ref_verbatim.available():
+        pytest.skip("verbatim reference not present")
+    from neuraloperator_amd import SphericalConv
+    fno = ref_verbatim.load_reference_fno()
+    torch.manual_seed(0)
+    model = fno.FNO(n_modes=(8, 16), hidden_channels=8, in_channels=2, out_channels=1, n_layers=2,
+                    factorization="dense", conv_module=SphericalConv)
+    assert all(isinstance(c, SphericalConv) for c in model.fno_blocks.convs)
+    x = torch.randn(2, 2, 17, 32)
+    with engine_on_emulation():
+        y = model(x)
+        y.square().mean().backward()
+    assert tuple(y.shape) == (2, 1, 17, 32) and torch.isfinite(y).all()
+    grads = [p.grad for c in model.fno_blocks.convs for p in c.parameters()]
+    assert all(g is not None and torch.isfinite(torch.view_as_real(g) if g.is_complex() else g).all() for g in grads)
