@@ -175,6 +175,22 @@ int sc_round_f16(const float* in, float* out, int64_t n, void* stream);
 int sc_bias_grad(const sc_plan* plan, const float* ghat, int64_t batch, int64_t channels,
                  float* gbias, void* stream);
 
+/* ---- batch-independent part of the 2-D Tucker contraction (TFNO) in one launch each way --------------------
+ *   t[fg, x, y] = sum_{c, d} core[fg, c, d] ux[x, c] uy[y, d]
+ * (_contract_tucker, neuralop/layers/spectral_convolution.py:76-103: the two mode factors absorbed into the core; fg =
+ * the (in-rank, out-rank) pairs).  All arrays complex64 interleaved, contiguous: core (fg, rx, ry), ux (mx, rx),
+ * uy (my, ry), t (fg, mx, my).  Backward: gcore / gux / guy overwritten, workspace sc_tucker_modes_workspace_bytes(d).
+ * Limits: mx rx <= 3072, my ry <= 1024 and the slices must fit LDS (checked; callers fall back to sc_modegemm). */
+typedef struct sc_tucker_desc {
+  int64_t fg, rx, ry, mx, my;
+} sc_tucker_desc;
+int sc_tucker_modes_supported(const sc_tucker_desc* d);
+int sc_tucker_modes_forward(const sc_tucker_desc* d, const float* core, const float* ux, const float* uy, float* t,
+                            void* stream);
+size_t sc_tucker_modes_workspace_bytes(const sc_tucker_desc* d);
+int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* core, const float* ux, const float* uy,
+                             const float* gt, float* gcore, float* gux, float* guy, void* workspace, void* stream);
+
 /* ---- pointwise half of an FNO block in one pass ("next" row f1 of SURVEY.md section 8) -------------------
  *   out = act( W2 gelu(W1 x + b1) + b2 + gate (.) skip_src )
  * replaces ChannelMLP.forward (neuralop/layers/channel_mlp.py:82-119: two Conv1d with kernel size 1 and a GELU),

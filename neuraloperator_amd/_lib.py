@@ -73,6 +73,10 @@ class Epilogue(Structure):
 SC_ACT_NONE, SC_ACT_GELU = 0, 1
 
 
+class TuckerDesc(Structure):
+    _fields_ = [("fg", c_int64), ("rx", c_int64), ("ry", c_int64), ("mx", c_int64), ("my", c_int64)]
+
+
 class PlinDesc(Structure):
     _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("spatial", c_int64)]
 
@@ -128,7 +132,8 @@ class ScEngineLib:
                "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
                "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes", "sc_pointwise_linear_forward",
                "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex",
-               "sc_pointwise_mlp_backward_ex"]
+               "sc_pointwise_mlp_backward_ex", "sc_tucker_modes_supported", "sc_tucker_modes_forward",
+               "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -197,6 +202,14 @@ class ScEngineLib:
         L.sc_pointwise_linear_workspace_bytes.restype = c_size_t
         L.sc_pointwise_linear_backward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 9
         L.sc_pointwise_linear_backward.restype = c_int
+        L.sc_tucker_modes_supported.argtypes = [POINTER(TuckerDesc)]
+        L.sc_tucker_modes_supported.restype = c_int
+        L.sc_tucker_modes_forward.argtypes = [POINTER(TuckerDesc)] + [c_void_p] * 5
+        L.sc_tucker_modes_forward.restype = c_int
+        L.sc_tucker_modes_workspace_bytes.argtypes = [POINTER(TuckerDesc)]
+        L.sc_tucker_modes_workspace_bytes.restype = c_size_t
+        L.sc_tucker_modes_backward.argtypes = [POINTER(TuckerDesc)] + [c_void_p] * 9
+        L.sc_tucker_modes_backward.restype = c_int
         L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.sc_round_f16.restype = c_int
         L.sc_last_error.restype = c_char_p
@@ -293,6 +306,19 @@ class ScEngineLib:
     def pointwise_linear_backward(self, batch, c_in, c_out, spatial, x, w, gout, gx, gw, gbias, ws, stream=0, addend=0):
         d = PlinDesc(batch, c_in, c_out, spatial)
         self._check(self.lib.sc_pointwise_linear_backward(byref(d), x, w, gout, addend, gx, gw, gbias, ws, stream))
+
+    def tucker_modes_supported(self, fg, rx, ry, mx, my):
+        return bool(self.lib.sc_tucker_modes_supported(byref(TuckerDesc(fg, rx, ry, mx, my))))
+
+    def tucker_modes_forward(self, fg, rx, ry, mx, my, core, ux, uy, t, stream=0):
+        self._check(self.lib.sc_tucker_modes_forward(byref(TuckerDesc(fg, rx, ry, mx, my)), core, ux, uy, t, stream))
+
+    def tucker_modes_workspace_bytes(self, fg, rx, ry, mx, my):
+        return int(self.lib.sc_tucker_modes_workspace_bytes(byref(TuckerDesc(fg, rx, ry, mx, my))))
+
+    def tucker_modes_backward(self, fg, rx, ry, mx, my, core, ux, uy, gt, gcore, gux, guy, ws, stream=0):
+        self._check(self.lib.sc_tucker_modes_backward(byref(TuckerDesc(fg, rx, ry, mx, my)), core, ux, uy, gt, gcore, gux,
+                                                      guy, ws, stream))
 
     def round_f16(self, in_ptr, out_ptr, n, stream=0):
         """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""

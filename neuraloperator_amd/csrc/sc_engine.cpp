@@ -24,6 +24,7 @@
 #include "sc_kernels_fft2p.h"
 #include "sc_kernels_plane.h"
 #include "sc_kernels_pmlp.h"
+#include "sc_kernels_tucker.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -1713,6 +1714,67 @@ extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* 
     default: return sc_fail("sc_engine: pointwise linear map backward: c_in = c_out must be 32 or 64");
   }
   return sc_check_launch("k_plin_bwd");
+}
+
+// ---- Tucker mode factors (sc_kernels_tucker.h)
+static size_t tucker_lds_bytes(const sc_tucker_desc* d, bool bwd) {
+  size_t c = (size_t)d->mx * d->rx + (size_t)d->my * d->ry + (size_t)d->rx * d->ry + (size_t)d->rx * d->my;
+  if (bwd) c += (size_t)d->mx * d->my + (size_t)d->rx * d->my;
+  return c * sizeof(cf32);
+}
+static int tucker_wgs(const sc_tucker_desc* d) { return (int)(d->fg < 512 ? d->fg : 512); }
+
+extern "C" int sc_tucker_modes_supported(const sc_tucker_desc* d) {
+  if (!d || d->fg <= 0 || d->rx <= 0 || d->ry <= 0 || d->mx <= 0 || d->my <= 0) return 0;
+  if (d->mx * d->rx > 256 * SC_TK_UX_PER_THREAD || d->my * d->ry > 256 * SC_TK_UY_PER_THREAD) return 0;
+  return tucker_lds_bytes(d, true) <= 150 * 1024 ? 1 : 0;
+}
+
+template <typename K>
+static int tucker_launch(K kernel, const TuckerModesArgs& g, size_t lds, sc_stream_t st, const char* what) {
+#ifndef SC_EMU
+  if (lds > 64 * 1024)
+    SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+  SC_LAUNCH(kernel, dim3((unsigned)g.n_wg), dim3(256), lds, st, g);
+  return sc_check_launch(what);
+}
+
+extern "C" int sc_tucker_modes_forward(const sc_tucker_desc* d, const float* core, const float* ux, const float* uy,
+                                       float* t, void* stream) {
+  SC_CHECK_ARG(d && core && ux && uy && t, "null argument");
+  SC_CHECK_ARG(sc_tucker_modes_supported(d), "Tucker mode factors: sizes outside the kernel's limits");
+  TuckerModesArgs g;
+  g.core = (const cf32*)core; g.ux = (const cf32*)ux; g.uy = (const cf32*)uy; g.gt = nullptr; g.t = (cf32*)t; g.partial = nullptr;
+  g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d);
+  return tucker_launch(k_tucker_modes_fwd, g, tucker_lds_bytes(d, false), (sc_stream_t)stream, "k_tucker_modes_fwd");
+}
+
+extern "C" size_t sc_tucker_modes_workspace_bytes(const sc_tucker_desc* d) {
+  if (!sc_tucker_modes_supported(d)) return 0;
+  const size_t np = 2 * ((size_t)d->mx * d->rx + (size_t)d->my * d->ry);
+  return (size_t)(tucker_wgs(d) + SC_PMLP_RED_GROUPS) * np * sizeof(float) + 256;
+}
+
+extern "C" int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* core, const float* ux, const float* uy,
+                                        const float* gt, float* gcore, float* gux, float* guy, void* workspace,
+                                        void* stream) {
+  SC_CHECK_ARG(d && core && ux && uy && gt && gcore && gux && guy && workspace, "null argument");
+  SC_CHECK_ARG(sc_tucker_modes_supported(d), "Tucker mode factors: sizes outside the kernel's limits");
+  TuckerModesArgs g;
+  g.core = (const cf32*)core; g.ux = (const cf32*)ux; g.uy = (const cf32*)uy; g.gt = (const cf32*)gt; g.t = (cf32*)gcore;
+  g.partial = (float*)workspace;
+  g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d);
+  sc_stream_t st = (sc_stream_t)stream;
+  int rc = tucker_launch(k_tucker_modes_bwd, g, tucker_lds_bytes(d, true), st, "k_tucker_modes_bwd");
+  if (rc) return rc;
+  const int np = 2 * (g.Mx * g.Rx + g.My * g.Ry);
+  float* stage = g.partial + (size_t)g.n_wg * np;
+  const unsigned nb = (unsigned)((np + 255) / 256);
+  const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
+  SC_LAUNCH(k_pmlp_reduce1, dim3(nb, (unsigned)groups), dim3(256), 0, st, (const float*)g.partial, g.n_wg, groups, np, stage);
+  SC_LAUNCH(k_tucker_scatter, dim3(nb), dim3(256), 0, st, (const float*)stage, groups, np, 2 * g.Mx * g.Rx, gux, guy);
+  return sc_check_launch("k_tucker_scatter");
 }
 
 extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream) {

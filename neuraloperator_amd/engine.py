@@ -500,6 +500,49 @@ class ModeGemmFn(torch.autograd.Function):
         return ga, gb, None, None, None, None
 
 
+class TuckerModes2dFn(torch.autograd.Function):
+    """T[f, g, x, y] = sum_{c, d} core[f, g, c, d] U_x[x, c] U_y[y, d] and its three gradients, one launch each way
+    (sc_tucker_modes_forward / _backward): the batch-independent part of the 2-D Tucker contraction
+    (spectral_convolution.py:76-103)."""
+
+    @staticmethod
+    def forward(ctx, core, ux, uy):
+        _require_gpu(core, "core")
+        lib = _lib.get_lib()
+        f, g, rx, ry = (int(v) for v in core.shape)
+        mx, my = int(ux.shape[0]), int(uy.shape[0])
+        c, a, b = (t.detach().to(torch.complex64).contiguous() for t in (core, ux, uy))
+        out = torch.empty((f, g, mx * my), dtype=torch.complex64, device=core.device)
+        with torch.cuda.device(core.device):
+            lib.tucker_modes_forward(f * g, rx, ry, mx, my, torch.view_as_real(c).data_ptr(), torch.view_as_real(a).data_ptr(),
+                                     torch.view_as_real(b).data_ptr(), torch.view_as_real(out).data_ptr(), _stream())
+        ctx.save_for_backward(c, a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gt):
+        c, a, b = ctx.saved_tensors
+        lib = _lib.get_lib()
+        f, g, rx, ry = (int(v) for v in c.shape)
+        mx, my = int(a.shape[0]), int(b.shape[0])
+        gt = gt.to(torch.complex64).contiguous()
+        gc, ga, gb = torch.empty_like(c), torch.empty_like(a), torch.empty_like(b)
+        ws = torch.empty(lib.tucker_modes_workspace_bytes(f * g, rx, ry, mx, my), dtype=torch.uint8, device=c.device)
+        p = lambda t: torch.view_as_real(t).data_ptr()
+        with torch.cuda.device(c.device):
+            lib.tucker_modes_backward(f * g, rx, ry, mx, my, p(c), p(a), p(b), p(gt), p(gc), p(ga), p(gb), ws.data_ptr(),
+                                      _stream())
+        return gc, ga, gb
+
+
+def tucker_modes_2d(core, ux, uy):
+    """None when the sizes are outside the kernel's limits (the caller then takes the chain of mode GEMMs)."""
+    f, g, rx, ry = (int(v) for v in core.shape)
+    if not _lib.get_lib().tucker_modes_supported(f * g, rx, ry, int(ux.shape[0]), int(uy.shape[0])):
+        return None
+    return TuckerModes2dFn.apply(core, ux, uy)
+
+
 def mode_gemm(a, b, n_modes, conj_a=False, conj_b=False, flags=0):
     return ModeGemmFn.apply(a, b, n_modes, conj_a, conj_b, flags)
 

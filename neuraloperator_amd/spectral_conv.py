@@ -402,6 +402,10 @@ class SpectralConv(BaseSpectralConv):
         skinny shapes; the whole chain is ~0.3 ms here."""
         core = wsl.core
         mode_f = list(wsl.factors[2:])
+        if len(mode_f) == 2 and core.dim() == 4:              # 2-D: core x_x U_x x_y U_y in one launch each way
+            t3 = engine.tucker_modes_2d(core, mode_f[0], mode_f[1])
+            if t3 is not None:
+                return t3
         f, g = int(core.shape[0]), int(core.shape[1])
         ranks = [int(r) for r in core.shape[2:]]
         nd = len(mode_f)
