@@ -180,7 +180,7 @@ int sc_bias_grad(const sc_plan* plan, const float* ghat, int64_t batch, int64_t 
  * (_contract_tucker, neuralop/layers/spectral_convolution.py:76-103: the two mode factors absorbed into the core; fg =
  * the (in-rank, out-rank) pairs).  All arrays complex64 interleaved, contiguous: core (fg, rx, ry), ux (mx, rx),
  * uy (my, ry), t (fg, mx, my).  Backward: gcore / gux / guy overwritten, workspace sc_tucker_modes_workspace_bytes(d).
- * Limits: mx rx <= 3072, my ry <= 1024 and the slices must fit LDS (checked; callers fall back to sc_modegemm). */
+ * Limits: mx, my, rx, ry <= 64, my ry <= 1024 (sc_tucker_modes_supported; callers fall back to sc_modegemm). */
 typedef struct sc_tucker_desc {
   int64_t fg, rx, ry, mx, my;
 } sc_tucker_desc;

@@ -1726,7 +1726,7 @@ static int tucker_wgs(const sc_tucker_desc* d) { return (int)(d->fg < 512 ? d->f
 
 extern "C" int sc_tucker_modes_supported(const sc_tucker_desc* d) {
   if (!d || d->fg <= 0 || d->rx <= 0 || d->ry <= 0 || d->mx <= 0 || d->my <= 0) return 0;
-  if (d->mx * d->rx > 256 * SC_TK_UX_PER_THREAD || d->my * d->ry > 256 * SC_TK_UY_PER_THREAD) return 0;
+  if (d->mx > 64 || d->my > 64 || d->rx > 64 || d->ry > 64 || d->my * d->ry > 256 * SC_TK_UY_PER_THREAD) return 0;
   return tucker_lds_bytes(d, true) <= 150 * 1024 ? 1 : 0;
 }
 

@@ -14,6 +14,8 @@
 #pragma once
 #include "sc_kernels_pmlp.h"
 
+#define SC_TK_TILE 16               // register tile of the big products: 4 interleaved groups of <= 16 (sizes <= 64)
+
 struct TuckerModesArgs {
   const cf32* core;        // [FG][Rx][Ry]
   const cf32* ux;          // [Mx][Rx]
@@ -46,18 +48,32 @@ k_tucker_modes_fwd(TuckerModesArgs g) {
       tmp[i] = acc;
     }
     SC_SYNC();
+    // out[x][y] = sum_c ux[x][c] tmp[c][y]: thread (x, yg) holds the row's outputs y = yg, yg + 4, ... in registers:
+    // one ux read + <= 16 tmp reads (broadcast across the x's of a wave) per 16 multiply-adds
     cf32* dst = g.t + (int64_t)fg * g.Mx * g.My;
-    for (int i = tid; i < g.Mx * g.My; i += 256) {
-      const int x = i / g.My, y = i - x * g.My;
-      cf32 acc = cf_make(0.f, 0.f);
-      for (int c = 0; c < g.Rx; ++c) cf_mac(acc, ux[x * g.Rx + c], tmp[c * g.My + y]);
-      dst[i] = acc;
+    {
+      const int x = tid >> 2, yg = tid & 3;
+      if (x < g.Mx) {
+        cf32 acc[SC_TK_TILE];
+#pragma unroll
+        for (int k = 0; k < SC_TK_TILE; ++k) acc[k] = cf_make(0.f, 0.f);
+        for (int c = 0; c < g.Rx; ++c) {
+          const cf32 a = ux[x * g.Rx + c];
+#pragma unroll
+          for (int k = 0; k < SC_TK_TILE; ++k) {
+            if (4 * k >= g.My) break;                                     // uniform; lanes past the edge re-read the last column
+            cf_mac(acc[k], a, tmp[c * g.My + (yg + 4 * k < g.My ? yg + 4 * k : g.My - 1)]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SC_TK_TILE; ++k)
+          if (yg + 4 * k < g.My) dst[x * g.My + yg + 4 * k] = acc[k];
+      }
     }
   }
 }
 
-// entries of gU_x / gU_y a thread owns: i = tid + 256 k
-#define SC_TK_UX_PER_THREAD 12      // Mx Rx <= 3072
+// entries of gU_y a thread owns: i = tid + 256 k; gU_x: thread (x, cg) owns c = cg, cg + 4, ...
 #define SC_TK_UY_PER_THREAD 4       // My Ry <= 1024
 
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
@@ -72,9 +88,9 @@ k_tucker_modes_bwd(TuckerModesArgs g) {
   const int tid = SC_TID;
   for (int i = tid; i < g.Mx * g.Rx; i += 256) ux[i] = g.ux[i];
   for (int i = tid; i < g.My * g.Ry; i += 256) uy[i] = g.uy[i];
-  cf32 aux[SC_TK_UX_PER_THREAD], auy[SC_TK_UY_PER_THREAD];
+  cf32 aux[SC_TK_TILE], auy[SC_TK_UY_PER_THREAD];
 #pragma unroll
-  for (int k = 0; k < SC_TK_UX_PER_THREAD; ++k) aux[k] = cf_make(0.f, 0.f);
+  for (int k = 0; k < SC_TK_TILE; ++k) aux[k] = cf_make(0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < SC_TK_UY_PER_THREAD; ++k) auy[k] = cf_make(0.f, 0.f);
   for (int fg = SC_BID_X; fg < g.FG; fg += g.n_wg) {
@@ -86,11 +102,30 @@ k_tucker_modes_bwd(TuckerModesArgs g) {
     SC_SYNC();
     for (int i = tid; i < g.Rx * g.My; i += 256) {
       const int c = i / g.My, y = i - c * g.My;
-      cf32 a = cf_make(0.f, 0.f), b = cf_make(0.f, 0.f);
+      cf32 a = cf_make(0.f, 0.f);
       for (int d = 0; d < g.Ry; ++d) cf_mac(a, co[c * g.Ry + d], uy[y * g.Ry + d]);          // tmp[c][y]
-      for (int x = 0; x < g.Mx; ++x) cf_mac_conj_a(b, ux[x * g.Rx + c], gt[x * g.My + y]);   // s[c][y] = sum_x conj(ux) gt
       tmp[i] = a;
-      s[i] = b;
+    }
+    {                                                           // s[c][y] = sum_x conj(ux[x][c]) gt[x][y]: thread (c, yg) of Rx x ng,
+      const int ng = 256 / g.Rx;                                //   ng = 256 / Rx >= 4 column groups so that all four waves work
+      const int c = tid / ng, yg = tid - c * ng;
+      if (c < g.Rx) {
+        cf32 acc[SC_TK_TILE];
+#pragma unroll
+        for (int k = 0; k < SC_TK_TILE; ++k) acc[k] = cf_make(0.f, 0.f);
+        for (int x = 0; x < g.Mx; ++x) {
+          const cf32 a = ux[x * g.Rx + c];
+#pragma unroll
+          for (int k = 0; k < SC_TK_TILE; ++k) {
+            if (ng * k >= g.My) break;
+            const int y = yg + ng * k;
+            cf_mac_conj_a(acc[k], a, gt[x * g.My + (y < g.My ? y : g.My - 1)]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SC_TK_TILE; ++k)
+          if (yg + ng * k < g.My) s[c * g.My + yg + ng * k] = acc[k];
+      }
     }
     SC_SYNC();
     cf32* gc = g.t + (int64_t)fg * g.Rx * g.Ry;
@@ -100,12 +135,17 @@ k_tucker_modes_bwd(TuckerModesArgs g) {
       for (int y = 0; y < g.My; ++y) cf_mac_conj_a(acc, uy[y * g.Ry + d], s[c * g.My + y]);
       gc[i] = acc;
     }
+    {                                                           // gux[x][c] += sum_y gt[x][y] conj(tmp[c][y]), c = cg + 4 k
+      const int x = tid >> 2, cg = tid & 3;
+      if (x < g.Mx) {
+        for (int y = 0; y < g.My; ++y) {
+          const cf32 b = gt[x * g.My + y];
 #pragma unroll
-    for (int k = 0; k < SC_TK_UX_PER_THREAD; ++k) {           // gux[x][c] += sum_y gt[x][y] conj(tmp[c][y])
-      const int i = tid + 256 * k;
-      if (i < g.Mx * g.Rx) {
-        const int x = i / g.Rx, c = i - x * g.Rx;
-        for (int y = 0; y < g.My; ++y) cf_mac_conj_a(aux[k], tmp[c * g.My + y], gt[x * g.My + y]);
+          for (int k = 0; k < SC_TK_TILE; ++k) {
+            if (4 * k >= g.Rx) break;
+            cf_mac_conj_a(aux[k], tmp[(cg + 4 * k < g.Rx ? cg + 4 * k : g.Rx - 1) * g.My + y], b);
+          }
+        }
       }
     }
 #pragma unroll
@@ -118,13 +158,15 @@ k_tucker_modes_bwd(TuckerModesArgs g) {
     }
   }
   float* dst = g.partial + (int64_t)SC_BID_X * 2 * (g.Mx * g.Rx + g.My * g.Ry);
+  {
+    const int x = tid >> 2, cg = tid & 3;
 #pragma unroll
-  for (int k = 0; k < SC_TK_UX_PER_THREAD; ++k) {
-    const int i = tid + 256 * k;
-    if (i < g.Mx * g.Rx) {
-      dst[2 * i] = aux[k].x;
-      dst[2 * i + 1] = aux[k].y;
-    }
+    for (int k = 0; k < SC_TK_TILE; ++k)
+      if (x < g.Mx && cg + 4 * k < g.Rx) {
+        const int i = x * g.Rx + cg + 4 * k;
+        dst[2 * i] = aux[k].x;
+        dst[2 * i + 1] = aux[k].y;
+      }
   }
   dst += 2 * g.Mx * g.Rx;
 #pragma unroll

@@ -17,7 +17,7 @@ def _c(*shape, g):
     return torch.complex(torch.randn(*shape, generator=g), torch.randn(*shape, generator=g))
 
 
-@pytest.mark.parametrize("fg,rx,ry,mx,my", [(40, 36, 19, 64, 33), (7, 3, 5, 6, 4), (600, 4, 2, 8, 5)])
+@pytest.mark.parametrize("fg,rx,ry,mx,my", [(40, 36, 19, 64, 33), (7, 3, 5, 6, 4), (600, 4, 2, 8, 5), (3, 64, 16, 64, 64)])
 def test_tucker_mode_factors(lib, fg, rx, ry, mx, my):
     g = torch.Generator().manual_seed(fg)
     core, ux, uy, gt = _c(fg, rx, ry, g=g), _c(mx, rx, g=g), _c(my, ry, g=g), _c(fg, mx, my, g=g)
@@ -38,6 +38,7 @@ def test_tucker_mode_factors(lib, fg, rx, ry, mx, my):
 
 
 def test_limits(lib):
-    assert not lib.tucker_modes_supported(10, 64, 19, 64, 33)       # 64 x 64 factor: more entries than a thread set holds
-    assert not lib.tucker_modes_supported(10, 36, 40, 64, 33)
-    assert lib.tucker_modes_workspace_bytes(10, 64, 19, 64, 33) == 0
+    assert lib.tucker_modes_supported(10, 64, 16, 64, 64)
+    assert not lib.tucker_modes_supported(10, 36, 19, 128, 33)      # more than 64 modes along a dim
+    assert not lib.tucker_modes_supported(10, 36, 40, 64, 33)       # My Ry beyond a thread set
+    assert lib.tucker_modes_workspace_bytes(10, 36, 19, 128, 33) == 0
