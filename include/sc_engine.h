@@ -152,6 +152,15 @@ typedef struct {
 
 int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                 void* stream);
+/* Two independent contractions: the same results as sc_modegemm(d0, ...) followed by sc_modegemm(d1, ...) (no output
+ * may alias an operand of the other call).  The pair of a layer's backward pass -- d0 the weight gradient
+ * (conj_a, autograd of spectral_convolution.py:21-46 w.r.t. the weight), d1 the gradient of the spectrum (conj_b) --
+ * runs as ONE launch of k_modegemm_dma_bwd when both qualify for the streamed matrix-core kernel: the second round of
+ * one job fills the tail of the other.  sc_modegemm_pair_fused: 1 if a pair with 16-byte aligned operands takes that
+ * launch, 0 if it runs as two. */
+int sc_modegemm_pair(const sc_modegemm_desc* d0, const float* A0, const float* B0, float* C0,
+                     const sc_modegemm_desc* d1, const float* A1, const float* B1, float* C1, void* stream);
+int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1);
 /* C[p, q] += sum_m sum_r opA(A[p, r, m]) * opB(B[r, q, m]) -- the gradient of a mode-independent
  * operand (Tucker / CP factor matrices, autograd of spectral_convolution.py:55-103): lanes run over
  * the modes, wave reduction, one atomic add per (p, q) and mode tile.  C (element offsets

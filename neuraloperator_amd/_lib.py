@@ -133,7 +133,8 @@ class ScEngineLib:
                "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes", "sc_pointwise_linear_forward",
                "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex",
                "sc_pointwise_mlp_backward_ex", "sc_tucker_modes_supported", "sc_tucker_modes_forward",
-               "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes"]
+               "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes", "sc_modegemm_pair",
+               "sc_modegemm_pair_fused"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -163,6 +164,11 @@ class ScEngineLib:
         L.sc_transform_inverse.restype = c_int
         L.sc_modegemm.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_modegemm.restype = c_int
+        L.sc_modegemm_pair.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p,
+                                       POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
+        L.sc_modegemm_pair.restype = c_int
+        L.sc_modegemm_pair_fused.argtypes = [POINTER(ModeGemmDesc), POINTER(ModeGemmDesc)]
+        L.sc_modegemm_pair_fused.restype = c_int
         L.sc_modegemm_msum.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_modegemm_msum.restype = c_int
         L.sc_modegemm_uses_matrix_cores.argtypes = [POINTER(ModeGemmDesc)]
@@ -280,6 +286,22 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    @staticmethod
+    def _gemm_desc(kw):
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    def modegemm_pair(self, kw0, a0, b0, c0, kw1, a1, b1, c1, stream=0):
+        """sc_modegemm(kw0 ...) and sc_modegemm(kw1 ...), one launch when the pair qualifies (a layer's backward)."""
+        d0, d1 = self._gemm_desc(kw0), self._gemm_desc(kw1)
+        self._check(self.lib.sc_modegemm_pair(byref(d0), a0, b0, c0, byref(d1), a1, b1, c1, stream))
+
+    def modegemm_pair_fused(self, kw0, kw1):
+        d0, d1 = self._gemm_desc(kw0), self._gemm_desc(kw1)
+        return bool(self.lib.sc_modegemm_pair_fused(byref(d0), byref(d1)))
 
     def pointwise_mlp_forward(self, batch, c_in, c_hid, c_out, spatial, act, x, w1, b1, w2, b2, skip, gate, out, stream=0):
         d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)

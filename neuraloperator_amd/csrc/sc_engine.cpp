@@ -1372,18 +1372,24 @@ static void dispatch_gemm8(const Gemm8Args& g, int ca, int cb, const cf32* A, co
   else launch_gemm8<GS, QT, SUB, D, IL, true, true>(g, A, B, C, st);
 }
 
-static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+// launch geometry of one contraction; `resident` = workgroups the launch may count on being co-resident
+static bool gemm8_args(const sc_modegemm_desc* d, Gemm8Args& g, int64_t resident_narrow, int64_t resident_wide,
+                       int force_shape /* -1: choose, 0: narrow, 1: wide */) {
   const int64_t cols = 32;
   const int64_t tiles = ((d->P + 31) / 32) * ((d->Q + cols - 1) / cols);
+  bool wide;
+  if (force_shape >= 0) wide = force_shape == 1;
+  else {
 #if defined(SC_G8_FORCE_NARROW)          // measurement builds only
-  const bool wide = false;
+    wide = false;
 #elif defined(SC_G8_FORCE_WIDE)
-  const bool wide = d->n_modes % 16 == 0;
+    wide = d->n_modes % 16 == 0;
 #else
-  const bool wide = d->n_modes % 16 == 0 && tiles >= 8;
+    wide = d->n_modes % 16 == 0 && tiles >= 8;
 #endif
+  }
   const int64_t modes = wide ? 16 : 8;
-  Gemm8Args g;
+  const int64_t resident = wide ? resident_wide : resident_narrow;
   g.P = (int)d->P; g.Q = (int)d->Q; g.R = (int)d->R;
   g.n_mg = (int)(d->n_modes / modes);
   g.n_pb = (int)((d->P + 31) / 32);
@@ -1399,10 +1405,10 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   // inside fewer workgroups instead of queueing a short second round
   const int64_t nblk = (int64_t)g.n_pb * g.n_qb;
   int64_t bpw = 1;
-  if (g.n_mg <= SC_G8_RESIDENT(wide) && g.n_mg * nblk > SC_G8_RESIDENT(wide)) {
+  if (g.n_mg <= resident && g.n_mg * nblk > resident) {
     bpw = nblk;
     for (int64_t b = 1; b <= nblk; ++b)
-      if (g.n_mg * ((nblk + b - 1) / b) <= SC_G8_RESIDENT(wide)) {
+      if (g.n_mg * ((nblk + b - 1) / b) <= resident) {
         bpw = b;
         break;
       }
@@ -1411,9 +1417,50 @@ static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf
   if (cap > 0 && cap <= nblk) bpw = cap;
   g.bpw = (int)bpw;
   g.G = (int)(g.n_mg * ((nblk + bpw - 1) / bpw));
+  return wide;
+}
+
+static int run_gemm8(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  Gemm8Args g;
+  const bool wide = gemm8_args(d, g, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), -1);
   if (wide) dispatch_gemm8<SC_G8_WIDE>(g, d->conj_a, d->conj_b, A, B, C, st);
   else dispatch_gemm8<SC_G8_NARROW>(g, d->conj_a, d->conj_b, A, B, C, st);
   return sc_check_launch("k_modegemm_dma");
+}
+
+// The two contractions of a backward pass (and the bias gradient) as ONE launch of k_modegemm_dma_bwd
+// (sc_kernels_gemm8.h): d0 = weight gradient (conj A), d1 = gradient of the spectrum (conj B).  Returns -1 when the
+// pair does not qualify (the caller then launches them one after the other).
+#ifndef SC_G8_PAIR_BPW                   // measurement builds: 0 = as chosen per job, 1 = all tiles of a mode group in
+#define SC_G8_PAIR_BPW 0                 // one workgroup (both jobs), 2 = that for the weight gradient only
+#endif
+static int run_gemm8_bwd(const sc_modegemm_desc* d0, const cf32* A0, const cf32* B0, cf32* C0,
+                         const sc_modegemm_desc* d1, const cf32* A1, const cf32* B1, cf32* C1,
+                         const Gemm8Bias& bias, sc_stream_t st) {
+#ifdef SC_G8_NO_PAIR                     // measurement builds only: the round-1 sequence of launches
+  return -1;
+#endif
+  if (!gemm8_eligible(d0, A0, B0, C0) || !gemm8_eligible(d1, A1, B1, C1)) return -1;
+  if (!(d0->conj_a && !d0->conj_b && !d1->conj_a && d1->conj_b)) return -1;
+  if (d0->n_modes != d1->n_modes) return -1;
+  // the narrow shape (3 workgroups per CU) for both jobs: the wide one wins on a weight gradient alone but loses
+  // inside a step, and one kernel has one shape
+  Gemm8Args g0, g1;
+  gemm8_args(d0, g0, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), 0);
+  gemm8_args(d1, g1, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), 0);
+#if SC_G8_PAIR_BPW >= 1
+  g0.bpw = g0.n_pb * g0.n_qb; g0.G = g0.n_mg;
+#endif
+#if SC_G8_PAIR_BPW == 1
+  g1.bpw = g1.n_pb * g1.n_qb; g1.G = g1.n_mg;
+#endif
+  if ((g0.G & 7) || (g1.G & 7)) return -1;                    // octets of workgroups alternate between the jobs
+  typedef Gemm8Cfg<4, 2, 2> K;
+  const int64_t nb = bias.ghat ? (bias.channels + K::NW - 1) / K::NW : 0;
+  if ((int64_t)g0.G + g1.G + nb >= ((int64_t)1 << 30)) return -1;
+  SC_LAUNCH((k_modegemm_dma_bwd<SC_G8_NARROW>), dim3((unsigned)(g0.G + g1.G + nb)), dim3(K::THREADS), 0, st,
+            g0, A0, B0, C0, g1, A1, B1, C1, bias);
+  return sc_check_launch("k_modegemm_dma_bwd");
 }
 
 extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
@@ -1456,6 +1503,42 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
     return run_mfma_gemm(d, a, b, c, st);
   if (g.Q > 4) return dispatch_modegemm_conj<4, 8>(g, d->conj_a, d->conj_b, a, b, c, st);
   return dispatch_modegemm_conj<4, 4>(g, d->conj_a, d->conj_b, a, b, c, st);
+}
+
+extern "C" int sc_modegemm_pair(const sc_modegemm_desc* d0, const float* A0, const float* B0, float* C0,
+                                const sc_modegemm_desc* d1, const float* A1, const float* B1, float* C1,
+                                void* stream) {
+  SC_CHECK_ARG(d0 && d1 && A0 && B0 && C0 && A1 && B1 && C1, "null argument");
+  if (d0->P > 0 && d0->Q > 0 && d0->R > 0 && d0->n_modes > 0 && d1->P > 0 && d1->Q > 0 && d1->R > 0) {
+    Gemm8Bias nobias;
+    std::memset(&nobias, 0, sizeof(nobias));
+    const int rc = run_gemm8_bwd(d0, (const cf32*)A0, (const cf32*)B0, (cf32*)C0, d1, (const cf32*)A1,
+                                 (const cf32*)B1, (cf32*)C1, nobias, (sc_stream_t)stream);
+    if (rc >= 0) return rc;
+  }
+  const int rc = sc_modegemm(d0, A0, B0, C0, stream);
+  return rc ? rc : sc_modegemm(d1, A1, B1, C1, stream);
+}
+
+extern "C" int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1) {
+  if (!d0 || !d1) return 0;
+#ifdef SC_G8_NO_PAIR
+  return 0;
+#else
+  static const float* const al = reinterpret_cast<const float*>(uintptr_t(256));   // alignment probe only
+  if (!gemm8_eligible(d0, al, al, al) || !gemm8_eligible(d1, al, al, al)) return 0;
+  if (!(d0->conj_a && !d0->conj_b && !d1->conj_a && d1->conj_b) || d0->n_modes != d1->n_modes) return 0;
+  Gemm8Args g0, g1;
+  gemm8_args(d0, g0, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), 0);
+  gemm8_args(d1, g1, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), 0);
+#if SC_G8_PAIR_BPW >= 1
+  g0.G = g0.n_mg;
+#endif
+#if SC_G8_PAIR_BPW == 1
+  g1.G = g1.n_mg;
+#endif
+  return !((g0.G & 7) || (g1.G & 7));
+#endif
 }
 
 template <bool CA, bool CB>
@@ -1974,33 +2057,49 @@ extern "C" int sc_layer_backward_ex(const sc_plan* p, const sc_layer_desc* L, co
   rc = sc_transform_forward(p, SC_FWD_ADJ_C2R, gy, ghat, B * Co, ws, stream);
   if (rc) return rc;
   // (running {gbias, gW} on a side stream beside {gXhat -> gx} was tried: 165 -> 145 us for the isolated pair,
-  // nothing measurable in the step -- every kernel here fills the chip; profiles/r01_stream_overlap.txt)
-  if (gbias) {
-    rc = sc_bias_grad(p, ghat, B, Co, gbias, stream);
-    if (rc) return rc;
+  // nothing measurable in the step -- every kernel here fills the chip; profiles/r01_stream_overlap.txt.  What
+  // does pay is ONE launch for {gbias, gW, gXhat}: k_modegemm_dma_bwd)
+  const int32_t gflags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
+  sc_modegemm_desc dw, dx;
+  // gW[i,o,m] = sum_b conj(xhat[b,i,m]) * ghat[b,o,m]
+  std::memset(&dw, 0, sizeof(dw));
+  dw.P = Ci; dw.Q = Co; dw.R = B; dw.n_modes = Mk;
+  dw.a_sp = Mk; dw.a_sr = Ci * Mk; dw.a_sm = 1; dw.conj_a = 1;
+  dw.b_sr = Co * Mk; dw.b_sq = Mk; dw.b_sm = 1;
+  dw.c_sp = Co * Wm; dw.c_sq = Wm; dw.c_sm = 1; dw.c_idx = idx;
+  dw.flags = gflags ? gflags : SC_GEMM_STREAM_C;
+  // gxhat[b,i,m] = sum_o ghat[b,o,m] * conj(W[i,o,m])
+  std::memset(&dx, 0, sizeof(dx));
+  dx.P = B; dx.Q = Ci; dx.R = Co; dx.n_modes = Mk;
+  dx.a_sp = Co * Mk; dx.a_sr = Mk; dx.a_sm = 1;
+  dx.b_sr = Wm; dx.b_sq = Co * Wm; dx.b_sm = 1; dx.b_idx = idx; dx.conj_b = 1;
+  dx.c_sp = Ci * Mk; dx.c_sq = Mk; dx.c_sm = 1;
+  dx.flags = gflags;
+  bool paired = false;
+  if (gw && gx && (!gbias || p->dc_index >= 0)) {
+    Gemm8Bias gb;
+    gb.ghat = gbias ? (const cf32*)ghat : nullptr;
+    gb.gbias = gbias; gb.batch = B; gb.channels = Co; gb.modes_per_image = Mk; gb.dc = p->dc_index;
+    rc = run_gemm8_bwd(&dw, (const cf32*)xhat_saved, (const cf32*)ghat, (cf32*)gw,
+                       &dx, (const cf32*)ghat, (const cf32*)w, (cf32*)gxhat, gb, (sc_stream_t)stream);
+    if (rc > 0) return rc;
+    paired = rc == 0;
   }
-  sc_modegemm_desc g;
-  if (gw) {
-    // gW[i,o,m] = sum_b conj(xhat[b,i,m]) * ghat[b,o,m]
-    std::memset(&g, 0, sizeof(g));
-    g.P = Ci; g.Q = Co; g.R = B; g.n_modes = Mk;
-    g.a_sp = Mk; g.a_sr = Ci * Mk; g.a_sm = 1; g.conj_a = 1;
-    g.b_sr = Co * Mk; g.b_sq = Mk; g.b_sm = 1;
-    g.c_sp = Co * Wm; g.c_sq = Wm; g.c_sm = 1; g.c_idx = idx;
-    g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : SC_GEMM_STREAM_C;
-    rc = sc_modegemm(&g, xhat_saved, ghat, gw, stream);
-    if (rc) return rc;
+  if (!paired) {
+    if (gbias) {
+      rc = sc_bias_grad(p, ghat, B, Co, gbias, stream);
+      if (rc) return rc;
+    }
+    if (gw) {
+      rc = sc_modegemm(&dw, xhat_saved, ghat, gw, stream);
+      if (rc) return rc;
+    }
+    if (gx) {
+      rc = sc_modegemm(&dx, ghat, w, gxhat, stream);
+      if (rc) return rc;
+    }
   }
   if (gx) {
-    // gxhat[b,i,m] = sum_o ghat[b,o,m] * conj(W[i,o,m])
-    std::memset(&g, 0, sizeof(g));
-    g.P = B; g.Q = Ci; g.R = Co; g.n_modes = Mk;
-    g.a_sp = Co * Mk; g.a_sr = Mk; g.a_sm = 1;
-    g.b_sr = Wm; g.b_sq = Co * Wm; g.b_sm = 1; g.b_idx = idx; g.conj_b = 1;
-    g.c_sp = Ci * Mk; g.c_sq = Mk; g.c_sm = 1;
-    g.flags = (p->d.flags & SC_PLAN_FORCE_GENERIC) ? SC_GEMM_FORCE_VALU : 0;
-    rc = sc_modegemm(&g, ghat, w, gxhat, stream);
-    if (rc) return rc;
     sc_epilogue ep;
     ep.skip = gx_addend; ep.preact = nullptr; ep.act = SC_ACT_NONE; ep.reserved = 0;
     rc = sc_transform_inverse_ex(p, SC_INV_ADJ_R2C, gxhat, nullptr, Ci, gx_addend ? &ep : nullptr, gx, B * Ci, ws, stream);

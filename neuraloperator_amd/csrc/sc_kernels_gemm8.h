@@ -92,11 +92,11 @@ SC_DEVICE void g8_wait_stage(const int newer_issued) {
 // IL: software-pipelined stage -- the next stage's LDS-DMA requests, operand fetches and operand preparation are
 // issued BETWEEN this stage's MFMAs (a v_mfma_f32_32x32x2_f32 occupies the matrix pipe for 64 cycles, during which
 // the wave may issue other instructions), operands double-buffered in registers
+// the work of ONE workgroup (index gid of g.G) of a contraction; `lds` is the kernel's D-stage ring
 template <int GS, int QT, int SUB, int D, bool IL, bool CA, bool CB>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
-k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, const cf32* __restrict__ B,
+                            cf32* __restrict__ C, int gid, sc_f4* lds) {
   typedef Gemm8Cfg<GS, QT, SUB> K;
-  SC_SHARED __attribute__((aligned(16))) sc_f4 lds[D * K::STAGE_G];
   static_assert(D * K::STAGE_G >= 2048, "the epilogue patch (32 KiB) lives in the ring");
 
   const int tid = SC_TID, lane = tid & 63;
@@ -105,7 +105,6 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
   //      neighbouring units, so the tiles of one mode group (which share A or B) meet in one L2
   const int nblk = g.n_pb * g.n_qb;
   const int chunks = (nblk + g.bpw - 1) / g.bpw;
-  int gid = SC_BID_X;
   if ((g.G & 7) == 0) gid = (gid & 7) * (g.G >> 3) + (gid >> 3);
   const int mg = gid / chunks, ch = gid - mg * chunks;
   constexpr int GPG = 16 / K::MODES;                           // workgroups per group of 16 modes
@@ -375,3 +374,57 @@ k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__
     SC_BARRIER_RAW();                   // the ring is refilled by the next tile
   }
 }
+
+template <int GS, int QT, int SUB, int D, bool IL, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
+k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+  SC_SHARED __attribute__((aligned(16))) sc_f4 lds[D * Gemm8Cfg<GS, QT, SUB>::STAGE_G];
+  g8_workgroup<GS, QT, SUB, D, IL, CA, CB>(g, A, B, C, SC_BID_X, lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// The two contractions of the backward pass in ONE launch (sc_layer_backward):
+//   job 0:  gW[i,o,m]    = sum_b conj(xhat[b,i,m]) ghat[b,o,m]       (conj A)
+//   job 1:  gxhat[b,i,m] = sum_o ghat[b,o,m] conj(W[i,o,m])          (conj B)
+// plus, in a few trailing workgroups, the bias gradient (the sum of ghat's zero-frequency coefficients over the
+// batch).  Why: a contraction launch of the metric shape is 528 workgroups on 256 CUs -- 16 CUs carry three where
+// the average is 2.06, and the launch is as slow as its busiest CU (profiles/r02_gemm_dma_v4_grid_scaling.txt:
+// 512 / 528 / 1024 workgroups take 35.9 / 43.6 / 68.8 us).  Together the two jobs are 1056 workgroups: the second
+// round of the one fills the tail of the other, both read ghat while it is in the Infinity Cache, and two launch
+// boundaries disappear.  Octets of consecutive workgroups (one per XCD) alternate between the jobs, so inside each
+// job workgroup k still runs on XCD k % 8 and g8_workgroup's XCD-aware unit order holds.
+// ------------------------------------------------------------------------------------------
+struct Gemm8Bias {
+  const cf32* ghat;      // null: no bias role
+  float* gbias;
+  int64_t batch, channels, modes_per_image, dc;
+};
+
+template <int GS, int QT, int SUB, int D, bool IL>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
+k_modegemm_dma_bwd(Gemm8Args g0, const cf32* __restrict__ A0, const cf32* __restrict__ B0, cf32* __restrict__ C0,
+                   Gemm8Args g1, const cf32* __restrict__ A1, const cf32* __restrict__ B1, cf32* __restrict__ C1,
+                   Gemm8Bias bias) {
+  typedef Gemm8Cfg<GS, QT, SUB> K;
+  SC_SHARED __attribute__((aligned(16))) sc_f4 lds[D * K::STAGE_G];
+  const int b = SC_BID_X;
+  const int n0 = g0.G >> 3, n1 = g1.G >> 3;                 // octets of each job (the host passes G % 8 == 0)
+  const int nmin = n0 < n1 ? n0 : n1;
+  const int oct = b >> 3, l8 = b & 7;
+  if (oct < n0 + n1) {
+    // octets alternate between the jobs while both have some left; the longer job takes the rest
+    const bool alt = oct < 2 * nmin;
+    const int job = alt ? (oct & 1) : (n1 > n0 ? 1 : 0);
+    const int k = (alt ? (oct >> 1) : (oct - nmin)) * 8 + l8;
+    if (job) g8_workgroup<GS, QT, SUB, D, IL, false, true>(g1, A1, B1, C1, k, lds);
+    else g8_workgroup<GS, QT, SUB, D, IL, true, false>(g0, A0, B0, C0, k, lds);
+  } else {
+    // bias role: wave w of trailing workgroup t takes channel t * NW + w
+    const int tid = SC_TID, lane = tid & 63, w = tid >> 6;
+    const int64_t c = (int64_t)(b - 8 * (n0 + n1)) * K::NW + w;
+    if (c < bias.channels)
+      sc_bias_grad_wave(bias.ghat, bias.gbias, bias.batch, bias.channels, bias.modes_per_image, bias.dc, c, lane,
+                        reinterpret_cast<float*>(lds) + 64 * w);
+  }
+}
+

@@ -443,14 +443,11 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   }
 }
 
-// gbias[c] = sum_b Re(ghat[(b*channels + c) * modes_per_image + dc])
-// one wave per channel, lanes run over the batch, xor-butterfly through LDS-free wave reduction
-SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_WAVE)
-k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias, int64_t batch, int64_t channels,
-            int64_t modes_per_image, int64_t dc) {
-  SC_SHARED float part[SC_WAVE];
-  const int64_t c = SC_BID_X;
-  const int lane = SC_TID;
+// gbias[c] = sum_b Re(ghat[(b * channels + c) * modes_per_image + dc]): one wave per channel, lanes run over the
+// batch, tree reduction through 64 floats of LDS (the order k_bias_grad uses: same bits)
+SC_DEVICE void sc_bias_grad_wave(const cf32* __restrict__ ghat, float* __restrict__ gbias, const int64_t batch,
+                                 const int64_t channels, const int64_t modes_per_image, const int64_t dc,
+                                 const int64_t c, const int lane, float* part) {
   float s = 0.f;
   for (int64_t b = lane; b < batch; b += SC_WAVE) s += ghat[(b * channels + c) * modes_per_image + dc].x;
   part[lane] = s;
@@ -463,6 +460,13 @@ k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias, int64_t ba
     SC_WAVE_SYNC();
   }
   if (lane == 0) gbias[c] = part[0];
+}
+
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_WAVE)
+k_bias_grad(const cf32* __restrict__ ghat, float* __restrict__ gbias, int64_t batch, int64_t channels,
+            int64_t modes_per_image, int64_t dc) {
+  SC_SHARED float part[SC_WAVE];
+  sc_bias_grad_wave(ghat, gbias, batch, channels, modes_per_image, dc, SC_BID_X, SC_TID, part);
 }
 
 

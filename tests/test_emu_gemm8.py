@@ -154,3 +154,77 @@ def test_tiled_operands(lib, layout):
     with pytest.raises(_lib.EngineError):
         lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
                      torch.view_as_real(c).data_ptr(), 0, **dict(kw, a_sg=16, flags=_lib.SC_GEMM_NO_STREAM))
+
+
+# ---- the two contractions of a backward pass in one launch (k_modegemm_dma_bwd, sc_modegemm_pair) ----------------
+def _pair_kw(B, Ci, Co, M):
+    kw_w = dict(P=Ci, Q=Co, R=B, n_modes=M, a_sp=M, a_sr=Ci * M, a_sm=1, conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1,
+                c_sp=Co * M, c_sq=M, c_sm=1, flags=_lib.SC_GEMM_STREAM_C)
+    kw_x = dict(P=B, Q=Ci, R=Co, n_modes=M, a_sp=Co * M, a_sr=M, a_sm=1, b_sr=M, b_sq=Co * M, b_sm=1, conj_b=1,
+                c_sp=Ci * M, c_sq=M, c_sm=1)
+    return kw_w, kw_x
+
+
+# (B, Ci, Co, M, one launch?)
+PAIR = [
+    (64, 64, 64, 16, True),      # 8 + 8 workgroups: octets alternate between the jobs
+    (32, 64, 64, 32, True),      # 16 (weight gradient) + 8: the longer job's trailing octet
+    (64, 32, 32, 64, True),      # 8 + 16: ... the other way round
+    (30, 48, 56, 64, True),      # ragged rows / columns in both jobs, odd r pair count in neither
+    (32, 64, 64, 16, False),     # 8 + 4 workgroups: not whole octets -> two launches, same results
+    (32, 64, 64, 20, False),     # mode count not a multiple of 8 -> generation 1, two launches
+]
+
+
+@pytest.mark.parametrize("case", PAIR, ids=lambda c: "B%d_Ci%d_Co%d_M%d_%s" % (c[:4] + ("one" if c[4] else "two",)))
+def test_backward_pair(lib, case):
+    B, Ci, Co, M, fused = case
+    x, g, w = _rand(B, Ci, M, seed=11), _rand(B, Co, M, seed=12), _rand(Ci, Co, M, seed=13)
+    kw_w, kw_x = _pair_kw(B, Ci, Co, M)
+    assert lib.modegemm_pair_fused(kw_w, kw_x) == fused, "test must exercise the intended launch"
+    gw = torch.full((Ci, Co, M), float("nan"), dtype=torch.complex64)
+    gx = torch.full((B, Ci, M), float("nan"), dtype=torch.complex64)
+    p = lambda t: torch.view_as_real(t).data_ptr()
+    lib.modegemm_pair(kw_w, p(x), p(g), p(gw), kw_x, p(g), p(w), p(gx))
+    # the two single launches give the same BITS (same tiles, same k order)
+    gw1, gx1 = torch.zeros_like(gw), torch.zeros_like(gx)
+    lib.modegemm(p(x), p(g), p(gw1), 0, **kw_w)
+    lib.modegemm(p(g), p(w), p(gx1), 0, **kw_x)
+    assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw1))
+    assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx1))
+    x128, g128, w128 = (t.numpy().astype(np.complex128) for t in (x, g, w))
+    assert rel_l2(gw.numpy(), np.einsum("bim,bom->iom", np.conj(x128), g128)) < TOL
+    assert rel_l2(gx.numpy(), np.einsum("bom,iom->bim", g128, np.conj(w128))) < TOL
+
+
+def test_pair_needs_the_backward_conjugations(lib):
+    kw_w, kw_x = _pair_kw(64, 64, 64, 16)
+    assert lib.modegemm_pair_fused(kw_w, kw_x)
+    assert not lib.modegemm_pair_fused(kw_x, kw_w)                       # roles swapped
+    assert not lib.modegemm_pair_fused(dict(kw_w, conj_a=0), kw_x)
+    assert not lib.modegemm_pair_fused(kw_w, dict(kw_x, flags=_lib.SC_GEMM_NO_STREAM))
+    assert not lib.modegemm_pair_fused(kw_w, dict(kw_x, n_modes=8))
+
+
+def test_layer_backward_takes_the_pair_launch(lib):
+    """sc_layer_backward at a shape whose two contractions qualify (kept block 8 x 8 = 64 modes, 32 x 32 channel
+    tiles): gW, gX-hat AND the bias gradient come out of k_modegemm_dma_bwd; against the oracle, and bit-identical
+    to the launch sequence of a plan that keeps everything off the matrix cores' pair launch"""
+    from engine_runner import layer_fwd_bwd
+    from oracle import spectral_oracle as so
+    B, C, nm, spatial = 32, 32, [8, 8], (16, 16)      # n_modes attribute (last entry already halved: 14 // 2 + 1)
+    kw_w, kw_x = _pair_kw(B, C, C, 64)
+    assert lib.modegemm_pair_fused(kw_w, kw_x)
+    g0 = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, *spatial, generator=g0)
+    gy = torch.randn(B, C, *spatial, generator=g0)
+    w = _rand(C, C, 8, 8, seed=22) * 0.1
+    bias = torch.randn(C, 1, 1, generator=g0)
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, gy, nm, nm)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xr, wr, br, nm, nm)
+    yo.backward(gy)
+    assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(gx.numpy(), xr.grad.numpy()) < TOL
+    assert rel_l2(gw.numpy(), wr.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), br.grad.numpy()) < TOL
