@@ -107,13 +107,15 @@ class PlanHandle:
     def __init__(self, lib, ptr):
         self._lib, self._as_parameter_ = lib, ptr
 
-    def destroy(self):
+    def destroy(self, _finalizing=sys.is_finalizing):
+        # (the default argument keeps sys.is_finalizing reachable while module globals are being torn down: a
+        # handle that outlives its module -- held by a script's globals -- is finalised after `sys` became None)
         ptr, self._as_parameter_ = self._as_parameter_, None
-        if ptr is not None and self._lib is not None and not _SHUTDOWN and not sys.is_finalizing():
-            try:
+        try:
+            if ptr is not None and self._lib is not None and not _SHUTDOWN and not _finalizing():
                 self._lib.sc_plan_destroy(ptr)
-            except Exception:            # interpreter shutdown
-                pass
+        except Exception:                # interpreter shutdown
+            pass
 
     def __del__(self):
         self.destroy()

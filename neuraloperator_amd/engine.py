@@ -352,6 +352,36 @@ def modegemm(a, b, *, P, Q, R, n_modes, a_strides, b_strides, out, c_strides, co
     return out
 
 
+def dense_contract_backward(xhat, w, g, need_x=True, need_w=True):
+    """The two autograd einsums of 'bixy,ioxy->boxy' (spectral_convolution.py:21-46):
+    gxhat[b,i,m] = sum_o g[b,o,m] conj(w[i,o,m]),  gw[i,o,m] = sum_b conj(xhat[b,i,m]) g[b,o,m]
+    on contiguous (b, c, modes...) complex64 blocks.  When both are wanted they go down as ONE call
+    (sc_modegemm_pair: one launch of k_modegemm_dma_bwd when the pair qualifies, else two launches)."""
+    b, ci = xhat.shape[:2]
+    co = w.shape[1]
+    mk = xhat[0, 0].numel()
+    gx = gw = None
+    if need_x and need_w and b and ci and co and mk:
+        kw_w = dict(P=ci, Q=co, R=b, n_modes=mk, a_sp=mk, a_sr=ci * mk, a_sm=1, conj_a=1,
+                    b_sr=co * mk, b_sq=mk, b_sm=1, c_sp=co * mk, c_sq=mk, c_sm=1)
+        kw_x = dict(P=b, Q=ci, R=co, n_modes=mk, a_sp=co * mk, a_sr=mk, a_sm=1,
+                    b_sr=mk, b_sq=co * mk, b_sm=1, conj_b=1, c_sp=ci * mk, c_sq=mk, c_sm=1)
+        gx, gw = torch.empty_like(xhat), torch.empty_like(w)
+        ptr = lambda t: torch.view_as_real(t).data_ptr()
+        with torch.cuda.device(g.device):
+            _lib.get_lib().modegemm_pair(kw_w, ptr(xhat), ptr(g), ptr(gw), kw_x, ptr(g), ptr(w), ptr(gx), _stream())
+        return gx, gw
+    if need_x:
+        gx = torch.empty_like(xhat)
+        modegemm(g, w, P=b, Q=ci, R=co, n_modes=mk, a_strides=(co * mk, mk, 1), b_strides=(mk, co * mk, 1),
+                 conj_b=True, out=gx, c_strides=(ci * mk, mk, 1))
+    if need_w:
+        gw = torch.empty_like(w)
+        modegemm(xhat, g, P=ci, Q=co, R=b, n_modes=mk, a_strides=(mk, ci * mk, 1), conj_a=True,
+                 b_strides=(co * mk, mk, 1), out=gw, c_strides=(co * mk, mk, 1))
+    return gx, gw
+
+
 class ModeContractDenseFn(torch.autograd.Function):
     """yhat[b,o,m] = sum_i xhat[b,i,m] * w[i,o,m] on an arbitrary (e.g. mode-sharded) block of
     modes; w has exactly the mode extents of xhat.  Three sc_modegemm launches in total
@@ -382,15 +412,7 @@ class ModeContractDenseFn(torch.autograd.Function):
         xhat, w = ctx.saved_tensors
         b, ci, co, mk = ctx.dims
         g = g.contiguous().to(torch.complex64)
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(xhat)
-            modegemm(g, w, P=b, Q=ci, R=co, n_modes=mk, a_strides=(co * mk, mk, 1),
-                     b_strides=(mk, co * mk, 1), conj_b=True, out=gx, c_strides=(ci * mk, mk, 1))
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(w)
-            modegemm(xhat, g, P=ci, Q=co, R=b, n_modes=mk, a_strides=(mk, ci * mk, 1), conj_a=True,
-                     b_strides=(co * mk, mk, 1), out=gw, c_strides=(co * mk, mk, 1))
+        gx, gw = dense_contract_backward(xhat, w, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return gx, gw
 
 
@@ -682,19 +704,7 @@ class EngineRawOps:
 
     @staticmethod
     def contract_bwd(xhat, w, ghat, need_x=True, need_w=True):
-        b, ci = xhat.shape[:2]
-        co = w.shape[1]
-        mk = xhat[0, 0].numel()
-        gx = gw = None
-        if need_x:
-            gx = torch.empty_like(xhat)
-            modegemm(ghat, w, P=b, Q=ci, R=co, n_modes=mk, a_strides=(co * mk, mk, 1), b_strides=(mk, co * mk, 1),
-                     conj_b=True, out=gx, c_strides=(ci * mk, mk, 1))
-        if need_w:
-            gw = torch.empty_like(w)
-            modegemm(xhat, ghat, P=ci, Q=co, R=b, n_modes=mk, a_strides=(mk, ci * mk, 1), conj_a=True,
-                     b_strides=(co * mk, mk, 1), out=gw, c_strides=(co * mk, mk, 1))
-        return gx, gw
+        return dense_contract_backward(xhat, w, ghat, need_x, need_w)
 
 
     def tucker_dense(self, core, factors):

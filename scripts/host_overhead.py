@@ -13,17 +13,21 @@ def step():
         p.grad = None
     y = conv(x)
     y.backward(g)
-for _ in range(5):
-    step()
-torch.cuda.synchronize()
+MODE = os.environ.get("MODE", "both")        # module | cabi | both  (one path per rocprofv3 run)
 N = 50
-t0 = time.perf_counter()
-for _ in range(N):
-    step()
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"enqueue {1e3 * (t1 - t0) / N:.3f} ms/step   total {1e3 * (t2 - t0) / N:.3f} ms/step")
+if MODE in ("module", "both"):
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"enqueue {1e3 * (t1 - t0) / N:.3f} ms/step   total {1e3 * (t2 - t0) / N:.3f} ms/step")
+if MODE == "module":
+    sys.exit(0)
 # pure C-ABI sequence without autograd / allocations
 from neuraloperator_amd import _lib
 from neuraloperator_amd.engine import get_plan
