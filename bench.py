@@ -200,15 +200,19 @@ def stage_profile(B, C, spatial, n_modes, flags, iters, io="f32"):
             stages[name][0]()
 
     settle_clocks(sequence)
-    torch.cuda.synchronize()
-    acc = {name: 0.0 for name in order}
+    # every iteration's events are recorded back to back and read after ONE synchronize at the end: a host-side
+    # wait per iteration would idle the GPU between sequences (and let its clocks drop, timed_steps)
+    evs = []
     for _ in range(iters):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)]
         ev[0].record()
         for i, name in enumerate(order):
             stages[name][0]()
             ev[i + 1].record()
-        torch.cuda.synchronize()
+        evs.append(ev)
+    torch.cuda.synchronize()
+    acc = {name: 0.0 for name in order}
+    for ev in evs:
         for i, name in enumerate(order):
             acc[name] += ev[i].elapsed_time(ev[i + 1])
     out = {}

@@ -1334,10 +1334,19 @@ static int run_mfma_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 //            its operands come from HBM there) and stays on the narrow shape
 // Measured (profiles/r02_gemm_dma_diag_grid_layout.txt): ONE workgroup needs ~33 us for its stages whatever the
 // operand layout, segment size, ring depth or instruction order -- so a launch is as fast as its busiest CU.
+#if defined(SC_G8_SHAPE) && SC_G8_SHAPE == 1       // measurement builds: one r pair per stage, deeper ring
+#define SC_G8_NARROW 4, 2, 1, 5, false             // 40 KiB of LDS: 4 workgroups per CU
+#define SC_G8_NARROW_RESIDENT 1024
+#elif defined(SC_G8_SHAPE) && SC_G8_SHAPE == 2
+#define SC_G8_NARROW 4, 2, 1, 4, false             // 32 KiB: 5 per CU
+#define SC_G8_NARROW_RESIDENT 1280
+#else
 #define SC_G8_NARROW 4, 2, 2, 3, false
+#define SC_G8_NARROW_RESIDENT 768
+#endif
 #define SC_G8_WIDE 8, 2, 1, 4, true
 // workgroups the chip holds at once: narrow 3 per CU (48 KiB of LDS each), wide 2 per CU (64 KiB)
-#define SC_G8_RESIDENT(wide) ((wide) ? 512 : 768)
+#define SC_G8_RESIDENT(wide) ((wide) ? 512 : SC_G8_NARROW_RESIDENT)
 static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
   if (d->flags & (SC_GEMM_FORCE_VALU | SC_GEMM_NO_STREAM | SC_GEMM_F16)) return false;
   if (d->accumulate || d->b_idx || d->c_idx) return false;

@@ -65,6 +65,13 @@ struct Gemm8Cfg {
   static constexpr int PPW = SUB * (NPA + NPB) / NW;   // pieces per wave and stage
   static constexpr int RP = 2048 / (16 * GS);          // rows of an epilogue patch (2048 granules = 32 KiB)
   static constexpr int EPW = 32 / GS;                  // patch stores per wave
+  // waves per SIMD the register allocator must leave room for: as many workgroups as fit the CU's 160 KiB of LDS
+  // with a ring of D stages, NW / 4 waves per SIMD each
+  static constexpr int occupancy(const int D) {
+    const int wgs = 163840 / (D * STAGE_G * 16);
+    const int w = wgs * NW / 4;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+  }
   static_assert(GS == 4 || GS == 8, "64- or 128-byte segments");
   static_assert(NPA == NW && NPB % NW == 0, "one A piece and NPB / NW B pieces per wave");
   static_assert(COLS % SP == 0, "column pieces");
@@ -376,7 +383,7 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
 }
 
 template <int GS, int QT, int SUB, int D, bool IL, bool CA, bool CB>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (Gemm8Cfg<GS, QT, SUB>::occupancy(D)))
 k_modegemm_dma(Gemm8Args g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
   SC_SHARED __attribute__((aligned(16))) sc_f4 lds[D * Gemm8Cfg<GS, QT, SUB>::STAGE_G];
   g8_workgroup<GS, QT, SUB, D, IL, CA, CB>(g, A, B, C, SC_BID_X, lds);
@@ -401,7 +408,7 @@ struct Gemm8Bias {
 };
 
 template <int GS, int QT, int SUB, int D, bool IL>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (GS == 8 ? 4 : (QT <= 2 ? 3 : 2)))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC((Gemm8Cfg<GS, QT, SUB>::THREADS), (Gemm8Cfg<GS, QT, SUB>::occupancy(D)))
 k_modegemm_dma_bwd(Gemm8Args g0, const cf32* __restrict__ A0, const cf32* __restrict__ B0, cf32* __restrict__ C0,
                    Gemm8Args g1, const cf32* __restrict__ A1, const cf32* __restrict__ B1, cf32* __restrict__ C1,
                    Gemm8Bias bias) {

@@ -3,6 +3,7 @@
 For every library, at the metric shape (B=32, C=64, 256 x 256, modes 64 x 64 -> 2112 kept modes):
   * `seq`  : k_bias_grad + the weight-gradient launch + the spectrum-gradient launch (sc_bias_grad, sc_modegemm x 2)
   * `pair` : sc_modegemm_pair (one launch of k_modegemm_dma_bwd when the build has it)
+  * `fwd`  : the forward contraction alone (sc_modegemm)
   * `step` : the whole layer step through sc_layer_forward + sc_layer_backward (what bench.py times)
 us per repetition, median and minimum of ROUNDS rounds; plus a bit comparison of `pair` against `seq`."""
 import os
@@ -39,6 +40,10 @@ gxhat = torch.empty(B, C, M, 2, device=dev)
 kw_w = dict(P=C, Q=C, R=B, n_modes=M, a_sp=M, a_sr=C * M, a_sm=1, conj_a=1, b_sr=C * M, b_sq=M, b_sm=1,
             c_sp=C * M, c_sq=M, c_sm=1, flags=_lib.SC_GEMM_STREAM_C)
 kw_x = dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1, b_sr=M, b_sq=C * M, b_sm=1, conj_b=1,
+            c_sp=C * M, c_sq=M, c_sm=1)
+
+
+kw_f = dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1, b_sr=C * M, b_sq=M, b_sm=1,
             c_sp=C * M, c_sq=M, c_sm=1)
 
 
@@ -86,7 +91,10 @@ def make(name, lib):
         lib.layer_backward(plan, L, g.data_ptr(), xhat.data_ptr(), w.data_ptr(), gx.data_ptr(), gw.data_ptr(),
                            gb.data_ptr(), ws.data_ptr(), st)
 
-    return dict(seq=seq, pair=pair, bwd=bwd, step=step)
+    def fwd():
+        lib.modegemm(xhat.data_ptr(), w.data_ptr(), gxhat.data_ptr(), st, **kw_f)
+
+    return dict(fwd=fwd, seq=seq, pair=pair, bwd=bwd, step=step)
 
 
 fns = {name: make(name, lib) for name, lib in libs}
@@ -100,15 +108,16 @@ for name, lib in libs:
     torch.cuda.synchronize()
     print(f"{name:>10}: pair launch fused = {lib.modegemm_pair_fused(kw_w, kw_x)}; gW bits equal "
           f"{torch.equal(gw, r_w)}, gXhat bits equal {torch.equal(gxhat, r_x)}")
-res = {(n, k): [] for n, _ in libs for k in ("seq", "pair", "bwd", "step")}
+KINDS = ("fwd", "seq", "pair", "bwd", "step")
+res = {(n, k): [] for n, _ in libs for k in KINDS}
 for _ in range(ROUNDS):
-    for k in ("seq", "pair", "bwd", "step"):
+    for k in KINDS:
         for n, _ in libs:
             res[(n, k)].append(timed(fns[n][k]))
 print(f"us per repetition (median / min of {ROUNDS} rounds x {REPS} reps), interleaved over the builds")
 for n, _ in libs:
     row = []
-    for k in ("seq", "pair", "bwd", "step"):
+    for k in KINDS:
         v = sorted(res[(n, k)])
         row.append(f"{k} {v[len(v) // 2]:7.1f} / {v[0]:7.1f}")
     print(f"{n:>10}: " + " | ".join(row))
