@@ -77,6 +77,20 @@ struct Gemm8Cfg {
   static_assert(COLS % SP == 0, "column pieces");
 };
 
+// Three real products per complex product on the narrow (non-pipelined) shape:
+//     P1 = Re A Re B,  P2 = Im A Im B,  P3 = (Re A + Im A)(Re B + Im B);   Re C = P1 - P2,  Im C = P3 - P1 - P2
+// Each MFMA then covers 32 COMPLEX columns (N = column, not (column, re / im)): 3 MFMAs per r pair and mode for the
+// 32 x 32 tile instead of 4, one 16-byte B fetch per lane instead of two, no re / im select.  The contraction's
+// matrix-pipe time is NOT hidden behind its memory time (profiles/r02_gemm_dma_v6_ablation.txt: forward 39.9 us,
+// 29.6 us without the MFMAs), so a quarter less of it shows.  Costs: 96 accumulator registers per wave instead of
+// 64 (fine at 3 waves per SIMD; the 8-wave pipelined shape keeps four products) and one more rounding per output:
+// the results differ from the four-product kernels in the last bits (2-3 ulp of |A||B| instead of 1-2).
+#ifdef SC_G8_NO_3M                       // measurement builds only
+#define SC_G8_USE_3M(GS, QT, IL) false
+#else
+#define SC_G8_USE_3M(GS, QT, IL) ((GS) == 4 && (QT) == 2 && !(IL))
+#endif
+
 #ifndef SC_EMU
 SC_DEVICE void sc_store16(cf32* dst, const sc_f4 v, const int stream) {
   if (stream) __builtin_nontemporal_store(v, reinterpret_cast<sc_f4*>(dst));
@@ -132,6 +146,9 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
   const int kk = lane >> 5, li = lane & 31, d = lane & 1, qq = li >> 1;
   const int a_g = (kk * 32 + li) * GS + (w ^ ((li >> K::SH) & (GS - 1)));
   const int b_g = K::A_G + (kk * K::COLS + qq) * GS + (w ^ ((qq >> K::SH) & (GS - 1)));   // + u * 16 * GS
+  constexpr bool M3 = SC_G8_USE_3M(GS, QT, IL);
+  constexpr int NB = M3 ? 1 : QT;                            // B fetches per lane and r pair
+  const int b_g3 = K::A_G + (kk * K::COLS + li) * GS + (w ^ ((li >> K::SH) & (GS - 1)));  // M3: lane = (kk, column li)
   const uint32_t m_re = (CB && d) ? 0x80000000u : 0u;        // B'[(r,re)][(q,1)] = Im B  (conj: -Im B)
   const uint32_t m_im = (!CB && !d) ? 0x80000000u : 0u;      // B'[(r,im)][(q,0)] = -Im B (conj: +Im B)
   const uint32_t dsel = d ? 0xffffffffu : 0u;
@@ -190,23 +207,29 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
     };
     struct Ops {                 // MFMA operands of one stage: (Re, Im) of both modes for this lane's row / columns
       sc_f4 a;
-      sc_f4 b[QT];
+      sc_f4 b[NB];
     };
     auto fetch = [&](const int buf, Ops (&o)[SUB]) {
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
         const sc_f4* sb = lds + buf * K::STAGE_G + sub * K::SUB_G;
         o[sub].a = sb[a_g];
+        if constexpr (M3) o[sub].b[0] = sb[b_g3];
+        else {
 #pragma unroll
-        for (int u = 0; u < QT; ++u) o[sub].b[u] = sb[b_g + u * 16 * GS];
+          for (int u = 0; u < QT; ++u) o[sub].b[u] = sb[b_g + u * 16 * GS];
+        }
       }
     };
 
-    sc_f32x16 acc[2][QT];
+    // four products: acc[mode j][column tile u] = 32 rows x (16 columns x (re, im));
+    // three products: acc[mode j][P1 / P2 / P3] = 32 rows x 32 columns
+    constexpr int NACC = M3 ? 3 : QT;
+    sc_f32x16 acc[2][NACC];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int u = 0; u < QT; ++u)
+      for (int u = 0; u < NACC; ++u)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][u][v] = 0.f;
 
@@ -223,12 +246,14 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
       q.ai[0] = (CA ? -o.a.y : o.a.y) * keep;
       q.ar[1] = o.a.z * keep;
       q.ai[1] = (CA ? -o.a.w : o.a.w) * keep;
+      if constexpr (!M3) {
 #pragma unroll
-      for (int u = 0; u < QT; ++u) {
-        q.br[0][u] = sc_xor_sign(bsel(o.b[u].y, o.b[u].x), m_re);
-        q.bm[0][u] = sc_xor_sign(bsel(o.b[u].x, o.b[u].y), m_im);
-        q.br[1][u] = sc_xor_sign(bsel(o.b[u].w, o.b[u].z), m_re);
-        q.bm[1][u] = sc_xor_sign(bsel(o.b[u].z, o.b[u].w), m_im);
+        for (int u = 0; u < QT; ++u) {
+          q.br[0][u] = sc_xor_sign(bsel(o.b[u].y, o.b[u].x), m_re);
+          q.bm[0][u] = sc_xor_sign(bsel(o.b[u].x, o.b[u].y), m_im);
+          q.br[1][u] = sc_xor_sign(bsel(o.b[u].w, o.b[u].z), m_re);
+          q.bm[1][u] = sc_xor_sign(bsel(o.b[u].z, o.b[u].w), m_im);
+        }
       }
     };
     auto fire = [&](const Prep& q) {
@@ -272,9 +297,29 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
       fetch(st % D, o);
 #pragma unroll
       for (int sub = 0; sub < SUB; ++sub) {
-        Prep q;
-        prep(o[sub], 2 * (st * SUB + sub), q);
-        fire(q);
+        if constexpr (M3) {
+          const int r0 = 2 * (st * SUB + sub);
+          const float keep = (r0 + kk < g.R) ? 1.f : 0.f;       // r values past the end: the duplicate contributes 0
+          const sc_f4 a = o[sub].a, b = o[sub].b[0];
+          const float ar0 = a.x * keep, ai0 = (CA ? -a.y : a.y) * keep, ar1 = a.z * keep, ai1 = (CA ? -a.w : a.w) * keep;
+          const float bi0 = CB ? -b.y : b.y, bi1 = CB ? -b.w : b.w;
+#ifdef SC_G8_ABL_NOMFMA
+          asm volatile("" ::"v"(ar0 + ai0), "v"(ar1 + ai1), "v"(b.x + bi0), "v"(b.z + bi1));
+#else
+          SC_SCHED_BARRIER();
+          sc_mfma_32x32x2(acc[0][0], ar0, b.x);
+          sc_mfma_32x32x2(acc[1][0], ar1, b.z);
+          sc_mfma_32x32x2(acc[0][1], ai0, bi0);
+          sc_mfma_32x32x2(acc[1][1], ai1, bi1);
+          sc_mfma_32x32x2(acc[0][2], ar0 + ai0, b.x + bi0);
+          sc_mfma_32x32x2(acc[1][2], ar1 + ai1, b.z + bi1);
+          SC_SCHED_BARRIER();
+#endif
+        } else {
+          Prep q;
+          prep(o[sub], 2 * (st * SUB + sub), q);
+          fire(q);
+        }
       }
     }
     } else {
@@ -339,22 +384,26 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
     float* patch = reinterpret_cast<float*>(lds);
     SC_WAIT_LGKM0();
     SC_BARRIER_RAW();                   // nobody still reads operands from the ring
-    const int pslot = ((w ^ ((qq >> K::SH) & (GS - 1))) * 4 + d) + qq * 4 * GS;   // + patch row * 64 GS + 2 j
     const bool full = p0 + 32 <= g.P && q0 + K::COLS <= g.Q;
-    bool first = true;
+    if constexpr (M3) {
+      // three products: a lane holds P1 / P2 / P3 of column li (both column tiles at once) for 16 of the 32 rows;
+      // the patch is [16 rows][32 cols][GS slots] granules, lane writes (re, im) of its mode pair as one 8-byte word
+      static_assert(K::RP == 32 && K::COLS == 32, "3-product epilogue: 32 x 32 tiles, 32 KiB patches");
+      const int pslot3 = (li * GS + (w ^ ((li >> K::SH) & (GS - 1)))) * 4;      // + patch row * 128 GS + 2 j
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-#pragma unroll
-      for (int h = 0; h < 32 / K::RP; ++h) {
-        if (!first) SC_BARRIER_RAW();   // the previous patch has been read (reads feed stores: complete)
-        first = false;
+      for (int h = 0; h < 2; ++h) {
+        if (h) SC_BARRIER_RAW();        // the previous patch has been read (reads feed stores: complete)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
             const int row = (v & 3) + 8 * (v >> 2);              // + 4 kk: row of the 32-row tile
-            if (row / K::RP == h)                                // compile time
-              patch[pslot + ((row % K::RP) + 4 * kk) * (64 * GS) + 2 * j] = acc[j][u][v];
+            if (row / 16 == h) {                                 // compile time
+              const float p1 = acc[j][0][v], p2 = acc[j][1][v], p3 = acc[j][2][v];
+              float* dst = patch + pslot3 + ((row % 16) + 4 * kk) * (128 * GS) + 2 * j;
+              dst[0] = p1 - p2;
+              dst[1] = (p3 - p1) - p2;
+            }
           }
         SC_WAIT_LGKM0();
         SC_BARRIER_RAW();
@@ -364,16 +413,54 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
 #pragma unroll
         for (int e = 0; e < K::EPW; ++e) {
           const int sbase = (w * K::EPW + e) * K::SP;            // first segment of this store (uniform)
-          const int prow_ = p0 + h * K::RP + (sbase >> 4);       // uniform
-          const int col = (sbase & 15) + sc_opaque(ls);
-          const int qc = q0 + u * 16 + col;
+          const int prow_ = p0 + h * 16 + (sbase >> 5);          // uniform
+          const int col = (sbase & 31) + sc_opaque(ls);
+          const int qc = q0 + col;
           const int gr = ltq ^ ((col >> K::SH) & (GS - 1));
-#ifdef SC_G8_ABL_NOSTORE             // measurement builds only: everything but the C stores
+#ifdef SC_G8_ABL_NOSTORE
           asm volatile("" ::"v"(val[e]));
           if (g.P < 0)
 #endif
           if (full || (prow_ < g.P && qc < g.Q))
             sc_store16(C + (int64_t)prow_ * g.c_sp + (int64_t)qc * g.c_sq + mC + 2 * gr, val[e], g.stream_c);
+        }
+      }
+    } else {
+      const int pslot = ((w ^ ((qq >> K::SH) & (GS - 1))) * 4 + d) + qq * 4 * GS;   // + patch row * 64 GS + 2 j
+      bool first = true;
+#pragma unroll
+      for (int u = 0; u < QT; ++u) {
+#pragma unroll
+        for (int h = 0; h < 32 / K::RP; ++h) {
+          if (!first) SC_BARRIER_RAW();   // the previous patch has been read (reads feed stores: complete)
+          first = false;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const int row = (v & 3) + 8 * (v >> 2);              // + 4 kk: row of the 32-row tile
+              if (row / K::RP == h)                                // compile time
+                patch[pslot + ((row % K::RP) + 4 * kk) * (64 * GS) + 2 * j] = acc[j][u][v];
+            }
+          SC_WAIT_LGKM0();
+          SC_BARRIER_RAW();
+          sc_f4 val[K::EPW];
+#pragma unroll
+          for (int e = 0; e < K::EPW; ++e) val[e] = lds[(w * K::EPW + e) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < K::EPW; ++e) {
+            const int sbase = (w * K::EPW + e) * K::SP;            // first segment of this store (uniform)
+            const int prow_ = p0 + h * K::RP + (sbase >> 4);       // uniform
+            const int col = (sbase & 15) + sc_opaque(ls);
+            const int qc = q0 + u * 16 + col;
+            const int gr = ltq ^ ((col >> K::SH) & (GS - 1));
+#ifdef SC_G8_ABL_NOSTORE             // measurement builds only: everything but the C stores
+            asm volatile("" ::"v"(val[e]));
+            if (g.P < 0)
+#endif
+            if (full || (prow_ < g.P && qc < g.Q))
+              sc_store16(C + (int64_t)prow_ * g.c_sp + (int64_t)qc * g.c_sq + mC + 2 * gr, val[e], g.stream_c);
+          }
         }
       }
     }
