@@ -94,7 +94,14 @@ def make(name, lib):
     def fwd():
         lib.modegemm(xhat.data_ptr(), w.data_ptr(), gxhat.data_ptr(), st, **kw_f)
 
-    return dict(fwd=fwd, seq=seq, pair=pair, bwd=bwd, step=step)
+    def tf():                       # forward transform alone (k_fft2d_fwd3)
+        lib.transform_forward(plan, _lib.SC_FWD_SCALED, x.data_ptr(), xhat.data_ptr(), B * C, ws.data_ptr(), st)
+
+    def ti():                       # inverse transform alone (k_fft2d_inv3)
+        lib.transform_inverse(plan, _lib.SC_INV_PADDED, xhat.data_ptr(), bias.data_ptr(), C, y.data_ptr(), B * C,
+                              ws.data_ptr(), st)
+
+    return dict(tf=tf, ti=ti, fwd=fwd, seq=seq, pair=pair, bwd=bwd, step=step)
 
 
 fns = {name: make(name, lib) for name, lib in libs}
@@ -108,7 +115,7 @@ for name, lib in libs:
     torch.cuda.synchronize()
     print(f"{name:>10}: pair launch fused = {lib.modegemm_pair_fused(kw_w, kw_x)}; gW bits equal "
           f"{torch.equal(gw, r_w)}, gXhat bits equal {torch.equal(gxhat, r_x)}")
-KINDS = ("fwd", "seq", "pair", "bwd", "step")
+KINDS = tuple(os.environ.get("KINDS", "fwd,seq,pair,bwd,step").split(","))
 res = {(n, k): [] for n, _ in libs for k in KINDS}
 for _ in range(ROUNDS):
     for k in KINDS:
