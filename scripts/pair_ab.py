@@ -1,6 +1,6 @@
 """A-B of the backward pass's contraction stage between engine builds on one box, interleaved:
     python scripts/pair_ab.py [lib.so ...]
-For every library, at the metric shape (B=32, C=64, 256 x 256, modes 64 x 64 -> 2112 kept modes):
+For every library, at the metric shape (B=32, C=64, 256 x 256, modes 64 x 64 -> 2112 kept modes) or SHAPE=...:
   * `seq`  : k_bias_grad + the weight-gradient launch + the spectrum-gradient launch (sc_bias_grad, sc_modegemm x 2)
   * `pair` : sc_modegemm_pair (one launch of k_modegemm_dma_bwd when the build has it)
   * `fwd`  : the forward contraction alone (sc_modegemm)
@@ -22,12 +22,18 @@ dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 ROUNDS = int(os.environ.get("ROUNDS", 7))
 REPS = int(os.environ.get("REPS", 20))
-B, C, H, W, KX, KY = 32, 64, 256, 256, 64, 33
-M = KX * KY
+# SHAPE="B,C,spatial...,kept..." (default: the metric shape; FNO3d 128^3: SHAPE=8,32,128,128,128,32,32,17)
+shape = [int(v) for v in os.environ.get("SHAPE", "32,64,256,256,64,33").split(",")]
+B, C = shape[:2]
+nd = (len(shape) - 2) // 2
+SPATIAL, KEPT = shape[2:2 + nd], shape[2 + nd:]
+M = 1
+for k in KEPT:
+    M *= k
 torch.manual_seed(0)
-x = torch.randn(B, C, H, W, device=dev)
-g = torch.randn(B, C, H, W, device=dev)
-w = torch.randn(C, C, KX, KY, 2, device=dev)
+x = torch.randn(B, C, *SPATIAL, device=dev)
+g = torch.randn(B, C, *SPATIAL, device=dev)
+w = torch.randn(C, C, *KEPT, 2, device=dev)
 bias = torch.randn(C, device=dev)
 y = torch.empty_like(x)
 gx = torch.empty_like(x)
@@ -62,8 +68,8 @@ def timed(fn, reps=REPS):
 
 ctx = {}
 for name, lib in libs:
-    plan = lib.plan_create([H, W], [KX, KY], fft_norm="forward", flags=0)
-    L = lib.layer_desc(B, C, C, [KX, KY], [0, 0])
+    plan = lib.plan_create(SPATIAL, KEPT, fft_norm="forward", flags=0)
+    L = lib.layer_desc(B, C, C, KEPT, [0] * nd)
     ws = torch.empty(lib.layer_workspace_bytes(plan, L), dtype=torch.uint8, device=dev)
     ctx[name] = (plan, L, ws)
 
@@ -114,7 +120,8 @@ for name, lib in libs:
     fns[name]["pair"]()
     torch.cuda.synchronize()
     print(f"{name:>10}: pair launch fused = {lib.modegemm_pair_fused(kw_w, kw_x)}; gW bits equal "
-          f"{torch.equal(gw, r_w)}, gXhat bits equal {torch.equal(gxhat, r_x)}")
+          f"{torch.equal(gw, r_w)}, gXhat bits equal {torch.equal(gxhat, r_x)}; kernels fwd/gW/gX "
+          f"{lib.modegemm_path(**kw_f)}/{lib.modegemm_path(**kw_w)}/{lib.modegemm_path(**kw_x)}")
 KINDS = tuple(os.environ.get("KINDS", "fwd,seq,pair,bwd,step").split(","))
 res = {(n, k): [] for n, _ in libs for k in KINDS}
 for _ in range(ROUNDS):

@@ -30,10 +30,13 @@ def emu_lib():
             for f in os.listdir(os.path.join(ROOT, "neuraloperator_amd", "csrc"))
             if f.endswith((".h", ".cpp"))]
     srcs += [os.path.join(EMU_DIR, "sc_emu_runtime.cpp"), os.path.join(ROOT, "include", "sc_engine.h")]
-    stale = (not os.path.isfile(EMU_LIB)) or any(
-        os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs)
-    if stale:
-        subprocess.check_call(["sh", os.path.join(EMU_DIR, "build_emu.sh")], stdout=subprocess.DEVNULL)
+    import fcntl
+    with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:      # pytest-xdist workers: one builds, the rest wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        stale = (not os.path.isfile(EMU_LIB)) or any(
+            os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs)
+        if stale:
+            subprocess.check_call(["sh", os.path.join(EMU_DIR, "build_emu.sh")], stdout=subprocess.DEVNULL)
     return _lib.ScEngineLib(EMU_LIB)
 
 

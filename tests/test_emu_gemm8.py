@@ -66,9 +66,11 @@ def test_forward(lib, case):
     assert rel_l2(y1.numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (32, 128, 128, 8), (30, 48, 70, 8), (32, 128, 128, 16), (30, 48, 70, 32)])
+@pytest.mark.parametrize("dims", [(32, 64, 64, 16), (32, 128, 128, 8), (30, 48, 70, 8), (32, 128, 128, 16), (30, 48, 70, 32),
+                                  (8, 32, 32, 8), (11, 32, 40, 16)])
 def test_gx_conj_b_transposed(lib, dims):
-    """gxhat[b,i,m] = sum_o ghat[b,o,m] conj(W[i,o,m]): B operand read through transposed strides"""
+    """gxhat[b,i,m] = sum_o ghat[b,o,m] conj(W[i,o,m]): B operand read through transposed strides; the last two: a small
+    batch (8 / 11 rows of one 32-row tile, the rest clamped duplicates that are never stored)"""
     B, Ci, Co, M = dims
     g, w = _rand(B, Co, M, seed=3), _rand(Ci, Co, M, seed=4)
     gx = torch.full((B, Ci, M), float("nan"), dtype=torch.complex64)
@@ -118,6 +120,11 @@ def test_eligibility(lib):
     assert lib.modegemm_path(**dict(base, n_modes=2110)) == 1            # not a multiple of 8
     assert lib.modegemm_path(**dict(base, a_sr=2111)) == 1               # rows not 16-byte aligned
     assert lib.modegemm_path(**dict(base, accumulate=1)) == 0
+    # a small batch streams only against a weight read across its rows (gX-hat), and not below 8 rows
+    gx = dict(base, P=8, b_sr=2112, b_sq=64 * 2112, conj_b=1)
+    assert lib.modegemm_path(**gx) == 2
+    assert lib.modegemm_path(**dict(gx, P=4)) == 0
+    assert lib.modegemm_path(**dict(base, P=8)) == 0                      # forward product: lanes-are-modes kernel
     assert lib.modegemm_path(**dict(base, Q=36)) == 1                    # ragged Tucker rank: 64-row tiles of gen 1
     assert lib.modegemm_path(**dict(base, P=4, Q=128)) == 0              # 4 rows: neither matrix-core kernel
     assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4)) == 2       # hidden 128 weight gradient
