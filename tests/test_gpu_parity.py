@@ -53,6 +53,8 @@ ORACLE_CASES = [
     (32, 64, 64, (32, 32), (16, 16), None),         # channel counts that take the MFMA contraction
     (64, 64, 64, (24, 20), (8, 10), None),          # ... with P = 64 row tiles in forward, odd-ish grid
     (32, 64, 64, (32, 32), (12, 12), (16, 16)),     # ... through the sub-block index tables
+    (8, 32, 32, (32, 32, 32), (16, 16, 16), None),  # small batch: gX-hat streams with clamped rows, backward pair launch
+    (12, 32, 48, (64, 64), (32, 30), None),         # ... 12 rows, ragged second column tile (kept 32 x 16)
 ]
 
 
@@ -248,6 +250,36 @@ def test_mfma_contractions_full_size(lib):
         assert rel_l2(out.cpu().numpy(), ref) < TOL, name
         out2 = run(a, b, torch.empty(shape, dtype=torch.cfloat, device=dev), L.SC_GEMM_FORCE_VALU, **kw)
         assert rel_l2(out2.cpu().numpy(), ref) < TOL, name
+
+
+def test_backward_pair_full_size(lib):
+    """sc_modegemm_pair at the metric shape (one launch of k_modegemm_dma_bwd): bit-identical to the two single
+    launches and within the bar of a complex128 einsum; the same for a small batch (8 rows) at the FNO3d mode count."""
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: torch.view_as_real(t).data_ptr()
+    for B, C, M in [(32, 64, 64 * 33), (8, 32, 32 * 32 * 17)]:
+        torch.manual_seed(5)
+        xh = torch.randn(B, C, M, dtype=torch.cfloat, device=dev)
+        gh = torch.randn(B, C, M, dtype=torch.cfloat, device=dev)
+        w = torch.randn(C, C, M, dtype=torch.cfloat, device=dev)
+        kw_w = dict(P=C, Q=C, R=B, n_modes=M, a_sp=M, a_sr=C * M, a_sm=1, conj_a=1, b_sr=C * M, b_sq=M, b_sm=1,
+                    c_sp=C * M, c_sq=M, c_sm=1)
+        kw_x = dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1, b_sr=M, b_sq=C * M, b_sm=1, conj_b=1,
+                    c_sp=C * M, c_sq=M, c_sm=1)
+        assert lib.modegemm_pair_fused(kw_w, kw_x)
+        gw = torch.full((C, C, M), float("nan"), dtype=torch.cfloat, device=dev)
+        gx = torch.full((B, C, M), float("nan"), dtype=torch.cfloat, device=dev)
+        lib.modegemm_pair(kw_w, p(xh), p(gh), p(gw), kw_x, p(gh), p(w), p(gx), st)
+        gw1, gx1 = torch.empty_like(gw), torch.empty_like(gx)
+        lib.modegemm(p(xh), p(gh), p(gw1), st, **kw_w)
+        lib.modegemm(p(gh), p(w), p(gx1), st, **kw_x)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw1))
+        assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx1))
+        x128, g128, w128 = xh.to(torch.complex128), gh.to(torch.complex128), w.to(torch.complex128)
+        assert rel_l2(gw.cpu().numpy(), torch.einsum("bim,bom->iom", x128.conj(), g128).cpu().numpy()) < TOL
+        assert rel_l2(gx.cpu().numpy(), torch.einsum("bom,iom->bim", g128, w128.conj()).cpu().numpy()) < TOL
 
 
 def test_module_dropin():
