@@ -19,6 +19,13 @@ shape, the reference's op sequence around the engine's convolution against the e
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
 kernel, timed live with events on the launch stream) and, at N=1, `cpu_baseline` (the
 oracle's torch restatement of the reference CPU path on a bounded sample).
+
+The timed region of the contract (W untimed steps, then exactly K steps between barrier + synchronize, max over
+ranks) is run TWICE: straight after set-up (`cold_start` on the line) and again after --settle-ms of the same step
+back to back (`clock_settle`); `value` / `ms_per_step` are the second, settled region.  MI355X clocks need ~20 ms of
+sustained load to settle -- the first ~30 steps after any idle period run 10-25 % slower
+(profiles/r02_clock_ramp.txt) -- so a 25-step region straight after start-up measures the governor, not the kernels
+(see timed_steps and DESIGN.md 5).  --settle-ms 0 reports the cold region alone.
 """
 import argparse
 import json
