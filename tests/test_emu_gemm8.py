@@ -174,12 +174,13 @@ def _pair_kw(B, Ci, Co, M):
 
 # (B, Ci, Co, M, one launch?)
 PAIR = [
-    (64, 64, 64, 16, True),      # 8 + 8 workgroups: octets alternate between the jobs
-    (32, 64, 64, 32, True),      # 16 (weight gradient) + 8: the longer job's trailing octet
+    (32, 32, 32, 64, True),      # 8 + 8 workgroups: octets alternate between the jobs
+    (32, 32, 64, 64, True),      # 16 (weight gradient) + 8: the longer job's trailing octet
     (64, 32, 32, 64, True),      # 8 + 16: ... the other way round
-    (30, 48, 56, 64, True),      # ragged rows / columns in both jobs, odd r pair count in neither
-    (32, 64, 64, 16, False),     # 8 + 4 workgroups: not whole octets -> two launches, same results
-    (32, 64, 64, 20, False),     # mode count not a multiple of 8 -> generation 1, two launches
+    (30, 48, 56, 32, True),      # ragged rows / columns in both jobs (16 + 8 workgroups)
+    (8, 32, 32, 64, True),       # small batch: gX-hat with 8 real rows of its 32-row tile, r loop of 2 stages in gW
+    (32, 32, 32, 8, False),      # 1 + 1 workgroups: not whole octets -> two launches, same results
+    (32, 32, 32, 20, False),     # mode count not a multiple of 8 -> generation 1, two launches
 ]
 
 
@@ -205,7 +206,7 @@ def test_backward_pair(lib, case):
 
 
 def test_pair_needs_the_backward_conjugations(lib):
-    kw_w, kw_x = _pair_kw(64, 64, 64, 16)
+    kw_w, kw_x = _pair_kw(32, 32, 32, 64)
     assert lib.modegemm_pair_fused(kw_w, kw_x)
     assert not lib.modegemm_pair_fused(kw_x, kw_w)                       # roles swapped
     assert not lib.modegemm_pair_fused(dict(kw_w, conj_a=0), kw_x)
@@ -215,11 +216,11 @@ def test_pair_needs_the_backward_conjugations(lib):
 
 def test_layer_backward_takes_the_pair_launch(lib):
     """sc_layer_backward at a shape whose two contractions qualify (kept block 8 x 8 = 64 modes, 32 x 32 channel
-    tiles): gW, gX-hat AND the bias gradient come out of k_modegemm_dma_bwd; against the oracle, and bit-identical
-    to the launch sequence of a plan that keeps everything off the matrix cores' pair launch"""
+    tiles, batch 8: the small-batch rule for gX-hat): gW, gX-hat AND the bias gradient come out of
+    k_modegemm_dma_bwd; against the oracle"""
     from engine_runner import layer_fwd_bwd
     from oracle import spectral_oracle as so
-    B, C, nm, spatial = 32, 32, [8, 8], (16, 16)      # n_modes attribute (last entry already halved: 14 // 2 + 1)
+    B, C, nm, spatial = 8, 32, [8, 8], (16, 16)       # n_modes attribute (last entry already halved: 14 // 2 + 1)
     kw_w, kw_x = _pair_kw(B, C, C, 64)
     assert lib.modegemm_pair_fused(kw_w, kw_x)
     g0 = torch.Generator().manual_seed(21)
