@@ -152,8 +152,10 @@ typedef struct {
 
 int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                 void* stream);
-/* Two independent contractions: the same results as sc_modegemm(d0, ...) followed by sc_modegemm(d1, ...) (no output
- * may alias an operand of the other call).  The pair of a layer's backward pass -- d0 the weight gradient
+/* Two independent contractions: sc_modegemm(d0, ...) followed by sc_modegemm(d1, ...) (no output may alias an operand
+ * of the other call) -- bit-identical to those two calls whenever each of them alone runs the 4-wave streamed shape or
+ * the pair runs as two launches, equal up to the rounding of the last bits otherwise (a job that alone would take the
+ * 8-wave four-product shape, e.g. the weight gradient at hidden 128, runs the 4-wave three-product shape here).  The pair of a layer's backward pass -- d0 the weight gradient
  * (conj_a, autograd of spectral_convolution.py:21-46 w.r.t. the weight), d1 the gradient of the spectrum (conj_b) --
  * runs as ONE launch of k_modegemm_dma_bwd when both qualify for the streamed matrix-core kernel: the second round of
  * one job fills the tail of the other.  sc_modegemm_pair_fused: 1 if a pair with 16-byte aligned operands takes that

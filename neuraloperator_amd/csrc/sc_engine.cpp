@@ -1462,6 +1462,10 @@ static int run_gemm8_bwd(const sc_modegemm_desc* d0, const cf32* A0, const cf32*
   // the narrow shape (3 workgroups per CU) for both jobs: the wide one wins on a weight gradient alone but loses
   // inside a step, and one kernel has one shape
   Gemm8Args g0, g1;
+#ifdef SC_G8_PAIR_NARROW_ONLY            // measurement builds: pair only what would run the narrow shape anyway
+  if (gemm8_args(d0, g0, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), -1) ||
+      gemm8_args(d1, g1, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), -1)) return -1;
+#endif
   gemm8_args(d0, g0, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), 0);
   gemm8_args(d1, g1, SC_G8_RESIDENT(false), SC_G8_RESIDENT(true), 0);
 #if SC_G8_PAIR_BPW >= 1
