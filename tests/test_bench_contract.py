@@ -28,8 +28,8 @@ def test_timed_steps_regions(bench):
     ms, cold, n = bench.timed_steps(step, steps=5, warmup=2, dist=None, dev=None, share=False, settle_ms=20.0)
     # cold region 2 + 5, settling steps, settled region 2 + 5
     assert len(calls) == 2 * (2 + 5) + n
-    assert n == int(20.0 / cold) + 1 and 5 <= n <= 11                    # ~2 ms per step -> ~10 settling steps
-    assert 1.5 < ms < 4.0 and 1.5 < cold < 4.0
+    assert n == int(20.0 / cold) + 1 and 1 <= n <= 11                    # ~2 ms per step -> ~10 settling steps
+    assert ms >= 1.9 and cold >= 1.9                                      # (no upper bounds: a loaded host sleeps longer)
 
 
 def test_settle_zero_reports_the_cold_region(bench):
