@@ -31,7 +31,9 @@
 //    k = (r0, r0+1) for the real parts and again for the imaginary parts, so no lane needs a value another loaded:
 //        A'[p][(r, re)] = Re A,  A'[p][(r, im)] = Im A
 //        B'[(r, re)][(q, 0 / 1)] = Re B / Im B,   B'[(r, im)][(q, 0 / 1)] = -Im B / Re B
-//    (conjugations are sign masks).  4 QT v_mfma_f32_32x32x2_f32 per wave and stage; exact fp32 (k-ordered fma chain);
+//    (conjugations are sign masks).  4 QT v_mfma_f32_32x32x2_f32 per wave and stage; exact fp32 (k-ordered fma chain).
+//    The 4-wave shape uses THREE real products per complex product instead (SC_G8_USE_3M below: N = complex column,
+//    12 MFMAs per stage, one B fetch per lane);
 //  * C leaves through 32 KiB LDS patches ([rows][16 cols][GS slots], same swizzle) as whole segments, 16-byte stores.
 // A workgroup may run several (row block, column block) tiles of its mode group one after the other (bpw): every
 // launch of the metric shape thereby has 264 workgroups, all co-resident.
