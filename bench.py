@@ -508,8 +508,9 @@ def timed_steps(step, steps, warmup, dist, dev, share, settle_ms=SETTLE_MS):
     return _timed_region(step, steps, warmup, dist, dev, share), cold, n
 
 
-def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed):
-    """(step fn, per-GPU batch, global batch, scaling, parallelism tag, conv) of one measurement."""
+def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv_kwargs=None):
+    """(step fn, per-GPU batch, global batch, scaling, parallelism tag, conv) of one measurement.
+    conv_kwargs: extra constructor arguments of the single-GPU layer (extra.tfno_rank01: Tucker weights)."""
     from neuraloperator_amd import SpectralConv
 
     B, C, spatial, n_modes = WORKLOADS[workload]
@@ -535,7 +536,7 @@ def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed):
         b_local, scaling, global_batch, par = B, "strong", B, f"pencil{world}"
         local_spatial[0] = spatial[0] // world
     else:
-        conv = SpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        conv = SpectralConv(C, C, n_modes, engine_flags=flags, **(conv_kwargs or {})).to(dev)
         b_local, scaling, global_batch = B, "weak", B * world
         par = f"dp{world}-allreduce" if world > 1 else "single"
         if world > 1:
@@ -629,21 +630,50 @@ def main():
     # ---- extra measurements (same launch, fewer steps): see the module docstring
     extra = {}
     if not args.no_extras and args.workload == "fno2d_256_m64_c64_b32" and args.io == "f32":
-        todo = [("fno3d_single", "replicas", "fno3d_128_m32_c32_b8")] if world == 1 else \
-            [("dp_allreduce", "replicas", args.workload), ("fno3d_modeshard", "modeshard", "fno3d_128_m32_c32_b8")]
-        for name, par_x, wl in todo:
-            if par_x == parallel and wl == args.workload:
+        # every BASELINE config on the driver-timed line: name, parallelism, workload,
+        # storage type of the real tensors, extra constructor arguments.  Each is bounded: settle + 3 + 10 steps.
+        f32, bf16 = torch.float32, torch.bfloat16
+        tucker = dict(factorization="tucker", rank=0.1, implementation="factorized")
+        todo = [("fno3d_single", "replicas", "fno3d_128_m32_c32_b8", f32, None),          # configs[3], one GPU
+                ("tfno_rank01", "replicas", args.workload, f32, tucker),                  # configs[2]
+                ("fno2d_1024_b4", "replicas", "fno2d_1024_m256_c128_b4", f32, None),      # configs[4]
+                ("bf16_io", "replicas", args.workload, bf16, None)] if world == 1 else \
+            [("dp_allreduce", "replicas", args.workload, f32, None),
+             ("fno3d_modeshard", "modeshard", "fno3d_128_m32_c32_b8", f32, None)]
+        for name, par_x, wl, io_x, kw_x in todo:
+            if par_x == parallel and wl == args.workload and io_x == io_dtype and kw_x is None:
                 continue
-            c = build_case(par_x, wl, world, dev, flags, io_dtype, dist, 99 + rank)
+            try:
+                c = build_case(par_x, wl, world, dev, flags, io_x, dist, 99 + rank, kw_x)
+            except Exception as e:                       # an extra never kills the line
+                extra[name] = {"value": None, "note": f"failed: {type(e).__name__}: {str(e)[:160]}"}
+                continue
             if c is None:
                 extra[name] = {"value": None, "note": f"batch of {wl} not divisible by {world} ranks"}
                 continue
             st_x, bl_x, gb_x, sc_x, tag_x, conv_x = c
             ms_x, cold_x, n_x = timed_steps(st_x, 10, 3, dist, dev, share, args.settle_ms)
+            Bx, Cx, sp_x, nm_x = WORKLOADS[wl]
+            kept_x, _ = kept_block(sp_x, halve_last_mode(nm_x), halve_last_mode(nm_x))
+            Rx, Wbx, Sx, tot_x = alg_bytes(bl_x, Cx, sp_x, kept_x, 2 if io_x == bf16 else 4)
+            formula = "4R+3Wb+9S"
+            if kw_x is not None:                         # Tucker replaces 3 Wb by 3 (core + factors)
+                wbytes = sum(8 * q.numel() for q in conv_x.weight.parameters())
+                tot_x, formula = 4 * Rx + 3 * wbytes + 9 * Sx, "4R+3(core+factors)+9S"
+                extra_cfg = {"weights": f"Tucker rank 0.1 -> core {list(conv_x.weight.core.shape)}, factorized contraction"}
+            else:
+                extra_cfg = {}
+            gbs_x = tot_x / ms_x / 1e6                   # per GPU: bl_x samples' bytes per step time
             extra[name] = {"workload": wl, "parallelism": tag_x, "scaling": sc_x, "B_per_gpu": bl_x,
                            "global_batch": gb_x, "ms_per_step": round(ms_x, 4),
                            "value": round(gb_x / (ms_x / 1e3), 2), "unit": "samples/s", "steps": 10, "warmup": 3,
-                           "cold_start_ms_per_step": round(cold_x, 4), "settle_steps": n_x}
+                           "cold_start_ms_per_step": round(cold_x, 4), "settle_steps": n_x,
+                           "real_tensor_io": "bf16" if io_x == bf16 else "f32",
+                           "alg_bytes_per_step": tot_x, "alg_bytes_formula": formula + " (SURVEY.md 8d), per GPU",
+                           "achieved_GBs": round(gbs_x, 1), "frac_of_8TBs": round(gbs_x / HBM_PEAK_GBS, 4), **extra_cfg}
+            if world > 1:                                # sharded weights: the single-GPU byte model does not apply
+                for k in ("alg_bytes_per_step", "alg_bytes_formula", "achieved_GBs", "frac_of_8TBs"):
+                    extra[name].pop(k)
             del st_x, conv_x, c
             torch.cuda.empty_cache()
         if world == 1:

@@ -372,3 +372,31 @@ SC_HD cf32 cf_conj(const cf32 a) { return cf_make(a.x, -a.y); }
 // multiply by -i  /  +i
 SC_HD cf32 cf_mul_mi(const cf32 a) { return cf_make(a.y, -a.x); }
 SC_HD cf32 cf_mul_pi(const cf32 a) { return cf_make(-a.y, a.x); }
+
+// --------------------------------------------------------------------------- activation of the block epilogue
+// erfc(|x|) by A&S 7.1.26: (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p |x|); |error| <= 1.5e-7 absolute.
+SC_DEVICE float sc_erfc_abs_fast(const float x) {
+  const float ax = fabsf(x);
+#ifndef SC_EMU
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-ax * ax);
+#else
+  const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
+  const float e = expf(-ax * ax);
+#endif
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return p * t * e;
+}
+// gelu(v) = 0.5 v (1 + erf(v / sqrt 2)).  1 + erf(z) = erfc(|z|) for z < 0 and 2 - erfc(|z|) for z >= 0: the
+// negative tail is taken from erfc DIRECTLY, so it does not cancel (1 + erf loses every digit for v < -4).
+// Absolute error of the activation <= 0.5 |v| 1.5e-7 (+ fp32 round-off); both engine paths -- the fused store path and
+// the stand-alone k_epilogue pass -- evaluate this one function, so a shape change never changes the activation's bits.
+SC_DEVICE float sc_erf_fast(const float x) { return copysignf(1.f - sc_erfc_abs_fast(x), x); }
+SC_DEVICE float sc_gelu(const float v) {
+  const float q = sc_erfc_abs_fast(v * 0.70710678118654752440f);
+  return 0.5f * v * (v < 0.f ? q : 2.f - q);
+}
+

@@ -1150,6 +1150,8 @@ extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* 
   if (ep) {
     SC_CHECK_ARG(ep->act == SC_ACT_NONE || ep->act == SC_ACT_GELU, "unknown activation");
     SC_CHECK_ARG(!p->cplx, "complex-data plans take no epilogue");
+    SC_CHECK_ARG(ep->act == SC_ACT_GELU || ep->preact == nullptr,
+                 "preact is the input of the activation: it is written only with SC_ACT_GELU (pass NULL with SC_ACT_NONE)");
     SC_CHECK_ARG(mode == SC_INV_PADDED || ep->act == SC_ACT_NONE,
                  "an activation in the epilogue belongs to the forward inverse transform (SC_INV_PADDED)");
   }

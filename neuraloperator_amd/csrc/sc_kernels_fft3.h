@@ -90,25 +90,9 @@ SC_DEVICE void f3_store(sc_bf16* row, const int lam, const int j, const float v)
 //      LDS-issue bound, so the library erff (~40 instructions; measured: the fused inverse 113 -> 570 us, no faster
 //      than the three elementwise passes it replaces) is replaced by the 5-term rational approximation of
 //      Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in erf, i.e. fp32 round-off class for the activation; 14
-//      instructions with v_rcp_f32 / v_exp_f32).
-SC_DEVICE float sc_erf_fast(const float x) {
-  const float ax = fabsf(x);
-#ifndef SC_EMU
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  const float e = __expf(-ax * ax);
-#else
-  const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
-  const float e = expf(-ax * ax);
-#endif
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = fmaf(-p * t, e, 1.f);
-  return copysignf(r, x);
-}
-SC_DEVICE float sc_gelu(const float v) { return 0.5f * v * (1.f + sc_erf_fast(v * 0.70710678118654752440f)); }
-
+//      instructions with v_rcp_f32 / v_exp_f32).  preact is written only with EPI 2 (SC_ACT_NONE + preact is
+//      rejected at the C-ABI, include/sc_engine.h).
+// (sc_erfc_abs_fast / sc_erf_fast / sc_gelu live in sc_device.h: the stand-alone epilogue pass uses them too)
 template <int EPI, typename IO>
 SC_DEVICE void f3_store_epi(IO* row, const float sk, IO* prow, const int lam, const int j, float v) {
   if (EPI >= 1) v += sk;

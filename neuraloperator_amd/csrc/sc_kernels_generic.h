@@ -482,7 +482,7 @@ k_epilogue(float* __restrict__ y, const float* __restrict__ skip, float* __restr
     float v = y[i] + skip[i];
     if (act == 1) {
       if (preact != nullptr) preact[i] = v;
-      v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));   // memory-bound pass: the library erf is free here
+      v = sc_gelu(v);              // the SAME function as the fused store path (sc_device.h): identical bits on every route
     }
     y[i] = v;
   }

@@ -15,9 +15,12 @@ from .modes import kept_block
 SC_PLAN_COMPLEX = _lib.SC_PLAN_COMPLEX
 SC_PLAN_IO_BF16 = _lib.SC_PLAN_IO_BF16
 _PLAN_LOCK = threading.Lock()
-_PLANS = collections.OrderedDict()     # least recently used first
-MAX_CACHED_PLANS = 64                  # variable-resolution / incremental-mode training creates a plan per
-                                       # (grid, kept modes, frequency map): evicted plans free their device tables
+_PLANS = collections.OrderedDict()     # least recently used first; the key starts with the device index
+MAX_CACHED_PLANS = 512                 # PER DEVICE.  Variable-resolution / incremental-mode training creates a plan per
+                                       # (grid, kept modes, frequency map); a plan is a few KB .. MB of device tables
+_RETIRED = collections.deque()         # (event, handle) of evicted plans: freed on a later cache MISS once the event
+                                       # has passed -- never inline on the hit path (sc_plan_destroy = hipFree = a
+                                       # device-wide synchronisation)
 _NO_BF16_IO = set()       # (device, spatial, kept, norm, flags) the engine has no bfloat16-I/O kernels for
 
 
@@ -48,11 +51,31 @@ def get_plan(device, spatial, kept, fft_norm="forward", flags=0, freq=None, real
                 plan = lib.plan_create(key[1], key[2], fft_norm=fft_norm, flags=flags, freq=freq,
                                        real_col=real_col)
             _PLANS[key] = plan
-            while len(_PLANS) > MAX_CACHED_PLANS:
-                _PLANS.popitem(last=False)      # the handle frees the plan once nothing else references it
+            _evict_and_reap(key[0])
         else:
             _PLANS.move_to_end(key)
     return plan
+
+
+def _evict_and_reap(dev_index):
+    """Called under _PLAN_LOCK on a cache miss (plan creation has just allocated and copied, i.e. already paid a
+    synchronising call).  Plans of `dev_index` beyond the per-device cap are RETIRED behind an event recorded on the
+    current stream; retired plans whose event has completed are released (their handle frees the device tables once
+    no autograd context references it any more)."""
+    mine = [k for k in _PLANS if k[0] == dev_index]
+    for k in mine[:max(len(mine) - MAX_CACHED_PLANS, 0)]:          # least recently used first
+        ev = None
+        if torch.cuda.is_available():
+            with torch.cuda.device(dev_index):
+                ev = torch.cuda.Event()
+                ev.record()
+        _RETIRED.append((ev, _PLANS.pop(k)))
+    for _ in range(len(_RETIRED)):
+        ev, handle = _RETIRED.popleft()
+        if ev is None or ev.query():
+            del handle
+        else:
+            _RETIRED.append((ev, handle))
 
 
 def get_plan_bf16_io(device, spatial, kept, fft_norm, flags):
@@ -76,6 +99,7 @@ def _destroy_plans():
     # (_lib marks the shutdown first: atexit handlers run in reverse order of registration, _lib is imported earlier)
     _lib._SHUTDOWN = True
     _PLANS.clear()
+    _RETIRED.clear()
 
 
 def _stream():

@@ -6,10 +6,26 @@ groups of ``model_parallel_size`` ranks, strided data-parallel groups, and a siz
 fallback when torch.distributed is not initialised.  One process per GPU; backend "nccl"
 (= RCCL over xGMI on ROCm) on GPUs, "gloo" for the CPU tests.
 """
+import logging
 import os
 
 import torch
 import torch.distributed as dist
+
+
+class disable_logging:
+    """Silence `logging` below `level` for the duration of a with-block (reference comm.py:24-32; the reference
+    disables in the constructor and re-enables on exit, kept as is)."""
+
+    def __init__(self, level=logging.ERROR):
+        logging.disable(level=level)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        logging.disable(level=logging.NOTSET)
+
 
 _DATA_PARALLEL_GROUP = None
 _MODEL_PARALLEL_GROUP = None
@@ -22,6 +38,17 @@ def get_world_size():
 
 def get_world_rank():
     return dist.get_rank() if dist.is_initialized() else 0
+
+
+def get_global_rank():
+    """Reference comm.py:54-60: the world rank of this process, looked up through its data-parallel group (the
+    reference passes its `get_local_rank()` -- which is dist.get_rank() there -- as the group rank; the only
+    self-consistent reading is "my rank in the data-parallel group -> my world rank", which is what this returns)."""
+    if not dist.is_initialized():
+        return 0
+    if _DATA_PARALLEL_GROUP is None:
+        return dist.get_rank()
+    return dist.get_global_rank(_DATA_PARALLEL_GROUP, dist.get_rank(group=_DATA_PARALLEL_GROUP))
 
 
 def get_local_rank():

@@ -51,8 +51,8 @@ class AdamW(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = _lib.get_lib()
-        for group in self.param_groups:
+        lib = None                                  # resolved when the first fused-eligible parameter is met: a model
+        for group in self.param_groups:             # without one (CPU-only, bf16, GaLore-only) never needs the library
             beta1, beta2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
@@ -78,6 +78,8 @@ class AdamW(Optimizer):
                 state["step"] += 1
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 view = torch.view_as_real if cplx else (lambda t: t)
+                if lib is None:
+                    lib = _lib.get_lib()
                 with torch.cuda.device(p.device):
                     lib.adamw_step(view(p).data_ptr(), view(grad).data_ptr(), view(m).data_ptr(), view(v).data_ptr(),
                                    p.numel(), cplx, torch.cuda.current_stream().cuda_stream,

@@ -58,6 +58,58 @@ def test_layer_forward_ex(lib, spatial, modes, act):
 
 
 @pytest.mark.parametrize("spatial", [(64, 256), (12, 10)])
+def test_gelu_of_the_epilogue_against_torch(lib, spatial):
+    """The activation itself, pinned for |v| <= 6 on BOTH routes (fused store path / stand-alone pass):
+    zero weight and bias make the layer's output gelu(skip).  Bars (include/sc_engine.h, SC_ACT_GELU): absolute error
+    <= 0.5 |v| 7e-7 (A&S 7.1.26's 1.5e-7 + fp32 round-off of its evaluation), and -- because the negative tail is
+    taken from erfc directly -- a RELATIVE error below 1 % down to v = -6, where 1 + erf(v / sqrt 2) = 2e-9 (the
+    1 + erf form had lost every digit there); the two routes agree bit for bit;
+    preact together with SC_ACT_NONE is refused."""
+    b, c = 1, 2
+    nm = so.halve_last((4, 4))
+    n = b * c * spatial[0] * spatial[1]
+    v = torch.linspace(-6.0, 6.0, n).reshape(b, c, *spatial).contiguous()
+    x = torch.zeros(b, c, *spatial)
+    w = torch.zeros(c, c, *nm, dtype=torch.cfloat)
+    kept, w_start = kept_block(list(spatial), nm, nm)
+    plan = lib.plan_create(list(spatial), kept)
+    L = lib.layer_desc(b, c, c, list(w.shape[2:]), w_start)
+    ws = torch.empty(lib.layer_workspace_bytes(plan, L), dtype=torch.uint8)
+    y = torch.full((b, c, *spatial), float("nan"))
+    xhat = torch.empty(b, c, *kept, 2)
+    wv = torch.view_as_real(w.contiguous())
+    zb = torch.zeros(c)
+    lib.layer_forward_ex(plan, L, x.data_ptr(), wv.data_ptr(), zb.data_ptr(), v.data_ptr(), 0, _lib.SC_ACT_GELU,
+                         y.data_ptr(), xhat.data_ptr(), ws.data_ptr())
+    want = torch.nn.functional.gelu(v.double())
+    err = (y.double() - want).abs()
+    assert bool((err <= 0.5 * v.abs().double() * 7e-7 + 1e-12).all()), float(err.max())
+    rel = err / want.abs().clamp_min(1e-300)
+    assert float(rel[v < -0.1].max()) < 1e-2, float(rel[v < -0.1].max())     # erfc form: no cancellation in the tail
+    assert float(rel[v > 0.1].max()) < 1e-6
+    with pytest.raises(RuntimeError):                                            # preact + SC_ACT_NONE
+        lib.layer_forward_ex(plan, L, x.data_ptr(), wv.data_ptr(), zb.data_ptr(), v.data_ptr(), y.data_ptr(),
+                             _lib.SC_ACT_NONE, y.data_ptr(), xhat.data_ptr(), ws.data_ptr())
+    lib.plan_destroy(plan)
+    # the other route on the same values: same bits
+    other = (12, 10) if spatial == (64, 256) else (64, 256)
+    m = min(n, b * c * other[0] * other[1])
+    vo = torch.zeros(b * c * other[0] * other[1])
+    vo[:m] = v.reshape(-1)[:m]
+    vo = vo.reshape(b, c, *other).contiguous()
+    kept2, w_start2 = kept_block(list(other), nm, nm)
+    plan2 = lib.plan_create(list(other), kept2)
+    L2 = lib.layer_desc(b, c, c, list(w.shape[2:]), w_start2)
+    ws2 = torch.empty(lib.layer_workspace_bytes(plan2, L2), dtype=torch.uint8)
+    y2 = torch.empty(b, c, *other)
+    xhat2 = torch.empty(b, c, *kept2, 2)
+    lib.layer_forward_ex(plan2, L2, torch.zeros(b, c, *other).data_ptr(), wv.data_ptr(), zb.data_ptr(), vo.data_ptr(), 0,
+                         _lib.SC_ACT_GELU, y2.data_ptr(), xhat2.data_ptr(), ws2.data_ptr())
+    assert torch.equal(y2.reshape(-1)[:m], y.reshape(-1)[:m])
+    lib.plan_destroy(plan2)
+
+
+@pytest.mark.parametrize("spatial", [(64, 256), (12, 10)])
 def test_module_forward_fused_with_autograd(spatial):
     from neuraloperator_amd import SpectralConv
     torch.manual_seed(6)

@@ -11,6 +11,14 @@ fp32 (north star).  Sizes:
                  J = 129, K = 256 and the hidden-128 contraction (Q = 128)
   C3  TFNO       B=4,  C=64, 256^2, Tucker rank 0.1 -> (36,36,36,19), factorized and reconstructed,
                  gradients of the core and of every factor
+
+Round 3 (VERDICT r2 "what's weak" 1):
+  C4  at its BENCH batch B=8 (small-batch streamed route + backward pair launch + k_pl128_* + k_ax128 as a layer)
+  C2  bf16 real-tensor I/O at the literal (32, 64, 64, 256^2, modes 64) shape
+  C2  with STRUCTURED inputs -- x = 1e3 + randn (DC-dominated spectrum), a smooth low-frequency field, a 0/1
+      Darcy-like coefficient field lifted to C = 64 -- so the three-real-product contraction (errors scale with
+      |A||B|, not with |Re| and |Im| separately) is judged on non-Gaussian spectra; distance to the float64
+      restatement (forward_np64 / backward_np64) is reported next to the distance to the fp32 reference path.
 """
 import numpy as np
 import pytest
@@ -33,6 +41,7 @@ def lib():
 AT_CONFIG = [
     ("C2_fno2d_256_m64_c64_b32", 32, 64, 64, (256, 256), (64, 64)),
     ("C4_fno3d_128_m32_c32_b2", 2, 32, 32, (128, 128, 128), (32, 32, 32)),
+    ("C4_fno3d_128_m32_c32_b8", 8, 32, 32, (128, 128, 128), (32, 32, 32)),      # BASELINE configs[3] at its bench batch
     ("C5_fno2d_1024_m256_c16to128_b1", 1, 16, 128, (1024, 1024), (256, 256)),
     ("C5_fno2d_1024_m256_c128to16_b2", 2, 128, 16, (1024, 1024), (256, 256)),
 ]
@@ -102,3 +111,101 @@ def test_tfno_tucker_rank01_at_config(impl):
         errs[f"g_factor_{i}"] = rel_l2(conv.weight.factors[i].grad.cpu().numpy(), f.grad.numpy())
     print(impl, " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     assert all(np.isfinite(v) and v < TOL for v in errs.values()), errs
+
+
+def _structured(kind, b, c, n, gen):
+    """Non-Gaussian inputs at the metric shape."""
+    if kind == "dc_offset":                               # |DC| = 1e3 against O(1) everywhere else
+        return 1e3 + torch.randn(b, c, n, n, generator=gen)
+    t = torch.arange(n, dtype=torch.float32) / n
+    yy, xx = torch.meshgrid(t, t, indexing="ij")
+    if kind == "smooth":                                  # a few low modes with 1/k^2 amplitudes + a small rough part
+        f = torch.zeros(b, c, n, n)
+        for k1 in range(0, 5):
+            for k2 in range(0, 5):
+                a = torch.randn(b, c, 1, 1, generator=gen) / (1.0 + k1 * k1 + k2 * k2)
+                ph = 6.2831853 * torch.rand(b, c, 1, 1, generator=gen)
+                f = f + a * torch.cos(6.2831853 * (k1 * yy + k2 * xx) + ph)
+        return f + 1e-3 * torch.randn(b, c, n, n, generator=gen)
+    if kind == "darcy01":                                 # thresholded smooth field: piecewise-constant 0 / 1 coefficient,
+        base = torch.zeros(b, 1, n, n)                    # lifted to C channels by a random 1 x 1 map (as FNO's lifting does)
+        for k1 in range(1, 4):
+            for k2 in range(1, 4):
+                a = torch.randn(b, 1, 1, 1, generator=gen) / (k1 * k1 + k2 * k2)
+                ph = 6.2831853 * torch.rand(b, 1, 1, 1, generator=gen)
+                base = base + a * torch.sin(6.2831853 * (k1 * yy + k2 * xx) + ph)
+        field = (base > 0).float()
+        lift = torch.randn(1, c, 1, 1, generator=gen)
+        off = torch.randn(1, c, 1, 1, generator=gen)
+        return field * lift + off
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["dc_offset", "smooth", "darcy01"])
+def test_metric_shape_structured_inputs(lib, kind):
+    """The metric shape (B = 32, C = 64, 256^2, modes 64: k_fft2d_*3 + the three-product k_modegemm_dma + the pair
+    launch) on inputs whose spectra are NOT iid Gaussian.  Bars: rel-L2 <= 1e-5 against the fp32 reference path
+    (spectral_convolution.py:417-570 via oracle.forward_torch + autograd) -- the north-star bar -- and <= 1e-5 against
+    the float64 restatement, whose distance to the fp32 CPU path is printed beside it."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+
+    b, c, n, modes = 32, 64, 256, (64, 64)
+    gen = torch.Generator().manual_seed(77)
+    nm = halve_last_mode(modes)
+    std = (2 / (2 * c)) ** 0.5
+    x = _structured(kind, b, c, n, gen).contiguous()
+    w = torch.view_as_complex(torch.randn(c, c, *nm, 2, generator=gen) * (std / 2 ** 0.5))
+    bias = std * torch.randn(c, 1, 1, generator=gen)
+    g = _structured(kind, b, c, n, gen).contiguous()          # the upstream gradient is structured as well
+    dev = torch.device("cuda:0")
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x.to(dev), w.to(dev), bias.to(dev), g.to(dev), nm, nm)
+    y, gx, gw, gb = y.cpu().numpy(), gx.cpu().numpy(), gw.cpu().numpy(), gb.cpu().numpy()
+    torch.cuda.empty_cache()
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    ref32 = dict(y=yo.detach().numpy(), gx=xc.grad.numpy(), gw=wc.grad.numpy(), gb=bc.grad.numpy())
+    y64, _ = so.forward_np64(x.numpy(), w.numpy(), bias.numpy(), nm, nm)
+    gx64, gw64, gb64 = so.backward_np64(x.numpy(), w.numpy(), g.numpy(), nm, nm)
+    ref64 = dict(y=y64, gx=gx64, gw=gw64, gb=gb64.reshape(ref32["gb"].shape))
+    got = dict(y=y, gx=gx, gw=gw, gb=gb.reshape(ref32["gb"].shape))
+    e32 = {k: rel_l2(got[k], ref32[k]) for k in got}
+    e64 = {k: rel_l2(got[k], ref64[k]) for k in got}
+    r64 = {k: rel_l2(ref32[k], ref64[k]) for k in got}
+    print(kind, "vs fp32 ref:", " ".join(f"{k}={v:.2e}" for k, v in e32.items()),
+          "| vs fp64:", " ".join(f"{k}={v:.2e}" for k, v in e64.items()),
+          "| fp32 ref vs fp64:", " ".join(f"{k}={v:.2e}" for k, v in r64.items()))
+    assert all(np.isfinite(v) and v < TOL for v in e32.values()), e32
+    assert all(np.isfinite(v) and v < TOL for v in e64.values()), e64
+
+
+def test_bf16_io_at_metric_shape(lib):
+    """BASELINE configs[1] literally: bf16 real-tensor I/O at (B = 32, C = 64 -> 64, 256^2, modes 64).  Bars as in
+    test_bf16_io_vs_oracle: y / gx within one bf16 ulp of the fp32 oracle evaluated on the SAME bf16
+    inputs and > 98 % bit-identical to the rounded oracle; gW / gbias (fp32 in HBM) at 1e-5."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd import _lib as L
+    from neuraloperator_amd.modes import halve_last_mode
+
+    b, c, n, modes = 32, 64, 256, (64, 64)
+    torch.manual_seed(2024)
+    nm = halve_last_mode(modes)
+    std = (2 / (2 * c)) ** 0.5
+    x = torch.randn(b, c, n, n).bfloat16()
+    w = torch.empty(c, c, *nm, dtype=torch.cfloat).normal_(0, std)
+    bias = std * torch.randn(c, 1, 1)
+    g = torch.randn(b, c, n, n).bfloat16()
+    dev = torch.device("cuda:0")
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x.to(dev), w.to(dev), bias.to(dev), g.to(dev), nm, nm, flags=L.SC_PLAN_IO_BF16)
+    assert y.dtype == torch.bfloat16 and gx.dtype == torch.bfloat16
+    y, gx, gw, gb = y.cpu(), gx.cpu(), gw.cpu().numpy(), gb.cpu().numpy()
+    torch.cuda.empty_cache()
+    xc, wc, bc = x.float().requires_grad_(True), w.requires_grad_(True), bias.requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g.float())
+    from test_gpu_parity import _bf16_checks
+    _bf16_checks(y, yo.detach(), "y")
+    _bf16_checks(gx, xc.grad, "gx")
+    assert rel_l2(gw, wc.grad.numpy()) < TOL
+    assert rel_l2(gb.reshape(-1), bc.grad.numpy().reshape(-1)) < TOL

@@ -58,6 +58,19 @@ ORACLE_CASES = [
 ]
 
 
+def _oracle_layer(x, w, bias, g, nm, contract=None):
+    """The CPU oracle (spectral_convolution.py:417-570 restated + autograd) on host copies of device tensors:
+    returns (y, gx, gW or None, gbias) as numpy arrays.  Used by the multi-GPU-layer / fused-block tests so that they
+    compare the HIP path with the ORACLE, not with another HIP path."""
+    from oracle import spectral_oracle as so
+    xc = x.detach().cpu().clone().requires_grad_(True)
+    wc = w.detach().cpu().clone().requires_grad_(contract is None)
+    bc = bias.detach().cpu().clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, list(nm), list(nm), contract=contract)
+    yo.backward(g.detach().cpu())
+    return (yo.detach().numpy(), xc.grad.numpy(), None if wc.grad is None else wc.grad.numpy(), bc.grad.numpy())
+
+
 def _bf16_checks(y, y_ref32, what):
     """bfloat16 result against the fp32 oracle on the same (bf16-valued) inputs: the engine rounds its fp32
     result once (nearest even), so it is within one bf16 ulp of the oracle and bit-identical to the rounded
@@ -562,7 +575,8 @@ def test_block_precision_half_mixed(name):
 def test_mode_parallel_layer_on_device_single_rank():
     """The mode-parallel layer with the engine's stage ops on the GPU (RCCL group of one rank: the all-to-alls
     degenerate, everything else -- stage plumbing, autograd through both transforms and the contraction --
-    is the multi-GPU code path; the sharding itself is covered by the world-size-2 gloo test)."""
+    is the multi-GPU code path; the sharding itself is covered by the world-size-2 / 8 gloo tests).  Reference =
+    the CPU oracle (forward_torch + autograd, Tucker: the oracle's pairwise contraction), not the plain engine layer."""
     import os
     import socket
     import torch.distributed as dist
@@ -583,18 +597,18 @@ def test_mode_parallel_layer_on_device_single_rank():
             mp_conv.weight.copy_(ref.weight.tensor)
             mp_conv.bias.copy_(ref.bias)
         x = torch.randn(4, 6, 32, 24, device=dev, requires_grad=True)
-        xr = x.detach().clone().requires_grad_(True)
         g = torch.randn(4, 5, 32, 24, device=dev)
-        y, yr = mp_conv(x), ref(xr)
+        y = mp_conv(x)
         y.backward(g)
-        yr.backward(g)
         mp_conv.reduce_replicated_grads()
-        assert rel_l2(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < TOL
-        assert rel_l2(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < TOL
-        assert rel_l2(mp_conv.weight.grad.cpu().numpy(), ref.weight.tensor.grad.cpu().numpy()) < TOL
-        assert rel_l2(mp_conv.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < TOL
+        yo, gxo, gwo, gbo = _oracle_layer(x, ref.weight.tensor, ref.bias, g, ref.n_modes)
+        assert rel_l2(y.detach().cpu().numpy(), yo) < TOL
+        assert rel_l2(x.grad.cpu().numpy(), gxo) < TOL
+        assert rel_l2(mp_conv.weight.grad.cpu().numpy(), gwo) < TOL
+        assert rel_l2(mp_conv.bias.grad.cpu().numpy(), gbo) < TOL
         # TFNO weights in the same layer: replicated core / factors, the first mode dim's factor sharded (here: whole)
-        tref = SpectralConv(6, 5, (16, 12), factorization="tucker", rank=0.5, implementation="factorized").to(dev)
+        from oracle import spectral_oracle as so
+        tref = SpectralConv(6, 5, (16, 12), factorization="tucker", rank=0.5, implementation="factorized")
         tmp = ModeParallelSpectralConv(6, 5, (16, 12), factorization="tucker", rank=0.5).to(dev)
         assert tuple(tmp.core.shape) == tuple(tref.weight.core.shape)
         with torch.no_grad():
@@ -605,16 +619,19 @@ def test_mode_parallel_layer_on_device_single_rank():
                 f.copy_(fr)
             tmp.bias.copy_(tref.bias)
         x2 = x.detach().clone().requires_grad_(True)
-        x3 = x.detach().clone().requires_grad_(True)
-        y2, y3 = tmp(x2), tref(x3)
+        y2 = tmp(x2)
         y2.backward(g)
-        y3.backward(g)
         tmp.reduce_replicated_grads()
-        assert rel_l2(y2.detach().cpu().numpy(), y3.detach().cpu().numpy()) < TOL
-        assert rel_l2(x2.grad.cpu().numpy(), x3.grad.cpu().numpy()) < TOL
-        assert rel_l2(tmp.core.grad.cpu().numpy(), tref.weight.core.grad.cpu().numpy()) < TOL
-        for f, fr in zip(tmp.factors, tref.weight.factors):
-            assert rel_l2(f.grad.cpu().numpy(), fr.grad.cpu().numpy()) < TOL
+        core = tref.weight.core.detach().clone().requires_grad_(True)
+        facs = [f.detach().clone().requires_grad_(True) for f in tref.weight.factors]
+        y3, gx3, _, gb3 = _oracle_layer(x, so.reconstruct_tucker(core, facs).detach(), tref.bias, g, tref.n_modes,
+                                        contract=lambda xk, wk: so.contract_tucker(xk, core, facs))
+        assert rel_l2(y2.detach().cpu().numpy(), y3) < TOL
+        assert rel_l2(x2.grad.cpu().numpy(), gx3) < TOL
+        assert rel_l2(tmp.bias.grad.cpu().numpy(), gb3) < TOL
+        assert rel_l2(tmp.core.grad.cpu().numpy(), core.grad.numpy()) < TOL
+        for f, fr in zip(tmp.factors, facs):
+            assert rel_l2(f.grad.cpu().numpy(), fr.grad.numpy()) < TOL
     finally:
         comm.cleanup()
         if dist.is_initialized():
@@ -628,7 +645,7 @@ def test_spatial_parallel_layer_on_device_single_rank(spatial, modes):
     """The spatially decomposed layer with the engine's stage ops on the GPU, one rank (no process
     group: the all-to-alls degenerate): the (N-1)-d real plans with the rows folded into the channel count, the 1-d
     complex axis plans with the centred frequency map, the contraction and autograd through all of them against
-    the plain layer.  Row sharding / padding / exchange: world-size-2 gloo test."""
+    the CPU oracle (forward_torch + autograd).  Row sharding / padding / exchange: world-size-2 gloo test."""
     from neuraloperator_amd import SpectralConv
     from neuraloperator_amd.mpu import SpatialParallelSpectralConv
 
@@ -641,15 +658,14 @@ def test_spatial_parallel_layer_on_device_single_rank(spatial, modes):
         sp.weight.copy_(ref.weight.tensor)
         sp.bias.copy_(ref.bias)
     x = torch.randn(3, 6, *spatial, device=dev, requires_grad=True)
-    xr = x.detach().clone().requires_grad_(True)
     g = torch.randn(3, 5, *spatial, device=dev)
-    y, yr = sp(x), ref(xr)
+    y = sp(x)
     y.backward(g)
-    yr.backward(g)
-    assert rel_l2(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < TOL
-    assert rel_l2(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < TOL
-    assert rel_l2(sp.weight.grad.cpu().numpy(), ref.weight.tensor.grad.cpu().numpy()) < TOL
-    assert rel_l2(sp.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < TOL
+    yo, gxo, gwo, gbo = _oracle_layer(x, ref.weight.tensor, ref.bias, g, ref.n_modes)     # the CPU oracle, not the engine
+    assert rel_l2(y.detach().cpu().numpy(), yo) < TOL
+    assert rel_l2(x.grad.cpu().numpy(), gxo) < TOL
+    assert rel_l2(sp.weight.grad.cpu().numpy(), gwo) < TOL
+    assert rel_l2(sp.bias.grad.cpu().numpy(), gbo) < TOL
 
 
 @pytest.mark.parametrize("name", golden_names("adamw_"))
@@ -794,9 +810,33 @@ def test_pointwise_mlp_pass(chans):
         assert rel_l2(a.grad.cpu().numpy(), b.grad.numpy()) < TOL
 
 
+def _block_oracle(blk, x, g, index):
+    """fno_block.py:377-414 (defaults: linear fno skip, soft-gating MLP skip, ChannelMLP, GELU, post-activation) on
+    the CPU: oracle.forward_torch for the convolution, ATen for the pointwise ops, autograd for every gradient."""
+    import torch.nn.functional as F
+    from oracle import spectral_oracle as so
+    P = {n: q.detach().cpu().clone().requires_grad_(True) for n, q in blk.named_parameters()}
+    xc = x.detach().cpu().clone().requires_grad_(True)
+    s = list(xc.shape)
+    flat = lambda t: t.reshape(s[0], t.shape[1], -1)
+    x_skip_fno = F.conv1d(flat(xc), P[f"fno_skips.{index}.conv.weight"]).reshape(s)
+    x_skip_mlp = P[f"channel_mlp_skips.{index}.weight"] * xc
+    nm = list(blk.convs[index].n_modes)
+    t = so.forward_torch(xc, P[f"convs.{index}.weight.tensor"], P[f"convs.{index}.bias"], nm, nm) + x_skip_fno
+    if index < blk.n_layers - 1:
+        t = F.gelu(t)
+    h = F.gelu(F.conv1d(flat(t), P[f"channel_mlp.{index}.fcs.0.weight"], P[f"channel_mlp.{index}.fcs.0.bias"]))
+    t = F.conv1d(h, P[f"channel_mlp.{index}.fcs.1.weight"], P[f"channel_mlp.{index}.fcs.1.bias"]).reshape(s) + x_skip_mlp
+    if index < blk.n_layers - 1:
+        t = F.gelu(t)
+    t.backward(g.detach().cpu())
+    return t.detach(), xc.grad, {n: q.grad for n, q in P.items() if q.grad is not None}
+
+
 def test_fused_block_forward_matches_op_sequence():
-    """A whole FNO block through the two fused passes against the reference's op sequence on the same parameters
-    (stand-in module with FNOBlocks' attribute surface; the verbatim class is checked on the CPU tier)."""
+    """A whole FNO block through the two fused passes against the reference's op sequence evaluated by the CPU ORACLE
+    on the same parameters (stand-in module with FNOBlocks' attribute surface; the verbatim class is checked on the
+    CPU tier) -- and, as a second check, against the unfused op sequence on the GPU."""
     from block_standin import Blocks
     from neuraloperator_amd import blocks as nb
     dev = torch.device("cuda:0")
@@ -817,13 +857,14 @@ def test_fused_block_forward_matches_op_sequence():
             y = fn(xi)
             y.backward(g)
             res.append((y.detach(), xi.grad.clone(), {n: q.grad.clone() for n, q in blk.named_parameters() if q.grad is not None}))
-        (y0, gx0, gp0), (y1, gx1, gp1) = res
-        assert rel_l2(y1.cpu().numpy(), y0.cpu().numpy()) < TOL and rel_l2(gx1.cpu().numpy(), gx0.cpu().numpy()) < TOL
-        assert set(gp0) == set(gp1)
-        for n in gp0:
-            a, b = gp1[n], gp0[n]
-            a, b = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
-            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, n
+        yo, gxo, gpo = _block_oracle(blk, x, g, index)
+        for y1, gx1, gp1 in res:                              # both GPU routes against the oracle
+            assert rel_l2(y1.cpu().numpy(), yo.numpy()) < TOL and rel_l2(gx1.cpu().numpy(), gxo.numpy()) < TOL
+            assert set(gpo) == set(gp1)
+            for n in gpo:
+                a, b = gp1[n].cpu(), gpo[n]
+                a, b = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
+                assert rel_l2(a.numpy(), b.numpy()) < 2e-5, n
 
 
 @pytest.mark.parametrize("c", [32, 64])
