@@ -124,6 +124,7 @@ enum {
   SC_GEMM_PAIRED = 4,        /* P = 32: two 4-wave workgroups per CU, 5 modes each (A-B; slower from HBM) */
   SC_GEMM_WIDE = 8,          /* 9 modes per workgroup even for a small mode count (A-B / tests)          */
   SC_GEMM_NO_STREAM = 16,    /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
+  SC_GEMM_NO_SB = 64,        /* never take the small-extent streaming kernel (k_modegemm_sb; A-B / tests)  */
   SC_GEMM_F16 = 32           /* the reference's complex-half contraction (fno_block_precision "half" / "mixed",
                               * einsum_utils.py:10-36): operands rounded to float16, four real products summed in
                               * fp32 and rounded to float16, re = t00 - t11, im = t10 + t01 rounded to float16;
@@ -173,7 +174,10 @@ int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const float* B, 
 int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
 /* which kernel a call with 16-byte aligned operands takes: 0 k_modegemm (VALU), 1 k_modegemm_mfma (register-staged
  * matrix-core kernel: sub-blocks through index tables, ragged ranks, factor operands), 2 k_modegemm_s8 (LDS-DMA
- * streamed matrix-core kernel: plain contiguous-mode operands, mode count a multiple of 8) */
+ * streamed matrix-core kernel: plain contiguous-mode operands, mode count a multiple of 8), 3 k_modegemm_sb (round 3:
+ * small-extent streaming kernel on the vector ALUs -- a batch of <= 4 rows against a large weight, or a reduction of
+ * <= 4 terms into a weight-sized result: plain contiguous-mode operands, even mode count, even row strides;
+ * bit-identical to path 0) */
 int sc_modegemm_path(const sc_modegemm_desc* d);
 
 /* out[i] = float16(in[i]) (round to nearest even), kept in fp32 storage; in == out allowed.  The cast points of

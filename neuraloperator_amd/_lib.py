@@ -27,6 +27,7 @@ SC_GEMM_PAIRED = 4
 SC_GEMM_WIDE = 8
 SC_GEMM_NO_STREAM = 16
 SC_GEMM_F16 = 32
+SC_GEMM_NO_SB = 64
 
 
 def SC_GEMM_GRID(n):

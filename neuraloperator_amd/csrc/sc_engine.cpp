@@ -25,6 +25,7 @@
 #include "sc_kernels_plane.h"
 #include "sc_kernels_pmlp.h"
 #include "sc_kernels_tucker.h"
+#include "sc_kernels_sb.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -1250,6 +1251,61 @@ static int dispatch_modegemm_conj(const ModeGemmArgs& g, int ca, int cb, const c
   return sc_check_launch("k_modegemm");
 }
 
+// ---- small-extent streaming path (sc_kernels_sb.h): a batch of <= SB_MAX rows against a large weight, or a
+//      reduction of <= SB_MAX terms into a weight-sized result (BASELINE configs[4], B = 4)
+static int sb_max_extent() {
+  // default 4: the regime where both older kernels are known to be slow.  SC_SB_MAX=n (environment,
+  // read once) moves the bound for A-B runs: 0 switches the path off, 8 also takes FNO3d's B = 8 launches
+  static const int v = [] {
+    const char* e = std::getenv("SC_SB_MAX");
+    const int n = e ? std::atoi(e) : 4;
+    return n < 0 ? 0 : (n > 8 ? 8 : n);
+  }();
+  return v;
+}
+static bool sb_gemm_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
+  if (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_SB)) return false;
+  if (d->accumulate || d->b_idx || d->c_idx || d->a_sg || d->b_sg || d->c_sg) return false;
+  if (d->a_sm != 1 || d->b_sm != 1 || d->c_sm != 1) return false;
+  if ((d->n_modes & 1) || d->n_modes < 2) return false;
+  if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;   // 16-byte aligned rows
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
+  const int64_t small = d->P < d->R ? d->P : d->R;
+  return small <= sb_max_extent();
+}
+
+template <int PT, int QT, int ST>
+static int run_sb_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  SbGemmArgs g;
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.c_sp = d->c_sp; g.c_sq = d->c_sq;
+  g.n_mt = (int)((d->n_modes + 511) / 512);
+  g.n_pt = (int)((d->P + PT - 1) / PT);
+  g.n_qt = (int)((d->Q + QT - 1) / QT);
+  const int64_t total = (int64_t)g.n_mt * g.n_pt * g.n_qt;
+  if (total >= ((int64_t)1 << 30)) return -1;
+  g.per_xcd = (int)((total + 7) / 8);
+  // an operand that exactly one tile reads crosses the chip once: keep it out of the caches the shared one lives in
+  g.nt_a = g.n_qt == 1;
+  g.nt_b = g.n_pt == 1;
+  static const bool plain_c = std::getenv("SC_SB_PLAIN_C") != nullptr;               // A-B
+  g.nt_c = (d->flags & SC_GEMM_STREAM_C) && !plain_c ? 1 : 0;
+  const dim3 grid((unsigned)(8 * g.per_xcd));
+  if (!d->conj_a && !d->conj_b) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, false, false>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
+  else if (d->conj_a && !d->conj_b) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, true, false>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
+  else if (!d->conj_a && d->conj_b) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, false, true>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
+  else SC_LAUNCH((k_modegemm_sb<PT, QT, ST, true, true>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
+  return sc_check_launch("k_modegemm_sb");
+}
+
+static int run_sb_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  // small batch: the register tile holds every row (4 x 4, or 8 x 2 for 5..8 rows), three reduction steps in
+  // flight; short reduction (weight gradient): 4 x 4 outputs per lane, two steps in flight
+  if (d->P <= 4) return run_sb_gemm_t<4, 4, 3>(d, A, B, C, st);
+  if (d->P <= 8 && d->P <= d->R) return run_sb_gemm_t<8, 2, 3>(d, A, B, C, st);
+  return run_sb_gemm_t<4, 4, 2>(d, A, B, C, st);
+}
+
 // ---- matrix-core path (sc_kernels_mfma.h): channel counts that fill 32 x 32 MFMA tiles ----------
 static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
   // one workgroup tile is 32 or 64 rows x 64 columns; ragged problems (Tucker / TT ranks such as 36) take it
@@ -1516,6 +1572,10 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
     else if (d->conj_b) SC_LAUNCH((k_modegemm_f16<false, true>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
     else SC_LAUNCH((k_modegemm_f16<false, false>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
     return sc_check_launch("k_modegemm_f16");
+  }
+  if (sb_gemm_eligible(d, A, B, C)) {
+    const int rc = run_sb_gemm(d, a, b, c, st);
+    if (rc >= 0) return rc;
   }
   if (gemm8_eligible(d, A, B, C)) return run_gemm8(d, a, b, c, st);
   SC_CHECK_ARG(!(d->a_sg || d->b_sg || d->c_sg),
@@ -1893,11 +1953,15 @@ extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream
 
 extern "C" int sc_modegemm_path(const sc_modegemm_desc* d) {
   if (!d) return 0;
+  if (sb_gemm_eligible(d, nullptr, nullptr, nullptr)) return 3;
   if (gemm8_eligible(d, nullptr, nullptr, nullptr)) return 2;
   return !(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d) ? 1 : 0;
 }
 
-extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) { return sc_modegemm_path(d) ? 1 : 0; }
+extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) {
+  const int path = sc_modegemm_path(d);
+  return path == 1 || path == 2;
+}
 
 extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,
                             float* gbias, void* stream) {

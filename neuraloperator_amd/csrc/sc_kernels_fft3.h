@@ -82,6 +82,16 @@ SC_DEVICE void f3_store(float* row, const int lam, const int j, const float v) {
 SC_DEVICE void f3_store(sc_bf16* row, const int lam, const int j, const float v) {
   SC_STORE_STREAM(&row[lam + 32 * j].v, sc_f32_to_bf16_bits(v));
 }
+// A-B (-DSC_F3_INV_PLAIN_GROUPS=n): the first n of the P row groups leave through ordinary stores -- a plain 537 MB
+// writer finishes in 87 us against 118 us for the non-temporal one, but leaves dirty lines the NEXT kernel pays for
+// (profiles/r01_writeback_ubench.txt); a fraction may drain inside the slack of a compute-bound successor
+#ifndef SC_F3_INV_PLAIN_GROUPS
+#define SC_F3_INV_PLAIN_GROUPS 0
+#endif
+SC_DEVICE void f3_store_plain(float* row, const int lam, const int j, const float v) { row[lam + 32 * j] = v; }
+SC_DEVICE void f3_store_plain(sc_bf16* row, const int lam, const int j, const float v) {
+  row[lam + 32 * j].v = sc_f32_to_bf16_bits(v);
+}
 
 // ---- block epilogue fused into the inverse transform's store path (the FNO block computes
 //      act(conv(x) + skip(x)), neuralop/layers/fno_block.py:392-414, as three more R-sized passes):
@@ -152,6 +162,26 @@ SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
 #ifndef SC_F3_TW1_LEGACY
 #define SC_F3_TW1_CS 1
 #endif
+// Round 3: the LAST row stage without LDS.  The pruned radix-4 over n4 (k = k1 + 8 k3 + 64 k4, one k4 per (k1, k3)) is
+// a 4-term sum whose terms were exchanged through LDS (8 ds_write_b64 + 4 ds_read_b128 per lane and round: ~40 % of
+// the row phase's LDS cycles).  Now the wave's two row pairs are laid out so that the four n4 terms of a
+// (k1, k3) sit in lanes l, l ^ 16, l ^ 32, l ^ 48 (post-transpose role: k1 = lane & 7, pair = bit 3, n4 = lane >> 4)
+// and the sum is a two-stage reduce-scatter with v_permlane16_swap / v_permlane32_swap: swap(t[i], t[i + 4]);
+// t[i] += t[i + 4] leaves k3 = i in the lower and k3 = i + 4 in the upper lane of a pair -- uniform code, no selects.
+// Each lane ends with two finished coefficients and stores them to the group tile.  A-B: -DSC_F3_EXCH2_LDS.
+#ifndef SC_F3_EXCH2_LDS
+#define SC_F3_SWAP 1
+#endif
+// explicit LDS read widths (sc_device.h: the compiler's ds_read2_b64 pairs run at half rate).  A-B: -DSC_F3_LDS_PLAIN
+#ifndef SC_F3_LDS_PLAIN
+#define SC_F3_LD64(p) sc_lds_ld64(p)
+#define SC_F3_LD128(p, a, b) sc_lds_ld128((p), (a), (b))
+#else
+#define SC_F3_LD64(p) (*(p))
+#define SC_F3_LD128(p, a, b) do { (a) = (p)[0]; (b) = (p)[1]; } while (0)
+#endif
+#define SC_F3_PS 286    // pair 1 of a wave inside the wave's exchange area: 8 * XRS - 2 (lands in pair 0's row padding;
+                        // shifts its banks by two 8-byte slots: the transposed reads of both pairs are conflict-free)
 template <int H, typename IO>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && sizeof(IO) == 4 ? SC_F3_FWD_OCC : 3))   // bf16 loads need 4 more VGPRs
 k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
@@ -184,7 +214,11 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
   }
 
   // ---- row phase roles and per-lane twiddles
+#ifdef SC_F3_SWAP
+  const int k1l = lane & 7, sq = (lane >> 3) & 1, n4 = lane >> 4;   // after the transpose: lane = (n4, pair, k1)
+#else
   const int k1l = lam >> 2, n4 = lam & 3;             // after the transpose: lane = (k1, n4)
+#endif
 #ifdef SC_F3_TW1_CS
   cf32 tw1[8];
 #pragma unroll
@@ -195,7 +229,12 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
   for (int k = 1; k < 8; ++k) tw1[k] = ctw3_make(tabW[(lam * k) & 255]);    // w256^(n2 k1)
 #endif
   const ctw4* tw2 = tw2t + n4;                           // LDS table [k3][n4]: four adjacent 16-B slots per read
+#ifdef SC_F3_SWAP
+  cf32* xb = xch + w * 16 * SC_F3_XRS + hs * SC_F3_PS;   // this lane's pair as the PRODUCER of the transpose
+  const cf32* xr = xch + w * 16 * SC_F3_XRS + sq * SC_F3_PS + k1l * SC_F3_XRS + n4;   // ... as its CONSUMER
+#else
   cf32* xb = xch + hw * 8 * SC_F3_XRS;
+#endif
 
   // ---- column phase roles: wave w owns columns 8 w .. 8 w + 7, 8 lanes per column
   const int cl = lane >> 3, mu = lane & 7;
@@ -213,8 +252,8 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     cf32 v[8], o[8];
 #pragma unroll
     for (int b1 = 0; b1 < 8; ++b1) {
-      const cf32 zk = zk0[(4 * b1 + (mu >> 1)) * L::TRS];
-      const cf32 zm = zm0[(4 * b1 + (mu >> 1)) * L::TRS];
+      const cf32 zk = SC_F3_LD64(zk0 + (4 * b1 + (mu >> 1)) * L::TRS);
+      const cf32 zm = SC_F3_LD64(zm0 + (4 * b1 + (mu >> 1)) * L::TRS);
       // member 0: A = (Z[k] + conj Z[-k]) / 2;  member 1: B = -i (Z[k] - conj Z[-k]) / 2
       const cf32 sres = cf_make(0.5f * (zk.x + sg * zm.x), 0.5f * (zk.y - sg * zm.y));
       v[b1] = (mu & 1) ? cf_make(sres.y, -sres.x) : sres;
@@ -227,7 +266,7 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     }
     SC_WAVE_SYNC();                                      // the 8 lanes of a column share a wave
 #pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = cb[mu * 8 + m];   // lane mu now plays q1 = mu
+    for (int m = 0; m < 8; m += 2) SC_F3_LD128(cb + mu * 8 + m, v[m], v[m + 1]);   // lane mu now plays q1 = mu
     dft8<-1>(v, o);                                      // over mu -> q2 : F_a[q1 + 8 q2]
 #pragma unroll
     for (int q2 = 0; q2 < 8; ++q2) {
@@ -265,10 +304,8 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
       }
     }
   };
-  prefetch(0, pz[0]);
-#if SC_F3_PF_DEPTH == 2
-  prefetch(1, pz[1]);
-#endif
+#pragma unroll
+  for (int d = 0; d < SC_F3_PF_DEPTH; ++d) prefetch(d, pz[d]);        // depth 1, 2 or 4 (4 rounds = one row group)
 
 #pragma unroll 1
   for (int a = 0; a < P; ++a) {
@@ -291,8 +328,9 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
         xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul_tw(o[k1], tw1[k1].c, tw1[k1].ns, tw1[k1].s);
 #endif
       SC_WAVE_SYNC();
+#ifndef SC_F3_SWAP
 #pragma unroll
-      for (int n3 = 0; n3 < 8; ++n3) v[n3] = xb[k1l * SC_F3_XRS + 4 * n3 + n4];
+      for (int n3 = 0; n3 < 8; ++n3) v[n3] = SC_F3_LD64(xb + k1l * SC_F3_XRS + 4 * n3 + n4);
       SC_WAVE_SYNC();
       dft8<-1>(v, o);                                    // over n3 (n2 = 4 n3 + n4) -> k3
       // last stage (over n4, k = k1 + 8 k3 + 64 k4) is pruned to one k4 per (k1, k3): k4 = 0 for
@@ -321,6 +359,53 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
       }
       SC_WAVE_SYNC();                                   // xb is rewritten by the next round
     }
+#else
+#pragma unroll
+      for (int n3 = 0; n3 < 8; ++n3) v[n3] = SC_F3_LD64(xr + 4 * n3);
+      SC_WAVE_SYNC();                                   // xb is rewritten by the next round
+      dft8<-1>(v, o);                                    // over n3 (n2 = 4 n3 + n4) -> k3
+      // last stage (over n4, k = k1 + 8 k3 + 64 k4), pruned to one k4 per (k1, k3): k4 = 0 for k3 < 4 (k = 0..31),
+      // k4 = 3 for k3 >= 4 (k = -32..-1), plus k = +32 (k1 = 0, k3 = 4, k4 = 0).  Twiddle, then sum the four n4
+      // lanes (l, l ^ 16, l ^ 32, l ^ 48) by a reduce-scatter in registers
+      cf32 t[8];
+      t[0] = o[0];
+#pragma unroll
+      for (int k3 = 1; k3 < 8; ++k3) t[k3] = cf_mul_tw(o[k3], tw2[4 * k3].c, tw2[4 * k3].ns, tw2[4 * k3].s);
+      cf32 e = cf_mul_tw(o[4], tw2[0].c, tw2[0].ns, tw2[0].s), e2 = e;   // k = +32 term (used where k1 = 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                      // bit 4: lower lane keeps k3 = i, upper k3 = i + 4
+        sc_swap16(t[i].x, t[i + 4].x);
+        sc_swap16(t[i].y, t[i + 4].y);
+        t[i] = cf_add(t[i], t[i + 4]);
+      }
+      sc_swap16(e.x, e2.x);                              // (all-reduce: both lanes get own + partner)
+      sc_swap16(e.y, e2.y);
+      e = cf_add(e, e2);
+      e2 = e;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                      // bit 5: lower half keeps i, upper half i + 2
+        sc_swap32(t[i].x, t[i + 2].x);
+        sc_swap32(t[i].y, t[i + 2].y);
+        t[i] = cf_add(t[i], t[i + 2]);
+      }
+      sc_swap32(e.x, e2.x);
+      sc_swap32(e.y, e2.y);
+      e = cf_add(e, e2);
+      {
+        // this lane holds k3 = 4 b4 + 2 b5 + {0, 1} of (pair sq, k1): k = k1 + 8 k3 -> tile column 32 + k (k3 < 4)
+        // or k - 32 (k3 >= 4, i.e. frequency k - 64)
+        const int b4 = n4 & 1, b5 = n4 >> 1;
+        cf32* tr = T + (r * 8 + 2 * w + sq) * L::TRS;
+        const int col = (b4 ? 0 : 32) + k1l + 16 * b5;
+        tr[col] = t[0];
+        tr[col + 8] = t[1];
+        if (k1l == 0 && b5 == 0) {                       // column 32 is transformed after the group loop
+          if (b4 == 0) tr[65 + 2 * a] = e;               // Z[+32]
+          else tr[66 + 2 * a] = t[0];                    // Z[-32]  (k1 = 0, k3 = 4)
+        }
+      }
+    }
+#endif
     SC_SYNC();
     // ---------------- 33 column FFTs of 64 points on T' ----------------
 #ifndef SC_F3_ABL_NOCOL
@@ -444,12 +529,12 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
     dft8<+1>(v, o);                                      // over q2 -> m (row b = m + 8 b1)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const cf32 val = (m == 0) ? o[0] : cf_mul_pk(o[m], cf_conj(tw64[m * 8 + mu]));
+      const cf32 val = (m == 0) ? o[0] : cf_mul_pk(o[m], cf_conj(SC_F3_LD64(tw64 + m * 8 + mu)));
       if (act) cb[m * 8 + mu] = val;
     }
     SC_WAVE_SYNC();
 #pragma unroll
-    for (int q1 = 0; q1 < 8; ++q1) v[q1] = cb[mu * 8 + q1];   // lane mu now plays m = mu
+    for (int q1 = 0; q1 < 8; q1 += 2) SC_F3_LD128(cb + mu * 8 + q1, v[q1], v[q1 + 1]);   // lane mu now plays m = mu
     dft8<+1>(v, o);                                      // over q1 -> b1
     if (act) {
 #pragma unroll
@@ -497,9 +582,9 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
         // lane j builds Z[j] (k1 = j & 7, k3 = j >> 3) and Z[j - 32] (k3 + 4); lane 0 also Z[+32]
         const cf32* ta = T + (2 * p) * L::URS;
         const cf32* tb = ta + L::URS;
-        const cf32 ua = ta[lam], ub = tb[lam];
+        const cf32 ua = SC_F3_LD64(ta + lam), ub = SC_F3_LD64(tb + lam);
         const int cm = (lam == 0) ? 33 + a : 32 - lam;   // column 32 lives in the group's spare column
-        const cf32 va = ta[cm], vb = tb[cm];
+        const cf32 va = SC_F3_LD64(ta + cm), vb = SC_F3_LD64(tb + cm);
         const cf32 zp = (lam == 0) ? cf_make(ua.x + badd, ub.x + badd) : cf_add_i(ua, ub);
         const cf32 zn = cf_conj_add_i(va, vb);
         cf32* zr = xb + (lam & 7) * SC_F3_XRS + (lam >> 3);
@@ -513,7 +598,8 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
         const cf32* zr = xb + k1l * SC_F3_XRS;
         cf32 xk[9];
 #pragma unroll
-        for (int k3 = 0; k3 < 9; ++k3) xk[k3] = zr[k3];
+        for (int k3 = 0; k3 < 8; k3 += 2) SC_F3_LD128(zr + k3, xk[k3], xk[k3 + 1]);
+        xk[8] = SC_F3_LD64(zr + 8);
         v[0] = xk[0];
 #pragma unroll
         for (int k3 = 1; k3 < 8; ++k3) v[k3] = cf_mul_tw(xk[k3], tw2c[4 * k3].c, tw2c[4 * k3].ns, tw2c[4 * k3].s);
@@ -526,7 +612,7 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
       SC_WAVE_SYNC();
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1) {
-        const cf32 t = xb[k1 * SC_F3_XRS + lam];
+        const cf32 t = SC_F3_LD64(xb + k1 * SC_F3_XRS + lam);
         v[k1] = (k1 == 0) ? t : cf_mul_tw(t, tw1c[k1].c, tw1c[k1].ns, tw1c[k1].s);
       }
       SC_WAVE_SYNC();                                   // xb is rewritten by the next round
@@ -535,10 +621,18 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
       IO* ra = yo + oa;
       IO* rb = yo + ob;
       if (EPI == 0) {
+        if (SC_F3_INV_PLAIN_GROUPS > 0 && a < SC_F3_INV_PLAIN_GROUPS) {
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-          f3_store(ra, lam, n1, o[n1].x);
-          f3_store(rb, lam, n1, o[n1].y);
+          for (int n1 = 0; n1 < 8; ++n1) {
+            f3_store_plain(ra, lam, n1, o[n1].x);
+            f3_store_plain(rb, lam, n1, o[n1].y);
+          }
+        } else {
+#pragma unroll
+          for (int n1 = 0; n1 < 8; ++n1) {
+            f3_store(ra, lam, n1, o[n1].x);
+            f3_store(rb, lam, n1, o[n1].y);
+          }
         }
       } else {
         const int64_t io = img * (int64_t)H * SC_F2D_W;

@@ -1,0 +1,133 @@
+// sc_kernels_sb.h -- the contraction when ONE of its three extents is tiny (round 3): a small batch against a large
+// weight (BASELINE configs[4]: B = 4 rows, 128 x 128 channels, 33 024 modes -> 4.33 GB of weights per launch) or,
+// in the weight gradient, a short reduction (R = B) into a weight-sized result.
+//
+//   C[p, q, m] = sum_r opA(A[p, r, m]) * opB(B[r, q, m])          (complex, mode stride 1 everywhere)
+//
+// replaces tl.einsum('bixy,ioxy->boxy') and its two autograd einsums (spectral_convolution.py:21-46) for these
+// shapes.  They are pure weight streaming -- 4 flop per byte, nothing for the matrix cores -- and the kernels that
+// served them moved the 4.33 GB at 2.8-3.8 TB/s (profiles/r02_bench_1024_settled.json: 1.14 + 1.39 + 1.55 ms of a
+// 7.07 ms step): k_modegemm reads 8 bytes per lane (a wave = one 512-byte piece per operand row) with a single
+// active wave per workgroup when P <= 4 and only what the compiler's unroll-by-2 leaves in flight; the streamed
+// matrix-core kernel spends 32 / P of its work on clamped duplicate rows.  Here
+//   * a lane owns TWO neighbouring modes: every access is 16 bytes per lane, a wave instruction moves 1 KiB and the
+//     four waves of a workgroup cover 4 KiB of one operand row -- whole DRAM pages per (r, q);
+//   * register tile PT x QT per lane (PT >= the whole small extent when that is P), fp32 FMAs on the vector ALUs;
+//   * the reduction loop keeps ST stages of BOTH operands in flight in registers (a rotating ring written out by
+//     hand: the compiler's own unrolling drains the queue at the end of every unrolled body), non-temporal loads for
+//     the operand that is streamed once (the weight), ordinary loads for the small one that every q tile re-reads
+//     from L2 (work items are dealt to the XCDs so that all q tiles of one mode tile share an L2, as in k_modegemm);
+//   * the weight gradient (R <= 8) is one pass of 16-byte stores; with `stream_c` they are non-temporal.
+// Exact fp32: each output is an r-ordered chain of fmaf -- bit-identical to k_modegemm's result.
+#pragma once
+#include "sc_device.h"
+#include "sc_kernels_generic.h"
+
+struct SbGemmArgs {
+  int64_t P, Q, R, M;
+  int64_t a_sp, a_sr, b_sr, b_sq, c_sp, c_sq;     // complex elements; mode stride 1
+  int n_mt, n_pt, n_qt, per_xcd;                  // mode tiles of 512, row tiles of PT, column tiles of QT
+  int nt_a, nt_b, nt_c;                           // non-temporal access to A / B (read once) and C (not read next)
+};
+
+#ifndef SC_EMU
+SC_DEVICE sc_f4 sb_load(const cf32* p, const int nt) {
+  const sc_f4* q = reinterpret_cast<const sc_f4*>(p);
+  return nt ? __builtin_nontemporal_load(q) : *q;
+}
+SC_DEVICE void sb_store(cf32* p, const sc_f4 v, const int nt) {
+  sc_f4* q = reinterpret_cast<sc_f4*>(p);
+  if (nt) __builtin_nontemporal_store(v, q);
+  else *q = v;
+}
+#else
+inline sc_f4 sb_load(const cf32* p, const int) {
+  sc_f4 v;
+  std::memcpy(&v, p, 16);
+  return v;
+}
+inline void sb_store(cf32* p, const sc_f4 v, const int) { std::memcpy(p, &v, 16); }
+#endif
+
+// acc (two modes: (x, y) and (z, w)) += a * b
+template <bool CA, bool CB>
+SC_DEVICE void sb_mac(sc_f4& acc, const sc_f4 a, const sc_f4 b) {
+  const float a0i = CA ? -a.y : a.y, a1i = CA ? -a.w : a.w;
+  const float b0i = CB ? -b.y : b.y, b1i = CB ? -b.w : b.w;
+  acc.x = fmaf(a.x, b.x, acc.x);
+  acc.x = fmaf(-a0i, b0i, acc.x);
+  acc.y = fmaf(a.x, b0i, acc.y);
+  acc.y = fmaf(a0i, b.x, acc.y);
+  acc.z = fmaf(a.z, b.z, acc.z);
+  acc.z = fmaf(-a1i, b1i, acc.z);
+  acc.w = fmaf(a.z, b1i, acc.w);
+  acc.w = fmaf(a1i, b.z, acc.w);
+}
+
+template <int PT, int QT, int ST, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+  const int tid = SC_TID, lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
+  // work item = (mode tile, row tile, column tile), mode tile slowest; consecutive items go to ONE XCD (block b runs
+  // on XCD b % 8): all column tiles of a mode tile re-read the same slice of the small operand from that L2
+  const int bid = SC_BID_X;
+  const int64_t item = (int64_t)(bid & 7) * g.per_xcd + (bid >> 3);
+  const int64_t per_mt = (int64_t)g.n_pt * g.n_qt;
+  if (item >= (int64_t)g.n_mt * per_mt) return;
+  const int mt = (int)(item / per_mt);
+  const int rem = (int)(item - (int64_t)mt * per_mt);
+  const int qt = rem / g.n_pt, pt = rem - qt * g.n_pt;
+  const int64_t m = ((int64_t)mt * 256 + w * 64 + lane) * 2;       // first of this lane's two modes
+  const bool active = m < g.M;                                      // M is even: a pair is inside or outside
+  const int64_t mm = active ? m : g.M - 2;
+  const int64_t p0 = (int64_t)pt * PT, q0 = (int64_t)qt * QT;
+
+  const cf32* Ap[PT];
+  const cf32* Bq[QT];
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp) Ap[pp] = A + ((p0 + pp < g.P) ? (p0 + pp) : (g.P - 1)) * g.a_sp + mm;
+#pragma unroll
+  for (int qq = 0; qq < QT; ++qq) Bq[qq] = B + ((q0 + qq < g.Q) ? (q0 + qq) : (g.Q - 1)) * g.b_sq + mm;
+
+  sc_f4 acc[PT][QT];
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) acc[pp][qq] = sc_f4{0.f, 0.f, 0.f, 0.f};
+
+  // ring of ST stages: stage s holds the operands of reduction step r with r % ST == s
+  sc_f4 ra[ST][PT], rb[ST][QT];
+  auto request = [&](const int64_t r, sc_f4 (&a)[PT], sc_f4 (&b)[QT]) {
+    const int64_t rr = r < g.R ? r : g.R - 1;                       // past the end: a harmless re-read, never used
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp) a[pp] = sb_load(Ap[pp] + rr * g.a_sr, g.nt_a);
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) b[qq] = sb_load(Bq[qq] + rr * g.b_sr, g.nt_b);
+  };
+#pragma unroll
+  for (int s = 0; s < ST; ++s) request(s, ra[s], rb[s]);
+#pragma unroll 1
+  for (int64_t r0 = 0; r0 < g.R; r0 += ST) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      if (r0 + s < g.R) {                                           // uniform
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+          for (int qq = 0; qq < QT; ++qq) sb_mac<CA, CB>(acc[pp][qq], ra[s][pp], rb[s][qq]);
+      }
+      if (r0 + s + ST < g.R) request(r0 + s + ST, ra[s], rb[s]);     // refill the slot just consumed
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int pp = 0; pp < PT; ++pp) {
+    if (p0 + pp >= g.P) continue;
+#pragma unroll
+    for (int qq = 0; qq < QT; ++qq) {
+      if (q0 + qq >= g.Q) continue;
+      sb_store(C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq + m, acc[pp][qq], g.nt_c);
+    }
+  }
+}

@@ -22,6 +22,8 @@ void barrier() { pthread_barrier_wait(&g_barrier); }
 // wave-level rendezvous: the product's SC_WAVE_SYNC / MFMA only couple the 64 lanes of one wave,
 // so code that diverges BETWEEN waves (e.g. one wave doing an extra task) must not deadlock here
 void wave_barrier() { pthread_barrier_wait(&g_wave_barriers[(size_t)g_ctx.tid >> 6]); }
+static std::vector<float> g_wave_scratch;                  // [wave][2][64], see sc_emu_swap (sc_device.h)
+float* wave_scratch() { return g_wave_scratch.data() + ((size_t)g_ctx.tid >> 6) * 128; }
 
 struct Job {
   dim3 grid;
@@ -54,6 +56,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg) {
   pthread_barrier_init(&g_barrier, nullptr, nt);
   const unsigned nw = (nt + 63) / 64;
   g_wave_barriers.resize(nw);
+  g_wave_scratch.assign((size_t)nw * 128, 0.f);
   for (unsigned i = 0; i < nw; ++i) {
     const unsigned cnt = (i + 1 < nw || nt % 64 == 0) ? 64 : nt % 64;
     pthread_barrier_init(&g_wave_barriers[i], nullptr, cnt);

@@ -1,0 +1,111 @@
+"""CPU tier: the small-extent streaming contraction (sc_kernels_sb.h, k_modegemm_sb: a lane owns two neighbouring
+modes, PT x QT register tile, a hand-written ring of reduction steps in flight) in host emulation against a numpy
+complex128 einsum and, bit for bit, against the lanes-are-modes VALU kernel it replaces for these shapes.  Covers the
+three contractions of a layer at a small batch (BASELINE configs[4]: B = 4) -- forward, gX with conj(B) through
+transposed strides, gW with conj(A) and a reduction of B terms -- mode counts that do not fill the 512-mode tile,
+ragged row / column tiles, reductions shorter and longer than the ring, and the dispatch rule."""
+import numpy as np
+import pytest
+import torch
+
+from engine_runner import emu_lib, rel_l2
+from neuraloperator_amd import _lib
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def _rand(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.complex(torch.randn(*shape, generator=g), torch.randn(*shape, generator=g))
+
+
+def _run(lib, a, b, c, flags=0, expect=3, **kw):
+    assert lib.modegemm_path(flags=flags, **kw) == expect, "test must exercise the intended kernel"
+    lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                 torch.view_as_real(c).data_ptr(), 0, flags=flags, **kw)
+    return c
+
+
+def _both(lib, a, b, shape, ref, **kw):
+    c = torch.full(shape, float("nan"), dtype=torch.complex64)
+    _run(lib, a, b, c, **kw)
+    assert rel_l2(c.numpy(), ref) < TOL
+    c0 = torch.full(shape, float("nan"), dtype=torch.complex64)           # the kernel it replaces: same fmaf chains
+    fl = _lib.SC_GEMM_NO_SB | _lib.SC_GEMM_FORCE_VALU | _lib.SC_GEMM_NO_STREAM
+    _run(lib, a, b, c0, flags=fl, expect=0, **kw)
+    assert torch.equal(torch.view_as_real(c), torch.view_as_real(c0))
+
+
+# (B, Ci, Co, M)
+@pytest.mark.parametrize("dims", [(4, 9, 12, 70), (3, 5, 6, 2), (4, 128, 8, 516), (1, 7, 5, 1026), (2, 2, 3, 130)],
+                         ids=lambda d: "B%d_Ci%d_Co%d_M%d" % d)
+def test_forward_small_batch(lib, dims):
+    B, Ci, Co, M = dims
+    x, w = _rand(B, Ci, M, seed=1), _rand(Ci, Co, M, seed=2)
+    ref = np.einsum("bim,iom->bom", x.numpy().astype(np.complex128), w.numpy().astype(np.complex128))
+    _both(lib, x, w, (B, Co, M), ref, P=B, Q=Co, R=Ci, n_modes=M, a_sp=Ci * M, a_sr=M, a_sm=1, b_sr=Co * M, b_sq=M,
+          b_sm=1, c_sp=Co * M, c_sq=M, c_sm=1)
+
+
+@pytest.mark.parametrize("dims", [(4, 10, 7, 66), (2, 6, 130, 8), (4, 5, 3, 600)], ids=lambda d: "B%d_Ci%d_Co%d_M%d" % d)
+def test_gx_conj_b_transposed(lib, dims):
+    B, Ci, Co, M = dims
+    g, w = _rand(B, Co, M, seed=3), _rand(Ci, Co, M, seed=4)
+    ref = np.einsum("bom,iom->bim", g.numpy().astype(np.complex128), np.conj(w.numpy().astype(np.complex128)))
+    _both(lib, g, w, (B, Ci, M), ref, P=B, Q=Ci, R=Co, n_modes=M, a_sp=Co * M, a_sr=M, a_sm=1, b_sr=M, b_sq=Co * M,
+          b_sm=1, conj_b=1, c_sp=Ci * M, c_sq=M, c_sm=1)
+
+
+@pytest.mark.parametrize("dims", [(4, 10, 7, 66), (3, 128, 5, 20), (1, 6, 9, 514), (2, 33, 34, 4)],
+                         ids=lambda d: "B%d_Ci%d_Co%d_M%d" % d)
+@pytest.mark.parametrize("stream", [0, 1])
+def test_gw_conj_a_short_reduction(lib, dims, stream):
+    B, Ci, Co, M = dims
+    x, g = _rand(B, Ci, M, seed=5), _rand(B, Co, M, seed=6)
+    ref = np.einsum("bim,bom->iom", np.conj(x.numpy().astype(np.complex128)), g.numpy().astype(np.complex128))
+    gw = torch.full((Ci, Co, M), float("nan"), dtype=torch.complex64)
+    kw = dict(P=Ci, Q=Co, R=B, n_modes=M, a_sp=M, a_sr=Ci * M, a_sm=1, conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1,
+              c_sp=Co * M, c_sq=M, c_sm=1)
+    _run(lib, x, g, gw, flags=_lib.SC_GEMM_STREAM_C if stream else 0, **kw)
+    assert rel_l2(gw.numpy(), ref) < TOL
+
+
+def test_dispatch_rule(lib):
+    """Taken for min(P, R) <= 4 on plain, even, aligned operands -- and never otherwise."""
+    base = dict(P=4, Q=16, R=16, n_modes=64, a_sp=16 * 64, a_sr=64, a_sm=1, b_sr=16 * 64, b_sq=64, b_sm=1,
+                c_sp=16 * 64, c_sq=64, c_sm=1)
+    assert lib.modegemm_path(**base) == 3
+    assert not lib.modegemm_uses_matrix_cores(**base)
+    assert lib.modegemm_path(**dict(base, P=5)) != 3                      # 5 rows: the older kernels keep it
+    assert lib.modegemm_path(**dict(base, P=32, R=4)) == 3                # short reduction
+    assert lib.modegemm_path(**dict(base, n_modes=63)) != 3               # odd mode count
+    assert lib.modegemm_path(**dict(base, a_sr=65)) != 3                  # a row that is not 16-byte aligned
+    assert lib.modegemm_path(**dict(base, accumulate=1)) != 3
+    assert lib.modegemm_path(flags=_lib.SC_GEMM_NO_SB, **base) != 3
+    assert lib.modegemm_path(flags=_lib.SC_GEMM_F16, **base) != 3
+
+
+def test_layer_at_small_batch_takes_it(lib):
+    """sc_layer_forward / _backward at B = 4 (the dense layer's three contractions) against the oracle."""
+    from engine_runner import layer_fwd_bwd
+    from oracle import spectral_oracle as so
+    torch.manual_seed(9)
+    b, ci, co, spatial, modes = 4, 6, 5, (16, 12), (8, 6)
+    nm = so.halve_last(modes)
+    x = torch.randn(b, ci, *spatial)
+    w = torch.randn(ci, co, *nm, dtype=torch.cfloat) * 0.4
+    bias = torch.randn(co, 1, 1)
+    g = torch.randn(b, co, *spatial)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm)
+    assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
+    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL

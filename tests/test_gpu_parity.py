@@ -66,7 +66,8 @@ def _oracle_layer(x, w, bias, g, nm, contract=None):
     xc = x.detach().cpu().clone().requires_grad_(True)
     wc = w.detach().cpu().clone().requires_grad_(contract is None)
     bc = bias.detach().cpu().clone().requires_grad_(True)
-    yo = so.forward_torch(xc, wc, bc, list(nm), list(nm), contract=contract)
+    kw = {} if contract is None else dict(contract=contract)
+    yo = so.forward_torch(xc, wc, bc, list(nm), list(nm), **kw)
     yo.backward(g.detach().cpu())
     return (yo.detach().numpy(), xc.grad.numpy(), None if wc.grad is None else wc.grad.numpy(), bc.grad.numpy())
 
@@ -263,6 +264,44 @@ def test_mfma_contractions_full_size(lib):
         assert rel_l2(out.cpu().numpy(), ref) < TOL, name
         out2 = run(a, b, torch.empty(shape, dtype=torch.cfloat, device=dev), L.SC_GEMM_FORCE_VALU, **kw)
         assert rel_l2(out2.cpu().numpy(), ref) < TOL, name
+
+
+def test_small_batch_contractions_full_width(lib):
+    """k_modegemm_sb (round 3: a batch of <= 4 rows against a hidden-128 weight, BASELINE configs[4]'s three
+    contractions; 8 256 of its 33 024 modes so that the complex128 reference stays small) vs a complex128 einsum and,
+    bit for bit, vs the lanes-are-modes VALU kernel it replaces."""
+    from neuraloperator_amd import _lib as L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(22)
+    B, C, M = 4, 128, 8256                          # 16 mode tiles of 512 + a ragged one
+    xh = torch.randn(B, C, M, dtype=torch.cfloat, device=dev)
+    gh = torch.randn(B, C, M, dtype=torch.cfloat, device=dev)
+    w = torch.randn(C, C, M, dtype=torch.cfloat, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    cases = {
+        "fwd": (xh, w, (B, C, M), "bim,iom->bom", dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1,
+                b_sr=C * M, b_sq=M, b_sm=1, c_sp=C * M, c_sq=M, c_sm=1), (False, False)),
+        "gx": (gh, w, (B, C, M), "bom,iom->bim", dict(P=B, Q=C, R=C, n_modes=M, a_sp=C * M, a_sr=M, a_sm=1,
+               b_sr=M, b_sq=C * M, b_sm=1, conj_b=1, c_sp=C * M, c_sq=M, c_sm=1), (False, True)),
+        "gw": (xh, gh, (C, C, M), "bim,bom->iom", dict(P=C, Q=C, R=B, n_modes=M, a_sp=M, a_sr=C * M, a_sm=1,
+               conj_a=1, b_sr=C * M, b_sq=M, b_sm=1, c_sp=C * M, c_sq=M, c_sm=1, flags=L.SC_GEMM_STREAM_C),
+               (True, False)),
+    }
+    for name, (a, b, shape, eq, kw, (ca, cb)) in cases.items():
+        assert lib.modegemm_path(**kw) == 3, name
+        a128, b128 = a.to(torch.complex128), b.to(torch.complex128)
+        ref = torch.einsum(eq, a128.conj() if ca else a128, b128.conj() if cb else b128).cpu().numpy()
+        out = torch.full(shape, float("nan"), dtype=torch.cfloat, device=dev)
+        lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                     torch.view_as_real(out).data_ptr(), st, **kw)
+        kw0 = dict(kw, flags=L.SC_GEMM_NO_SB | L.SC_GEMM_FORCE_VALU | L.SC_GEMM_NO_STREAM)
+        assert lib.modegemm_path(**kw0) == 0
+        out0 = torch.empty(shape, dtype=torch.cfloat, device=dev)
+        lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
+                     torch.view_as_real(out0).data_ptr(), st, **kw0)
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu().numpy(), ref) < TOL, name
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(out0)), name
 
 
 def test_backward_pair_full_size(lib):
