@@ -125,6 +125,7 @@ enum {
   SC_GEMM_WIDE = 8,          /* 9 modes per workgroup even for a small mode count (A-B / tests)          */
   SC_GEMM_NO_STREAM = 16,    /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
   SC_GEMM_NO_SB = 64,        /* never take the small-extent streaming kernel (k_modegemm_sb; A-B / tests)  */
+  SC_GEMM_SB_WM4 = 128,      /* k_modegemm_sb: the four waves over 512 contiguous modes of one tile (A-B / tests) */
   SC_GEMM_F16 = 32           /* the reference's complex-half contraction (fno_block_precision "half" / "mixed",
                               * einsum_utils.py:10-36): operands rounded to float16, four real products summed in
                               * fp32 and rounded to float16, re = t00 - t11, im = t10 + t01 rounded to float16;
@@ -328,6 +329,32 @@ int sc_transform_inverse_ex(const sc_plan* plan, int mode, const float* yhat, co
 int sc_layer_forward_ex(const sc_plan* plan, const sc_layer_desc* L, const float* x, const float* w,
                         const float* bias, const sc_epilogue* ep, float* y, float* xhat_saved, void* workspace,
                         void* stream);
+
+/* ---- sharded spectra (round 3; mode-parallel layers) -------------------------------------------
+ * The reference defines the exchange of a mode-sharded layer only as a shape contract (mpu/helpers.py:81-99, the
+ * unused `_transpose`: split dim0, all-to-all, concatenate dim1).  Here the transforms on either side of that
+ * all-to-all write / read its rank-major buffer IN PLACE, so that no permutation copy is left around the collective:
+ * the kept block of every image is cut along its FIRST mode dim into n_blocks blocks of `rows` rows
+ * (n_blocks * rows >= k1; rows past k1 are zeros on the wire) and block p of image i lives at
+ *     xhat + p * block_stride + (i * rows + r) * rest + j        (complex elements; rest = k2 * .. * kN)
+ * i.e. xhat is the tensor [n_blocks][n_images][rows][rest] (block_stride >= n_images * rows * rest).  The fused 2-D
+ * kernels address this layout natively; every other shape runs the plain transform through a staging copy in the
+ * workspace plus ONE streaming permutation -- same results, sc_plan_workspace_bytes_sharded() bytes of workspace. */
+typedef struct {
+  int64_t n_blocks;      /* ranks of the model-parallel group                               */
+  int64_t rows;          /* rows of the first kept dim per block: ceil(k1 / n_blocks)       */
+  int64_t block_stride;  /* complex elements from one block to the next                     */
+} sc_spectrum_shards;
+size_t sc_plan_workspace_bytes_sharded(const sc_plan* plan, int64_t n_images);
+/* as sc_transform_forward / sc_transform_inverse (same modes), spectrum in the sharded layout */
+int sc_transform_forward_sharded(const sc_plan* plan, int mode, const float* x, float* xhat, int64_t n_images,
+                                 const sc_spectrum_shards* shards, void* workspace, void* stream);
+int sc_transform_inverse_sharded(const sc_plan* plan, int mode, const float* yhat, const float* bias,
+                                 int64_t channels, float* y, int64_t n_images, const sc_spectrum_shards* shards,
+                                 void* workspace, void* stream);
+/* sc_bias_grad on a sharded adjoint spectrum (batch * channels images) */
+int sc_bias_grad_sharded(const sc_plan* plan, const float* ghat, int64_t batch, int64_t channels,
+                         const sc_spectrum_shards* shards, float* gbias, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------ */
 const char* sc_last_error(void);

@@ -28,6 +28,7 @@ SC_GEMM_WIDE = 8
 SC_GEMM_NO_STREAM = 16
 SC_GEMM_F16 = 32
 SC_GEMM_NO_SB = 64
+SC_GEMM_SB_WM4 = 128
 
 
 def SC_GEMM_GRID(n):
@@ -49,6 +50,10 @@ class AdamwDesc(Structure):
     _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double),
                 ("eps", ctypes.c_double), ("weight_decay", ctypes.c_double), ("step", c_int64),
                 ("correct_bias", c_int32), ("reserved", c_int32)]
+
+
+class SpectrumShards(Structure):           # sc_spectrum_shards
+    _fields_ = [("n_blocks", c_int64), ("rows", c_int64), ("block_stride", c_int64)]
 
 
 class ModeGemmDesc(Structure):
@@ -137,7 +142,8 @@ class ScEngineLib:
                "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex",
                "sc_pointwise_mlp_backward_ex", "sc_tucker_modes_supported", "sc_tucker_modes_forward",
                "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes", "sc_modegemm_pair",
-               "sc_modegemm_pair_fused"]
+               "sc_modegemm_pair_fused", "sc_plan_workspace_bytes_sharded", "sc_transform_forward_sharded",
+               "sc_transform_inverse_sharded", "sc_bias_grad_sharded"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -180,6 +186,17 @@ class ScEngineLib:
         L.sc_modegemm_path.restype = c_int
         L.sc_bias_grad.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
         L.sc_bias_grad.restype = c_int
+        L.sc_plan_workspace_bytes_sharded.argtypes = [c_void_p, c_int64]
+        L.sc_plan_workspace_bytes_sharded.restype = c_size_t
+        L.sc_transform_forward_sharded.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                                   POINTER(SpectrumShards), c_void_p, c_void_p]
+        L.sc_transform_forward_sharded.restype = c_int
+        L.sc_transform_inverse_sharded.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                                   POINTER(SpectrumShards), c_void_p, c_void_p]
+        L.sc_transform_inverse_sharded.restype = c_int
+        L.sc_bias_grad_sharded.argtypes = [c_void_p, c_void_p, c_int64, c_int64, POINTER(SpectrumShards), c_void_p,
+                                           c_void_p]
+        L.sc_bias_grad_sharded.restype = c_int
         L.sc_adamw_step.argtypes = [POINTER(AdamwDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_int, c_void_p]
         L.sc_adamw_step.restype = c_int
@@ -273,6 +290,26 @@ class ScEngineLib:
 
     def plan_kernel_name(self, plan, which):
         return self.lib.sc_plan_kernel_name(plan, which).decode()
+
+    # -- sharded spectra (mode-parallel layers): the all-to-all buffer [n_blocks][n_images][rows][rest] in place
+    def plan_workspace_bytes_sharded(self, plan, n_images):
+        return int(self.lib.sc_plan_workspace_bytes_sharded(plan, n_images))
+
+    @staticmethod
+    def shards(n_blocks, rows, block_stride):
+        return SpectrumShards(int(n_blocks), int(rows), int(block_stride))
+
+    def transform_forward_sharded(self, plan, mode, x_ptr, xhat_ptr, n_images, shards, ws_ptr, stream=0):
+        self._check(self.lib.sc_transform_forward_sharded(plan, mode, x_ptr, xhat_ptr, n_images, byref(shards),
+                                                          ws_ptr, stream))
+
+    def transform_inverse_sharded(self, plan, mode, yhat_ptr, bias_ptr, channels, y_ptr, n_images, shards, ws_ptr,
+                                  stream=0):
+        self._check(self.lib.sc_transform_inverse_sharded(plan, mode, yhat_ptr, bias_ptr, channels, y_ptr, n_images,
+                                                          byref(shards), ws_ptr, stream))
+
+    def bias_grad_sharded(self, plan, ghat_ptr, batch, channels, shards, gbias_ptr, stream=0):
+        self._check(self.lib.sc_bias_grad_sharded(plan, ghat_ptr, batch, channels, byref(shards), gbias_ptr, stream))
 
     # -- stages ------------------------------------------------------------------------
     def transform_forward(self, plan, mode, x_ptr, xhat_ptr, n_images, ws_ptr, stream=0):

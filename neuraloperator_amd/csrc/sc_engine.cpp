@@ -1067,8 +1067,17 @@ static int run_axis(int jt, const cf32* in, cf32* out, const DeviceTable& t, int
 // ------------------------------------------------------------------------------------------
 // transforms
 // ------------------------------------------------------------------------------------------
+static int transform_forward_impl(const sc_plan* p, int mode, const float* x, float* xhat, int64_t n_images,
+                                  void* workspace, void* stream, F3Shard sh);
+
 extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, float* xhat,
                                     int64_t n_images, void* workspace, void* stream) {
+  return transform_forward_impl(p, mode, x, xhat, n_images, workspace, stream, F3Shard{0, 0});
+}
+
+// sh.rows > 0 (sharded spectrum): only plans whose kernels address it natively arrive here with it (native_shards)
+static int transform_forward_impl(const sc_plan* p, int mode, const float* x, float* xhat, int64_t n_images,
+                                  void* workspace, void* stream, F3Shard sh) {
   SC_CHECK_ARG(p, "null argument");
   SC_CHECK_ARG(mode == SC_FWD_SCALED || mode == SC_FWD_ADJ_C2R, "bad forward mode");
   if (n_images <= 0) return 0;
@@ -1078,8 +1087,8 @@ extern "C" int sc_transform_forward(const sc_plan* p, int mode, const float* x, 
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
     if (p->d.flags & SC_PLAN_IO_BF16)
-      return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error);
-    return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error);
+      return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error, sh);
+    return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error, sh);
   }
   if (p->f2p) return f2p_forward(p, mode, x, (cf32*)xhat, n_images, workspace, st);
   const int L = p->nd - 1;
@@ -1143,9 +1152,20 @@ extern "C" int sc_transform_inverse(const sc_plan* p, int mode, const float* yha
   return sc_transform_inverse_ex(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream);
 }
 
+static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat, const float* bias,
+                                  int64_t channels, const sc_epilogue* ep, float* y, int64_t n_images,
+                                  void* workspace, void* stream, F3Shard sh);
+
 extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* yhat, const float* bias,
                                        int64_t channels, const sc_epilogue* ep, float* y, int64_t n_images,
                                        void* workspace, void* stream) {
+  return transform_inverse_impl(p, mode, yhat, bias, channels, ep, y, n_images, workspace, stream, F3Shard{0, 0});
+}
+
+// sh.rows > 0 (sharded spectrum): only plans whose kernels address it natively arrive here with it (native_shards)
+static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat, const float* bias,
+                                  int64_t channels, const sc_epilogue* ep, float* y, int64_t n_images,
+                                  void* workspace, void* stream, F3Shard sh) {
   SC_CHECK_ARG(p, "null argument");
   if (ep && !ep->skip) ep = nullptr;
   if (ep) {
@@ -1171,9 +1191,9 @@ extern "C" int sc_transform_inverse_ex(const sc_plan* p, int mode, const float* 
     if (p->d.flags & SC_PLAN_IO_BF16)
       return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
                           &g_last_error, epi, ep ? (const sc_bf16*)ep->skip : nullptr,
-                          ep ? (sc_bf16*)ep->preact : nullptr);
+                          ep ? (sc_bf16*)ep->preact : nullptr, sh);
     return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error, epi,
-                        ep ? ep->skip : nullptr, ep ? ep->preact : nullptr);
+                        ep ? ep->skip : nullptr, ep ? ep->preact : nullptr, sh);
   }
   if (ep) {                                  // size-agnostic passes: the plain transform, then one streaming pass
     int rc2 = sc_transform_inverse_ex(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream);
@@ -1274,15 +1294,15 @@ static bool sb_gemm_eligible(const sc_modegemm_desc* d, const void* A, const voi
   return small <= sb_max_extent();
 }
 
-template <int PT, int QT, int ST>
+template <int PT, int QT, int ST, int WM, int WP, int WQ>
 static int run_sb_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
   SbGemmArgs g;
   g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
   g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.c_sp = d->c_sp; g.c_sq = d->c_sq;
-  g.n_mt = (int)((d->n_modes + 511) / 512);
+  g.n_mt = (int)((d->n_modes + 128 * WM - 1) / (128 * WM));
   g.n_pt = (int)((d->P + PT - 1) / PT);
   g.n_qt = (int)((d->Q + QT - 1) / QT);
-  const int64_t total = (int64_t)g.n_mt * g.n_pt * g.n_qt;
+  const int64_t total = (int64_t)g.n_mt * ((g.n_pt + WP - 1) / WP) * ((g.n_qt + WQ - 1) / WQ);
   if (total >= ((int64_t)1 << 30)) return -1;
   g.per_xcd = (int)((total + 7) / 8);
   // an operand that exactly one tile reads crosses the chip once: keep it out of the caches the shared one lives in
@@ -1291,19 +1311,27 @@ static int run_sb_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   static const bool plain_c = std::getenv("SC_SB_PLAIN_C") != nullptr;               // A-B
   g.nt_c = (d->flags & SC_GEMM_STREAM_C) && !plain_c ? 1 : 0;
   const dim3 grid((unsigned)(8 * g.per_xcd));
-  if (!d->conj_a && !d->conj_b) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, false, false>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
-  else if (d->conj_a && !d->conj_b) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, true, false>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
-  else if (!d->conj_a && d->conj_b) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, false, true>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
-  else SC_LAUNCH((k_modegemm_sb<PT, QT, ST, true, true>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C);
+#define SC_SB_LAUNCH(CA, CB) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, WM, WP, WQ, CA, CB>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C)
+  if (!d->conj_a && !d->conj_b) SC_SB_LAUNCH(false, false);
+  else if (d->conj_a && !d->conj_b) SC_SB_LAUNCH(true, false);
+  else if (!d->conj_a && d->conj_b) SC_SB_LAUNCH(false, true);
+  else SC_SB_LAUNCH(true, true);
+#undef SC_SB_LAUNCH
   return sc_check_launch("k_modegemm_sb");
 }
 
 static int run_sb_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
   // small batch: the register tile holds every row (4 x 4, or 8 x 2 for 5..8 rows), three reduction steps in
-  // flight; short reduction (weight gradient): 4 x 4 outputs per lane, two steps in flight
-  if (d->P <= 4) return run_sb_gemm_t<4, 4, 3>(d, A, B, C, st);
-  if (d->P <= 8 && d->P <= d->R) return run_sb_gemm_t<8, 2, 3>(d, A, B, C, st);
-  return run_sb_gemm_t<4, 4, 2>(d, A, B, C, st);
+  // flight; short reduction (weight gradient): 4 x 4 outputs per lane, two steps in flight.  Wave arrangement
+  // (sc_kernels_sb.h): the four waves over four column tiles (2 x 2 tiles for the weight gradient) of one 128-mode
+  // tile; SC_GEMM_SB_WM4 / SC_SB_WM=4 (flag / environment, A-B) = four neighbouring 128-mode tiles of one tile instead
+  static const bool wm4_env = [] { const char* e = std::getenv("SC_SB_WM"); return e && std::atoi(e) == 4; }();
+  const bool wm4 = wm4_env || (d->flags & SC_GEMM_SB_WM4);
+  if (d->P <= 4)
+    return wm4 ? run_sb_gemm_t<4, 4, 3, 4, 1, 1>(d, A, B, C, st) : run_sb_gemm_t<4, 4, 3, 1, 1, 4>(d, A, B, C, st);
+  if (d->P <= 8 && d->P <= d->R)
+    return wm4 ? run_sb_gemm_t<8, 2, 3, 4, 1, 1>(d, A, B, C, st) : run_sb_gemm_t<8, 2, 3, 1, 1, 4>(d, A, B, C, st);
+  return wm4 ? run_sb_gemm_t<4, 4, 2, 4, 1, 1>(d, A, B, C, st) : run_sb_gemm_t<4, 4, 2, 1, 2, 2>(d, A, B, C, st);
 }
 
 // ---- matrix-core path (sc_kernels_mfma.h): channel counts that fill 32 x 32 MFMA tiles ----------
@@ -1961,6 +1989,98 @@ extern "C" int sc_modegemm_path(const sc_modegemm_desc* d) {
 extern "C" int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d) {
   const int path = sc_modegemm_path(d);
   return path == 1 || path == 2;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sharded spectrum layout (mode-parallel layers): the truncated spectrum is written / read as the
+// rank-major all-to-all buffer [block][image][rows][rest] in place of the plain [image][k1][rest] block
+// ------------------------------------------------------------------------------------------
+static bool native_shards(const sc_plan* p) { return p->fast && !(p->d.flags & SC_PLAN_FFT_GEN2); }
+static int64_t shard_rest(const sc_plan* p) {
+  int64_t r = 1;
+  for (int d = 1; d < p->nd; ++d) r *= p->k[d];
+  return r;
+}
+static size_t shard_ws_base(const sc_plan* p, int64_t n_images) {
+  return (sc_plan_workspace_bytes(p, n_images) + 255) / 256 * 256;
+}
+static int check_shards(const sc_plan* p, const sc_spectrum_shards* sh, int64_t n_images) {
+  SC_CHECK_ARG(p && sh, "null argument");
+  SC_CHECK_ARG(!p->cplx, "sharded spectra: real-data plans");
+  SC_CHECK_ARG(sh->n_blocks >= 1 && sh->rows >= 1 && sh->n_blocks * sh->rows >= p->k[0],
+               "shards must cover the first kept dim: n_blocks * rows >= k1");
+  SC_CHECK_ARG((sh->n_blocks - 1) * sh->rows < p->k[0], "a whole block past the first kept dim");
+  SC_CHECK_ARG(sh->block_stride >= n_images * sh->rows * shard_rest(p), "block_stride smaller than a block");
+  SC_CHECK_ARG(sh->rows < ((int64_t)1 << 30), "rows too large");
+  return 0;
+}
+
+extern "C" size_t sc_plan_workspace_bytes_sharded(const sc_plan* p, int64_t n_images) {
+  if (!p) return 0;
+  if (native_shards(p)) return sc_plan_workspace_bytes(p, n_images);
+  return shard_ws_base(p, n_images) + (size_t)(n_images * p->modes) * sizeof(cf32);
+}
+
+template <bool TO_SHARDS>
+static int run_spectrum_shard(const sc_plan* p, const sc_spectrum_shards* sh, const cf32* src, cf32* dst,
+                              int64_t n_images, sc_stream_t st) {
+  const int64_t total = n_images * sh->rows * sh->n_blocks * shard_rest(p);
+  int64_t blocks = (total + SC_BLOCK - 1) / SC_BLOCK;
+  if (blocks > 8192) blocks = 8192;
+  SC_LAUNCH((k_spectrum_shard<TO_SHARDS>), dim3((unsigned)blocks), dim3(SC_BLOCK), 0, st, src, dst, n_images,
+            (int64_t)p->k[0], shard_rest(p), (int64_t)sh->rows, (int64_t)sh->n_blocks, (int64_t)sh->block_stride,
+            blocks * SC_BLOCK);
+  return sc_check_launch("k_spectrum_shard");
+}
+
+extern "C" int sc_transform_forward_sharded(const sc_plan* p, int mode, const float* x, float* xhat,
+                                            int64_t n_images, const sc_spectrum_shards* sh, void* workspace,
+                                            void* stream) {
+  if (n_images <= 0) return 0;
+  if (int rc = check_shards(p, sh, n_images)) return rc;
+  sc_stream_t st = (sc_stream_t)stream;
+  if (native_shards(p)) {
+    // rows past k1 (k1 not a multiple of the block size) are zeros on the wire: clear the one block that has them
+    if (sh->n_blocks * sh->rows != p->k[0]) {
+      cf32* last = (cf32*)xhat + (sh->n_blocks - 1) * sh->block_stride;
+      if (hipMemsetAsync(last, 0, (size_t)(n_images * sh->rows * shard_rest(p)) * sizeof(cf32), st) != hipSuccess)
+        return sc_fail("sc_engine: hipMemsetAsync failed");
+    }
+    return transform_forward_impl(p, mode, x, xhat, n_images, workspace, stream, F3Shard{(int)sh->rows, sh->block_stride});
+  }
+  SC_CHECK_ARG(workspace, "workspace required (sc_plan_workspace_bytes_sharded)");
+  cf32* stage = (cf32*)((unsigned char*)workspace + shard_ws_base(p, n_images));
+  if (int rc = sc_transform_forward(p, mode, x, (float*)stage, n_images, workspace, stream)) return rc;
+  return run_spectrum_shard<true>(p, sh, stage, (cf32*)xhat, n_images, st);
+}
+
+extern "C" int sc_transform_inverse_sharded(const sc_plan* p, int mode, const float* yhat, const float* bias,
+                                            int64_t channels, float* y, int64_t n_images,
+                                            const sc_spectrum_shards* sh, void* workspace, void* stream) {
+  if (n_images <= 0) return 0;
+  if (int rc = check_shards(p, sh, n_images)) return rc;
+  if (native_shards(p))
+    return transform_inverse_impl(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream,
+                                  F3Shard{(int)sh->rows, sh->block_stride});
+  SC_CHECK_ARG(workspace, "workspace required (sc_plan_workspace_bytes_sharded)");
+  cf32* stage = (cf32*)((unsigned char*)workspace + shard_ws_base(p, n_images));
+  if (int rc = run_spectrum_shard<false>(p, sh, (const cf32*)yhat, stage, n_images, (sc_stream_t)stream)) return rc;
+  return sc_transform_inverse(p, mode, (const float*)stage, bias, channels, y, n_images, workspace, stream);
+}
+
+// bias gradient off a SHARDED adjoint spectrum (the DC coefficient of every image sits in one block)
+extern "C" int sc_bias_grad_sharded(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,
+                                    const sc_spectrum_shards* sh, float* gbias, void* stream) {
+  SC_CHECK_ARG(p && ghat && gbias, "null argument");
+  SC_CHECK_ARG(p->dc_index >= 0, "the plan's frequency maps keep no zero-frequency coefficient");
+  if (int rc = check_shards(p, sh, batch * channels)) return rc;
+  if (channels <= 0) return 0;
+  const int64_t rest = shard_rest(p);
+  const int64_t row = p->dc_index / rest, col = p->dc_index - row * rest, blk = row / sh->rows;
+  const cf32* base = (const cf32*)ghat + blk * sh->block_stride;
+  SC_LAUNCH(k_bias_grad, dim3((unsigned)channels), dim3(SC_WAVE), 0, (sc_stream_t)stream, base, gbias, batch,
+            channels, sh->rows * rest, (row - blk * sh->rows) * rest + col);
+  return sc_check_launch("k_bias_grad");
 }
 
 extern "C" int sc_bias_grad(const sc_plan* p, const float* ghat, int64_t batch, int64_t channels,

@@ -113,6 +113,19 @@ SC_DEVICE void f3_store_epi(IO* row, const float sk, IO* prow, const int lam, co
   f3_store(row, lam, j, v);
 }
 
+// Sharded spectrum addressing (mode-parallel layers: the transform writes / reads the rank-major all-to-all buffer
+// in place, include/sc_engine.h sc_spectrum_shards): block p = rows [p rows, (p + 1) rows) of the first kept dim of
+// EVERY image, [block][image][rows][My]; rows <= 0 = the plain [image][Mx][My] layout
+struct F3Shard {
+  int rows;
+  int64_t block_stride;      // complex elements between blocks
+};
+SC_HD int64_t f3_shard_index(const F3Shard sh, const int64_t img, const int i, const int My) {
+  const int row = i / My, col = i - row * My;
+  const int blk = row / sh.rows;
+  return (int64_t)blk * sh.block_stride + (img * sh.rows + (row - blk * sh.rows)) * (int64_t)My + col;
+}
+
 // 8-point DFT, natural order in and out: b[k] = sum_n a[n] w8^(nk), w8 = exp(DIR 2 pi i / 8)
 template <int DIR>
 SC_HD void dft8(const cf32 (&a)[8], cf32 (&b)[8]) {
@@ -185,7 +198,7 @@ SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
 template <int H, typename IO>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && sizeof(IO) == 4 ? SC_F3_FWD_OCC : 3))   // bf16 loads need 4 more VGPRs
 k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
-             const cf32* __restrict__ tabH, int Mx, int My, float s_dc, float s_other) {
+             const cf32* __restrict__ tabH, int Mx, int My, float s_dc, float s_other, F3Shard sh) {
   constexpr int P = H / 64;
   typedef F3Lds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
@@ -446,8 +459,12 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     }
   }
   SC_SYNC();
-  cf32* dst = xhat + img * (int64_t)Mx * My;
-  for (int i = tid; i < Mx * My; i += 256) dst[i] = OUT[i];
+  if (sh.rows <= 0) {
+    cf32* dst = xhat + img * (int64_t)Mx * My;
+    for (int i = tid; i < Mx * My; i += 256) dst[i] = OUT[i];
+  } else {                                                // sharded spectrum (include/sc_engine.h, sc_spectrum_shards)
+    for (int i = tid; i < Mx * My; i += 256) xhat[f3_shard_index(sh, img, i, My)] = OUT[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -457,7 +474,7 @@ template <int H, typename IO, int EPI = 0>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && EPI == 0 ? 4 : 3))
 k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
              int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
-             float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact) {
+             float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact, F3Shard sh) {
   constexpr int P = H / 64;
   typedef F3Lds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
@@ -485,7 +502,11 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
     tw2t[tid] = ctw4_make(cf_conj((tk >= 4) ? cf_rot_i(t, tn) : t));
   }
   cf32* IN = T;
-  for (int i = tid; i < Mx * My; i += 256) IN[i] = src[i];
+  if (sh.rows <= 0) {
+    for (int i = tid; i < Mx * My; i += 256) IN[i] = src[i];
+  } else {
+    for (int i = tid; i < Mx * My; i += 256) IN[i] = yhat[f3_shard_index(sh, img, i, My)];
+  }
   const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
 
   const int k1l = lam >> 2, n4 = lam & 3;
@@ -654,18 +675,18 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
 // ------------------------------------------------------------------------------------------
 template <int H, typename IO>
 static void fft3_launch_fwd(const Fft2dPlan* fp, const IO* x, cf32* xhat, int64_t n_images, float s_dc,
-                            float s_other, sc_stream_t st) {
+                            float s_other, sc_stream_t st, F3Shard sh) {
   SC_LAUNCH((k_fft2d_fwd3<H, IO>), dim3((unsigned)n_images), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
-            (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other);
+            (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, sh);
 }
 
 template <int H, typename IO>
 static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const float* bias, int channels,
                             int64_t n_images, float s_dc, float s_other, sc_stream_t st, int epi = 0,
-                            const IO* skip = nullptr, IO* preact = nullptr) {
+                            const IO* skip = nullptr, IO* preact = nullptr, F3Shard sh = F3Shard{0, 0}) {
 #define SC_F3_INV(E)                                                                                        \
   SC_LAUNCH((k_fft2d_inv3<H, IO, E>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels, \
-            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, skip, preact)
+            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, skip, preact, sh)
   if (epi == 2) SC_F3_INV(2);
   else if (epi == 1) SC_F3_INV(1);
   else SC_F3_INV(0);
@@ -675,14 +696,14 @@ static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const 
 // x / y: float32, or bfloat16 storage when the plan carries SC_PLAN_IO_BF16 (IO = sc_bf16)
 template <typename IO>
 static inline int fft3_forward(const Fft2dPlan* fp, int mode, const IO* x, cf32* xhat, int64_t n_images,
-                               sc_stream_t st, std::string* err) {
+                               sc_stream_t st, std::string* err, F3Shard sh = F3Shard{0, 0}) {
   const float s_dc = (mode == 0) ? fp->sf : fp->si;
   const float s_other = (mode == 0) ? fp->sf : 2.f * fp->si;
   switch (fp->H) {
-    case 64: fft3_launch_fwd<64, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
-    case 128: fft3_launch_fwd<128, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
-    case 256: fft3_launch_fwd<256, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
-    case 512: fft3_launch_fwd<512, IO>(fp, x, xhat, n_images, s_dc, s_other, st); break;
+    case 64: fft3_launch_fwd<64, IO>(fp, x, xhat, n_images, s_dc, s_other, st, sh); break;
+    case 128: fft3_launch_fwd<128, IO>(fp, x, xhat, n_images, s_dc, s_other, st, sh); break;
+    case 256: fft3_launch_fwd<256, IO>(fp, x, xhat, n_images, s_dc, s_other, st, sh); break;
+    case 512: fft3_launch_fwd<512, IO>(fp, x, xhat, n_images, s_dc, s_other, st, sh); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {
@@ -695,14 +716,15 @@ static inline int fft3_forward(const Fft2dPlan* fp, int mode, const IO* x, cf32*
 template <typename IO>
 static inline int fft3_inverse(const Fft2dPlan* fp, int mode, const cf32* yhat, const float* bias,
                                int64_t channels, IO* y, int64_t n_images, sc_stream_t st, std::string* err,
-                               int epi = 0, const IO* skip = nullptr, IO* preact = nullptr) {
+                               int epi = 0, const IO* skip = nullptr, IO* preact = nullptr,
+                               F3Shard sh = F3Shard{0, 0}) {
   const float s_dc = (mode == 0) ? fp->si : fp->sf;
   const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
   switch (fp->H) {
-    case 64: fft3_launch_inv<64, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
-    case 128: fft3_launch_inv<128, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
-    case 256: fft3_launch_inv<256, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
-    case 512: fft3_launch_inv<512, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact); break;
+    case 64: fft3_launch_inv<64, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact, sh); break;
+    case 128: fft3_launch_inv<128, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact, sh); break;
+    case 256: fft3_launch_inv<256, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact, sh); break;
+    case 512: fft3_launch_inv<512, IO>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, epi, skip, preact, sh); break;
     default: *err = "sc_engine: fft2d: unsupported H"; return 1;
   }
   if (hipGetLastError() != hipSuccess) {

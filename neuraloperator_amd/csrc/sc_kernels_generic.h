@@ -489,6 +489,29 @@ k_epilogue(float* __restrict__ y, const float* __restrict__ skip, float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// Sharded spectrum layout for the shapes whose transform kernels do not address it natively (everything off the fused
+// 2-D kernels): ONE streaming permutation between the plain [image][k1][rest] block and the rank-major all-to-all
+// buffer [block][image][rows][rest] (include/sc_engine.h, sc_spectrum_shards).  TO_SHARDS: plain -> sharded (rows
+// past k1 of the last blocks are written as zeros), else sharded -> plain.
+// ------------------------------------------------------------------------------------------
+template <bool TO_SHARDS>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_spectrum_shard(const cf32* __restrict__ src, cf32* __restrict__ dst, int64_t n_images, int64_t k1, int64_t rest,
+                 int64_t rows, int64_t n_blocks, int64_t block_stride, int64_t stride) {
+  const int64_t per_img = rows * n_blocks * rest;           // padded rows included
+  const int64_t total = n_images * per_img;
+  for (int64_t e = (int64_t)SC_BID_X * SC_BLOCK + SC_TID; e < total; e += stride) {
+    const int64_t img = e / per_img, rem = e - img * per_img;
+    const int64_t row = rem / rest, col = rem - row * rest;
+    const int64_t blk = row / rows;
+    const int64_t sh = blk * block_stride + (img * rows + (row - blk * rows)) * rest + col;
+    const int64_t pl = (img * k1 + row) * rest + col;
+    if (TO_SHARDS) dst[sh] = row < k1 ? src[pl] : cf_make(0.f, 0.f);
+    else if (row < k1) dst[pl] = src[sh];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused AdamW step (neuralop/training/adamw.py:155-200 without the GaLore projection): one read of
 // (p, g, m, v), one write of (p, m, v).  Streaming: 7 arrays of the weight's size cross HBM once.
 // CPX: elements are complex64 -- m and the update are complex, v accumulates g conj(g) = |g|^2 (its

@@ -10,8 +10,9 @@
 // 7.07 ms step): k_modegemm reads 8 bytes per lane (a wave = one 512-byte piece per operand row) with a single
 // active wave per workgroup when P <= 4 and only what the compiler's unroll-by-2 leaves in flight; the streamed
 // matrix-core kernel spends 32 / P of its work on clamped duplicate rows.  Here
-//   * a lane owns TWO neighbouring modes: every access is 16 bytes per lane, a wave instruction moves 1 KiB and the
-//     four waves of a workgroup cover 4 KiB of one operand row -- whole DRAM pages per (r, q);
+//   * a lane owns TWO neighbouring modes: every access is 16 bytes per lane, a wave instruction moves 1 KiB of one
+//     operand row; the four waves of a workgroup take four column tiles of the same 128 modes (or 4 KiB of contiguous
+//     modes of one tile: see the wave arrangements below);
 //   * register tile PT x QT per lane (PT >= the whole small extent when that is P), fp32 FMAs on the vector ALUs;
 //   * the reduction loop keeps ST stages of BOTH operands in flight in registers (a rotating ring written out by
 //     hand: the compiler's own unrolling drains the queue at the end of every unrolled body), non-temporal loads for
@@ -26,7 +27,7 @@
 struct SbGemmArgs {
   int64_t P, Q, R, M;
   int64_t a_sp, a_sr, b_sr, b_sq, c_sp, c_sq;     // complex elements; mode stride 1
-  int n_mt, n_pt, n_qt, per_xcd;                  // mode tiles of 512, row tiles of PT, column tiles of QT
+  int n_mt, n_pt, n_qt, per_xcd;                  // mode tiles of 128 WM, row tiles of PT, column tiles of QT
   int nt_a, nt_b, nt_c;                           // non-temporal access to A / B (read once) and C (not read next)
 };
 
@@ -64,21 +65,31 @@ SC_DEVICE void sb_mac(sc_f4& acc, const sc_f4 a, const sc_f4 b) {
   acc.w = fmaf(a1i, b.z, acc.w);
 }
 
-template <int PT, int QT, int ST, bool CA, bool CB>
+// WM x WP x WQ = the four waves of a workgroup over (mode tiles of 128, row tiles, column tiles):
+//   4 x 1 x 1  one (row, column) tile, 512 contiguous modes: 4 KiB of every operand row per workgroup instruction;
+//   1 x 1 x 4  four neighbouring column tiles of ONE 128-mode tile: the small operand's slice is fetched once per
+//              workgroup (the other three waves hit L1) and the slice all column tiles share is 4 x smaller, so it
+//              stays in the XCD's L2 (4 MB) instead of being re-read from the Infinity Cache by every column tile;
+//   1 x 2 x 2  the same for the weight gradient, where BOTH operands are small and re-read by 32 tiles each.
+template <int PT, int QT, int ST, int WM, int WP, int WQ, bool CA, bool CB>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
 k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+  static_assert(WM * WP * WQ == 4, "four waves per workgroup");
   const int tid = SC_TID, lane = tid & 63;
   const int w = SC_UNIFORM(tid >> 6);
-  // work item = (mode tile, row tile, column tile), mode tile slowest; consecutive items go to ONE XCD (block b runs
-  // on XCD b % 8): all column tiles of a mode tile re-read the same slice of the small operand from that L2
+  const int wm = w % WM, wq = (w / WM) % WQ, wp = w / (WM * WQ);
+  // work item = (mode tile, row tile group, column tile group), mode tile slowest; consecutive items go to ONE XCD
+  // (block b runs on XCD b % 8): all tiles of a mode tile re-read the same slices of the small operand(s) from that L2
   const int bid = SC_BID_X;
   const int64_t item = (int64_t)(bid & 7) * g.per_xcd + (bid >> 3);
-  const int64_t per_mt = (int64_t)g.n_pt * g.n_qt;
+  const int n_ptg = (g.n_pt + WP - 1) / WP, n_qtg = (g.n_qt + WQ - 1) / WQ;
+  const int64_t per_mt = (int64_t)n_ptg * n_qtg;
   if (item >= (int64_t)g.n_mt * per_mt) return;
   const int mt = (int)(item / per_mt);
   const int rem = (int)(item - (int64_t)mt * per_mt);
-  const int qt = rem / g.n_pt, pt = rem - qt * g.n_pt;
-  const int64_t m = ((int64_t)mt * 256 + w * 64 + lane) * 2;       // first of this lane's two modes
+  const int qt = (rem / n_ptg) * WQ + wq, pt = (rem - (rem / n_ptg) * n_ptg) * WP + wp;
+  if (pt >= g.n_pt || qt >= g.n_qt) return;                         // whole wave idle (no barriers in this kernel)
+  const int64_t m = (((int64_t)mt * WM + wm) * 64 + lane) * 2;      // first of this lane's two modes
   const bool active = m < g.M;                                      // M is even: a pair is inside or outside
   const int64_t mm = active ? m : g.M - 2;
   const int64_t p0 = (int64_t)pt * PT, q0 = (int64_t)qt * QT;

@@ -716,6 +716,67 @@ class EngineRawOps:
                 lib.bias_grad(plan, gh.data_ptr(), n, c, gb.data_ptr(), _stream())
         return torch.view_as_complex(gh), gb
 
+    # ---- the same four stages with the spectrum in the rank-major all-to-all layout [P][n][c][rows][rest]
+    #      (include/sc_engine.h, sc_spectrum_shards): the buffer handed to / received from all_to_all_single is
+    #      written / read in place, no permutation copy on either side of the collective
+    def _sharded(self, lib, plan, n_images, P, rows, rest, dev):
+        sh = lib.shards(P, rows, n_images * rows * rest)
+        return sh, _ws(lib.plan_workspace_bytes_sharded(plan, n_images), dev)
+
+    def fwd_sharded(self, x, kept, P, rows, out=None, mode=None):       # -> [P, n, c, rows, *kept[1:], 2] float32
+        _require_gpu(x)
+        lib = _lib.get_lib()
+        x = x.contiguous().float()
+        n, c = x.shape[:2]
+        rest = 1
+        for k in kept[1:]:
+            rest *= int(k)
+        plan = self._plan(x.device, list(x.shape[2:]), kept)
+        with torch.cuda.device(x.device):
+            buf = self._out(out, (P, n, c, rows, *kept[1:], 2), x.device)
+            sh, ws = self._sharded(lib, plan, n * c, P, rows, rest, x.device)
+            lib.transform_forward_sharded(plan, _lib.SC_FWD_SCALED if mode is None else mode, x.data_ptr(),
+                                          buf.data_ptr(), n * c, sh, ws.data_ptr(), _stream())
+        return buf
+
+    def inv_adjoint_sharded(self, gy, kept, P, rows, out=None, want_bias=False):
+        buf = self.fwd_sharded(gy, kept, P, rows, out=out, mode=_lib.SC_FWD_ADJ_C2R)
+        gb = None
+        if want_bias:
+            lib = _lib.get_lib()
+            n, c = gy.shape[:2]
+            rest = 1
+            for k in kept[1:]:
+                rest *= int(k)
+            plan = self._plan(gy.device, list(gy.shape[2:]), kept)
+            with torch.cuda.device(gy.device):
+                gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+                lib.bias_grad_sharded(plan, buf.data_ptr(), n, c, lib.shards(P, rows, n * c * rows * rest),
+                                      gb.data_ptr(), _stream())
+        return buf, gb
+
+    def inv_sharded(self, buf, bias, spatial, k1, out=None, mode=None):   # buf [P, n, c, rows, rest.., 2] float32
+        lib = _lib.get_lib()
+        if buf.dtype != torch.float32 or not buf.is_contiguous():
+            raise ValueError("inv_sharded: a contiguous float32 [P, n, c, rows, ..., 2] buffer is required")
+        P, n, c, rows = (int(v) for v in buf.shape[:4])
+        kept = [int(k1)] + [int(v) for v in buf.shape[4:-1]]
+        rest = 1
+        for k in kept[1:]:
+            rest *= k
+        plan = self._plan(buf.device, list(spatial), kept)
+        with torch.cuda.device(buf.device):
+            y = self._out(out, (n, c, *spatial), buf.device)
+            sh, ws = self._sharded(lib, plan, n * c, P, rows, rest, buf.device)
+            bflat = None if bias is None else bias.detach().reshape(-1).float().contiguous()
+            lib.transform_inverse_sharded(plan, _lib.SC_INV_PADDED if mode is None else mode, buf.data_ptr(),
+                                          0 if bflat is None else bflat.data_ptr(), c, y.data_ptr(), n * c, sh,
+                                          ws.data_ptr(), _stream())
+        return y
+
+    def fwd_adjoint_sharded(self, buf, spatial, k1, out=None):
+        return self.inv_sharded(buf, None, spatial, k1, out=out, mode=_lib.SC_INV_ADJ_R2C)
+
     @staticmethod
     def contract(xhat, w):
         b, ci = xhat.shape[:2]

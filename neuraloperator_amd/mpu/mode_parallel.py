@@ -19,9 +19,13 @@ One autograd Function runs the whole pipeline (``_ModeParallelFn``) so that the 
 the local batch (or, for one sample per rank, the channels) is cut into a few chunks, chunk j's all-to-all is
 enqueued (RCCL runs it on the process group's own stream) as soon as its transform is launched, and the
 transform of chunk j+1 runs meanwhile; on the way back every chunk's inverse transform starts when ITS exchange
-has landed.  Per exchange one S-sized copy (the chunk-major send permutation one way, the mode-major receive
-permutation the other); the R-sized real tensors are written in place (``out=`` slices).  When k1 is not a
-multiple of P the mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
+has landed.  NO copy is left around the collectives (round 3): the transforms write / read the rank-major
+all-to-all buffers in place (engine ``*_sharded`` calls: include/sc_engine.h, sc_spectrum_shards), the receive
+buffer of the way out IS the contraction's operand and the contraction's result IS the send buffer of the way back;
+the R-sized real tensors are written in place (``out=`` slices).  With one sample per rank (BASELINE configs[3] on 8
+GPUs) the channels take the place of the batch as the chunked dim, and the default there is ONE chunk: at 4.5 MB per
+rank and exchange the pipeline's extra launches cost more than the overlap wins.  When k1 is not a multiple of P the
+mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
 """
 import math
 
@@ -50,31 +54,9 @@ class _Exchange:
         A2A_STATS["bytes"] += send.numel() * send.element_size()
         return dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
-    # (n, C, k1, rest) complex  ->  this rank's rows of every rank's chunk: recv [P, n, C, rows, rest, 2]
-    def modes_out(self, xh, recv):
-        P, rows, k1 = self.P, self.rows, self.k1
-        xr = torch.view_as_real(xh)
-        n, c = xr.shape[:2]
-        if rows * P == k1:
-            send = xr.unflatten(2, (P, rows)).movedim(2, 0).contiguous()
-        else:                                           # zero-padded rows on the wire
-            send = xr.new_zeros((P, n, c, rows, *xr.shape[3:]))
-            for p in range(P):
-                r = min(rows, k1 - p * rows)
-                if r > 0:
-                    send[p, :, :, :r] = xr[:, :, p * rows:p * rows + r]
-        return self._a2a(recv, send), send
-
-    # send [P, n, C, rows, rest, 2] (rank-major rows of the contraction result) -> recv of the same shape
-    def batch_out(self, send, recv):
-        return self._a2a(recv, send), send
-
-    # recv [P, n, C, rows, rest, 2] -> (n, C, k1, rest) complex
-    def modes_in(self, recv):
-        out = recv.movedim(0, 2).flatten(2, 3)
-        if self.rows * self.P != self.k1:
-            out = out[:, :, :self.k1]
-        return torch.view_as_complex(out.contiguous())
+    # send / recv: [P, n, C, rows, rest.., 2] float32, contiguous (block p <-> rank p of the group)
+    def exchange(self, send, recv):
+        return self._a2a(recv, send)
 
 
 class _ModeParallelFn(torch.autograd.Function):
@@ -89,53 +71,60 @@ class _ModeParallelFn(torch.autograd.Function):
         w = weight.detach().contiguous()
         ex = _Exchange(layer._group(), P, rows, kept[0])
         by_batch = b >= 2 or P == 1
-        chunks = _bounds(b, min(layer.comm_chunks, b)) if by_batch else _bounds(ci, min(layer.comm_chunks, ci))
+        chunks = _bounds(b, min(layer._chunks(True), b)) if by_batch else _bounds(ci, min(layer._chunks(False), ci))
         ctx.cfg = (layer, spatial, kept, b, ci, co, by_batch)
         dev = x.device
 
-        # ---- forward transform + exchange (split modes, cat batch)
+        # ---- forward transform + exchange (split modes, cat batch): the transform writes the send buffer
+        #      [P, n, ci', rows, rest] directly, the receive buffer is a slice of the contraction's operand
         xd = x.detach()
+        k1 = kept[0]
         if by_batch:
             xhat_all = torch.empty((P * b, ci, rows, *rest, 2), dtype=torch.float32, device=dev)
         else:
             xhat_all = torch.empty((P, ci, rows, *rest, 2), dtype=torch.float32, device=dev)
+        single = (not by_batch) and len(chunks) == 1
         pend = []
         for (c0, c1) in chunks:
-            xh = ops.fwd(xd[c0:c1] if by_batch else xd[:, c0:c1], kept)
+            send = ops.fwd_sharded(xd[c0:c1] if by_batch else xd[:, c0:c1], kept, P, rows)
             if by_batch:
                 recv = xhat_all[P * c0:P * c1].view(P, c1 - c0, ci, rows, *rest, 2)
+            elif single:
+                recv = xhat_all.view(P, 1, ci, rows, *rest, 2)
             else:
                 recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
-            pend.append((ex.modes_out(xh, recv), recv, c0, c1))
-        for (work, _send), recv, c0, c1 in pend:
+            pend.append((ex.exchange(send, recv), send, recv, c0, c1))
+        for work, _send, recv, c0, c1 in pend:
             work.wait()
-            if not by_batch:
+            if not by_batch and not single:
                 xhat_all[:, c0:c1] = recv[:, 0]
         xhat_all = torch.view_as_complex(xhat_all)
 
         # ---- contraction on this rank's mode rows, whole batch
         yhat_all = ops.contract(xhat_all, w).contiguous()
 
-        # ---- exchange back (split batch, cat modes) + zero-padded inverse
+        # ---- exchange back (split batch, cat modes) + zero-padded inverse reading the receive buffer in place
         y = torch.empty((b, co, *spatial), dtype=torch.float32, device=dev)
         yr = torch.view_as_real(yhat_all)
-        ochunks = chunks if by_batch else _bounds(co, min(layer.comm_chunks, co))
+        ochunks = chunks if by_batch else _bounds(co, min(layer._chunks(False), co))
+        osingle = (not by_batch) and len(ochunks) == 1
         pend = []
         for (c0, c1) in ochunks:
             if by_batch:
                 send = yr[P * c0:P * c1].view(P, c1 - c0, co, rows, *rest, 2)
+            elif osingle:
+                send = yr.view(P, 1, co, rows, *rest, 2)
             else:
                 send = yr[:, c0:c1].contiguous().view(P, 1, c1 - c0, rows, *rest, 2)
             recv = torch.empty_like(send)
-            pend.append((ex.batch_out(send, recv), recv, c0, c1))
+            pend.append((ex.exchange(send, recv), send, recv, c0, c1))
         bflat = None if bias is None else bias.detach().reshape(-1)
-        for (work, _send), recv, c0, c1 in pend:
+        for work, _send, recv, c0, c1 in pend:
             work.wait()
-            yh = ex.modes_in(recv)
             if by_batch:
-                ops.inv(yh, bflat, spatial, out=y[c0:c1])
+                ops.inv_sharded(recv, bflat, spatial, k1, out=y[c0:c1])
             else:
-                ops.inv(yh, None if bflat is None else bflat[c0:c1], spatial, out=y[:, c0:c1])
+                ops.inv_sharded(recv, None if bflat is None else bflat[c0:c1], spatial, k1, out=y[:, c0:c1])
         ctx.save_for_backward(xhat_all, w)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
@@ -151,26 +140,30 @@ class _ModeParallelFn(torch.autograd.Function):
         ex = _Exchange(layer._group(), P, rows, kept[0])
         dev = gy.device
         gy = gy.contiguous()
-        chunks = _bounds(b, min(layer.comm_chunks, b)) if by_batch else _bounds(co, min(layer.comm_chunks, co))
+        chunks = _bounds(b, min(layer._chunks(True), b)) if by_batch else _bounds(co, min(layer._chunks(False), co))
+        k1 = kept[0]
 
         # ---- adjoint of the inverse transform (+ bias gradient) + exchange (split modes, cat batch)
         if by_batch:
             ghat_all = torch.empty((P * b, co, rows, *rest, 2), dtype=torch.float32, device=dev)
         else:
             ghat_all = torch.empty((P, co, rows, *rest, 2), dtype=torch.float32, device=dev)
+        single = (not by_batch) and len(chunks) == 1
         want_b = need_b and ctx.has_bias
         gb_parts, pend = [], []
         for (c0, c1) in chunks:
-            gh, gb = ops.inv_adjoint(gy[c0:c1] if by_batch else gy[:, c0:c1], kept, want_bias=want_b)
+            send, gb = ops.inv_adjoint_sharded(gy[c0:c1] if by_batch else gy[:, c0:c1], kept, P, rows, want_bias=want_b)
             gb_parts.append(gb)
             if by_batch:
                 recv = ghat_all[P * c0:P * c1].view(P, c1 - c0, co, rows, *rest, 2)
+            elif single:
+                recv = ghat_all.view(P, 1, co, rows, *rest, 2)
             else:
                 recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
-            pend.append((ex.modes_out(gh, recv), recv, c0, c1))
-        for (work, _send), recv, c0, c1 in pend:
+            pend.append((ex.exchange(send, recv), send, recv, c0, c1))
+        for work, _send, recv, c0, c1 in pend:
             work.wait()
-            if not by_batch:
+            if not by_batch and not single:
                 ghat_all[:, c0:c1] = recv[:, 0]
         ghat_all = torch.view_as_complex(ghat_all)
         gbias = None
@@ -180,24 +173,26 @@ class _ModeParallelFn(torch.autograd.Function):
         # ---- the two gradient contractions on this rank's mode rows (gW is complete: no all-reduce)
         gxhat_all, gw = ops.contract_bwd(xhat_all, w, ghat_all, need_x, need_w)
 
-        # ---- exchange back + adjoint of the forward transform
+        # ---- exchange back + adjoint of the forward transform reading the receive buffer in place
         gx = None
         if need_x:
             gx = torch.empty((b, ci, *spatial), dtype=torch.float32, device=dev)
             gr = torch.view_as_real(gxhat_all.contiguous())
-            ichunks = chunks if by_batch else _bounds(ci, min(layer.comm_chunks, ci))
+            ichunks = chunks if by_batch else _bounds(ci, min(layer._chunks(False), ci))
+            isingle = (not by_batch) and len(ichunks) == 1
             pend = []
             for (c0, c1) in ichunks:
                 if by_batch:
                     send = gr[P * c0:P * c1].view(P, c1 - c0, ci, rows, *rest, 2)
+                elif isingle:
+                    send = gr.view(P, 1, ci, rows, *rest, 2)
                 else:
                     send = gr[:, c0:c1].contiguous().view(P, 1, c1 - c0, rows, *rest, 2)
                 recv = torch.empty_like(send)
-                pend.append((ex.batch_out(send, recv), recv, c0, c1))
-            for (work, _send), recv, c0, c1 in pend:
+                pend.append((ex.exchange(send, recv), send, recv, c0, c1))
+            for work, _send, recv, c0, c1 in pend:
                 work.wait()
-                gxh = ex.modes_in(recv)
-                ops.fwd_adjoint(gxh, spatial, out=gx[c0:c1] if by_batch else gx[:, c0:c1])
+                ops.fwd_adjoint_sharded(recv, spatial, k1, out=gx[c0:c1] if by_batch else gx[:, c0:c1])
         return gx, gw, gbias, None
 
 
@@ -206,7 +201,8 @@ class ModeParallelSpectralConv(BaseSpectralConv):
 
     Constructor arguments follow SpectralConv; ``n_modes`` is fixed at construction (the
     shard layout depends on it).  ``ops`` (tests only) replaces the local stages (an object with the
-    interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in.
+    interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in (None: 4 batch chunks,
+    or one piece when a rank holds a single sample).
 
     Weights: dense (``weight``: this rank's mode rows of the (Cin, Cout, modes...) tensor), or
     ``factorization="tucker"`` (TFNO, spectral_convolution.py:76-103): the core and the factors of the channel and
@@ -216,7 +212,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     ``reduce_replicated_grads``."""
 
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
-                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=4,
+                 fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=None,
                  factorization=None, rank=0.5, **unused):
         super().__init__(device=device)
         for k in ("complex_data", "separable"):
@@ -234,7 +230,10 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             raise NotImplementedError("mode sharding needs >= 2 spatial dims (dim 0 is sharded)")
         self.fft_norm = fft_norm
         self.group = group
-        self.comm_chunks = max(1, int(comm_chunks))
+        # pieces the exchange is pipelined in: None = 4 batch chunks when a rank holds >= 2 samples, ONE piece when it
+        # holds a single sample (channel chunks would need strided wire buffers, i.e. copies, and 4.5 MB exchanges are
+        # latency-bound: fewer launches win); an explicit number applies to both cases
+        self.comm_chunks = None if comm_chunks is None else max(1, int(comm_chunks))
         self.P = comm.get_model_parallel_size() if group is None else dist.get_world_size(group)
         self.rank = comm.get_model_parallel_rank() if group is None else dist.get_rank(group)
         # rows of the first mode dim per rank; k1 not divisible by P: the last rank(s) carry zero rows
@@ -257,7 +256,8 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             self.weight = None
             self.core = nn.Parameter(torch.empty(*ranks, dtype=torch.cfloat, device=device).normal_(0, std_f))
             sizes = [in_channels, out_channels, self.rows, *self._n_modes[1:]]
-            self.factors = nn.ParameterList(
+            from ..factorized import FactorList      # tltorch's names: factors.factor_{i} (legacy factors.{i} loads too)
+            self.factors = FactorList(
                 [nn.Parameter(torch.empty(n, r, dtype=torch.cfloat, device=device).normal_(0, std_f))
                  for n, r in zip(sizes, ranks)])
             with torch.no_grad():
@@ -272,6 +272,11 @@ class ModeParallelSpectralConv(BaseSpectralConv):
 
     def _group(self):
         return self.group if self.group is not None else comm.get_model_parallel_group()
+
+    def _chunks(self, by_batch):
+        if self.comm_chunks is not None:
+            return self.comm_chunks
+        return 4 if by_batch else 1
 
     @property
     def n_modes(self):
@@ -324,6 +329,34 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             for q in self.replicated_parameters():
                 t = torch.view_as_real(q.data) if q.is_complex() else q.data
                 dist.broadcast(t, dist.get_global_rank(grp, src) if grp is not None else src, group=grp)
+
+    def load_full_state_dict(self, state_dict, prefix=""):
+        """Load the UNSHARDED parameters of a reference / single-GPU layer (state-dict keys of
+        neuralop's SpectralConv and of neuraloperator_amd.SpectralConv: ``weight.tensor`` -- or a bare ``weight`` --
+        for dense weights, ``weight.core`` + ``weight.factors.factor_{i}`` for Tucker, ``bias``), keeping this rank's
+        mode rows of the dense weight / of the first mode dim's factor.  Complex tensors stored as real
+        (..., 2) views are accepted."""
+        def get(*names):
+            for n in names:
+                if prefix + n in state_dict:
+                    t = state_dict[prefix + n]
+                    if not t.is_complex() and t.shape[-1:] == (2,) and t.dtype.is_floating_point and n != "bias":
+                        t = torch.view_as_complex(t.contiguous())
+                    return t
+            raise KeyError(f"none of {[prefix + n for n in names]} in the state dict")
+        with torch.no_grad():
+            if self.factorization == "dense":
+                full = get("weight.tensor", "weight")
+                self.weight.copy_(self.shard_dense_weight(full[:, :, :self._n_modes[0]].to(self.weight.device), self.rank, self.P))
+            else:
+                self.core.copy_(get("weight.core", "core"))
+                for i, f in enumerate(self.factors):
+                    full = get(f"weight.factors.factor_{i}", f"weight.factors.{i}", f"factors.factor_{i}", f"factors.{i}")
+                    full = full.to(f.device)
+                    f.copy_(self.shard_tucker_factor(full, self.rank, self.P) if i == 2 else full)
+            if self.bias is not None and (prefix + "bias") in state_dict:
+                self.bias.copy_(state_dict[prefix + "bias"].reshape(self.bias.shape))
+        return self
 
     @staticmethod
     def shard_tucker_factor(full_factor, rank, world):

@@ -95,6 +95,32 @@ class OracleRawOps:
         gb = gy.sum(dim=[0] + list(range(2, gy.ndim))) if want_bias else None
         return gh, gb
 
+    # ---- sharded layout [P][n][c][rows][rest..][2] (float32), rows past k1 zero: the all-to-all buffer in place
+    @staticmethod
+    def _to_shards(xh, P, rows):
+        xr = torch.view_as_real(xh)
+        n, c, k1 = xr.shape[:3]
+        pad = xr.new_zeros((n, c, P * rows, *xr.shape[3:]))
+        pad[:, :, :k1] = xr
+        return pad.unflatten(2, (P, rows)).movedim(2, 0).contiguous()
+
+    @staticmethod
+    def _from_shards(buf, k1):
+        return torch.view_as_complex(buf.movedim(0, 2).flatten(2, 3)[:, :, :k1].contiguous())
+
+    def fwd_sharded(self, x, kept, P, rows, out=None, mode=None):
+        return self._ret(self._to_shards(self.fwd(x, kept), P, rows), out)
+
+    def inv_adjoint_sharded(self, gy, kept, P, rows, out=None, want_bias=False):
+        gh, gb = self.inv_adjoint(gy, kept, want_bias=want_bias)
+        return self._ret(self._to_shards(gh, P, rows), out), gb
+
+    def inv_sharded(self, buf, bias, spatial, k1, out=None, mode=None):
+        return self.inv(self._from_shards(buf, k1), bias, spatial, out=out)
+
+    def fwd_adjoint_sharded(self, buf, spatial, k1, out=None):
+        return self.fwd_adjoint(self._from_shards(buf, k1), spatial, out=out)
+
     def contract(self, xhat, w):
         return so.contract_dense(xhat, w)
 

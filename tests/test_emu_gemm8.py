@@ -25,6 +25,7 @@ def _rand(*shape, seed):
 
 
 def run(lib, a, b, c, flags=0, expect=2, **kw):
+    flags |= _lib.SC_GEMM_NO_SB            # this file pins the streamed / generation-1 kernels (small extents: test_emu_sb.py)
     assert lib.modegemm_path(flags=flags, **kw) == expect, "test must exercise the intended kernel"
     lib.modegemm(torch.view_as_real(a).data_ptr(), torch.view_as_real(b).data_ptr(),
                  torch.view_as_real(c).data_ptr(), 0, flags=flags, **kw)
@@ -123,11 +124,14 @@ def test_eligibility(lib):
     # a small batch streams only against a weight read across its rows (gX-hat), and not below 8 rows
     gx = dict(base, P=8, b_sr=2112, b_sq=64 * 2112, conj_b=1)
     assert lib.modegemm_path(**gx) == 2
-    assert lib.modegemm_path(**dict(gx, P=4)) == 0
+    assert lib.modegemm_path(**dict(gx, P=4)) == 3                        # round 3: <= 4 rows -> the small-extent streaming kernel
+    assert lib.modegemm_path(**dict(gx, P=4, flags=_lib.SC_GEMM_NO_SB)) == 0
     assert lib.modegemm_path(**dict(base, P=8)) == 0                      # forward product: lanes-are-modes kernel
     assert lib.modegemm_path(**dict(base, Q=36)) == 1                    # ragged Tucker rank: 64-row tiles of gen 1
-    assert lib.modegemm_path(**dict(base, P=4, Q=128)) == 0              # 4 rows: neither matrix-core kernel
-    assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4)) == 2       # hidden 128 weight gradient
+    assert lib.modegemm_path(**dict(base, P=4, Q=128)) == 3              # 4 rows: neither matrix-core kernel
+    assert lib.modegemm_path(**dict(base, P=4, Q=128, flags=_lib.SC_GEMM_NO_SB)) == 0
+    assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4)) == 3       # hidden 128 weight gradient at B = 4
+    assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4, flags=_lib.SC_GEMM_NO_SB)) == 2
 
 
 @pytest.mark.parametrize("layout", ["AC", "B", "ABC"])

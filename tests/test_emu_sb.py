@@ -35,6 +35,9 @@ def _both(lib, a, b, shape, ref, **kw):
     c = torch.full(shape, float("nan"), dtype=torch.complex64)
     _run(lib, a, b, c, **kw)
     assert rel_l2(c.numpy(), ref) < TOL
+    c4 = torch.full(shape, float("nan"), dtype=torch.complex64)           # the other wave arrangement: same bits
+    _run(lib, a, b, c4, flags=_lib.SC_GEMM_SB_WM4, **kw)
+    assert torch.equal(torch.view_as_real(c), torch.view_as_real(c4))
     c0 = torch.full(shape, float("nan"), dtype=torch.complex64)           # the kernel it replaces: same fmaf chains
     fl = _lib.SC_GEMM_NO_SB | _lib.SC_GEMM_FORCE_VALU | _lib.SC_GEMM_NO_STREAM
     _run(lib, a, b, c0, flags=fl, expect=0, **kw)
@@ -73,6 +76,9 @@ def test_gw_conj_a_short_reduction(lib, dims, stream):
               c_sp=Co * M, c_sq=M, c_sm=1)
     _run(lib, x, g, gw, flags=_lib.SC_GEMM_STREAM_C if stream else 0, **kw)
     assert rel_l2(gw.numpy(), ref) < TOL
+    gw4 = torch.full((Ci, Co, M), float("nan"), dtype=torch.complex64)
+    _run(lib, x, g, gw4, flags=_lib.SC_GEMM_SB_WM4, **kw)
+    assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw4))
 
 
 def test_dispatch_rule(lib):

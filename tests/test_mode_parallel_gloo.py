@@ -37,6 +37,8 @@ def _worker(rank, world, port, spatial, modes, ret, bl=2, chunks=4):
     comm.init(model_parallel_size=world, backend="gloo")
     assert comm.get_model_parallel_size() == world and comm.get_model_parallel_rank() == rank
     assert comm.get_data_parallel_size() == 1
+    assert comm.get_global_rank() == rank and comm.get_world_rank() == rank
+    from neuraloperator_amd.mpu.mappings import A2A_STATS
     nm = halve_last_mode(modes)
     B, ci, co = bl * world, 3, 4
     torch.manual_seed(0)                      # identical full tensors on every rank
@@ -46,13 +48,27 @@ def _worker(rank, world, port, spatial, modes, ret, bl=2, chunks=4):
     bias = torch.randn(co, *(1,) * len(spatial))
 
     conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=chunks)
-    with torch.no_grad():
-        conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, rank, world))
-        conv.bias.copy_(bias)
+    if rank % 2:                                      # a reference / single-GPU checkpoint (real-view storage too)
+        conv.load_full_state_dict({"conv.weight.tensor": torch.view_as_real(w), "conv.bias": bias}, prefix="conv.")
+        assert torch.equal(conv.weight.detach(), ModeParallelSpectralConv.shard_dense_weight(w, rank, world))
+    else:
+        with torch.no_grad():
+            conv.weight.copy_(ModeParallelSpectralConv.shard_dense_weight(w, rank, world))
+            conv.bias.copy_(bias)
     xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
+    A2A_STATS.update(calls=0, bytes=0)
     y = conv(xs)
     y.backward(g[rank * bl:(rank + 1) * bl])
     conv.reduce_replicated_grads()
+    # 4 exchanges per layer step, each in `pieces` all-to-all calls, each moving the rank's whole
+    # truncated spectrum once (zero-padded mode rows included): 4 S_local bytes per step and rank
+    pieces = conv._chunks(bl >= 2)
+    rows_ = -(-nm[0] // world)
+    rest_ = int(np.prod(nm[1:]))
+    n_fwd = min(pieces, bl if bl >= 2 else ci)
+    n_bwd = min(pieces, bl if bl >= 2 else co)
+    assert A2A_STATS["calls"] == 2 * (n_fwd + n_bwd), (A2A_STATS, n_fwd, n_bwd)
+    assert A2A_STATS["bytes"] == 2 * 8 * bl * world * rows_ * rest_ * (ci + co), A2A_STATS
 
     xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     yf = so.forward_torch(xf, wf, bf, nm, nm)
@@ -77,7 +93,18 @@ def _worker(rank, world, port, spatial, modes, ret, bl=2, chunks=4):
     ((16, 12), (7, 6), 1, 2),          # one sample per rank: the exchange is pipelined over channel chunks
 ])
 def test_mode_parallel_matches_single_process(spatial, modes, bl, chunks):
-    world = 2
+    _run_world(2, spatial, modes, bl, chunks)
+
+
+@pytest.mark.parametrize("chunks", [None, 2], ids=["one_piece", "channel_chunks"])
+def test_mode_parallel_world8_one_sample_per_rank(chunks):
+    """BASELINE configs[3]'s layout on one node: 8 ranks, B = 8 in total (ONE sample per rank), 32 mode rows ->
+    4 rows per rank, 3-d.  The default (None) exchanges each spectrum in one piece with no copy around the
+    collective; an explicit chunk count pipelines over channel chunks."""
+    _run_world(8, (32, 6, 8), (32, 4, 6), 1, chunks)
+
+
+def _run_world(world, spatial, modes, bl, chunks):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -215,6 +242,13 @@ def _tucker_worker(rank, world, port, spatial, modes, ret):
                 conv.factors[i].copy_(f if rank == 0 else torch.zeros_like(f))
         conv.bias.copy_(bias if rank == 0 else torch.zeros_like(bias))
     conv.sync_replicated_parameters(src=0)                                     # ... and broadcasts them
+    # state-dict names follow tltorch's FactorList (a TFNO checkpoint's `weight.factors.factor_i`), and an unsharded
+    # checkpoint loads through load_full_state_dict with this rank's rows of the first mode dim's factor
+    assert {"core", "bias", *(f"factors.factor_{i}" for i in range(len(full_f)))} <= set(conv.state_dict())
+    before = [f.detach().clone() for f in conv.factors]
+    sd = {"weight.core": core, "bias": bias, **{f"weight.factors.factor_{i}": f for i, f in enumerate(full_f)}}
+    conv.load_full_state_dict(sd)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, conv.factors)) and torch.equal(conv.core.detach(), core)
     xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
     y = conv(xs)
     y.backward(g[rank * bl:(rank + 1) * bl])
