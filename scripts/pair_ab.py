@@ -107,7 +107,13 @@ def make(name, lib):
         lib.transform_inverse(plan, _lib.SC_INV_PADDED, xhat.data_ptr(), bias.data_ptr(), C, y.data_ptr(), B * C,
                               ws.data_ptr(), st)
 
-    return dict(tf=tf, ti=ti, fwd=fwd, seq=seq, pair=pair, bwd=bwd, step=step)
+    def gw_only():
+        lib.modegemm(xhat.data_ptr(), ghat.data_ptr(), gw.data_ptr(), st, **kw_w)
+
+    def gx_only():
+        lib.modegemm(ghat.data_ptr(), w.data_ptr(), gxhat.data_ptr(), st, **kw_x)
+
+    return dict(tf=tf, ti=ti, fwd=fwd, seq=seq, pair=pair, bwd=bwd, step=step, gw=gw_only, gx=gx_only)
 
 
 fns = {name: make(name, lib) for name, lib in libs}
