@@ -49,6 +49,7 @@ WORKLOADS = {
     # not BASELINE configs: common small grids on the size-agnostic path (plane-form passes)
     "fno2d_64_m32_c64_b64": (64, 64, (64, 64), (32, 32)),
     "fno2d_128_m32_c64_b32": (32, 64, (128, 128), (32, 32)),
+    "fno2d_192_m64_c64_b32": (32, 64, (192, 192), (64, 64)),      # radix-3 lines (32 x 6) on the two-pass route
     "fno3d_64_m16_c32_b8": (8, 32, (64, 64, 64), (16, 16, 16)),
 }
 

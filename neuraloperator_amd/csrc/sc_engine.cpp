@@ -416,16 +416,31 @@ static int fft_col_scales(sc_plan* p, float** fwd, float** inv) {
   return 0;
 }
 
-static int f2p_plan_init(sc_plan* p) {
+// points per lane of the lines the two-pass kernels are instantiated for (N = 32 P)
+static bool f2p_line_ok(int64_t n) {
+  if (n % 32) return false;
+  switch (n / 32) {
+    case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: case 20: case 32: return true;
+    default: return false;
+  }
+}
+
+// large_only: the round-2 envelope (both sizes 512 / 1024), tried BEFORE the 128 x 128 plane kernels; the general
+// call comes after them, so that grids with a fused one-launch route keep it
+static int f2p_plan_init(sc_plan* p, bool large_only) {
   if (p->nd != 2 || p->cplx || p->custom_map || p->d.real_col) return 0;
-  for (int d = 0; d < 2; ++d)
-    if (p->n[d] != 512 && p->n[d] != 1024) return 0;
+  for (int d = 0; d < 2; ++d) {
+    if (large_only ? (p->n[d] != 512 && p->n[d] != 1024) : !f2p_line_ok(p->n[d])) return 0;
+  }
   const int P0 = (int)(p->n[0] / 32), P1 = (int)(p->n[1] / 32);
   const int64_t K0 = p->k[0], J = p->k[1];
   if (J > p->n[1] / 2) return 0;                          // kept columns stay below the Nyquist column
-  const int k2r = f2p_pow2_at_least((((K0 + 1) / 2) + P0 - 1) / P0);
-  const int k2c = f2p_pow2_at_least(J > 1 ? (J - 1 + P1 - 1) / P1 : 1);
+  int k2r = f2p_pow2_at_least((((K0 + 1) / 2) + P0 - 1) / P0);
+  int k2c = f2p_pow2_at_least(J > 1 ? (J - 1 + P1 - 1) / P1 : 1);
   if (k2r > 8 || k2c > 8) return 0;
+  // lines of 512 / 1024 points are instantiated for every pruning range, the other lengths for 4 and 8 only
+  if (P0 != 16 && P0 != 32 && k2r < 4) k2r = 4;
+  if (P1 != 16 && P1 != 32 && k2c < 4) k2c = 4;
   p->f2p_p[0] = P0;
   p->f2p_p[1] = P1;
   p->f2p_k2[0] = k2r;
@@ -481,6 +496,11 @@ static bool f2p_dispatch(int P, int K2, F&& f) {
     case 1602: f(sc_int<16>(), sc_int<2>()); return true;
     case 1604: f(sc_int<16>(), sc_int<4>()); return true;
     case 1608: f(sc_int<16>(), sc_int<8>()); return true;
+#define SC_F2P_CASES(P) case P * 100 + 4: f(sc_int<P>(), sc_int<4>()); return true; \
+                        case P * 100 + 8: f(sc_int<P>(), sc_int<8>()); return true;
+    SC_F2P_CASES(2) SC_F2P_CASES(3) SC_F2P_CASES(4) SC_F2P_CASES(5) SC_F2P_CASES(6) SC_F2P_CASES(8)
+    SC_F2P_CASES(10) SC_F2P_CASES(12) SC_F2P_CASES(20)
+#undef SC_F2P_CASES
     default: return false;
   }
 }
@@ -675,9 +695,13 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     std::string why;
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
-  if (!rc && !p->fast && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !(desc->flags & SC_PLAN_IO_BF16)) rc = f2p_plan_init(p);
+  if (!rc && !p->fast && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !(desc->flags & SC_PLAN_IO_BF16))
+    rc = f2p_plan_init(p, true);
   if (!rc && !p->fast && !p->f2p && !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT)))
     rc = pl128_plan_init(p);
+  if (!rc && !p->fast && !p->f2p && !p->pl128 &&
+      !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT | SC_PLAN_NO_F2P_SMALL)))
+    rc = f2p_plan_init(p, false);
   if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
     rc = sc_fail("sc_engine: SC_PLAN_IO_BF16 is implemented on the fused 2-D kernels (generation 3) only: "
                  "width 256, height 64..512, kept block <= 64 x 33, no frequency maps");

@@ -30,8 +30,10 @@
 // way out (in: build Z from A, B), so a half-wave moves 2 x 4 KB rows per round with 128-byte coalesced accesses.
 // The inverse kernels are the exact transposes (zero-padded 32-point stage first).
 //
-// Scope (sc_engine.cpp: f2p_eligible): 2 dims, both sizes in {512, 1024}, default centred frequency maps, real
-// data, kept columns below the Nyquist column; everything else stays on the size-agnostic passes.
+// Scope (sc_engine.cpp: f2p_plan_init): 2 dims, both sizes 32 P with P in {2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 32}
+// (round 3; before: {16, 32}), default centred frequency maps, real data, kept columns below the Nyquist column,
+// kept half-ranges up to 8 P per axis; everything else stays on the size-agnostic passes.  Grids the fused one-image
+// kernels (W = 256, kept <= 64 x 33) or the 128 x 128 plane kernels serve keep those.
 #pragma once
 #include "sc_kernels_fft3.h"
 
@@ -113,14 +115,128 @@ SC_HD void dft32(const cf32 (&a)[32], cf32 (&b)[32]) {
   });
 }
 
+// ---- round 3: stage-1 codelets for every P in {2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 32}, i.e. lines of
+//      N = 32 P = 64, 96, 128, 160, 192, 256, 320, 384, 512, 640, 1024 points (the reference's FFT is O(N log N) on
+//      any size: spectral_convolution.py:443, 548, 559; before this round every width off 256 / 512 / 1024 ran the
+//      direct O(N k) DFT on the matrix cores).  Radix 3 and 5 are written out; composite P = R1 x R2 is one
+//      Cooley-Tukey step with compile-time twiddles.
+// cos(2 pi j / 60), j = 0..15: every twiddle of w_6, w_10, w_12, w_20 is +-table[.] by symmetry
+constexpr float f2p_cos60(int j) {
+  constexpr float Q[16] = {1.f, 0.99452189536827328986f, 0.97814760073380568883f, 0.95105651629515353118f,
+                           0.91354545764260086660f, 0.86602540378443870761f, 0.80901699437494745126f,
+                           0.74314482547739424412f, 0.66913060635885823757f, 0.58778525229247313710f, 0.5f,
+                           0.40673664307580037480f, 0.30901699437494745126f, 0.20791169081775923155f,
+                           0.10452846326765345697f, 0.f};
+  j = ((j % 60) + 60) % 60;
+  if (j > 30) j = 60 - j;
+  return j > 15 ? -Q[30 - j] : Q[j];
+}
+constexpr float f2p_sin60(int j) { return f2p_cos60(j - 15); }
+// a * exp(DIR 2 pi i M / P), M and P compile-time, P a divisor of 60
+template <int DIR, int P, int M>
+SC_HD cf32 mul_wP(const cf32 a) {
+  static_assert(60 % P == 0, "twiddle table: divisors of 60");
+  constexpr int j = (((M % P) + P) % P) * (60 / P);
+  if constexpr (j == 0) {
+    return a;
+  } else if constexpr (j == 15) {
+    return rot90<DIR>(a);
+  } else if constexpr (j == 30) {
+    return cf_make(-a.x, -a.y);
+  } else if constexpr (j == 45) {
+    return rot90<-DIR>(a);
+  } else {
+    constexpr float c = f2p_cos60(j), sn = (DIR < 0) ? -f2p_sin60(j) : f2p_sin60(j);
+    return cf_mul_tw(a, c, -sn, sn);
+  }
+}
+// small in-place DFTs, natural order: a_k <- sum_n a_n w_R^(nk), w_R = exp(DIR 2 pi i / R)
+template <int DIR>
+SC_HD void dft3(cf32& a0, cf32& a1, cf32& a2) {
+  constexpr float h = 0.86602540378443864676f;             // sin(2 pi / 3)
+  const cf32 sm = cf_add(a1, a2), d = cf_sub(a1, a2);
+  const cf32 m = cf_make(a0.x - 0.5f * sm.x, a0.y - 0.5f * sm.y);
+  const cf32 r = cf_scale(rot90<DIR>(d), h);               // (DIR i) sin(2 pi / 3) (a1 - a2)
+  a0 = cf_add(a0, sm);
+  a1 = cf_add(m, r);
+  a2 = cf_sub(m, r);
+}
+template <int DIR>
+SC_HD void dft5(cf32& a0, cf32& a1, cf32& a2, cf32& a3, cf32& a4) {
+  constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;   // cos(2 pi / 5), cos(4 pi / 5)
+  constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;    // sin(2 pi / 5), sin(4 pi / 5)
+  const cf32 p1 = cf_add(a1, a4), p2 = cf_add(a2, a3), d1 = cf_sub(a1, a4), d2 = cf_sub(a2, a3);
+  const cf32 e1 = cf_make(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+  const cf32 e2 = cf_make(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+  const cf32 o1 = rot90<DIR>(cf_make(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y));
+  const cf32 o2 = rot90<DIR>(cf_make(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y));
+  a0 = cf_add(a0, cf_add(p1, p2));
+  a1 = cf_add(e1, o1);
+  a4 = cf_sub(e1, o1);
+  a2 = cf_add(e2, o2);
+  a3 = cf_sub(e2, o2);
+}
+template <int R, int DIR>
+SC_HD void f2p_small_dft(cf32 (&v)[R]) {
+  if constexpr (R == 2) {
+    const cf32 t = v[0];
+    v[0] = cf_add(t, v[1]);
+    v[1] = cf_sub(t, v[1]);
+  } else if constexpr (R == 3) {
+    dft3<DIR>(v[0], v[1], v[2]);
+  } else if constexpr (R == 4) {
+    radix4<DIR>(v[0], v[1], v[2], v[3]);
+  } else {
+    static_assert(R == 5, "radices 2, 3, 4, 5");
+    dft5<DIR>(v[0], v[1], v[2], v[3], v[4]);
+  }
+}
+// P = R1 x R2 (n = R2 n1 + n2, k = k1 + R1 k2):  X[k1 + R1 k2] = sum_n2 w_R2^(n2 k2) w_P^(n2 k1) sum_n1 w_R1^(n1 k1) a[R2 n1 + n2]
+template <int R1, int R2, int DIR>
+SC_HD void f2p_ct(const cf32 (&a)[R1 * R2], cf32 (&b)[R1 * R2]) {
+  constexpr int P = R1 * R2;
+  cf32 y[R2][R1];
+#pragma unroll
+  for (int n2 = 0; n2 < R2; ++n2) {
+#pragma unroll
+    for (int n1 = 0; n1 < R1; ++n1) y[n2][n1] = a[R2 * n1 + n2];
+    f2p_small_dft<R1, DIR>(y[n2]);
+  }
+  sc_static_for<0, R1>([&](auto k1t) {
+    constexpr int k1 = decltype(k1t)::value;
+    cf32 v[R2];
+    sc_static_for<0, R2>([&](auto n2t) {
+      constexpr int n2 = decltype(n2t)::value;
+      v[n2] = mul_wP<DIR, P, n2 * k1>(y[n2][k1]);
+    });
+    f2p_small_dft<R2, DIR>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) b[k1 + R1 * k2] = v[k2];
+  });
+}
+
 // stage-1 codelet of a line: P points per lane
 template <int P, int DIR>
 SC_HD void f2p_dftP(cf32 (&a)[P], cf32 (&b)[P]) {
   if constexpr (P == 32) {
     dft32<DIR>(a, b);
-  } else {
-    static_assert(P == 16, "lines of 512 or 1024 points");
+  } else if constexpr (P == 16) {
     fft16<DIR>(a, b);
+  } else if constexpr (P == 8) {
+    dft8<DIR>(a, b);
+  } else if constexpr (P == 20) {
+    f2p_ct<5, 4, DIR>(a, b);
+  } else if constexpr (P == 12) {
+    f2p_ct<3, 4, DIR>(a, b);
+  } else if constexpr (P == 10) {
+    f2p_ct<5, 2, DIR>(a, b);
+  } else if constexpr (P == 6) {
+    f2p_ct<3, 2, DIR>(a, b);
+  } else {
+    static_assert(P == 2 || P == 3 || P == 4 || P == 5, "lines of 32 P points, P in {2,3,4,5,6,8,10,12,16,20,32}");
+#pragma unroll
+    for (int i = 0; i < P; ++i) b[i] = a[i];
+    f2p_small_dft<P, DIR>(b);
   }
 }
 
@@ -217,12 +333,12 @@ k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __r
     if (it + 1 < SC_F2P_R2C_ITER) fetch(it + 1);
     E[t] = u[0];
 #pragma unroll
-    for (int k1 = 1; k1 < P; ++k1) E[k1 * SC_F2P_RS + t] = cf_mul_cs(u[k1], tw[k1 * 32 + t]);
+    for (int k1 = 1; k1 < P; ++k1) E[k1 * SC_F2P_RS + t] = cf_mul_cs(u[k1], sc_lds_ld64(tw + k1 * 32 + t));
     SC_WAVE_SYNC();
     cf32 y[32], Zk[2 * K2 + 1];
     const int L = t < P ? t : 0;                         // lane L plays k1 = L (lanes >= P idle at P = 16)
 #pragma unroll
-    for (int q = 0; q < 32; ++q) y[q] = E[L * SC_F2P_RS + q];
+    for (int q = 0; q < 32; ++q) y[q] = sc_lds_ld64(E + L * SC_F2P_RS + q);   // explicit widths: sc_device.h
     SC_WAVE_SYNC();
     dft32_kept<-1, K2, true>(y, Zk);                     // Z[L + P k2], k2 = -K2 .. K2
     if (t < P) {
@@ -236,7 +352,7 @@ k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __r
     for (int i = 0; i < NI; ++i) {
       const int k = t + 32 * i;
       if (k < J) {
-        const cf32 zk = E[KOFF + k], zm = E[KOFF - k];
+        const cf32 zk = sc_lds_ld64(E + KOFF + k), zm = sc_lds_ld64(E + KOFF - k);
         const float s = sc[i];
         // A = (Z[k] + conj Z[-k]) / 2,  B = -i (Z[k] - conj Z[-k]) / 2
         cf32* d = dst + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
@@ -279,12 +395,12 @@ k_f2p_col_fwd(const cf32* __restrict__ panel, cf32* __restrict__ xhat, const cf3
   cf32* Ec = E + c * SC_F2P_CS;
   Ec[s] = u[0];
 #pragma unroll
-  for (int k1 = 1; k1 < P; ++k1) Ec[k1 * SC_F2P_RS + s] = cf_mul_cs(u[k1], tw[k1 * 32 + s]);
+  for (int k1 = 1; k1 < P; ++k1) Ec[k1 * SC_F2P_RS + s] = cf_mul_cs(u[k1], sc_lds_ld64(tw + k1 * 32 + s));
   SC_SYNC();
   if (s < P) {
     cf32 y[32], X[2 * K2 + 1];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) y[q] = Ec[s * SC_F2P_RS + q];
+    for (int q = 0; q < 32; ++q) y[q] = sc_lds_ld64(Ec + s * SC_F2P_RS + q);
     dft32_kept<-1, K2, false>(y, X);
     if (live) {
       cf32* dst = xhat + img * (int64_t)K0 * J + col;
@@ -339,7 +455,7 @@ k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf3
   SC_SYNC();
   cf32 u[P], z[P];
 #pragma unroll
-  for (int k1 = 0; k1 < P; ++k1) u[k1] = Ec[k1 * SC_F2P_RS + s];
+  for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(Ec + k1 * SC_F2P_RS + s);
   f2p_dftP<P, +1>(u, z);                                 // over k1 -> j : line point n = s + 32 j
   if (live) {
     cf32* dst = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
@@ -411,7 +527,7 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
     cf32 in[2 * K2 + 1];
     const int L = t < P ? t : 0;
 #pragma unroll
-    for (int i = 0; i < 2 * K2; ++i) in[i] = E[KOFF + L + P * (i - K2)];
+    for (int i = 0; i < 2 * K2; ++i) in[i] = sc_lds_ld64(E + KOFF + L + P * (i - K2));
     in[2 * K2] = (t == 0) ? E[2 * KOFF] : cf_make(0.f, 0.f);
     SC_WAVE_SYNC();
     {
@@ -426,7 +542,7 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
     SC_WAVE_SYNC();
     cf32 u[P], z[P];
 #pragma unroll
-    for (int k1 = 0; k1 < P; ++k1) u[k1] = E[k1 * SC_F2P_RS + t];
+    for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(E + k1 * SC_F2P_RS + t);
     SC_WAVE_SYNC();                                      // E is rewritten by the next pair's Z
     f2p_dftP<P, +1>(u, z);                               // z[j] = a[t + 32 j] + i b[t + 32 j]
     const float bv = bias ? bias[(img + img0) % channels] : 0.f;   // img0: first image of this chunk

@@ -78,7 +78,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
       SC_WAVE_SYNC();
       cf32 y[16], o[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) y[q] = E[L * SC_PL_ES + q];
+      for (int q = 0; q < 16; ++q) y[q] = sc_lds_ld64(E + L * SC_PL_ES + q);   // explicit widths: sc_device.h
       fft16<-1>(y, o);                                   // over t -> k2: Z[L + 8 k2]
       if (t < 8) {
         Zs[16 + t] = o[0];
@@ -111,7 +111,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
     if (act) {
       cf32 v[16], u[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = T[(t + 8 * j) * SC_PL_RS + c];
+      for (int j = 0; j < 16; ++j) v[j] = sc_lds_ld64(T + (t + 8 * j) * SC_PL_RS + c);
       fft16<-1>(v, u);                                   // over j -> k1
       E2[t] = u[0];
 #pragma unroll
@@ -125,7 +125,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
         const int k1 = t + 8 * h;
         cf32 y[8], o[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) y[q] = E2[k1 * 9 + q];
+        for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + k1 * 9 + q);
         dft8<-1>(y, o);                                  // over t -> k2: k = k1 + 16 k2; kept: k2 = 0 and k2 = -1
         const int rp = k1 + K0 / 2, rn = k1 - 16 + K0 / 2;
         if (c < J) {
@@ -186,7 +186,7 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
     if (act) {
       cf32 u[16], v[16];
 #pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) u[k1] = E2[k1 * 9 + t];
+      for (int k1 = 0; k1 < 16; ++k1) u[k1] = sc_lds_ld64(E2 + k1 * 9 + t);
       fft16<+1>(u, v);                                   // over k1 -> j: row n = t + 8 j
 #pragma unroll
       for (int j = 0; j < 16; ++j) T[(t + 8 * j) * SC_PL_RS + c] = v[j];
@@ -208,7 +208,7 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
       const int p = g + 16 * r;
       {
         // Z[k] = A + i B, Z[-k] = conj A + i conj B; k = 0: (Re A, Re B)
-        const cf32 A = T[(2 * p) * SC_PL_RS + t], B = T[(2 * p + 1) * SC_PL_RS + t];
+        const cf32 A = sc_lds_ld64(T + (2 * p) * SC_PL_RS + t), B = sc_lds_ld64(T + (2 * p + 1) * SC_PL_RS + t);
         Zs[16 + t] = (t == 0) ? cf_make(A.x, B.x) : cf_make(A.x - B.y, A.y + B.x);
         if (t > 0) Zs[16 - t] = cf_make(A.x + B.y, B.x - A.y);
         if (t == 0) {
@@ -235,7 +235,7 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
       SC_WAVE_SYNC();
       cf32 u[8], z[8];
 #pragma unroll
-      for (int k1 = 0; k1 < 8; ++k1) u[k1] = E[k1 * SC_PL_ES + t];
+      for (int k1 = 0; k1 < 8; ++k1) u[k1] = sc_lds_ld64(E + k1 * SC_PL_ES + t);
       dft8<+1>(u, z);                                    // over k1 -> j: z[j] = a[t + 16 j] + i b[t + 16 j]
       float* ra = yp + (2 * p) * SC_PL_N + t;
 #pragma unroll
@@ -281,7 +281,7 @@ k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restr
       const int k1 = t + 8 * h;
       cf32 y[8], r[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) y[q] = E2[k1 * 9 + q];
+      for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + k1 * 9 + q);
       dft8<-1>(y, r);
       const int rp = k1 + K / 2, rn = k1 - 16 + K / 2;
       if (live && rp < K) dst[(int64_t)rp * inner] = r[0];
@@ -306,7 +306,7 @@ k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restr
     SC_WAVE_SYNC();
     cf32 u[16], v[16];
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) u[k1] = E2[k1 * 9 + t];
+    for (int k1 = 0; k1 < 16; ++k1) u[k1] = sc_lds_ld64(E2 + k1 * 9 + t);
     fft16<+1>(u, v);
     if (live) {
       cf32* dst = out + (o * SC_PL_N + t) * inner + col;

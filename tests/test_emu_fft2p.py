@@ -57,6 +57,15 @@ CASES = [
     ((512, 1024), (31, 17), 2),         # odd kept rows, ragged columns
     ((512, 512), (256, 120), 1),        # half of the rows, widest column range the codelets cover
     ((1024, 1024), (2, 1), 1),
+    # round 3: lines of 32 P points, P in {2, 3, 4, 5, 6, 8, 10, 12, 20} (radix 3 / 5 codelets, composite P)
+    ((64, 64), (32, 17), 3),            # the common small grid (fno2d_64, modes 32): P = 2
+    ((96, 96), (24, 13), 2),            # P = 3
+    ((192, 192), (64, 33), 1),          # P = 6 = 3 x 2, the widest kept block of the fused 256-wide kernels
+    ((160, 320), (20, 11), 2),          # P = 5 and 10 = 5 x 2
+    ((384, 640), (48, 25), 1),          # P = 12 = 3 x 4 and 20 = 5 x 4
+    ((128, 64), (16, 9), 2),            # P = 4 and 2 (not a 128 x 128 plane)
+    ((256, 256), (128, 65), 1),         # P = 8: a kept block beyond the fused kernels' 64 x 33
+    ((64, 1024), (5, 3), 2),            # mixed with a 1024-point line
 ]
 
 
@@ -119,7 +128,8 @@ def test_two_pass_scope(lib):
     """Outside the route's scope the plan stays on the size-agnostic passes (and still works)."""
     for spatial, kept in (((1024, 1024), (256, 513)),     # Nyquist column kept
                           ((2048, 1024), (64, 33)),       # line length without a codelet
-                          ((1024, 256), (64, 33))):
+                          ((1024, 288), (64, 33)),        # 288 = 32 x 9: no radix-9 codelet
+                          ((64, 64), (64, 33))):          # keep-everything: beyond the pruned 32-point stage's range
         plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
         try:
             assert lib.plan_kernel_name(plan, 0) != "k_f2p_r2c"

@@ -55,6 +55,13 @@ ORACLE_CASES = [
     (32, 64, 64, (32, 32), (12, 12), (16, 16)),     # ... through the sub-block index tables
     (8, 32, 32, (32, 32, 32), (16, 16, 16), None),  # small batch: gX-hat streams with clamped rows, backward pair launch
     (12, 32, 48, (64, 64), (32, 30), None),         # ... 12 rows, ragged second column tile (kept 32 x 16)
+    # round 3: two-pass factorised route for lines of 32 P points, P in {2, 3, 4, 5, 6, 8, 10, 12, 20}
+    (2, 8, 8, (64, 64), (32, 32), None),            # P = 2
+    (2, 4, 6, (96, 96), (24, 24), None),            # P = 3
+    (2, 8, 8, (192, 192), (64, 64), None),          # P = 6
+    (1, 4, 4, (384, 640), (48, 48), None),          # P = 12, 20
+    (2, 3, 5, (160, 320), (20, 20), None),          # P = 5, 10
+    (1, 4, 4, (256, 256), (128, 128), None),        # P = 8: kept block beyond the fused kernels' 64 x 33
 ]
 
 
@@ -171,6 +178,30 @@ def test_vs_oracle(lib, case, flags):
     assert rel_l2(gx.cpu().numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(gw.cpu().numpy(), wc.grad.numpy()) < TOL
     assert rel_l2(gb.cpu().numpy(), bc.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("spatial,kept", [((64, 64), (32, 17)), ((96, 96), (24, 13)), ((192, 192), (64, 33)),
+                                          ((384, 640), (48, 25)), ((256, 256), (128, 65)), ((160, 320), (20, 11))])
+def test_factorised_route_for_32p_lines(lib, spatial, kept):
+    """Round 3: grids of 32 P points per axis (64 .. 640) are never on the direct-DFT passes any more; the fused
+    256-wide kernels and the 128 x 128 plane kernels keep their shapes."""
+    from neuraloperator_amd import _lib as L
+    plan = lib.plan_create(list(spatial), list(kept))
+    try:
+        assert lib.plan_kernel_name(plan, 0) == "k_f2p_r2c" and lib.plan_kernel_name(plan, 1) == "k_f2p_c2r"
+    finally:
+        lib.plan_destroy(plan)
+    plan = lib.plan_create(list(spatial), list(kept), flags=L.SC_PLAN_NO_F2P_SMALL)
+    try:
+        assert lib.plan_kernel_name(plan, 0) != "k_f2p_r2c"
+    finally:
+        lib.plan_destroy(plan)
+    for sp, kp, name in (((256, 256), (64, 33), "k_fft2d_fwd3"), ((128, 128), (32, 17), "k_pl128_fwd")):
+        plan = lib.plan_create(list(sp), list(kp))
+        try:
+            assert lib.plan_kernel_name(plan, 0) == name
+        finally:
+            lib.plan_destroy(plan)
 
 
 def test_full_size_properties(lib):
