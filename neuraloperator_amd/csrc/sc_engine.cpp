@@ -514,17 +514,19 @@ static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, i
   for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
     const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
     const int64_t n_blk = ni * NCB;
-    const int per_xcd = (int)((n_blk + 7) / 8);
     const float* xs = x + i0 * p->ntot;
     bool ok = f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / (16 * SC_F2P_R2C_ITER))),
+      constexpr int G = 32 / decltype(P)::value;           // row pairs per half-wave
+      SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)((ni * N0 / 2 + 8 * G - 1) / (8 * G))),
                 dim3(256), 0, st,
-                xs, panel, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_fwd[mode], N0, J, NCB);
+                xs, panel, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_fwd[mode], N0, J, NCB, ni * N0 / 2);
     });
     cf32* dst = xhat + i0 * p->modes;
     ok = ok && f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * per_xcd)), dim3(256), 0, st,
-                (const cf32*)panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, per_xcd);
+      constexpr int G = 32 / decltype(P)::value;           // panel blocks per workgroup
+      const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
+      SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * pxc)), dim3(256), 0, st,
+                (const cf32*)panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
     });
     if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
   }
@@ -540,18 +542,20 @@ static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float
   for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
     const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
     const int64_t n_blk = ni * NCB;
-    const int per_xcd = (int)((n_blk + 7) / 8);
     const cf32* src = yhat + i0 * p->modes;
     bool ok = f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * per_xcd)), dim3(256), 0, st,
-                src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, per_xcd);
+      constexpr int G = 32 / decltype(P)::value;
+      const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
+      SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * pxc)), dim3(256), 0, st,
+                src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
     });
     float* ys = y + i0 * p->ntot;
     ok = ok && f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
-      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(ni * N0 / (16 * SC_F2P_C2R_ITER))),
+      constexpr int G = 32 / decltype(P)::value;
+      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)((ni * N0 / 2 + 8 * G - 1) / (8 * G))),
                 dim3(256), 0, st,
                 (const cf32*)panel, ys, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_inv[mode], bias,
-                (int)channels, (int)(i0 % channels), N0, J, NCB);
+                (int)channels, (int)(i0 % channels), N0, J, NCB, ni * N0 / 2);
     });
     if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
   }

@@ -288,71 +288,86 @@ SC_HD void dft32_padded(const cf32 (&in)[2 * K2 + 1], cf32 (&g)[32]) {
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 1 forward: real rows -> kept columns of the panel.  One half-wave per packed row pair, 8 pairs per workgroup
-// and round, SC_F2P_R2C_ITER rounds per workgroup: the rows of the next round are requested as soon as the first
-// stage has consumed the current ones (the occupancy of this kernel is set by its LDS, so the 64 extra registers
-// of the prefetch cost nothing).
+// Round 3: G = 32 / P lines per half-wave (row kernels) / panel blocks per workgroup (column kernels).  Stage 2 of a
+// line -- the pruned 32-point DFT over t -- is one lane per k1, i.e. only P of the 32 lanes of a line work in it; with
+// one line per half-wave a 64-point line (P = 2) kept 2 lanes busy and the route ran 4 x slower than the direct-DFT
+// passes it was meant to replace (profiles/r03_f2p_widths_ab.txt).  Now a half-wave transforms G row pairs at once:
+// stage 1 runs G radix-P codelets per lane (G P <= 32 points, the register budget of the P = 32 case), the exchange
+// rows are [g P + k1][t], and lane t < G P plays (pair g = t / P, k1 = t % P) in stage 2 -- 30 to 32 of 32 lanes busy
+// for every P (P = 16: two pairs instead of one).  The per-pair Z arrays (2 KOFF + 1 values each) share the
+// exchange buffer as before.
 // ------------------------------------------------------------------------------------------
-// (measured, profiles/r02_f2p_round_loop_ab.txt: 1 / 2 / 4 rounds -> 0.652-0.654 / 0.656-0.689 / 0.666 ms per forward
-// transform at 1024^2: nothing to gain, the default stays 1)
-#ifndef SC_F2P_R2C_ITER
-#define SC_F2P_R2C_ITER 1
-#endif
+
+// ------------------------------------------------------------------------------------------
+// pass 1 forward: real rows -> kept columns of the panel.  One half-wave per G packed row pairs, 8 half-waves per
+// workgroup; n_pairs = row pairs of this launch (images x N0 / 2).
+// ------------------------------------------------------------------------------------------
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __restrict__ twN,
-          const float* __restrict__ cs, int N0, int J, int NCB) {
-  constexpr int N = 32 * P, KOFF = P * K2;
+          const float* __restrict__ cs, int N0, int J, int NCB, int64_t n_pairs) {
+  constexpr int N = 32 * P, KOFF = P * K2, G = 32 / P, ZS = 2 * KOFF + 1;
   constexpr int NI = (KOFF + 32) / 32;                   // k = t + 32 i <= KOFF
+  static_assert(G * ZS <= 32 * SC_F2P_RS, "the Z arrays of a half-wave share its exchange buffer");
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
   const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
-  cf32 z[P], u[P];
-  auto fetch = [&](const int it) {
-    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_R2C_ITER + it) * 8 + hw);
-    const float* xa = x + rA * N + t;
+  const int64_t pair0 = ((int64_t)SC_BID_X * 8 + hw) * G;
+  cf32 z[G][P];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;   // past the end: a harmless re-read
+    const float* xa = x + 2 * pr * N + t;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      z[j].x = SC_LOAD_STREAM(xa + 32 * j);
-      z[j].y = SC_LOAD_STREAM(xa + N + 32 * j);
+      z[g][j].x = SC_LOAD_STREAM(xa + 32 * j);
+      z[g][j].y = SC_LOAD_STREAM(xa + N + 32 * j);
     }
-  };
-  fetch(0);
+  }
   float sc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) sc[i] = (t + 32 * i < J) ? cs[t + 32 * i] : 0.f;   // 0.5 x norm x column weight
   SC_SYNC();                                             // twiddle table
   cf32* E = Eall[hw];
-#pragma unroll 1
-  for (int it = 0; it < SC_F2P_R2C_ITER; ++it) {
-    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_R2C_ITER + it) * 8 + hw);
-    const int64_t img = rA / N0;
-    const int n = (int)(rA - img * N0);
-    f2p_dftP<P, -1>(z, u);                               // over j -> k1
-    if (it + 1 < SC_F2P_R2C_ITER) fetch(it + 1);
-    E[t] = u[0];
 #pragma unroll
-    for (int k1 = 1; k1 < P; ++k1) E[k1 * SC_F2P_RS + t] = cf_mul_cs(u[k1], sc_lds_ld64(tw + k1 * 32 + t));
-    SC_WAVE_SYNC();
+  for (int g = 0; g < G; ++g) {
+    cf32 u[P];
+    f2p_dftP<P, -1>(z[g], u);                            // over j -> k1
+    E[(g * P) * SC_F2P_RS + t] = u[0];
+#pragma unroll
+    for (int k1 = 1; k1 < P; ++k1) E[(g * P + k1) * SC_F2P_RS + t] = cf_mul_cs(u[k1], sc_lds_ld64(tw + k1 * 32 + t));
+  }
+  SC_WAVE_SYNC();
+  {
     cf32 y[32], Zk[2 * K2 + 1];
-    const int L = t < P ? t : 0;                         // lane L plays k1 = L (lanes >= P idle at P = 16)
+    const int L = t < G * P ? t : 0;                     // lane L plays (pair L / P, k1 = L % P)
 #pragma unroll
     for (int q = 0; q < 32; ++q) y[q] = sc_lds_ld64(E + L * SC_F2P_RS + q);   // explicit widths: sc_device.h
     SC_WAVE_SYNC();
-    dft32_kept<-1, K2, true>(y, Zk);                     // Z[L + P k2], k2 = -K2 .. K2
-    if (t < P) {
+    dft32_kept<-1, K2, true>(y, Zk);                     // Z[k1 + P k2], k2 = -K2 .. K2
+    if (t < G * P) {
+      const int g = t / P, k1 = t - g * P;
+      cf32* Zb = E + g * ZS;
 #pragma unroll
-      for (int i = 0; i < 2 * K2; ++i) E[KOFF + t + P * (i - K2)] = Zk[i];
-      if (t == 0) E[2 * KOFF] = Zk[2 * K2];
+      for (int i = 0; i < 2 * K2; ++i) Zb[KOFF + k1 + P * (i - K2)] = Zk[i];
+      if (k1 == 0) Zb[2 * KOFF] = Zk[2 * K2];
     }
-    SC_WAVE_SYNC();
+  }
+  SC_WAVE_SYNC();
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    const int64_t pr = pair0 + g;
+    if (pr >= n_pairs) break;                            // uniform per half-wave
+    const int64_t rA = 2 * pr, img = rA / N0;
+    const int n = (int)(rA - img * N0);
+    const cf32* Zb = E + g * ZS;
     cf32* dst = panel + ((img * NCB) * (int64_t)N0 + n) * SC_F2P_CB;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = t + 32 * i;
       if (k < J) {
-        const cf32 zk = sc_lds_ld64(E + KOFF + k), zm = sc_lds_ld64(E + KOFF - k);
+        const cf32 zk = sc_lds_ld64(Zb + KOFF + k), zm = sc_lds_ld64(Zb + KOFF - k);
         const float s = sc[i];
         // A = (Z[k] + conj Z[-k]) / 2,  B = -i (Z[k] - conj Z[-k]) / 2
         cf32* d = dst + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
@@ -360,126 +375,137 @@ k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __r
         d[SC_F2P_CB] = cf_make(s * (zk.y + zm.y), s * (zm.x - zk.x));
       }
     }
-    SC_WAVE_SYNC();                                      // E is rewritten by the next round
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 2 forward: one panel block (N0 rows x 8 columns) per workgroup -> the kept rows of its columns.
-// thread = (column c = tid & 7, slot s = tid >> 3): slot s is lane t = s of the column's line in stage 1 and
-// k1 = s in stage 2.
+// pass 2 forward: G panel blocks (N0 rows x 8 columns each) per workgroup -> the kept rows of their columns.
+// thread = (column c = tid & 7, slot s = tid >> 3): slot s is lane t = s of every block's column line in stage 1
+// and (block g = s / P, k1 = s % P) in stage 2.
 // ------------------------------------------------------------------------------------------
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_col_fwd(const cf32* __restrict__ panel, cf32* __restrict__ xhat, const cf32* __restrict__ twN, int NCB, int J,
               int K0, int64_t n_blk, int per_xcd) {
-  constexpr int N0 = 32 * P;
+  constexpr int N0 = 32 * P, G = 32 / P;
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_F2P_CS];
   const int tid = SC_TID, c = tid & 7, s = tid >> 3;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
   // consecutive panel blocks (the column blocks of one image) on ONE XCD: their 64-byte output pieces share
   // 128-byte lines, which then merge in that XCD's L2 (the dispatcher places workgroup b on XCD b % 8)
-  const int64_t blk = f2p_block(per_xcd);
-  if (blk >= n_blk) return;
-  const int cb = (int)(blk % NCB);
-  const int64_t img = blk / NCB;
-  const int col = cb * SC_F2P_CB + c;
-  const bool live = col < J;
-  const cf32* src = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
-  cf32 z[P], u[P];
+  const int64_t blk0 = f2p_block(per_xcd) * G;
+  if (blk0 >= n_blk) return;
+  cf32 z[G][P];
 #pragma unroll
-  for (int j = 0; j < P; ++j) z[j] = live ? src[(int64_t)32 * j * SC_F2P_CB] : cf_make(0.f, 0.f);
+  for (int g = 0; g < G; ++g) {
+    const int64_t blk = blk0 + g < n_blk ? blk0 + g : n_blk - 1;
+    const int col = (int)(blk % NCB) * SC_F2P_CB + c;
+    const cf32* src = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[g][j] = col < J ? src[(int64_t)32 * j * SC_F2P_CB] : cf_make(0.f, 0.f);
+  }
   SC_SYNC();
-  f2p_dftP<P, -1>(z, u);
   cf32* Ec = E + c * SC_F2P_CS;
-  Ec[s] = u[0];
 #pragma unroll
-  for (int k1 = 1; k1 < P; ++k1) Ec[k1 * SC_F2P_RS + s] = cf_mul_cs(u[k1], sc_lds_ld64(tw + k1 * 32 + s));
+  for (int g = 0; g < G; ++g) {
+    cf32 u[P];
+    f2p_dftP<P, -1>(z[g], u);
+    Ec[(g * P) * SC_F2P_RS + s] = u[0];
+#pragma unroll
+    for (int k1 = 1; k1 < P; ++k1) Ec[(g * P + k1) * SC_F2P_RS + s] = cf_mul_cs(u[k1], sc_lds_ld64(tw + k1 * 32 + s));
+  }
   SC_SYNC();
-  if (s < P) {
+  if (s < G * P) {
+    const int g = s / P, k1 = s - g * P;
+    const int64_t blk = blk0 + g;
     cf32 y[32], X[2 * K2 + 1];
 #pragma unroll
     for (int q = 0; q < 32; ++q) y[q] = sc_lds_ld64(Ec + s * SC_F2P_RS + q);
     dft32_kept<-1, K2, false>(y, X);
-    if (live) {
-      cf32* dst = xhat + img * (int64_t)K0 * J + col;
+    if (blk < n_blk) {
+      const int col = (int)(blk % NCB) * SC_F2P_CB + c;
+      if (col < J) {
+        cf32* dst = xhat + (blk / NCB) * (int64_t)K0 * J + col;
 #pragma unroll
-      for (int i = 0; i < 2 * K2; ++i) {
-        const int row = s + P * (i - K2) + K0 / 2;
-        if (row >= 0 && row < K0) dst[(int64_t)row * J] = X[i];
+        for (int i = 0; i < 2 * K2; ++i) {
+          const int row = k1 + P * (i - K2) + K0 / 2;
+          if (row >= 0 && row < K0) dst[(int64_t)row * J] = X[i];
+        }
       }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 2 inverse: kept rows of 8 columns -> full columns of the panel block (zero padded in frequency)
+// pass 2 inverse: kept rows of 8 columns -> full columns of the panel block (zero padded in frequency), G blocks
+// per workgroup
 // ------------------------------------------------------------------------------------------
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf32* __restrict__ twN, int NCB, int J,
               int K0, int64_t n_blk, int per_xcd) {
-  constexpr int N0 = 32 * P;
+  constexpr int N0 = 32 * P, G = 32 / P;
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_F2P_CS];
   const int tid = SC_TID, c = tid & 7, s = tid >> 3;
   for (int i = tid; i < P * 32; i += 256) tw[i] = twN[i];
   // consecutive panel blocks on ONE XCD (see k_f2p_col_fwd): the 64-byte pieces of the kept rows that neighbouring
-  // column blocks read share 128-byte lines -- fetched once per XCD instead of once per block (126 MB per chunk for 45 MB of kept rows before, profiles/r02_pmc_traffic_raw_fno2d_1024.txt)
-  const int64_t blk = f2p_block(per_xcd);
-  if (blk >= n_blk) return;
-  const int cb = (int)(blk % NCB);
-  const int64_t img = blk / NCB;
-  const int col = cb * SC_F2P_CB + c;
-  const bool live = col < J;
+  // column blocks read share 128-byte lines -- fetched once per XCD instead of once per block
+  const int64_t blk0 = f2p_block(per_xcd) * G;
+  if (blk0 >= n_blk) return;
   cf32 in[2 * K2 + 1];
   {
-    const cf32* src = yhat + img * (int64_t)K0 * J + col;
+    const bool on = s < G * P;
+    const int g = on ? s / P : 0, k1 = s - g * P;
+    const int64_t blk = blk0 + g;
+    const bool live_b = on && blk < n_blk;
+    const int col = live_b ? (int)(blk % NCB) * SC_F2P_CB + c : 0;
+    const cf32* src = yhat + (live_b ? blk / NCB : 0) * (int64_t)K0 * J + col;
 #pragma unroll
     for (int i = 0; i < 2 * K2; ++i) {
-      const int row = s + P * (i - K2) + K0 / 2;
-      in[i] = (live && s < P && row >= 0 && row < K0) ? src[(int64_t)row * J] : cf_make(0.f, 0.f);
+      const int row = k1 + P * (i - K2) + K0 / 2;
+      in[i] = (live_b && col < J && row >= 0 && row < K0) ? src[(int64_t)row * J] : cf_make(0.f, 0.f);
     }
     in[2 * K2] = cf_make(0.f, 0.f);
   }
   SC_SYNC();
   cf32* Ec = E + c * SC_F2P_CS;
-  if (s < P) {
-    cf32 g[32];
-    dft32_padded<+1, K2, false>(in, g);
-    Ec[s * SC_F2P_RS] = g[0];
+  if (s < G * P) {
+    const int k1 = s % P;
+    cf32 gq[32];
+    dft32_padded<+1, K2, false>(in, gq);
+    Ec[s * SC_F2P_RS] = gq[0];
 #pragma unroll
-    for (int q = 1; q < 32; ++q) Ec[s * SC_F2P_RS + q] = cf_mul_cs(g[q], cf_conj(tw[s * 32 + q]));
+    for (int q = 1; q < 32; ++q) Ec[s * SC_F2P_RS + q] = cf_mul_cs(gq[q], cf_conj(sc_lds_ld64(tw + k1 * 32 + q)));
   }
   SC_SYNC();
-  cf32 u[P], z[P];
 #pragma unroll
-  for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(Ec + k1 * SC_F2P_RS + s);
-  f2p_dftP<P, +1>(u, z);                                 // over k1 -> j : line point n = s + 32 j
-  if (live) {
-    cf32* dst = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
+  for (int g = 0; g < G; ++g) {
+    const int64_t blk = blk0 + g;
+    cf32 u[P], z[P];
 #pragma unroll
-    for (int j = 0; j < P; ++j) dst[(int64_t)32 * j * SC_F2P_CB] = z[j];
+    for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(Ec + (g * P + k1) * SC_F2P_RS + s);
+    f2p_dftP<P, +1>(u, z);                               // over k1 -> j : line point n = s + 32 j
+    if (blk < n_blk && (int)(blk % NCB) * SC_F2P_CB + c < J) {
+      cf32* dst = panel + blk * (int64_t)N0 * SC_F2P_CB + s * SC_F2P_CB + c;
+#pragma unroll
+      for (int j = 0; j < P; ++j) dst[(int64_t)32 * j * SC_F2P_CB] = z[j];
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 1 inverse: kept columns of two panel rows -> two real rows (+ bias).  A half-wave transforms SC_F2P_C2R_ITER
-// packed row pairs in a row and requests the (few) panel values of the next pair before it transforms the current
-// one, so only the first pair of a workgroup waits for memory.
+// pass 1 inverse: kept columns of two panel rows -> two real rows (+ bias), G row pairs per half-wave
 // ------------------------------------------------------------------------------------------
-// (measured, profiles/r02_f2p_round_loop_ab.txt: 1 / 4 / 8 pairs per half-wave -> 0.913-0.920 / 0.911-0.926 / 0.910 ms
-// per inverse transform at 1024^2 -- the other resident workgroup already covers the wait; the default stays 1)
-#ifndef SC_F2P_C2R_ITER
-#define SC_F2P_C2R_ITER 1
-#endif
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ twN,
-          const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J, int NCB) {
-  constexpr int N = 32 * P, KOFF = P * K2;
+          const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J, int NCB,
+          int64_t n_pairs) {
+  constexpr int N = 32 * P, KOFF = P * K2, G = 32 / P, ZS = 2 * KOFF + 1;
   constexpr int NI = (KOFF + 32) / 32;
+  static_assert(G * ZS <= 32 * SC_F2P_RS, "the Z arrays of a half-wave share its exchange buffer");
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
   const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
@@ -488,62 +514,57 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
   float sc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) sc[i] = (t + 32 * i < J) ? cs[t + 32 * i] : 0.f;   // norm x column weight (x 1/2, k > 0)
-  cf32 pa[NI], pb[NI];
-  auto fetch = [&](const int it) {
-    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_C2R_ITER + it) * 8 + hw);
-    const int64_t img = rA / N0;
-    const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int k = t + 32 * i;
-      if (k < J) {
-        const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
-        pa[i] = a[0];
-        pb[i] = a[SC_F2P_CB];
-      } else {
-        pa[i] = pb[i] = cf_make(0.f, 0.f);
-      }
-    }
-  };
-  fetch(0);
-  SC_SYNC();                                             // twiddle table
+  const int64_t pair0 = ((int64_t)SC_BID_X * 8 + hw) * G;
+  // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B) -- straight into the pair's Z array
 #pragma unroll 1
-  for (int it = 0; it < SC_F2P_C2R_ITER; ++it) {
-    const int64_t rA = 2 * (((int64_t)SC_BID_X * SC_F2P_C2R_ITER + it) * 8 + hw);
-    const int64_t img = rA / N0;
+  for (int g = 0; g < G; ++g) {
+    const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;
+    const int64_t rA = 2 * pr, img = rA / N0;
+    const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+    cf32* Zb = E + g * ZS;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = t + 32 * i;
       if (k <= KOFF) {
-        const cf32 A = pa[i], B = pb[i];
+        cf32 A = cf_make(0.f, 0.f), B = A;
+        if (k < J) {
+          const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
+          A = a[0];
+          B = a[SC_F2P_CB];
+        }
         const float s = sc[i];
-        // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B)
-        E[KOFF + k] = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
-        if (k > 0) E[KOFF - k] = cf_make(s * (A.x + B.y), s * (B.x - A.y));
+        Zb[KOFF + k] = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
+        if (k > 0) Zb[KOFF - k] = cf_make(s * (A.x + B.y), s * (B.x - A.y));
       }
     }
-    if (it + 1 < SC_F2P_C2R_ITER) fetch(it + 1);
-    SC_WAVE_SYNC();
+  }
+  SC_SYNC();                                             // twiddle table (and this half-wave's Z arrays)
+  {
     cf32 in[2 * K2 + 1];
-    const int L = t < P ? t : 0;
+    const bool on = t < G * P;
+    const int g = on ? t / P : 0, k1 = t - g * P;
+    const cf32* Zb = E + g * ZS;
 #pragma unroll
-    for (int i = 0; i < 2 * K2; ++i) in[i] = sc_lds_ld64(E + KOFF + L + P * (i - K2));
-    in[2 * K2] = (t == 0) ? E[2 * KOFF] : cf_make(0.f, 0.f);
+    for (int i = 0; i < 2 * K2; ++i) in[i] = sc_lds_ld64(Zb + KOFF + k1 + P * (i - K2));
+    in[2 * K2] = (k1 == 0) ? Zb[2 * KOFF] : cf_make(0.f, 0.f);
     SC_WAVE_SYNC();
-    {
-      cf32 g[32];
-      dft32_padded<+1, K2, true>(in, g);
-      if (t < P) {
-        E[t * SC_F2P_RS] = g[0];
+    cf32 gq[32];
+    dft32_padded<+1, K2, true>(in, gq);
+    if (on) {
+      E[t * SC_F2P_RS] = gq[0];
 #pragma unroll
-        for (int q = 1; q < 32; ++q) E[t * SC_F2P_RS + q] = cf_mul_cs(g[q], cf_conj(tw[t * 32 + q]));
-      }
+      for (int q = 1; q < 32; ++q) E[t * SC_F2P_RS + q] = cf_mul_cs(gq[q], cf_conj(sc_lds_ld64(tw + k1 * 32 + q)));
     }
-    SC_WAVE_SYNC();
+  }
+  SC_WAVE_SYNC();
+#pragma unroll 1
+  for (int g = 0; g < G; ++g) {
+    const int64_t pr = pair0 + g;
+    if (pr >= n_pairs) break;                            // uniform per half-wave
+    const int64_t rA = 2 * pr, img = rA / N0;
     cf32 u[P], z[P];
 #pragma unroll
-    for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(E + k1 * SC_F2P_RS + t);
-    SC_WAVE_SYNC();                                      // E is rewritten by the next pair's Z
+    for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(E + (g * P + k1) * SC_F2P_RS + t);
     f2p_dftP<P, +1>(u, z);                               // z[j] = a[t + 32 j] + i b[t + 32 j]
     const float bv = bias ? bias[(img + img0) % channels] : 0.f;   // img0: first image of this chunk
     float* ya = y + rA * N + t;

@@ -232,7 +232,7 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 #else
   const int k1l = lam >> 2, n4 = lam & 3;             // after the transpose: lane = (k1, n4)
 #endif
-#ifdef SC_F3_TW1_CS
+#if defined(SC_F3_TW1_CS)
   cf32 tw1[8];
 #pragma unroll
   for (int k = 1; k < 8; ++k) tw1[k] = tabW[(lam * k) & 255];               // w256^(n2 k1) as (c, s)
@@ -335,7 +335,7 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 #endif
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1)
-#ifdef SC_F3_TW1_CS
+#if defined(SC_F3_TW1_CS)
         xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul_cs(o[k1], tw1[k1]);
 #else
         xb[k1 * SC_F3_XRS + lam] = (k1 == 0) ? o[0] : cf_mul_tw(o[k1], tw1[k1].c, tw1[k1].ns, tw1[k1].s);
