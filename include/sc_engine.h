@@ -80,6 +80,8 @@ enum {
                                 (the host adds the real bias); transforms only, no sc_layer_*      */
   SC_PLAN_NO_F2P_SMALL = 32, /* keep grids of 64 .. 640 points per axis (32 P, P in {2,3,4,5,6,8,10,12,20}) on the
                                 direct-DFT passes instead of the two-pass factorised route (round 3; A-B)  */
+  SC_PLAN_F2P_SMALL_ALWAYS = 64, /* take the two-pass route for supported grids below 128 x 128 points too (A-B, tests:
+                                by default those stay on the one-launch direct-DFT plane passes, which are faster there) */
   SC_PLAN_IO_BF16 = 16       /* the REAL tensors (x, y, gy, gx) are bfloat16 in memory -- the `float*`
                                 arguments that carry them then point at 2-byte elements; spectra,
                                 weights, bias and every arithmetic step stay float32 and y / gx are

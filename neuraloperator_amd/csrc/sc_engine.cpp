@@ -432,6 +432,10 @@ static int f2p_plan_init(sc_plan* p, bool large_only) {
   for (int d = 0; d < 2; ++d) {
     if (large_only ? (p->n[d] != 512 && p->n[d] != 1024) : !f2p_line_ok(p->n[d])) return 0;
   }
+  // small planes: two launches + a panel per transform lose against the one-launch direct-DFT plane form of the
+  // matrix-core passes (64^2, modes 32: 0.39 vs 0.23 ms/step; 192^2, modes 64: 0.70 vs 1.31 ms/step --
+  // profiles/r03_f2p_widths_ab.txt).  Taken from 128 x 128 points per plane; SC_PLAN_F2P_SMALL_ALWAYS overrides (A-B, tests)
+  if (!large_only && p->n[0] * p->n[1] < 128 * 128 && !(p->d.flags & SC_PLAN_F2P_SMALL_ALWAYS)) return 0;
   const int P0 = (int)(p->n[0] / 32), P1 = (int)(p->n[1] / 32);
   const int64_t K0 = p->k[0], J = p->k[1];
   if (J > p->n[1] / 2) return 0;                          // kept columns stay below the Nyquist column

@@ -515,23 +515,33 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
 #pragma unroll
   for (int i = 0; i < NI; ++i) sc[i] = (t + 32 * i < J) ? cs[t + 32 * i] : 0.f;   // norm x column weight (x 1/2, k > 0)
   const int64_t pair0 = ((int64_t)SC_BID_X * 8 + hw) * G;
-  // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B) -- straight into the pair's Z array
-#pragma unroll 1
+  // the few panel values of all G pairs are requested first (one exposed memory latency per half-wave, not G)
+  cf32 pa[G][NI], pb[G][NI];
+#pragma unroll
   for (int g = 0; g < G; ++g) {
     const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;
     const int64_t rA = 2 * pr, img = rA / N0;
     const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int k = t + 32 * i;
+      pa[g][i] = pb[g][i] = cf_make(0.f, 0.f);
+      if (k < J) {
+        const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
+        pa[g][i] = a[0];
+        pb[g][i] = a[SC_F2P_CB];
+      }
+    }
+  }
+  // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B) -- into the pair's Z array
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
     cf32* Zb = E + g * ZS;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = t + 32 * i;
       if (k <= KOFF) {
-        cf32 A = cf_make(0.f, 0.f), B = A;
-        if (k < J) {
-          const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
-          A = a[0];
-          B = a[SC_F2P_CB];
-        }
+        const cf32 A = pa[g][i], B = pb[g][i];
         const float s = sc[i];
         Zb[KOFF + k] = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
         if (k > 0) Zb[KOFF - k] = cf_make(s * (A.x + B.y), s * (B.x - A.y));

@@ -74,9 +74,15 @@ def test_two_pass_transforms(lib, spatial, kept, n_img):
     rng = np.random.default_rng(5)
     N0, N1 = spatial
     K0, J = kept
-    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+    # planes below 128 x 128 points stay on the direct-DFT passes by default (faster there): forced here
+    small = N0 * N1 < 128 * 128
+    if small:
+        pd = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+        assert lib.plan_kernel_name(pd, 0) != "k_f2p_r2c"
+        lib.plan_destroy(pd)
+    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=_lib.SC_PLAN_F2P_SMALL_ALWAYS if small else 0)
     try:
-        assert lib.plan_kernel_name(plan, 0) == "k_f2p_r2c", "the large power-of-two grid takes the two-pass route"
+        assert lib.plan_kernel_name(plan, 0) == "k_f2p_r2c", "grids of 32 P points per axis take the two-pass route"
         ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8)
         x = torch.from_numpy(rng.standard_normal((n_img, N0, N1)).astype(np.float32))
         ntot = N0 * N1

@@ -154,7 +154,7 @@ def test_module_bf16_activations():
         assert rel_l2(gb.cpu().numpy(), conv.bias.grad.cpu().numpy()) < TOL
 
 
-@pytest.mark.parametrize("flags", [0, 1, 5], ids=["default", "force_generic", "force_generic_valu"])
+@pytest.mark.parametrize("flags", [0, 1, 5, 64], ids=["default", "force_generic", "force_generic_valu", "two_pass_small"])
 @pytest.mark.parametrize("case", ORACLE_CASES, ids=lambda c: "x".join(map(str, c[3])) + f"_m{c[4][0]}_c{c[1]}")
 def test_vs_oracle(lib, case, flags):
     from oracle import spectral_oracle as so
@@ -186,7 +186,14 @@ def test_factorised_route_for_32p_lines(lib, spatial, kept):
     """Round 3: grids of 32 P points per axis (64 .. 640) are never on the direct-DFT passes any more; the fused
     256-wide kernels and the 128 x 128 plane kernels keep their shapes."""
     from neuraloperator_amd import _lib as L
+    small = spatial[0] * spatial[1] < 128 * 128          # small planes: the one-launch direct-DFT passes are faster
     plan = lib.plan_create(list(spatial), list(kept))
+    try:
+        name = lib.plan_kernel_name(plan, 0)
+        assert (name != "k_f2p_r2c") if small else (name == "k_f2p_r2c" and lib.plan_kernel_name(plan, 1) == "k_f2p_c2r")
+    finally:
+        lib.plan_destroy(plan)
+    plan = lib.plan_create(list(spatial), list(kept), flags=L.SC_PLAN_F2P_SMALL_ALWAYS)
     try:
         assert lib.plan_kernel_name(plan, 0) == "k_f2p_r2c" and lib.plan_kernel_name(plan, 1) == "k_f2p_c2r"
     finally:
