@@ -182,6 +182,8 @@ int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
  * streamed matrix-core kernel: plain contiguous-mode operands, mode count a multiple of 8), 3 k_modegemm_sb (round 3:
  * small-extent streaming kernel on the vector ALUs -- a batch of <= 4 rows against a large weight, or a reduction of
  * <= 4 terms into a weight-sized result: plain contiguous-mode operands, even mode count, even row strides;
+ * bit-identical to path 0), 4 k_modegemm_bfac (round 3: b_sm == 0, i.e. a mode-independent right operand -- the channel
+ * factor matrices of Tucker / CP contractions -- read through the scalar cache; unit mode strides of A and C, Q >= 8;
  * bit-identical to path 0) */
 int sc_modegemm_path(const sc_modegemm_desc* d);
 

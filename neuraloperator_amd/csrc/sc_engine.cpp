@@ -1366,6 +1366,39 @@ static int run_sb_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, 
   return wm4 ? run_sb_gemm_t<4, 4, 2, 4, 1, 1>(d, A, B, C, st) : run_sb_gemm_t<4, 4, 2, 1, 2, 2>(d, A, B, C, st);
 }
 
+// ---- mode-independent right operand (sc_kernels_sb.h, k_modegemm_bfac): factor matrices through the scalar cache
+static bool bfac_gemm_eligible(const sc_modegemm_desc* d) {
+  if (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_SB)) return false;
+  if (d->accumulate || d->b_idx || d->c_idx || d->a_sg || d->b_sg || d->c_sg) return false;
+  if (d->b_sm != 0 || d->a_sm != 1 || d->c_sm != 1) return false;
+  return d->Q >= 8 && d->R >= 4 && d->n_modes >= 64;
+}
+
+template <int QC>
+static int run_bfac_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  BfacGemmArgs g;
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.c_sp = d->c_sp; g.c_sq = d->c_sq;
+  g.n_mt = (int)((d->n_modes + 63) / 64);
+  g.n_qg = (int)((d->Q + 4 * QC - 1) / (4 * QC));
+  const int64_t total = (int64_t)g.n_mt * g.n_qg * d->P;
+  if (total >= ((int64_t)1 << 31)) return -1;
+  const dim3 grid((unsigned)total);
+#define SC_BF_LAUNCH(CA, CB) SC_LAUNCH((k_modegemm_bfac<QC, CA, CB>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C)
+  if (!d->conj_a && !d->conj_b) SC_BF_LAUNCH(false, false);
+  else if (d->conj_a && !d->conj_b) SC_BF_LAUNCH(true, false);
+  else if (!d->conj_a && d->conj_b) SC_BF_LAUNCH(false, true);
+  else SC_BF_LAUNCH(true, true);
+#undef SC_BF_LAUNCH
+  return sc_check_launch("k_modegemm_bfac");
+}
+
+static int run_bfac_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  // columns per wave: 9 when that divides the work into whole waves better (ranks such as 36, 18, 27), else 8
+  const int64_t w8 = (d->Q + 7) / 8, w9 = (d->Q + 8) / 9;
+  return (w9 * 9 - d->Q < w8 * 8 - d->Q) ? run_bfac_gemm_t<9>(d, A, B, C, st) : run_bfac_gemm_t<8>(d, A, B, C, st);
+}
+
 // ---- matrix-core path (sc_kernels_mfma.h): channel counts that fill 32 x 32 MFMA tiles ----------
 static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
   // one workgroup tile is 32 or 64 rows x 64 columns; ragged problems (Tucker / TT ranks such as 36) take it
@@ -1632,6 +1665,10 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
     else if (d->conj_b) SC_LAUNCH((k_modegemm_f16<false, true>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
     else SC_LAUNCH((k_modegemm_f16<false, false>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
     return sc_check_launch("k_modegemm_f16");
+  }
+  if (bfac_gemm_eligible(d)) {
+    const int rc = run_bfac_gemm(d, a, b, c, st);
+    if (rc >= 0) return rc;
   }
   if (sb_gemm_eligible(d, A, B, C)) {
     const int rc = run_sb_gemm(d, a, b, c, st);
@@ -2013,6 +2050,7 @@ extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream
 
 extern "C" int sc_modegemm_path(const sc_modegemm_desc* d) {
   if (!d) return 0;
+  if (bfac_gemm_eligible(d)) return 4;
   if (sb_gemm_eligible(d, nullptr, nullptr, nullptr)) return 3;
   if (gemm8_eligible(d, nullptr, nullptr, nullptr)) return 2;
   return !(d->flags & SC_GEMM_FORCE_VALU) && mfma_gemm_eligible(d) ? 1 : 0;

@@ -142,3 +142,61 @@ k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__
     }
   }
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Contraction with a MODE-INDEPENDENT right operand (round 3): C[p, q, m] = sum_r opA(A[p, r, m]) * opB(B[r, q])
+// -- the channel-factor steps of the factorized contractions (spectral_convolution.py:55-103: z = xhat U_in,
+// yhat = t U_out^T and their adjoints in the backward pass; CP's factor products).  B is a small matrix (64 x 36
+// complex at TFNO rank 0.1) that every mode shares, so it never has to be a per-lane operand: lanes = modes, the wave
+// reads B[r, q] through the SCALAR cache (wave-uniform address -> s_load) and uses it as the scalar source of the FMAs;
+// a lane holds QC complex accumulators and streams its A values once.  The four waves of a workgroup take four
+// neighbouring chunks of QC columns for the same (row, mode tile): the A slice is fetched once per workgroup, the
+// other waves hit L1.  The register-staged matrix-core kernel that served these calls spends its time on 64-column
+// tiles for a rank of 36 and on operand staging: 41 us per call at TFNO rank 0.1 for 1.25 GFLOP and 54 MB
+// (profiles/r03_tfno_kernel_stats.txt).  Exact fp32, r-ordered fmaf chains: bit-identical to k_modegemm.
+// ------------------------------------------------------------------------------------------
+struct BfacGemmArgs {
+  int64_t P, Q, R, M;
+  int64_t a_sp, a_sr, b_sr, b_sq, c_sp, c_sq;
+  int n_mt, n_qg;                                 // mode tiles of 64, groups of 4 QC columns
+};
+
+template <int QC, bool CA, bool CB>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_modegemm_bfac(BfacGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+  const int tid = SC_TID, lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
+  // item = (row p, mode tile, column group): mode tile fastest, so that neighbouring workgroups stream neighbouring
+  // 512-byte pieces of the same A rows
+  const int64_t item = SC_BID_X;
+  const int mt = (int)(item % g.n_mt);
+  const int64_t rest = item / g.n_mt;
+  const int qg = (int)(rest % g.n_qg);
+  const int64_t p = rest / g.n_qg;
+  const int64_t q0 = ((int64_t)qg * 4 + w) * QC;                    // wave-uniform
+  if (q0 >= g.Q) return;                                            // whole wave idle (no barriers in this kernel)
+  const int64_t m = (int64_t)mt * 64 + lane;
+  const bool active = m < g.M;
+  const cf32* Ap = A + p * g.a_sp + (active ? m : g.M - 1);
+  cf32 acc[QC];
+#pragma unroll
+  for (int j = 0; j < QC; ++j) acc[j] = cf_make(0.f, 0.f);
+#pragma unroll 4
+  for (int64_t r = 0; r < g.R; ++r) {
+    cf32 a = Ap[r * g.a_sr];
+    if (CA) a.y = -a.y;
+    const cf32* Br = B + r * g.b_sr;                                // wave-uniform address: scalar loads
+#pragma unroll
+    for (int j = 0; j < QC; ++j) {
+      const int64_t q = (q0 + j < g.Q) ? (q0 + j) : (g.Q - 1);
+      cf32 b = Br[q * g.b_sq];
+      if (CB) b.y = -b.y;
+      cf_mac(acc[j], a, b);
+    }
+  }
+  if (!active) return;
+#pragma unroll
+  for (int j = 0; j < QC; ++j)
+    if (q0 + j < g.Q) C[p * g.c_sp + (q0 + j) * g.c_sq + m] = acc[j];
+}

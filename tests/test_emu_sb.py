@@ -115,3 +115,29 @@ def test_layer_at_small_batch_takes_it(lib):
     assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
     assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+
+
+# ---- k_modegemm_bfac: a mode-independent right operand (factor matrix) read through the scalar cache -----------------
+@pytest.mark.parametrize("dims", [(3, 64, 36, 130), (2, 36, 64, 70), (4, 10, 19, 64), (1, 5, 8, 200), (2, 7, 40, 66)],
+                         ids=lambda d: "P%d_R%d_Q%d_M%d" % d)
+@pytest.mark.parametrize("transposed", [False, True], ids=["B_rq", "B_qr"])
+@pytest.mark.parametrize("conj", [(0, 0), (0, 1), (1, 0)], ids=["plain", "conjB", "conjA"])
+def test_factor_operand(lib, dims, transposed, conj):
+    """C[p,q,m] = sum_r opA(A[p,r,m]) opB(B[r,q]) with B stored [r][q] or [q][r] (z = xhat U_in, yhat = t U_out^T and
+    the adjoints of the Tucker / CP chains): against complex128 and, bit for bit, the VALU kernel."""
+    P, R, Q, M = dims
+    ca, cb = conj
+    a = _rand(P, R, M, seed=7)
+    bm = _rand(R, Q, seed=8)
+    store = bm.t().contiguous() if transposed else bm.contiguous()
+    kw = dict(P=P, Q=Q, R=R, n_modes=M, a_sp=R * M, a_sr=M, a_sm=1, b_sm=0, conj_a=ca, conj_b=cb,
+              b_sr=(1 if transposed else Q), b_sq=(R if transposed else 1), c_sp=Q * M, c_sq=M, c_sm=1)
+    a128, b128 = a.numpy().astype(np.complex128), bm.numpy().astype(np.complex128)
+    ref = np.einsum("prm,rq->pqm", np.conj(a128) if ca else a128, np.conj(b128) if cb else b128)
+    c = torch.full((P, Q, M), float("nan"), dtype=torch.complex64)
+    _run(lib, a, store, c, expect=4, **kw)
+    assert rel_l2(c.numpy(), ref) < TOL
+    c0 = torch.full((P, Q, M), float("nan"), dtype=torch.complex64)
+    fl = _lib.SC_GEMM_NO_SB | _lib.SC_GEMM_FORCE_VALU | _lib.SC_GEMM_NO_STREAM
+    _run(lib, a, store, c0, flags=fl, expect=0, **kw)
+    assert torch.equal(torch.view_as_real(c), torch.view_as_real(c0))
