@@ -161,16 +161,16 @@ SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-// occupancy of the forward kernel: 4 workgroups per CU (128 VGPRs) with a ONE-round-deep row prefetch and the
-// first-stage twiddles as (c, s) pairs.  Measured (profiles/r01_fft_gen3_ablation.txt, session 3): once the
-// packed butterflies stopped wasting VALU slots on register moves the kernel became latency-bound, and a fourth
-// resident workgroup hides more of the LDS / HBM latency than the second prefetch round did (124.6-126.3 ->
-// 116.4-120.4 us).  A-B: -DSC_F3_FWD_OCC=3 -DSC_F3_PF_DEPTH=2 -DSC_F3_TW1_LEGACY.
+// occupancy / prefetch depth of the forward kernel.  Round 3: with the last row stage in registers the kernel's compute
+// (67 us) is well below its load stream (86 us alone) and the two overlap imperfectly (106.5 us at depth 1, four
+// workgroups per CU); a TWO-round-deep row prefetch at three workgroups per CU (152 VGPRs) runs 103-105 us and the
+// layer step 538.9 -> 529.9 us (21 interleaved rounds, profiles/r03_prefetch_depth_step_ab.txt).  Depth 2 at four
+// workgroups spills (120 us), depth 4 at two / three: 117 / 179 us.  A-B: -DSC_F3_FWD_OCC=4 -DSC_F3_PF_DEPTH=1 (round 2).
 #ifndef SC_F3_FWD_OCC
-#define SC_F3_FWD_OCC 4
+#define SC_F3_FWD_OCC 3
 #endif
 #ifndef SC_F3_PF_DEPTH
-#define SC_F3_PF_DEPTH 1
+#define SC_F3_PF_DEPTH 2
 #endif
 #ifndef SC_F3_TW1_LEGACY
 #define SC_F3_TW1_CS 1

@@ -386,8 +386,11 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
     if (m >= g.M) continue;
     const uint32_t la = (uint32_t)(m * g.a_sm);
     const uint32_t lb = g.b_idx ? (uint32_t)g.b_idx[m] : (uint32_t)(m * g.b_sm);
-#pragma unroll 2
-    for (int64_t r = 0; r < g.R; ++r) {                       // two steps of operand loads in flight
+#ifndef SC_MSUM_UNROLL
+#define SC_MSUM_UNROLL 4                                      // steps of operand loads in flight (A-B: 2 = round 2)
+#endif
+#pragma unroll SC_MSUM_UNROLL
+    for (int64_t r = 0; r < g.R; ++r) {
       cf32 a[PT], b[QT];
 #pragma unroll
       for (int pp = 0; pp < PT; ++pp) {

@@ -182,17 +182,30 @@ k_modegemm_bfac(BfacGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   cf32 acc[QC];
 #pragma unroll
   for (int j = 0; j < QC; ++j) acc[j] = cf_make(0.f, 0.f);
-#pragma unroll 4
-  for (int64_t r = 0; r < g.R; ++r) {
-    cf32 a = Ap[r * g.a_sr];
-    if (CA) a.y = -a.y;
-    const cf32* Br = B + r * g.b_sr;                                // wave-uniform address: scalar loads
+  // the lane's A values are requested DEPTH steps ahead (a wave's r loop is otherwise one exposed memory latency per
+  // unrolled body: 64 steps x ~1 us at four loads in flight made the first version no faster than the kernel it replaced)
+  constexpr int DEPTH = 16;
+  cf32 ring[DEPTH];
 #pragma unroll
-    for (int j = 0; j < QC; ++j) {
-      const int64_t q = (q0 + j < g.Q) ? (q0 + j) : (g.Q - 1);
-      cf32 b = Br[q * g.b_sq];
-      if (CB) b.y = -b.y;
-      cf_mac(acc[j], a, b);
+  for (int i = 0; i < DEPTH; ++i) ring[i] = Ap[(i < g.R ? i : g.R - 1) * g.a_sr];
+#pragma unroll 1
+  for (int64_t r0 = 0; r0 < g.R; r0 += DEPTH) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      const int64_t r = r0 + i;
+      if (r < g.R) {                                                 // uniform
+        cf32 a = ring[i];
+        if (CA) a.y = -a.y;
+        const cf32* Br = B + r * g.b_sr;                             // wave-uniform address: scalar loads
+#pragma unroll
+        for (int j = 0; j < QC; ++j) {
+          const int64_t q = (q0 + j < g.Q) ? (q0 + j) : (g.Q - 1);
+          cf32 b = Br[q * g.b_sq];
+          if (CB) b.y = -b.y;
+          cf_mac(acc[j], a, b);
+        }
+      }
+      if (r + DEPTH < g.R) ring[i] = Ap[(r + DEPTH) * g.a_sr];       // refill the slot just consumed
     }
   }
   if (!active) return;
