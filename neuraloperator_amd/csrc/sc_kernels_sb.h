@@ -107,30 +107,39 @@ k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__
 #pragma unroll
     for (int qq = 0; qq < QT; ++qq) acc[pp][qq] = sc_f4{0.f, 0.f, 0.f, 0.f};
 
-  // ring of ST stages: stage s holds the operands of reduction step r with r % ST == s
+  // ring of ST stages: stage s holds the operands of reduction step r with r % ST == s.  NO uniform branch may
+  // surround a load in the steady state: behind one the compiler cannot count the loads in flight and waits with
+  // vmcnt(0), i.e. for the refill it has just issued (the first version did exactly that) -- steps past the end are
+  // clamped re-reads of the last one (requested, never used), whole blocks of ST steps run unguarded, the
+  // R % ST remaining steps use what the ring already holds.
   sc_f4 ra[ST][PT], rb[ST][QT];
   auto request = [&](const int64_t r, sc_f4 (&a)[PT], sc_f4 (&b)[QT]) {
-    const int64_t rr = r < g.R ? r : g.R - 1;                       // past the end: a harmless re-read, never used
+    const int64_t rr = r < g.R ? r : g.R - 1;
 #pragma unroll
     for (int pp = 0; pp < PT; ++pp) a[pp] = sb_load(Ap[pp] + rr * g.a_sr, g.nt_a);
 #pragma unroll
     for (int qq = 0; qq < QT; ++qq) b[qq] = sb_load(Bq[qq] + rr * g.b_sr, g.nt_b);
   };
+  auto multiply = [&](const sc_f4 (&a)[PT], const sc_f4 (&b)[QT]) {
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp)
+#pragma unroll
+      for (int qq = 0; qq < QT; ++qq) sb_mac<CA, CB>(acc[pp][qq], a[pp], b[qq]);
+  };
 #pragma unroll
   for (int s = 0; s < ST; ++s) request(s, ra[s], rb[s]);
+  const int64_t RB = (g.R / ST) * ST;
 #pragma unroll 1
-  for (int64_t r0 = 0; r0 < g.R; r0 += ST) {
+  for (int64_t r0 = 0; r0 < RB; r0 += ST) {
 #pragma unroll
     for (int s = 0; s < ST; ++s) {
-      if (r0 + s < g.R) {                                           // uniform
-#pragma unroll
-        for (int pp = 0; pp < PT; ++pp)
-#pragma unroll
-          for (int qq = 0; qq < QT; ++qq) sb_mac<CA, CB>(acc[pp][qq], ra[s][pp], rb[s][qq]);
-      }
-      if (r0 + s + ST < g.R) request(r0 + s + ST, ra[s], rb[s]);     // refill the slot just consumed
+      multiply(ra[s], rb[s]);
+      request(r0 + s + ST, ra[s], rb[s]);                             // refill the slot just consumed
     }
   }
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (RB + s < g.R) multiply(ra[s], rb[s]);                         // the R % ST last steps (no loads behind the branch)
   if (!active) return;
 #pragma unroll
   for (int pp = 0; pp < PT; ++pp) {
@@ -183,31 +192,38 @@ k_modegemm_bfac(BfacGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
 #pragma unroll
   for (int j = 0; j < QC; ++j) acc[j] = cf_make(0.f, 0.f);
   // the lane's A values are requested DEPTH steps ahead (a wave's r loop is otherwise one exposed memory latency per
-  // unrolled body: 64 steps x ~1 us at four loads in flight made the first version no faster than the kernel it replaced)
-  constexpr int DEPTH = 16;
+  // unrolled body).  As in k_modegemm_sb no uniform branch surrounds a load: behind one the compiler waits with
+  // vmcnt(0) for the refill it has just issued -- the first ring did, and ran SLOWER than no ring (50-56 vs 30-45 us,
+  // profiles/r03_tfno_kernel_stats.txt).  Steps past the end are clamped re-reads, whole blocks run unguarded.
+  constexpr int DEPTH = 8;
   cf32 ring[DEPTH];
+  auto step = [&](const int64_t r, cf32 a) {
+    if (CA) a.y = -a.y;
+    const cf32* Br = B + r * g.b_sr;                                 // wave-uniform address: scalar loads
+#pragma unroll
+    for (int j = 0; j < QC; ++j) {
+      const int64_t q = (q0 + j < g.Q) ? (q0 + j) : (g.Q - 1);
+      cf32 b = Br[q * g.b_sq];
+      if (CB) b.y = -b.y;
+      cf_mac(acc[j], a, b);
+    }
+  };
 #pragma unroll
   for (int i = 0; i < DEPTH; ++i) ring[i] = Ap[(i < g.R ? i : g.R - 1) * g.a_sr];
+  const int64_t RB = (g.R / DEPTH) * DEPTH;
 #pragma unroll 1
-  for (int64_t r0 = 0; r0 < g.R; r0 += DEPTH) {
+  for (int64_t r0 = 0; r0 < RB; r0 += DEPTH) {
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) {
-      const int64_t r = r0 + i;
-      if (r < g.R) {                                                 // uniform
-        cf32 a = ring[i];
-        if (CA) a.y = -a.y;
-        const cf32* Br = B + r * g.b_sr;                             // wave-uniform address: scalar loads
-#pragma unroll
-        for (int j = 0; j < QC; ++j) {
-          const int64_t q = (q0 + j < g.Q) ? (q0 + j) : (g.Q - 1);
-          cf32 b = Br[q * g.b_sq];
-          if (CB) b.y = -b.y;
-          cf_mac(acc[j], a, b);
-        }
-      }
-      if (r + DEPTH < g.R) ring[i] = Ap[(r + DEPTH) * g.a_sr];       // refill the slot just consumed
+      const cf32 a = ring[i];
+      const int64_t rn = r0 + i + DEPTH;
+      ring[i] = Ap[(rn < g.R ? rn : g.R - 1) * g.a_sr];              // refill first: the load overlaps the multiplies
+      step(r0 + i, a);
     }
   }
+#pragma unroll
+  for (int i = 0; i < DEPTH - 1; ++i)
+    if (RB + i < g.R) step(RB + i, ring[i]);                          // the R % DEPTH last steps
   if (!active) return;
 #pragma unroll
   for (int j = 0; j < QC; ++j)
