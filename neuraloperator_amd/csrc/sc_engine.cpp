@@ -1371,7 +1371,7 @@ static bool bfac_gemm_eligible(const sc_modegemm_desc* d) {
   if (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_SB)) return false;
   if (d->accumulate || d->b_idx || d->c_idx || d->a_sg || d->b_sg || d->c_sg) return false;
   if (d->b_sm != 0 || d->a_sm != 1 || d->c_sm != 1) return false;
-  return d->Q >= 8 && d->R >= 4 && d->n_modes >= 64;
+  return d->Q >= 8 && d->R >= 4 && d->n_modes >= 64 && d->R * ((d->Q + 1) & ~(int64_t)1) <= 8192;   // B in <= 64 KiB of LDS
 }
 
 template <int QC>
@@ -1384,7 +1384,8 @@ static int run_bfac_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32*
   const int64_t total = (int64_t)g.n_mt * g.n_qg * d->P;
   if (total >= ((int64_t)1 << 31)) return -1;
   const dim3 grid((unsigned)total);
-#define SC_BF_LAUNCH(CA, CB) SC_LAUNCH((k_modegemm_bfac<QC, CA, CB>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C)
+  const size_t shmem = (size_t)(d->R * ((d->Q + 1) & ~(int64_t)1)) * sizeof(cf32);
+#define SC_BF_LAUNCH(CA, CB) SC_LAUNCH((k_modegemm_bfac<QC, CA, CB>), grid, dim3(SC_BLOCK), shmem, st, g, A, B, C)
   if (!d->conj_a && !d->conj_b) SC_BF_LAUNCH(false, false);
   else if (d->conj_a && !d->conj_b) SC_BF_LAUNCH(true, false);
   else if (!d->conj_a && d->conj_b) SC_BF_LAUNCH(false, true);

@@ -174,8 +174,22 @@ struct BfacGemmArgs {
 template <int QC, bool CA, bool CB>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
 k_modegemm_bfac(BfacGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
+  // the whole factor matrix, conjugated if asked, as lds[r][q] (q contiguous whatever B's own layout is): every wave
+  // then reads its QC columns of row r with broadcast 16-byte LDS reads.  (First versions read B through the scalar
+  // cache: 30-33 us per call for the [r][q] layout, 42-45 us for the transposed one of the backward pass -- scalar
+  // loads return out of order, so every step waited for all of them; a deeper ring of A loads made it worse:
+  // profiles/r03_tfno_kernel_stats.txt.)
+  SC_DYN_SHARED(cf32, lds);
   const int tid = SC_TID, lane = tid & 63;
   const int w = SC_UNIFORM(tid >> 6);
+  const int Qp = (int)((g.Q + 1) & ~(int64_t)1);                    // row stride: even, so that rows stay 16-byte aligned
+  for (int i = tid; i < (int)(g.R * g.Q); i += SC_BLOCK) {
+    const int r = i / (int)g.Q, q = i - r * (int)g.Q;
+    cf32 b = B[r * g.b_sr + q * g.b_sq];
+    if (CB) b.y = -b.y;
+    lds[r * Qp + q] = b;
+  }
+  SC_SYNC();
   // item = (row p, mode tile, column group): mode tile fastest, so that neighbouring workgroups stream neighbouring
   // 512-byte pieces of the same A rows
   const int64_t item = SC_BID_X;
@@ -183,47 +197,32 @@ k_modegemm_bfac(BfacGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   const int64_t rest = item / g.n_mt;
   const int qg = (int)(rest % g.n_qg);
   const int64_t p = rest / g.n_qg;
-  const int64_t q0 = ((int64_t)qg * 4 + w) * QC;                    // wave-uniform
-  if (q0 >= g.Q) return;                                            // whole wave idle (no barriers in this kernel)
+  const int q0 = (qg * 4 + w) * QC;                                 // wave-uniform
+  if (q0 >= g.Q) return;                                            // whole wave idle (no barrier below)
   const int64_t m = (int64_t)mt * 64 + lane;
   const bool active = m < g.M;
   const cf32* Ap = A + p * g.a_sp + (active ? m : g.M - 1);
   cf32 acc[QC];
 #pragma unroll
   for (int j = 0; j < QC; ++j) acc[j] = cf_make(0.f, 0.f);
-  // the lane's A values are requested DEPTH steps ahead (a wave's r loop is otherwise one exposed memory latency per
-  // unrolled body).  As in k_modegemm_sb no uniform branch surrounds a load: behind one the compiler waits with
-  // vmcnt(0) for the refill it has just issued -- the first ring did, and ran SLOWER than no ring (50-56 vs 30-45 us,
-  // profiles/r03_tfno_kernel_stats.txt).  Steps past the end are clamped re-reads, whole blocks run unguarded.
-  constexpr int DEPTH = 8;
-  cf32 ring[DEPTH];
-  auto step = [&](const int64_t r, cf32 a) {
+  const bool whole = q0 + QC <= g.Q && (q0 & 1) == 0;               // wave-uniform: aligned 16-byte reads of a full chunk
+#pragma unroll 4
+  for (int64_t r = 0; r < g.R; ++r) {
+    cf32 a = Ap[r * g.a_sr];
     if (CA) a.y = -a.y;
-    const cf32* Br = B + r * g.b_sr;                                 // wave-uniform address: scalar loads
+    const cf32* br = lds + r * Qp + q0;
+    cf32 b[QC];
+    if (whole) {
 #pragma unroll
-    for (int j = 0; j < QC; ++j) {
-      const int64_t q = (q0 + j < g.Q) ? (q0 + j) : (g.Q - 1);
-      cf32 b = Br[q * g.b_sq];
-      if (CB) b.y = -b.y;
-      cf_mac(acc[j], a, b);
+      for (int j = 0; j + 1 < QC; j += 2) sc_lds_ld128(br + j, b[j], b[j + 1]);
+      if (QC & 1) b[QC - 1] = sc_lds_ld64(br + QC - 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < QC; ++j) b[j] = br[q0 + j < g.Q ? j : (int)g.Q - 1 - q0];
     }
-  };
 #pragma unroll
-  for (int i = 0; i < DEPTH; ++i) ring[i] = Ap[(i < g.R ? i : g.R - 1) * g.a_sr];
-  const int64_t RB = (g.R / DEPTH) * DEPTH;
-#pragma unroll 1
-  for (int64_t r0 = 0; r0 < RB; r0 += DEPTH) {
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i) {
-      const cf32 a = ring[i];
-      const int64_t rn = r0 + i + DEPTH;
-      ring[i] = Ap[(rn < g.R ? rn : g.R - 1) * g.a_sr];              // refill first: the load overlaps the multiplies
-      step(r0 + i, a);
-    }
+    for (int j = 0; j < QC; ++j) cf_mac(acc[j], a, b[j]);
   }
-#pragma unroll
-  for (int i = 0; i < DEPTH - 1; ++i)
-    if (RB + i < g.R) step(RB + i, ring[i]);                          // the R % DEPTH last steps
   if (!active) return;
 #pragma unroll
   for (int j = 0; j < QC; ++j)
