@@ -72,6 +72,8 @@ def parse():
                     help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
                          "bf16 = the bf16-I/O reading of BASELINE configs[1], fused 2-D kernels only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="roofline.traffic from profiles/pmc_traffic.json instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--settle-ms", type=float, default=SETTLE_MS,
                     help="untimed back-to-back steps (this many ms) between the cold timed region and the one `value` "
                          "reports: MI355X clocks settle ~20 ms into sustained load (0 = report the cold region only)")
@@ -318,6 +320,47 @@ def block_extra(B, C, spatial, n_modes, dev):
         torch.cuda.synchronize()
         out[tag] = round(e0.elapsed_time(e1) / 5, 4)
     return out
+
+
+def measure_traffic_live(workload_shape, kernel_substr, timeout_s=75):
+    """HBM bytes per launch of the dominant kernel, read from the PMC counters IN THIS RUN: two rocprofv3 passes
+    (FETCH_SIZE, WRITE_SIZE -- separate, as MI355X_MICROARCH.md prescribes) over scripts/layer_one.py (the whole layer
+    step through the C-ABI) in subprocesses, gfx950 correction FETCH_SIZE x 2, KB = 1024 B.  Returns (bytes, note) or
+    (None, reason): rocprofv3 wraps a process, so the counters cannot be read inside the timed process itself."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(exe):
+        return None, "rocprofv3 not found"
+    B, C, spatial, n_modes = workload_shape
+    env = dict(os.environ, TMPDIR="/tmp", LAYER_REPS="2",
+               LAYER_SHAPE=",".join(str(v) for v in (B, C, *spatial, *n_modes)))
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="sc_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--", sys.executable,
+                            os.path.join(ROOT, "scripts", "layer_one.py")], cwd="/tmp", env=env, timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            got = []
+            for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+                cur = sqlite3.connect(db).cursor()
+                for k, n, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+                    if n == counter and kernel_substr in k:
+                        got.append(float(v))
+            if not got:
+                return None, f"no {counter} rows for {kernel_substr}"
+            vals[counter] = sum(got) / len(got)
+        except Exception as e:                      # never let the counters kill the bench line
+            return None, f"{counter} pass failed: {type(e).__name__}: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(round(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)), \
+        (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+         f"scripts/layer_one.py, mean of {kernel_substr} launches, FETCH_SIZE x 2 (gfx950), KB = 1024 B")
 
 
 def engine_path(names):
@@ -702,11 +745,21 @@ def main():
         # the dominant kernel's own duration: back-to-back launches where that is measured (transforms), else in sequence
         dom_ms = stages[dom].get("ms_back_to_back", stages[dom]["ms"])
         dom_gbs = round(stages[dom]["alg_bytes"] / dom_ms / 1e6, 1)
+        traffic_source = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, gfx950 "
+                          "corrections applied; not re-measured by this run)")
+        if world == 1 and not args.no_pmc and args.io == "f32" and not args.plan_flags and not args.force_generic:
+            torch.cuda.synchronize()
+            live, note = measure_traffic_live(WORKLOADS[args.workload], kern)
+            if live is not None:
+                traffic_lookup, traffic, traffic_source = traffic, live, note
+                if traffic_lookup:
+                    traffic_source += f"; committed lookup (profiles/pmc_traffic.json): {traffic_lookup}"
+            else:
+                traffic_source += f"; live counters unavailable ({note})"
         roof = {"bound": "hbm", "kernel": kern, "stage": dom,
                 "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "kernel, gfx950 corrections applied; not re-measured by this run)",
+                "traffic_source": traffic_source,
                 "alg_bytes_per_launch": stages[dom]["alg_bytes"], "ms_per_launch": dom_ms,
                 "ms_per_launch_how": "2 x stage-iters launches back to back between one pair of events"
                                      if "ms_back_to_back" in stages[dom] else "in the layer's sequence, an event each side"}

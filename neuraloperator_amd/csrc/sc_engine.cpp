@@ -1736,7 +1736,14 @@ static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf
   if (splits < 1) splits = 1;
   if (splits > g.n_mt) splits = g.n_mt;
   g.per_xcd = (int)splits;
-  const int64_t total = splits * g.n_pg * g.n_qt;
+  // when the mode tiles alone do not fill the chip (TFNO rank 0.1: 33 tiles x 20 output tiles = 660 workgroups, 2.8 waves
+  // per SIMD, 45 % of the wave cycles issue-stalled: profiles/r03_tfno_pmc.txt) the reduction index is cut as well;
+  // SC_MSUM_RSPLIT (environment, A-B) overrides
+  static const int rsplit_env = [] { const char* e = std::getenv("SC_MSUM_RSPLIT"); return e ? std::atoi(e) : 0; }();
+  int64_t rsplit = rsplit_env > 0 ? rsplit_env : 1;
+  if (rsplit > g.R) rsplit = g.R;
+  g.r_split = (int)rsplit;
+  const int64_t total = splits * g.n_pg * g.n_qt * rsplit;
   if (wide) SC_LAUNCH((k_modegemm_msum<4, 8, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
   else SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
 }
@@ -1985,7 +1992,12 @@ static size_t tucker_lds_bytes(const sc_tucker_desc* d, bool bwd) {
   if (bwd) c += (size_t)d->mx * d->my + (size_t)d->rx * d->my;
   return c * sizeof(cf32);
 }
-static int tucker_wgs(const sc_tucker_desc* d) { return (int)(d->fg < 512 ? d->fg : 512); }
+static int tucker_wgs(const sc_tucker_desc* d) {
+  // workgroups of the two mode-factor kernels (each walks slices wg, wg + n, ...); SC_TK_WGS (environment, A-B)
+  static const int env = [] { const char* e = std::getenv("SC_TK_WGS"); return e ? std::atoi(e) : 0; }();
+  const int64_t cap = env > 0 ? env : 512;
+  return (int)(d->fg < cap ? d->fg : cap);
+}
 
 extern "C" int sc_tucker_modes_supported(const sc_tucker_desc* d) {
   if (!d || d->fg <= 0 || d->rx <= 0 || d->ry <= 0 || d->mx <= 0 || d->my <= 0) return 0;

@@ -188,6 +188,7 @@ struct ModeGemmArgs {
   int accumulate;
   // launch geometry: 1-D grid of 8 * per_xcd blocks, work item = (mode tile, p group, q tile)
   int n_mt, n_pg, n_qt, per_xcd;
+  int r_split;                  // k_modegemm_msum: the reduction index r is cut into this many chunks (more workgroups)
 };
 
 template <int PT, int QT, bool CA, bool CB>
@@ -369,7 +370,9 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
   const int tid = SC_TID;
   const int lane = tid & 63;
   const int w = SC_UNIFORM(tid >> 6);
-  const int item = SC_BID_X;
+  const int rsp = g.r_split > 1 ? g.r_split : 1;
+  const int item = SC_BID_X / rsp, rs = SC_BID_X - item * rsp;
+  const int64_t rch = (g.R + rsp - 1) / rsp, r_lo = rs * rch, r_hi = (r_lo + rch < g.R) ? r_lo + rch : g.R;
   const int ms = item / (g.n_pg * g.n_qt);                   // mode split: tiles ms, ms + per_xcd, ...
   const int rem = item - ms * (g.n_pg * g.n_qt);
   const int qt = rem / g.n_pg, pg = rem - qt * g.n_pg;
@@ -390,7 +393,7 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
 #define SC_MSUM_UNROLL 2                                      // steps of operand loads in flight (4: 49.6 -> 57.9 us at TFNO rank 0.1)
 #endif
 #pragma unroll SC_MSUM_UNROLL
-    for (int64_t r = 0; r < g.R; ++r) {
+    for (int64_t r = r_lo; r < r_hi; ++r) {
       cf32 a[PT], b[QT];
 #pragma unroll
       for (int pp = 0; pp < PT; ++pp) {

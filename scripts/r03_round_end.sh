@@ -7,7 +7,7 @@ O=gpurun_out/r3z; mkdir -p $O
 (python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12) > $O/smoke.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-reference --no-extras > $GRAFT_REPO_ROOT/$O/bench_prof.json 2> $GRAFT_REPO_ROOT/$O/bench_prof.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-reference --no-extras --no-pmc > $GRAFT_REPO_ROOT/$O/bench_prof.json 2> $GRAFT_REPO_ROOT/$O/bench_prof.err)
 python scripts/rocprof_summary.py /tmp/prof > $O/kernel_stats.txt 2>&1
 (cd /tmp && LAYER_REPS=3 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
 (cd /tmp && LAYER_REPS=3 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_w -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
