@@ -792,6 +792,38 @@ class EngineRawOps:
         return dense_contract_backward(xhat, w, ghat, need_x, need_w)
 
 
+    @staticmethod
+    def contract_separable(xhat, w):
+        """yhat[b, c, m] = xhat[b, c, m] w[c, m] (``_contract_dense_separable``, spectral_convolution.py:49-52):
+        one sc_modegemm launch with (channel, mode) as the lane index, R = Q = 1."""
+        b = xhat.shape[0]
+        m = w.numel()
+        return _raw_mode_gemm(xhat.reshape(b, 1, m), w.reshape(1, 1, m), m, False, False).reshape(xhat.shape)
+
+    @staticmethod
+    def contract_separable_bwd(xhat, w, ghat, need_x=True, need_w=True):
+        b = xhat.shape[0]
+        m = w.numel()
+        gx = _raw_mode_gemm(ghat.reshape(b, 1, m), w.reshape(1, 1, m), m, False, True).reshape(xhat.shape) \
+            if need_x else None
+        gw = _raw_mode_gemm(xhat.reshape(1, b, m), ghat.reshape(b, 1, m), m, True, False).reshape(w.shape) \
+            if need_w else None
+        return gx, gw
+
+    def cp_dense(self, weights, factors):
+        """Dense (Cin, Cout, modes...) block of a CP weight on the engine with autograd (SpectralConv._cp_dense)."""
+        from types import SimpleNamespace
+        from .spectral_conv import SpectralConv
+        kept = [int(f.shape[0]) for f in factors[2:]]
+        return SpectralConv._cp_dense(SpectralConv, SimpleNamespace(weights=weights, factors=list(factors)), kept)
+
+    def tt_dense(self, cores):
+        """Dense block of a tensor-train weight on the engine with autograd (SpectralConv._tt_dense)."""
+        from types import SimpleNamespace
+        from .spectral_conv import SpectralConv
+        kept = [int(c.shape[1]) for c in cores[2:]]
+        return SpectralConv._tt_dense(SimpleNamespace(factors=list(cores)), kept)
+
     def tucker_dense(self, core, factors):
         """Dense (Cin, Cout, modes...) block of a Tucker weight on the engine, with autograd to the core and every
         factor (the chain of sc_modegemm launches of SpectralConv._tucker_dense)."""

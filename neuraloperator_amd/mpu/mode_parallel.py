@@ -66,7 +66,7 @@ class _ModeParallelFn(torch.autograd.Function):
         spatial = list(x.shape[2:])
         kept = list(layer._n_modes)
         b, ci = x.shape[:2]
-        co = weight.shape[1]
+        co = ci if layer.separable else weight.shape[1]
         rest = kept[1:]
         w = weight.detach().contiguous()
         ex = _Exchange(layer._group(), P, rows, kept[0])
@@ -101,7 +101,7 @@ class _ModeParallelFn(torch.autograd.Function):
         xhat_all = torch.view_as_complex(xhat_all)
 
         # ---- contraction on this rank's mode rows, whole batch
-        yhat_all = ops.contract(xhat_all, w).contiguous()
+        yhat_all = (ops.contract_separable(xhat_all, w) if layer.separable else ops.contract(xhat_all, w)).contiguous()
 
         # ---- exchange back (split batch, cat modes) + zero-padded inverse reading the receive buffer in place
         y = torch.empty((b, co, *spatial), dtype=torch.float32, device=dev)
@@ -171,7 +171,8 @@ class _ModeParallelFn(torch.autograd.Function):
             gbias = (torch.stack(gb_parts).sum(0) if by_batch else torch.cat(gb_parts)).reshape(ctx.bias_shape)
 
         # ---- the two gradient contractions on this rank's mode rows (gW is complete: no all-reduce)
-        gxhat_all, gw = ops.contract_bwd(xhat_all, w, ghat_all, need_x, need_w)
+        cbwd = ops.contract_separable_bwd if layer.separable else ops.contract_bwd
+        gxhat_all, gw = cbwd(xhat_all, w, ghat_all, need_x, need_w)
 
         # ---- exchange back + adjoint of the forward transform reading the receive buffer in place
         gx = None
@@ -204,24 +205,29 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in (None: 4 batch chunks,
     or one piece when a rank holds a single sample).
 
-    Weights: dense (``weight``: this rank's mode rows of the (Cin, Cout, modes...) tensor), or
-    ``factorization="tucker"`` (TFNO, spectral_convolution.py:76-103): the core and the factors of the channel and
-    unsharded mode dims are REPLICATED, the factor of the first mode dim is sharded by rows like the dense weight;
-    a rank contracts with the dense block rebuilt from its shard (1 / P of the reconstruction work), the gradients
-    of the replicated parameters are partial sums over this rank's modes and are summed over the group by
-    ``reduce_replicated_grads``."""
+    Weights: dense (``weight``: this rank's mode rows of the (Cin, Cout, modes...) tensor; ``separable=True``: of the
+    (C, modes...) tensor, spectral_convolution.py:49-52), or ``factorization`` "tucker" / "cp" / "tt"
+    (spectral_convolution.py:55-132): the core / CP weights and every factor that does not carry the first mode dim are
+    REPLICATED, the factor (TT: core) of the first mode dim is sharded by rows like the dense weight; a rank contracts
+    with the dense block rebuilt from its shard (1 / P of the reconstruction work), the gradients of the replicated
+    parameters are partial sums over this rank's modes and are summed over the group by ``reduce_replicated_grads``.
+    (Round 3: CP, TT and separable joined dense and Tucker.)"""
 
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
                  fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=None,
-                 factorization=None, rank=0.5, **unused):
+                 factorization=None, rank=0.5, separable=False, **unused):
         super().__init__(device=device)
-        for k in ("complex_data", "separable"):
-            if unused.get(k):
-                raise NotImplementedError(f"{k}=True is not supported by the mode-parallel layer")
+        if unused.get("complex_data"):
+            raise NotImplementedError("complex_data=True is not supported by the mode-parallel layer")
         fac = (factorization or "dense").lower()
-        if fac not in ("dense", "tucker"):
-            raise NotImplementedError("mode-parallel layer: dense or Tucker weights")
-        self.factorization = fac
+        if fac not in ("dense", "tucker", "cp", "tt"):
+            raise NotImplementedError("mode-parallel layer: dense, Tucker, CP or TT weights")
+        if separable and fac != "dense":
+            raise NotImplementedError("mode-parallel layer: separable weights are dense")
+        if separable and in_channels != out_channels:
+            raise ValueError("To use separable Fourier Conv, in_channels must be equal to out_channels, "
+                             f"but got in_channels={in_channels} and out_channels={out_channels}")   # :347-353
+        self.factorization, self.separable = fac, bool(separable)
         self.in_channels, self.out_channels = in_channels, out_channels
         self._n_modes = halve_last_mode(n_modes)
         self.max_n_modes = list(self._n_modes)
@@ -241,27 +247,42 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         if init_std == "auto":
             init_std = (2 / (in_channels + out_channels)) ** 0.5
         live = min(self.rows, max(0, self._n_modes[0] - self.rank * self.rows))
+        self.core = self.cp_weights = None
         if fac == "dense":
-            w = torch.empty(in_channels, out_channels, self.rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
+            lead = (in_channels,) if self.separable else (in_channels, out_channels)
+            w = torch.empty(*lead, self.rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
             w.normal_(0, init_std)
             with torch.no_grad():
-                w[:, :, live:] = 0
+                w[(slice(None),) * len(lead) + (slice(live, None),)] = 0
             self.weight = nn.Parameter(w)
             self.weight.mode_sharded = True          # exclude from data-parallel all-reduce within the group
         else:
-            from ..factorized import tucker_rank
+            # factorized weights (spectral_convolution.py:55-132): the ranks follow from the FULL shape (tensorly's
+            # rules, factorized.py), every factor that does not carry the first mode dim is REPLICATED, the one that
+            # does (index 2) is sharded by rows like the dense weight; a rank contracts with the dense block rebuilt
+            # from its shard (1 / P of the reconstruction work)
+            from ..factorized import FactorList, cp_rank, tt_rank, tucker_rank
             full_shape = [in_channels, out_channels, *self._n_modes]
-            ranks = tucker_rank(full_shape, rank)
-            std_f = (init_std / math.prod(math.sqrt(r) for r in ranks)) ** (1.0 / (len(full_shape) + 1))
-            self.weight = None
-            self.core = nn.Parameter(torch.empty(*ranks, dtype=torch.cfloat, device=device).normal_(0, std_f))
             sizes = [in_channels, out_channels, self.rows, *self._n_modes[1:]]
-            from ..factorized import FactorList      # tltorch's names: factors.factor_{i} (legacy factors.{i} loads too)
-            self.factors = FactorList(
-                [nn.Parameter(torch.empty(n, r, dtype=torch.cfloat, device=device).normal_(0, std_f))
-                 for n, r in zip(sizes, ranks)])
+            self.weight = None
+            mk = lambda *sh, std: nn.Parameter(torch.empty(*sh, dtype=torch.cfloat, device=device).normal_(0, std))
+            if fac == "tucker":
+                ranks = tucker_rank(full_shape, rank)
+                std_f = (init_std / math.prod(math.sqrt(r) for r in ranks)) ** (1.0 / (len(full_shape) + 1))
+                self.core = mk(*ranks, std=std_f)
+                self.factors = FactorList([mk(n, r, std=std_f) for n, r in zip(sizes, ranks)])
+            elif fac == "cp":
+                r = cp_rank(full_shape, rank)
+                std_f = (init_std / math.sqrt(r)) ** (1.0 / len(full_shape))
+                self.cp_weights = nn.Parameter(torch.ones(r, dtype=torch.cfloat, device=device))
+                self.factors = FactorList([mk(n, r, std=std_f) for n in sizes])
+            else:
+                ranks = tt_rank(full_shape, rank)                                  # r_0 .. r_n, r_0 = r_n = 1
+                std_f = (init_std / math.prod(ranks)) ** (1.0 / len(full_shape))
+                self.factors = FactorList([mk(ranks[i], n, ranks[i + 1], std=std_f) for i, n in enumerate(sizes)])
             with torch.no_grad():
-                self.factors[2][live:] = 0
+                f2 = self.factors[2]
+                (f2[:, live:] if fac == "tt" else f2[live:]).zero_()
             self.factors[2].mode_sharded = True
         self.bias = nn.Parameter(init_std * torch.randn(out_channels, *(1,) * self.order, device=device)) \
             if bias else None
@@ -300,16 +321,27 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             raise ValueError(f"grid {spatial} is too small for n_modes {self._n_modes} in the mode-parallel layer")
         if x.shape[1] != self.in_channels:
             raise ValueError(f"input has {x.shape[1]} channels, the layer expects {self.in_channels}")
-        w = self.weight if self.factorization == "dense" else self.ops.tucker_dense(self.core, list(self.factors))
+        w = self._dense_block()
         if self.P == 1 and not dist.is_initialized():
             return _single_rank(self, x, spatial, w)
         return _ModeParallelFn.apply(x, w, self.bias, self)
 
+    def _dense_block(self):
+        """this rank's (Cin, Cout, rows, ...) block -- (C, rows, ...) when separable -- with autograd to the parameters"""
+        if self.factorization == "dense":
+            return self.weight
+        if self.factorization == "tucker":
+            return self.ops.tucker_dense(self.core, list(self.factors))
+        if self.factorization == "cp":
+            return self.ops.cp_dense(self.cp_weights, list(self.factors))
+        return self.ops.tt_dense(list(self.factors))
+
     # ---- helpers for the training loop -----------------------------------------------------------
     def replicated_parameters(self):
         ps = [] if self.bias is None else [self.bias]
-        if self.factorization == "tucker":
-            ps += [self.core] + [f for i, f in enumerate(self.factors) if i != 2]
+        if self.factorization != "dense":
+            ps += [q for q in (self.core, self.cp_weights) if q is not None]
+            ps += [f for i, f in enumerate(self.factors) if i != 2]
         return ps
 
     def reduce_replicated_grads(self):
@@ -346,17 +378,32 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             raise KeyError(f"none of {[prefix + n for n in names]} in the state dict")
         with torch.no_grad():
             if self.factorization == "dense":
-                full = get("weight.tensor", "weight")
-                self.weight.copy_(self.shard_dense_weight(full[:, :, :self._n_modes[0]].to(self.weight.device), self.rank, self.P))
+                full = get("weight.tensor", "weight").to(self.weight.device)
+                md = 1 if self.separable else 2                      # the first mode dim of the stored tensor
+                self.weight.copy_(self._shard_rows(full, md))
             else:
-                self.core.copy_(get("weight.core", "core"))
+                if self.core is not None:
+                    self.core.copy_(get("weight.core", "core"))
+                if self.cp_weights is not None:
+                    self.cp_weights.copy_(get("weight.weights", "weights", "cp_weights"))
                 for i, f in enumerate(self.factors):
                     full = get(f"weight.factors.factor_{i}", f"weight.factors.{i}", f"factors.factor_{i}", f"factors.{i}")
                     full = full.to(f.device)
-                    f.copy_(self.shard_tucker_factor(full, self.rank, self.P) if i == 2 else full)
+                    f.copy_(self._shard_rows(full, 1 if self.factorization == "tt" else 0) if i == 2 else full)
             if self.bias is not None and (prefix + "bias") in state_dict:
                 self.bias.copy_(state_dict[prefix + "bias"].reshape(self.bias.shape))
         return self
+
+    def _shard_rows(self, full, dim):
+        """rows [rank * rows, (rank + 1) * rows) of ``full`` along ``dim`` (zero rows past the end)"""
+        k1 = full.shape[dim]
+        shape = list(full.shape)
+        shape[dim] = self.rows
+        out = full.new_zeros(shape)
+        live = min(self.rows, max(0, k1 - self.rank * self.rows))
+        if live > 0:
+            out.narrow(dim, 0, live).copy_(full.narrow(dim, self.rank * self.rows, live))
+        return out
 
     @staticmethod
     def shard_tucker_factor(full_factor, rank, world):
@@ -390,7 +437,8 @@ class _SingleRankFn(torch.autograd.Function):
         spatial, kept = list(x.shape[2:]), list(layer._n_modes)
         w = weight.detach().contiguous()
         xhat = ops.fwd(x.detach(), kept)
-        y = ops.inv(ops.contract(xhat, w), None if bias is None else bias.detach().reshape(-1), spatial)
+        yhat = ops.contract_separable(xhat, w) if layer.separable else ops.contract(xhat, w)
+        y = ops.inv(yhat, None if bias is None else bias.detach().reshape(-1), spatial)
         ctx.save_for_backward(xhat, w)
         ctx.cfg = (layer, spatial, kept, None if bias is None else tuple(bias.shape))
         return y
@@ -401,7 +449,8 @@ class _SingleRankFn(torch.autograd.Function):
         xhat, w = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         gh, gb = layer.ops.inv_adjoint(gy.contiguous(), kept, want_bias=need_b and bshape is not None)
-        gxh, gw = layer.ops.contract_bwd(xhat, w, gh, need_x, need_w)
+        cbwd = layer.ops.contract_separable_bwd if layer.separable else layer.ops.contract_bwd
+        gxh, gw = cbwd(xhat, w, gh, need_x, need_w)
         gx = layer.ops.fwd_adjoint(gxh, spatial) if need_x else None
         return gx, gw, None if gb is None else gb.reshape(bshape), None
 

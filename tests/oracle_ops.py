@@ -127,6 +127,21 @@ class OracleRawOps:
     def tucker_dense(self, core, factors):
         return so.reconstruct_tucker(core, list(factors))
 
+    def cp_dense(self, weights, factors):
+        return so.reconstruct_cp(weights, list(factors))
+
+    def tt_dense(self, cores):
+        return so.reconstruct_tt(list(cores))
+
+    def contract_separable(self, xhat, w):
+        return so.contract_dense_separable(xhat, w)
+
+    def contract_separable_bwd(self, xhat, w, ghat, need_x=True, need_w=True):
+        with torch.enable_grad():
+            xr, wr = xhat.detach().requires_grad_(True), w.detach().requires_grad_(True)
+            gx, gw = torch.autograd.grad(so.contract_dense_separable(xr, wr), (xr, wr), ghat)
+        return (gx if need_x else None), (gw if need_w else None)
+
     def contract_bwd(self, xhat, w, ghat, need_x=True, need_w=True):
         with torch.enable_grad():
             xr, wr = xhat.detach().requires_grad_(True), w.detach().requires_grad_(True)

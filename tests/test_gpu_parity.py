@@ -717,6 +717,48 @@ def test_mode_parallel_layer_on_device_single_rank():
             os.environ.pop(k, None)
 
 
+@pytest.mark.parametrize("kind", ["cp", "tt", "separable"])
+def test_mode_parallel_variants_on_device_single_rank(kind):
+    """CP / TT / separable weights of the mode-parallel layer (round 3) through the engine's raw ops on the GPU (one rank,
+    no process group: the dense block rebuilt on the engine with autograd, the separable contraction as an engine
+    launch) against the CPU oracle with the reconstructed weight."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    ci, co, modes, spatial = 6, (6 if kind == "separable" else 5), (16, 12), (32, 24)
+    kw = dict(separable=True) if kind == "separable" else dict(factorization=kind, rank=0.5)
+    conv = ModeParallelSpectralConv(ci, co, modes, **kw).to(dev)
+    with torch.no_grad():
+        for q in conv.parameters():
+            if q.is_complex():
+                q.copy_(torch.randn(q.shape, dtype=torch.cfloat) * 0.6)
+    x = torch.randn(3, ci, *spatial, device=dev, requires_grad=True)
+    g = torch.randn(3, co, *spatial, device=dev)
+    y = conv(x)
+    y.backward(g)
+    leaves = [q.detach().cpu().clone().requires_grad_(True) for q in conv.parameters() if q.is_complex()]
+    names = [n for n, q in conv.named_parameters() if q.is_complex()]
+    if kind == "separable":
+        w = leaves[0]
+    elif kind == "cp":
+        w = so.reconstruct_cp(leaves[names.index("cp_weights")], [leaves[names.index(f"factors.factor_{i}")] for i in range(4)])
+    else:
+        w = so.reconstruct_tt([leaves[names.index(f"factors.factor_{i}")] for i in range(4)])
+    xc = x.detach().cpu().requires_grad_(True)
+    bc = conv.bias.detach().cpu().requires_grad_(True)
+    nm = list(conv.n_modes)
+    yo = so.forward_torch(xc, w, bc, nm, nm, separable=(kind == "separable"),
+                          contract=so.contract_dense_separable if kind == "separable" else so.contract_dense)
+    yo.backward(g.cpu())
+    assert rel_l2(y.detach().cpu().numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(x.grad.cpu().numpy(), xc.grad.numpy()) < TOL
+    assert rel_l2(conv.bias.grad.cpu().numpy(), bc.grad.numpy()) < TOL
+    grads = {n: q.grad for n, q in conv.named_parameters() if q.is_complex()}
+    for n, lf in zip(names, leaves):
+        assert rel_l2(grads[n].cpu().numpy(), lf.grad.numpy()) < 2e-5, n
+
+
 @pytest.mark.parametrize("spatial,modes,P", [((64, 256), (16, 12), 4), ((256, 256), (64, 64), 8), ((128, 256), (10, 64), 4),
                                              ((24, 20), (8, 10), 2), ((16, 128, 128), (8, 32, 32), 8),
                                              ((12, 16, 20), (5, 8, 8), 3)])

@@ -290,3 +290,88 @@ def test_mode_parallel_tucker_matches_single_process(spatial, modes):
     for rank, errs in ret.items():
         for k, v in errs.items():
             assert np.isfinite(v) and v < 2e-5, (rank, k, v)
+
+
+def _variant_worker(rank, world, port, kind, spatial, modes, ret):
+    """CP / TT / separable weights in the mode-parallel layer (round 3): the factor that carries the first mode dim (TT:
+    the core; separable: the tensor itself) sharded by rows, everything else replicated."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleRawOps
+
+    comm.init(model_parallel_size=world, backend="gloo")
+    nm = halve_last_mode(modes)
+    bl, ci, co = 2, 4, (4 if kind == "separable" else 3)
+    B = bl * world
+    kw = dict(separable=True) if kind == "separable" else dict(factorization=kind, rank=0.7)
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm), comm_chunks=2, **kw)
+    rows = -(-nm[0] // world)
+    live = min(rows, nm[0] - rank * rows)
+    torch.manual_seed(0)                      # identical full tensors on every rank
+    x = torch.randn(B, ci, *spatial)
+    g = torch.randn(B, co, *spatial)
+    bias = torch.randn(co, *(1,) * len(spatial))
+    full_shape = [ci, co, *nm]
+    if kind == "separable":
+        wfull = torch.randn(ci, *nm, dtype=torch.cfloat) * 0.5
+        sd = {"weight.tensor": wfull, "bias": bias}
+        leaves = [wfull.clone().requires_grad_(True)]
+        dense = lambda L: L[0]
+    elif kind == "cp":
+        R = int(conv.cp_weights.shape[0])
+        lam = torch.randn(R, dtype=torch.cfloat)
+        facs = [torch.randn(n, R, dtype=torch.cfloat) * 0.6 for n in full_shape]
+        sd = {"weight.weights": lam, "bias": bias, **{f"weight.factors.factor_{i}": f for i, f in enumerate(facs)}}
+        leaves = [lam.clone().requires_grad_(True)] + [f.clone().requires_grad_(True) for f in facs]
+        dense = lambda L: so.reconstruct_cp(L[0], L[1:])
+    else:
+        ranks = [int(f.shape[0]) for f in conv.factors] + [1]
+        cores = [torch.randn(ranks[i], n, ranks[i + 1], dtype=torch.cfloat) * 0.6 for i, n in enumerate(full_shape)]
+        sd = {"bias": bias, **{f"weight.factors.factor_{i}": c for i, c in enumerate(cores)}}
+        leaves = [c.clone().requires_grad_(True) for c in cores]
+        dense = lambda L: so.reconstruct_tt(L)
+    conv.load_full_state_dict(sd)             # an unsharded checkpoint: this rank keeps its rows
+    xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
+    y = conv(xs)
+    y.backward(g[rank * bl:(rank + 1) * bl])
+    conv.reduce_replicated_grads()
+
+    xf, bf = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yf = so.forward_torch(xf, dense(leaves), bf, nm, nm, separable=(kind == "separable"),
+                          contract=so.contract_dense_separable if kind == "separable" else so.contract_dense)
+    yf.backward(g)
+    errs = dict(y=so.rel_l2(y.detach().numpy(), yf.detach()[rank * bl:(rank + 1) * bl].numpy()),
+                gx=so.rel_l2(xs.grad.numpy(), xf.grad[rank * bl:(rank + 1) * bl].numpy()),
+                gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()))
+    sl = slice(rank * rows, rank * rows + live)
+    if kind == "separable":
+        errs["gw"] = so.rel_l2(conv.weight.grad[:, :live].numpy(), leaves[0].grad[:, sl].numpy())
+    else:
+        params = ([conv.cp_weights] if kind == "cp" else []) + list(conv.factors)
+        off = 1 if kind == "cp" else 0
+        for i, (q, lf) in enumerate(zip(params, leaves)):
+            if i - off == 2:                                   # the sharded factor / core: this rank's rows
+                if kind == "tt":
+                    errs[f"g{i}"] = so.rel_l2(q.grad[:, :live].numpy(), lf.grad[:, sl].numpy())
+                else:
+                    errs[f"g{i}"] = so.rel_l2(q.grad[:live].numpy(), lf.grad[sl].numpy())
+            else:
+                errs[f"g{i}"] = so.rel_l2(q.grad.numpy(), lf.grad.numpy())
+    ret[rank] = errs
+    comm.cleanup()
+
+
+@pytest.mark.parametrize("kind,spatial,modes", [("cp", (16, 12), (8, 6)), ("tt", (16, 12), (8, 6)), ("separable", (16, 12), (8, 6)),
+                                                ("cp", (16, 12), (5, 6)), ("tt", (8, 8, 6), (4, 4, 4)), ("separable", (16, 12), (7, 6))])
+def test_mode_parallel_cp_tt_separable(kind, spatial, modes):
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_variant_worker, args=(world, _free_port(), kind, spatial, modes, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank, errs in ret.items():
+        for k, v in errs.items():
+            assert np.isfinite(v) and v < 2e-5, (kind, rank, k, v)
