@@ -9,8 +9,12 @@ The decomposition itself lives in tensorly (``tensorly.decomposition.tucker``, a
 ``tucker_hooi`` restates its published algorithm -- higher-order orthogonal iteration from an SVD initialisation,
 stopping when the relative reconstruction error moves by less than ``tol`` -- and is therefore "parity unpinned" against
 tensorly itself (singular vectors are only defined up to a phase anyway; the projected update depends on the
-SUBSPACES only, which the tests check).  Mode products are plain library GEMMs (torch.matmul on the unfoldings: rocBLAS
-on the GPU), the SVDs torch.linalg.svd."""
+SUBSPACES only, which the tests check).  The SVDs are torch.linalg.svd (a few per ``update_proj_gap`` steps, off the
+per-step path).  The per-step work -- the mode products of ``project`` / ``project_back`` on the weight-sized
+gradient -- runs on the ENGINE for complex64 CUDA tensors (round 3): ``t x_d U`` is one sc_modegemm launch with the
+factor as the mode-independent operand (k_modegemm_bfac: lanes = everything behind dim d), the last dim through one
+transposing copy; other dtypes / CPU tensors use torch.matmul on the unfoldings (same arithmetic order per output:
+an r-ordered sum)."""
 import torch
 
 from .factorized import tucker_rank
@@ -20,9 +24,39 @@ def _unfold(t, mode):
     return torch.movedim(t, mode, 0).reshape(t.shape[mode], -1)
 
 
+def _engine_mode_dot(t, matrix, mode, transpose):
+    """t x_mode matrix on the engine (complex64, CUDA): C[p, q, m] = sum_r A[p, r, m] opB(B)[r, q] with
+    p = the dims before ``mode``, m = the dims behind it (the lanes), B = matrix^T (conj(matrix) when ``transpose``)."""
+    from . import engine
+    t = t.contiguous()
+    shape = list(t.shape)
+    n = shape[mode]
+    lead = 1
+    for v in shape[:mode]:
+        lead *= int(v)
+    tail = 1
+    for v in shape[mode + 1:]:
+        tail *= int(v)
+    # out[.., q, ..] = sum_r M[q, r] t[.., r, ..] with M = matrix (forward) or matrix^H (transpose):
+    # B[r, q] = M[q, r] = matrix[q, r]            -> matrix viewed with swapped strides, no conjugate
+    #         = conj(matrix[r, q]) (transpose)     -> matrix itself, conjugated by the kernel
+    mtx = matrix.to(torch.complex64)
+    b = mtx if transpose else mtx.transpose(0, 1)
+    q = int(b.shape[1])
+    if tail > 1:
+        out = engine._raw_mode_gemm(t.reshape(lead, n, tail), b, tail, False, bool(transpose))
+        return out.reshape(*shape[:mode], q, *shape[mode + 1:])
+    # last dim: nothing behind it to put on the lanes -- one transposing copy makes the leading dims the lanes
+    tt = t.reshape(lead, n).transpose(0, 1).contiguous().reshape(1, n, lead)
+    out = engine._raw_mode_gemm(tt, b, lead, False, bool(transpose))                    # [1, q, lead]
+    return out.reshape(q, lead).transpose(0, 1).reshape(*shape[:mode], q)
+
+
 def mode_dot(t, matrix, mode, transpose=False):
     """t x_mode matrix: contracts dim ``mode`` of t with the columns of ``matrix`` (rows, with the conjugate, when
     ``transpose``: the adjoint of the forward product)."""
+    if t.is_cuda and t.dtype == torch.complex64 and torch.is_complex(matrix) and t.numel() >= 1024:
+        return _engine_mode_dot(t, matrix, mode % t.ndim, transpose)
     m = matrix.conj().transpose(0, 1) if transpose else matrix
     moved = torch.movedim(t, mode, 0)
     out = (m @ moved.reshape(moved.shape[0], -1)).reshape(m.shape[0], *moved.shape[1:])

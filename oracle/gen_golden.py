@@ -232,6 +232,45 @@ def gen_adamw(name, kw, steps, seed):
     return out
 
 
+def gen_galore(name, rank, kw, steps, seed):
+    """Tensor-GaLore branch of the VERBATIM AdamW (training/adamw.py:94-111, 139-196) on a complex (8, 6, 12, 7)
+    weight: every gradient, the projection factors the run computed at its first step (tensorly's Tucker is absent, so
+    the verbatim optimizer drives THIS repo's projector -- the subspace is an input of the test, the optimizer
+    arithmetic and the mode products are what it pins), the parameter and the low-rank moments after every step."""
+    from neuraloperator_amd import galore
+    adamw = ref_verbatim.load_reference_adamw()
+    saved = adamw.TensorGaLoreProjector
+    adamw.TensorGaLoreProjector = galore.TensorGaLoreProjector
+    try:
+        torch.manual_seed(seed)
+        w = torch.nn.Parameter(torch.randn(8, 6, 12, 7, dtype=torch.cfloat))
+        b = torch.nn.Parameter(torch.randn(5))
+        import json
+        out = dict(w0=_np(w).copy(), b0=_np(b).copy(), steps=np.array(steps), kwargs=np.array(json.dumps(kw)),
+                   rank=np.array(json.dumps(rank)))
+        opt = adamw.AdamW([b], galore_params=[w], galore_rank=rank, **kw)
+        for t in range(steps):
+            gw, gb = torch.randn_like(w), torch.randn_like(b)
+            out[f"gw_{t}"], out[f"gb_{t}"] = _np(gw), _np(gb)
+            w.grad, b.grad = gw.clone(), gb.clone()
+            opt.step()
+            out[f"w_{t}"] = _np(w).copy()
+        st = opt.state[w]
+        for d, f in enumerate(st["projector"].proj_tensor):
+            out[f"proj_{d}"] = _np(f).copy()
+        out["m"], out["v"], out["b"] = _np(st["exp_avg"]).copy(), _np(st["exp_avg_sq"]).copy(), _np(b).copy()
+        np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **out)
+        return out
+    finally:
+        adamw.TensorGaLoreProjector = saved
+
+
+GALORE_CASES = [
+    ("galore_adamw_rank04", 0.4, dict(lr=1e-2), 4),
+    ("galore_adamw_ranks_decay", [4, 3, 5, 3], dict(lr=3e-3, weight_decay=0.05, correct_bias=False, galore_scale=0.5), 3),
+]
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     ref = ref_verbatim.load_reference()
@@ -254,6 +293,9 @@ def main():
     for i, case in enumerate(ADAMW_CASES):
         o = gen_adamw(*case, seed=5000 + i)
         print(f"{case[0]:32s} |pc|={np.abs(o['pc']).mean():.3f} v dtype {o['v_c'].dtype}")
+    for i, case in enumerate(GALORE_CASES):
+        o = gen_galore(*case, seed=7000 + i)
+        print(f"{case[0]:32s} low-rank moments {o['m'].shape}")
     total = sum(os.path.getsize(os.path.join(GOLDEN_DIR, f)) for f in os.listdir(GOLDEN_DIR))
     print(f"golden dir: {total/1024:.0f} KiB")
 

@@ -6,9 +6,11 @@ neuraloperator_amd.AdamW.
 * optimizer: the VERBATIM reference AdamW (training/adamw.py, GaLore branch :139-196) driving this repo's projector
   against neuraloperator_amd.AdamW -- same parameter trajectory and state, bit for bit on the CPU.
 tensorly's own ``tucker`` is absent (un-vendored third party): the decomposition is pinned by its defining properties."""
+import numpy as np
 import pytest
 import torch
 
+from conftest import golden_names, load_golden
 from neuraloperator_amd import AdamW, galore
 from oracle import ref_verbatim
 
@@ -91,3 +93,33 @@ def test_full_rank_projection_is_the_identity():
     u0 = [f.clone() for f in p.proj_tensor]
     p.project(torch.randn(4, 3, 5, generator=g), 200)
     assert all(torch.equal(a, b) for a, b in zip(u0, p.proj_tensor))
+
+
+@pytest.mark.parametrize("name", golden_names("galore_adamw_"))
+def test_adamw_galore_replays_the_golden_trajectory(name):
+    """The committed trajectories of the verbatim reference AdamW (oracle/gen_golden.py: gen_galore), replayed by this
+    repo's AdamW with the golden subspace factors loaded -- the CPU twin of the -m gpu test that runs the mode products
+    on the engine (tests/test_gpu_parity.py)."""
+    import json
+    g = load_golden(name)
+    kw = json.loads(str(g["kwargs"]))
+    rank = json.loads(str(g["rank"]))
+    w = torch.nn.Parameter(torch.from_numpy(g["w0"]))
+    b = torch.nn.Parameter(torch.from_numpy(g["b0"]))
+    opt = AdamW([b], galore_params=[w], galore_rank=rank, **kw)
+    proj = galore.TensorGaLoreProjector(rank=opt.galore_rank, update_proj_gap=opt.galore_update_proj_gap,
+                                        scale=opt.galore_scale, activation_checkpoint=opt.activation_checkpoint,
+                                        warm_restart=opt.warm_restart)
+    proj.proj_tensor = [torch.from_numpy(g[f"proj_{d}"]) for d in range(w.dim())]
+    opt.state[w]["step"] = 0
+    opt.state[w]["projector"] = proj
+    for t in range(int(g["steps"])):
+        w.grad = torch.from_numpy(g[f"gw_{t}"])
+        b.grad = torch.from_numpy(g[f"gb_{t}"])
+        opt.step()
+        assert np.linalg.norm(w.detach().numpy() - g[f"w_{t}"]) <= 2e-6 * np.linalg.norm(g[f"w_{t}"]), t
+    st = opt.state[w]
+    assert tuple(st["exp_avg"].shape) == tuple(g["m"].shape)
+    assert np.allclose(st["exp_avg"].numpy(), g["m"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(st["exp_avg_sq"].numpy(), g["v"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(b.detach().numpy(), g["b"], rtol=1e-6, atol=1e-7)

@@ -375,3 +375,70 @@ def test_mode_parallel_cp_tt_separable(kind, spatial, modes):
     for rank, errs in ret.items():
         for k, v in errs.items():
             assert np.isfinite(v) and v < 2e-5, (kind, rank, k, v)
+
+
+def _optim_worker(rank, world, port, ret):
+    """Two AdamW steps on the mode-parallel layer: every rank's optimizer state is its own weight shard's (1/P of the
+    dense weight's moments; the bias, replicated, steps identically on every rank after reduce_replicated_grads), and
+    the stitched-together weights equal the single-process AdamW on the unsharded layer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuraloperator_amd import AdamW
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleRawOps
+
+    comm.init(model_parallel_size=world, backend="gloo")
+    spatial, modes, bl, ci, co = (16, 12), (8, 6), 2, 3, 4
+    nm = halve_last_mode(modes)
+    rows = nm[0] // world
+    torch.manual_seed(3)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
+    bias = torch.randn(co, 1, 1)
+    xs = [torch.randn(bl * world, ci, *spatial) for _ in range(2)]
+    gs = [torch.randn(bl * world, co, *spatial) for _ in range(2)]
+    kw = dict(lr=1e-2, weight_decay=0.01)
+
+    conv = ModeParallelSpectralConv(ci, co, modes, ops=OracleRawOps(nm))
+    conv.load_full_state_dict({"weight": w, "bias": bias})
+    opt = AdamW(conv.parameters(), **kw)
+    wf, bf = torch.nn.Parameter(w.clone()), torch.nn.Parameter(bias.clone())
+    optf = AdamW([wf, bf], **kw)
+    for x, g in zip(xs, gs):
+        opt.zero_grad()
+        conv(x[rank * bl:(rank + 1) * bl]).backward(g[rank * bl:(rank + 1) * bl])
+        conv.reduce_replicated_grads()
+        opt.step()
+        optf.zero_grad()
+        so.forward_torch(x, wf, bf, nm, nm).backward(g)
+        optf.step()
+    st = opt.state[conv.weight]
+    assert tuple(st["exp_avg"].shape) == (ci, co, rows, nm[1]) == tuple(conv.weight.shape)
+    n_state = sum(v.numel() for s in opt.state.values() for v in s.values() if torch.is_tensor(v))
+    n_full = sum(v.numel() for s in optf.state.values() for v in s.values() if torch.is_tensor(v))
+    sl = slice(rank * rows, (rank + 1) * rows)
+    ret[rank] = dict(
+        w=so.rel_l2(conv.weight.detach().numpy(), wf.detach()[:, :, sl].numpy()),
+        m=so.rel_l2(st["exp_avg"].numpy(), optf.state[wf]["exp_avg"][:, :, sl].numpy()),
+        v=so.rel_l2(st["exp_avg_sq"].numpy(), optf.state[wf]["exp_avg_sq"][:, :, sl].numpy()),
+        b=so.rel_l2(conv.bias.detach().numpy(), bf.detach().numpy()),
+        state_numel=n_state, full_numel=n_full, bias_numel=bias.numel())
+    comm.cleanup()
+
+
+def test_optimizer_state_is_sharded_with_the_weight():
+    """SURVEY 8 row f2 under mode parallelism: AdamW's moments live with the weight shard (no rank holds the dense
+    weight's state), and two steps reproduce the single-process trajectory."""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_optim_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for rank, r in ret.items():
+        for k in "wmvb":
+            assert np.isfinite(r[k]) and r[k] < 1e-5, (rank, k, r[k])
+        # per-rank state = the full state's weight part / world + the replicated bias's
+        per_bias = 2 * r["bias_numel"]
+        assert (r["state_numel"] - per_bias) * world == r["full_numel"] - per_bias, r
