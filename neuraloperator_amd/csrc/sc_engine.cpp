@@ -1513,14 +1513,15 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   // 36 stay on the 64-row tiles of k_modegemm_mfma)
   const int64_t cols = 32;
   const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + cols - 1) / cols * cols;
-  bool rows_ok = 4 * d->P >= 3 * Pp;
+  static const int64_t fill4 = [] { const char* e = std::getenv("SC_G8_FILL4"); return e ? (int64_t)std::atoi(e) : (int64_t)3; }();
+  bool rows_ok = 4 * d->P >= fill4 * Pp;
   // a small batch against a weight read ACROSS its rows (the gradient of the spectrum: B[r, q] = W[q, r], q stride >
   // r stride): the lanes-are-modes VALU kernel gathers 512-byte pieces of W there (FNO3d 128^3, B = 8: 115 us), the
   // streamed kernel does not care (55 us) although 32 / P of its matrix work is spent on clamped duplicate rows.  Not
   // for the forward product (VALU 45 us, streamed 53 us) and not below 8 rows (B = 4 at 1024^2 / hidden 128: 1.09 ->
   // 1.50 ms): profiles/r02_gemm_small_batch_ab.txt
   if (d->P >= 8 && d->P <= 32 && d->b_sq > d->b_sr) rows_ok = true;
-  if (!rows_ok || 4 * d->Q < 3 * Qp) return false;
+  if (!rows_ok || 4 * d->Q < fill4 * Qp) return false;
   if (d->R < 4) return false;
   if (Pp / 32 * (Qp / cols) * (d->n_modes / 8) >= ((int64_t)1 << 30)) return false;
   return true;
