@@ -1509,11 +1509,13 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   // 16-byte granules: every row / column of every operand must start on an even complex element
   if ((d->a_sp | d->a_sr | d->b_sr | d->b_sq | d->c_sp | d->c_sq) & 1) return false;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return false;
-  // tiles are 32 rows x 32 columns: take problems that fill them to >= 3/4 (ragged Tucker / TT ranks such as
-  // 36 stay on the 64-row tiles of k_modegemm_mfma)
+  // tiles are 32 rows x 32 columns: take problems that fill them to >= 1/2 (SC_G8_FILL4 quarters; round 2: 3/4).  The
+  // ragged 36 x 36 per-mode products of the Tucker chain at configs[2] (two or four tiles, 56 % / 32 % filled) take
+  // 24 / 25 / 39 us here against 57 / 57 / 65 us on the register-staged k_modegemm_mfma
+  // (profiles/r03_tfno_kernel_stats_g8fill2.txt): the operand stream, not the matrix pipe, is what a tile costs
   const int64_t cols = 32;
   const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + cols - 1) / cols * cols;
-  static const int64_t fill4 = [] { const char* e = std::getenv("SC_G8_FILL4"); return e ? (int64_t)std::atoi(e) : (int64_t)3; }();
+  static const int64_t fill4 = [] { const char* e = std::getenv("SC_G8_FILL4"); return e ? (int64_t)std::atoi(e) : (int64_t)2; }();
   bool rows_ok = 4 * d->P >= fill4 * Pp;
   // a small batch against a weight read ACROSS its rows (the gradient of the spectrum: B[r, q] = W[q, r], q stride >
   // r stride): the lanes-are-modes VALU kernel gathers 512-byte pieces of W there (FNO3d 128^3, B = 8: 115 us), the
@@ -1988,7 +1990,13 @@ extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* 
 }
 
 // ---- Tucker mode factors (sc_kernels_tucker.h)
+// matrix-core form (round 3) unless SC_TK_VALU is set (environment, A-B against the round-2 VALU kernels)
+static bool tucker_use_mx() {
+  static const bool valu = std::getenv("SC_TK_VALU") != nullptr;
+  return !valu;
+}
 static size_t tucker_lds_bytes(const sc_tucker_desc* d, bool bwd) {
+  if (tucker_use_mx()) return (size_t)tkm_layout((int)d->rx, (int)d->ry, (int)d->mx, (int)d->my, bwd).total * sizeof(cf32);
   size_t c = (size_t)d->mx * d->rx + (size_t)d->my * d->ry + (size_t)d->rx * d->ry + (size_t)d->rx * d->my;
   if (bwd) c += (size_t)d->mx * d->my + (size_t)d->rx * d->my;
   return c * sizeof(cf32);
@@ -2023,6 +2031,11 @@ extern "C" int sc_tucker_modes_forward(const sc_tucker_desc* d, const float* cor
   TuckerModesArgs g;
   g.core = (const cf32*)core; g.ux = (const cf32*)ux; g.uy = (const cf32*)uy; g.gt = nullptr; g.t = (cf32*)t; g.partial = nullptr;
   g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d);
+  if (tucker_use_mx()) {
+    const size_t lds = tucker_lds_bytes(d, false);
+    if (d->rx * d->ry <= 4 * 256) return tucker_launch(k_tucker_modes_fwd_mx<4>, g, lds, (sc_stream_t)stream, "k_tucker_modes_fwd_mx");
+    return tucker_launch(k_tucker_modes_fwd_mx<16>, g, lds, (sc_stream_t)stream, "k_tucker_modes_fwd_mx");
+  }
   return tucker_launch(k_tucker_modes_fwd, g, tucker_lds_bytes(d, false), (sc_stream_t)stream, "k_tucker_modes_fwd");
 }
 
@@ -2042,7 +2055,18 @@ extern "C" int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* co
   g.partial = (float*)workspace;
   g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d);
   sc_stream_t st = (sc_stream_t)stream;
-  int rc = tucker_launch(k_tucker_modes_bwd, g, tucker_lds_bytes(d, true), st, "k_tucker_modes_bwd");
+  int rc;
+  if (tucker_use_mx()) {
+    // the smallest instantiation that holds the problem: (3, 9, 3, 2) is ranks (36, ., 36, 19) on 64 x 33 kept modes
+    const auto t16 = [](int64_t n) { return (n + 15) / 16; };
+    const int64_t sx = (t16(d->mx) * t16(d->rx) + 3) / 4, sy = (t16(d->my) * t16(d->ry) + 3) / 4;
+    const size_t lds = tucker_lds_bytes(d, true);
+    if (d->rx * d->ry <= 3 * 256 && d->mx * d->my <= 9 * 256 && sx <= 3 && sy <= 2)
+      rc = tucker_launch(k_tucker_modes_bwd_mx<3, 9, 3, 2>, g, lds, st, "k_tucker_modes_bwd_mx");
+    else
+      rc = tucker_launch(k_tucker_modes_bwd_mx<16, 16, 4, 4>, g, lds, st, "k_tucker_modes_bwd_mx");
+  } else
+    rc = tucker_launch(k_tucker_modes_bwd, g, tucker_lds_bytes(d, true), st, "k_tucker_modes_bwd");
   if (rc) return rc;
   const int np = 2 * (g.Mx * g.Rx + g.My * g.Ry);
   float* stage = g.partial + (size_t)g.n_wg * np;
