@@ -130,6 +130,7 @@ enum {
   SC_GEMM_NO_STREAM = 16,    /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
   SC_GEMM_NO_SB = 64,        /* never take the small-extent streaming kernel (k_modegemm_sb; A-B / tests)  */
   SC_GEMM_SB_WM4 = 128,      /* k_modegemm_sb: the four waves over 512 contiguous modes of one tile (A-B / tests) */
+  SC_GEMM_NO_FMX = 1 << 24,  /* never take the matrix-core factor-matrix / mode-sum kernels (sc_kernels_fmx.h; A-B / tests) */
   SC_GEMM_F16 = 32           /* the reference's complex-half contraction (fno_block_precision "half" / "mixed",
                               * einsum_utils.py:10-36): operands rounded to float16, four real products summed in
                               * fp32 and rounded to float16, re = t00 - t11, im = t10 + t01 rounded to float16;
@@ -175,6 +176,14 @@ int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modegemm_desc* d
  * p*c_sp + q*c_sq) must be zeroed by the caller; c_sm / c_idx / accumulate are ignored. */
 int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const float* B, float* C,
                      void* stream);
+/* The same sum, C[p, q] OVERWRITTEN (no zeroing by the caller), on the matrix cores (round 3, sc_kernels_fmx.h:
+ * k_modegemm_msum_mx stages [rows][64 modes] chunks of both operands in LDS and accumulates 16 x 16 tiles over all
+ * chunks of a workgroup; one partial per workgroup in `workspace`, fixed-order reduction: run-to-run deterministic,
+ * unlike the atomic adds of sc_modegemm_msum).  Qualifies when both operands have mode stride 1, 8 <= P, Q <= 64 and
+ * n_modes >= 64: sc_modegemm_msum_workspace_bytes returns the bytes needed (0 = does not qualify: use sc_modegemm_msum). */
+size_t sc_modegemm_msum_workspace_bytes(const sc_modegemm_desc* d);
+int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, const float* B, float* C, void* workspace,
+                        size_t workspace_bytes, void* stream);
 /* 1 if this call runs on a matrix-core kernel, 0 for the VALU kernel */
 int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
 /* which kernel a call with 16-byte aligned operands takes: 0 k_modegemm (VALU), 1 k_modegemm_mfma (register-staged
@@ -184,7 +193,9 @@ int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
  * <= 4 terms into a weight-sized result: plain contiguous-mode operands, even mode count, even row strides;
  * bit-identical to path 0), 4 k_modegemm_bfac (round 3: b_sm == 0, i.e. a mode-independent right operand -- the channel
  * factor matrices of Tucker / CP contractions -- read through the scalar cache; unit mode strides of A and C, Q >= 8;
- * bit-identical to path 0) */
+ * bit-identical to path 0), 5 k_modegemm_bfac_mx (round 3: the same operand shape with 8 <= Q <= 64, 4 <= R <= 64 and
+ * >= 64 modes on the matrix cores: chunks of 64 modes staged in LDS, 16 x 16 x 4 MFMA tiles, three real products per
+ * complex product -- equal to path 0 up to the rounding of the last bits) */
 int sc_modegemm_path(const sc_modegemm_desc* d);
 
 /* out[i] = float16(in[i]) (round to nearest even), kept in fp32 storage; in == out allowed.  The cast points of

@@ -31,6 +31,7 @@ SC_GEMM_NO_STREAM = 16
 SC_GEMM_F16 = 32
 SC_GEMM_NO_SB = 64
 SC_GEMM_SB_WM4 = 128
+SC_GEMM_NO_FMX = 1 << 24
 
 
 def SC_GEMM_GRID(n):
@@ -136,7 +137,7 @@ class ScEngineLib:
     # every symbol include/sc_engine.h declares
     SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
                "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
-               "sc_modegemm_msum", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
+               "sc_modegemm_msum", "sc_modegemm_msum_ws", "sc_modegemm_msum_workspace_bytes", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
                "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
@@ -182,6 +183,10 @@ class ScEngineLib:
         L.sc_modegemm_pair_fused.restype = c_int
         L.sc_modegemm_msum.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_modegemm_msum.restype = c_int
+        L.sc_modegemm_msum_workspace_bytes.argtypes = [POINTER(ModeGemmDesc)]
+        L.sc_modegemm_msum_workspace_bytes.restype = c_size_t
+        L.sc_modegemm_msum_ws.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.sc_modegemm_msum_ws.restype = c_int
         L.sc_modegemm_uses_matrix_cores.argtypes = [POINTER(ModeGemmDesc)]
         L.sc_modegemm_uses_matrix_cores.restype = c_int
         L.sc_modegemm_path.argtypes = [POINTER(ModeGemmDesc)]
@@ -393,6 +398,20 @@ class ScEngineLib:
         for k, v in kw.items():
             setattr(d, k, v)
         self._check(self.lib.sc_modegemm_msum(byref(d), a_ptr, b_ptr, c_ptr, stream))
+
+    def modegemm_msum_workspace_bytes(self, **kw):
+        """Bytes of workspace sc_modegemm_msum_ws needs for this problem; 0 = it does not qualify (use modegemm_msum)."""
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return int(self.lib.sc_modegemm_msum_workspace_bytes(byref(d)))
+
+    def modegemm_msum_ws(self, a_ptr, b_ptr, c_ptr, ws_ptr, ws_bytes, stream=0, **kw):
+        """C[p, q] = sum over modes and r, OVERWRITTEN (matrix-core kernel + fixed-order reduction)."""
+        d = ModeGemmDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        self._check(self.lib.sc_modegemm_msum_ws(byref(d), a_ptr, b_ptr, c_ptr, ws_ptr, ws_bytes, stream))
 
     def modegemm_uses_matrix_cores(self, **kw):
         d = ModeGemmDesc()

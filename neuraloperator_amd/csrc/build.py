@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libsc_engine.so")
 SOURCES = ["sc_engine.cpp"]
-HEADERS = ["sc_device.h", "sc_kernels_generic.h", "sc_kernels_fft.h", "sc_kernels_fft3.h", "sc_kernels_mfma.h", "sc_kernels_gemm8.h", "sc_kernels_mdft.h", "sc_kernels_fft2p.h", "sc_kernels_plane.h", "sc_kernels_pmlp.h", "sc_kernels_tucker.h", "sc_kernels_sb.h",
+HEADERS = ["sc_device.h", "sc_kernels_generic.h", "sc_kernels_fft.h", "sc_kernels_fft3.h", "sc_kernels_mfma.h", "sc_kernels_gemm8.h", "sc_kernels_mdft.h", "sc_kernels_fft2p.h", "sc_kernels_plane.h", "sc_kernels_pmlp.h", "sc_kernels_tucker.h", "sc_kernels_sb.h", "sc_kernels_fmx.h",
            os.path.join("..", "..", "include", "sc_engine.h")]
 
 

@@ -26,6 +26,7 @@
 #include "sc_kernels_pmlp.h"
 #include "sc_kernels_tucker.h"
 #include "sc_kernels_sb.h"
+#include "sc_kernels_fmx.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -1400,6 +1401,101 @@ static int run_bfac_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   return (w9 * 9 - d->Q < w8 * 8 - d->Q) ? run_bfac_gemm_t<9>(d, A, B, C, st) : run_bfac_gemm_t<8>(d, A, B, C, st);
 }
 
+#ifndef SC_EMU
+#define SC_FMX_ATTR(kern, lds)                                                                                    \
+  if ((lds) > 64 * 1024)                                                                                         \
+  SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)))
+#else
+#define SC_FMX_ATTR(kern, lds) (void)0
+#endif
+static int tucker_abl() {
+  static const int v = [] { const char* e = std::getenv("SC_TK_ABL"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+// ---- factor-matrix products and mode-summed contractions on the matrix cores (sc_kernels_fmx.h) ---------------
+static bool fmx_off() {
+  static const bool off = std::getenv("SC_FMX_OFF") != nullptr;                        // A-B against the VALU kernels
+  return off;
+}
+// workgroups for n chunks with `cap` co-resident: every workgroup the same number of rounds
+static int fmx_wgs(int64_t chunks, int64_t cap) {
+  const int64_t rounds = (chunks + cap - 1) / cap;
+  return (int)((chunks + rounds - 1) / rounds);
+}
+static bool fmx_bfac_eligible(const sc_modegemm_desc* d) {
+  if (fmx_off() || (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_FMX | SC_GEMM_FORCE_VALU))) return false;
+  if (d->accumulate || d->b_idx || d->c_idx || d->a_sg || d->b_sg || d->c_sg) return false;
+  if (d->b_sm != 0 || d->a_sm != 1 || d->c_sm != 1) return false;
+  if (d->Q < 8 || d->Q > 64 || d->R < 4 || d->R > 64 || d->n_modes < 64) return false;
+  return d->P * ((d->n_modes + 63) / 64) < ((int64_t)1 << 30);
+}
+template <int PF>
+static int run_fmx_bfac_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  FmxArgs g;
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.c_sp = d->c_sp; g.c_sq = d->c_sq;
+  g.n_mb = (int)((d->n_modes + 63) / 64);
+  g.n_chunks = (int)(d->P * g.n_mb);
+  const int q4 = (int)((d->Q + 3) & ~(int64_t)3), r4 = (int)((d->R + 3) & ~(int64_t)3);
+  g.ldb = tkm_ld_rows(r4);
+  g.abl = tucker_abl();
+  g.inv_q = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)d->Q - 1) / (uint64_t)d->Q);
+  const size_t lds = (size_t)(q4 * g.ldb + r4 * SC_FMX_LDK) * sizeof(cf32);
+  g.n_wg = fmx_wgs(g.n_chunks, 256 * (int64_t)(160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds));
+#define SC_FX_LAUNCH(CA, CB)                                                                                     \
+  do {                                                                                                           \
+    auto kern = k_modegemm_bfac_mx<PF, CA, CB>;                                                                  \
+    SC_FMX_ATTR(kern, lds);                                                                                      \
+    SC_LAUNCH(kern, dim3((unsigned)g.n_wg), dim3(256), lds, st, g, A, B, C);                                     \
+  } while (0)
+  if (!d->conj_a && !d->conj_b) SC_FX_LAUNCH(false, false);
+  else if (d->conj_a && !d->conj_b) SC_FX_LAUNCH(true, false);
+  else if (!d->conj_a && d->conj_b) SC_FX_LAUNCH(false, true);
+  else SC_FX_LAUNCH(true, true);
+#undef SC_FX_LAUNCH
+  return sc_check_launch("k_modegemm_bfac_mx");
+}
+static int run_fmx_bfac(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  return d->R <= 36 ? run_fmx_bfac_t<9>(d, A, B, C, st) : run_fmx_bfac_t<16>(d, A, B, C, st);
+}
+
+static bool fmx_msum_eligible(const sc_modegemm_desc* d) {
+  if (fmx_off() || (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_FMX | SC_GEMM_FORCE_VALU))) return false;
+  if (d->b_idx || d->c_idx || d->a_sg || d->b_sg || d->c_sg) return false;
+  if (d->a_sm != 1 || d->b_sm != 1) return false;
+  if (d->P < 8 || d->P > 64 || d->Q < 8 || d->Q > 64 || d->n_modes < 64 || d->R < 1) return false;
+  return d->R * ((d->n_modes + 63) / 64) < ((int64_t)1 << 30);
+}
+static void fmx_msum_args(const sc_modegemm_desc* d, FmxArgs& g, size_t& lds) {
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.c_sp = d->c_sp; g.c_sq = d->c_sq;
+  g.n_mb = (int)((d->n_modes + 63) / 64);
+  g.n_chunks = (int)(d->R * g.n_mb);
+  g.ldb = 0;
+  g.inv_q = 0;
+  g.abl = tucker_abl();
+  const int p4 = (int)((d->P + 3) & ~(int64_t)3), q4 = (int)((d->Q + 3) & ~(int64_t)3);
+  lds = (size_t)((p4 + q4) * SC_FMX_LDR) * sizeof(cf32);
+  const int64_t per_cu = 160 * 1024 / lds > 3 ? 3 : 160 * 1024 / lds;
+  g.n_wg = fmx_wgs(g.n_chunks, 256 * per_cu);
+}
+template <int PFA, int PFB, int SLOTS>
+static int run_fmx_msum_t(const sc_modegemm_desc* d, const FmxArgs& g, size_t lds, const cf32* A, const cf32* B,
+                          cf32* partial, sc_stream_t st) {
+#define SC_FX_LAUNCH(CA, CB)                                                                                     \
+  do {                                                                                                           \
+    auto kern = k_modegemm_msum_mx<PFA, PFB, SLOTS, CA, CB>;                                                     \
+    SC_FMX_ATTR(kern, lds);                                                                                      \
+    SC_LAUNCH(kern, dim3((unsigned)g.n_wg), dim3(256), lds, st, g, A, B, partial);                               \
+  } while (0)
+  if (!d->conj_a && !d->conj_b) SC_FX_LAUNCH(false, false);
+  else if (d->conj_a && !d->conj_b) SC_FX_LAUNCH(true, false);
+  else if (!d->conj_a && d->conj_b) SC_FX_LAUNCH(false, true);
+  else SC_FX_LAUNCH(true, true);
+#undef SC_FX_LAUNCH
+  return sc_check_launch("k_modegemm_msum_mx");
+}
+
 // ---- matrix-core path (sc_kernels_mfma.h): channel counts that fill 32 x 32 MFMA tiles ----------
 static bool mfma_gemm_eligible(const sc_modegemm_desc* d) {
   // one workgroup tile is 32 or 64 rows x 64 columns; ragged problems (Tucker / TT ranks such as 36) take it
@@ -1670,6 +1766,7 @@ extern "C" int sc_modegemm(const sc_modegemm_desc* d, const float* A, const floa
     else SC_LAUNCH((k_modegemm_f16<false, false>), grid, dim3(SC_BLOCK), 0, st, g, a, b, c);
     return sc_check_launch("k_modegemm_f16");
   }
+  if (fmx_bfac_eligible(d)) return run_fmx_bfac(d, a, b, c, st);
   if (bfac_gemm_eligible(d)) {
     const int rc = run_bfac_gemm(d, a, b, c, st);
     if (rc >= 0) return rc;
@@ -1775,6 +1872,43 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
   else if (!d->conj_a && d->conj_b) launch_msum<false, true>(g, a, b, c, st);
   else launch_msum<true, true>(g, a, b, c, st);
   return sc_check_launch("k_modegemm_msum");
+}
+
+// C[p, q] = sum over modes and r (OVERWRITTEN, not accumulated) with a caller-provided workspace: the matrix-core
+// kernel + fixed-order reduction of sc_kernels_fmx.h where the problem qualifies (workspace_bytes > 0), else the
+// caller uses sc_modegemm_msum on a zeroed C
+extern "C" size_t sc_modegemm_msum_workspace_bytes(const sc_modegemm_desc* d) {
+  if (!d || d->P <= 0 || d->Q <= 0 || d->n_modes <= 0 || d->R <= 0 || !fmx_msum_eligible(d)) return 0;
+  FmxArgs g;
+  size_t lds;
+  fmx_msum_args(d, g, lds);
+  return (size_t)g.n_wg * (size_t)(d->P * d->Q) * sizeof(cf32) + 256;
+}
+
+extern "C" int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, const float* B, float* C, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  SC_CHECK_ARG(d && A && B && C && workspace, "null argument");
+  SC_CHECK_ARG(d->P > 0 && d->Q > 0 && d->R > 0 && d->n_modes > 0, "empty extent");
+  SC_CHECK_ARG(fmx_msum_eligible(d), "sc_modegemm_msum_ws: the problem does not qualify (sc_modegemm_msum_workspace_bytes == 0)");
+  SC_CHECK_ARG(workspace_bytes >= sc_modegemm_msum_workspace_bytes(d), "workspace too small");
+  FmxArgs g;
+  size_t lds;
+  fmx_msum_args(d, g, lds);
+  sc_stream_t st = (sc_stream_t)stream;
+  cf32* partial = (cf32*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const cf32* a = (const cf32*)A;
+  const cf32* b = (const cf32*)B;
+  const int64_t pa = (d->P + 3) / 4, pb = (d->Q + 3) / 4;
+  const int64_t tiles = ((d->P + 15) / 16) * ((d->Q + 15) / 16);
+  int rc;
+  if (pa <= 16 && pb <= 9 && tiles <= 12) rc = run_fmx_msum_t<16, 9, 3>(d, g, lds, a, b, partial, st);
+  else if (pa <= 9 && pb <= 16 && tiles <= 12) rc = run_fmx_msum_t<9, 16, 3>(d, g, lds, a, b, partial, st);
+  else rc = run_fmx_msum_t<16, 16, 4>(d, g, lds, a, b, partial, st);
+  if (rc) return rc;
+  const int npc = (int)(d->P * d->Q);
+  SC_LAUNCH(k_fmx_reduce, dim3((unsigned)((npc + 15) / 16)), dim3(256), 0, st, (const cf32*)partial, g.n_wg, npc, (int)d->Q,
+            (cf32*)C, d->c_sp, d->c_sq);
+  return sc_check_launch("k_fmx_reduce");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1991,15 +2125,20 @@ extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* 
 
 // ---- Tucker mode factors (sc_kernels_tucker.h)
 // matrix-core form (round 3) unless SC_TK_VALU is set (environment, A-B against the round-2 VALU kernels)
-static bool tucker_use_mx() {
+// (also VALU where the padded, conflict-free LDS layout of the matrix-core kernels does not fit: every extent near 64)
+static bool tucker_use_mx(const sc_tucker_desc* d) {
   static const bool valu = std::getenv("SC_TK_VALU") != nullptr;
-  return !valu;
+  return !valu && (size_t)tkm_layout((int)d->rx, (int)d->ry, (int)d->mx, (int)d->my, true).total * sizeof(cf32) <= 150 * 1024;
 }
 static size_t tucker_lds_bytes(const sc_tucker_desc* d, bool bwd) {
-  if (tucker_use_mx()) return (size_t)tkm_layout((int)d->rx, (int)d->ry, (int)d->mx, (int)d->my, bwd).total * sizeof(cf32);
+  if (tucker_use_mx(d)) return (size_t)tkm_layout((int)d->rx, (int)d->ry, (int)d->mx, (int)d->my, bwd).total * sizeof(cf32);
   size_t c = (size_t)d->mx * d->rx + (size_t)d->my * d->ry + (size_t)d->rx * d->ry + (size_t)d->rx * d->my;
   if (bwd) c += (size_t)d->mx * d->my + (size_t)d->rx * d->my;
   return c * sizeof(cf32);
+}
+static void tucker_invs(TuckerModesArgs& g) {
+  const auto inv = [](int n) { return (uint32_t)((((uint64_t)1 << 32) + (uint64_t)n - 1) / (uint64_t)n); };
+  g.inv_rx = inv(g.Rx); g.inv_ry = inv(g.Ry); g.inv_my = inv(g.My);
 }
 static int tucker_wgs(const sc_tucker_desc* d) {
   // workgroups of the two mode-factor kernels (each walks slices wg, wg + n, ...); SC_TK_WGS (environment, A-B)
@@ -2030,8 +2169,9 @@ extern "C" int sc_tucker_modes_forward(const sc_tucker_desc* d, const float* cor
   SC_CHECK_ARG(sc_tucker_modes_supported(d), "Tucker mode factors: sizes outside the kernel's limits");
   TuckerModesArgs g;
   g.core = (const cf32*)core; g.ux = (const cf32*)ux; g.uy = (const cf32*)uy; g.gt = nullptr; g.t = (cf32*)t; g.partial = nullptr;
-  g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d);
-  if (tucker_use_mx()) {
+  g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d); g.abl = tucker_abl();
+  tucker_invs(g);
+  if (tucker_use_mx(d)) {
     const size_t lds = tucker_lds_bytes(d, false);
     if (d->rx * d->ry <= 4 * 256) return tucker_launch(k_tucker_modes_fwd_mx<4>, g, lds, (sc_stream_t)stream, "k_tucker_modes_fwd_mx");
     return tucker_launch(k_tucker_modes_fwd_mx<16>, g, lds, (sc_stream_t)stream, "k_tucker_modes_fwd_mx");
@@ -2053,10 +2193,11 @@ extern "C" int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* co
   TuckerModesArgs g;
   g.core = (const cf32*)core; g.ux = (const cf32*)ux; g.uy = (const cf32*)uy; g.gt = (const cf32*)gt; g.t = (cf32*)gcore;
   g.partial = (float*)workspace;
-  g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d);
+  g.FG = (int)d->fg; g.Rx = (int)d->rx; g.Ry = (int)d->ry; g.Mx = (int)d->mx; g.My = (int)d->my; g.n_wg = tucker_wgs(d); g.abl = tucker_abl();
+  tucker_invs(g);
   sc_stream_t st = (sc_stream_t)stream;
   int rc;
-  if (tucker_use_mx()) {
+  if (tucker_use_mx(d)) {
     // the smallest instantiation that holds the problem: (3, 9, 3, 2) is ranks (36, ., 36, 19) on 64 x 33 kept modes
     const auto t16 = [](int64_t n) { return (n + 15) / 16; };
     const int64_t sx = (t16(d->mx) * t16(d->rx) + 3) / 4, sy = (t16(d->my) * t16(d->ry) + 3) / 4;
@@ -2069,6 +2210,11 @@ extern "C" int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* co
     rc = tucker_launch(k_tucker_modes_bwd, g, tucker_lds_bytes(d, true), st, "k_tucker_modes_bwd");
   if (rc) return rc;
   const int np = 2 * (g.Mx * g.Rx + g.My * g.Ry);
+  if (tucker_use_mx(d)) {
+    SC_LAUNCH(k_tucker_reduce, dim3((unsigned)((np / 2 + 15) / 16)), dim3(256), 0, st, (const cf32*)g.partial, g.n_wg, np / 2,
+              g.Mx * g.Rx, (cf32*)gux, (cf32*)guy);
+    return sc_check_launch("k_tucker_reduce");
+  }
   float* stage = g.partial + (size_t)g.n_wg * np;
   const unsigned nb = (unsigned)((np + 255) / 256);
   const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
@@ -2088,6 +2234,7 @@ extern "C" int sc_round_f16(const float* in, float* out, int64_t n, void* stream
 
 extern "C" int sc_modegemm_path(const sc_modegemm_desc* d) {
   if (!d) return 0;
+  if (fmx_bfac_eligible(d)) return 5;
   if (bfac_gemm_eligible(d)) return 4;
   if (sb_gemm_eligible(d, nullptr, nullptr, nullptr)) return 3;
   if (gemm8_eligible(d, nullptr, nullptr, nullptr)) return 2;

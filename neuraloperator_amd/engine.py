@@ -471,6 +471,15 @@ def _raw_mode_gemm(a, b, n_modes, conj_a, conj_b, reduce_modes=False, flags=0):
     dev = a.device
     with torch.cuda.device(dev):
         if reduce_modes:
+            kw = dict(P=P, Q=Q, R=R, n_modes=n_modes, a_sp=a_sp, a_sr=a_sr, a_sm=a_sm, b_sr=b_sr, b_sq=b_sq, b_sm=b_sm,
+                      conj_a=int(conj_a), conj_b=int(conj_b), flags=int(flags), c_sp=Q, c_sq=1, c_sm=0)
+            ws_bytes = lib.modegemm_msum_workspace_bytes(**kw) if P and Q and n_modes and R else 0
+            if ws_bytes:
+                # matrix-core kernel + fixed-order reduction (sc_kernels_fmx.h): C is overwritten, no zero fill
+                out = torch.empty((P, Q), dtype=torch.complex64, device=dev)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                lib.modegemm_msum_ws(a.data_ptr(), b.data_ptr(), out.data_ptr(), ws.data_ptr(), ws_bytes, _stream(), **kw)
+                return out
             out = torch.zeros((P, Q), dtype=torch.complex64, device=dev)
             fn, c = lib.modegemm_msum, dict(c_sp=Q, c_sq=1, c_sm=0)
         else:

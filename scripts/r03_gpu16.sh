@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 16: Tucker mode-factor kernels on the matrix cores (16x16x4 tiles, three real products)
-O=gpurun_out/r3o; mkdir -p $O
+O=gpurun_out/r3p; mkdir -p $O
 (timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_at_config.py -x -q -k "tucker or tfno or factor" 2>&1 | tail -4) > $O/pytest_tucker.log
 cat $O/pytest_tucker.log
 for v in mx valu mx valu; do
