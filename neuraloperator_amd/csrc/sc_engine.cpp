@@ -1429,7 +1429,7 @@ static bool fmx_bfac_eligible(const sc_modegemm_desc* d) {
   if (d->Q < 8 || d->Q > 64 || d->R < 4 || d->R > 64 || d->n_modes < 64) return false;
   return d->P * ((d->n_modes + 63) / 64) < ((int64_t)1 << 30);
 }
-template <int PF>
+template <int PF, int TQ>
 static int run_fmx_bfac_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
   FmxArgs g;
   g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
@@ -1444,7 +1444,7 @@ static int run_fmx_bfac_t(const sc_modegemm_desc* d, const cf32* A, const cf32* 
   g.n_wg = fmx_wgs(g.n_chunks, 256 * (int64_t)(160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds));
 #define SC_FX_LAUNCH(CA, CB)                                                                                     \
   do {                                                                                                           \
-    auto kern = k_modegemm_bfac_mx<PF, CA, CB>;                                                                  \
+    auto kern = k_modegemm_bfac_mx<PF, TQ, CA, CB>;                                                                  \
     SC_FMX_ATTR(kern, lds);                                                                                      \
     SC_LAUNCH(kern, dim3((unsigned)g.n_wg), dim3(256), lds, st, g, A, B, C);                                     \
   } while (0)
@@ -1456,7 +1456,8 @@ static int run_fmx_bfac_t(const sc_modegemm_desc* d, const cf32* A, const cf32* 
   return sc_check_launch("k_modegemm_bfac_mx");
 }
 static int run_fmx_bfac(const sc_modegemm_desc* d, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  return d->R <= 36 ? run_fmx_bfac_t<9>(d, A, B, C, st) : run_fmx_bfac_t<16>(d, A, B, C, st);
+  if (d->R <= 36) return d->Q <= 48 ? run_fmx_bfac_t<9, 3>(d, A, B, C, st) : run_fmx_bfac_t<9, 4>(d, A, B, C, st);
+  return d->Q <= 48 ? run_fmx_bfac_t<16, 3>(d, A, B, C, st) : run_fmx_bfac_t<16, 4>(d, A, B, C, st);
 }
 
 static bool fmx_msum_eligible(const sc_modegemm_desc* d) {
@@ -1899,10 +1900,9 @@ extern "C" int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, co
   const cf32* a = (const cf32*)A;
   const cf32* b = (const cf32*)B;
   const int64_t pa = (d->P + 3) / 4, pb = (d->Q + 3) / 4;
-  const int64_t tiles = ((d->P + 15) / 16) * ((d->Q + 15) / 16);
   int rc;
-  if (pa <= 16 && pb <= 9 && tiles <= 12) rc = run_fmx_msum_t<16, 9, 3>(d, g, lds, a, b, partial, st);
-  else if (pa <= 9 && pb <= 16 && tiles <= 12) rc = run_fmx_msum_t<9, 16, 3>(d, g, lds, a, b, partial, st);
+  if (pa <= 16 && pb <= 9 && d->Q <= 48) rc = run_fmx_msum_t<16, 9, 3>(d, g, lds, a, b, partial, st);
+  else if (pa <= 9) rc = run_fmx_msum_t<9, 16, 4>(d, g, lds, a, b, partial, st);
   else rc = run_fmx_msum_t<16, 16, 4>(d, g, lds, a, b, partial, st);
   if (rc) return rc;
   const int npc = (int)(d->P * d->Q);
@@ -2173,8 +2173,12 @@ extern "C" int sc_tucker_modes_forward(const sc_tucker_desc* d, const float* cor
   tucker_invs(g);
   if (tucker_use_mx(d)) {
     const size_t lds = tucker_lds_bytes(d, false);
-    if (d->rx * d->ry <= 4 * 256) return tucker_launch(k_tucker_modes_fwd_mx<4>, g, lds, (sc_stream_t)stream, "k_tucker_modes_fwd_mx");
-    return tucker_launch(k_tucker_modes_fwd_mx<16>, g, lds, (sc_stream_t)stream, "k_tucker_modes_fwd_mx");
+    sc_stream_t st = (sc_stream_t)stream;
+    const bool few = d->rx * d->ry <= 4 * 256, y3 = d->my <= 48;
+    if (few && y3) return tucker_launch(k_tucker_modes_fwd_mx<4, 3>, g, lds, st, "k_tucker_modes_fwd_mx");
+    if (few) return tucker_launch(k_tucker_modes_fwd_mx<4, 4>, g, lds, st, "k_tucker_modes_fwd_mx");
+    if (y3) return tucker_launch(k_tucker_modes_fwd_mx<16, 3>, g, lds, st, "k_tucker_modes_fwd_mx");
+    return tucker_launch(k_tucker_modes_fwd_mx<16, 4>, g, lds, st, "k_tucker_modes_fwd_mx");
   }
   return tucker_launch(k_tucker_modes_fwd, g, tucker_lds_bytes(d, false), (sc_stream_t)stream, "k_tucker_modes_fwd");
 }
@@ -2198,14 +2202,12 @@ extern "C" int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* co
   sc_stream_t st = (sc_stream_t)stream;
   int rc;
   if (tucker_use_mx(d)) {
-    // the smallest instantiation that holds the problem: (3, 9, 3, 2) is ranks (36, ., 36, 19) on 64 x 33 kept modes
-    const auto t16 = [](int64_t n) { return (n + 15) / 16; };
-    const int64_t sx = (t16(d->mx) * t16(d->rx) + 3) / 4, sy = (t16(d->my) * t16(d->ry) + 3) / 4;
+    // the smallest instantiation that holds the problem: (3, 9, 3, 3, 2) is ranks (36, ., 36, 19) on 64 x 33 kept modes
     const size_t lds = tucker_lds_bytes(d, true);
-    if (d->rx * d->ry <= 3 * 256 && d->mx * d->my <= 9 * 256 && sx <= 3 && sy <= 2)
-      rc = tucker_launch(k_tucker_modes_bwd_mx<3, 9, 3, 2>, g, lds, st, "k_tucker_modes_bwd_mx");
+    if (d->rx * d->ry <= 3 * 256 && d->mx * d->my <= 9 * 256 && d->rx <= 48 && d->my <= 48 && d->ry <= 32)
+      rc = tucker_launch(k_tucker_modes_bwd_mx<3, 9, 3, 3, 2>, g, lds, st, "k_tucker_modes_bwd_mx");
     else
-      rc = tucker_launch(k_tucker_modes_bwd_mx<16, 16, 4, 4>, g, lds, st, "k_tucker_modes_bwd_mx");
+      rc = tucker_launch(k_tucker_modes_bwd_mx<16, 16, 4, 4, 4>, g, lds, st, "k_tucker_modes_bwd_mx");
   } else
     rc = tucker_launch(k_tucker_modes_bwd, g, tucker_lds_bytes(d, true), st, "k_tucker_modes_bwd");
   if (rc) return rc;

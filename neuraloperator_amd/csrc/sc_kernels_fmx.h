@@ -16,9 +16,10 @@
 #pragma once
 #include "sc_kernels_tucker.h"
 
-// LDS row strides of a 64-mode chunk (8-byte units, see tkm_layout): read with k down the rows (bfac_mx: k = r) /
-// along the rows (msum_mx: k = mode)
-#define SC_FMX_LDK 80
+// LDS row stride of a 64-mode chunk (8-byte units, see tkm_layout): 2 x odd.  The chunk of bfac_mx is read with k down
+// the rows, for which 80 (16 mod 32) would be conflict free -- but 41 instead of 34 KB per chunk drops the kernel from
+// three to two workgroups per CU, and bank conflicts are 3 % of its LDS cycles (profiles/r03_fmx_pmc.txt)
+#define SC_FMX_LDK 66
 #define SC_FMX_LDR 66
 
 struct FmxArgs {
@@ -31,14 +32,15 @@ struct FmxArgs {
   int abl;                          // measurement only (SC_TK_ABL): 1 = no k loops, 2 = no result stores
 };
 
-template <int PF, bool CA, bool CB>
+// PF: prefetch registers per thread (ceil(R / 4)); TQ: 16-blocks of q a wave multiplies at once (>= ceil(Q / 16))
+template <int PF, int TQ, bool CA, bool CB>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_modegemm_bfac_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ C) {
   SC_DYN_SHARED(cf32, lds);
   const int Q = (int)g.Q, R = (int)g.R;
   const int q4 = (Q + 3) & ~3, r4 = (R + 3) & ~3;
   cf32* bt = lds;                                  // [q4][ldb]: bt[q][r] = B[r, q]
-  cf32* ac = lds + q4 * g.ldb;                     // [r4][80]: the chunk, ac[r][m]
+  cf32* ac = lds + q4 * g.ldb;                     // [r4][66]: the chunk, ac[r][m]
   const int tid = SC_TID, lane = tid & 63, w = SC_UNIFORM(tid >> 6);
   cf32 pf[PF];
   auto fetch = [&](const int c) {
@@ -67,7 +69,6 @@ k_modegemm_bfac_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict
 #pragma unroll
   for (int k = 0; k < 16; ++k)
     if (tid + 256 * k < Q * R) bt[to[k]] = tb[k];
-  const int tq = (Q + 15) >> 4;
   for (int c = SC_BID_X; c < g.n_chunks; c += g.n_wg) {
     SC_SYNC();                                     // the factor table (first round) / readers of the previous chunk
 #pragma unroll
@@ -80,24 +81,27 @@ k_modegemm_bfac_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict
     const int p = c / g.n_mb, mb = c - p * g.n_mb;
     const int64_t left = g.M - (int64_t)mb * 64;
     const int nm = left < 64 ? (int)left : 64;
-    const int tm = (nm + 15) >> 4;
     cf32* dst = C + (int64_t)p * g.c_sp + (int64_t)mb * 64;
-    for (int t = w; t < tq * tm; t += 4) {
-      const int i0 = (t / tm) * 16, j0 = (t % tm) * 16;
-      TkAcc a;
-      tk_zero(a);
-      tk_tile<CB, CA>(bt, g.ldb, 1, ac, SC_FMX_LDK, 1, i0, j0, Q, nm, R, lane, a, g.abl);
+    // wave w: the modes 16 w .. of the chunk (the shared operand of a k step) against all TQ blocks of q
+    if (16 * w < nm) {
+      TkAcc a[TQ];
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) tk_zero(a[t]);
+      tk_multi<TQ, false, CB, CA>(bt, g.ldb, 1, ac, SC_FMX_LDK, 1, 0, 16 * w, Q, nm, R, lane, a, g.abl);
       // rows of the result are q (stride c_sq), columns the modes
-      const int j = j0 + (lane & 15), ib = i0 + 4 * (lane >> 4);
+      const int j = 16 * w + (lane & 15), ib = 4 * (lane >> 4);
       if (j < nm && !(g.abl & 2)) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (ib + v < Q) dst[(int64_t)(ib + v) * g.c_sq + j] = tk_result<CA != CB>(a, v);
+        for (int t = 0; t < TQ; ++t)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (16 * t + ib + v < Q) dst[(int64_t)(16 * t + ib + v) * g.c_sq + j] = tk_result<CA != CB>(a[t], v);
       }
     }
   }
 }
 
+// PFA / PFB: prefetch registers per thread (ceil(P / 4), ceil(Q / 4)); SLOTS: 16-blocks of q (>= ceil(Q / 16))
 template <int PFA, int PFB, int SLOTS, bool CA, bool CB>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_modegemm_msum_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B, cf32* __restrict__ partial) {
@@ -126,10 +130,10 @@ k_modegemm_msum_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict
   };
   if ((int)SC_BID_X < g.n_chunks) fetch(SC_BID_X);
   for (int i = tid; i < (p4 + q4) * SC_FMX_LDR; i += 256) lds[i] = cf_make(0.f, 0.f);
-  TkAcc acc[SLOTS];
+  TkAcc acc[SLOTS];                                // wave w: rows p = 16 w .. against all SLOTS blocks of q
 #pragma unroll
   for (int k = 0; k < SLOTS; ++k) tk_zero(acc[k]);
-  const int tp = (P + 15) >> 4, tq = (Q + 15) >> 4;
+  const int tp = (P + 15) >> 4;
   for (int c = SC_BID_X; c < g.n_chunks; c += g.n_wg) {
     SC_SYNC();                                     // the zero fill (first round) / readers of the previous chunk
 #pragma unroll
@@ -144,18 +148,12 @@ k_modegemm_msum_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict
     }
     SC_SYNC();
     if (c + g.n_wg < g.n_chunks) fetch(c + g.n_wg);
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-      const int t = w + 4 * k;
-      if (t < tp * tq)
-        tk_tile<CA, CB>(ac, SC_FMX_LDR, 1, bc, 1, SC_FMX_LDR, (t / tq) * 16, (t % tq) * 16, P, Q, 64, lane, acc[k], g.abl);
-    }
+    if (w < tp) tk_multi<SLOTS, true, CA, CB>(ac, SC_FMX_LDR, 1, bc, 1, SC_FMX_LDR, 16 * w, 0, P, Q, 64, lane, acc, g.abl);
   }
   cf32* dst = partial + (int64_t)SC_BID_X * P * Q;
+  if (w < tp) {
 #pragma unroll
-  for (int k = 0; k < SLOTS; ++k) {
-    const int t = w + 4 * k;
-    if (t < tp * tq) tk_store<CA != CB>(acc[k], dst, Q, (t / tq) * 16, (t % tq) * 16, P, Q, lane);
+    for (int k = 0; k < SLOTS; ++k) tk_store<CA != CB>(acc[k], dst, Q, 16 * w, 16 * k, P, Q, lane);
   }
 }
 

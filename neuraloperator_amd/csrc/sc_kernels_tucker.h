@@ -206,15 +206,24 @@ k_tucker_scatter(const float* __restrict__ stage, int n, int np, int o_uy, float
 // ------------------------------------------------------------------------------------------
 #ifndef SC_EMU
 typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+// Written as inline assembly with the accumulator TIED (D = C): through the builtin the compiler routes the
+// accumulators of a multi-tile k loop through one scratch tuple (four v_accvgpr_mov per MFMA, every MFMA dependent on
+// the copy before it).  Wait states the compiler cannot see (cdna_hip_programming.md 5.7 item 2): `s_nop 1` ahead of
+// the MFMA covers an operand the vector ALU has just written; the FIRST read of any accumulator by compiler code goes
+// through sc_mfma_fence (12 states behind the last 8-pass MFMA), the others through sc_mfma_order.
 SC_DEVICE void sc_mfma_16x16x4(sc_f32x4& acc, const float a, const float b) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
+SC_DEVICE void sc_mfma_fence(sc_f32x4& acc) { asm volatile("s_nop 11" : "+v"(acc)); }
+SC_DEVICE void sc_mfma_order(sc_f32x4& acc) { asm volatile("" : "+v"(acc)); }
 #else
 struct sc_f32x4 {
   float v[4];
   float& operator[](int i) { return v[i]; }
   const float& operator[](int i) const { return v[i]; }
 };
+inline void sc_mfma_fence(sc_f32x4&) {}
+inline void sc_mfma_order(sc_f32x4&) {}
 // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; it owns D[row = 4 (l >> 4) + v][col = l & 15]
 // (cdna_hip_programming.md 3)
 inline void sc_mfma_16x16x4(sc_f32x4& acc, const float a, const float b) {
@@ -242,54 +251,102 @@ SC_DEVICE void tk_zero(TkAcc& t) {
     for (int v = 0; v < 4; ++v) t.p[u][v] = 0.f;
 }
 
-// acc += the 16 x 16 tile (i0.., j0..) of opA(A)(M x K) opB(B)(K x N): A(i, k) = A[i a_si + k a_sk], B(k, j) = B[k b_sk + j b_sj]
-// (complex, LDS).  The k extent of every LDS array is padded with ZEROS to a multiple of 4 (tkm_layout), so the loop
-// has no edge handling; rows / columns past the end read the last valid one (never stored).  Conjugations cost
-// nothing inside the loop: with sa, sb = -1 for a conjugated operand the three products are
+// acc[t] += NT 16 x 16 tiles of opA(A)(M x K) opB(B)(K x N): A(i, k) = A[i a_si + k a_sk], B(k, j) = B[k b_sk + j b_sj]
+// (complex, LDS).  SHARE_A: the tiles (i0, j0 + 16 t) of one block of rows -- the A operand of a k step is read once
+// for all of them; otherwise the tiles (i0 + 16 t, j0) of one block of columns share the B operand.  Per k step:
+// 1 + NT LDS reads, 3 NT independent MFMAs (NT = 3: 288 matrix-pipe cycles), a handful of vector instructions; one
+// tile set-up per NT tiles (a wave that walks single tiles spends 8 vector instructions per MFMA: SQ_INSTS_VALU /
+// SQ_INSTS_MFMA of the first version, profiles/r03_fmx_pmc.txt).
+// The k extent of every LDS array is padded with ZEROS to a multiple of 4 (tkm_layout), so the loop has no edge
+// handling; rows / columns past the end read the last valid one (never stored; whole blocks past the end are wasted
+// work the callers avoid through NT).  Conjugations cost nothing inside the loop: with sa, sb = -1 for a conjugated
+// operand the three products are
 //     P1 = Re A Re B,  P2 = Im A Im B,  P3 = (Re A + sa Im A)(Re B + sb Im B)
 // and  Re C = P1 - sa sb P2,  Im C = P3 - P1 - sa sb P2  (tk_result).
-// The operands of step s + 1 are requested before the MFMAs of step s are issued; the loop body is two LDS reads, two
-// pointer increments, two additions and three MFMAs (96 matrix-pipe cycles).
-template <bool CA, bool CB>
-SC_DEVICE void tk_tile(const cf32* A, const int a_si, const int a_sk, const cf32* B, const int b_sk, const int b_sj,
-                       const int i0, const int j0, const int M, const int N, const int K, const int lane, TkAcc& acc,
-                       const int abl = 0) {
+// The operands of step s + 1 are requested before the MFMAs of step s are issued -- without a branch around the
+// requests (the compiler would wait for every outstanding read at the join): the last step re-reads itself.
+template <int NT, bool SHARE_A, bool CA, bool CB>
+SC_DEVICE void tk_multi(const cf32* A, const int a_si, const int a_sk, const cf32* B, const int b_sk, const int b_sj,
+                        const int i0, const int j0, const int M, const int N, const int K, const int lane,
+                        TkAcc (&acc)[NT], const int abl = 0) {
   const int li = lane & 15, kq = lane >> 4;
-  const int i = i0 + li < M ? i0 + li : M - 1, j = j0 + li < N ? j0 + li : N - 1;
-  const cf32* ap = A + i * a_si + kq * a_sk;
-  const cf32* bp = B + j * b_sj + kq * b_sk;
   const int ns = (abl & 1) ? 0 : (K + 3) >> 2;
-  const int ng = ns >> 1;                                    // pairs of k steps
-  const int as4 = 4 * a_sk, bs4 = 4 * b_sk;
-  sc_f32x4 p0 = acc.p[0], p1 = acc.p[1], p2 = acc.p[2];
-  auto step = [&](const cf32 a, const cf32 b) {
-    sc_mfma_16x16x4(p0, a.x, b.x);
-    sc_mfma_16x16x4(p1, a.y, b.y);
-    sc_mfma_16x16x4(p2, CA ? a.x - a.y : a.x + a.y, CB ? b.x - b.y : b.x + b.y);
-  };
-  if (ng > 0) {
-    // two steps per iteration; the four operands of the NEXT pair are requested before this pair's six MFMAs (192
-    // matrix-pipe cycles) are issued.  No branch around the requests (the compiler would wait for every outstanding
-    // read at the join): the last iteration re-reads its own pair.
-    cf32 a0 = sc_lds_ld64(ap), b0 = sc_lds_ld64(bp), a1 = sc_lds_ld64(ap + as4), b1 = sc_lds_ld64(bp + bs4);
-    for (int g = 0; g < ng; ++g) {
-      const int adv = g + 1 < ng ? 2 : 0;                    // uniform select
-      ap += adv * as4;
-      bp += adv * bs4;
-      const cf32 na0 = sc_lds_ld64(ap), nb0 = sc_lds_ld64(bp), na1 = sc_lds_ld64(ap + as4), nb1 = sc_lds_ld64(bp + bs4);
-      SC_SCHED_BARRIER();
-      step(a0, b0);
-      step(a1, b1);
-      SC_SCHED_BARRIER();
-      a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+  if (ns == 0) return;
+  const cf32* sp;                                            // the shared operand, the NT others
+  const cf32* mp[NT];
+  int s_step, m_step;
+  if (SHARE_A) {
+    const int i = i0 + li < M ? i0 + li : M - 1;
+    sp = A + i * a_si + kq * a_sk;
+    s_step = 4 * a_sk;
+    m_step = 4 * b_sk;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int j = j0 + 16 * t + li < N ? j0 + 16 * t + li : N - 1;
+      mp[t] = B + j * b_sj + kq * b_sk;
     }
-    ap += 2 * as4;
-    bp += 2 * bs4;
+  } else {
+    const int j = j0 + li < N ? j0 + li : N - 1;
+    sp = B + j * b_sj + kq * b_sk;
+    s_step = 4 * b_sk;
+    m_step = 4 * a_sk;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int i = i0 + 16 * t + li < M ? i0 + 16 * t + li : M - 1;
+      mp[t] = A + i * a_si + kq * a_sk;
+    }
   }
-  if (ns & 1) step(sc_lds_ld64(ap), sc_lds_ld64(bp));        // uniform: the odd last step
-  acc.p[0] = p0;
-  acc.p[1] = p1;
-  acc.p[2] = p2;
+  sc_f32x4 p[NT][3];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) p[t][u] = acc[t].p[u];
+  cf32 sv = sc_lds_ld64(sp), mv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mv[t] = sc_lds_ld64(mp[t]);
+  constexpr bool CS = SHARE_A ? CA : CB, CM = SHARE_A ? CB : CA;    // conjugation of the shared / the other operand
+  for (int st = 0; st < ns; ++st) {
+    const int adv = st + 1 < ns ? 1 : 0;                     // uniform select
+    sp += adv * s_step;
+    const cf32 sn = sc_lds_ld64(sp);
+    cf32 mn[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      mp[t] += adv * m_step;
+      mn[t] = sc_lds_ld64(mp[t]);
+    }
+    const float s3 = CS ? sv.x - sv.y : sv.x + sv.y;
+    float m3[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) m3[t] = CM ? mv[t].x - mv[t].y : mv[t].x + mv[t].y;
+    // the A operand of an MFMA is the row side
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (SHARE_A) sc_mfma_16x16x4(p[t][0], sv.x, mv[t].x);
+      else sc_mfma_16x16x4(p[t][0], mv[t].x, sv.x);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (SHARE_A) sc_mfma_16x16x4(p[t][1], sv.y, mv[t].y);
+      else sc_mfma_16x16x4(p[t][1], mv[t].y, sv.y);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (SHARE_A) sc_mfma_16x16x4(p[t][2], s3, m3[t]);
+      else sc_mfma_16x16x4(p[t][2], m3[t], s3);
+    }
+    sv = sn;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) mv[t] = mn[t];
+  }
+  sc_mfma_fence(p[0][0]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (t || u) sc_mfma_order(p[t][u]);
+      acc[t].p[u] = p[t][u];
+    }
 }
 
 // element v of the lane's 4 results of a tile; SS = sa sb < 0 (exactly one operand conjugated)
@@ -366,7 +423,9 @@ SC_DEVICE void tkm_table_store(cf32* dst, const int n, const int cols, const uin
   }
 }
 
-template <int PFC>
+// PFC: prefetch registers per thread for a core slice (ceil(Rx Ry / 256)); TY: 16-blocks of y a wave multiplies at once
+// (>= ceil(My / 16); blocks past the end are wasted work)
+template <int PFC, int TY>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_tucker_modes_fwd_mx(TuckerModesArgs g) {
   SC_DYN_SHARED(cf32, lds);
@@ -400,7 +459,7 @@ k_tucker_modes_fwd_mx(TuckerModesArgs g) {
     const int i = tid + 256 * k, r = tkm_div(i, g.inv_ry);
     oc[k] = r * L.ldc + (i - r * g.Ry);
   }
-  const int ti_c = (g.Rx + 15) >> 4, tj_y = (g.My + 15) >> 4, ti_x = (g.Mx + 15) >> 4;
+  const int t_c = (g.Rx + 15) >> 4, t_x = (g.Mx + 15) >> 4;
   for (int fg = SC_BID_X; fg < g.FG; fg += g.n_wg) {
     SC_SYNC();                                     // tables (first round) / readers of co and tmp (later rounds)
 #pragma unroll
@@ -408,30 +467,33 @@ k_tucker_modes_fwd_mx(TuckerModesArgs g) {
       if (tid + 256 * k < n_co) co[oc[k]] = pf[k];
     SC_SYNC();
     if (fg + g.n_wg < g.FG) fetch(fg + g.n_wg);
-    // tmp[c][y] = sum_d co[c][d] uy[y][d]
-    for (int t = w; t < ti_c * tj_y; t += 4) {
-      const int i0 = (t / tj_y) * 16, j0 = (t % tj_y) * 16;
-      TkAcc a;
-      tk_zero(a);
-      tk_tile<false, false>(co, L.ldc, 1, uy, 1, L.ldy, i0, j0, g.Rx, g.My, g.Ry, lane, a, g.abl);
-      tk_store<false>(a, tmp, L.ldt, i0, j0, g.Rx, g.My, lane, g.abl);
+    // tmp[c][y] = sum_d co[c][d] uy[y][d]: wave w takes the rows c = 16 w .., all TY blocks of y
+    if (w < t_c) {
+      TkAcc a[TY];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_zero(a[t]);
+      tk_multi<TY, true, false, false>(co, L.ldc, 1, uy, 1, L.ldy, 16 * w, 0, g.Rx, g.My, g.Ry, lane, a, g.abl);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_store<false>(a[t], tmp, L.ldt, 16 * w, 16 * t, g.Rx, g.My, lane, g.abl);
     }
     SC_SYNC();
-    // out[x][y] = sum_c ux[x][c] tmp[c][y]
+    // out[x][y] = sum_c ux[x][c] tmp[c][y]: wave w takes the rows x = 16 w ..
     cf32* dst = g.t + (int64_t)fg * g.Mx * g.My;
-    for (int t = w; t < ti_x * tj_y; t += 4) {
-      const int i0 = (t / tj_y) * 16, j0 = (t % tj_y) * 16;
-      TkAcc a;
-      tk_zero(a);
-      tk_tile<false, false>(ux, L.ldx, 1, tmp, L.ldt, 1, i0, j0, g.Mx, g.My, g.Rx, lane, a, g.abl);
-      tk_store<false>(a, dst, g.My, i0, j0, g.Mx, g.My, lane, g.abl);
+    if (w < t_x) {
+      TkAcc a[TY];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_zero(a[t]);
+      tk_multi<TY, true, false, false>(ux, L.ldx, 1, tmp, L.ldt, 1, 16 * w, 0, g.Mx, g.My, g.Rx, lane, a, g.abl);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_store<false>(a[t], dst, g.My, 16 * w, 16 * t, g.Mx, g.My, lane, g.abl);
     }
   }
 }
 
 // PFC / PFG: prefetch registers per thread for a core slice / a gT slice (ceil(Rx Ry / 256), ceil(Mx My / 256));
-// SX / SY: gradient tiles per wave (ceil(tiles / 4)).  The host picks the smallest instantiation that holds the problem.
-template <int PFC, int PFG, int SX, int SY>
+// TC / TY / TD: 16-blocks of c (Rx) / y (My) / d (Ry) a wave multiplies at once (>= the number of blocks; blocks past the
+// end are wasted work).  The host picks the smallest instantiation that holds the problem.
+template <int PFC, int PFG, int TC, int TY, int TD>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_tucker_modes_bwd_mx(TuckerModesArgs g) {
   SC_DYN_SHARED(cf32, lds);
@@ -476,16 +538,13 @@ k_tucker_modes_bwd_mx(TuckerModesArgs g) {
     const int i = tid + 256 * k, r = tkm_div(i, g.inv_my);
     og[k] = r * L.ldg + (i - r * g.My);
   }
-  const int t_c = (g.Rx + 15) >> 4, t_y = (g.My + 15) >> 4, t_x = (g.Mx + 15) >> 4, t_d = (g.Ry + 15) >> 4;
-  // gradient tiles of this wave: gux tile t = w + 4 slot (x block t / t_c, c block t % t_c), guy tile t = w + 4 slot
-  // (y block t / t_d, d block t % t_d); the tiles of gcore (w2) and tmp (w3) start at rotated waves so that the waves
-  // with one tile fewer of the one product take one more of the other
-  const int w2 = (w + 2) & 3, w3 = (w + 3) & 3;
-  TkAcc aux[SX], auy[SY];
+  const int t_c = (g.Rx + 15) >> 4, t_y = (g.My + 15) >> 4, t_x = (g.Mx + 15) >> 4;
+  // gradient tiles of this wave: gux rows x = 16 w .. x all TC blocks of c; guy rows y = 16 w .. x all TD blocks of d
+  TkAcc aux[TC], auy[TD];
 #pragma unroll
-  for (int k = 0; k < SX; ++k) tk_zero(aux[k]);
+  for (int k = 0; k < TC; ++k) tk_zero(aux[k]);
 #pragma unroll
-  for (int k = 0; k < SY; ++k) tk_zero(auy[k]);
+  for (int k = 0; k < TD; ++k) tk_zero(auy[k]);
   for (int fg = SC_BID_X; fg < g.FG; fg += g.n_wg) {
     SC_SYNC();
 #pragma unroll
@@ -496,58 +555,53 @@ k_tucker_modes_bwd_mx(TuckerModesArgs g) {
       if (tid + 256 * k < n_gt) gt[og[k]] = pfg[k];
     SC_SYNC();
     if (fg + g.n_wg < g.FG) fetch(fg + g.n_wg);
-    // phase A: s[c][y] = sum_x conj(ux[x][c]) gt[x][y]  and  tmp[c][y] = sum_d co[c][d] uy[y][d]
-    for (int t = w; t < t_c * t_y; t += 4) {
-      const int i0 = (t / t_y) * 16, j0 = (t % t_y) * 16;
-      TkAcc a;
-      tk_zero(a);
-      tk_tile<true, false>(ux, 1, L.ldx, gt, L.ldg, 1, i0, j0, g.Rx, g.My, g.Mx, lane, a, g.abl);
-      tk_store<true>(a, s, L.lds, i0, j0, g.Rx, g.My, lane, g.abl);
+    // phase A: s[c][y] = sum_x conj(ux[x][c]) gt[x][y] (wave w: rows c = 16 w ..) and tmp[c][y] = sum_d co[c][d] uy[y][d]
+    // (with fewer than four blocks of c the otherwise idle wave 3 takes all of them: 3 x 5 k steps against 16)
+    if (w < t_c) {
+      TkAcc a[TY];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_zero(a[t]);
+      tk_multi<TY, true, true, false>(ux, 1, L.ldx, gt, L.ldg, 1, 16 * w, 0, g.Rx, g.My, g.Mx, lane, a, g.abl);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_store<true>(a[t], s, L.lds, 16 * w, 16 * t, g.Rx, g.My, lane, g.abl);
     }
-    for (int t = w3; t < t_c * t_y; t += 4) {
-      const int i0 = (t / t_y) * 16, j0 = (t % t_y) * 16;
-      TkAcc a;
-      tk_zero(a);
-      tk_tile<false, false>(co, L.ldc, 1, uy, 1, L.ldy, i0, j0, g.Rx, g.My, g.Ry, lane, a, g.abl);
-      tk_store<false>(a, tmp, L.ldt, i0, j0, g.Rx, g.My, lane, g.abl);
+    for (int b = (t_c < 4 ? (w == 3 ? 0 : t_c) : w); b < t_c; b += (t_c < 4 ? 1 : 4)) {
+      TkAcc a[TY];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_zero(a[t]);
+      tk_multi<TY, true, false, false>(co, L.ldc, 1, uy, 1, L.ldy, 16 * b, 0, g.Rx, g.My, g.Ry, lane, a, g.abl);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) tk_store<false>(a[t], tmp, L.ldt, 16 * b, 16 * t, g.Rx, g.My, lane, g.abl);
     }
     SC_SYNC();
-    // phase B: gcore[c][d] = sum_y s[c][y] conj(uy[y][d])
+    // phase B: gcore[c][d] = sum_y s[c][y] conj(uy[y][d]): block b of c on wave 3 - b (the waves with fewer rows below)
     cf32* gc = g.t + (int64_t)fg * n_co;
-    for (int t = w2; t < t_c * t_d; t += 4) {
-      const int i0 = (t / t_d) * 16, j0 = (t % t_d) * 16;
-      TkAcc a;
-      tk_zero(a);
-      tk_tile<false, true>(s, L.lds, 1, uy, L.ldy, 1, i0, j0, g.Rx, g.Ry, g.My, lane, a, g.abl);
-      tk_store<true>(a, gc, g.Ry, i0, j0, g.Rx, g.Ry, lane, g.abl);
+    {
+      const int b = 3 - w;
+      if (b < t_c) {
+        TkAcc a[TD];
+#pragma unroll
+        for (int t = 0; t < TD; ++t) tk_zero(a[t]);
+        tk_multi<TD, true, false, true>(s, L.lds, 1, uy, L.ldy, 1, 16 * b, 0, g.Rx, g.Ry, g.My, lane, a, g.abl);
+#pragma unroll
+        for (int t = 0; t < TD; ++t) tk_store<true>(a[t], gc, g.Ry, 16 * b, 16 * t, g.Rx, g.Ry, lane, g.abl);
+      }
     }
     // gux[x][c] += sum_y gt[x][y] conj(tmp[c][y])
-#pragma unroll
-    for (int k = 0; k < SX; ++k) {
-      const int t = w + 4 * k;
-      if (t < t_x * t_c)
-        tk_tile<false, true>(gt, L.ldg, 1, tmp, 1, L.ldt, (t / t_c) * 16, (t % t_c) * 16, g.Mx, g.Rx, g.My, lane, aux[k], g.abl);
-    }
+    if (w < t_x) tk_multi<TC, true, false, true>(gt, L.ldg, 1, tmp, 1, L.ldt, 16 * w, 0, g.Mx, g.Rx, g.My, lane, aux, g.abl);
     // guy[y][d] += sum_c s[c][y] conj(co[c][d])
-#pragma unroll
-    for (int k = 0; k < SY; ++k) {
-      const int t = w + 4 * k;
-      if (t < t_y * t_d)
-        tk_tile<false, true>(s, 1, L.lds, co, L.ldc, 1, (t / t_d) * 16, (t % t_d) * 16, g.My, g.Ry, g.Rx, lane, auy[k], g.abl);
-    }
+    if (w < t_y) tk_multi<TD, true, false, true>(s, 1, L.lds, co, L.ldc, 1, 16 * w, 0, g.My, g.Ry, g.Rx, lane, auy, g.abl);
   }
   // one partial per workgroup: [gux (Mx Rx) | guy (My Ry)] interleaved complex; every entry is owned by one lane
   cf32* dst = reinterpret_cast<cf32*>(g.partial + (int64_t)SC_BID_X * 2 * (g.Mx * g.Rx + g.My * g.Ry));
+  if (w < t_x) {
 #pragma unroll
-  for (int k = 0; k < SX; ++k) {
-    const int t = w + 4 * k;
-    if (t < t_x * t_c) tk_store<true>(aux[k], dst, g.Rx, (t / t_c) * 16, (t % t_c) * 16, g.Mx, g.Rx, lane, g.abl);
+    for (int k = 0; k < TC; ++k) tk_store<true>(aux[k], dst, g.Rx, 16 * w, 16 * k, g.Mx, g.Rx, lane, g.abl);
   }
   dst += g.Mx * g.Rx;
+  if (w < t_y) {
 #pragma unroll
-  for (int k = 0; k < SY; ++k) {
-    const int t = w + 4 * k;
-    if (t < t_y * t_d) tk_store<true>(auy[k], dst, g.Ry, (t / t_d) * 16, (t % t_d) * 16, g.My, g.Ry, lane, g.abl);
+    for (int k = 0; k < TD; ++k) tk_store<true>(auy[k], dst, g.Ry, 16 * w, 16 * k, g.My, g.Ry, lane, g.abl);
   }
 }
 
