@@ -329,16 +329,23 @@ class ScEngineLib:
                                                   y_ptr, n_images, ws_ptr, stream))
 
     def modegemm(self, a_ptr, b_ptr, c_ptr, stream=0, **kw):
-        d = ModeGemmDesc()
-        for k, v in kw.items():
-            setattr(d, k, v)
-        self._check(self.lib.sc_modegemm(byref(d), a_ptr, b_ptr, c_ptr, stream))
+        self._check(self.lib.sc_modegemm(byref(self._gemm_desc(kw)), a_ptr, b_ptr, c_ptr, stream))
+
+    _DESC_CACHE = {}
 
     @staticmethod
     def _gemm_desc(kw):
-        d = ModeGemmDesc()
-        for k, v in kw.items():
-            setattr(d, k, v)
+        """The descriptor of a contraction, cached by value: building a 22-field ctypes structure through setattr costs
+        about as much host time as the launch itself (a factorized layer step issues ~20 of them)."""
+        key = tuple(kw.items())
+        d = ScEngineLib._DESC_CACHE.get(key)
+        if d is None:
+            if len(ScEngineLib._DESC_CACHE) > 4096:
+                ScEngineLib._DESC_CACHE.clear()
+            d = ModeGemmDesc()
+            for k, v in kw.items():
+                setattr(d, k, v)
+            ScEngineLib._DESC_CACHE[key] = d
         return d
 
     def modegemm_pair(self, kw0, a0, b0, c0, kw1, a1, b1, c1, stream=0):
@@ -394,24 +401,15 @@ class ScEngineLib:
         self._check(self.lib.sc_round_f16(in_ptr, out_ptr, n, stream))
 
     def modegemm_msum(self, a_ptr, b_ptr, c_ptr, stream=0, **kw):
-        d = ModeGemmDesc()
-        for k, v in kw.items():
-            setattr(d, k, v)
-        self._check(self.lib.sc_modegemm_msum(byref(d), a_ptr, b_ptr, c_ptr, stream))
+        self._check(self.lib.sc_modegemm_msum(byref(self._gemm_desc(kw)), a_ptr, b_ptr, c_ptr, stream))
 
     def modegemm_msum_workspace_bytes(self, **kw):
         """Bytes of workspace sc_modegemm_msum_ws needs for this problem; 0 = it does not qualify (use modegemm_msum)."""
-        d = ModeGemmDesc()
-        for k, v in kw.items():
-            setattr(d, k, v)
-        return int(self.lib.sc_modegemm_msum_workspace_bytes(byref(d)))
+        return int(self.lib.sc_modegemm_msum_workspace_bytes(byref(self._gemm_desc(kw))))
 
     def modegemm_msum_ws(self, a_ptr, b_ptr, c_ptr, ws_ptr, ws_bytes, stream=0, **kw):
         """C[p, q] = sum over modes and r, OVERWRITTEN (matrix-core kernel + fixed-order reduction)."""
-        d = ModeGemmDesc()
-        for k, v in kw.items():
-            setattr(d, k, v)
-        self._check(self.lib.sc_modegemm_msum_ws(byref(d), a_ptr, b_ptr, c_ptr, ws_ptr, ws_bytes, stream))
+        self._check(self.lib.sc_modegemm_msum_ws(byref(self._gemm_desc(kw)), a_ptr, b_ptr, c_ptr, ws_ptr, ws_bytes, stream))
 
     def modegemm_uses_matrix_cores(self, **kw):
         d = ModeGemmDesc()

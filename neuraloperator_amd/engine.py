@@ -598,6 +598,48 @@ def tucker_modes_2d(core, ux, uy):
     return TuckerModes2dFn.apply(core, ux, uy)
 
 
+class TuckerChainFn(torch.autograd.Function):
+    """The activation side of the factorized Tucker contraction as ONE autograd node (round 3):
+        z[b,f,m] = sum_i xhat[b,i,m] U_in[i,f];  t[b,g,m] = sum_f z[b,f,m] T[f,g,m];  yhat[b,o,m] = sum_g t[b,g,m] U_out[o,g]
+    (the pairwise order of _forward_tucker, spectral_convolution.py:76-103) -- the same launches as three ModeGemmFn
+    nodes, but a step of this layer is ~30 launches of 20-100 us each and the host needs about as long to walk four
+    autograd nodes and their views as the device needs to run them (scripts/tfno_cpu_bound.py: 0.62 ms to issue a
+    0.77 ms step).  Backward: the six products of the three nodes, in the order their gradients are needed."""
+
+    @staticmethod
+    def forward(ctx, xhat, u_in, t3, u_out):
+        _require_gpu(xhat, "xhat")
+        c64 = lambda v: v if v.dtype == torch.complex64 else v.to(torch.complex64)
+        xhat, u_in, t3, u_out = c64(xhat), c64(u_in), c64(t3), c64(u_out)
+        m = int(xhat.shape[2])
+        z = _raw_mode_gemm(xhat, u_in, m, False, False)
+        t = _raw_mode_gemm(z, t3, m, False, False)
+        yhat = _raw_mode_gemm(t, u_out.transpose(0, 1), m, False, False)
+        ctx.save_for_backward(xhat, u_in, t3, u_out, z, t)
+        return yhat
+
+    @staticmethod
+    def backward(ctx, gy):
+        xhat, u_in, t3, u_out, z, t = ctx.saved_tensors
+        m = int(xhat.shape[2])
+        gy = gy.contiguous()
+        need = ctx.needs_input_grad
+        # yhat = t U_out^T:  gt = gy conj(U_out);  g(U_out^T)[g,o] = sum_{b,m} conj(t[b,g,m]) gy[b,o,m]
+        gt = _raw_mode_gemm(gy, u_out, m, False, True)
+        gu_out = _raw_mode_gemm(t.transpose(0, 1), gy, m, True, False, reduce_modes=True).transpose(0, 1) if need[3] else None
+        # t = z T:  gz = gt T^H;  gT[f,g,m] = sum_b conj(z[b,f,m]) gt[b,g,m]
+        gz = _raw_mode_gemm(gt, t3.transpose(0, 1), m, False, True)
+        gt3 = _raw_mode_gemm(z.transpose(0, 1), gt, m, True, False) if need[2] else None
+        # z = xhat U_in:  gxhat = gz U_in^H;  gU_in[i,f] = sum_{b,m} conj(xhat[b,i,m]) gz[b,f,m]
+        gx = _raw_mode_gemm(gz, u_in.transpose(0, 1), m, False, True) if need[0] else None
+        gu_in = _raw_mode_gemm(xhat.transpose(0, 1), gz, m, True, False, reduce_modes=True) if need[1] else None
+        return gx, gu_in, gt3, gu_out
+
+
+def tucker_chain(xhat, u_in, t3, u_out):
+    return TuckerChainFn.apply(xhat, u_in, t3, u_out)
+
+
 def mode_gemm(a, b, n_modes, conj_a=False, conj_b=False, flags=0):
     return ModeGemmFn.apply(a, b, n_modes, conj_a, conj_b, flags)
 

@@ -438,7 +438,7 @@ class SpectralConv(BaseSpectralConv):
             T[f,g,modes] = core x_modes U_modes     (batch independent)
             z[b,f,m] = sum_i xhat[b,i,m] U_in[i,f]; t[b,g,m] = sum_f z[b,f,m] T[f,g,m];
             yhat[b,o,m] = sum_g t[b,g,m] U_out[o,g]
-        every step an sc_modegemm launch, autograd through sc_modegemm / sc_modegemm_msum."""
+        every step an sc_modegemm launch, autograd through sc_modegemm / sc_modegemm_msum (engine.TuckerChainFn)."""
         kept, wsl = self._used_block(spatial)
         u_in, u_out = wsl.factors[0], wsl.factors[1]
         t3 = self._tucker_core_times_modes(wsl, kept)
@@ -446,7 +446,5 @@ class SpectralConv(BaseSpectralConv):
         ops = engine.EngineOps(self.fft_norm, self.engine_flags)
         xhat = ops.forward_transform(x, kept)               # (B, Cin, *kept) complex64
         b, ci = xhat.shape[:2]
-        z = engine.mode_gemm(xhat.reshape(b, ci, m), u_in, m)
-        t = engine.mode_gemm(z, t3, m)
-        yhat = engine.mode_gemm(t, u_out.transpose(0, 1), m)
+        yhat = engine.tucker_chain(xhat.reshape(b, ci, m), u_in, t3, u_out)           # the three steps, one autograd node
         return ops.inverse_transform(yhat.reshape(b, u_out.shape[0], *kept), self.bias, spatial)

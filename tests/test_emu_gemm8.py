@@ -127,7 +127,8 @@ def test_eligibility(lib):
     assert lib.modegemm_path(**dict(gx, P=4)) == 3                        # round 3: <= 4 rows -> the small-extent streaming kernel
     assert lib.modegemm_path(**dict(gx, P=4, flags=_lib.SC_GEMM_NO_SB)) == 0
     assert lib.modegemm_path(**dict(base, P=8)) == 0                      # forward product: lanes-are-modes kernel
-    assert lib.modegemm_path(**dict(base, Q=36)) == 1                    # ragged Tucker rank: 64-row tiles of gen 1
+    assert lib.modegemm_path(**dict(base, Q=36)) == 2                    # ragged Tucker rank: round 3, tiles filled >= 1/2 stream
+    assert lib.modegemm_path(**dict(base, Q=15)) != 2                    # 15 of 32 columns: below half a tile
     assert lib.modegemm_path(**dict(base, P=4, Q=128)) == 3              # 4 rows: neither matrix-core kernel
     assert lib.modegemm_path(**dict(base, P=4, Q=128, flags=_lib.SC_GEMM_NO_SB)) == 0
     assert lib.modegemm_path(**dict(base, P=128, Q=128, R=4)) == 3       # hidden 128 weight gradient at B = 4
