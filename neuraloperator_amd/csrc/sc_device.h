@@ -103,6 +103,19 @@ typedef hipStream_t sc_stream_t;
 #define SC_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 
+// compute units of the current device (256 on MI355X): the grid of a PERSISTENT kernel is workgroups-per-CU x this
+static inline int sc_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 #else
 // --------------------------------------------------------------------------- host emulation
 #include <cstdlib>
@@ -210,6 +223,9 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, sc_stream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+// the emulated "chip" has ONE compute unit: persistent kernels then walk several work items per workgroup in the
+// CPU tier, which is what their loops and cross-item prefetches need to be tested on
+inline int sc_cu_count() { return 1; }
 #endif
 
 // compile-time integer tag (selects a template body from a wave-uniform runtime value)

@@ -470,11 +470,18 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 // ------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------
+#ifndef SC_F3_INV_WGS
+#define SC_F3_INV_WGS 3       // persistent workgroups per compute unit
+#endif
+#ifndef SC_F3_INV_OCC
+#define SC_F3_INV_OCC 3       // register budget: waves per SIMD the allocator leaves room for
+#endif
 template <int H, typename IO, int EPI = 0>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && EPI == 0 ? 4 : 3))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && EPI == 0 ? SC_F3_INV_OCC : 3))
 k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
              int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
-             float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact, F3Shard sh) {
+             float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact, F3Shard sh,
+             int64_t n_images, int gstride) {
   constexpr int P = H / 64;
   typedef F3Lds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
@@ -489,9 +496,6 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
   const int w = SC_UNIFORM(tid >> 6);
   const int lane = tid & 63, hs = lane >> 5, lam = lane & 31;
   const int hw = w * 2 + hs;
-  const int64_t img = SC_BID_X;
-  IO* yo = y + img * (int64_t)H * SC_F2D_W;
-  const cf32* src = yhat + img * (int64_t)Mx * My;
 
   for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
   if (tid < 64) tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];
@@ -501,13 +505,6 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
     const cf32 t = tabW[(8 * tn * (tk == 0 ? 4 : tk)) & 255];
     tw2t[tid] = ctw4_make(cf_conj((tk >= 4) ? cf_rot_i(t, tn) : t));
   }
-  cf32* IN = T;
-  if (sh.rows <= 0) {
-    for (int i = tid; i < Mx * My; i += 256) IN[i] = src[i];
-  } else {
-    for (int i = tid; i < Mx * My; i += 256) IN[i] = yhat[f3_shard_index(sh, img, i, My)];
-  }
-  const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
 
   const int k1l = lam >> 2, n4 = lam & 3;
   ctw3 tw1c[8];
@@ -517,20 +514,57 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
   cf32* xb = xch + hw * 8 * SC_F3_XRS;
 
   const int cl = lane >> 3, mu = lane & 7;
-  SC_SYNC();
-  // this lane's spectrum column entries: q = mu + 8 q2  (fx = q or q - 64), scaled once
-  cf32 yh[8];
+  // Round 3, second session: PERSISTENT workgroups (images b, b + gstride, ...; the host launches THREE per compute
+  // unit).  A lane's spectrum entries -- column c = 8 w + cl, rows q = mu + 8 q2 (fx = q or q - 64) -- and the parked
+  // 33rd column come straight from global memory into registers (the block was staged through LDS before: two
+  // workgroup barriers and an exposed latency at the start of every image) and those of the NEXT image are requested
+  // as soon as the last group's column transforms have consumed this image's, i.e. they land during the last four
+  // row rounds.  Requests are unconditional (entries outside the kept block read element 0 and are zeroed when they
+  // are scaled).  Measured (MI355X, metric shape, profiles/r03s2_fft3_persistent_ab.txt): 106.9 us one image per
+  // workgroup -> 103-105 us with the register staging alone -> 99.2 us persistent at 3 workgroups per compute unit
+  // (4 per unit: 112 us, 2: 110 us) against 97 us for a pure non-temporal writer of the same bytes.
+  cf32 yh[8], y32r;
+  auto request = [&](const int64_t im) {
+    const int c = 8 * w + sc_opaque(cl);
+    const int mu_o = sc_opaque(mu), t_o = sc_opaque(tid);
+    if (sh.rows <= 0) {
+      const cf32* src = yhat + im * (int64_t)Mx * My;
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int row = f2d_fx(mu_o + 8 * q2) + Mx / 2;
+        yh[q2] = src[(row >= 0 && row < Mx && c < My) ? row * My + c : 0];
+      }
+      const int row = f2d_fx(t_o & 63) + Mx / 2;
+      y32r = src[(row >= 0 && row < Mx && 32 < My) ? row * My + 32 : 0];
+    } else {                                             // sharded spectrum (include/sc_engine.h, sc_spectrum_shards)
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int row = f2d_fx(mu_o + 8 * q2) + Mx / 2;
+        yh[q2] = yhat[f3_shard_index(sh, im, (row >= 0 && row < Mx && c < My) ? row * My + c : 0, My)];
+      }
+      const int row = f2d_fx(t_o & 63) + Mx / 2;
+      y32r = yhat[f3_shard_index(sh, im, (row >= 0 && row < Mx && 32 < My) ? row * My + 32 : 0, My)];
+    }
+  };
+  if ((int64_t)SC_BID_X < n_images) request(SC_BID_X);
+  SC_SYNC();                                             // tables
+
+#pragma unroll 1
+  for (int64_t img = SC_BID_X; img < n_images; img += gstride) {
+  IO* yo = y + img * (int64_t)H * SC_F2D_W;
+  const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
   {
-    const int c = 8 * w + cl;
+    const int c = 8 * w + sc_opaque(cl);
+    const int mu_o = sc_opaque(mu), t_o = sc_opaque(tid);
+    const float sc_c = (c == 0) ? s_dc : s_other;
 #pragma unroll
     for (int q2 = 0; q2 < 8; ++q2) {
-      const int row = f2d_fx(mu + 8 * q2) + Mx / 2;
-      const bool ok = row >= 0 && row < Mx;
-      yh[q2] = (ok && c < My) ? cf_scale(IN[row * My + c], (c == 0) ? s_dc : s_other) : cf_make(0.f, 0.f);
+      const int row = f2d_fx(mu_o + 8 * q2) + Mx / 2;
+      yh[q2] = (row >= 0 && row < Mx && c < My) ? cf_scale(yh[q2], sc_c) : cf_make(0.f, 0.f);
     }
     if (tid < 64) {                                      // 33rd column parked in LDS, indexed by q
-      const int row = f2d_fx(tid) + Mx / 2;
-      y32[tid] = (row >= 0 && row < Mx && 32 < My) ? cf_scale(IN[row * My + 32], s_other) : cf_make(0.f, 0.f);
+      const int row = f2d_fx(t_o) + Mx / 2;
+      y32[tid] = (row >= 0 && row < Mx && 32 < My) ? cf_scale(y32r, s_other) : cf_make(0.f, 0.f);
     }
   }
   SC_SYNC();
@@ -581,9 +615,14 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
   for (int a = 0; a < P; ++a) {
     // ---------------- 32 inverse column FFTs (64 points) -> T[b][c], rows h = P b + a ------------
     column(8 * w + cl, xch + (8 * w + cl) * SC_F3_CCS, a, sc_int<0>(), true);
+    if (a == P - 1) request(img + gstride < n_images ? img + gstride : img);   // next image's entries (this one's are spent)
     SC_SYNC();
     // ---------------- rows: Hermitian-extended, zero-padded C2R of packed row pairs ---------------
+#ifdef SC_F3_INV_ROLLED_R
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
     for (int r = 0; r < 4; ++r) {
       const int p = r * 8 + hw;
       // block epilogue: the round's 16 skip values are requested here and consumed ~1 us later, after the row
@@ -668,6 +707,7 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
     }
     SC_SYNC();                                          // T is rewritten by the next group
   }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -685,8 +725,11 @@ static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const 
                             int64_t n_images, float s_dc, float s_other, sc_stream_t st, int epi = 0,
                             const IO* skip = nullptr, IO* preact = nullptr, F3Shard sh = F3Shard{0, 0}) {
 #define SC_F3_INV(E)                                                                                        \
-  SC_LAUNCH((k_fft2d_inv3<H, IO, E>), dim3((unsigned)n_images), dim3(256), 0, st, yhat, y, bias, channels, \
-            (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, skip, preact, sh)
+  SC_LAUNCH((k_fft2d_inv3<H, IO, E>), dim3((unsigned)(grid < n_images ? grid : n_images)), dim3(256), 0, st, yhat, y,  \
+            bias, channels, (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, skip, preact,  \
+            sh, n_images, (int)(grid < n_images ? grid : n_images))
+  // persistent workgroups, SC_F3_INV_WGS per compute unit (3: measured best, see the kernel)
+  const int64_t grid = (int64_t)SC_F3_INV_WGS * sc_cu_count();
   if (epi == 2) SC_F3_INV(2);
   else if (epi == 1) SC_F3_INV(1);
   else SC_F3_INV(0);

@@ -24,9 +24,10 @@ int main(int argc, char** argv) {
   fft2d_upload(&owned, 256, &tW); fft2d_upload(&owned, H, &tH);
   auto fwd = [&] { hipLaunchKernelGGL((k_fft2d_fwd3<256, float>), dim3(NIMG), dim3(256), 0, 0, (const float*)x, xh,
                                       (const cf32*)tW, (const cf32*)tH, 64, 33, 1.f / 65536.f, 1.f / 65536.f, F3Shard{0, 0}); };
-  auto inv = [&] { hipLaunchKernelGGL((k_fft2d_inv3<256, float, 0>), dim3(NIMG), dim3(256), 0, 0, (const cf32*)xh, y,
+  const int IGRID = getenv("F3_INV_GRID") ? atoi(getenv("F3_INV_GRID")) : SC_F3_INV_WGS * sc_cu_count();
+  auto inv = [&] { hipLaunchKernelGGL((k_fft2d_inv3<256, float, 0>), dim3(IGRID), dim3(256), 0, 0, (const cf32*)xh, y,
                                       (const float*)bias, C, (const cf32*)tW, (const cf32*)tH, 64, 33, 1.f, 2.f,
-                                      (const float*)nullptr, (float*)nullptr, F3Shard{0, 0}); };
+                                      (const float*)nullptr, (float*)nullptr, F3Shard{0, 0}, (int64_t)NIMG, IGRID); };
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](auto f, int n) {
     hipEventRecord(e0); for (int i = 0; i < n; ++i) f(); hipEventRecord(e1); hipEventSynchronize(e1);

@@ -46,6 +46,10 @@ FAST_CASES = [
     (1, 2, 1, 128, (32, 32)),
     (1, 1, 1, 512, (10, 6)),
     (2, 1, 1, 256, (5, 7)),       # odd kept counts
+    # more images than the emulated chip holds workgroups (sc_cu_count() = 1 in emulation): the persistent kernels
+    # walk several images per workgroup with their prefetch running across them
+    (4, 2, 2, 64, (20, 16)),
+    (2, 2, 3, 128, (12, 12)),
 ]
 
 
