@@ -682,6 +682,15 @@ class EngineOps:
     def inverse_transform(self, yhat, bias, spatial, freq=None, real_col=0):
         return TransformInverseFn.apply(yhat, bias, list(spatial), self.fft_norm, self.flags, freq, real_col)
 
+    @staticmethod
+    def contract_separable(xhat, w):
+        """yhat[b, c, m] = xhat[b, c, m] w[c, m] (spectral_convolution.py:49-52): one 1 x 1 product per (channel, mode)"""
+        b, c = int(xhat.shape[0]), int(xhat.shape[1])
+        m = c
+        for k in xhat.shape[2:]:
+            m *= int(k)
+        return mode_gemm(xhat.reshape(b, 1, m), w.reshape(1, 1, m), m).reshape(xhat.shape)
+
     # one complex axis of a separable transform (the sharded dim of mpu.SpatialParallelSpectralConv):
     # x (B, L, n) complex -> (B, L, k) with kept row r reading FFT index rows[r], and its zero-padded inverse;
     # 1-d complex plans with an explicit frequency map (sc_plan_desc.freq)

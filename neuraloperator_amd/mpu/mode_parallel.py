@@ -200,10 +200,20 @@ class _ModeParallelFn(torch.autograd.Function):
 class ModeParallelSpectralConv(BaseSpectralConv):
     """SpectralConv whose first mode dim is sharded across the model-parallel group.
 
-    Constructor arguments follow SpectralConv; ``n_modes`` is fixed at construction (the
-    shard layout depends on it).  ``ops`` (tests only) replaces the local stages (an object with the
+    Constructor arguments follow SpectralConv.  ``ops`` (tests only) replaces the local stages (an object with the
     interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in (None: 4 batch chunks,
     or one piece when a rank holds a single sample).
+
+    The shard layout follows ``max_n_modes`` (= the construction-time ``n_modes``, or the explicit ``max_n_modes``
+    argument): rank p owns rows [p rows, (p + 1) rows) of the STORED weight's first mode dim.  ``n_modes`` may be
+    lowered at run time (incremental training, fno_block.py:460-464, incremental.py:183-259), the grid may be smaller
+    than the modes and ``forward(x, output_shape)`` / ``resolution_scaling_factor`` may change the resolution
+    (spectral_convolution.py:465-559): those calls take ``_forward_general`` -- the used centred sub-block of the
+    weight stays where it is stored, the kept spectrum rows travel to the ranks that own their weight rows (embedded in
+    the fixed rows-of-max wire layout, zero elsewhere), the other mode dims use the sub-block's columns -- built from the
+    autograd stages of the single-GPU layer (``agops``: engine.EngineOps) and mappings.all_to_all.  It is the
+    functional route (one copy on each side of each exchange); the copy-free pipelined route serves the full block on
+    an unchanged grid, which is what the BASELINE configs time.
 
     Weights: dense (``weight``: this rank's mode rows of the (Cin, Cout, modes...) tensor; ``separable=True``: of the
     (C, modes...) tensor, spectral_convolution.py:49-52), or ``factorization`` "tucker" / "cp" / "tt"
@@ -215,7 +225,8 @@ class ModeParallelSpectralConv(BaseSpectralConv):
 
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
                  fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=None,
-                 factorization=None, rank=0.5, separable=False, **unused):
+                 factorization=None, rank=0.5, separable=False, max_n_modes=None, resolution_scaling_factor=None,
+                 agops=None, **unused):
         super().__init__(device=device)
         if unused.get("complex_data"):
             raise NotImplementedError("complex_data=True is not supported by the mode-parallel layer")
@@ -230,10 +241,19 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         self.factorization, self.separable = fac, bool(separable)
         self.in_channels, self.out_channels = in_channels, out_channels
         self._n_modes = halve_last_mode(n_modes)
-        self.max_n_modes = list(self._n_modes)
+        # spectral_convolution.py:317-321: an explicit max_n_modes is stored UN-halved; None = the (halved) n_modes
+        self.max_n_modes = list(self._n_modes) if max_n_modes is None else [int(v) for v in max_n_modes]
         self.order = len(self._n_modes)
         if self.order < 2:
             raise NotImplementedError("mode sharding needs >= 2 spatial dims (dim 0 is sharded)")
+        if len(self.max_n_modes) != self.order or any(n > m for n, m in zip(self._n_modes, self.max_n_modes)):
+            raise ValueError(f"n_modes {self._n_modes} exceeds max_n_modes {self.max_n_modes}")
+        if resolution_scaling_factor is not None:
+            from ..spectral_conv import _validate_scaling_factor
+            resolution_scaling_factor = _validate_scaling_factor(resolution_scaling_factor, self.order)
+        self.resolution_scaling_factor = resolution_scaling_factor
+        self.engine_flags = engine_flags
+        self._agops = agops
         self.fft_norm = fft_norm
         self.group = group
         # pieces the exchange is pipelined in: None = 4 batch chunks when a rank holds >= 2 samples, ONE piece when it
@@ -243,14 +263,14 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         self.P = comm.get_model_parallel_size() if group is None else dist.get_world_size(group)
         self.rank = comm.get_model_parallel_rank() if group is None else dist.get_rank(group)
         # rows of the first mode dim per rank; k1 not divisible by P: the last rank(s) carry zero rows
-        self.rows = -(-self._n_modes[0] // self.P)
+        self.rows = -(-self.max_n_modes[0] // self.P)
         if init_std == "auto":
             init_std = (2 / (in_channels + out_channels)) ** 0.5
-        live = min(self.rows, max(0, self._n_modes[0] - self.rank * self.rows))
+        live = min(self.rows, max(0, self.max_n_modes[0] - self.rank * self.rows))
         self.core = self.cp_weights = None
         if fac == "dense":
             lead = (in_channels,) if self.separable else (in_channels, out_channels)
-            w = torch.empty(*lead, self.rows, *self._n_modes[1:], dtype=torch.cfloat, device=device)
+            w = torch.empty(*lead, self.rows, *self.max_n_modes[1:], dtype=torch.cfloat, device=device)
             w.normal_(0, init_std)
             with torch.no_grad():
                 w[(slice(None),) * len(lead) + (slice(live, None),)] = 0
@@ -262,8 +282,8 @@ class ModeParallelSpectralConv(BaseSpectralConv):
             # does (index 2) is sharded by rows like the dense weight; a rank contracts with the dense block rebuilt
             # from its shard (1 / P of the reconstruction work)
             from ..factorized import FactorList, cp_rank, tt_rank, tucker_rank
-            full_shape = [in_channels, out_channels, *self._n_modes]
-            sizes = [in_channels, out_channels, self.rows, *self._n_modes[1:]]
+            full_shape = [in_channels, out_channels, *self.max_n_modes]
+            sizes = [in_channels, out_channels, self.rows, *self.max_n_modes[1:]]
             self.weight = None
             mk = lambda *sh, std: nn.Parameter(torch.empty(*sh, dtype=torch.cfloat, device=device).normal_(0, std))
             if fac == "tucker":
@@ -305,26 +325,72 @@ class ModeParallelSpectralConv(BaseSpectralConv):
 
     @n_modes.setter
     def n_modes(self, value):
-        raise NotImplementedError("the mode-parallel layer fixes n_modes at construction (shard layout)")
+        # spectral_convolution.py:400-415; the shard layout follows max_n_modes and does not move
+        nm = halve_last_mode(value)
+        if len(nm) != self.order or any(n > m for n, m in zip(nm, self.max_n_modes)):
+            raise ValueError(f"n_modes {nm} exceeds max_n_modes {self.max_n_modes} (the stored, sharded weight)")
+        self._n_modes = nm
+
+    def _out_shape(self, spatial, output_shape):
+        if output_shape is not None:
+            return [int(v) for v in output_shape]
+        if self.resolution_scaling_factor is not None:
+            return [round(s * r) for (s, r) in zip(spatial, self.resolution_scaling_factor)]
+        return list(spatial)
 
     def transform(self, x, output_shape=None):
-        if output_shape is not None and list(output_shape) != list(x.shape[2:]):
-            raise NotImplementedError("resolution change is not supported by the mode-parallel layer")
-        return x
+        """the skip path's resize (spectral_convolution.py:383-398): purely local, every rank resizes its batch shard"""
+        spatial = list(x.shape[2:])
+        out_shape = self._out_shape(spatial, output_shape)
+        if out_shape == spatial:
+            return x
+        from ..spectral_conv import SpectralConv
+        return SpectralConv._resample(self, x, out_shape)
 
     def forward(self, x, output_shape=None):
         spatial = list(x.shape[2:])
-        if output_shape is not None and list(output_shape) != spatial:
-            raise NotImplementedError("resolution change is not supported by the mode-parallel layer")
-        kept, _ = kept_block(spatial, self._n_modes, self.max_n_modes)
-        if kept != list(self._n_modes):
-            raise ValueError(f"grid {spatial} is too small for n_modes {self._n_modes} in the mode-parallel layer")
         if x.shape[1] != self.in_channels:
             raise ValueError(f"input has {x.shape[1]} channels, the layer expects {self.in_channels}")
+        out_shape = self._out_shape(spatial, output_shape)
+        kept, w_start = kept_block(spatial, self._n_modes, self.max_n_modes)
+        if kept != list(self.max_n_modes) or out_shape != spatial:
+            return self._forward_general(x, spatial, out_shape, kept, w_start)
         w = self._dense_block()
         if self.P == 1 and not dist.is_initialized():
             return _single_rank(self, x, spatial, w)
         return _ModeParallelFn.apply(x, w, self.bias, self)
+
+    def _forward_general(self, x, spatial, out_shape, kept, w_start):
+        """Runtime-reduced ``n_modes``, a grid smaller than the modes, or a different output grid (class docstring).
+        kept / w_start: extents and first rows of the used centred sub-block of the STORED weight (modes.kept_block);
+        the synthesis map places the kept rows on the output grid with the reference's end-padding quirk
+        (modes.synthesis_freqs)."""
+        from .. import modes as _modes
+        from .mappings import all_to_all
+        ag = self._agops
+        if ag is None:
+            from ..engine import EngineOps
+            ag = self._agops = EngineOps(self.fft_norm, self.engine_flags)
+        P, rows = self.P, self.rows
+        fs, real_col = _modes.synthesis_freqs(spatial, out_shape, kept)
+        xhat = ag.forward_transform(x, kept, None)                          # (n, Cin, k1', rest')
+        w = self._dense_block()                                             # this rank's rows of the stored weight
+        lead = 1 if self.separable else 2
+        cols = tuple(slice(s0, s0 + k) for s0, k in zip(w_start[1:], kept[1:]))
+        w = w[(slice(None),) * (lead + 1) + cols]                           # sub-block columns of the other mode dims
+        if P > 1:
+            # kept row r multiplies stored weight row w_start[0] + r: it travels to the rank that owns that row
+            n = x.shape[0]
+            wire = xhat.new_zeros((n, xhat.shape[1], P * rows, *kept[1:]))
+            wire[:, :, w_start[0]:w_start[0] + kept[0]] = xhat
+            xloc = all_to_all(wire, 2, 0, self._group())                    # (P n, Cin, rows, rest')
+            yloc = ag.contract_separable(xloc, w) if self.separable else ag.contract(xloc, w.contiguous())
+            ywire = all_to_all(yloc, 0, 2, self._group())                   # (n, Cout, P rows, rest')
+            yhat = ywire[:, :, w_start[0]:w_start[0] + kept[0]].contiguous()
+        else:
+            wr = w[(slice(None),) * lead + (slice(w_start[0], w_start[0] + kept[0]),)].contiguous()
+            yhat = ag.contract_separable(xhat, wr) if self.separable else ag.contract(xhat, wr)
+        return ag.inverse_transform(yhat, self.bias, out_shape, fs, real_col)
 
     def _dense_block(self):
         """this rank's (Cin, Cout, rows, ...) block -- (C, rows, ...) when separable -- with autograd to the parameters"""

@@ -147,3 +147,59 @@ class OracleRawOps:
             xr, wr = xhat.detach().requires_grad_(True), w.detach().requires_grad_(True)
             gx, gw = torch.autograd.grad(so.contract_dense(xr, wr), (xr, wr), ghat)
         return (gx if need_x else None), (gw if need_w else None)
+
+
+class OracleAgOps:
+    """The interface of neuraloperator_amd.engine.EngineOps (autograd stages with explicit frequency maps,
+    sc_plan_desc.freq) in plain torch: what mpu.ModeParallelSpectralConv._forward_general is built from.  Default maps
+    (freq None): non-last dims row r <-> signed frequency r - k // 2, last dim column c <-> c; a synthesis map entry
+    None drops the row (neuraloperator_amd.modes.synthesis_freqs)."""
+
+    @staticmethod
+    def forward_transform(x, kept, freq=None):
+        nd = x.ndim - 2
+        spatial = list(x.shape[2:])
+        xh = torch.fft.rfftn(x, dim=list(range(-nd, 0)), norm="forward")
+        for d, k in enumerate(kept):
+            if freq is not None and freq[d] is not None:
+                ix = [int(f) for f in freq[d]]
+            elif d < nd - 1:
+                ix = [(r - k // 2) % spatial[d] for r in range(k)]
+            else:
+                ix = list(range(k))
+            xh = xh.index_select(2 + d, torch.as_tensor(ix))
+        return xh
+
+    @staticmethod
+    def contract(xhat, w):
+        return so.contract_dense(xhat, w)
+
+    @staticmethod
+    def contract_separable(xhat, w):
+        return so.contract_dense_separable(xhat, w)
+
+    @staticmethod
+    def inverse_transform(yhat, bias, spatial, freq=None, real_col=0):
+        nd = len(spatial)
+        kept = list(yhat.shape[2:])
+        full = list(spatial[:-1]) + [spatial[-1] // 2 + 1]
+        cur = yhat
+        for d in range(nd):
+            k = kept[d]
+            if freq is not None and freq[d] is not None:
+                ix = list(freq[d])
+            elif d < nd - 1:
+                ix = [(r - k // 2) % spatial[d] for r in range(k)]
+            else:
+                ix = list(range(k))
+            keep = [r for r in range(k) if ix[r] is not None]
+            src = cur.index_select(2 + d, torch.as_tensor(keep))
+            shape = list(cur.shape)
+            shape[2 + d] = full[d]
+            cur = torch.zeros(shape, dtype=cur.dtype).index_add(2 + d, torch.as_tensor([int(ix[r]) for r in keep]), src)
+        if real_col:                                   # spectral_convolution.py:552-556 on a resized grid
+            mask = torch.ones(full[-1])
+            mask[real_col] = 0.0
+            cur = torch.complex(cur.real, cur.imag * mask)
+        y = torch.fft.irfftn(cur, s=list(spatial), dim=list(range(-nd, 0)), norm="forward")
+        return y + bias if bias is not None else y

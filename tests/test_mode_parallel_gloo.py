@@ -104,6 +104,82 @@ def test_mode_parallel_world8_one_sample_per_rank(chunks):
     _run_world(8, (32, 6, 8), (32, 4, 6), 1, chunks)
 
 
+def _general_worker(rank, world, port, case, ret):
+    """runtime-reduced n_modes / grid smaller than the modes / resolution change on the sharded layer"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleAgOps, OracleRawOps
+
+    spatial, max_modes, run_modes, out_shape, separable = case
+    comm.init(model_parallel_size=world, backend="gloo")
+    mx = halve_last_mode(max_modes)
+    bl = 2
+    B, ci = bl * world, 3
+    co = ci if separable else 4
+    torch.manual_seed(0)
+    x = torch.randn(B, ci, *spatial)
+    w = torch.empty(*((ci,) if separable else (ci, co)), *mx, dtype=torch.cfloat).normal_(0, 0.4)
+    bias = torch.randn(co, *(1,) * len(spatial))
+    conv = ModeParallelSpectralConv(ci, co, max_modes, ops=OracleRawOps(mx), agops=OracleAgOps(), separable=separable)
+    conv.load_full_state_dict({"weight.tensor": w, "bias": bias})
+    if run_modes is not None:
+        conv.n_modes = run_modes                                   # fno_block.py:460-464
+        assert conv.n_modes == halve_last_mode(run_modes) and conv.max_n_modes == mx
+        with pytest.raises(ValueError):
+            conv.n_modes = [m + 2 for m in max_modes]
+        conv.n_modes = run_modes
+    xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
+    y = conv(xs, output_shape=out_shape)
+    g = torch.randn(B, co, *y.shape[2:], generator=torch.Generator().manual_seed(5))
+    y.backward(g[rank * bl:(rank + 1) * bl])
+    conv.reduce_replicated_grads()
+
+    xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yf = so.forward_torch(xf, wf, bf, conv.n_modes, mx, separable=separable, output_shape=out_shape)
+    yf.backward(g)
+    rows = -(-mx[0] // world)
+    live = min(rows, mx[0] - rank * rows)
+    md = 1 if separable else 2
+    gw_ref = wf.grad.narrow(md, rank * rows, live)
+    gw = conv.weight.grad.narrow(md, 0, live)
+    errs = dict(
+        y=so.rel_l2(y.detach().numpy(), yf.detach()[rank * bl:(rank + 1) * bl].numpy()),
+        gx=so.rel_l2(xs.grad.numpy(), xf.grad[rank * bl:(rank + 1) * bl].numpy()),
+        gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()),
+        gw=float((gw - gw_ref).abs().max() / max(float(gw_ref.abs().max()), 1e-30)),
+    )
+    # the skip path's resize is local: every rank resizes its own batch shard
+    if out_shape is not None and len(spatial) == 2:
+        t = conv.transform(xs.detach(), output_shape=out_shape)
+        assert list(t.shape[2:]) == list(out_shape)
+    ret[rank] = errs
+    comm.cleanup()
+
+
+@pytest.mark.parametrize("case", [
+    ((16, 12), (8, 8), (6, 4), None, False),       # n_modes lowered at run time: rows 1..6 of the 8 stored rows
+    ((16, 12), (8, 8), (5, 6), None, False),       # odd reduced count (python's floor on the negative slice bound)
+    ((6, 6), (8, 8), None, None, False),           # grid smaller than the modes
+    ((16, 12), (8, 6), None, (24, 20), False),     # finer output grid (the reference's end-padding placement)
+    ((16, 12), (8, 6), (6, 6), (12, 8), False),    # fewer modes AND a coarser output grid
+    ((8, 8, 6), (4, 4, 4), (2, 4, 4), None, False),
+    ((16, 12), (8, 6), (6, 4), None, True),        # separable weights
+], ids=["m8_to_6x4", "m8_to_5x6", "grid_smaller", "finer_out", "fewer_modes_coarser_out", "3d", "separable"])
+def test_mode_parallel_general_path_matches_single_process(case):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_general_worker, args=(2, port, case, ret), nprocs=2, join=True)
+    assert len(ret) == 2
+    for rank, errs in ret.items():
+        for k, v in errs.items():
+            assert np.isfinite(v) and v < 1e-5, (rank, k, v)
+
+
 def _run_world(world, spatial, modes, bl, chunks):
     port = _free_port()
     mgr = mp.Manager()
