@@ -224,6 +224,30 @@ size_t sc_tucker_modes_workspace_bytes(const sc_tucker_desc* d);
 int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* core, const float* ux, const float* uy,
                              const float* gt, float* gcore, float* gux, float* guy, void* workspace, void* stream);
 
+/* ---- activation side of the factorized Tucker contraction, ONE call each way (round 3, session 2) -----------------
+ *   z[b, f, m] = sum_i xhat[b, i, m] u_in[i, f];   t[b, g, m] = sum_f z[b, f, m] t3[f, g, m];
+ *   yhat[b, o, m] = sum_g t[b, g, m] u_out[o, g]
+ * -- the pairwise order of _contract_tucker's einsum 'abcd,fghi,bf,eg,ch,di->aecd' (neuralop/layers/
+ * spectral_convolution.py:76-103; t3 = the core with the mode factors absorbed, sc_tucker_modes_forward) and the six
+ * products of its autograd.  The launches are exactly those of the corresponding sc_modegemm / sc_modegemm_msum_ws
+ * calls (same kernels, same bits); the point is the HOST: a factorized layer step issued call by call from Python
+ * costs 0.6-0.76 ms of host time for 0.76 ms of device time (profiles/r03s2_tfno_host.txt), one call per direction
+ * takes the 9 products off the interpreter.  All arrays complex64 interleaved, contiguous: xhat (B, Cin, M),
+ * u_in (Cin, R1), t3 (R1, R2, M), u_out (Cout, R2), z (B, R1, M), t (B, R2, M), yhat (B, Cout, M).
+ * Backward: gy (B, Cout, M) in; gxhat (B, Cin, M), gu_in (Cin, R1), gt3 (R1, R2, M), gu_out (Cout, R2) overwritten
+ * (a null pointer skips that gradient); workspace: sc_tucker_chain_workspace_bytes (holds gt, gz and the partial
+ * sums of the two factor gradients). */
+typedef struct sc_tucker_chain_desc {
+  int64_t batch, c_in, c_out, r_in, r_out, n_modes;
+} sc_tucker_chain_desc;
+int sc_tucker_chain_forward(const sc_tucker_chain_desc* d, const float* xhat, const float* u_in, const float* t3,
+                            const float* u_out, float* z, float* t, float* yhat, void* stream);
+size_t sc_tucker_chain_workspace_bytes(const sc_tucker_chain_desc* d);
+int sc_tucker_chain_backward(const sc_tucker_chain_desc* d, const float* xhat, const float* u_in, const float* t3,
+                             const float* u_out, const float* z, const float* t, const float* gy, float* gxhat,
+                             float* gu_in, float* gt3, float* gu_out, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ---- pointwise half of an FNO block in one pass ("next" row f1 of SURVEY.md section 8) -------------------
  *   out = act( W2 gelu(W1 x + b1) + b2 + gate (.) skip_src )
  * replaces ChannelMLP.forward (neuralop/layers/channel_mlp.py:82-119: two Conv1d with kernel size 1 and a GELU),

@@ -86,6 +86,11 @@ class TuckerDesc(Structure):
     _fields_ = [("fg", c_int64), ("rx", c_int64), ("ry", c_int64), ("mx", c_int64), ("my", c_int64)]
 
 
+class TuckerChainDesc(Structure):
+    _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("r_in", c_int64), ("r_out", c_int64),
+                ("n_modes", c_int64)]
+
+
 class PlinDesc(Structure):
     _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("spatial", c_int64)]
 
@@ -146,7 +151,8 @@ class ScEngineLib:
                "sc_pointwise_mlp_backward_ex", "sc_tucker_modes_supported", "sc_tucker_modes_forward",
                "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes", "sc_modegemm_pair",
                "sc_modegemm_pair_fused", "sc_plan_workspace_bytes_sharded", "sc_transform_forward_sharded",
-               "sc_transform_inverse_sharded", "sc_bias_grad_sharded"]
+               "sc_transform_inverse_sharded", "sc_bias_grad_sharded", "sc_tucker_chain_forward",
+               "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -243,6 +249,12 @@ class ScEngineLib:
         L.sc_tucker_modes_workspace_bytes.restype = c_size_t
         L.sc_tucker_modes_backward.argtypes = [POINTER(TuckerDesc)] + [c_void_p] * 9
         L.sc_tucker_modes_backward.restype = c_int
+        L.sc_tucker_chain_forward.argtypes = [POINTER(TuckerChainDesc)] + [c_void_p] * 8
+        L.sc_tucker_chain_forward.restype = c_int
+        L.sc_tucker_chain_workspace_bytes.argtypes = [POINTER(TuckerChainDesc)]
+        L.sc_tucker_chain_workspace_bytes.restype = c_size_t
+        L.sc_tucker_chain_backward.argtypes = [POINTER(TuckerChainDesc)] + [c_void_p] * 12 + [c_size_t, c_void_p]
+        L.sc_tucker_chain_backward.restype = c_int
         L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.sc_round_f16.restype = c_int
         L.sc_last_error.restype = c_char_p
@@ -395,6 +407,18 @@ class ScEngineLib:
     def tucker_modes_backward(self, fg, rx, ry, mx, my, core, ux, uy, gt, gcore, gux, guy, ws, stream=0):
         self._check(self.lib.sc_tucker_modes_backward(byref(TuckerDesc(fg, rx, ry, mx, my)), core, ux, uy, gt, gcore, gux,
                                                       guy, ws, stream))
+
+    def tucker_chain_forward(self, dims, xhat, u_in, t3, u_out, z, t, yhat, stream=0):
+        """dims = (batch, c_in, c_out, r_in, r_out, n_modes); device pointers of contiguous complex64 arrays"""
+        self._check(self.lib.sc_tucker_chain_forward(byref(TuckerChainDesc(*dims)), xhat, u_in, t3, u_out, z, t, yhat, stream))
+
+    def tucker_chain_workspace_bytes(self, dims):
+        return int(self.lib.sc_tucker_chain_workspace_bytes(byref(TuckerChainDesc(*dims))))
+
+    def tucker_chain_backward(self, dims, xhat, u_in, t3, u_out, z, t, gy, gxhat, gu_in, gt3, gu_out, ws, ws_bytes, stream=0):
+        """null (0) gradient pointers skip that gradient"""
+        self._check(self.lib.sc_tucker_chain_backward(byref(TuckerChainDesc(*dims)), xhat, u_in, t3, u_out, z, t, gy, gxhat,
+                                                      gu_in, gt3, gu_out, ws, ws_bytes, stream))
 
     def round_f16(self, in_ptr, out_ptr, n, stream=0):
         """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""

@@ -1912,6 +1912,115 @@ extern "C" int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, co
 }
 
 // ------------------------------------------------------------------------------------------
+// activation side of the factorized Tucker contraction: the nine products of a layer step from TWO host calls
+// (include/sc_engine.h; the launches are those of the corresponding sc_modegemm / sc_modegemm_msum_ws calls)
+// ------------------------------------------------------------------------------------------
+static sc_modegemm_desc tkc_desc(int64_t P, int64_t Q, int64_t R, int64_t M, int64_t a_sp, int64_t a_sr, int64_t a_sm,
+                                 int64_t b_sr, int64_t b_sq, int64_t b_sm, int64_t c_sp, int64_t c_sq, int64_t c_sm,
+                                 int conj_a, int conj_b) {
+  sc_modegemm_desc d;
+  std::memset(&d, 0, sizeof(d));
+  d.P = P; d.Q = Q; d.R = R; d.n_modes = M;
+  d.a_sp = a_sp; d.a_sr = a_sr; d.a_sm = a_sm;
+  d.b_sr = b_sr; d.b_sq = b_sq; d.b_sm = b_sm;
+  d.c_sp = c_sp; d.c_sq = c_sq; d.c_sm = c_sm;
+  d.conj_a = conj_a; d.conj_b = conj_b;
+  return d;
+}
+// the two factor gradients: C[p, q] = sum_{m, r} conj(A[p, r, m]) B[r, q, m]
+static sc_modegemm_desc tkc_gu_in_desc(const sc_tucker_chain_desc* c) {      // gu_in[i, f] <- xhat^H gz
+  const int64_t M = c->n_modes;
+  return tkc_desc(c->c_in, c->r_in, c->batch, M, M, c->c_in * M, 1, c->r_in * M, M, 1, c->r_in, 1, 0, 1, 0);
+}
+static sc_modegemm_desc tkc_gu_out_desc(const sc_tucker_chain_desc* c) {     // gu_out[o, g] <- (t^H gy)[g, o]
+  const int64_t M = c->n_modes;
+  return tkc_desc(c->r_out, c->c_out, c->batch, M, M, c->r_out * M, 1, c->c_out * M, M, 1, 1, c->r_out, 0, 1, 0);
+}
+static size_t tkc_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static bool tkc_valid(const sc_tucker_chain_desc* d) {
+  return d && d->batch > 0 && d->c_in > 0 && d->c_out > 0 && d->r_in > 0 && d->r_out > 0 && d->n_modes > 0;
+}
+
+extern "C" int sc_tucker_chain_forward(const sc_tucker_chain_desc* c, const float* xhat, const float* u_in,
+                                       const float* t3, const float* u_out, float* z, float* t, float* yhat,
+                                       void* stream) {
+  SC_CHECK_ARG(tkc_valid(c), "sc_tucker_chain: null or empty descriptor");
+  SC_CHECK_ARG(xhat && u_in && t3 && u_out && z && t && yhat, "null argument");
+  const int64_t B = c->batch, Ci = c->c_in, Co = c->c_out, R1 = c->r_in, R2 = c->r_out, M = c->n_modes;
+  // z = xhat u_in (mode-independent right operand)
+  sc_modegemm_desc d = tkc_desc(B, R1, Ci, M, Ci * M, M, 1, R1, 1, 0, R1 * M, M, 1, 0, 0);
+  int rc = sc_modegemm(&d, xhat, u_in, z, stream);
+  if (rc) return rc;
+  // t = z t3 (per-mode R1 x R2 products)
+  d = tkc_desc(B, R2, R1, M, R1 * M, M, 1, R2 * M, M, 1, R2 * M, M, 1, 0, 0);
+  rc = sc_modegemm(&d, z, t3, t, stream);
+  if (rc) return rc;
+  // yhat = t u_out^T
+  d = tkc_desc(B, Co, R2, M, R2 * M, M, 1, 1, R2, 0, Co * M, M, 1, 0, 0);
+  return sc_modegemm(&d, t, u_out, yhat, stream);
+}
+
+extern "C" size_t sc_tucker_chain_workspace_bytes(const sc_tucker_chain_desc* c) {
+  if (!tkc_valid(c)) return 0;
+  const sc_modegemm_desc di = tkc_gu_in_desc(c), dout = tkc_gu_out_desc(c);
+  const size_t wi = sc_modegemm_msum_workspace_bytes(&di), wo = sc_modegemm_msum_workspace_bytes(&dout);
+  return tkc_align((size_t)c->batch * c->r_out * c->n_modes * sizeof(cf32)) +
+         tkc_align((size_t)c->batch * c->r_in * c->n_modes * sizeof(cf32)) + tkc_align(wi > wo ? wi : wo) + 512;
+}
+
+// one factor gradient: the matrix-core kernel with its fixed-order reduction where it qualifies, else zero fill +
+// the atomic-add kernel
+static int tkc_factor_grad(const sc_modegemm_desc* d, const float* A, const float* B, float* C, int64_t c_elems,
+                           void* ws, size_t ws_bytes, void* stream) {
+  const size_t need = sc_modegemm_msum_workspace_bytes(d);
+  if (need && need <= ws_bytes) return sc_modegemm_msum_ws(d, A, B, C, ws, ws_bytes, stream);
+  if (hipMemsetAsync(C, 0, (size_t)c_elems * sizeof(cf32), (sc_stream_t)stream) != hipSuccess)
+    return sc_fail("sc_tucker_chain_backward: hipMemsetAsync failed");
+  return sc_modegemm_msum(d, A, B, C, stream);
+}
+
+extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const float* xhat, const float* u_in,
+                                        const float* t3, const float* u_out, const float* z, const float* t,
+                                        const float* gy, float* gxhat, float* gu_in, float* gt3, float* gu_out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  SC_CHECK_ARG(tkc_valid(c), "sc_tucker_chain: null or empty descriptor");
+  SC_CHECK_ARG(xhat && u_in && t3 && u_out && z && t && gy && workspace, "null argument");
+  SC_CHECK_ARG(workspace_bytes >= sc_tucker_chain_workspace_bytes(c), "workspace too small");
+  const int64_t B = c->batch, Ci = c->c_in, Co = c->c_out, R1 = c->r_in, R2 = c->r_out, M = c->n_modes;
+  unsigned char* w0 = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float* gt = (float*)w0;
+  float* gz = (float*)(w0 + tkc_align((size_t)B * R2 * M * sizeof(cf32)));
+  unsigned char* wred = (unsigned char*)gz + tkc_align((size_t)B * R1 * M * sizeof(cf32));
+  const size_t wred_bytes = workspace_bytes - (size_t)(wred - (unsigned char*)workspace);
+  int rc;
+  // yhat = t u_out^T:  gt = gy conj(u_out);  gu_out[o, g] = sum_{b, m} conj(t[b, g, m]) gy[b, o, m]
+  sc_modegemm_desc d = tkc_desc(B, R2, Co, M, Co * M, M, 1, R2, 1, 0, R2 * M, M, 1, 0, 1);
+  if ((rc = sc_modegemm(&d, gy, u_out, gt, stream))) return rc;
+  if (gu_out) {
+    d = tkc_gu_out_desc(c);
+    if ((rc = tkc_factor_grad(&d, t, gy, gu_out, Co * R2, wred, wred_bytes, stream))) return rc;
+  }
+  // t = z t3:  gz = gt t3^H;  gt3[f, g, m] = sum_b conj(z[b, f, m]) gt[b, g, m]
+  d = tkc_desc(B, R1, R2, M, R2 * M, M, 1, M, R2 * M, 1, R1 * M, M, 1, 0, 1);
+  if ((rc = sc_modegemm(&d, gt, t3, gz, stream))) return rc;
+  if (gt3) {
+    d = tkc_desc(R1, R2, B, M, M, R1 * M, 1, R2 * M, M, 1, R2 * M, M, 1, 1, 0);
+    if ((rc = sc_modegemm(&d, z, gt, gt3, stream))) return rc;
+  }
+  // z = xhat u_in:  gxhat = gz u_in^H;  gu_in[i, f] = sum_{b, m} conj(xhat[b, i, m]) gz[b, f, m]
+  if (gxhat) {
+    d = tkc_desc(B, Ci, R1, M, R1 * M, M, 1, 1, R1, 0, Ci * M, M, 1, 0, 1);
+    if ((rc = sc_modegemm(&d, gz, u_in, gxhat, stream))) return rc;
+  }
+  if (gu_in) {
+    d = tkc_gu_in_desc(c);
+    if ((rc = tkc_factor_grad(&d, xhat, gz, gu_in, Ci * R1, wred, wred_bytes, stream))) return rc;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // pointwise MLP of an FNO block (sc_kernels_pmlp.h)
 // ------------------------------------------------------------------------------------------
 template <int CI, int CH, int CO>

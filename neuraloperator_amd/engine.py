@@ -103,7 +103,12 @@ def _destroy_plans():
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's current stream: torch.cuda.current_stream().cuda_stream builds a Stream object per call
+    # (~12 us of host time, four to a dozen calls per layer step)
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:                                      # a torch build without the private accessor
+        return torch.cuda.current_stream().cuda_stream
 
 
 def _ws(nbytes, device):
@@ -604,35 +609,60 @@ class TuckerChainFn(torch.autograd.Function):
     (the pairwise order of _forward_tucker, spectral_convolution.py:76-103) -- the same launches as three ModeGemmFn
     nodes, but a step of this layer is ~30 launches of 20-100 us each and the host needs about as long to walk four
     autograd nodes and their views as the device needs to run them (scripts/tfno_cpu_bound.py: 0.62 ms to issue a
-    0.77 ms step).  Backward: the six products of the three nodes, in the order their gradients are needed."""
+    0.77 ms step).  Session 2: ONE C-ABI call per direction (sc_tucker_chain_forward / _backward) issues the three /
+    six products from C++.  Backward: the six products of the three nodes, in the order their gradients are needed."""
 
     @staticmethod
     def forward(ctx, xhat, u_in, t3, u_out):
         _require_gpu(xhat, "xhat")
-        c64 = lambda v: v if v.dtype == torch.complex64 else v.to(torch.complex64)
+        c64 = lambda v: (v if v.dtype == torch.complex64 else v.to(torch.complex64)).contiguous()
         xhat, u_in, t3, u_out = c64(xhat), c64(u_in), c64(t3), c64(u_out)
-        m = int(xhat.shape[2])
-        z = _raw_mode_gemm(xhat, u_in, m, False, False)
-        t = _raw_mode_gemm(z, t3, m, False, False)
-        yhat = _raw_mode_gemm(t, u_out.transpose(0, 1), m, False, False)
+        b, ci, m = (int(v) for v in xhat.shape)
+        r1, r2, co = int(u_in.shape[1]), int(u_out.shape[1]), int(u_out.shape[0])
+        if tuple(t3.shape) != (r1, r2, m) or int(u_in.shape[0]) != ci:
+            raise ValueError(f"tucker_chain: xhat {tuple(xhat.shape)} u_in {tuple(u_in.shape)} t3 {tuple(t3.shape)} "
+                             f"u_out {tuple(u_out.shape)} do not chain")
+        dev = xhat.device
+        z = torch.empty((b, r1, m), dtype=torch.complex64, device=dev)
+        t = torch.empty((b, r2, m), dtype=torch.complex64, device=dev)
+        yhat = torch.empty((b, co, m), dtype=torch.complex64, device=dev)
+        ctx.dims = (b, ci, co, r1, r2, m)
+        if b and m:
+            # ONE host call for the three products (round 3, session 2: sc_tucker_chain_forward issues the same three
+            # sc_modegemm launches from C++; a factorized step was ~0.6-0.76 ms of interpreter time per 0.76 ms of device time)
+            with torch.cuda.device(dev):
+                _lib.get_lib().tucker_chain_forward(ctx.dims, xhat.data_ptr(), u_in.data_ptr(), t3.data_ptr(), u_out.data_ptr(),
+                                                    z.data_ptr(), t.data_ptr(), yhat.data_ptr(), _stream())
         ctx.save_for_backward(xhat, u_in, t3, u_out, z, t)
         return yhat
 
     @staticmethod
     def backward(ctx, gy):
         xhat, u_in, t3, u_out, z, t = ctx.saved_tensors
-        m = int(xhat.shape[2])
-        gy = gy.contiguous()
+        b, ci, co, r1, r2, m = ctx.dims
+        gy = (gy if gy.dtype == torch.complex64 else gy.to(torch.complex64)).contiguous()
         need = ctx.needs_input_grad
-        # yhat = t U_out^T:  gt = gy conj(U_out);  g(U_out^T)[g,o] = sum_{b,m} conj(t[b,g,m]) gy[b,o,m]
-        gt = _raw_mode_gemm(gy, u_out, m, False, True)
-        gu_out = _raw_mode_gemm(t.transpose(0, 1), gy, m, True, False, reduce_modes=True).transpose(0, 1) if need[3] else None
-        # t = z T:  gz = gt T^H;  gT[f,g,m] = sum_b conj(z[b,f,m]) gt[b,g,m]
-        gz = _raw_mode_gemm(gt, t3.transpose(0, 1), m, False, True)
-        gt3 = _raw_mode_gemm(z.transpose(0, 1), gt, m, True, False) if need[2] else None
-        # z = xhat U_in:  gxhat = gz U_in^H;  gU_in[i,f] = sum_{b,m} conj(xhat[b,i,m]) gz[b,f,m]
-        gx = _raw_mode_gemm(gz, u_in.transpose(0, 1), m, False, True) if need[0] else None
-        gu_in = _raw_mode_gemm(xhat.transpose(0, 1), gz, m, True, False, reduce_modes=True) if need[1] else None
+        dev = xhat.device
+        new = lambda *sh: torch.empty(sh, dtype=torch.complex64, device=dev)
+        gx = new(b, ci, m) if need[0] else None
+        gu_in = new(ci, r1) if need[1] else None
+        gt3 = new(r1, r2, m) if need[2] else None
+        gu_out = new(co, r2) if need[3] else None
+        if b and m:
+            lib = _lib.get_lib()
+            p = lambda v: 0 if v is None else v.data_ptr()
+            with torch.cuda.device(dev):
+                nb = lib.tucker_chain_workspace_bytes(ctx.dims)
+                ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                # the six products of the three steps, in the order their gradients are needed: gt = gy conj(U_out),
+                # gU_out = sum t^H gy, gz = gt T^H, gT = z^H gt, gxhat = gz U_in^H, gU_in = sum xhat^H gz
+                lib.tucker_chain_backward(ctx.dims, xhat.data_ptr(), u_in.data_ptr(), t3.data_ptr(), u_out.data_ptr(),
+                                          z.data_ptr(), t.data_ptr(), gy.data_ptr(), p(gx), p(gu_in), p(gt3), p(gu_out),
+                                          ws.data_ptr(), nb, _stream())
+        else:
+            for v in (gx, gu_in, gt3, gu_out):
+                if v is not None:
+                    v.zero_()
         return gx, gu_in, gt3, gu_out
 
 

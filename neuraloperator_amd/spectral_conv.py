@@ -277,6 +277,8 @@ class SpectralConv(BaseSpectralConv):
     # ---- Tucker weights on the engine -----------------------------------------------------------
     def _used_block(self, spatial):
         kept, w_start = kept_block(spatial, list(self.n_modes), list(self.max_n_modes))
+        if not any(w_start) and list(kept) == [int(v) for v in self.max_n_modes]:
+            return kept, self.weight                        # the whole stored block: nothing to slice (host time)
         lead = (slice(None),) if self.separable else (slice(None), slice(None))       # :471-474
         idx = lead + tuple(slice(s0, s0 + k) for s0, k in zip(w_start, kept))
         return kept, self.weight[idx]                       # factors row-sliced to the used block
