@@ -166,7 +166,11 @@ int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float
  * (conj_a, autograd of spectral_convolution.py:21-46 w.r.t. the weight), d1 the gradient of the spectrum (conj_b) --
  * runs as ONE launch of k_modegemm_dma_bwd when both qualify for the streamed matrix-core kernel: the second round of
  * one job fills the tail of the other.  sc_modegemm_pair_fused: 1 if a pair with 16-byte aligned operands takes that
- * launch, 0 if it runs as two. */
+ * launch, 0 if it runs as two.
+ * Round 3, session 2: a SMALL-BATCH pair (d0->R = d1->P <= 4 rows against weight-sized d0's C / d1's B, B0 and A1 the
+ * same array; BASELINE configs[4]) runs as ONE launch of k_modegemm_sb_bwd (sc_kernels_sb.h): a single pass over the
+ * weight serves both gradients (the weight is read while its gradient is written), bit-identical to the two
+ * k_modegemm_sb launches it replaces; sc_layer_backward takes the same launch. */
 int sc_modegemm_pair(const sc_modegemm_desc* d0, const float* A0, const float* B0, float* C0,
                      const sc_modegemm_desc* d1, const float* A1, const float* B1, float* C1, void* stream);
 int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1);

@@ -1367,6 +1367,55 @@ static int run_sb_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, 
   return wm4 ? run_sb_gemm_t<4, 4, 2, 4, 1, 1>(d, A, B, C, st) : run_sb_gemm_t<4, 4, 2, 1, 2, 2>(d, A, B, C, st);
 }
 
+// ---- the two contractions of a small-batch backward pass in one pass over the weight (sc_kernels_sb.h,
+//      k_modegemm_sb_bwd): d0 = weight gradient (conj A: xhat^H ghat), d1 = gradient of the spectrum (conj B: ghat W^H),
+//      both operands named ghat the SAME array.  Returns -1 when the pair does not qualify.
+template <int BT>
+static int run_sb_bwd_t(const SbBwdArgs& g, const cf32* xhat, const cf32* ghat, const cf32* W, cf32* gW, cf32* gxhat,
+                        sc_stream_t st) {
+  SC_LAUNCH((k_modegemm_sb_bwd<BT, 4, 2>), dim3((unsigned)(8 * g.per_xcd)), dim3(SC_BLOCK), 0, st, g, xhat, ghat, W, gW,
+            gxhat);
+  return sc_check_launch("k_modegemm_sb_bwd");
+}
+
+static bool sb_bwd_eligible(const sc_modegemm_desc* d0, const void* A0, const void* B0, const void* C0,
+                            const sc_modegemm_desc* d1, const void* A1, const void* B1, const void* C1) {
+  static const bool off = std::getenv("SC_SB_NO_PAIR") != nullptr;                     // A-B
+  if (off) return false;
+  if (!sb_gemm_eligible(d0, A0, B0, C0) || !sb_gemm_eligible(d1, A1, B1, C1)) return false;
+  if (!(d0->conj_a && !d0->conj_b && !d1->conj_a && d1->conj_b)) return false;
+  if (B0 != A1 || d0->b_sr != d1->a_sp || d0->b_sq != d1->a_sr) return false;          // one ghat[b, o, m]
+  if (d0->n_modes != d1->n_modes || d0->R != d1->P || d0->P != d1->Q || d0->Q != d1->R) return false;
+  if (d0->R < 1 || d0->R > 4 || d0->R > sb_max_extent()) return false;                // the batch lives in registers
+  // the weight-sized arrays must dominate: otherwise the separate launches (more, smaller work items) fill the chip better
+  return d0->P * d0->Q >= 64 * d0->R;
+}
+
+static int run_sb_bwd(const sc_modegemm_desc* d0, const cf32* A0, const cf32* B0, cf32* C0,
+                      const sc_modegemm_desc* d1, const cf32* A1, const cf32* B1, cf32* C1, sc_stream_t st) {
+  if (!sb_bwd_eligible(d0, A0, B0, C0, d1, A1, B1, C1)) return -1;
+  SbBwdArgs g;
+  g.B = d0->R; g.Ci = d0->P; g.Co = d0->Q; g.M = d0->n_modes;
+  g.x_si = d0->a_sp; g.x_sb = d0->a_sr;
+  g.g_sb = d0->b_sr; g.g_so = d0->b_sq;
+  g.gw_si = d0->c_sp; g.gw_so = d0->c_sq;
+  g.w_so = d1->b_sr; g.w_si = d1->b_sq;
+  g.gx_sb = d1->c_sp; g.gx_si = d1->c_sq;
+  g.n_mt = (int)((g.M + 127) / 128);
+  g.n_itg = (int)(((g.Ci + 3) / 4 + 3) / 4);
+  const int64_t total = (int64_t)g.n_mt * g.n_itg;
+  if (total >= ((int64_t)1 << 30)) return -1;
+  g.per_xcd = (int)((total + 7) / 8);
+  static const bool plain_c = std::getenv("SC_SB_PLAIN_C") != nullptr;                 // A-B
+  g.nt_gw = (d0->flags & SC_GEMM_STREAM_C) && !plain_c ? 1 : 0;
+  switch (g.B) {
+    case 1: return run_sb_bwd_t<1>(g, A0, B0, B1, C0, C1, st);
+    case 2: return run_sb_bwd_t<2>(g, A0, B0, B1, C0, C1, st);
+    case 3: return run_sb_bwd_t<3>(g, A0, B0, B1, C0, C1, st);
+    default: return run_sb_bwd_t<4>(g, A0, B0, B1, C0, C1, st);
+  }
+}
+
 // ---- mode-independent right operand (sc_kernels_sb.h, k_modegemm_bfac): factor matrices through the scalar cache
 static bool bfac_gemm_eligible(const sc_modegemm_desc* d) {
   if (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_SB)) return false;
@@ -1793,8 +1842,11 @@ extern "C" int sc_modegemm_pair(const sc_modegemm_desc* d0, const float* A0, con
   if (d0->P > 0 && d0->Q > 0 && d0->R > 0 && d0->n_modes > 0 && d1->P > 0 && d1->Q > 0 && d1->R > 0) {
     Gemm8Bias nobias;
     std::memset(&nobias, 0, sizeof(nobias));
-    const int rc = run_gemm8_bwd(d0, (const cf32*)A0, (const cf32*)B0, (cf32*)C0, d1, (const cf32*)A1,
-                                 (const cf32*)B1, (cf32*)C1, nobias, (sc_stream_t)stream);
+    int rc = run_sb_bwd(d0, (const cf32*)A0, (const cf32*)B0, (cf32*)C0, d1, (const cf32*)A1, (const cf32*)B1, (cf32*)C1,
+                        (sc_stream_t)stream);
+    if (rc >= 0) return rc;
+    rc = run_gemm8_bwd(d0, (const cf32*)A0, (const cf32*)B0, (cf32*)C0, d1, (const cf32*)A1,
+                       (const cf32*)B1, (cf32*)C1, nobias, (sc_stream_t)stream);
     if (rc >= 0) return rc;
   }
   const int rc = sc_modegemm(d0, A0, B0, C0, stream);
@@ -2648,7 +2700,20 @@ extern "C" int sc_layer_backward_ex(const sc_plan* p, const sc_layer_desc* L, co
   dx.c_sp = Ci * Mk; dx.c_sq = Mk; dx.c_sm = 1;
   dx.flags = gflags;
   bool paired = false;
-  if (gw && gx && (!gbias || p->dc_index >= 0)) {
+  if (gw && gx && !idx) {
+    // small batch against a large weight (BASELINE configs[4]): ONE pass over W for both gradients
+    rc = run_sb_bwd(&dw, (const cf32*)xhat_saved, (const cf32*)ghat, (cf32*)gw, &dx, (const cf32*)ghat, (const cf32*)w,
+                    (cf32*)gxhat, (sc_stream_t)stream);
+    if (rc > 0) return rc;
+    if (rc == 0) {
+      paired = true;
+      if (gbias) {
+        rc = sc_bias_grad(p, ghat, B, Co, gbias, stream);
+        if (rc) return rc;
+      }
+    }
+  }
+  if (!paired && gw && gx && (!gbias || p->dc_index >= 0)) {
     Gemm8Bias gb;
     gb.ghat = gbias ? (const cf32*)ghat : nullptr;
     gb.gbias = gbias; gb.batch = B; gb.channels = Co; gb.modes_per_image = Mk; gb.dc = p->dc_index;

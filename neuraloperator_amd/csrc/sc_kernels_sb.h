@@ -154,6 +154,113 @@ k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__
 
 
 // ------------------------------------------------------------------------------------------
+// The two contractions of a SMALL-BATCH backward pass in ONE pass over the weight (round 3, session 2):
+//   gW[i, o, m]    = sum_b conj(xhat[b, i, m]) ghat[b, o, m]          (weight-sized result)
+//   gxhat[b, i, m] = sum_o ghat[b, o, m] conj(W[i, o, m])             (weight-sized operand)
+// BASELINE configs[4] (B = 4, 128 x 128 channels, 33 024 modes: W and gW are 4.33 GB each): as two launches of
+// k_modegemm_sb the pair takes 1.20 + 1.39 ms -- per reduction step the spectrum gradient loads 4 weight + 4 ghat
+// values per lane, the weight gradient 32 operand values per 16 stored ones, all of the small operands re-read from
+// L2 by every tile.  Here a wave owns IT weight rows i (and 128 modes, two per lane), keeps xhat[b, i, .] and the
+// gxhat accumulators in registers and walks o ONCE: per step it loads W[i, o, .] (IT values, streamed) and
+// ghat[b, o, .] (BT values, shared by the four waves of the workgroup through L1 and by the workgroups of a mode
+// tile through their XCD's L2), adds ghat conj(W) into the accumulators and stores gW[i, o, .] = sum_b conj(xhat)
+// ghat -- 8 loads and 4 stores where the two launches issue 16 loads and 4 stores, and the weight is read while its
+// gradient is written (a copy-shaped stream).  Same fmaf chains as k_modegemm_sb (o-ordered / b-ordered): both
+// results are bit-identical to the two launches.
+// ------------------------------------------------------------------------------------------
+struct SbBwdArgs {
+  int64_t B, Ci, Co, M;
+  int64_t x_sb, x_si;          // xhat[b, i, m]   (complex elements; mode stride 1 everywhere)
+  int64_t g_sb, g_so;          // ghat[b, o, m]
+  int64_t w_si, w_so;          // W[i, o, m]
+  int64_t gw_si, gw_so;        // gW[i, o, m]
+  int64_t gx_sb, gx_si;        // gxhat[b, i, m]
+  int n_mt, n_itg, per_xcd;    // mode tiles of 128, groups of 4 row tiles
+  int nt_gw;                   // non-temporal stores for gW (not read by the next kernel)
+};
+
+template <int BT, int IT, int ST>
+SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
+k_modegemm_sb_bwd(SbBwdArgs g, const cf32* __restrict__ xhat, const cf32* __restrict__ ghat, const cf32* __restrict__ W,
+                  cf32* __restrict__ gW, cf32* __restrict__ gxhat) {
+  const int tid = SC_TID, lane = tid & 63;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int bid = SC_BID_X;
+  const int64_t item = (int64_t)(bid & 7) * g.per_xcd + (bid >> 3);
+  if (item >= (int64_t)g.n_mt * g.n_itg) return;
+  const int mt = (int)(item / g.n_itg);
+  const int64_t i0 = ((item - (int64_t)mt * g.n_itg) * 4 + w) * IT;
+  if (i0 >= g.Ci) return;                                              // whole wave idle (no barriers in this kernel)
+  const int64_t m = ((int64_t)mt * 64 + lane) * 2;                     // first of this lane's two modes
+  const bool active = m < g.M;
+  const int64_t mm = active ? m : g.M - 2;
+
+  // rows / modes past the end are CLAMPED, loads and stores alike: such a lane recomputes -- from the same inputs --
+  // and stores again exactly what the owner of the clamped element stores, so every access of the loop is
+  // unconditional (behind a branch the compiler could no longer count the ring's loads in flight)
+  const cf32* Wp[IT];
+  cf32* GWp[IT];
+  const cf32* Gp[BT];
+  sc_f4 xh[BT][IT], acc[BT][IT];
+#pragma unroll
+  for (int ii = 0; ii < IT; ++ii) {
+    const int64_t i = (i0 + ii < g.Ci) ? i0 + ii : g.Ci - 1;
+    Wp[ii] = W + i * g.w_si + mm;
+    GWp[ii] = gW + i * g.gw_si + mm;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      xh[b][ii] = sb_load(xhat + b * g.x_sb + i * g.x_si + mm, 0);
+      acc[b][ii] = sc_f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < BT; ++b) Gp[b] = ghat + b * g.g_sb + mm;
+
+  // ring of ST steps over o (see k_modegemm_sb: no uniform branch around a load; steps past the end re-read the last)
+  sc_f4 rw[ST][IT], rg[ST][BT];
+  auto request = [&](const int64_t o, sc_f4 (&wv)[IT], sc_f4 (&gv)[BT]) {
+    const int64_t oo = o < g.Co ? o : g.Co - 1;
+#pragma unroll
+    for (int ii = 0; ii < IT; ++ii) wv[ii] = sb_load(Wp[ii] + oo * g.w_so, 1);
+#pragma unroll
+    for (int b = 0; b < BT; ++b) gv[b] = sb_load(Gp[b] + oo * g.g_so, 0);
+  };
+  auto step = [&](const int64_t o, const sc_f4 (&wv)[IT], const sc_f4 (&gv)[BT]) {
+#pragma unroll
+    for (int ii = 0; ii < IT; ++ii) {
+      sc_f4 gw = sc_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < BT; ++b) sb_mac<true, false>(gw, xh[b][ii], gv[b]);       // conj(xhat) ghat, b-ordered
+      sb_store(GWp[ii] + o * g.gw_so, gw, g.nt_gw);
+#pragma unroll
+      for (int b = 0; b < BT; ++b) sb_mac<false, true>(acc[b][ii], gv[b], wv[ii]);  // ghat conj(W), o-ordered
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < ST; ++s) request(s, rw[s], rg[s]);
+  const int64_t OB = (g.Co / ST) * ST;
+#pragma unroll 1
+  for (int64_t o0 = 0; o0 < OB; o0 += ST) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      step(o0 + s, rw[s], rg[s]);
+      request(o0 + s + ST, rw[s], rg[s]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (OB + s < g.Co) step(OB + s, rw[s], rg[s]);
+  if (!active) return;
+#pragma unroll
+  for (int ii = 0; ii < IT; ++ii) {
+    if (i0 + ii >= g.Ci) continue;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) sb_store(gxhat + b * g.gx_sb + (i0 + ii) * g.gx_si + m, acc[b][ii], 0);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Contraction with a MODE-INDEPENDENT right operand (round 3): C[p, q, m] = sum_r opA(A[p, r, m]) * opB(B[r, q])
 // -- the channel-factor steps of the factorized contractions (spectral_convolution.py:55-103: z = xhat U_in,
 // yhat = t U_out^T and their adjoints in the backward pass; CP's factor products).  B is a small matrix (64 x 36

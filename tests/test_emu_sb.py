@@ -141,3 +141,32 @@ def test_factor_operand(lib, dims, transposed, conj):
     fl = _lib.SC_GEMM_NO_SB | _lib.SC_GEMM_FORCE_VALU | _lib.SC_GEMM_NO_STREAM
     _run(lib, a, store, c0, flags=fl, expect=0, **kw)
     assert torch.equal(torch.view_as_real(c), torch.view_as_real(c0))
+
+
+# ---- the two contractions of a small-batch backward pass in ONE pass over the weight (k_modegemm_sb_bwd, session 2)
+# (B, Ci, Co, M): ragged row tiles (Ci % 4, < 16), mode counts off the 128-mode tile, reductions shorter / longer than
+# the ring, every batch size the kernel is instantiated for
+@pytest.mark.parametrize("dims", [(4, 16, 16, 128), (4, 9, 12, 70), (3, 5, 17, 2), (1, 18, 5, 258), (2, 33, 3, 130),
+                                  (4, 128, 2, 20)], ids=lambda d: "B%d_Ci%d_Co%d_M%d" % d)
+def test_backward_pair_one_pass_over_the_weight(lib, dims):
+    B, Ci, Co, M = dims
+    xh, gh, w = _rand(B, Ci, M, seed=1), _rand(B, Co, M, seed=2), _rand(Ci, Co, M, seed=3)
+    kw_w = dict(P=Ci, Q=Co, R=B, n_modes=M, a_sp=M, a_sr=Ci * M, a_sm=1, conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1,
+                c_sp=Co * M, c_sq=M, c_sm=1, flags=_lib.SC_GEMM_STREAM_C)
+    kw_x = dict(P=B, Q=Ci, R=Co, n_modes=M, a_sp=Co * M, a_sr=M, a_sm=1, b_sr=M, b_sq=Co * M, b_sm=1, conj_b=1,
+                c_sp=Ci * M, c_sq=M, c_sm=1)
+    p = lambda t: torch.view_as_real(t).data_ptr()
+    nan = lambda *sh: torch.full(sh, float("nan"), dtype=torch.complex64)
+    gw, gx = nan(Ci, Co, M), nan(B, Ci, M)
+    lib.modegemm_pair(kw_w, p(xh), p(gh), p(gw), kw_x, p(gh), p(w), p(gx))
+    c = lambda v: v.numpy().astype(np.complex128)
+    assert rel_l2(gw.numpy(), np.einsum("bim,bom->iom", np.conj(c(xh)), c(gh))) < TOL
+    assert rel_l2(gx.numpy(), np.einsum("bom,iom->bim", c(gh), np.conj(c(w)))) < TOL
+    # the two launches it replaces: same fmaf chains, same bits
+    gw2, gx2 = nan(Ci, Co, M), nan(B, Ci, M)
+    lib.modegemm(p(xh), p(gh), p(gw2), 0, **kw_w)
+    lib.modegemm(p(gh), p(w), p(gx2), 0, **kw_x)
+    if Ci * Co >= 64 * B:                       # the one-pass kernel ran (else the pair is those two launches anyway)
+        assert lib.modegemm_path(**kw_w) == 3 and lib.modegemm_path(**kw_x) == 3
+    assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw2))
+    assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx2))
