@@ -83,6 +83,23 @@ int main() {
   hipMemcpy(hy2.data(), (float*)gW + 123456789, 4096 * 4, hipMemcpyDeviceToHost);
   hipMemcpy(hx2.data(), (float*)gxh + 1234567, 4096 * 4, hipMemcpyDeviceToHost);
   int same = 1; for (int i = 0; i < 4096; ++i) same &= (hy[i] == hy2[i]) && (hx[i] == hx2[i]);
+  {
+    hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
+    auto both = [&] {
+      hipLaunchKernelGGL((k_modegemm_sb<SB_PT, SB_QT, SB_ST, 1, 1, 4, false, true>), dim3(8 * gx.per_xcd), dim3(256), 0, s1, gx, (const cf32*)gh, (const cf32*)W, yh);
+      hipLaunchKernelGGL((k_modegemm_sb<SB_PT_GW, SB_QT_GW, SB_ST_GW, 1, 2, 2, true, false>), dim3(8 * gw.per_xcd), dim3(256), 0, s2, gw, (const cf32*)xh, (const cf32*)gh, gW);
+    };
+    hipDeviceSynchronize();
+    for (int i = 0; i < 3; ++i) both();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0); hipStreamWaitEvent(s1, e0, 0); hipStreamWaitEvent(s2, e0, 0);
+    for (int i = 0; i < 6; ++i) both();
+    hipEvent_t f1, f2; hipEventCreate(&f1); hipEventCreate(&f2);
+    hipEventRecord(f1, s1); hipEventRecord(f2, s2); hipStreamWaitEvent(0, f1, 0); hipStreamWaitEvent(0, f2, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("two streams, gx || gw: %7.1f us per pair\n", ms * 1e3f / 6);
+  }
   printf("%-22s fwd %7.1f us   gx %7.1f us   gw %7.1f us   gx+gw fused %7.1f us (bits equal: %d)   checksum %.9e\n", ABL_NAME, tf, tx, tw, tb, same, cs);
   return 0;
 }
