@@ -95,6 +95,17 @@ SC_DEVICE void sc_swap32(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
+// ---- a load the compiler does not track (persistent store-bound kernels: the next work item's few inputs are
+// requested while this item's rows are still being stored).  vmcnt counts loads and stores in issue order on gfx9, and
+// hipcc's wait insertion, merging the loop's entry paths, drains EVERYTHING (s_waitcnt vmcnt(0): all stores of the
+// previous item included) before the first use of a register that a tracked load of the previous iteration wrote --
+// a full store drain per item (measured on the 128 x 128 plane kernels: 428 -> 587 us).  Issued as inline assembly the
+// load is invisible to that pass; the kernel waits with its own COUNTED s_waitcnt ("at most N operations outstanding",
+// N = the operations issued after the loads) and then passes every loaded value through sc_landed(), an empty
+// assembly statement that is ordered after the wait and that every use depends on.  Extra operations in flight that
+// the compiler does not know of can only make its own counted waits wait longer, never shorter.
+// (sc_gload8_untracked / sc_landed: below, after cf32; the counted wait is sc_wait_vmcnt<N>())
+
 // float add into LDS shared by the waves of a workgroup: ds_add_f32 (no return value)
 #define SC_LDS_ADD(ptr, val) atomicAdd((ptr), (val))
 
@@ -304,6 +315,33 @@ SC_HD cf32 cf_make(float x, float y) {
   r.y = y;
   return r;
 }
+#ifndef SC_EMU
+SC_DEVICE cf32 sc_gload8_untracked(const cf32* p) {
+  typedef float f2v_ __attribute__((ext_vector_type(2)));
+  f2v_ v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return cf_make(v.x, v.y);
+}
+SC_DEVICE void sc_landed(cf32& v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y));
+}
+SC_DEVICE float sc_gload4_untracked(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// also: "use" a value the compiler DOES track, here and now -- its own wait for the load that produced it is then
+// placed in front of this statement (e.g. ahead of a loop) instead of at the first real use (inside the loop, where a
+// s_waitcnt vmcnt(0) would drain the loop's stores on every trip)
+SC_DEVICE void sc_landed(float& v) {
+  asm volatile("" : "+v"(v));
+}
+#else
+inline cf32 sc_gload8_untracked(const cf32* p) { return *p; }
+inline float sc_gload4_untracked(const float* p) { return *p; }
+inline void sc_landed(cf32&) {}
+inline void sc_landed(float&) {}
+#endif
 // acc += a * b
 SC_HD void cf_mac(cf32& acc, const cf32 a, const cf32 b) {
   acc.x = fmaf(a.x, b.x, acc.x);

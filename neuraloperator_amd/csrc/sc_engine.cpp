@@ -385,6 +385,9 @@ static int build_mdft_tables(sc_plan* p) {
 // ------------------------------------------------------------------------------------------
 // two-pass factorised route (sc_kernels_fft2p.h): eligibility, tables, launches
 // ------------------------------------------------------------------------------------------
+#ifndef SC_F2P_C2R_WGS
+#define SC_F2P_C2R_WGS 2        // persistent workgroups of k_f2p_c2r per compute unit (76 KB of LDS each)
+#endif
 #ifndef SC_F2P_CHUNK_MB
 #define SC_F2P_CHUNK_MB 192     // panel bytes in flight between the two passes (Infinity Cache: 256 MB); measured
                                 // 32 / 96 / 192 / unchunked: 0.84 / 0.74 / 0.70 / 0.73 ms forward, 1.45 / 1.02 / 0.94 / 1.07 ms inverse
@@ -557,10 +560,12 @@ static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float
     float* ys = y + i0 * p->ntot;
     ok = ok && f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
       constexpr int G = 32 / decltype(P)::value;
-      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)((ni * N0 / 2 + 8 * G - 1) / (8 * G))),
-                dim3(256), 0, st,
+      const int64_t n_items = (ni * N0 / 2 + 8 * G - 1) / (8 * G);
+      int64_t grid = (int64_t)SC_F2P_C2R_WGS * sc_cu_count();   // persistent workgroups (sc_kernels_fft2p.h)
+      if (grid > n_items) grid = n_items;
+      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)grid), dim3(256), 0, st,
                 (const cf32*)panel, ys, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_inv[mode], bias,
-                (int)channels, (int)(i0 % channels), N0, J, NCB, ni * N0 / 2);
+                (int)channels, (int)(i0 % channels), N0, J, NCB, ni * N0 / 2, n_items, (int)grid);
     });
     if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
   }

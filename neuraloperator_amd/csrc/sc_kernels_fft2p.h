@@ -498,14 +498,25 @@ k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf3
 // ------------------------------------------------------------------------------------------
 // pass 1 inverse: kept columns of two panel rows -> two real rows (+ bias), G row pairs per half-wave
 // ------------------------------------------------------------------------------------------
+// Round 3, session 2: PERSISTENT workgroups (items b, b + gstride, ...; an item = 8 G row pairs).  A workgroup's life
+// used to be: request the few panel values of its row pairs, wait a full memory latency, transform, issue 64 stores per
+// lane, exit -- a quarter to a third of it waiting for that first load with nothing else in flight from this half-wave
+// (1024^2: 10 us per workgroup, ~3 of them latency).  Now the panel values of the NEXT item are requested as soon as
+// this item's have been turned into the half-wave's Z arrays, and land while it transforms and stores.  The request
+// is an UNTRACKED load with the kernel's own counted wait (sc_device.h: a tracked one makes hipcc drain every store of
+// the previous item before the first use -- the 128 x 128 plane kernels lost 35 % to that): an item issues exactly
+// NST = 2 P G (48 ... 64) stores per lane after the request, so "at most min(NST, 63) operations outstanding" means the
+// values have landed.
 template <int P, int K2>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ twN,
           const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J, int NCB,
-          int64_t n_pairs) {
+          int64_t n_pairs, int64_t n_items, int gstride) {
   constexpr int N = 32 * P, KOFF = P * K2, G = 32 / P, ZS = 2 * KOFF + 1;
   constexpr int NI = (KOFF + 32) / 32;
   static_assert(G * ZS <= 32 * SC_F2P_RS, "the Z arrays of a half-wave share its exchange buffer");
+  constexpr int NST = 2 * P * G;                         // stores per lane and item (48 ... 64): the counted wait below
+  static_assert(NST <= 64, "vmcnt range");
   SC_SHARED __attribute__((aligned(16))) cf32 tw[P * 32];
   SC_SHARED __attribute__((aligned(16))) cf32 Eall[8][32 * SC_F2P_RS];
   const int tid = SC_TID, hw = tid >> 5, t = tid & 31;
@@ -514,25 +525,48 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
   float sc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) sc[i] = (t + 32 * i < J) ? cs[t + 32 * i] : 0.f;   // norm x column weight (x 1/2, k > 0)
-  const int64_t pair0 = ((int64_t)SC_BID_X * 8 + hw) * G;
-  // the few panel values of all G pairs are requested first (one exposed memory latency per half-wave, not G)
+  // the few panel values of all G pairs of an item (columns past J read the pair's first element and are zeroed)
   cf32 pa[G][NI], pb[G][NI];
+  float bv[G];                                           // the pair's bias value rides along (a tracked load inside the
+                                                         // loop would be waited for with vmcnt(0): a store drain per pair)
+  auto request = [&](const int64_t item) {
+    const int64_t pair0 = (item * 8 + hw) * G;
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;
-    const int64_t rA = 2 * pr, img = rA / N0;
-    const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+    for (int g = 0; g < G; ++g) {
+      const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;
+      const int64_t rA = 2 * pr, img = rA / N0;
+      const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+      bv[g] = bias ? sc_gload4_untracked(bias + (img + img0) % channels) : 0.f;   // img0: first image of this chunk
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int k = t + 32 * i;
-      pa[g][i] = pb[g][i] = cf_make(0.f, 0.f);
-      if (k < J) {
-        const cf32* a = src + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
-        pa[g][i] = a[0];
-        pb[g][i] = a[SC_F2P_CB];
+      for (int i = 0; i < NI; ++i) {
+        const int k = t + 32 * i;
+        const cf32* a = src + (k < J ? (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7) : 0);
+        pa[g][i] = sc_gload8_untracked(a);
+        pb[g][i] = sc_gload8_untracked(a + SC_F2P_CB);
       }
     }
-  }
+  };
+  auto landed = [&] {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        sc_landed(pa[g][i]);
+        sc_landed(pb[g][i]);
+      }
+#pragma unroll
+    for (int g = 0; g < G; ++g) sc_landed(bv[g]);
+  };
+  if ((int64_t)SC_BID_X < n_items) request(SC_BID_X);
+  sc_wait_vmcnt<0>();
+  landed();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) sc_landed(sc[i]);         // (tracked loads: waited for HERE, not inside the loop)
+  SC_SYNC();                                             // twiddle table
+
+#pragma unroll 1
+  for (int64_t item = SC_BID_X; item < n_items; item += gstride) {
+  const int64_t pair0 = (item * 8 + hw) * G;
   // Z[k] = s (A + i B),  Z[-k] = s (conj A + i conj B);  k = 0: s (Re A + i Re B) -- into the pair's Z array
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -541,14 +575,19 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
     for (int i = 0; i < NI; ++i) {
       const int k = t + 32 * i;
       if (k <= KOFF) {
-        const cf32 A = pa[g][i], B = pb[g][i];
+        const bool in = k < J;
+        const cf32 A = in ? pa[g][i] : cf_make(0.f, 0.f), B = in ? pb[g][i] : cf_make(0.f, 0.f);
         const float s = sc[i];
         Zb[KOFF + k] = (k == 0) ? cf_make(s * A.x, s * B.x) : cf_make(s * (A.x - B.y), s * (A.y + B.x));
         if (k > 0) Zb[KOFF - k] = cf_make(s * (A.x + B.y), s * (B.x - A.y));
       }
     }
   }
-  SC_SYNC();                                             // twiddle table (and this half-wave's Z arrays)
+  float bvc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bvc[g] = bv[g];
+  request(item + gstride < n_items ? item + gstride : item);   // the next item's values (this one's are spent)
+  SC_WAVE_SYNC();                                        // this half-wave's Z arrays (both half-waves of a wave run in step)
   {
     cf32 in[2 * K2 + 1];
     const bool on = t < G * P;
@@ -569,19 +608,22 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
   SC_WAVE_SYNC();
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
-    const int64_t pr = pair0 + g;
-    if (pr >= n_pairs) break;                            // uniform per half-wave
+    // pairs past the end are clamped to the last one (the same values stored again): every item issues its 64 stores
+    const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;
     const int64_t rA = 2 * pr, img = rA / N0;
     cf32 u[P], z[P];
 #pragma unroll
     for (int k1 = 0; k1 < P; ++k1) u[k1] = sc_lds_ld64(E + (g * P + k1) * SC_F2P_RS + t);
     f2p_dftP<P, +1>(u, z);                               // z[j] = a[t + 32 j] + i b[t + 32 j]
-    const float bv = bias ? bias[(img + img0) % channels] : 0.f;   // img0: first image of this chunk
     float* ya = y + rA * N + t;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      SC_STORE_STREAM(ya + 32 * j, z[j].x + bv);
-      SC_STORE_STREAM(ya + N + 32 * j, z[j].y + bv);
+      SC_STORE_STREAM(ya + 32 * j, z[j].x + bvc[g]);
+      SC_STORE_STREAM(ya + N + 32 * j, z[j].y + bvc[g]);
     }
+  }
+  SC_WAVE_SYNC();                                        // the exchange buffer is rewritten by the next item
+  sc_wait_vmcnt<(NST < 63 ? NST : 63)>();               // the request went out in front of this item's NST stores
+  landed();
   }
 }
