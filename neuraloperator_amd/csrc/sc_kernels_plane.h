@@ -34,7 +34,9 @@ struct PlLds {
   static constexpr int off_E = off_T + T_c;
   static constexpr int off_Z = off_E + (E_c > E2_c ? E_c : E2_c);
   static constexpr int off_IO = off_Z + Z_c;
-  static constexpr int total_c = off_IO + IO_c;                  // 6164 complex = 49 KB: 3 workgroups per CU
+  static constexpr int off_tab = off_IO + IO_c;                  // w128^m, m = 0..127 (session 2: the column phases read
+                                                                 // their twiddles here instead of 14-15 global loads per lane)
+  static constexpr int total_c = off_tab + SC_PL_N;              // 6292 complex = 50 KB: 3 workgroups per CU
 };
 
 // ------------------------------------------------------------------------------------------
@@ -48,16 +50,22 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
   const int tid = SC_TID;
   const int64_t plane = SC_BID_X;
   const float* xp = x + plane * (int64_t)(SC_PL_N * SC_PL_N);
+#ifndef SC_PL_TAB_GLOBAL
+  cf32* tabl = lds + PlLds::off_tab;
+  if (tid < SC_PL_N) tabl[tid] = tab128[tid];            // published by the barrier between the row and column phases
+#else
+  const cf32* tabl = tab128;
+#endif
   // ---------------- rows: 4 rounds of 16 packed row pairs ----------------
   {
     const int g = tid >> 4, t = tid & 15, L = t & 7;
     cf32* E = lds + PlLds::off_E + g * (8 * SC_PL_ES);
     cf32* Zs = lds + PlLds::off_Z + g * 34;
-    cf32 tw1[8];
-#pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = tab128[(t * k1) & 127];
-    cf32 pf[8];
-    auto prefetch = [&](const int r) {
+#ifndef SC_PL_PF_DEPTH
+#define SC_PL_PF_DEPTH 1     // rounds of row loads in flight ahead of the one being transformed (A-B: 2)
+#endif
+    cf32 pfs[SC_PL_PF_DEPTH][8];
+    auto prefetch = [&](const int r, cf32 (&pf)[8]) {
       const float* ra = xp + (2 * (g + 16 * r)) * SC_PL_N + t;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -65,13 +73,30 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
         pf[j].y = SC_LOAD_STREAM(ra + SC_PL_N + 16 * j);
       }
     };
-    prefetch(0);
+#pragma unroll
+    for (int d = 0; d < SC_PL_PF_DEPTH; ++d) prefetch(d, pfs[d]);
+    // the lane's row twiddles out of the LDS table (the first round's loads are in flight meanwhile; A-B
+    // -DSC_PL_TW1_GLOBAL: 7 global loads per lane and plane instead of one barrier)
+    cf32 tw1[8];
+#if !defined(SC_PL_TAB_GLOBAL) && !defined(SC_PL_TW1_GLOBAL)
+    SC_SYNC();
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = sc_lds_ld64(tabl + ((t * k1) & 127));
+#else
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = tab128[(t * k1) & 127];
+#endif
+#if SC_PL_PF_DEPTH == 1
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
     for (int r = 0; r < 4; ++r) {
       const int p = g + 16 * r;
       cf32 u[8];
+      cf32 (&pf)[8] = pfs[r % SC_PL_PF_DEPTH];
       dft8<-1>(pf, u);                                   // over j -> k1
-      if (r < 3) prefetch(r + 1);
+      if (r + SC_PL_PF_DEPTH < 4) prefetch(r + SC_PL_PF_DEPTH, pf);
       E[t] = u[0];
 #pragma unroll
       for (int k1 = 1; k1 < 8; ++k1) E[k1 * SC_PL_ES + t] = cf_mul_cs(u[k1], tw1[k1]);
@@ -115,7 +140,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
       fft16<-1>(v, u);                                   // over j -> k1
       E2[t] = u[0];
 #pragma unroll
-      for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], tab128[(t * k1) & 127]);
+      for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], tabl[(t * k1) & 127]);
     }
     SC_WAVE_SYNC();
     if (act) {
@@ -156,6 +181,12 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
     const cf32* src = in + plane * (int64_t)K0 * J;
     for (int i = tid; i < K0 * J; i += 256) IN[i] = src[i];
   }
+#ifndef SC_PL_TAB_GLOBAL
+  cf32* tabl = lds + PlLds::off_tab;
+  if (tid < SC_PL_N) tabl[tid] = tab128[tid];
+#else
+  const cf32* tabl = tab128;
+#endif
   SC_SYNC();
   // ---------------- columns: kept rows -> all 128 rows of the tile ----------------
   {
@@ -179,7 +210,7 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
         dft8<+1>(e, o);
         E2[k1 * 9] = o[0];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) E2[k1 * 9 + q] = cf_mul_cs(o[q], cf_conj(tab128[(q * k1) & 127]));
+        for (int q = 1; q < 8; ++q) E2[k1 * 9 + q] = cf_mul_cs(o[q], cf_conj(tabl[(q * k1) & 127]));
       }
     }
     SC_WAVE_SYNC();
@@ -200,7 +231,7 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
     cf32* Zs = lds + PlLds::off_Z + g * 34;
     cf32 tw2[16];
 #pragma unroll
-    for (int q = 1; q < 16; ++q) tw2[q] = cf_conj(tab128[(q * L) & 127]);
+    for (int q = 1; q < 16; ++q) tw2[q] = cf_conj(tabl[(q * L) & 127]);
     const float bv = bias ? bias[(plane / planes_per_image) % channels] : 0.f;
     float* yp = y + plane * (int64_t)(SC_PL_N * SC_PL_N);
 #pragma unroll 1
@@ -259,8 +290,10 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
 template <int DIR>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
 k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ tab128, int64_t inner, int K) {
-  SC_SHARED __attribute__((aligned(16))) cf32 lds[4 * 8 * 148];
+  SC_SHARED __attribute__((aligned(16))) cf32 lds[4 * 8 * 148 + SC_PL_N];
   const int tid = SC_TID, w = tid >> 6, lane = tid & 63, c = lane & 7, t = lane >> 3;
+  cf32* tabl = lds + 4 * 8 * 148;                        // w128^m in LDS (session 2): 15 LDS reads per lane instead of 15 global loads
+  if (tid < SC_PL_N) tabl[tid] = tab128[tid];
   const int64_t o = SC_BID_Y;
   const int64_t col = ((int64_t)SC_BID_X * 4 + w) * 8 + c;
   const bool live = col < inner;
@@ -270,10 +303,11 @@ k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restr
     cf32 v[16], u[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = live ? src[(int64_t)8 * j * inner] : cf_make(0.f, 0.f);
+    SC_SYNC();                                           // the table (the line's loads are in flight meanwhile)
     fft16<-1>(v, u);
     E2[t] = u[0];
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], tab128[(t * k1) & 127]);
+    for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], sc_lds_ld64(tabl + ((t * k1) & 127)));
     SC_WAVE_SYNC();
     cf32* dst = out + o * K * inner + col;
 #pragma unroll
@@ -298,10 +332,11 @@ k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restr
 #pragma unroll
       for (int q = 1; q < 7; ++q) e[q] = cf_make(0.f, 0.f);
       e[7] = (live && rn >= 0) ? src[(int64_t)rn * inner] : cf_make(0.f, 0.f);
+      if (h == 0) SC_SYNC();                             // the table (uniform: h is the unrolled loop's index)
       dft8<+1>(e, g);
       E2[k1 * 9] = g[0];
 #pragma unroll
-      for (int q = 1; q < 8; ++q) E2[k1 * 9 + q] = cf_mul_cs(g[q], cf_conj(tab128[(q * k1) & 127]));
+      for (int q = 1; q < 8; ++q) E2[k1 * 9 + q] = cf_mul_cs(g[q], cf_conj(sc_lds_ld64(tabl + ((q * k1) & 127))));
     }
     SC_WAVE_SYNC();
     cf32 u[16], v[16];
