@@ -40,6 +40,8 @@
 #define SC_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // the instruction scheduler may not move anything across this point
 #define SC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// no memory operation is moved across this point by the compiler (no instruction is emitted)
+#define SC_COMPILER_FENCE() asm volatile("" ::: "memory")
 // returns x, but opaque to the optimiser: address arithmetic that depends on it cannot be hoisted
 // above this point (epilogue store addresses computed -- and spilled -- before the main loop otherwise)
 SC_DEVICE int sc_opaque(int x) {
@@ -167,6 +169,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_WAVE_SYNC() scemu::wave_barrier()   /* emulated lanes are free-running threads */
 #define SC_UNIFORM(x) (x)
 #define SC_SCHED_BARRIER() do { } while (0)
+#define SC_COMPILER_FENCE() do { } while (0)
 #define SC_STORE_STREAM(ptr, val) (*(ptr) = (val))
 #define SC_LOAD_STREAM(ptr) (*(ptr))
 inline int sc_opaque(int x) { return x; }

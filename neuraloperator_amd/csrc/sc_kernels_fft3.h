@@ -215,16 +215,20 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
   const int64_t img = SC_BID_X;
   const IO* xi = x + img * (int64_t)H * SC_F2D_W;
 
-  for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
-  if (tid < 64) {
-    tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];   // w64^(mu q1)
-  }
-  if (tid < 32) {
-    // [k3][n4]: w32^(n4 k3), times i^n4 for k3 >= 4 (the k4 = 3 terms); slot [0][n4] = w32^(4 n4) (k = +32)
-    const int tn = tid & 3, tk = tid >> 2;
-    const cf32 t = tabW[(8 * tn * (tk == 0 ? 4 : tk)) & 255];
-    tw2t[tid] = ctw4_make((tk >= 4) ? cf_rot_i(t, tn) : t);
-  }
+  // Session 2: the workgroup's tables are REQUESTED here -- every request unconditional, into registers -- and stored to
+  // LDS only after the first row rounds have been requested as well (below).  Before, each table was loaded, waited
+  // for and stored inside its own `if (tid < n)` block: three L2 latencies one after the other plus the lane's row
+  // twiddles, all in front of the first request for image data, once per image.
+  // (Untracked loads, sc_device.h: the compiler sinks an ordinary load of a __restrict__ table into the block that uses
+  // it -- behind the row requests -- and then drains everything for it.)
+  constexpr int NTH = (H + 255) / 256;
+  cf32 rH[NTH];
+#pragma unroll
+  for (int q = 0; q < NTH; ++q) rH[q] = sc_gload8_untracked(tabH + (tid + 256 * q) % H);
+  cf32 r64 = sc_gload8_untracked(tabW + ((4 * ((tid & 63) >> 3) * (tid & 7)) & 255));   // w64^(mu q1)
+  // [k3][n4]: w32^(n4 k3), times i^n4 for k3 >= 4 (the k4 = 3 terms); slot [0][n4] = w32^(4 n4) (k = +32)
+  const int t2n = tid & 3, t2k = (tid >> 2) & 7;
+  cf32 r2 = sc_gload8_untracked(tabW + ((8 * t2n * (t2k == 0 ? 4 : t2k)) & 255));
 
   // ---- row phase roles and per-lane twiddles
 #ifdef SC_F3_SWAP
@@ -295,7 +299,6 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     SC_WAVE_SYNC();                                      // cb is rewritten by the next task
   };
 
-  SC_SYNC();
   // software prefetch, SC_F3_PF_DEPTH rounds deep: the values of round t + depth are requested while round t
   // is transformed (depth register sets, rounds alternate between them).  A round is short (~1 us), about the
   // loaded HBM latency: depth 2 covers it alone at 3 workgroups per CU, depth 1 relies on the other resident
@@ -317,8 +320,23 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
       }
     }
   };
+  SC_COMPILER_FENCE();                                   // the table requests stay ahead of the row rounds (the compiler
+                                                         // had sunk one below them and then drained everything for it)
 #pragma unroll
   for (int d = 0; d < SC_F3_PF_DEPTH; ++d) prefetch(d, pz[d]);        // depth 1, 2 or 4 (4 rounds = one row group)
+  SC_COMPILER_FENCE();
+  // the tables (requested ahead of the row rounds: vmcnt is in order, so waiting for them leaves the rounds in flight)
+  sc_wait_vmcnt<(16 * SC_F3_PF_DEPTH < 63 ? 16 * SC_F3_PF_DEPTH : 63)>();
+#pragma unroll
+  for (int q = 0; q < NTH; ++q) sc_landed(rH[q]);
+  sc_landed(r64);
+  sc_landed(r2);
+#pragma unroll
+  for (int q = 0; q < NTH; ++q)
+    if (tid + 256 * q < H) twH[tid + 256 * q] = rH[q];
+  if (tid < 64) tw64[tid] = r64;
+  if (tid < 32) tw2t[tid] = ctw4_make((t2k >= 4) ? cf_rot_i(r2, t2n) : r2);
+  SC_SYNC();
 
 #pragma unroll 1
   for (int a = 0; a < P; ++a) {
