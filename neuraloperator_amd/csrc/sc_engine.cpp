@@ -1474,7 +1474,16 @@ static bool fmx_off() {
 // workgroups for n chunks with `cap` co-resident: every workgroup the same number of rounds
 static int fmx_wgs(int64_t chunks, int64_t cap) {
   const int64_t rounds = (chunks + cap - 1) / cap;
-  return (int)((chunks + rounds - 1) / rounds);
+  int64_t wgs = (chunks + rounds - 1) / rounds;
+  // Session 2: a launch is as slow as its busiest compute unit, so the workgroup count is rounded DOWN to a multiple
+  // of the unit count when that costs the busiest workgroup at most one more chunk: TFNO rank 0.1 has 1056 chunks
+  // (32 rows x 33 mode blocks): 528 workgroups of 2 chunks put three workgroups = 6 chunks on 16 units (average 4.1),
+  // 512 workgroups (32 of them with 3 chunks) put 5 on the busiest.  SC_FMX_WGS_EXACT=1 (environment, A-B): the old rule
+  static const bool exact = std::getenv("SC_FMX_WGS_EXACT") != nullptr;
+  const int64_t cus = sc_cu_count();
+  const int64_t m = (wgs / cus) * cus;
+  if (!exact && m >= cus && m < wgs && (chunks + m - 1) / m <= rounds + 1) wgs = m;
+  return (int)wgs;
 }
 static bool fmx_bfac_eligible(const sc_modegemm_desc* d) {
   if (fmx_off() || (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_FMX | SC_GEMM_FORCE_VALU))) return false;
@@ -1495,7 +1504,7 @@ static int run_fmx_bfac_t(const sc_modegemm_desc* d, const cf32* A, const cf32* 
   g.abl = tucker_abl();
   g.inv_q = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)d->Q - 1) / (uint64_t)d->Q);
   const size_t lds = (size_t)(q4 * g.ldb + r4 * SC_FMX_LDK) * sizeof(cf32);
-  g.n_wg = fmx_wgs(g.n_chunks, 256 * (int64_t)(160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds));
+  g.n_wg = fmx_wgs(g.n_chunks, sc_cu_count() * (int64_t)(160 * 1024 / lds > 4 ? 4 : 160 * 1024 / lds));
 #define SC_FX_LAUNCH(CA, CB)                                                                                     \
   do {                                                                                                           \
     auto kern = k_modegemm_bfac_mx<PF, TQ, CA, CB>;                                                                  \
@@ -1532,7 +1541,7 @@ static void fmx_msum_args(const sc_modegemm_desc* d, FmxArgs& g, size_t& lds) {
   const int p4 = (int)((d->P + 3) & ~(int64_t)3), q4 = (int)((d->Q + 3) & ~(int64_t)3);
   lds = (size_t)((p4 + q4) * SC_FMX_LDR) * sizeof(cf32);
   const int64_t per_cu = 160 * 1024 / lds > 3 ? 3 : 160 * 1024 / lds;
-  g.n_wg = fmx_wgs(g.n_chunks, 256 * per_cu);
+  g.n_wg = fmx_wgs(g.n_chunks, sc_cu_count() * per_cu);
 }
 template <int PFA, int PFB, int SLOTS>
 static int run_fmx_msum_t(const sc_modegemm_desc* d, const FmxArgs& g, size_t lds, const cf32* A, const cf32* B,
