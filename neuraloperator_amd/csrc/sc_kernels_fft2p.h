@@ -529,20 +529,25 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
   cf32 pa[G][NI], pb[G][NI];
   float bv[G];                                           // the pair's bias value rides along (a tracked load inside the
                                                          // loop would be waited for with vmcnt(0): a store drain per pair)
-  auto request = [&](const int64_t item) {
+  // first: the workgroup's FIRST item, requested ahead of the loop with ordinary loads (the compiler waits for them
+  // itself; with untracked loads there it copied one destination register ahead of the wait in one instantiation --
+  // tests/test_isa_untracked_loads.py checks every instantiation's ISA for exactly that)
+  auto request = [&](auto first, const int64_t item) {
+    constexpr bool TRACKED = decltype(first)::value != 0;
     const int64_t pair0 = (item * 8 + hw) * G;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int64_t pr = pair0 + g < n_pairs ? pair0 + g : n_pairs - 1;
       const int64_t rA = 2 * pr, img = rA / N0;
       const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
-      bv[g] = bias ? sc_gload4_untracked(bias + (img + img0) % channels) : 0.f;   // img0: first image of this chunk
+      const float* bp = bias + (img + img0) % channels;                          // img0: first image of this chunk
+      bv[g] = bias ? (TRACKED ? *bp : sc_gload4_untracked(bp)) : 0.f;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int k = t + 32 * i;
         const cf32* a = src + (k < J ? (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7) : 0);
-        pa[g][i] = sc_gload8_untracked(a);
-        pb[g][i] = sc_gload8_untracked(a + SC_F2P_CB);
+        pa[g][i] = TRACKED ? a[0] : sc_gload8_untracked(a);
+        pb[g][i] = TRACKED ? a[SC_F2P_CB] : sc_gload8_untracked(a + SC_F2P_CB);
       }
     }
   };
@@ -557,9 +562,8 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
 #pragma unroll
     for (int g = 0; g < G; ++g) sc_landed(bv[g]);
   };
-  if ((int64_t)SC_BID_X < n_items) request(SC_BID_X);
-  sc_wait_vmcnt<0>();
-  landed();
+  if ((int64_t)SC_BID_X < n_items) request(sc_int<1>(), SC_BID_X);
+  landed();                                              // (the compiler's own wait for the tracked loads lands here)
 #pragma unroll
   for (int i = 0; i < NI; ++i) sc_landed(sc[i]);         // (tracked loads: waited for HERE, not inside the loop)
   SC_SYNC();                                             // twiddle table
@@ -586,7 +590,7 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
   float bvc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) bvc[g] = bv[g];
-  request(item + gstride < n_items ? item + gstride : item);   // the next item's values (this one's are spent)
+  request(sc_int<0>(), item + gstride < n_items ? item + gstride : item);   // the next item's values (this one's are spent)
   SC_WAVE_SYNC();                                        // this half-wave's Z arrays (both half-waves of a wave run in step)
   {
     cf32 in[2 * K2 + 1];

@@ -1,0 +1,132 @@
+"""CPU tier (needs hipcc, no GPU): register discipline of the UNTRACKED loads (sc_device.h: sc_gload8_untracked /
+sc_gload4_untracked).  Such a load is an inline-assembly instruction the compiler knows nothing about: it believes the
+destination registers hold their value at once, so a copy, a spill or a reuse of those registers between the load and
+the kernel's own counted wait would capture garbage (or be clobbered when the data lands).  For every instantiation the
+library ships this test compiles the kernel to ISA and walks the control-flow graph from each untracked load to the
+kernel's own `s_waitcnt vmcnt(N)` (the inline-assembly one): no instruction on the way may mention a destination
+register."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "neuraloperator_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+C2R = [(p, k2) for p in (2, 3, 4, 5, 6, 8, 10, 12, 20) for k2 in (4, 8)] + [(p, k2) for p in (16, 32) for k2 in (1, 2, 4, 8)]
+PROBE = '#include "%s/sc_kernels_fft2p.h"\n' % CSRC + "".join(
+    "template __global__ void k_f2p_c2r<%d, %d>(const cf32*, float*, const cf32*, const float*, const float*, int, int, int, "
+    "int, int, int64_t, int64_t, int);\n" % pk for pk in C2R) + "".join(
+    "template __global__ void k_fft2d_fwd3<%d, %s>(const %s*, cf32*, const cf32*, const cf32*, int, int, float, float, F3Shard);\n"
+    % (h, io, io) for h in (64, 128, 256, 512) for io in ("float", "sc_bf16")) + "int main() { return 0; }\n"
+
+
+def _regs(text):
+    out = set()
+    for m in re.finditer(r"\b([va])\[(\d+):(\d+)\]", text):
+        out.update("%s%d" % (m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+    for m in re.finditer(r"\b([va])(\d+)\b", text):
+        out.add(m.group(1) + m.group(2))
+    return out
+
+
+def _functions(asm):
+    cur, name = None, None
+    for line in asm.split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name, cur = m.group(1), []
+        if cur is not None:
+            cur.append(line)
+            if "s_endpgm" in line:
+                yield name, cur
+                cur = None
+
+
+def _check(name, lines):
+    """-> (number of untracked loads, list of violations)"""
+    label = {}
+    in_asm = False
+    kind = []                      # per line: ("load", dst) | ("wait",) | ("ins", regs, branch target or None, falls through)
+    for i, raw in enumerate(lines):
+        line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
+        if raw.strip().startswith(";;#ASMSTART"):
+            in_asm = True
+            kind.append(None)
+            continue
+        if raw.strip().startswith(";;#ASMEND"):
+            in_asm = False
+            kind.append(None)
+            continue
+        m = re.match(r"^(\.LBB\w+):", raw)
+        if m:
+            label[m.group(1)] = i
+            kind.append(None)
+            continue
+        if not line or line.startswith(".") or line.endswith(":"):
+            kind.append(None)
+            continue
+        if in_asm and line.startswith("global_load_dword"):
+            kind.append(("load", _regs(line.split(",")[0])))
+        elif in_asm and line.startswith("s_waitcnt vmcnt("):
+            kind.append(("wait",))
+        else:
+            tgt, fall = None, True
+            mb = re.match(r"^(s_cbranch_\w+|s_branch)\s+(\.LBB\w+)", line)
+            if mb:
+                tgt, fall = mb.group(2), mb.group(1) != "s_branch"
+            if line.startswith("s_endpgm"):
+                fall = False
+            kind.append(("ins", _regs(line), tgt, fall))
+    loads = [i for i, k in enumerate(kind) if k and k[0] == "load"]
+    bad = []
+    for l0 in loads:
+        dst = kind[l0][1]
+        seen, stack = set(), [l0 + 1]
+        while stack:
+            i = stack.pop()
+            while i < len(kind) and i not in seen:
+                seen.add(i)
+                k = kind[i]
+                if k is None:
+                    i += 1
+                    continue
+                if k[0] == "wait":
+                    break
+                if k[0] == "load":
+                    if k[1] & dst:
+                        bad.append((l0, i, lines[i].strip()))
+                    i += 1
+                    continue
+                if k[1] & dst:
+                    bad.append((l0, i, lines[i].strip()))
+                if k[2] is not None and k[2] in label:
+                    stack.append(label[k[2]])
+                if not k[3]:
+                    break
+                i += 1
+    return len(loads), bad
+
+
+@pytest.mark.skipif(not os.path.isfile(HIPCC), reason="hipcc not available")
+def test_untracked_load_destinations_are_untouched_until_the_counted_wait():
+    with tempfile.TemporaryDirectory() as td:
+        src, out = os.path.join(td, "probe.hip"), os.path.join(td, "probe.s")
+        with open(src, "w") as f:
+            f.write(PROBE)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", src, "-o", out],
+                              stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    seen = 0
+    for name, lines in _functions(asm):
+        if "k_f2p_c2r" not in name and "k_fft2d_fwd3" not in name:
+            continue
+        n, bad = _check(name, lines)
+        assert n > 0, f"{name}: no untracked load found (the probe no longer matches the kernels)"
+        assert not bad, f"{name}: destination of an untracked load touched before the counted wait: {bad[:4]}"
+        seen += 1
+    assert seen == len(C2R) + 8
