@@ -11,7 +11,8 @@
 ``fused_block_forward(blocks, x, index)`` runs exactly that (three engine passes forward) on the parameters of an ``FNOBlocks``-shaped module (the
 verbatim reference class, built with ``conv_module=neuraloperator_amd.SpectralConv``): same result as
 ``blocks(x, index)``; configurations outside its scope (normalisation layers, pre-activation, tanh stabiliser, a
-resolution change, other skip types) take the module's own forward."""
+resolution change, other skip types) take the module's own forward.  Session 2: pre-activation blocks and blocks with
+normalisation layers run the same engine passes composed by autograd (``_fused_block_variant``)."""
 import torch
 import torch.nn.functional as F
 
@@ -238,8 +239,12 @@ class FusedBlockFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
-def _block_in_scope(blocks, index, output_shape):
-    if output_shape is not None or getattr(blocks, "preactivation", False) or getattr(blocks, "norm", None) is not None:
+def _block_in_scope(blocks, index, output_shape, variants=False):
+    """the default block (post-activation, no normalisation layers); ``variants``: also pre-activation and / or
+    normalisation layers (session 2: the same engine passes, composed -- fused_block_forward)"""
+    if output_shape is not None:
+        return False
+    if not variants and (getattr(blocks, "preactivation", False) or getattr(blocks, "norm", None) is not None):
         return False
     if getattr(blocks, "stabilizer", None) is not None or getattr(blocks, "complex_data", False):
         return False
@@ -259,16 +264,59 @@ def _block_in_scope(blocks, index, output_shape):
     return act is F.gelu and getattr(mlp, "non_linearity", None) is F.gelu
 
 
+def _fused_block_variant(blocks, x, index, last, conv, fc1, fc2, lin, pre, norm):
+    """Pre-activation (fno_block.py:416-458) and / or normalisation layers (:399-403, :408-409, :421-422, :447-448) on
+    the engine passes of the default block, composed with autograd between them:
+
+      pre-activation, no norm   x = gelu(x) [one ATen pass]; 1 x 1 skip; Fourier layer with the add (+ GELU unless last)
+                                in its store path; pointwise MLP pass with the soft-gating skip of the ACTIVATED x, no
+                                closing activation
+      normalisation layers      they sit between the convolution and the add / behind the MLP, so the add and the
+                                activations around them stay ATen calls; the 1 x 1 skip, the spectral convolution and
+                                the pointwise MLP pass (both 1 x 1 convolutions, the GELU between them, the soft-gating
+                                skip) run on the engine
+
+    Same operations in the same order as the reference's two forward methods."""
+    act = blocks.non_linearity
+    nn_ = getattr(blocks, "n_norms", 2)
+    gate = blocks.channel_mlp_skips[index].weight
+    if pre:
+        x = act(x)
+        if norm is not None:
+            x = norm[nn_ * index](x)
+    x_skip_fno = fused_linear(x, lin.weight, lin.bias)
+    if norm is None:                                     # pre-activation only: the add (+ activation) in the store path
+        y = conv.forward_fused(x, x_skip_fno, activation=None if last else "gelu")
+        return fused_channel_mlp(y, fc1.weight, fc1.bias, fc2.weight, fc2.bias, skip_src=x, gate=gate, activation=None)
+    x_fno = conv(x)
+    if not pre:
+        x_fno = norm[nn_ * index](x_fno)
+    y = x_fno + x_skip_fno
+    if not last:
+        y = act(y)
+    if pre:
+        y = norm[nn_ * index + 1](y)
+    out = fused_channel_mlp(y, fc1.weight, fc1.bias, fc2.weight, fc2.bias, skip_src=x, gate=gate, activation=None)
+    if not pre:
+        out = norm[nn_ * index + 1](out)
+        if not last:
+            out = act(out)
+    return out
+
+
 def fused_block_forward(blocks, x, index=0, output_shape=None):
     """FNOBlocks.forward_with_postactivation (fno_block.py:377-414) for block ``index`` in two engine passes + the 1 x 1
     skip convolution (a plain library GEMM); the module's own forward outside the scope described in the module
     docstring."""
-    if not _block_in_scope(blocks, index, output_shape):
+    if not _block_in_scope(blocks, index, output_shape, variants=True):
         return blocks(x, index, output_shape=output_shape)
     last = index >= blocks.n_layers - 1
     conv = blocks.convs[index]
     fc1, fc2 = blocks.channel_mlp[index].fcs
     lin = blocks.fno_skips[index].conv
+    pre, norm = bool(getattr(blocks, "preactivation", False)), getattr(blocks, "norm", None)
+    if pre or norm is not None:
+        return _fused_block_variant(blocks, x, index, last, conv, fc1, fc2, lin, pre, norm)
     c, ch = int(x.shape[1]), int(fc1.weight.shape[0])
     from .factorized import DenseWeight
     one_node = _on_engine(x) and x.dtype == torch.float32 and x[0, 0].numel() % 32 == 0 and \

@@ -43,18 +43,26 @@ class ChannelMLP(nn.Module):
 
 
 class Blocks(nn.Module):
-    def __init__(self, channels, n_modes, n_layers=2, expansion=0.5):
+    def __init__(self, channels, n_modes, n_layers=2, expansion=0.5, preactivation=False):
         super().__init__()
         from neuraloperator_amd import SpectralConv
         nd = len(n_modes)
         self.n_layers, self.non_linearity = n_layers, F.gelu
-        self.preactivation, self.norm, self.stabilizer, self.complex_data, self.use_channel_mlp = False, None, None, False, True
+        self.preactivation, self.norm, self.stabilizer, self.complex_data, self.use_channel_mlp = bool(preactivation), None, None, False, True
         self.convs = nn.ModuleList([SpectralConv(channels, channels, n_modes) for _ in range(n_layers)])
         self.fno_skips = nn.ModuleList([Flattened1dConv(channels, channels) for _ in range(n_layers)])
         self.channel_mlp = nn.ModuleList([ChannelMLP(channels, int(round(channels * expansion))) for _ in range(n_layers)])
         self.channel_mlp_skips = nn.ModuleList([SoftGating(channels, nd) for _ in range(n_layers)])
 
     def forward(self, x, index=0, output_shape=None):                     # fno_block.py:377-414, defaults
+        if self.preactivation:                                            # fno_block.py:416-458, no normalisation layers
+            x = F.gelu(x)
+            x_skip_fno = self.fno_skips[index](x)
+            x_skip_mlp = self.channel_mlp_skips[index](x)
+            x = self.convs[index](x) + x_skip_fno
+            if index < self.n_layers - 1:
+                x = F.gelu(x)
+            return self.channel_mlp[index](x) + x_skip_mlp
         x_skip_fno = self.fno_skips[index](x)
         x_skip_mlp = self.channel_mlp_skips[index](x)
         x = self.convs[index](x) + x_skip_fno

@@ -1063,29 +1063,33 @@ def _block_oracle(blk, x, g, index):
     xc = x.detach().cpu().clone().requires_grad_(True)
     s = list(xc.shape)
     flat = lambda t: t.reshape(s[0], t.shape[1], -1)
-    x_skip_fno = F.conv1d(flat(xc), P[f"fno_skips.{index}.conv.weight"]).reshape(s)
-    x_skip_mlp = P[f"channel_mlp_skips.{index}.weight"] * xc
+    pre = bool(getattr(blk, "preactivation", False))                    # fno_block.py:416-458 instead of :377-414
+    xin = F.gelu(xc) if pre else xc
+    x_skip_fno = F.conv1d(flat(xin), P[f"fno_skips.{index}.conv.weight"]).reshape(s)
+    x_skip_mlp = P[f"channel_mlp_skips.{index}.weight"] * xin
     nm = list(blk.convs[index].n_modes)
-    t = so.forward_torch(xc, P[f"convs.{index}.weight.tensor"], P[f"convs.{index}.bias"], nm, nm) + x_skip_fno
+    t = so.forward_torch(xin, P[f"convs.{index}.weight.tensor"], P[f"convs.{index}.bias"], nm, nm) + x_skip_fno
     if index < blk.n_layers - 1:
         t = F.gelu(t)
     h = F.gelu(F.conv1d(flat(t), P[f"channel_mlp.{index}.fcs.0.weight"], P[f"channel_mlp.{index}.fcs.0.bias"]))
     t = F.conv1d(h, P[f"channel_mlp.{index}.fcs.1.weight"], P[f"channel_mlp.{index}.fcs.1.bias"]).reshape(s) + x_skip_mlp
-    if index < blk.n_layers - 1:
+    if index < blk.n_layers - 1 and not pre:
         t = F.gelu(t)
     t.backward(g.detach().cpu())
     return t.detach(), xc.grad, {n: q.grad for n, q in P.items() if q.grad is not None}
 
 
-def test_fused_block_forward_matches_op_sequence():
+@pytest.mark.parametrize("pre", [False, True], ids=["postactivation", "preactivation"])
+def test_fused_block_forward_matches_op_sequence(pre):
     """A whole FNO block through the two fused passes against the reference's op sequence evaluated by the CPU ORACLE
     on the same parameters (stand-in module with FNOBlocks' attribute surface; the verbatim class is checked on the
-    CPU tier) -- and, as a second check, against the unfused op sequence on the GPU."""
+    CPU tier) -- and, as a second check, against the unfused op sequence on the GPU.  Pre-activation blocks
+    (fno_block.py:416-458; session 2) run the same engine passes composed by autograd."""
     from block_standin import Blocks
     from neuraloperator_amd import blocks as nb
     dev = torch.device("cuda:0")
     torch.manual_seed(4)
-    blk = Blocks(64, (16, 16)).to(dev)
+    blk = Blocks(64, (16, 16), preactivation=pre).to(dev)
     with torch.no_grad():
         for q in blk.parameters():
             if q.is_complex():
