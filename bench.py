@@ -365,11 +365,11 @@ def measure_traffic_live(workload_shape, kernel_substr, timeout_s=75):
 
 def engine_path(names):
     """Which transform kernels the plan of this workload runs (sc_plan_kernel_name): the fused one-image-per-workgroup
-    FFT (256-wide grids), the two-pass factorised FFT (512 / 1024 per axis), the factorised plane kernels (128 x 128
+    FFT (256-wide grids), the two-pass factorised FFT (512 / 1024 per axis), the factorised plane kernels (128 x 128 or 64 x 64
     last two axes) or the size-agnostic direct-DFT passes."""
     if names["fast"]:
         return "fused-fft"
-    return {"k_f2p_r2c": "two-pass-fft", "k_pl128_fwd": "plane-fft"}.get(names["fwd"], "generic-dft")
+    return {"k_f2p_r2c": "two-pass-fft", "k_pl128_fwd": "plane-fft", "k_pl64_fwd": "plane-fft"}.get(names["fwd"], "generic-dft")
 
 
 def cpu_baseline(C, spatial, n_modes, threads, budget_s=10.0):

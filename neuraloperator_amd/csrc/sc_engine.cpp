@@ -23,6 +23,7 @@
 #include "sc_kernels_mdft.h"
 #include "sc_kernels_fft2p.h"
 #include "sc_kernels_plane.h"
+#include "sc_kernels_plane64.h"
 #include "sc_kernels_pmlp.h"
 #include "sc_kernels_tucker.h"
 #include "sc_kernels_sb.h"
@@ -117,6 +118,7 @@ struct sc_plan {
   float* f2p_cs_inv[2] = {nullptr, nullptr};   // [SC_INV_PADDED], [SC_INV_ADJ_R2C]
   // factorised last-two-axes kernels for 128 x 128 planes (sc_kernels_plane.h)
   bool pl128 = false;
+  bool pl64 = false;                    // 64 x 64 planes (sc_kernels_plane64.h); shares pl_tab128 (here: w64^m) and pl_cs_*
   cf32* pl_tab128 = nullptr;
   float* pl_cs_fwd[2] = {nullptr, nullptr};
   float* pl_cs_inv[2] = {nullptr, nullptr};
@@ -486,6 +488,21 @@ static int pl128_plan_init(sc_plan* p) {
   return 0;
 }
 
+static int pl64_plan_init(sc_plan* p) {
+  const int L = p->nd - 1;
+  if (p->nd < 2 || p->cplx || p->custom_map || p->d.real_col) return 0;
+  if (p->n[L] != SC_P64_N || p->n[L - 1] != SC_P64_N || p->k[L] > SC_P64_JMAX || p->k[L - 1] > SC_P64_KMAX) return 0;
+  std::vector<cf32> h(64);
+  for (int m = 0; m < 64; ++m) h[(size_t)m] = twiddle(m, 1, 64, -1.0, 1.0);
+  DeviceTable dt;
+  int rc = upload_table(p, h, 1, 64, &dt);
+  if (!rc) rc = fft_col_scales(p, p->pl_cs_fwd, p->pl_cs_inv);
+  if (rc) return rc;
+  p->pl_tab128 = dt.ptr;
+  p->pl64 = true;
+  return 0;
+}
+
 static int64_t f2p_panel_elems_per_image(const sc_plan* p) { return (int64_t)p->f2p_ncb * p->n[0] * SC_F2P_CB; }
 static int64_t f2p_chunk_images(const sc_plan* p, int64_t n_images) {
   int64_t c = ((int64_t)SC_F2P_CHUNK_MB << 20) / (f2p_panel_elems_per_image(p) * (int64_t)sizeof(cf32));
@@ -714,6 +731,10 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   if (!rc && !p->fast && !p->f2p && !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT)))
     rc = pl128_plan_init(p);
   if (!rc && !p->fast && !p->f2p && !p->pl128 &&
+      !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT | SC_PLAN_F2P_SMALL_ALWAYS)) &&
+      !getenv("SC_PLAN_NO_PL64"))
+    rc = pl64_plan_init(p);
+  if (!rc && !p->fast && !p->f2p && !p->pl128 && !p->pl64 &&
       !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT | SC_PLAN_NO_F2P_SMALL)))
     rc = f2p_plan_init(p, false);
   if (!rc && (desc->flags & SC_PLAN_IO_BF16) && (!p->fast || (desc->flags & SC_PLAN_FFT_GEN2)))
@@ -823,13 +844,13 @@ static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, co
 // ---- "plane" form: the last TWO axes in one launch when the second-to-last has 128, 64 or 32 rows --------
 static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32; }
 static bool plane_fwd_ok(const sc_plan* p, int mode) {
-  if (p->pl128) return true;
+  if (p->pl128 || p->pl64) return true;
   const int L = p->nd - 1;
   return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_pl_fwd && plane_rows_ok(p->n[L - 1]) &&
          2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane;
 }
 static bool plane_inv_ok(const sc_plan* p, int mode) {
-  if (p->pl128) return true;
+  if (p->pl128 || p->pl64) return true;
   const int L = p->nd - 1;
   if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_pl_inv && plane_rows_ok(p->n[L - 1]) &&
         2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane))
@@ -867,6 +888,13 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
     SC_LAUNCH(k_pl128_fwd, dim3((unsigned)(lines / SC_PL_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
               (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L]);
     return sc_check_launch("k_pl128_fwd");
+  }
+  if (p->pl64) {
+    const int L = p->nd - 1;
+    if (((uintptr_t)in) & 15) return sc_fail("sc_engine: the 64 x 64 plane kernels need 16-byte aligned planes");
+    SC_LAUNCH(k_pl64_fwd, dim3((unsigned)(lines / SC_P64_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
+              (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L]);
+    return sc_check_launch("k_pl64_fwd");
   }
   const bool tail = p->l_r2c_tail[mode] != nullptr;
   if (tail) {
@@ -983,6 +1011,12 @@ static int run_plane_inv(const sc_plan* p, int mode, const cf32* in, float* out,
               (const float*)p->pl_cs_inv[mode], bias, lpi / SC_PL_N, (int)channels, (int)p->k[L - 1], (int)p->k[L]);
     return sc_check_launch("k_pl128_inv");
   }
+  if (p->pl64) {
+    if (((uintptr_t)out) & 15) return sc_fail("sc_engine: the 64 x 64 plane kernels need 16-byte aligned planes");
+    SC_LAUNCH(k_pl64_inv, dim3((unsigned)(lines / SC_P64_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
+              (const float*)p->pl_cs_inv[mode], bias, lpi / SC_P64_N, (int)channels, (int)p->k[L - 1], (int)p->k[L]);
+    return sc_check_launch("k_pl64_inv");
+  }
   const int N = (int)p->n[L], J = (int)p->k[L];
   const int n_nt = (N + 31) / 32;
   const int64_t nr = p->n[L - 1];
@@ -1058,9 +1092,17 @@ static void launch_mdft_axis(const cf32* in, cf32* out, const float* tab, int64_
 static bool ax128_ok(const sc_plan* p, int d) {
   return p->pl128 && d < p->nd - 2 && p->n[d] == SC_PL_N && p->k[d] <= SC_PL_KMAX;
 }
+static bool ax64_ok(const sc_plan* p, int d) {
+  return p->pl64 && d < p->nd - 2 && p->n[d] == SC_P64_N && p->k[d] <= SC_P64_KMAX;
+}
 static int run_ax128(const sc_plan* p, int dir, const cf32* in, cf32* out, int64_t outer, int K, int64_t inner,
                      sc_stream_t st) {
   const dim3 grid((unsigned)((inner + 31) / 32), (unsigned)outer);
+  if (p->pl64) {
+    if (dir < 0) SC_LAUNCH((k_ax64<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
+    else SC_LAUNCH((k_ax64<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
+    return sc_check_launch("k_ax64");
+  }
   if (dir < 0) SC_LAUNCH((k_ax128<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
   else SC_LAUNCH((k_ax128<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
   return sc_check_launch("k_ax128");
@@ -1162,7 +1204,7 @@ static int transform_forward_impl(const sc_plan* p, int mode, const float* x, fl
     int64_t outer = n_images;
     for (int e = 0; e < d; ++e) outer *= p->n[e];
     cf32* dst = (d == 0) ? (cf32*)xhat : (cur == bufA ? bufB : bufA);
-    if (ax128_ok(p, d) && outer <= 65535)
+    if ((ax128_ok(p, d) || ax64_ok(p, d)) && outer <= 65535)
       rc = run_ax128(p, -1, cur, dst, outer, (int)p->k[d], inner, st);
     else if (p->mdft && p->m_ax_fwd[d])
       rc = run_axis_mdft(p->m_ax_fwd[d], cur, dst, outer, (int)p->n[d], (int)p->k[d], inner, st);
@@ -1267,7 +1309,7 @@ static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat,
     const int remaining = L - 1 - d;  // passes after this one
     cf32* dst = (remaining % 2 == 0) ? bufA : bufB;
     int rc;
-    if (ax128_ok(p, d) && outer <= 65535)
+    if ((ax128_ok(p, d) || ax64_ok(p, d)) && outer <= 65535)
       rc = run_ax128(p, +1, cur, dst, outer, (int)p->k[d], inner, st);
     else if (p->mdft && p->m_ax_inv[d])
       rc = run_axis_mdft(p->m_ax_inv[d], cur, dst, outer, (int)p->k[d], (int)p->n[d], inner, st);
@@ -2779,6 +2821,7 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   if (p->cplx) return "k_axis_pass";
   if (p->f2p) return which == 0 ? "k_f2p_r2c" : "k_f2p_c2r";
   if (p->pl128) return which == 0 ? "k_pl128_fwd" : "k_pl128_inv";
+  if (p->pl64) return which == 0 ? "k_pl64_fwd" : "k_pl64_inv";
   if (p->mdft) {
     if (which == 0 && plane_fwd_ok(p, 0)) return "k_mdft_r2c_lds<plane>";
     if (which == 1 && plane_inv_ok(p, 0)) return "k_mdft_c2r_lds<plane>";

@@ -190,7 +190,10 @@ def test_factorised_route_for_32p_lines(lib, spatial, kept):
     plan = lib.plan_create(list(spatial), list(kept))
     try:
         name = lib.plan_kernel_name(plan, 0)
-        assert (name != "k_f2p_r2c") if small else (name == "k_f2p_r2c" and lib.plan_kernel_name(plan, 1) == "k_f2p_c2r")
+        if spatial == (64, 64):                          # session 2: its own one-launch plane kernels (sc_kernels_plane64.h)
+            assert name == "k_pl64_fwd" and lib.plan_kernel_name(plan, 1) == "k_pl64_inv"
+        else:
+            assert (name != "k_f2p_r2c") if small else (name == "k_f2p_r2c" and lib.plan_kernel_name(plan, 1) == "k_f2p_c2r")
     finally:
         lib.plan_destroy(plan)
     plan = lib.plan_create(list(spatial), list(kept), flags=L.SC_PLAN_F2P_SMALL_ALWAYS)
