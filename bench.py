@@ -72,6 +72,9 @@ def parse():
                     help="storage type of the real tensors x / y / gy / gx (arithmetic is fp32 either way); "
                          "bf16 = the bf16-I/O reading of BASELINE configs[1], fused 2-D kernels only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="time hipGraph replays of the step (neuraloperator_amd/graph.py) instead of eager steps: for "
+                         "workloads whose eager step is bound by the host's issue rate; single GPU only")
     ap.add_argument("--no-pmc", action="store_true",
                     help="roofline.traffic from profiles/pmc_traffic.json instead of two live rocprofv3 --pmc passes")
     ap.add_argument("--settle-ms", type=float, default=SETTLE_MS,
@@ -601,6 +604,7 @@ def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv
         if post is not None:
             post()
 
+    step.x, step.g = x, g                                # --graph captures the same step on the same tensors
     return step, b_local, global_batch, scaling, par, conv
 
 
@@ -663,6 +667,11 @@ def main():
     if case is None:
         raise SystemExit(f"{args.workload}: batch {B} not divisible by {world} ranks for the strong-scaling run")
     step, b_local, global_batch, scaling, par, conv = case
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph: single GPU only (the collectives of the sharded layers are not captured)")
+        from neuraloperator_amd.graph import capture_step
+        step = capture_step(conv, step.x, step.g).replay
     mappings.A2A_STATS.update(calls=0, bytes=0)
     ms, ms_cold, n_settle = timed_steps(step, args.steps, args.warmup, dist, dev, share, args.settle_ms)
     value = global_batch / (ms / 1e3)
@@ -775,6 +784,7 @@ def main():
             "config": {"workload": args.workload, "B_per_gpu": b_local, "global_batch": global_batch,
                        "channels": C, "grid": list(spatial), "n_modes": list(n_modes), "kept": kept,
                        "parallelism": par, "engine_path": engine_path(names),
+                       "launch": "hipGraph replay of the step" if args.graph else "eager",
                        "real_tensor_io": args.io,
                        "weights": "dense complex64, random init"},
             "roofline": roof,

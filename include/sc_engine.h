@@ -183,11 +183,16 @@ int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const float* B, 
 /* The same sum, C[p, q] OVERWRITTEN (no zeroing by the caller), on the matrix cores (round 3, sc_kernels_fmx.h:
  * k_modegemm_msum_mx stages [rows][64 modes] chunks of both operands in LDS and accumulates 16 x 16 tiles over all
  * chunks of a workgroup; one partial per workgroup in `workspace`, fixed-order reduction: run-to-run deterministic,
- * unlike the atomic adds of sc_modegemm_msum).  Qualifies when both operands have mode stride 1, 8 <= P, Q <= 64 and
- * n_modes >= 64: sc_modegemm_msum_workspace_bytes returns the bytes needed (0 = does not qualify: use sc_modegemm_msum). */
+ * unlike the atomic adds of sc_modegemm_msum).  The matrix-core kernel takes problems where both operands have mode
+ * stride 1, 8 <= P, Q <= 64 and n_modes >= 64 (sc_modegemm_msum_path == 1); every other problem runs the VALU kernel
+ * of sc_modegemm_msum with one workspace slot per (mode split, r split) instead of atomics and the same fixed-order
+ * reduction (path 0; session 2) -- so the result of this entry point is the same bits on every run for every shape.
+ * sc_modegemm_msum_workspace_bytes returns the bytes needed (0 only for an empty problem or one beyond the launch grid). */
 size_t sc_modegemm_msum_workspace_bytes(const sc_modegemm_desc* d);
 int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, const float* B, float* C, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* 1: sc_modegemm_msum_ws runs k_modegemm_msum_mx (matrix cores), 0: the slot form of the VALU kernel */
+int sc_modegemm_msum_path(const sc_modegemm_desc* d);
 /* 1 if this call runs on a matrix-core kernel, 0 for the VALU kernel */
 int sc_modegemm_uses_matrix_cores(const sc_modegemm_desc* d);
 /* which kernel a call with 16-byte aligned operands takes: 0 k_modegemm (VALU), 1 k_modegemm_mfma (register-staged

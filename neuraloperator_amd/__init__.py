@@ -9,5 +9,6 @@ from .factorized import CPWeight, DenseWeight, SpectralWeight, TTWeight, TuckerW
 from .optim import AdamW  # noqa: F401
 from .galore import TensorGaLoreProjector  # noqa: F401
 from .spherical import SHT, SphericalConv  # noqa: F401
+from .graph import GraphedStep, capture_step  # noqa: F401
 
 __version__ = "0.1.0"

@@ -142,7 +142,7 @@ class ScEngineLib:
     # every symbol include/sc_engine.h declares
     SYMBOLS = ["sc_plan_create", "sc_plan_destroy", "sc_plan_workspace_bytes", "sc_plan_is_fast",
                "sc_transform_forward", "sc_transform_inverse", "sc_modegemm",
-               "sc_modegemm_msum", "sc_modegemm_msum_ws", "sc_modegemm_msum_workspace_bytes", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
+               "sc_modegemm_msum", "sc_modegemm_msum_ws", "sc_modegemm_msum_workspace_bytes", "sc_modegemm_msum_path", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
                "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
@@ -193,6 +193,8 @@ class ScEngineLib:
         L.sc_modegemm_msum_workspace_bytes.restype = c_size_t
         L.sc_modegemm_msum_ws.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
         L.sc_modegemm_msum_ws.restype = c_int
+        L.sc_modegemm_msum_path.argtypes = [POINTER(ModeGemmDesc)]
+        L.sc_modegemm_msum_path.restype = c_int
         L.sc_modegemm_uses_matrix_cores.argtypes = [POINTER(ModeGemmDesc)]
         L.sc_modegemm_uses_matrix_cores.restype = c_int
         L.sc_modegemm_path.argtypes = [POINTER(ModeGemmDesc)]
@@ -428,8 +430,12 @@ class ScEngineLib:
         self._check(self.lib.sc_modegemm_msum(byref(self._gemm_desc(kw)), a_ptr, b_ptr, c_ptr, stream))
 
     def modegemm_msum_workspace_bytes(self, **kw):
-        """Bytes of workspace sc_modegemm_msum_ws needs for this problem; 0 = it does not qualify (use modegemm_msum)."""
+        """Bytes of workspace sc_modegemm_msum_ws needs for this problem (0: empty problem)."""
         return int(self.lib.sc_modegemm_msum_workspace_bytes(byref(self._gemm_desc(kw))))
+
+    def modegemm_msum_path(self, **kw):
+        """1: sc_modegemm_msum_ws runs the matrix-core kernel, 0: the slot form of the VALU kernel."""
+        return int(self.lib.sc_modegemm_msum_path(byref(self._gemm_desc(kw))))
 
     def modegemm_msum_ws(self, a_ptr, b_ptr, c_ptr, ws_ptr, ws_bytes, stream=0, **kw):
         """C[p, q] = sum over modes and r, OVERWRITTEN (matrix-core kernel + fixed-order reduction)."""

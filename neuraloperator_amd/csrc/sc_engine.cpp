@@ -1930,9 +1930,8 @@ extern "C" int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modeg
 #endif
 }
 
-template <bool CA, bool CB>
-static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
-  ModeGemmArgs g = g0;
+// launch geometry of k_modegemm_msum; returns the number of (mode split, r split) slots
+static int64_t msum_geometry(ModeGemmArgs& g, bool* wide_out) {
   g.n_mt = (int)((g.M + SC_WAVE - 1) / SC_WAVE);
   // 4 x 8 outputs per wave (12 operand loads per 32 products) when the problem still yields enough workgroups,
   // 2 x 4 for small outputs
@@ -1940,7 +1939,7 @@ static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf
   const int PT = wide ? 4 : 2, QT = wide ? 8 : 4;
   g.n_pg = (int)((g.P + 4 * PT - 1) / (4 * PT));
   g.n_qt = (int)((g.Q + QT - 1) / QT);
-  // mode splits: enough workgroups to fill the chip (~4096), as few atomic adds per output as that allows
+  // mode splits: enough workgroups to fill the chip (~4096), as few partial sums per output as that allows
   int64_t splits = 4096 / ((int64_t)g.n_pg * g.n_qt);
   if (splits < 1) splits = 1;
   if (splits > g.n_mt) splits = g.n_mt;
@@ -1952,9 +1951,26 @@ static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf
   int64_t rsplit = rsplit_env > 0 ? rsplit_env : 1;
   if (rsplit > g.R) rsplit = g.R;
   g.r_split = (int)rsplit;
-  const int64_t total = splits * g.n_pg * g.n_qt * rsplit;
-  if (wide) SC_LAUNCH((k_modegemm_msum<4, 8, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
-  else SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
+  *wide_out = wide;
+  return splits * rsplit;
+}
+
+template <bool CA, bool CB, bool PART = false>
+static void launch_msum(const ModeGemmArgs& g0, const cf32* A, const cf32* B, cf32* C, sc_stream_t st) {
+  ModeGemmArgs g = g0;
+  bool wide;
+  const int64_t total = msum_geometry(g, &wide) * g.n_pg * g.n_qt;
+  if (wide) SC_LAUNCH((k_modegemm_msum<4, 8, CA, CB, PART>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
+  else SC_LAUNCH((k_modegemm_msum<2, 4, CA, CB, PART>), dim3((unsigned)total), dim3(SC_BLOCK), 0, st, g, A, B, C);
+}
+
+static void msum_args(const sc_modegemm_desc* d, ModeGemmArgs& g) {
+  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
+  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.a_sm = d->a_sm;
+  g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.b_sm = d->b_sm;
+  g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = 0;
+  g.b_idx = d->b_idx; g.c_idx = nullptr;
+  g.accumulate = 1;
 }
 
 /* C[p,q] += sum_m sum_r opA(A[p,r,m]) opB(B[r,q,m]); C (strides c_sp, c_sq) zeroed by the caller */
@@ -1964,12 +1980,7 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
   SC_CHECK_ARG(d->P >= 0 && d->Q >= 0 && d->R >= 0 && d->n_modes >= 0, "negative extent");
   if (d->P == 0 || d->Q == 0 || d->n_modes == 0 || d->R == 0) return 0;
   ModeGemmArgs g;
-  g.P = d->P; g.Q = d->Q; g.R = d->R; g.M = d->n_modes;
-  g.a_sp = d->a_sp; g.a_sr = d->a_sr; g.a_sm = d->a_sm;
-  g.b_sr = d->b_sr; g.b_sq = d->b_sq; g.b_sm = d->b_sm;
-  g.c_sp = d->c_sp; g.c_sq = d->c_sq; g.c_sm = 0;
-  g.b_idx = d->b_idx; g.c_idx = nullptr;
-  g.accumulate = 1;
+  msum_args(d, g);
   SC_CHECK_ARG(((g.P + 7) / 8) * ((g.Q + 3) / 4) < ((int64_t)1 << 30) && (g.M + 63) / 64 < ((int64_t)1 << 31),
                "problem too large for one launch grid");
   sc_stream_t st = (sc_stream_t)stream;
@@ -1984,29 +1995,61 @@ extern "C" int sc_modegemm_msum(const sc_modegemm_desc* d, const float* A, const
 }
 
 // C[p, q] = sum over modes and r (OVERWRITTEN, not accumulated) with a caller-provided workspace: the matrix-core
-// kernel + fixed-order reduction of sc_kernels_fmx.h where the problem qualifies (workspace_bytes > 0), else the
-// caller uses sc_modegemm_msum on a zeroed C
+// kernel of sc_kernels_fmx.h where the problem qualifies, else k_modegemm_msum<PART>; one partial per workgroup /
+// slot and a fixed-order reduction either way (bit-reproducible, unlike the atomics of sc_modegemm_msum)
+static bool msum_slots_ok(const sc_modegemm_desc* d) {
+  return ((d->P + 7) / 8) * ((d->Q + 3) / 4) < ((int64_t)1 << 30) && (d->n_modes + 63) / 64 < ((int64_t)1 << 31) &&
+         d->P * d->Q < ((int64_t)1 << 31);
+}
 extern "C" size_t sc_modegemm_msum_workspace_bytes(const sc_modegemm_desc* d) {
-  if (!d || d->P <= 0 || d->Q <= 0 || d->n_modes <= 0 || d->R <= 0 || !fmx_msum_eligible(d)) return 0;
+  if (!d || d->P <= 0 || d->Q <= 0 || d->n_modes <= 0 || d->R <= 0) return 0;
+  if (!fmx_msum_eligible(d)) {
+    if (!msum_slots_ok(d)) return 0;
+    ModeGemmArgs mg;
+    msum_args(d, mg);
+    bool wide;
+    return (size_t)msum_geometry(mg, &wide) * (size_t)(d->P * d->Q) * sizeof(cf32) + 256;
+  }
   FmxArgs g;
   size_t lds;
   fmx_msum_args(d, g, lds);
   return (size_t)g.n_wg * (size_t)(d->P * d->Q) * sizeof(cf32) + 256;
 }
 
+extern "C" int sc_modegemm_msum_path(const sc_modegemm_desc* d) {
+  return d && d->P > 0 && d->Q > 0 && d->n_modes > 0 && d->R > 0 && fmx_msum_eligible(d) ? 1 : 0;
+}
+
 extern "C" int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, const float* B, float* C, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   SC_CHECK_ARG(d && A && B && C && workspace, "null argument");
   SC_CHECK_ARG(d->P > 0 && d->Q > 0 && d->R > 0 && d->n_modes > 0, "empty extent");
-  SC_CHECK_ARG(fmx_msum_eligible(d), "sc_modegemm_msum_ws: the problem does not qualify (sc_modegemm_msum_workspace_bytes == 0)");
+  SC_CHECK_ARG(fmx_msum_eligible(d) || msum_slots_ok(d),
+               "sc_modegemm_msum_ws: the problem does not qualify (sc_modegemm_msum_workspace_bytes == 0)");
   SC_CHECK_ARG(workspace_bytes >= sc_modegemm_msum_workspace_bytes(d), "workspace too small");
-  FmxArgs g;
-  size_t lds;
-  fmx_msum_args(d, g, lds);
   sc_stream_t st = (sc_stream_t)stream;
   cf32* partial = (cf32*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const cf32* a = (const cf32*)A;
   const cf32* b = (const cf32*)B;
+  if (!fmx_msum_eligible(d)) {
+    ModeGemmArgs mg;
+    msum_args(d, mg);
+    bool wide;
+    const int64_t slots = msum_geometry(mg, &wide);
+    if (!d->conj_a && !d->conj_b) launch_msum<false, false, true>(mg, a, b, partial, st);
+    else if (d->conj_a && !d->conj_b) launch_msum<true, false, true>(mg, a, b, partial, st);
+    else if (!d->conj_a && d->conj_b) launch_msum<false, true, true>(mg, a, b, partial, st);
+    else launch_msum<true, true, true>(mg, a, b, partial, st);
+    int rc = sc_check_launch("k_modegemm_msum<slots>");
+    if (rc) return rc;
+    const int npc = (int)(d->P * d->Q);
+    SC_LAUNCH(k_fmx_reduce, dim3((unsigned)((npc + 15) / 16)), dim3(256), 0, st, (const cf32*)partial, (int)slots, npc,
+              (int)d->Q, (cf32*)C, d->c_sp, d->c_sq);
+    return sc_check_launch("k_fmx_reduce");
+  }
+  FmxArgs g;
+  size_t lds;
+  fmx_msum_args(d, g, lds);
   const int64_t pa = (d->P + 3) / 4, pb = (d->Q + 3) / 4;
   int rc;
   if (pa <= 16 && pb <= 9 && d->Q <= 48) rc = run_fmx_msum_t<16, 9, 3>(d, g, lds, a, b, partial, st);

@@ -361,8 +361,12 @@ k_round_f16(const float* __restrict__ in, float* __restrict__ out, int64_t n, in
 // (per_xcd = number of mode splits here) with per-lane partial sums, then ONE wave reduction and one
 // atomic add per (p, q).  (One atomic per mode TILE was 729 adds onto each of 627 addresses for a
 // 19 x 33 gradient over 46656 modes: 300 us of atomic serialisation.)  C must be zeroed by the caller.
+// PART (session 2): no atomics -- every (mode split, r split) pair owns one slot [P][Q] of a workspace that C points
+// at, written exactly once per (p, q); k_fmx_reduce then adds the slots in a fixed order, so that the result is the
+// same bits on every run (float atomics land in arrival order: the small Tucker / CP factor gradients that take this
+// kernel differed in the last bits from run to run, seen by the hipGraph-against-eager test).
 // ------------------------------------------------------------------------------------------
-template <int PT, int QT, bool CA, bool CB>
+template <int PT, int QT, bool CA, bool CB, bool PART = false>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(SC_BLOCK)
 k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__ B,
                 cf32* __restrict__ C) {
@@ -437,12 +441,17 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
       const int i = (h0 + lane) >> 1;
       const int pp = i / QT, qq = i % QT;
       if (wave_on && p0 + pp < g.P && q0 + qq < g.Q) {
-        float* dst = reinterpret_cast<float*>(C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq) + ((h0 + lane) & 1);
+        if (PART) {
+          const int64_t slot = (int64_t)ms * rsp + rs;
+          reinterpret_cast<float*>(C + (slot * g.P + p0 + pp) * g.Q + (q0 + qq))[(h0 + lane) & 1] = sum;
+        } else {
+          float* dst = reinterpret_cast<float*>(C + (p0 + pp) * g.c_sp + (q0 + qq) * g.c_sq) + ((h0 + lane) & 1);
 #ifndef SC_EMU
-        atomicAdd(dst, sum);
+          atomicAdd(dst, sum);
 #else
-        *dst += sum;      // emulated workgroups run one after another, waves own different p
+          *dst += sum;      // emulated workgroups run one after another, waves own different p
 #endif
+        }
       }
     }
     SC_WAVE_SYNC();

@@ -1,0 +1,57 @@
+"""hipGraph replay of one forward + backward step.
+
+The engine's passes are plain kernel launches on PyTorch's current stream, so a whole step -- ``module(x)`` and the
+autograd backward of its result -- records into one hipGraph (``torch.cuda.CUDAGraph``) and replays with ONE host
+call.  It pays where the eager step is bound by the host's issue rate (~0.18 ms per SpectralConv step on the
+round-3 box: a 2-D 64 x 64 grid with B = 64, C = 64 needs 0.146 ms of GPU time -- profiles/r03s2_graph_step_time.txt);
+large grids are GPU-bound either way.  Results are bit-identical to the eager step (tests/test_gpu_graph.py).
+
+A graph replays fixed addresses: ``x`` and ``grad_out`` are STATIC tensors (refill them in place with ``copy_``),
+``step.output``, ``x.grad`` and every parameter's ``.grad`` are rewritten by each replay -- do not set them to None
+between replays (``zero_grad(set_to_none=True)`` would detach the optimizer from the memory the graph writes).
+Reference lines: the step this replays is spectral_convolution.py:419-571 and its autograd backward.
+"""
+import torch
+
+__all__ = ["GraphedStep", "capture_step"]
+
+
+class GraphedStep:
+    """One captured forward + backward of ``module`` at ``x`` with the output gradient ``grad_out``."""
+
+    def __init__(self, module, x, grad_out, warmup=3):
+        if not (x.is_cuda and grad_out.is_cuda):
+            raise RuntimeError("GraphedStep: hipGraph capture needs device tensors (there is no CPU path)")
+        self.module, self.x, self.grad_out = module, x, grad_out
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):                    # plans, tables and workspaces are created outside the capture
+            for _ in range(max(int(warmup), 1)):
+                self._clear()
+                module(x).backward(grad_out)
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        self._clear()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.output = module(x)
+            self.output.backward(grad_out)
+        self.output = self.output.detach()
+
+    def _clear(self):
+        if self.x.requires_grad:
+            self.x.grad = None
+        for p in self.params:
+            p.grad = None
+
+    def replay(self):
+        """Run the step again on the current contents of ``x`` / ``grad_out`` / the parameters; returns the (static)
+        output tensor.  Gradients are OVERWRITTEN, not accumulated."""
+        self.graph.replay()
+        return self.output
+
+    __call__ = replay
+
+
+def capture_step(module, x, grad_out, warmup=3):
+    return GraphedStep(module, x, grad_out, warmup)

@@ -105,10 +105,32 @@ def test_mode_summed_contraction(lib, dims, conj):
 def test_mode_summed_limits(lib):
     kw = dict(P=64, Q=36, R=4, n_modes=128, a_sp=128, a_sr=64 * 128, a_sm=1, b_sr=36 * 128, b_sq=128, b_sm=1, c_sp=36,
               c_sq=1, c_sm=0)
-    assert lib.modegemm_msum_workspace_bytes(**kw) > 0
-    assert lib.modegemm_msum_workspace_bytes(**{**kw, "P": 65}) == 0
-    assert lib.modegemm_msum_workspace_bytes(**{**kw, "Q": 4}) == 0
-    assert lib.modegemm_msum_workspace_bytes(**{**kw, "b_sm": 0}) == 0
-    assert lib.modegemm_msum_workspace_bytes(flags=_lib.SC_GEMM_NO_FMX, **kw) == 0
+    assert lib.modegemm_msum_workspace_bytes(**kw) > 0 and lib.modegemm_msum_path(**kw) == 1
+    # outside the matrix-core kernel's shapes: the slot form of the VALU kernel (still a workspace, still no atomics)
+    for other in ({**kw, "P": 65}, {**kw, "Q": 4}, {**kw, "b_sm": 0}, {**kw, "flags": _lib.SC_GEMM_NO_FMX}):
+        assert lib.modegemm_msum_path(**other) == 0 and lib.modegemm_msum_workspace_bytes(**other) > 0
     with pytest.raises(Exception):
         lib.modegemm_msum_ws(0, 0, 0, 0, 0, 0, **kw)
+
+
+@pytest.mark.parametrize("dims", [(6, 3, 5, 150), (10, 4, 7, 64), (19, 2, 33, 60), (65, 3, 36, 130)], ids=str)
+@pytest.mark.parametrize("conj", [(1, 0), (0, 0)], ids=["conjA", "plain"])
+def test_mode_summed_contraction_slot_form(lib, dims, conj):
+    """Shapes the matrix-core kernel refuses (small Tucker / CP factors, P > 64): sc_modegemm_msum_ws runs the VALU
+    kernel with one workspace slot per (mode split, r split) and the fixed-order reduction -- no atomics."""
+    P, R, Q, M = dims
+    ca, cb = conj
+    act = _rand(R, P, M, seed=21)
+    a = act.transpose(0, 1)
+    b = _rand(R, Q, M, seed=22)
+    kw = dict(P=P, Q=Q, R=R, n_modes=M, a_sp=a.stride(0), a_sr=a.stride(1), a_sm=1, b_sr=Q * M, b_sq=M, b_sm=1,
+              conj_a=ca, conj_b=cb, c_sp=Q, c_sq=1, c_sm=0)
+    assert lib.modegemm_msum_path(**kw) == 0
+    nbytes = lib.modegemm_msum_workspace_bytes(**kw)
+    assert nbytes > 0
+    ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8)                 # NaN patterns: every slot must be written
+    c = torch.full((P, Q), float("nan"), dtype=torch.complex64)
+    lib.modegemm_msum_ws(_p(act), _p(b), _p(c), ws.data_ptr(), nbytes, 0, **kw)
+    a128, b128 = a.numpy().astype(np.complex128), b.numpy().astype(np.complex128)
+    ref = np.einsum("prm,rqm->pq", np.conj(a128) if ca else a128, np.conj(b128) if cb else b128)
+    assert rel_l2(c.numpy(), ref) < 1e-5
