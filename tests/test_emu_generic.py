@@ -192,7 +192,8 @@ def test_plane_kernels_match_oracle(lib, case):
     yo.backward(g)
     # 128 x 128 planes with a kept block <= 32 x 17 have their own factorised kernels (sc_kernels_plane.h, tested in
     # test_emu_plane128.py); SC_PLAN_FORCE_GENERIC keeps such a plan on the direct-DFT plane kernels tested here
-    fft_plane = list(spatial[-2:]) == [128, 128] and nm[-2] <= 32 and nm[-1] <= 17
+    # (session 2: the same for 64 x 64 planes, sc_kernels_plane64.h / test_emu_plane64.py)
+    fft_plane = list(spatial[-2:]) in ([128, 128], [64, 64]) and nm[-2] <= 32 and nm[-1] <= 17
     flags = _lib.SC_PLAN_FORCE_GENERIC if fft_plane else 0
     plan = lib.plan_create(list(spatial), list(nm), flags=flags)
     fused = 2 * nm[-2] <= spatial[-2]
