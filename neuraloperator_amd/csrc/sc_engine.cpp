@@ -892,8 +892,13 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
   if (p->pl64) {
     const int L = p->nd - 1;
     if (((uintptr_t)in) & 15) return sc_fail("sc_engine: the 64 x 64 plane kernels need 16-byte aligned planes");
-    SC_LAUNCH(k_pl64_fwd, dim3((unsigned)(lines / SC_P64_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
-              (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L]);
+    // planes per workgroup: the next plane's rows are in flight while this one is transformed (A-B: SC_P64_PPW)
+    static const int ppw_env = [] { const char* e = std::getenv("SC_P64_PPW"); return e ? std::atoi(e) : 0; }();
+    const int64_t n_planes = lines / SC_P64_N;
+    int ppw = ppw_env > 0 ? ppw_env : SC_P64_PPW_DEFAULT;
+    while (ppw > 1 && n_planes / ppw < (int64_t)8 * sc_cu_count()) --ppw;     // keep two full rounds of workgroups
+    SC_LAUNCH(k_pl64_fwd, dim3((unsigned)((n_planes + ppw - 1) / ppw)), dim3(256), 0, st, in, out,
+              (const cf32*)p->pl_tab128, (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L], n_planes, ppw);
     return sc_check_launch("k_pl64_fwd");
   }
   const bool tail = p->l_r2c_tail[mode] != nullptr;

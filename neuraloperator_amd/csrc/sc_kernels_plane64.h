@@ -27,6 +27,10 @@
 #define SC_P64_SS 68          // staging row stride (floats)
 #define SC_P64_JMAX 17
 #define SC_P64_KMAX 32
+#ifndef SC_P64_PPW_DEFAULT
+#define SC_P64_PPW_DEFAULT 2  // planes per workgroup of the forward kernel (sc_engine.cpp; environment SC_P64_PPW overrides): 4096 planes
+                              // 21.5 -> 19.7 us, 16384 planes 68 -> 65.5 us (profiles/r03s2_pl64_ppw_ab.txt)
+#endif
 
 struct P64Lds {
   static constexpr int T_c = SC_P64_N * SC_P64_RS;               // 1280 complex
@@ -45,34 +49,42 @@ struct P64Lds {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// ppw consecutive planes per workgroup (host: SC_P64_PPW): the rows of plane i + 1 are requested as soon as those of
+// plane i have been staged, so a workgroup has loads in flight while it transforms
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
 k_pl64_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __restrict__ tab64,
-           const float* __restrict__ cs, int K0, int J) {
+           const float* __restrict__ cs, int K0, int J, int64_t n_planes, int ppw) {
   SC_SHARED __attribute__((aligned(16))) cf32 lds[P64Lds::total_c];
   cf32* T = lds + P64Lds::off_T;
   cf32* tabl = lds + P64Lds::off_tab;
+  cf32* OUT = lds + P64Lds::off_IO;
   const int tid = SC_TID, w = tid >> 6, lane = tid & 63;
-  const int64_t plane = SC_BID_X;
-  const float* xp = x + plane * (int64_t)(SC_P64_N * SC_P64_N);
-  // ---------------- rows: the plane's 32 packed row pairs at once ----------------
-  {
-    const int gl = lane >> 3, t = lane & 7, p = tid >> 3;
-    cf32* Ew = lds + P64Lds::off_E + w * P64Lds::Ew_c;   // this wave's exchange / staging / Z area
-    float* stg = reinterpret_cast<float*>(Ew);
-    sc_f4 ld[4];
-    {
-      const sc_f4* src = reinterpret_cast<const sc_f4*>(xp + w * (16 * SC_P64_N)) + lane;
+  const int64_t plane0 = (int64_t)SC_BID_X * ppw;
+  const int gl = lane >> 3, t = lane & 7, p = tid >> 3;
+  cf32* Ew = lds + P64Lds::off_E + w * P64Lds::Ew_c;     // this wave's exchange / staging / Z area
+  float* stg = reinterpret_cast<float*>(Ew);
+  sc_f4 ld[4];
+  auto request = [&](const int64_t plane) {
+    const int64_t pl = plane < n_planes ? plane : n_planes - 1;         // past the end: a harmless re-read
+    const sc_f4* src = reinterpret_cast<const sc_f4*>(x + pl * (int64_t)(SC_P64_N * SC_P64_N) + w * (16 * SC_P64_N)) + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ld[i] = SC_LOAD_STREAM(src + 64 * i);
-    }
-    if (tid < SC_P64_N) tabl[tid] = tab64[tid];
-    SC_SYNC();                                           // the table (the rows are in flight meanwhile)
-    cf32 tw1[8];
+    for (int i = 0; i < 4; ++i) ld[i] = SC_LOAD_STREAM(src + 64 * i);
+  };
+  request(plane0);
+  if (tid < SC_P64_N) tabl[tid] = tab64[tid];
+  SC_SYNC();                                             // the table (the rows are in flight meanwhile)
+  cf32 tw1[8];
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = sc_lds_ld64(tabl + ((t * k1) & 63));
+  for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = sc_lds_ld64(tabl + ((t * k1) & 63));
+#pragma unroll 1
+  for (int it = 0; it < ppw; ++it) {
+    const int64_t plane = plane0 + it;
+    if (plane >= n_planes) break;                        // uniform
+    // ---------------- rows: the plane's 32 packed row pairs at once ----------------
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<sc_f4*>(stg + (4 * i + (lane >> 4)) * SC_P64_SS + 4 * (lane & 15)) = ld[i];
+    if (it + 1 < ppw) request(plane + 1);
     SC_WAVE_SYNC();
     cf32 a[8], u[8];
     {
@@ -87,65 +99,66 @@ k_pl64_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __re
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) E[k1 * SC_P64_ES + t] = cf_mul_cs(u[k1], tw1[k1]);
     SC_WAVE_SYNC();
-    cf32 y[8], o[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E + t * SC_P64_ES + q);
-    dft8<-1>(y, o);                                      // over t -> k2: Z[t + 8 k2]
-    SC_WAVE_SYNC();                                      // ... and then Z[-16..16] of the wave's 8 row pairs
-    cf32* Zs = Ew + gl * 34;
-    Zs[16 + t] = o[0];
-    Zs[24 + t] = o[1];
-    Zs[8 + t] = o[7];
-    Zs[t] = o[6];
-    if (t == 0) Zs[32] = o[2];
-    SC_WAVE_SYNC();
-    // A = (Z[k] + conj Z[-k]) / 2, B = -i (Z[k] - conj Z[-k]) / 2 (the 1/2 rides on the column scale)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = t + 8 * h;
-      const cf32 zk = Zs[16 + c], zm = Zs[16 - c];
-      T[(2 * p) * SC_P64_RS + c] = cf_make(zk.x + zm.x, zk.y - zm.y);
-      T[(2 * p + 1) * SC_P64_RS + c] = cf_make(zk.y + zm.y, zm.x - zk.x);
-    }
-    if (t == 0) {
-      const cf32 zt = Zs[32], zb = Zs[0];
-      T[(2 * p) * SC_P64_RS + 16] = cf_make(zt.x + zb.x, zt.y - zb.y);
-      T[(2 * p + 1) * SC_P64_RS + 16] = cf_make(zt.y + zb.y, zb.x - zt.x);
-    }
-  }
-  SC_SYNC();
-  // ---------------- columns: 8 lanes per kept column ----------------
-  cf32* OUT = lds + P64Lds::off_IO;
-  {
-    const int c = tid >> 3, t = tid & 7;
-    const bool act = c < SC_P64_JMAX;                    // waves 0, 1 and the first group of wave 2
-    cf32* E2 = lds + P64Lds::off_E + (act ? c : 0) * 72;
-    if (act) {
-      cf32 v[8], u[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = sc_lds_ld64(T + (t + 8 * j) * SC_P64_RS + c);
-      dft8<-1>(v, u);                                    // over j -> k1
-      E2[t] = u[0];
-#pragma unroll
-      for (int k1 = 1; k1 < 8; ++k1) E2[k1 * SC_P64_ES + t] = cf_mul_cs(u[k1], sc_lds_ld64(tabl + ((t * k1) & 63)));
-    }
-    SC_WAVE_SYNC();
-    if (act && c < J) {
-      const float s = cs[c];
+    {
       cf32 y[8], o[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + t * SC_P64_ES + q);
-      dft8<-1>(y, o);                                    // over t -> k2: k = t + 8 k2; kept: k2 = 0, 1, -1, -2
-      const int r0 = t + K0 / 2;
-      if (r0 < K0) OUT[r0 * J + c] = cf_scale(o[0], s);
-      if (r0 + 8 < K0) OUT[(r0 + 8) * J + c] = cf_scale(o[1], s);
-      if (r0 - 8 >= 0) OUT[(r0 - 8) * J + c] = cf_scale(o[7], s);
-      if (r0 - 16 >= 0) OUT[(r0 - 16) * J + c] = cf_scale(o[6], s);
+      for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E + t * SC_P64_ES + q);
+      dft8<-1>(y, o);                                    // over t -> k2: Z[t + 8 k2]
+      SC_WAVE_SYNC();                                    // ... and then Z[-16..16] of the wave's 8 row pairs
+      cf32* Zs = Ew + gl * 34;
+      Zs[16 + t] = o[0];
+      Zs[24 + t] = o[1];
+      Zs[8 + t] = o[7];
+      Zs[t] = o[6];
+      if (t == 0) Zs[32] = o[2];
+      SC_WAVE_SYNC();
+      // A = (Z[k] + conj Z[-k]) / 2, B = -i (Z[k] - conj Z[-k]) / 2 (the 1/2 rides on the column scale)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = t + 8 * h;
+        const cf32 zk = Zs[16 + c], zm = Zs[16 - c];
+        T[(2 * p) * SC_P64_RS + c] = cf_make(zk.x + zm.x, zk.y - zm.y);
+        T[(2 * p + 1) * SC_P64_RS + c] = cf_make(zk.y + zm.y, zm.x - zk.x);
+      }
+      if (t == 0) {
+        const cf32 zt = Zs[32], zb = Zs[0];
+        T[(2 * p) * SC_P64_RS + 16] = cf_make(zt.x + zb.x, zt.y - zb.y);
+        T[(2 * p + 1) * SC_P64_RS + 16] = cf_make(zt.y + zb.y, zb.x - zt.x);
+      }
     }
+    SC_SYNC();
+    // ---------------- columns: 8 lanes per kept column ----------------
+    {
+      const int c = tid >> 3;
+      const bool act = c < SC_P64_JMAX;                  // waves 0, 1 and the first group of wave 2
+      cf32* E2 = lds + P64Lds::off_E + (act ? c : 0) * 72;
+      if (act) {
+        cf32 v[8], u2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sc_lds_ld64(T + (t + 8 * j) * SC_P64_RS + c);
+        dft8<-1>(v, u2);                                 // over j -> k1
+        E2[t] = u2[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) E2[k1 * SC_P64_ES + t] = cf_mul_cs(u2[k1], tw1[k1]);
+      }
+      SC_WAVE_SYNC();
+      if (act && c < J) {
+        const float s = cs[c];
+        cf32 y[8], o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + t * SC_P64_ES + q);
+        dft8<-1>(y, o);                                  // over t -> k2: k = t + 8 k2; kept: k2 = 0, 1, -1, -2
+        const int r0 = t + K0 / 2;
+        if (r0 < K0) OUT[r0 * J + c] = cf_scale(o[0], s);
+        if (r0 + 8 < K0) OUT[(r0 + 8) * J + c] = cf_scale(o[1], s);
+        if (r0 - 8 >= 0) OUT[(r0 - 8) * J + c] = cf_scale(o[7], s);
+        if (r0 - 16 >= 0) OUT[(r0 - 16) * J + c] = cf_scale(o[6], s);
+      }
+    }
+    SC_SYNC();                                           // also: the column exchange is free for the next plane's staging
+    cf32* dst = out + plane * (int64_t)K0 * J;
+    for (int i = tid; i < K0 * J; i += 256) dst[i] = OUT[i];
   }
-  SC_SYNC();
-  cf32* dst = out + plane * (int64_t)K0 * J;
-  for (int i = tid; i < K0 * J; i += 256) dst[i] = OUT[i];
 }
 
 // ------------------------------------------------------------------------------------------
