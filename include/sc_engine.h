@@ -245,7 +245,14 @@ int sc_tucker_modes_backward(const sc_tucker_desc* d, const float* core, const f
  * u_in (Cin, R1), t3 (R1, R2, M), u_out (Cout, R2), z (B, R1, M), t (B, R2, M), yhat (B, Cout, M).
  * Backward: gy (B, Cout, M) in; gxhat (B, Cin, M), gu_in (Cin, R1), gt3 (R1, R2, M), gu_out (Cout, R2) overwritten
  * (a null pointer skips that gradient); workspace: sc_tucker_chain_workspace_bytes (holds gt, gz and the partial
- * sums of the two factor gradients). */
+ * sums of the two factor gradients).
+ * The backward call uses TWO streams (session 2): gt, gt3, gxhat on `stream`, the factor gradients and gz on a
+ * non-blocking stream the engine owns, forked from and joined back into `stream` with events (no host
+ * synchronisation; records into a hipGraph as a fork / join): everything the call issued is complete, in `stream`'s
+ * order, when work issued to `stream` afterwards runs.  The launches are latency-bound and only partly dependent; side
+ * by side the six take 146 instead of 193 us under the profiler, 0.735 -> 0.721 ms per TFNO step
+ * (profiles/r03s2_tfno_two_streams_ab.txt, _timeline.txt).  Same kernels, same bits.  SC_NO_SIDE_STREAM=1
+ * (environment) keeps every launch on `stream`. */
 typedef struct sc_tucker_chain_desc {
   int64_t batch, c_in, c_out, r_in, r_out, n_modes;
 } sc_tucker_chain_desc;

@@ -129,6 +129,45 @@ static inline int sc_cu_count() {
   return cached[dev];
 }
 
+// ---- a second stream of the engine's own (session 2): INDEPENDENT small launches of one host call (the factor
+// gradients of the Tucker chain beside its activation products) run side by side instead of in a row -- each of them
+// alone leaves most of the chip waiting on its own latencies.  sc_side_fork: the side stream waits for everything
+// issued to `main` so far; sc_side_join: `main` waits for everything issued to the side stream so far.  Events only,
+// no host synchronisation, so the pattern also records into a hipGraph as a fork / join.  One set per device, created
+// on first use; SC_NO_SIDE_STREAM=1 (environment) or any creation failure -> nullptr = the caller stays on one stream.
+struct ScSide {
+  hipStream_t stream;
+  hipEvent_t fork_ev[4], join_ev[4];
+  int n_fork, n_join;
+};
+static inline ScSide* sc_side_get() {
+  static ScSide* cached[64] = {nullptr};
+  static bool tried[64] = {false};
+  static const bool off = [] { const char* e = getenv("SC_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
+  if (off) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!tried[dev]) {
+    tried[dev] = true;
+    ScSide* s = new ScSide();
+    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 4; ++i)
+      ok = hipEventCreateWithFlags(&s->fork_ev[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s->join_ev[i], hipEventDisableTiming) == hipSuccess;
+    s->n_fork = s->n_join = 0;
+    cached[dev] = ok ? s : nullptr;
+  }
+  return cached[dev];
+}
+static inline bool sc_side_fork(ScSide* s, hipStream_t main) {
+  hipEvent_t e = s->fork_ev[s->n_fork++ & 3];
+  return hipEventRecord(e, main) == hipSuccess && hipStreamWaitEvent(s->stream, e, 0) == hipSuccess;
+}
+static inline bool sc_side_join(ScSide* s, hipStream_t main) {
+  hipEvent_t e = s->join_ev[s->n_join++ & 3];
+  return hipEventRecord(e, s->stream) == hipSuccess && hipStreamWaitEvent(main, e, 0) == hipSuccess;
+}
+
 #else
 // --------------------------------------------------------------------------- host emulation
 #include <cstdlib>
@@ -240,6 +279,13 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 // the emulated "chip" has ONE compute unit: persistent kernels then walk several work items per workgroup in the
 // CPU tier, which is what their loops and cross-item prefetches need to be tested on
 inline int sc_cu_count() { return 1; }
+// emulated launches are synchronous: there is no second stream
+struct ScSide {
+  sc_stream_t stream;
+};
+inline ScSide* sc_side_get() { return nullptr; }
+inline bool sc_side_fork(ScSide*, sc_stream_t) { return true; }
+inline bool sc_side_join(ScSide*, sc_stream_t) { return true; }
 #endif
 
 // compile-time integer tag (selects a template body from a wave-uniform runtime value)

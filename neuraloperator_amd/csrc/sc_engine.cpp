@@ -2150,29 +2150,42 @@ extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const flo
   unsigned char* wred = (unsigned char*)gz + tkc_align((size_t)B * R1 * M * sizeof(cf32));
   const size_t wred_bytes = workspace_bytes - (size_t)(wred - (unsigned char*)workspace);
   int rc;
+  // Two streams (session 2): the six launches are small, latency-bound and only partly dependent, so the factor
+  // gradients and gz run on the engine's side stream beside gt / gt3 / gxhat:
+  //     main:  gt ----------> gt3 ---------> [gz ready] gxhat
+  //     side:  gu_out -> [gt ready] gz ----> gu_in                      (the two reductions share `wred`: same stream)
+  // Without a side stream (emulation, SC_NO_SIDE_STREAM=1) the same launches are issued in this order on `stream`.
+  sc_stream_t main = (sc_stream_t)stream;
+  ScSide* side = sc_side_get();
+  void* ss = side ? (void*)side->stream : stream;
+  const char* sync_fail = "sc_tucker_chain_backward: event record / wait failed";
+  if (side && !sc_side_fork(side, main)) return sc_fail(sync_fail);                 // the inputs are ready
   // yhat = t u_out^T:  gt = gy conj(u_out);  gu_out[o, g] = sum_{b, m} conj(t[b, g, m]) gy[b, o, m]
   sc_modegemm_desc d = tkc_desc(B, R2, Co, M, Co * M, M, 1, R2, 1, 0, R2 * M, M, 1, 0, 1);
   if ((rc = sc_modegemm(&d, gy, u_out, gt, stream))) return rc;
   if (gu_out) {
     d = tkc_gu_out_desc(c);
-    if ((rc = tkc_factor_grad(&d, t, gy, gu_out, Co * R2, wred, wred_bytes, stream))) return rc;
+    if ((rc = tkc_factor_grad(&d, t, gy, gu_out, Co * R2, wred, wred_bytes, ss))) return rc;
   }
+  if (side && !sc_side_fork(side, main)) return sc_fail(sync_fail);                 // gt is ready
   // t = z t3:  gz = gt t3^H;  gt3[f, g, m] = sum_b conj(z[b, f, m]) gt[b, g, m]
   d = tkc_desc(B, R1, R2, M, R2 * M, M, 1, M, R2 * M, 1, R1 * M, M, 1, 0, 1);
-  if ((rc = sc_modegemm(&d, gt, t3, gz, stream))) return rc;
+  if ((rc = sc_modegemm(&d, gt, t3, gz, ss))) return rc;
   if (gt3) {
     d = tkc_desc(R1, R2, B, M, M, R1 * M, 1, R2 * M, M, 1, R2 * M, M, 1, 1, 0);
     if ((rc = sc_modegemm(&d, z, gt, gt3, stream))) return rc;
   }
-  // z = xhat u_in:  gxhat = gz u_in^H;  gu_in[i, f] = sum_{b, m} conj(xhat[b, i, m]) gz[b, f, m]
+  if (side && !sc_side_join(side, main)) return sc_fail(sync_fail);                 // gz (and gu_out) for main, after gt3
+  if (gu_in) {
+    d = tkc_gu_in_desc(c);                                                         // gu_in[i, f] = sum conj(xhat) gz
+    if ((rc = tkc_factor_grad(&d, xhat, gz, gu_in, Ci * R1, wred, wred_bytes, ss))) return rc;
+  }
+  // z = xhat u_in:  gxhat = gz u_in^H
   if (gxhat) {
     d = tkc_desc(B, Ci, R1, M, R1 * M, M, 1, 1, R1, 0, Ci * M, M, 1, 0, 1);
     if ((rc = sc_modegemm(&d, gz, u_in, gxhat, stream))) return rc;
   }
-  if (gu_in) {
-    d = tkc_gu_in_desc(c);
-    if ((rc = tkc_factor_grad(&d, xhat, gz, gu_in, Ci * R1, wred, wred_bytes, stream))) return rc;
-  }
+  if (side && !sc_side_join(side, main)) return sc_fail(sync_fail);                 // gu_in
   return 0;
 }
 

@@ -16,12 +16,13 @@ for impl in (sys.argv[1:] or ["factorized", "reconstructed"]):
         for p in conv.parameters():
             p.grad = None
         conv(x).backward(g)
-    for _ in range(3):
+    for _ in range(int(os.environ.get('TFNO_WARM', '3'))):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(10):
+    n_steps = int(os.environ.get('TFNO_STEPS', '10'))
+    for _ in range(n_steps):
         step()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 10 * 1e3
+    ms = (time.perf_counter() - t0) / n_steps * 1e3
     print(f"Tucker rank {tuple(conv.weight.core.shape)} implementation={impl}: {ms:.3f} ms/step  {32 / ms * 1e3:.0f} samples/s")
