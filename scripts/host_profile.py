@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuraloperator_amd import SpectralConv
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-x = torch.randn(32, 64, 256, 256, device=dev, requires_grad=True)
-g = torch.randn(32, 64, 256, 256, device=dev)
+SP = int(os.environ.get("HP_GRID", "256"))
+x = torch.randn(32, 64, SP, SP, device=dev, requires_grad=True)
+g = torch.randn(32, 64, SP, SP, device=dev)
 kw = dict(factorization="tucker", rank=0.1, implementation="factorized") if "tucker" in sys.argv else {}
-conv = SpectralConv(64, 64, (64, 64), **kw).to(dev)
+conv = SpectralConv(64, 64, (min(64, SP // 2),) * 2, **kw).to(dev)
 
 
 def step():
