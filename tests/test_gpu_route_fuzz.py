@@ -1,0 +1,126 @@
+"""GPU tier: every fast transform route against the size-agnostic passes of the same library (SC_PLAN_FORCE_GENERIC) on
+seeded random shapes -- grids whose axes come from the sizes the factorised routes serve (64 ... 512, radix-3 / 5 sizes,
+3-D grids with 64- / 128-point planes), kept blocks of every parity incl. 1 and the largest a route takes, ragged image
+counts.  All four transform modes through the C-ABI; both routes compute the same pruned transform (spectral_
+convolution.py:443-449, 500-519, 531-568), so they must agree to fp32 round-off."""
+import numpy as np
+import pytest
+import torch
+
+from neuraloperator_amd import _lib
+from engine_runner import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-6
+
+
+def _cases():
+    rng = np.random.default_rng(2026)
+    axes = [64, 96, 128, 160, 192, 256, 320, 384, 512]
+    out = []
+    for _ in range(28):                                  # 2-D
+        n0, n1 = int(rng.choice(axes)), int(rng.choice(axes))
+        k0 = int(rng.integers(1, min(64, n0 // 2) + 1))
+        j = int(rng.integers(1, min(33, n1 // 2) + 1))
+        out.append(((n0, n1), (k0, j), int(rng.integers(1, 40))))
+    for _ in range(10):                                  # 3-D with 64- or 128-point planes
+        n = int(rng.choice([64, 128]))
+        d0 = int(rng.choice([n, 5, 12, 33]))
+        k0 = int(rng.integers(1, min(32, max(d0 // 2, 1)) + 1))
+        k1 = int(rng.integers(1, 33))
+        j = int(rng.integers(1, 18))
+        out.append(((d0, n, n), (k0, k1, j), int(rng.integers(1, 4))))
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("GPU tier: no GPU visible")
+    return _lib.get_lib()
+
+
+@pytest.mark.parametrize("spatial,kept,n_img", CASES,
+                         ids=["x".join(map(str, s)) + "_k" + "x".join(map(str, k)) + f"_n{n}" for s, k, n in CASES])
+def test_fast_route_matches_size_agnostic_passes(lib, spatial, kept, n_img):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(hash((spatial, kept)) & 0xFFFFFFF)
+    x = torch.randn((n_img, *spatial), generator=g).to(dev)
+    yhat = torch.randn((n_img, *kept, 2), generator=g).to(dev)
+    bias = torch.randn(n_img, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    names = {}
+    for tag, flags in (("fast", 0), ("generic", _lib.SC_PLAN_FORCE_GENERIC)):
+        plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=flags)
+        try:
+            names[tag] = lib.plan_kernel_name(plan, 0)
+            ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8, device=dev)
+            outs = []
+            for mode in (_lib.SC_FWD_SCALED, _lib.SC_FWD_ADJ_C2R):
+                xh = torch.full((n_img, *kept, 2), float("nan"), device=dev)
+                lib.transform_forward(plan, mode, x.data_ptr(), xh.data_ptr(), n_img, ws.data_ptr(), st)
+                outs.append(xh)
+            for mode, b in ((_lib.SC_INV_PADDED, bias.data_ptr()), (_lib.SC_INV_ADJ_R2C, 0)):
+                y = torch.full((n_img, *spatial), float("nan"), device=dev)
+                lib.transform_inverse(plan, mode, yhat.data_ptr(), b, n_img, y.data_ptr(), n_img, ws.data_ptr(), st)
+                outs.append(y)
+            torch.cuda.synchronize()
+            res[tag] = [o.cpu().numpy() for o in outs]
+        finally:
+            lib.plan_destroy(plan)
+    for i, (a, b) in enumerate(zip(res["fast"], res["generic"])):
+        assert np.isfinite(a).all() and np.isfinite(b).all(), f"output {i}: non-finite ({names})"
+        assert rel_l2(a, b) < TOL, f"output {i}: {names} differ"
+
+
+def _gemm_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    for _ in range(36):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                    # dense layer shapes: batch x channels, many modes
+            P, R, Q = int(rng.choice([1, 2, 4, 8, 20, 32, 33, 64])), int(rng.choice([3, 8, 32, 36, 64, 128])), int(rng.choice([5, 32, 36, 64, 128]))
+            M = int(rng.choice([8, 24, 64, 136, 544, 1000, 2112]))
+        elif kind == 1:                                  # ragged Tucker-like ranks
+            P, R, Q = int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            M = int(rng.integers(1, 700))
+        elif kind == 2:                                  # small batch against wide channels
+            P, R, Q = int(rng.choice([1, 2, 3, 4])), int(rng.choice([64, 128])), int(rng.choice([64, 128]))
+            M = int(rng.choice([512, 1026, 4096]))
+        else:                                            # tiny
+            P, R, Q, M = (int(v) for v in rng.integers(1, 9, size=4))
+        out.append((P, R, Q, M, int(rng.integers(0, 2)), int(rng.integers(0, 2))))
+    return out
+
+
+GEMM_CASES = _gemm_cases()
+
+
+@pytest.mark.parametrize("P,R,Q,M,ca,cb", GEMM_CASES, ids=[f"P{c[0]}_R{c[1]}_Q{c[2]}_M{c[3]}_c{c[4]}{c[5]}" for c in GEMM_CASES])
+def test_contraction_routes_agree(lib, P, R, Q, M, ca, cb):
+    """C[p, q, m] = sum_r opA(A[p, r, m]) opB(B[r, q, m]) (the einsum of spectral_convolution.py:21-46 and its two
+    autograd einsums): whatever kernel the dispatcher picks against the lanes-are-modes VALU kernel and a float64
+    einsum."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(P * 1000003 + R * 10007 + Q * 101 + M)
+    a = torch.randn((P, R, M, 2), generator=g)
+    b = torch.randn((R, Q, M, 2), generator=g)
+    kw = dict(P=P, Q=Q, R=R, n_modes=M, a_sp=R * M, a_sr=M, a_sm=1, b_sr=Q * M, b_sq=M, b_sm=1, c_sp=Q * M, c_sq=M, c_sm=1,
+              conj_a=ca, conj_b=cb)
+    st = torch.cuda.current_stream().cuda_stream
+    ad, bd = a.to(dev), b.to(dev)
+    outs = []
+    for flags in (0, _lib.SC_GEMM_FORCE_VALU):
+        c = torch.full((P, Q, M, 2), float("nan"), device=dev)
+        lib.modegemm(ad.data_ptr(), bd.data_ptr(), c.data_ptr(), st, flags=flags, **kw)
+        torch.cuda.synchronize()
+        outs.append(torch.view_as_complex(c.cpu()).numpy())
+    a128 = torch.view_as_complex(a).numpy().astype(np.complex128)
+    b128 = torch.view_as_complex(b).numpy().astype(np.complex128)
+    ref = np.einsum("prm,rqm->pqm", np.conj(a128) if ca else a128, np.conj(b128) if cb else b128)
+    assert rel_l2(outs[0], ref) < 2e-6 and rel_l2(outs[1], ref) < 2e-6
+    assert rel_l2(outs[0], outs[1]) < 2e-6
