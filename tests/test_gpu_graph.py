@@ -4,12 +4,14 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="GPU tier: no GPU visible")
 
 
 def _flat(t):
     return torch.view_as_real(t) if t.is_complex() else t
 
 
+@needs_gpu
 @pytest.mark.parametrize("spatial,n_modes,kw", [
     ((64, 64), (32, 32), {}),
     ((256, 256), (64, 64), {}),
@@ -54,6 +56,7 @@ def test_graph_needs_a_device():
         capture_step(lin, torch.zeros(1, 2), torch.zeros(1, 2))
 
 
+@needs_gpu
 @pytest.mark.parametrize("kw", [dict(factorization="tucker", rank=0.5, implementation="factorized"),
                                 dict(factorization="cp", rank=0.5, implementation="factorized")], ids=["tucker", "cp"])
 def test_small_factor_gradients_are_reproducible(kw):
