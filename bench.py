@@ -46,11 +46,13 @@ WORKLOADS = {
     "darcy_16_m12_c32_b4": (4, 32, (16, 16), (12, 12)),           # configs[0] shape
     "fno3d_128_m32_c32_b8": (8, 32, (128, 128, 128), (32, 32, 32)),  # configs[3] shape
     "fno2d_1024_m256_c128_b4": (4, 128, (1024, 1024), (256, 256)),   # configs[4] shape
-    # not BASELINE configs: common small grids on the size-agnostic path (plane-form passes)
+    # not BASELINE configs: common small grids (plane kernels / two-pass route)
     "fno2d_64_m32_c64_b64": (64, 64, (64, 64), (32, 32)),
     "fno2d_128_m32_c64_b32": (32, 64, (128, 128), (32, 32)),
     "fno2d_192_m64_c64_b32": (32, 64, (192, 192), (64, 64)),      # radix-3 lines (32 x 6) on the two-pass route
     "fno3d_64_m16_c32_b8": (8, 32, (64, 64, 64), (16, 16, 16)),
+    # diagnostic: the per-rank transform load of configs[3] strong-scaled over 8 GPUs (one sample per rank)
+    "fno3d_128_m32_c32_b1": (1, 32, (128, 128, 128), (32, 32, 32)),
 }
 
 
