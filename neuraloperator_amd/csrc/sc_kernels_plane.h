@@ -18,6 +18,12 @@
 #pragma once
 #include "sc_kernels_fft2p.h"
 
+// forward row loads: 16-byte accesses staged through the wave's exchange area (session 2; -DSC_PL_DIRECT_LOADS = the 4-byte
+// loads in the lanes' own order of round 3: 446-454 us against 404-421 us at FNO3d 128^3, bit-identical results,
+// profiles/r03s2_pl128_staged_loads_ab.txt)
+#if !defined(SC_PL_DIRECT_LOADS) && !defined(SC_PL_STAGED_LOADS)
+#define SC_PL_STAGED_LOADS 1
+#endif
 #define SC_PL_N 128
 #define SC_PL_RS 20          // tile row stride (complex): column-phase reads conflict-free
 #define SC_PL_ES 17          // row-phase exchange stride (per k1)
@@ -65,6 +71,22 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
 #define SC_PL_PF_DEPTH 1     // rounds of row loads in flight ahead of the one being transformed (A-B: 2)
 #endif
     cf32 pfs[SC_PL_PF_DEPTH][8];
+#ifdef SC_PL_STAGED_LOADS
+    // Session 2 (as in sc_kernels_plane64.h): a wave owns the 8 consecutive rows of its four row pairs (4 KB per round)
+    // and reads them as four 16-byte loads per lane -- one contiguous KB per instruction instead of 64-byte pieces of
+    // four rows -- into its own part of the exchange buffer (row stride 136 floats: conflict-free both ways); lanes pick
+    // up x[t + 16 j] from there.  The registers of the next round's loads are the same 16 as before.
+    const int wv = tid >> 6, lane = tid & 63;
+    float* stg = reinterpret_cast<float*>(lds + PlLds::off_E + wv * (4 * 8 * SC_PL_ES));
+    sc_f4 ldq[SC_PL_PF_DEPTH][4];
+    auto request = [&](const int r, sc_f4 (&q)[4]) {
+      const sc_f4* src = reinterpret_cast<const sc_f4*>(xp + (2 * (4 * wv + 16 * r)) * SC_PL_N) + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = SC_LOAD_STREAM(src + 64 * i);
+    };
+#pragma unroll
+    for (int d = 0; d < SC_PL_PF_DEPTH; ++d) request(d, ldq[d]);
+#else
     auto prefetch = [&](const int r, cf32 (&pf)[8]) {
       const float* ra = xp + (2 * (g + 16 * r)) * SC_PL_N + t;
 #pragma unroll
@@ -75,6 +97,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
     };
 #pragma unroll
     for (int d = 0; d < SC_PL_PF_DEPTH; ++d) prefetch(d, pfs[d]);
+#endif
     // the lane's row twiddles out of the LDS table (the first round's loads are in flight meanwhile; A-B
     // -DSC_PL_TW1_GLOBAL: 7 global loads per lane and plane instead of one barrier)
     cf32 tw1[8];
@@ -95,8 +118,24 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
       const int p = g + 16 * r;
       cf32 u[8];
       cf32 (&pf)[8] = pfs[r % SC_PL_PF_DEPTH];
+#ifdef SC_PL_STAGED_LOADS
+      sc_f4 (&lq)[4] = ldq[r % SC_PL_PF_DEPTH];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<sc_f4*>(stg + (2 * i + (lane >> 5)) * 136 + 4 * (lane & 31)) = lq[i];
+      if (r + SC_PL_PF_DEPTH < 4) request(r + SC_PL_PF_DEPTH, lq);
+      SC_WAVE_SYNC();
+      {
+        const float* ra = stg + (2 * (g & 3)) * 136 + t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = cf_make(ra[16 * j], ra[136 + 16 * j]);
+      }
+      SC_WAVE_SYNC();                                    // the staging area is this wave's exchange area
+      dft8<-1>(pf, u);                                   // over j -> k1
+#else
       dft8<-1>(pf, u);                                   // over j -> k1
       if (r + SC_PL_PF_DEPTH < 4) prefetch(r + SC_PL_PF_DEPTH, pf);
+#endif
       E[t] = u[0];
 #pragma unroll
       for (int k1 = 1; k1 < 8; ++k1) E[k1 * SC_PL_ES + t] = cf_mul_cs(u[k1], tw1[k1]);
