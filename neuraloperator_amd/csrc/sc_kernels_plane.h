@@ -307,12 +307,34 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
 #pragma unroll
       for (int k1 = 0; k1 < 8; ++k1) u[k1] = sc_lds_ld64(E + k1 * SC_PL_ES + t);
       dft8<+1>(u, z);                                    // over k1 -> j: z[j] = a[t + 16 j] + i b[t + 16 j]
+#ifdef SC_PL_STAGED_STORES
+      // A-B (session 2), NOT taken: the wave's 8 rows through its exchange area and out as four 16-byte stores per lane
+      // -- 435-439 us against 419-425 us for the 64-byte pieces below (profiles/r03s2_pl128_staged_loads_ab.txt):
+      // what helps the loads does not help the non-temporal stores
+      {
+        const int wv = tid >> 6, lane = tid & 63;
+        float* stg = reinterpret_cast<float*>(lds + PlLds::off_E + wv * (4 * 8 * SC_PL_ES));
+        SC_WAVE_SYNC();                                  // every lane has read its exchange values
+        float* rs = stg + (2 * (g & 3)) * 136 + t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rs[16 * j] = z[j].x + bv;
+          rs[136 + 16 * j] = z[j].y + bv;
+        }
+        SC_WAVE_SYNC();
+        sc_f4* dst = reinterpret_cast<sc_f4*>(yp + (2 * (4 * wv + 16 * r)) * SC_PL_N) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          SC_STORE_STREAM(dst + 64 * i, *reinterpret_cast<const sc_f4*>(stg + (2 * i + (lane >> 5)) * 136 + 4 * (lane & 31)));
+      }
+#else
       float* ra = yp + (2 * p) * SC_PL_N + t;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         SC_STORE_STREAM(ra + 16 * j, z[j].x + bv);
         SC_STORE_STREAM(ra + SC_PL_N + 16 * j, z[j].y + bv);
       }
+#endif
       SC_WAVE_SYNC();                                    // Zs / E are rewritten by the next round
     }
   }

@@ -255,6 +255,18 @@ k_pl64_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __res
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) u[k1] = sc_lds_ld64(E + k1 * SC_P64_ES + t);
     dft8<+1>(u, z);                                      // over k1 -> j: z[j] = a[t + 8 j] + i b[t + 8 j]
+#ifdef SC_P64_DIRECT_STORES                            // A-B, NOT taken: 32-byte pieces straight from the lanes -- 107 against
+                                                       // 71 us at 16384 planes (profiles/r03s2_pl128_staged_loads_ab.txt)
+    {
+      float* ra = y + plane * (int64_t)(SC_P64_N * SC_P64_N) + (2 * p) * SC_P64_N + t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        SC_STORE_STREAM(ra + 8 * j, z[j].x + bv);
+        SC_STORE_STREAM(ra + SC_P64_N + 8 * j, z[j].y + bv);
+      }
+    }
+    return;
+#endif
     SC_WAVE_SYNC();                                      // the exchange becomes the staging of the wave's 16 rows
     {
       float* ra = stg + (2 * gl) * SC_P64_SS + t;
