@@ -885,8 +885,13 @@ static void dispatch_plane_fwd(const sc_plan* p, int mode, const float* in, cf32
 static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
   if (p->pl128) {
     const int L = p->nd - 1;
-    SC_LAUNCH(k_pl128_fwd, dim3((unsigned)(lines / SC_PL_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
-              (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L]);
+    // planes per workgroup: the next plane's first rows are in flight while this one is finished (A-B: SC_PL_PPW)
+    static const int ppw_env = [] { const char* e = std::getenv("SC_PL_PPW"); return e ? std::atoi(e) : 0; }();
+    const int64_t n_planes = lines / SC_PL_N;
+    int ppw = ppw_env > 0 ? ppw_env : SC_PL_PPW_DEFAULT;
+    while (ppw > 1 && n_planes / ppw < (int64_t)6 * sc_cu_count()) --ppw;     // keep two full rounds of workgroups
+    SC_LAUNCH(k_pl128_fwd, dim3((unsigned)((n_planes + ppw - 1) / ppw)), dim3(256), 0, st, in, out,
+              (const cf32*)p->pl_tab128, (const float*)p->pl_cs_fwd[mode], (int)p->k[L - 1], (int)p->k[L], n_planes, ppw);
     return sc_check_launch("k_pl128_fwd");
   }
   if (p->pl64) {

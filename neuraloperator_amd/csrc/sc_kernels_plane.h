@@ -24,6 +24,9 @@
 #if !defined(SC_PL_DIRECT_LOADS) && !defined(SC_PL_STAGED_LOADS)
 #define SC_PL_STAGED_LOADS 1
 #endif
+#ifndef SC_PL_PPW_DEFAULT
+#define SC_PL_PPW_DEFAULT 1   // planes per workgroup of the forward kernel (sc_engine.cpp; environment SC_PL_PPW overrides)
+#endif
 #define SC_PL_N 128
 #define SC_PL_RS 20          // tile row stride (complex): column-phase reads conflict-free
 #define SC_PL_ES 17          // row-phase exchange stride (per k1)
@@ -48,67 +51,81 @@ struct PlLds {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// ppw consecutive planes per workgroup (session 2, host: SC_PL_PPW): row round n = 4 it + r of the workgroup's planes;
+// the loads of round n + depth are requested while round n is transformed -- also across the plane boundary, so only
+// the first plane of a workgroup starts with nothing in flight
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 3)
 k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __restrict__ tab128,
-            const float* __restrict__ cs, int K0, int J) {
+            const float* __restrict__ cs, int K0, int J, int64_t n_planes, int ppw) {
   SC_SHARED __attribute__((aligned(16))) cf32 lds[PlLds::total_c];
   cf32* T = lds + PlLds::off_T;
+  cf32* OUT = lds + PlLds::off_IO;
   const int tid = SC_TID;
-  const int64_t plane = SC_BID_X;
-  const float* xp = x + plane * (int64_t)(SC_PL_N * SC_PL_N);
+  const int64_t plane0 = (int64_t)SC_BID_X * ppw;
 #ifndef SC_PL_TAB_GLOBAL
   cf32* tabl = lds + PlLds::off_tab;
-  if (tid < SC_PL_N) tabl[tid] = tab128[tid];            // published by the barrier between the row and column phases
+  if (tid < SC_PL_N) tabl[tid] = tab128[tid];            // published by the barrier ahead of the row twiddles
 #else
   const cf32* tabl = tab128;
 #endif
-  // ---------------- rows: 4 rounds of 16 packed row pairs ----------------
-  {
-    const int g = tid >> 4, t = tid & 15, L = t & 7;
-    cf32* E = lds + PlLds::off_E + g * (8 * SC_PL_ES);
-    cf32* Zs = lds + PlLds::off_Z + g * 34;
+  const int g = tid >> 4, t = tid & 15, L = t & 7;
+  cf32* E = lds + PlLds::off_E + g * (8 * SC_PL_ES);
+  cf32* Zs = lds + PlLds::off_Z + g * 34;
 #ifndef SC_PL_PF_DEPTH
 #define SC_PL_PF_DEPTH 1     // rounds of row loads in flight ahead of the one being transformed (A-B: 2)
 #endif
-    cf32 pfs[SC_PL_PF_DEPTH][8];
+  const int n_rounds = 4 * ppw;
+  cf32 pfs[SC_PL_PF_DEPTH][8];
 #ifdef SC_PL_STAGED_LOADS
-    // Session 2 (as in sc_kernels_plane64.h): a wave owns the 8 consecutive rows of its four row pairs (4 KB per round)
-    // and reads them as four 16-byte loads per lane -- one contiguous KB per instruction instead of 64-byte pieces of
-    // four rows -- into its own part of the exchange buffer (row stride 136 floats: conflict-free both ways); lanes pick
-    // up x[t + 16 j] from there.  The registers of the next round's loads are the same 16 as before.
-    const int wv = tid >> 6, lane = tid & 63;
-    float* stg = reinterpret_cast<float*>(lds + PlLds::off_E + wv * (4 * 8 * SC_PL_ES));
-    sc_f4 ldq[SC_PL_PF_DEPTH][4];
-    auto request = [&](const int r, sc_f4 (&q)[4]) {
-      const sc_f4* src = reinterpret_cast<const sc_f4*>(xp + (2 * (4 * wv + 16 * r)) * SC_PL_N) + lane;
+  // Session 2 (as in sc_kernels_plane64.h): a wave owns the 8 consecutive rows of its four row pairs (4 KB per round)
+  // and reads them as four 16-byte loads per lane -- one contiguous KB per instruction instead of 64-byte pieces of
+  // four rows -- into its own part of the exchange buffer (row stride 136 floats: conflict-free both ways); lanes pick
+  // up x[t + 16 j] from there.  The registers of the next round's loads are the same 16 as before.
+  const int wv = tid >> 6, lane = tid & 63;
+  float* stg = reinterpret_cast<float*>(lds + PlLds::off_E + wv * (4 * 8 * SC_PL_ES));
+  sc_f4 ldq[SC_PL_PF_DEPTH][4];
+  auto request = [&](const int n, sc_f4 (&q)[4]) {
+    if (n >= n_rounds) return;
+    int64_t pl = plane0 + (n >> 2);
+    pl = pl < n_planes ? pl : n_planes - 1;              // past the end: a harmless re-read
+    const sc_f4* src = reinterpret_cast<const sc_f4*>(x + pl * (int64_t)(SC_PL_N * SC_PL_N) +
+                                                      (2 * (4 * wv + 16 * (n & 3))) * SC_PL_N) + lane;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = SC_LOAD_STREAM(src + 64 * i);
-    };
+    for (int i = 0; i < 4; ++i) q[i] = SC_LOAD_STREAM(src + 64 * i);
+  };
 #pragma unroll
-    for (int d = 0; d < SC_PL_PF_DEPTH; ++d) request(d, ldq[d]);
+  for (int d = 0; d < SC_PL_PF_DEPTH; ++d) request(d, ldq[d]);
 #else
-    auto prefetch = [&](const int r, cf32 (&pf)[8]) {
-      const float* ra = xp + (2 * (g + 16 * r)) * SC_PL_N + t;
+  auto prefetch = [&](const int n, cf32 (&pf)[8]) {
+    if (n >= n_rounds) return;
+    int64_t pl = plane0 + (n >> 2);
+    pl = pl < n_planes ? pl : n_planes - 1;
+    const float* ra = x + pl * (int64_t)(SC_PL_N * SC_PL_N) + (2 * (g + 16 * (n & 3))) * SC_PL_N + t;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        pf[j].x = SC_LOAD_STREAM(ra + 16 * j);
-        pf[j].y = SC_LOAD_STREAM(ra + SC_PL_N + 16 * j);
-      }
-    };
+    for (int j = 0; j < 8; ++j) {
+      pf[j].x = SC_LOAD_STREAM(ra + 16 * j);
+      pf[j].y = SC_LOAD_STREAM(ra + SC_PL_N + 16 * j);
+    }
+  };
 #pragma unroll
-    for (int d = 0; d < SC_PL_PF_DEPTH; ++d) prefetch(d, pfs[d]);
+  for (int d = 0; d < SC_PL_PF_DEPTH; ++d) prefetch(d, pfs[d]);
 #endif
-    // the lane's row twiddles out of the LDS table (the first round's loads are in flight meanwhile; A-B
-    // -DSC_PL_TW1_GLOBAL: 7 global loads per lane and plane instead of one barrier)
-    cf32 tw1[8];
+  // the lane's row twiddles out of the LDS table (the first round's loads are in flight meanwhile; A-B
+  // -DSC_PL_TW1_GLOBAL: 7 global loads per lane and plane instead of one barrier)
+  cf32 tw1[8];
 #if !defined(SC_PL_TAB_GLOBAL) && !defined(SC_PL_TW1_GLOBAL)
-    SC_SYNC();
+  SC_SYNC();
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = sc_lds_ld64(tabl + ((t * k1) & 127));
+  for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = sc_lds_ld64(tabl + ((t * k1) & 127));
 #else
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = tab128[(t * k1) & 127];
+  for (int k1 = 1; k1 < 8; ++k1) tw1[k1] = tab128[(t * k1) & 127];
 #endif
+#pragma unroll 1
+  for (int it = 0; it < ppw; ++it) {
+    const int64_t plane = plane0 + it;
+    if (plane >= n_planes) break;                        // uniform
+    // ---------------- rows: 4 rounds of 16 packed row pairs ----------------
 #if SC_PL_PF_DEPTH == 1
 #pragma unroll 1
 #else
@@ -123,7 +140,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         *reinterpret_cast<sc_f4*>(stg + (2 * i + (lane >> 5)) * 136 + 4 * (lane & 31)) = lq[i];
-      if (r + SC_PL_PF_DEPTH < 4) request(r + SC_PL_PF_DEPTH, lq);
+      request(4 * it + r + SC_PL_PF_DEPTH, lq);
       SC_WAVE_SYNC();
       {
         const float* ra = stg + (2 * (g & 3)) * 136 + t;
@@ -134,7 +151,7 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
       dft8<-1>(pf, u);                                   // over j -> k1
 #else
       dft8<-1>(pf, u);                                   // over j -> k1
-      if (r + SC_PL_PF_DEPTH < 4) prefetch(r + SC_PL_PF_DEPTH, pf);
+      prefetch(4 * it + r + SC_PL_PF_DEPTH, pf);
 #endif
       E[t] = u[0];
 #pragma unroll
@@ -164,44 +181,43 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
         }
       }
     }
-  }
-  SC_SYNC();
-  // ---------------- columns: 8 lanes per kept column ----------------
-  cf32* OUT = lds + PlLds::off_IO;
-  {
-    const int c = tid >> 3, t = tid & 7;
-    const bool act = c < SC_PL_JMAX;                     // waves 0, 1 and the first group of wave 2
-    cf32* E2 = lds + PlLds::off_E + (act ? c : 0) * 148;
-    if (act) {
-      cf32 v[16], u[16];
+    SC_SYNC();
+    // ---------------- columns: 8 lanes per kept column ----------------
+    {
+      const int c = tid >> 3, tc = tid & 7;
+      const bool act = c < SC_PL_JMAX;                   // waves 0, 1 and the first group of wave 2
+      cf32* E2 = lds + PlLds::off_E + (act ? c : 0) * 148;
+      if (act) {
+        cf32 v[16], u[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = sc_lds_ld64(T + (t + 8 * j) * SC_PL_RS + c);
-      fft16<-1>(v, u);                                   // over j -> k1
-      E2[t] = u[0];
+        for (int j = 0; j < 16; ++j) v[j] = sc_lds_ld64(T + (tc + 8 * j) * SC_PL_RS + c);
+        fft16<-1>(v, u);                                 // over j -> k1
+        E2[tc] = u[0];
 #pragma unroll
-      for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], tabl[(t * k1) & 127]);
-    }
-    SC_WAVE_SYNC();
-    if (act) {
-      const float s = (c < J) ? cs[c] : 0.f;
+        for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + tc] = cf_mul_cs(u[k1], tabl[(tc * k1) & 127]);
+      }
+      SC_WAVE_SYNC();
+      if (act) {
+        const float s = (c < J) ? cs[c] : 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k1 = t + 8 * h;
-        cf32 y[8], o[8];
+        for (int h = 0; h < 2; ++h) {
+          const int k1 = tc + 8 * h;
+          cf32 y[8], o[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + k1 * 9 + q);
-        dft8<-1>(y, o);                                  // over t -> k2: k = k1 + 16 k2; kept: k2 = 0 and k2 = -1
-        const int rp = k1 + K0 / 2, rn = k1 - 16 + K0 / 2;
-        if (c < J) {
-          if (rp < K0) OUT[rp * J + c] = cf_scale(o[0], s);
-          if (rn >= 0) OUT[rn * J + c] = cf_scale(o[7], s);
+          for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + k1 * 9 + q);
+          dft8<-1>(y, o);                                // over t -> k2: k = k1 + 16 k2; kept: k2 = 0 and k2 = -1
+          const int rp = k1 + K0 / 2, rn = k1 - 16 + K0 / 2;
+          if (c < J) {
+            if (rp < K0) OUT[rp * J + c] = cf_scale(o[0], s);
+            if (rn >= 0) OUT[rn * J + c] = cf_scale(o[7], s);
+          }
         }
       }
     }
+    SC_SYNC();                                           // also: the column exchange is free for the next plane's staging
+    cf32* dst = out + plane * (int64_t)K0 * J;
+    for (int i = tid; i < K0 * J; i += 256) dst[i] = OUT[i];
   }
-  SC_SYNC();
-  cf32* dst = out + plane * (int64_t)K0 * J;
-  for (int i = tid; i < K0 * J; i += 256) dst[i] = OUT[i];
 }
 
 // ------------------------------------------------------------------------------------------

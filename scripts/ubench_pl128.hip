@@ -28,8 +28,9 @@ int main(int argc, char** argv) {
   std::vector<void*> owned;
   fft2d_upload(&owned, 128, &t128);
 #ifdef PL_OLD_SIG
-  auto fwd = [&] { hipLaunchKernelGGL(k_pl128_fwd, dim3(NPL), dim3(256), 0, 0, (const float*)x, xh, (const cf32*)t128,
-                                      (const float*)cs, K0, J); };
+  const int PPW = getenv("PL_PPW") ? atoi(getenv("PL_PPW")) : 1;      // planes per workgroup of the forward kernel
+  auto fwd = [&] { hipLaunchKernelGGL(k_pl128_fwd, dim3((NPL + PPW - 1) / PPW), dim3(256), 0, 0, (const float*)x, xh, (const cf32*)t128,
+                                      (const float*)cs, K0, J, (int64_t)NPL, PPW); };
   auto inv = [&] { hipLaunchKernelGGL(k_pl128_inv, dim3(NPL), dim3(256), 0, 0, (const cf32*)xh, y, (const cf32*)t128,
                                       (const float*)cs, (const float*)bias, (int64_t)128, C, K0, J); };
 #else
