@@ -682,11 +682,11 @@ def main():
     del step, conv, case
     torch.cuda.empty_cache()
 
-    # ---- extra measurements (same launch, fewer steps): see the module docstring
+    # ---- extra measurements (same launch, same W + K protocol): see the module docstring
     extra = {}
     if not args.no_extras and args.workload == "fno2d_256_m64_c64_b32" and args.io == "f32":
         # every BASELINE config on the driver-timed line: name, parallelism, workload,
-        # storage type of the real tensors, extra constructor arguments.  Each is bounded: settle + 3 + 10 steps.
+        # storage type of the real tensors, extra constructor arguments.  Each runs the contract's own W + K steps (after the same settling as the headline).
         f32, bf16 = torch.float32, torch.bfloat16
         tucker = dict(factorization="tucker", rank=0.1, implementation="factorized")
         todo = [("fno3d_single", "replicas", "fno3d_128_m32_c32_b8", f32, None),          # configs[3], one GPU
@@ -707,7 +707,7 @@ def main():
                 extra[name] = {"value": None, "note": f"batch of {wl} not divisible by {world} ranks"}
                 continue
             st_x, bl_x, gb_x, sc_x, tag_x, conv_x = c
-            ms_x, cold_x, n_x = timed_steps(st_x, 10, 3, dist, dev, share, args.settle_ms)
+            ms_x, cold_x, n_x = timed_steps(st_x, args.steps, args.warmup, dist, dev, share, args.settle_ms)
             Bx, Cx, sp_x, nm_x = WORKLOADS[wl]
             kept_x, _ = kept_block(sp_x, halve_last_mode(nm_x), halve_last_mode(nm_x))
             Rx, Wbx, Sx, tot_x = alg_bytes(bl_x, Cx, sp_x, kept_x, 2 if io_x == bf16 else 4)
@@ -721,7 +721,7 @@ def main():
             gbs_x = tot_x / ms_x / 1e6                   # per GPU: bl_x samples' bytes per step time
             extra[name] = {"workload": wl, "parallelism": tag_x, "scaling": sc_x, "B_per_gpu": bl_x,
                            "global_batch": gb_x, "ms_per_step": round(ms_x, 4),
-                           "value": round(gb_x / (ms_x / 1e3), 2), "unit": "samples/s", "steps": 10, "warmup": 3,
+                           "value": round(gb_x / (ms_x / 1e3), 2), "unit": "samples/s", "steps": args.steps, "warmup": args.warmup,
                            "cold_start_ms_per_step": round(cold_x, 4), "settle_steps": n_x,
                            "real_tensor_io": "bf16" if io_x == bf16 else "f32",
                            "alg_bytes_per_step": tot_x, "alg_bytes_formula": formula + " (SURVEY.md 8d), per GPU",
