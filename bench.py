@@ -51,6 +51,7 @@ WORKLOADS = {
     "fno2d_128_m32_c64_b32": (32, 64, (128, 128), (32, 32)),
     "fno2d_192_m64_c64_b32": (32, 64, (192, 192), (64, 64)),      # radix-3 lines (32 x 6) on the two-pass route
     "fno3d_64_m16_c32_b8": (8, 32, (64, 64, 64), (16, 16, 16)),
+    "fno2d_512_m64_c64_b8": (8, 64, (512, 512), (64, 64)),        # two-pass route, P = 16
     # diagnostic: the per-rank transform load of configs[3] strong-scaled over 8 GPUs (one sample per rank)
     "fno3d_128_m32_c32_b1": (1, 32, (128, 128, 128), (32, 32, 32)),
 }
