@@ -2226,7 +2226,10 @@ extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, c
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
   const int64_t wgs = (g.n_tiles + 3) / 4;
-  g.n_wg = (int)(wgs < 2048 ? wgs : 2048);                  // persistent: the weight tables are built once per workgroup
+  // persistent: the weight tables are built once per workgroup (SC_PMLP_FWD_WGS = workgroup count, A-B)
+  static const int wgs_env = [] { const char* e = std::getenv("SC_PMLP_FWD_WGS"); return e ? std::atoi(e) : 0; }();
+  const int64_t resident = wgs_env > 0 ? wgs_env : 2048;     // 2048 / 768 / 512 workgroups: 0.381 / 0.407 / 0.437 ms (session 2)
+  g.n_wg = (int)(wgs < resident ? wgs : resident);
   sc_stream_t st = (sc_stream_t)stream;
   switch (pmlp_shape_id(d)) {
     case 111: launch_pmlp_fwd<1, 1, 1>(g, gate != nullptr, d->act, st); break;
@@ -2336,8 +2339,10 @@ static int plin_shape_id(const sc_plin_desc* d) {
   return (int)(d->c_in / 32) * 10 + (int)(d->c_out / 32);
 }
 static int plin_bwd_wgs(const sc_plin_desc* d) {
+  static const int env = [] { const char* e = std::getenv("SC_PLIN_BWD_WGS"); return e ? std::atoi(e) : 0; }();   // A-B
+  const int64_t cap = env > 0 ? env : 512;
   const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
-  return (int)(wgs < 512 ? wgs : 512);
+  return (int)(wgs < cap ? wgs : cap);
 }
 
 extern "C" int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x, const float* w, const float* bias,
@@ -2352,7 +2357,15 @@ extern "C" int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
   const int64_t wgs = (g.n_tiles + 3) / 4;
-  g.n_wg = (int)(wgs < 2048 ? wgs : 2048);
+  // persistent: exactly as many workgroups as the chip holds at once -- two per compute unit (the kernel's launch bound;
+  // the weight table in LDS is 4 / 16 / 64 KB) -- instead of 2048: 0.274 -> 0.22 ms at the metric shape (session 2,
+  // profiles/r03s2_plin_time.txt; a next-tile prefetch at three or four per unit measured slower: 0.237 / 0.266 ms)
+  const int64_t lds = (int64_t)(d->c_in / 32) * 16 * (d->c_out / 32) * 64 * 4 + d->c_out * 4;
+  int64_t per_cu = 160 * 1024 / lds;
+  per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);
+  static const int plin_wgs_env = [] { const char* e = std::getenv("SC_PLIN_FWD_WGS"); return e ? std::atoi(e) : 0; }();
+  const int64_t resident = plin_wgs_env > 0 ? plin_wgs_env : per_cu * sc_cu_count();
+  g.n_wg = (int)(wgs < resident ? wgs : resident);
   sc_stream_t st = (sc_stream_t)stream;
   const dim3 grid((unsigned)g.n_wg), block(256);
   switch (plin_shape_id(d)) {
