@@ -280,6 +280,18 @@ typedef struct sc_pmlp_desc {
 } sc_pmlp_desc;
 int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1, const float* w2,
                              const float* b2, const float* skip_src, const float* gate, float* out, void* stream);
+/* The whole pointwise side of a default block's forward in ONE pass (session 2):
+ *     s = conv + (ws x + bs);   y = act(s);   out = act( W2 gelu(W1 y + b1) + b2 + gate (.) x )
+ * conv = the spectral convolution's output (sc_layer_forward without an epilogue), ws / bs = the block's 1 x 1 linear
+ * skip (neuralop/layers/skip_connections.py:119-169), x = the block input; y and -- with SC_ACT_GELU -- s (`pre`) are
+ * STORED because the backward passes (sc_pointwise_mlp_backward_ex with x = y, x_pre = s, then
+ * sc_pointwise_linear_backward and sc_layer_backward_ex) read them.  Replaces sc_pointwise_linear_forward + the block
+ * epilogue of sc_layer_forward_ex + sc_pointwise_mlp_forward (8 tensor-sized passes) by 1 + 5: the skip is never
+ * written and y is not read back.  d->c_in == d->c_out in {32, 64} channels with c_hid as for the MLP pass; bs, b1, b2
+ * optional; `pre` is required with SC_ACT_GELU and ignored otherwise. */
+int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* conv, const float* x, const float* ws, const float* bs,
+                               const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
+                               float* y, float* pre, float* out, void* stream);
 /* gradient of the above with respect to everything: nothing but the forward's INPUTS is needed (h and the
  * pre-activations are recomputed inside the tile).  gx (batch, c_in, spatial), gskip_src (batch, c_out, spatial; with a
  * gate), gw1 / gw2 like w1 / w2, gb1 / gb2 / ggate (null when the forward had none) are all overwritten.  workspace:

@@ -145,7 +145,7 @@ class ScEngineLib:
                "sc_modegemm_msum", "sc_modegemm_msum_ws", "sc_modegemm_msum_workspace_bytes", "sc_modegemm_msum_path", "sc_modegemm_uses_matrix_cores", "sc_modegemm_path", "sc_bias_grad", "sc_adamw_step",
                "sc_layer_workspace_bytes", "sc_layer_forward", "sc_layer_backward",
                "sc_last_error", "sc_version", "sc_plan_kernel_name", "sc_transform_inverse_ex",
-               "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward",
+               "sc_layer_forward_ex", "sc_round_f16", "sc_pointwise_mlp_forward", "sc_pointwise_block_forward",
                "sc_pointwise_mlp_backward", "sc_pointwise_mlp_workspace_bytes", "sc_pointwise_linear_forward",
                "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex",
                "sc_pointwise_mlp_backward_ex", "sc_tucker_modes_supported", "sc_tucker_modes_forward",
@@ -231,6 +231,8 @@ class ScEngineLib:
         L.sc_layer_backward.restype = c_int
         L.sc_pointwise_mlp_forward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 9
         L.sc_pointwise_mlp_forward.restype = c_int
+        L.sc_pointwise_block_forward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 13
+        L.sc_pointwise_block_forward.restype = c_int
         L.sc_pointwise_mlp_workspace_bytes.argtypes = [POINTER(PmlpDesc)]
         L.sc_pointwise_mlp_workspace_bytes.restype = c_size_t
         L.sc_pointwise_mlp_backward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 17
@@ -378,6 +380,12 @@ class ScEngineLib:
     def pointwise_mlp_workspace_bytes(self, batch, c_in, c_hid, c_out, spatial, act):
         d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
         return int(self.lib.sc_pointwise_mlp_workspace_bytes(byref(d)))
+
+    def pointwise_block_forward(self, batch, c, c_hid, spatial, act, conv, x, ws, bs, w1, b1, w2, b2, gate, y, pre, out,
+                                stream=0):
+        """s = conv + (ws x + bs); y = act(s); out = act(W2 gelu(W1 y + b1) + b2 + gate x) in one pass (y, pre stored)."""
+        d = PmlpDesc(batch, c, c_hid, c, spatial, act, 0)
+        self._check(self.lib.sc_pointwise_block_forward(byref(d), conv, x, ws, bs, w1, b1, w2, b2, gate, y, pre, out, stream))
 
     def pointwise_mlp_backward(self, batch, c_in, c_hid, c_out, spatial, act, x, w1, b1, w2, b2, skip, gate, gout,
                                gx, gw1, gb1, gw2, gb2, gskip, ggate, ws, stream=0, x_pre=0):

@@ -13,6 +13,8 @@ verbatim reference class, built with ``conv_module=neuraloperator_amd.SpectralCo
 ``blocks(x, index)``; configurations outside its scope (normalisation layers, pre-activation, tanh stabiliser, a
 resolution change, other skip types) take the module's own forward.  Session 2: pre-activation blocks and blocks with
 normalisation layers run the same engine passes composed by autograd (``_fused_block_variant``)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -150,6 +152,10 @@ def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=No
     return F.gelu(z) if activation == "gelu" else z
 
 
+_PBLOCK_SHAPES = {(32, 32), (64, 32), (64, 64)}          # (channels, hidden): sc_pointwise_block_forward's kernels
+_NO_PBLOCK = os.environ.get("SC_BLOCK_NO_PBLOCK") == "1"   # A-B: the three-pass forward of round 2
+
+
 class FusedBlockFn(torch.autograd.Function):
     """One default FNO block as ONE autograd node: linear skip -> Fourier layer with the add + GELU epilogue ->
     pointwise MLP pass.  The block input feeds three branches; as separate nodes autograd adds their three gradients
@@ -184,16 +190,26 @@ class FusedBlockFn(torch.autograd.Function):
         L = lib.layer_desc(b, c, c, list(cwc.shape[2:]), w_start)
         with torch.cuda.device(dev):
             st = _stream()
-            skip = torch.empty_like(x)
-            lib.pointwise_linear_forward(b, c, c, s, p(x), p(lwc), p(lbc), p(skip), st)
             ws = engine._ws(lib.layer_workspace_bytes(plan, L), dev)
             y = torch.empty_like(x)
             pre = None if last else torch.empty_like(x)
             xhat = torch.empty((b, c, *kept, 2), dtype=torch.float32, device=dev)
-            lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), p(skip), p(pre), act, p(y), p(xhat),
-                                 p(ws), st)
             out = torch.empty_like(x)
-            lib.pointwise_mlp_forward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(out), st)
+            if (c, ch) in _PBLOCK_SHAPES and not _NO_PBLOCK:
+                # session 2: a plain inverse transform, then ONE pointwise pass for skip + add + GELU + MLP + gate (the
+                # skip is never written, y is not read back: 1 + 5 tensor-sized passes instead of 8); y and pre are
+                # the same tensors as before, so the backward below does not change
+                conv = torch.empty_like(x)
+                lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), 0, 0, _lib.SC_ACT_NONE, p(conv),
+                                     p(xhat), p(ws), st)
+                lib.pointwise_block_forward(b, c, ch, s, act, p(conv), p(x), p(lwc), p(lbc), p(w1c), p(b1c), p(w2c), p(b2c),
+                                            p(gtc), p(y), p(pre), p(out), st)
+            else:
+                skip = torch.empty_like(x)
+                lib.pointwise_linear_forward(b, c, c, s, p(x), p(lwc), p(lbc), p(skip), st)
+                lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), p(skip), p(pre), act, p(y),
+                                     p(xhat), p(ws), st)
+                lib.pointwise_mlp_forward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(out), st)
         ctx.save_for_backward(x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc)
         ctx.cfg = (plan, L, b, c, ch, s, act, tuple(cw.shape), None if cb is None else tuple(cb.shape), tuple(lw.shape),
                    lb is not None, tuple(w1.shape), tuple(w2.shape), tuple(gate.shape))

@@ -2245,6 +2245,45 @@ extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, c
 
 #define SC_PMLP_RED_GROUPS 16
 // waves per workgroup of the backward kernel: one per SIMD (its register file holds the weight-gradient accumulators)
+template <int CC, int CH>
+static void launch_pblock_fwd(const PblockArgs& g, int act, sc_stream_t st) {
+  const dim3 grid((unsigned)g.n_wg), block(256);
+  if (act) SC_LAUNCH((k_pblock_fwd<CC, CH, 1>), grid, block, 0, st, g);
+  else SC_LAUNCH((k_pblock_fwd<CC, CH, 0>), grid, block, 0, st, g);
+}
+
+extern "C" int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* conv, const float* x, const float* ws,
+                                          const float* bs, const float* w1, const float* b1, const float* w2,
+                                          const float* b2, const float* gate, float* y, float* pre, float* out,
+                                          void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  if (d->batch <= 0 || d->spatial <= 0) return 0;
+  SC_CHECK_ARG(conv && x && ws && w1 && w2 && gate && y && out, "null argument");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU, "unknown activation");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || pre, "the pre-activation buffer is required with SC_ACT_GELU");
+  SC_CHECK_ARG(d->c_in == d->c_out, "pointwise block pass: c_in == c_out (the linear skip maps the block's channels onto themselves)");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise block pass: the spatial size must be a multiple of 32");
+  PblockArgs g;
+  g.conv = conv; g.x = x; g.ws = ws; g.bs = bs; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.gate = gate;
+  g.y = y; g.pre = d->act == SC_ACT_GELU ? pre : nullptr; g.out = out;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  const int64_t wgs = (g.n_tiles + 3) / 4;
+  static const int wgs_env = [] { const char* e = std::getenv("SC_PBLOCK_FWD_WGS"); return e ? std::atoi(e) : 0; }();
+  const int64_t cap = wgs_env > 0 ? wgs_env : 2048;          // persistent: the weight tables are built once per workgroup
+  g.n_wg = (int)(wgs < cap ? wgs : cap);
+  sc_stream_t st = (sc_stream_t)stream;
+  switch (pmlp_shape_id(d)) {
+    case 111: launch_pblock_fwd<1, 1>(g, d->act == SC_ACT_GELU, st); break;
+    case 212: launch_pblock_fwd<2, 1>(g, d->act == SC_ACT_GELU, st); break;
+    case 222: launch_pblock_fwd<2, 2>(g, d->act == SC_ACT_GELU, st); break;
+    default:
+      return sc_fail("sc_engine: pointwise block pass: (c, c_hid, c) must be (32,32,32), (64,32,64) or (64,64,64)");
+  }
+  return sc_check_launch("k_pblock_fwd");
+}
+
 static int pmlp_bwd_waves(const sc_pmlp_desc*) { return 4; }
 static int pmlp_bwd_wgs(const sc_pmlp_desc* d) {
   const int nw = pmlp_bwd_waves(d);

@@ -162,6 +162,160 @@ k_pmlp_fwd(PmlpArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Session 2: the WHOLE pointwise side of a default FNO block forward in one pass (fno_block.py:377-414):
+//     s  = conv + (Ws x + bs)          conv = the spectral convolution's output, Ws = the 1 x 1 linear skip
+//     y  = gelu(s)  (ACT 1; y = s for the last block)      -> stored (the backward pass reads it) together with s
+//     out = act( W2 gelu(W1 y + b1) + b2 + gate (.) x )
+// Before: k_plin_fwd wrote the skip (x in, skip out), the inverse FFT's epilogue read it back and wrote y and s, and
+// k_pmlp_fwd read y and x: 8 R-sized passes.  Here the inverse FFT writes conv plainly (1) and this pass reads conv and
+// x and writes s, y, out (5): the skip never exists in memory and y is not read back.  The skip product uses the same
+// operand table and k order as k_plin_fwd (same bits), its accumulators -- after the GELU -- are the B operand of the
+// first MLP product through the accumulator-as-operand arrangement of the second one (W1 pre-arranged in accumulator
+// row order over the input channels), so y never leaves the registers on its way into the MLP.
+// ------------------------------------------------------------------------------------------
+struct PblockArgs {
+  const float* conv;      // (batch, C, spatial)
+  const float* x;         // (batch, C, spatial): the block input (linear skip + gate)
+  const float* ws;        // (C, C)
+  const float* bs;        // (C) or null
+  const float* w1;        // (32 CH, C)
+  const float* b1;
+  const float* w2;        // (C, 32 CH)
+  const float* b2;
+  const float* gate;      // (C)
+  float* y;               // (batch, C, spatial)
+  float* pre;             // (batch, C, spatial) with ACT 1, else null
+  float* out;
+  int64_t n_tiles, spatial;
+  int tiles_per_sample, n_wg;
+};
+
+template <int CC, int CH, int ACT>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_pblock_fwd(PblockArgs g) {
+  constexpr int C = 32 * CC, C_HID = 32 * CH, S1 = 16 * CC;
+  SC_SHARED float AS[CC * S1 * 64];                        // Ws, B operand rows (2 s, 2 s + 1)
+  SC_SHARED float A1[CH * CC * 16 * 64];                   // W1, K in accumulator row order over the C input channels
+  SC_SHARED float A2[CC * CH * 16 * 64];                   // W2, K in accumulator row order over the hidden channels
+  SC_SHARED float BS[C], B1[C_HID], B2[C], GT[C];
+  const int tid = SC_TID, lane = tid & 63, n = lane & 31, half = lane >> 5;
+  const int w = SC_UNIFORM(tid >> 6);
+  for (int i = tid; i < CC * S1 * 64; i += 256) {
+    const int l = i & 63, s = (i >> 6) % S1, om = (i >> 6) / S1;
+    AS[i] = g.ws[(32 * om + (l & 31)) * C + 2 * s + (l >> 5)];
+  }
+  for (int i = tid; i < CH * CC * 16 * 64; i += 256) {
+    const int l = i & 63, v = (i >> 6) & 15, om = (i >> 10) % CC, hm = (i >> 10) / CC;
+    A1[i] = g.w1[(32 * hm + (l & 31)) * C + 32 * om + pmlp_row(v, l >> 5)];
+  }
+  for (int i = tid; i < CC * CH * 16 * 64; i += 256) {
+    const int l = i & 63, v = (i >> 6) & 15, hm = ((i >> 10) % CH), om = (i >> 10) / CH;
+    A2[i] = g.w2[(32 * om + (l & 31)) * C_HID + 32 * hm + pmlp_row(v, l >> 5)];
+  }
+  for (int i = tid; i < C_HID; i += 256) B1[i] = g.b1 ? g.b1[i] : 0.f;
+  for (int i = tid; i < C; i += 256) {
+    BS[i] = g.bs ? g.bs[i] : 0.f;
+    B2[i] = g.b2 ? g.b2[i] : 0.f;
+    GT[i] = g.gate[i];
+  }
+  SC_SYNC();
+  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
+  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+#pragma unroll 1
+  for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
+    const int64_t b = tile / g.tiles_per_sample;
+    const int64_t px0 = (tile - b * g.tiles_per_sample) * 32;
+    const int64_t sp = sc_opaque_s((int)g.spatial);
+    const int64_t base = b * C * sp + px0;
+    const float* xs = g.x + base;
+    const float* cs = g.conv + base;
+    float* ys = g.y + base;
+    float* ps = ACT == 1 ? g.pre + base : nullptr;
+    float* os = g.out + base;
+    const int hq = sc_opaque(half);
+    float xr[CC * 16];
+#pragma unroll
+    for (int s = 0; s < CC * 16; ++s) xr[s] = xs[(int64_t)(2 * s) * sp + lo_b];   // ordinary loads: read again below
+    SC_SCHED_BARRIER();
+    // ---- linear skip + conv -> s, y (both stored); y stays in the accumulator registers
+    sc_f32x16 yv[CC];
+#pragma unroll
+    for (int om = 0; om < CC; ++om) {
+      float cv[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) cv[v] = SC_LOAD_STREAM(cs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) yv[om][v] = 0.f;
+#pragma unroll
+      for (int s0 = 0; s0 < S1; s0 += 8) {
+#pragma unroll
+        for (int s = s0; s < s0 + 8; ++s) sc_mfma_32x32x2(yv[om], AS[(om * S1 + s) * 64 + lane], xr[s]);
+        SC_SCHED_BARRIER();
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
+        float sv = cv[v] + (yv[om][v] + BS[32 * om + pmlp_row(v, hq)]);   // conv + skip, as the epilogue adds them
+        if (ACT == 1) {
+          SC_STORE_STREAM(ps + ro, sv);
+          sv = sc_gelu(sv);
+        }
+        SC_STORE_STREAM(ys + ro, sv);
+        yv[om][v] = sv;
+        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      }
+    }
+    // ---- hidden layer: h = gelu(W1 y + b1), y as the B operand straight from its accumulators
+    sc_f32x16 acc1[CH];
+#pragma unroll
+    for (int hm = 0; hm < CH; ++hm) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc1[hm][v] = 0.f;
+#pragma unroll
+      for (int om = 0; om < CC; ++om)
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc1[hm], A1[((hm * CC + om) * 16 + v) * 64 + lane], yv[om][v]);
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        acc1[hm][v] = sc_gelu(acc1[hm][v] + B1[32 * hm + pmlp_row(v, hq)]);
+        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      }
+    }
+    // ---- output layer + soft-gating skip + closing activation (as k_pmlp_fwd)
+#pragma unroll
+    for (int om = 0; om < CC; ++om) {
+      float sk[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v)                                      // second (last) read of x: out of L2
+        sk[v] = SC_LOAD_STREAM(xs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+      sc_f32x16 acc2;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc2[v] = 0.f;
+#pragma unroll
+      for (int hm = 0; hm < CH; ++hm)
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc2, A2[((om * CH + hm) * 16 + v) * 64 + lane], acc1[hm][v]);
+          SC_SCHED_BARRIER();
+        }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int r = 32 * om + pmlp_row(v, hq);
+        float val = fmaf(GT[r], sk[v], acc2[v] + B2[r]);
+        if (ACT == 1) val = sc_gelu(val);
+        SC_STORE_STREAM(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, val);
+        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: everything recomputed from x (and skip_src) inside the tile -- nothing but x is saved by the forward.
 //   gz  = gout (.) act'(z_pre)                     gskip = gate (.) gz,  ggate += sum_px gz (.) skip,  gb2 += sum_px gz
 //   gh  = W2^T gz,  ghp = gh (.) gelu'(h_pre)      gb1 += sum_px ghp

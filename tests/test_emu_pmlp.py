@@ -136,3 +136,53 @@ def test_pointwise_linear(lib, c, bias):
     assert rel_l2(gx.numpy(), xd.grad.numpy()) < 1e-5 and rel_l2(gw.numpy(), wd.grad.numpy()) < 1e-5
     if bias:
         assert rel_l2(gb.numpy(), bd.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("chans", [(32, 32), (64, 32), (64, 64)], ids=str)
+@pytest.mark.parametrize("act,bias", [(1, True), (0, True), (1, False)])
+def test_pointwise_block_forward(lib, chans, act, bias):
+    """The whole pointwise side of a default block in one pass (session 2, k_pblock_fwd):
+    s = conv + (Ws x + bs), y = act(s), out = act(W2 gelu(W1 y + b1) + b2 + gate x) -- fno_block.py:392-412 with the
+    linear skip (skip_connections.py:119-169), ChannelMLP and soft-gating skip; y and s are outputs too.  Also against
+    the three passes it replaces (same operand order in the skip product: y and s agree to the bit)."""
+    c, ch = chans
+    g = torch.Generator().manual_seed(c + ch + act)
+    B, S = 3, 96
+    x, conv = torch.randn(B, c, S, generator=g), torch.randn(B, c, S, generator=g)
+    ws = torch.randn(c, c, generator=g) / c ** 0.5
+    w1 = torch.randn(ch, c, generator=g) / c ** 0.5
+    w2 = torch.randn(c, ch, generator=g) / ch ** 0.5
+    bs = torch.randn(c, generator=g) if bias else None
+    b1 = torch.randn(ch, generator=g) if bias else None
+    b2 = torch.randn(c, generator=g) if bias else None
+    gt = torch.randn(c, generator=g)
+    y, pre, out = (torch.full((B, c, S), float("nan")) for _ in range(3))
+    p = lambda t: 0 if t is None else t.data_ptr()
+    lib.pointwise_block_forward(B, c, ch, S, act, p(conv), p(x), p(ws), p(bs), p(w1), p(b1), p(w2), p(b2), p(gt), p(y),
+                                p(pre) if act else 0, p(out), 0)
+    s_ref = conv.double() + torch.einsum("oc,bcs->bos", ws.double(), x.double()) + (0 if bs is None else bs.double()[None, :, None])
+    y_ref = F.gelu(s_ref) if act else s_ref
+    out_ref = _ref(y_ref.float(), w1, b1, w2, b2, x, gt, act)
+    assert rel_l2(y.numpy(), y_ref.numpy()) < TOL
+    if act:
+        assert rel_l2(pre.numpy(), s_ref.numpy()) < TOL
+    assert rel_l2(out.numpy(), out_ref.numpy()) < 2 * TOL
+    # the passes it replaces
+    skip = torch.empty_like(x)
+    lib.pointwise_linear_forward(B, c, c, S, p(x), p(ws), p(bs), p(skip), 0)
+    s3 = conv + skip
+    if act:
+        assert torch.equal(pre, s3)
+    else:
+        assert torch.equal(y, s3)
+
+
+def test_pointwise_block_argument_checks(lib):
+    z = torch.zeros(1, 64, 32)
+    w = torch.zeros(64, 64)
+    with pytest.raises(_lib.EngineError):                # GELU without the pre-activation buffer
+        lib.pointwise_block_forward(1, 64, 64, 32, 1, z.data_ptr(), z.data_ptr(), w.data_ptr(), 0, w.data_ptr(), 0, w.data_ptr(), 0,
+                                    w.data_ptr(), z.data_ptr(), 0, z.data_ptr(), 0)
+    with pytest.raises(_lib.EngineError):                # 128 channels: no kernel
+        lib.pointwise_block_forward(1, 128, 64, 32, 0, z.data_ptr(), z.data_ptr(), w.data_ptr(), 0, w.data_ptr(), 0, w.data_ptr(), 0,
+                                    w.data_ptr(), z.data_ptr(), 0, z.data_ptr(), 0)
