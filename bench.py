@@ -67,6 +67,13 @@ def parse():
                     help="N > 1: auto = modeshard; replicas = data-parallel copies with the gradient all-reduce; "
                          "modeshard = mode-parallel layer (batch-sharded activations, mode-sharded weights); pencil = "
                          "spatially decomposed layer (every sample spans all ranks: rows of the first grid dim sharded)")
+    ap.add_argument("--comm-chunks", type=int, default=0,
+                    help="modeshard: pieces every exchange is pipelined in (0 = the layer's default)")
+    ap.add_argument("--chunk-dim", default=None, choices=["batch", "channels"],
+                    help="modeshard: the chunked dim (default: batch, channels when a rank holds ONE sample).  "
+                         "`--parallel modeshard --workload fno3d_128_m32_c32_b1 --chunk-dim channels` on ONE GPU = the "
+                         "per-rank compute of configs[3] strong-scaled over 8 GPUs, chunked launches included "
+                         "(a one-rank RCCL group: the exchanges degenerate to device copies)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra.* measurements")
     ap.add_argument("--no-gpu-reference", action="store_true", help="skip gpu_reference_baseline")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
@@ -558,7 +565,7 @@ def timed_steps(step, steps, warmup, dist, dev, share, settle_ms=SETTLE_MS):
     return _timed_region(step, steps, warmup, dist, dev, share), cold, n
 
 
-def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv_kwargs=None):
+def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv_kwargs=None, mp_kwargs=None):
     """(step fn, per-GPU batch, global batch, scaling, parallelism tag, conv) of one measurement.
     conv_kwargs: extra constructor arguments of the single-GPU layer (extra.tfno_rank01: Tucker weights)."""
     from neuraloperator_amd import SpectralConv
@@ -567,9 +574,9 @@ def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv
     torch.manual_seed(seed)
     local_spatial = list(spatial)
     post = None
-    if parallel == "modeshard" and world > 1:
+    if parallel == "modeshard" and (world > 1 or dist is not None):
         from neuraloperator_amd.mpu import ModeParallelSpectralConv
-        conv = ModeParallelSpectralConv(C, C, n_modes, engine_flags=flags).to(dev)
+        conv = ModeParallelSpectralConv(C, C, n_modes, engine_flags=flags, **(mp_kwargs or {})).to(dev)
         if workload == "fno2d_256_m64_c64_b32":
             b_local, scaling = B, "weak"                 # the metric workload: B = 32 per GPU at every N
         else:
@@ -636,9 +643,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.parallel == "modeshard":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -666,7 +674,12 @@ def main():
         if engine.get_plan_bf16_io(dev, list(spatial), kept_chk, "forward", flags) is None:
             raise SystemExit(f"--io bf16: {args.workload} does not run on the fused 2-D kernels (no bf16 I/O there)")
 
-    case = build_case(parallel, args.workload, world, dev, flags, io_dtype, dist, 1234 + rank)
+    mp_kw = {}
+    if args.comm_chunks > 0:
+        mp_kw["comm_chunks"] = args.comm_chunks
+    if args.chunk_dim:
+        mp_kw["chunk_dim"] = args.chunk_dim
+    case = build_case(parallel, args.workload, world, dev, flags, io_dtype, dist, 1234 + rank, mp_kwargs=mp_kw)
     if case is None:
         raise SystemExit(f"{args.workload}: batch {B} not divisible by {world} ranks for the strong-scaling run")
     step, b_local, global_batch, scaling, par, conv = case
@@ -805,7 +818,7 @@ def main():
                                      "(profiles/r02_clock_ramp.txt: the first ~30 steps after any idle period run "
                                      "10-25 % slower)"},
         }
-        if world > 1:
+        if world > 1 or parallel == "modeshard":
             out["collectives"] = {"backend": "gloo (SC_BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL over xGMI)",
                                   "all_to_all_calls_per_step": round(a2a["calls"] / n_timed, 2),
                                   "all_to_all_bytes_per_step_per_rank": int(a2a["bytes"] / n_timed)}

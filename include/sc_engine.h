@@ -174,6 +174,10 @@ int sc_modegemm(const sc_modegemm_desc* d, const float* A, const float* B, float
 int sc_modegemm_pair(const sc_modegemm_desc* d0, const float* A0, const float* B0, float* C0,
                      const sc_modegemm_desc* d1, const float* A1, const float* B1, float* C1, void* stream);
 int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1);
+/* Which launch(es) sc_modegemm_pair issues for 16-byte aligned operands with B0 == A1 (introspection for tests and
+ * profiles, like sc_modegemm_path): 2 = one launch of k_modegemm_sb_bwd, 1 = one launch of k_modegemm_dma_bwd,
+ * 0 = two sc_modegemm launches. */
+int sc_modegemm_pair_path(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1);
 /* C[p, q] += sum_m sum_r opA(A[p, r, m]) * opB(B[r, q, m]) -- the gradient of a mode-independent
  * operand (Tucker / CP factor matrices, autograd of spectral_convolution.py:55-103): lanes run over
  * the modes, wave reduction, one atomic add per (p, q) and mode tile.  C (element offsets

@@ -150,7 +150,7 @@ class ScEngineLib:
                "sc_pointwise_linear_backward", "sc_pointwise_linear_workspace_bytes", "sc_layer_backward_ex",
                "sc_pointwise_mlp_backward_ex", "sc_tucker_modes_supported", "sc_tucker_modes_forward",
                "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes", "sc_modegemm_pair",
-               "sc_modegemm_pair_fused", "sc_plan_workspace_bytes_sharded", "sc_transform_forward_sharded",
+               "sc_modegemm_pair_fused", "sc_modegemm_pair_path", "sc_plan_workspace_bytes_sharded", "sc_transform_forward_sharded",
                "sc_transform_inverse_sharded", "sc_bias_grad_sharded", "sc_tucker_chain_forward",
                "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes"]
 
@@ -187,6 +187,8 @@ class ScEngineLib:
         L.sc_modegemm_pair.restype = c_int
         L.sc_modegemm_pair_fused.argtypes = [POINTER(ModeGemmDesc), POINTER(ModeGemmDesc)]
         L.sc_modegemm_pair_fused.restype = c_int
+        L.sc_modegemm_pair_path.argtypes = [POINTER(ModeGemmDesc), POINTER(ModeGemmDesc)]
+        L.sc_modegemm_pair_path.restype = c_int
         L.sc_modegemm_msum.argtypes = [POINTER(ModeGemmDesc), c_void_p, c_void_p, c_void_p, c_void_p]
         L.sc_modegemm_msum.restype = c_int
         L.sc_modegemm_msum_workspace_bytes.argtypes = [POINTER(ModeGemmDesc)]
@@ -372,6 +374,11 @@ class ScEngineLib:
     def modegemm_pair_fused(self, kw0, kw1):
         d0, d1 = self._gemm_desc(kw0), self._gemm_desc(kw1)
         return bool(self.lib.sc_modegemm_pair_fused(byref(d0), byref(d1)))
+
+    def modegemm_pair_path(self, kw0, kw1):
+        """2 = one pass over the weight (k_modegemm_sb_bwd), 1 = one k_modegemm_dma_bwd launch, 0 = two launches."""
+        d0, d1 = self._gemm_desc(kw0), self._gemm_desc(kw1)
+        return int(self.lib.sc_modegemm_pair_path(byref(d0), byref(d1)))
 
     def pointwise_mlp_forward(self, batch, c_in, c_hid, c_out, spatial, act, x, w1, b1, w2, b2, skip, gate, out, stream=0):
         d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)

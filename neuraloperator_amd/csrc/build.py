@@ -8,8 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libsc_engine.so")
 SOURCES = ["sc_engine.cpp"]
-HEADERS = ["sc_device.h", "sc_kernels_generic.h", "sc_kernels_fft.h", "sc_kernels_fft3.h", "sc_kernels_mfma.h", "sc_kernels_gemm8.h", "sc_kernels_mdft.h", "sc_kernels_fft2p.h", "sc_kernels_plane.h", "sc_kernels_pmlp.h", "sc_kernels_tucker.h", "sc_kernels_sb.h", "sc_kernels_fmx.h",
-           os.path.join("..", "..", "include", "sc_engine.h")]
+# every kernel header next to the source (globbed: a new sc_kernels_*.h can not be forgotten here)
+HEADERS = sorted(f for f in os.listdir(HERE) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sc_engine.h")]
 
 
 def find_hipcc():

@@ -14,6 +14,7 @@
 
 #ifndef SC_EMU
 // --------------------------------------------------------------------------- HIP (product)
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #define SC_GLOBAL __global__
@@ -135,23 +136,29 @@ static inline int sc_cu_count() {
 // issued to `main` so far; sc_side_join: `main` waits for everything issued to the side stream so far.  Events only,
 // no host synchronisation, so the pattern also records into a hipGraph as a fork / join.  One set per device, created
 // on first use; SC_NO_SIDE_STREAM=1 (environment) or any creation failure -> nullptr = the caller stays on one stream.
+// Thread safety: creation is once per device under a mutex; fork / join take the set's own mutex and a
+// FRESH slot of an 8-deep event ring under it, so two host threads that issue on the same device serialise their
+// record + wait pairs instead of interleaving them (hipEventRecord + hipStreamWaitEvent of one pair stay atomic).
 struct ScSide {
   hipStream_t stream;
-  hipEvent_t fork_ev[4], join_ev[4];
-  int n_fork, n_join;
+  hipEvent_t fork_ev[8], join_ev[8];
+  unsigned n_fork, n_join;
+  std::mutex mu;
 };
 static inline ScSide* sc_side_get() {
   static ScSide* cached[64] = {nullptr};
   static bool tried[64] = {false};
+  static std::mutex create_mu;
   static const bool off = [] { const char* e = getenv("SC_NO_SIDE_STREAM"); return e && e[0] == '1'; }();
   if (off) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(create_mu);
   if (!tried[dev]) {
     tried[dev] = true;
     ScSide* s = new ScSide();
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 4; ++i)
+    for (int i = 0; ok && i < 8; ++i)
       ok = hipEventCreateWithFlags(&s->fork_ev[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&s->join_ev[i], hipEventDisableTiming) == hipSuccess;
     s->n_fork = s->n_join = 0;
@@ -160,13 +167,26 @@ static inline ScSide* sc_side_get() {
   return cached[dev];
 }
 static inline bool sc_side_fork(ScSide* s, hipStream_t main) {
-  hipEvent_t e = s->fork_ev[s->n_fork++ & 3];
+  std::lock_guard<std::mutex> lock(s->mu);
+  hipEvent_t e = s->fork_ev[s->n_fork++ & 7];
   return hipEventRecord(e, main) == hipSuccess && hipStreamWaitEvent(s->stream, e, 0) == hipSuccess;
 }
 static inline bool sc_side_join(ScSide* s, hipStream_t main) {
-  hipEvent_t e = s->join_ev[s->n_join++ & 3];
+  std::lock_guard<std::mutex> lock(s->mu);
+  hipEvent_t e = s->join_ev[s->n_join++ & 7];
   return hipEventRecord(e, s->stream) == hipSuccess && hipStreamWaitEvent(main, e, 0) == hipSuccess;
 }
+// joins on scope exit once armed: an early error return of a forked call must not leave the side stream running over
+// a workspace the caller frees next, nor a hipGraph capture with an unjoined fork
+struct ScSideJoinGuard {
+  ScSide* side;
+  hipStream_t main;
+  bool armed;
+  ScSideJoinGuard(ScSide* s, hipStream_t m) : side(s), main(m), armed(false) {}
+  ~ScSideJoinGuard() {
+    if (side && armed) (void)sc_side_join(side, main);
+  }
+};
 
 #else
 // --------------------------------------------------------------------------- host emulation
@@ -286,6 +306,10 @@ struct ScSide {
 inline ScSide* sc_side_get() { return nullptr; }
 inline bool sc_side_fork(ScSide*, sc_stream_t) { return true; }
 inline bool sc_side_join(ScSide*, sc_stream_t) { return true; }
+struct ScSideJoinGuard {
+  bool armed = false;
+  ScSideJoinGuard(ScSide*, sc_stream_t) {}
+};
 #endif
 
 // compile-time integer tag (selects a template body from a wave-uniform runtime value)

@@ -114,6 +114,7 @@ struct sc_plan {
   int f2p_k2[2] = {0, 0};       // range of the pruned 32-point stage: kept rows / kept columns
   int f2p_ncb = 0;              // panel blocks of 8 kept columns
   cf32* f2p_tw[2] = {nullptr, nullptr};
+  cf32* f2p_w1024 = nullptr;    // exp(-2 pi i m / 1024), m = 0..1023: rows of 1024 points on k_f2p_c2r_w1024 (round 4)
   float* f2p_cs_fwd[2] = {nullptr, nullptr};   // [SC_FWD_SCALED], [SC_FWD_ADJ_C2R]
   float* f2p_cs_inv[2] = {nullptr, nullptr};   // [SC_INV_PADDED], [SC_INV_ADJ_R2C]
   // factorised last-two-axes kernels for 128 x 128 planes (sc_kernels_plane.h)
@@ -469,6 +470,14 @@ static int f2p_plan_init(sc_plan* p, bool large_only) {
   }
   int rc = fft_col_scales(p, p->f2p_cs_fwd, p->f2p_cs_inv);
   if (rc) return rc;
+  if (p->n[1] == 1024 && J <= 129) {                     // one wave per row pair (k_f2p_c2r_w1024): kept columns |k| <= 128
+    std::vector<cf32> h(1024);
+    for (int m = 0; m < 1024; ++m) h[(size_t)m] = twiddle(m, 1, 1024, -1.0, 1.0);
+    DeviceTable dt;
+    rc = upload_table(p, h, 1, 1024, &dt);
+    if (rc) return rc;
+    p->f2p_w1024 = dt.ptr;
+  }
   p->f2p = true;
   return 0;
 }
@@ -530,61 +539,161 @@ static bool f2p_dispatch(int P, int K2, F&& f) {
   }
 }
 
+// Round 4: the two passes of a transform run as a TWO-STAGE PIPELINE over half-sized chunks on two streams (the caller's
+// and the engine's side stream, sc_device.h): the small pass of chunk c (k_f2p_col_*: latency / L2 bound, a fraction of
+// the chip's bandwidth) runs beside the large pass of its neighbour chunk (k_f2p_r2c / k_f2p_c2r: VALU + HBM), the panel
+// is double-buffered inside the same workspace (two halves), and the dependencies are events only (fork / join: the
+// pattern records into a hipGraph).  SC_F2P_NO_PIPE=1 (environment) or no side stream (emulation, SC_NO_SIDE_STREAM=1):
+// the passes alternate on the caller's stream as before, over full-sized chunks.
+static bool f2p_pipe_enabled() {
+  static const bool off = [] { const char* e = std::getenv("SC_F2P_NO_PIPE"); return e && e[0] == '1'; }();
+  return !off;
+}
+struct F2pChunks {
+  int64_t chunk;      // images per chunk
+  int64_t n_chunks;
+  bool pipe;          // two half-workspace panel buffers, two streams
+};
+static F2pChunks f2p_chunks(const sc_plan* p, int64_t n_images, const ScSide* side) {
+  F2pChunks c;
+  const int64_t full = f2p_chunk_images(p, n_images);        // what the workspace was sized for
+  c.pipe = side != nullptr && f2p_pipe_enabled() && full >= 2 && n_images >= 16;
+  c.chunk = c.pipe ? full / 2 : full;
+  // equal chunks (no short tail chunk at the end of the pipeline)
+  c.n_chunks = (n_images + c.chunk - 1) / c.chunk;
+  if (c.pipe && c.n_chunks < 2) c.n_chunks = 2;
+  c.chunk = (n_images + c.n_chunks - 1) / c.n_chunks;
+  return c;
+}
+
+static bool f2p_launch_r2c(const sc_plan* p, int mode, const float* xs, cf32* panel, int64_t ni, sc_stream_t st) {
+  const int N0 = (int)p->n[0], J = (int)p->k[1], NCB = p->f2p_ncb;
+  return f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
+    constexpr int G = 32 / decltype(P)::value;           // row pairs per half-wave
+    SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)((ni * N0 / 2 + 8 * G - 1) / (8 * G))),
+              dim3(256), 0, st,
+              xs, panel, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_fwd[mode], N0, J, NCB, ni * N0 / 2);
+  });
+}
+static bool f2p_launch_col_fwd(const sc_plan* p, const cf32* panel, cf32* dst, int64_t ni, sc_stream_t st) {
+  const int J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
+  const int64_t n_blk = ni * NCB;
+  return f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
+    constexpr int G = 32 / decltype(P)::value;           // panel blocks per workgroup
+    const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
+    SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * pxc)), dim3(256), 0, st,
+              panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
+  });
+}
+static bool f2p_launch_col_inv(const sc_plan* p, const cf32* src, cf32* panel, int64_t ni, sc_stream_t st) {
+  const int J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
+  const int64_t n_blk = ni * NCB;
+  return f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
+    constexpr int G = 32 / decltype(P)::value;
+    const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
+    SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * pxc)), dim3(256), 0, st,
+              src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
+  });
+}
+static bool f2p_launch_c2r(const sc_plan* p, int mode, const cf32* panel, float* ys, const float* bias, int64_t channels,
+                           int64_t i0, int64_t ni, sc_stream_t st) {
+  const int N0 = (int)p->n[0], J = (int)p->k[1], NCB = p->f2p_ncb;
+  static const bool no_w1024 = std::getenv("SC_F2P_NO_W1024") != nullptr;          // A-B: the half-wave kernel
+  if (p->f2p_w1024 && !no_w1024) {
+    // rows of 1024 points: one wave per packed row pair, four 4-wave workgroups per compute unit (sc_kernels_fft2p.h)
+    static const int wgs = [] { const char* e = std::getenv("SC_F2P_W1024_WGS"); return e ? std::atoi(e) : 4; }();
+    const int64_t n_pairs = ni * N0 / 2, n_items = (n_pairs + 3) / 4;
+    int64_t grid = (int64_t)(wgs > 0 ? wgs : 4) * sc_cu_count();
+    if (grid > n_items) grid = n_items;
+    SC_LAUNCH(k_f2p_c2r_w1024, dim3((unsigned)grid), dim3(256), 0, st, panel, ys, (const cf32*)p->f2p_w1024,
+              (const float*)p->f2p_cs_inv[mode], bias, (int)channels, (int)(i0 % channels), N0, J, NCB, n_pairs, n_items,
+              (int)grid);
+    return true;
+  }
+  return f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
+    constexpr int G = 32 / decltype(P)::value;
+    const int64_t n_items = (ni * N0 / 2 + 8 * G - 1) / (8 * G);
+    int64_t grid = (int64_t)SC_F2P_C2R_WGS * sc_cu_count();   // persistent workgroups (sc_kernels_fft2p.h)
+    if (grid > n_items) grid = n_items;
+    SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)grid), dim3(256), 0, st,
+              panel, ys, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_inv[mode], bias,
+              (int)channels, (int)(i0 % channels), N0, J, NCB, ni * N0 / 2, n_items, (int)grid);
+  });
+}
+
 static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, int64_t n_images, void* workspace,
                        sc_stream_t st) {
   SC_CHECK_ARG(workspace, "workspace required");
-  cf32* panel = (cf32*)workspace;
-  const int N0 = (int)p->n[0], J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
-  const int64_t chunk = f2p_chunk_images(p, n_images);
-  for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
-    const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
-    const int64_t n_blk = ni * NCB;
-    const float* xs = x + i0 * p->ntot;
-    bool ok = f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
-      constexpr int G = 32 / decltype(P)::value;           // row pairs per half-wave
-      SC_LAUNCH((k_f2p_r2c<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)((ni * N0 / 2 + 8 * G - 1) / (8 * G))),
-                dim3(256), 0, st,
-                xs, panel, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_fwd[mode], N0, J, NCB, ni * N0 / 2);
-    });
-    cf32* dst = xhat + i0 * p->modes;
-    ok = ok && f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
-      constexpr int G = 32 / decltype(P)::value;           // panel blocks per workgroup
-      const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
-      SC_LAUNCH((k_f2p_col_fwd<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * pxc)), dim3(256), 0, st,
-                (const cf32*)panel, dst, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
-    });
-    if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
+  ScSide* side = sc_side_get();
+  const F2pChunks ck = f2p_chunks(p, n_images, side);
+  cf32* buf[2] = {(cf32*)workspace, (cf32*)workspace + (ck.pipe ? ck.chunk * f2p_panel_elems_per_image(p) : 0)};
+  const char* nok = "sc_engine: two-pass route: no kernel for this line length / kept range";
+  const char* sync_fail = "sc_engine: two-pass route: event record / wait failed";
+  auto ni_of = [&](int64_t c) { const int64_t i0 = c * ck.chunk; return n_images - i0 < ck.chunk ? n_images - i0 : ck.chunk; };
+  if (!ck.pipe) {
+    for (int64_t c = 0; c < ck.n_chunks; ++c) {
+      const int64_t i0 = c * ck.chunk, ni = ni_of(c);
+      if (!f2p_launch_r2c(p, mode, x + i0 * p->ntot, buf[0], ni, st) ||
+          !f2p_launch_col_fwd(p, buf[0], xhat + i0 * p->modes, ni, st))
+        return sc_fail(nok);
+    }
+    return sc_check_launch("k_f2p_r2c / k_f2p_col_fwd");
   }
+  // main: r2c(0) r2c(1) r2c(2) ...        side: col_fwd(0) col_fwd(1) ...   (col_fwd(c) after r2c(c); r2c(c + 2) after
+  // col_fwd(c): same panel buffer)
+  ScSideJoinGuard guard(side, st);
+  sc_stream_t ss = (sc_stream_t)side->stream;
+  if (!f2p_launch_r2c(p, mode, x, buf[0], ni_of(0), st)) return sc_fail(nok);
+  for (int64_t c = 0; c < ck.n_chunks; ++c) {
+    const int64_t i0 = c * ck.chunk, ni = ni_of(c);
+    if (guard.armed && !sc_side_join(side, st)) return sc_fail(sync_fail);          // main: col_fwd(<= c - 1) are done
+    if (!sc_side_fork(side, st)) return sc_fail(sync_fail);                          // side: r2c(c) is done
+    guard.armed = true;
+    if (!f2p_launch_col_fwd(p, buf[c & 1], xhat + i0 * p->modes, ni, ss)) return sc_fail(nok);
+    if (c + 1 < ck.n_chunks &&
+        !f2p_launch_r2c(p, mode, x + (i0 + ck.chunk) * p->ntot, buf[(c + 1) & 1], ni_of(c + 1), st))
+      return sc_fail(nok);
+  }
+  guard.armed = false;
+  if (!sc_side_join(side, st)) return sc_fail(sync_fail);
   return sc_check_launch("k_f2p_r2c / k_f2p_col_fwd");
 }
 
 static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float* bias, int64_t channels, float* y,
                        int64_t n_images, void* workspace, sc_stream_t st) {
   SC_CHECK_ARG(workspace, "workspace required");
-  cf32* panel = (cf32*)workspace;
-  const int N0 = (int)p->n[0], J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
-  const int64_t chunk = f2p_chunk_images(p, n_images);
-  for (int64_t i0 = 0; i0 < n_images; i0 += chunk) {
-    const int64_t ni = (n_images - i0 < chunk) ? n_images - i0 : chunk;
-    const int64_t n_blk = ni * NCB;
-    const cf32* src = yhat + i0 * p->modes;
-    bool ok = f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
-      constexpr int G = 32 / decltype(P)::value;
-      const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
-      SC_LAUNCH((k_f2p_col_inv<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)(8 * pxc)), dim3(256), 0, st,
-                src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
-    });
-    float* ys = y + i0 * p->ntot;
-    ok = ok && f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
-      constexpr int G = 32 / decltype(P)::value;
-      const int64_t n_items = (ni * N0 / 2 + 8 * G - 1) / (8 * G);
-      int64_t grid = (int64_t)SC_F2P_C2R_WGS * sc_cu_count();   // persistent workgroups (sc_kernels_fft2p.h)
-      if (grid > n_items) grid = n_items;
-      SC_LAUNCH((k_f2p_c2r<decltype(P)::value, decltype(K2)::value>), dim3((unsigned)grid), dim3(256), 0, st,
-                (const cf32*)panel, ys, (const cf32*)p->f2p_tw[1], (const float*)p->f2p_cs_inv[mode], bias,
-                (int)channels, (int)(i0 % channels), N0, J, NCB, ni * N0 / 2, n_items, (int)grid);
-    });
-    if (!ok) return sc_fail("sc_engine: two-pass route: no kernel for this line length / kept range");
+  ScSide* side = sc_side_get();
+  const F2pChunks ck = f2p_chunks(p, n_images, side);
+  cf32* buf[2] = {(cf32*)workspace, (cf32*)workspace + (ck.pipe ? ck.chunk * f2p_panel_elems_per_image(p) : 0)};
+  const char* nok = "sc_engine: two-pass route: no kernel for this line length / kept range";
+  const char* sync_fail = "sc_engine: two-pass route: event record / wait failed";
+  auto ni_of = [&](int64_t c) { const int64_t i0 = c * ck.chunk; return n_images - i0 < ck.chunk ? n_images - i0 : ck.chunk; };
+  if (!ck.pipe) {
+    for (int64_t c = 0; c < ck.n_chunks; ++c) {
+      const int64_t i0 = c * ck.chunk, ni = ni_of(c);
+      if (!f2p_launch_col_inv(p, yhat + i0 * p->modes, buf[0], ni, st) ||
+          !f2p_launch_c2r(p, mode, buf[0], y + i0 * p->ntot, bias, channels, i0, ni, st))
+        return sc_fail(nok);
+    }
+    return sc_check_launch("k_f2p_col_inv / k_f2p_c2r");
+  }
+  // side: col_inv(0) col_inv(1) ...       main: c2r(0) c2r(1) ...   (c2r(c) after col_inv(c); col_inv(c + 2) after
+  // c2r(c): same panel buffer)
+  ScSideJoinGuard guard(side, st);
+  sc_stream_t ss = (sc_stream_t)side->stream;
+  if (!sc_side_fork(side, st)) return sc_fail(sync_fail);                            // side: the spectrum is ready
+  guard.armed = true;
+  if (!f2p_launch_col_inv(p, yhat, buf[0], ni_of(0), ss)) return sc_fail(nok);
+  for (int64_t c = 0; c < ck.n_chunks; ++c) {
+    const int64_t i0 = c * ck.chunk, ni = ni_of(c);
+    if (!sc_side_join(side, st)) return sc_fail(sync_fail);                          // main: col_inv(<= c) are done
+    guard.armed = false;
+    if (c + 1 < ck.n_chunks) {
+      if (!sc_side_fork(side, st)) return sc_fail(sync_fail);                        // side: c2r(<= c - 1) are done
+      guard.armed = true;
+      if (!f2p_launch_col_inv(p, yhat + (i0 + ck.chunk) * p->modes, buf[(c + 1) & 1], ni_of(c + 1), ss)) return sc_fail(nok);
+    }
+    if (!f2p_launch_c2r(p, mode, buf[c & 1], y + i0 * p->ntot, bias, channels, i0, ni, st)) return sc_fail(nok);
   }
   return sc_check_launch("k_f2p_col_inv / k_f2p_c2r");
 }
@@ -843,13 +952,20 @@ static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, co
 #define SC_C2R_NPF 12          // registers per thread holding the next tile's input (k_mdft_c2r_lds)
 // ---- "plane" form: the last TWO axes in one launch when the second-to-last has 128, 64 or 32 rows --------
 static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32; }
-static bool plane_fwd_ok(const sc_plan* p, int mode) {
+// io = the real tensor the pass reads (forward) / writes (inverse); nullptr = "aligned".  The plane kernels and the
+// matrix-core DFT passes move its rows with 16-byte accesses.  A contiguous view with an odd storage offset
+// (flat[1:1 + n].view(...), a gradient handed over out of a bucketed buffer) takes the VALU passes with 4-byte accesses
+// for the real-side pass instead (k_last_r2c / k_last_c2r: slow, correct, rare) -- the call does not fail.
+static bool sc_io_aligned(const void* io) { return !(((uintptr_t)io) & 15); }
+static bool plane_fwd_ok(const sc_plan* p, int mode, const void* io = nullptr) {
+  if (!sc_io_aligned(io)) return false;
   if (p->pl128 || p->pl64) return true;
   const int L = p->nd - 1;
   return p->nd >= 2 && p->mdft && !p->cplx && p->l_r2c[mode] && p->m_pl_fwd && plane_rows_ok(p->n[L - 1]) &&
          2 * p->k[L - 1] <= p->n[L - 1] && !mdft_switches().nolds && !mdft_switches().noplane;
 }
-static bool plane_inv_ok(const sc_plan* p, int mode) {
+static bool plane_inv_ok(const sc_plan* p, int mode, const void* io = nullptr) {
+  if (!sc_io_aligned(io)) return false;
   if (p->pl128 || p->pl64) return true;
   const int L = p->nd - 1;
   if (!(p->nd >= 2 && p->mdft && !p->cplx && p->l_c2r[mode] && p->m_pl_inv && plane_rows_ok(p->n[L - 1]) &&
@@ -883,6 +999,7 @@ static void dispatch_plane_fwd(const sc_plan* p, int mode, const float* in, cf32
 
 // x (planes x 128 x N real) -> (planes x K1 x J complex): last axis + second-to-last axis
 static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
+  if (!sc_io_aligned(in)) return sc_fail("sc_engine: the plane kernels need 16-byte aligned planes (plane_fwd_ok)");
   if (p->pl128) {
     const int L = p->nd - 1;
     // planes per workgroup: the next plane's first rows are in flight while this one is finished (A-B: SC_PL_PPW)
@@ -896,7 +1013,6 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
   }
   if (p->pl64) {
     const int L = p->nd - 1;
-    if (((uintptr_t)in) & 15) return sc_fail("sc_engine: the 64 x 64 plane kernels need 16-byte aligned planes");
     // planes per workgroup: the next plane's rows are in flight while this one is transformed (A-B: SC_P64_PPW)
     static const int ppw_env = [] { const char* e = std::getenv("SC_P64_PPW"); return e ? std::atoi(e) : 0; }();
     const int64_t n_planes = lines / SC_P64_N;
@@ -920,7 +1036,8 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
 static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64_t lines, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
-  if (p->mdft && p->l_r2c[mode] && lines < ((int64_t)1 << 36) && !mdft_switches().nolds) {
+  const bool al = sc_io_aligned(in);                   // 16-byte loads in the matrix-core passes
+  if (al && p->mdft && p->l_r2c[mode] && lines < ((int64_t)1 << 36) && !mdft_switches().nolds) {
     const float* tab = p->l_r2c[mode];
     const cf32* tail = p->l_r2c_tail[mode];
     if (tail) {
@@ -932,7 +1049,7 @@ static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64
     }
     return sc_check_launch("k_mdft_r2c_lds");
   }
-  if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
+  if (al && p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
     if (p->m_r2c_tail[mode] && !mdft_switches().notail && 2 * J > 32)
       dispatch_mdft_r2c<true>(in, out, p->m_r2c[mode], p->m_r2c_tail[mode], lines, N, J, (2 * J - 2) / 32, st);
     else
@@ -1016,13 +1133,13 @@ static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, 
 static int run_plane_inv(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias, int64_t lines,
                          int64_t lpi, int64_t channels, sc_stream_t st) {
   const int L = p->nd - 1;
+  if (!sc_io_aligned(out)) return sc_fail("sc_engine: the plane kernels need 16-byte aligned planes (plane_inv_ok)");
   if (p->pl128) {
     SC_LAUNCH(k_pl128_inv, dim3((unsigned)(lines / SC_PL_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
               (const float*)p->pl_cs_inv[mode], bias, lpi / SC_PL_N, (int)channels, (int)p->k[L - 1], (int)p->k[L]);
     return sc_check_launch("k_pl128_inv");
   }
   if (p->pl64) {
-    if (((uintptr_t)out) & 15) return sc_fail("sc_engine: the 64 x 64 plane kernels need 16-byte aligned planes");
     SC_LAUNCH(k_pl64_inv, dim3((unsigned)(lines / SC_P64_N)), dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128,
               (const float*)p->pl_cs_inv[mode], bias, lpi / SC_P64_N, (int)channels, (int)p->k[L - 1], (int)p->k[L]);
     return sc_check_launch("k_pl64_inv");
@@ -1047,7 +1164,8 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
                    int64_t lpi, int64_t channels, sc_stream_t st) {
   const int L = p->nd - 1;
   const int N = (int)p->n[L], J = (int)p->k[L];
-  if (p->mdft && p->l_c2r[mode] && lines < ((int64_t)1 << 36) && (bias == nullptr || lpi % 32 == 0) &&
+  const bool al = sc_io_aligned(out);                  // 16-byte stores in the matrix-core passes
+  if (al && p->mdft && p->l_c2r[mode] && lines < ((int64_t)1 << 36) && (bias == nullptr || lpi % 32 == 0) &&
       !mdft_switches().nolds) {
     const int n_nt = (N + 31) / 32;
     if (n_nt >= 4) launch_mdft_c2r_lds<4>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
@@ -1055,7 +1173,7 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
     else launch_mdft_c2r_lds<1>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
     return sc_check_launch("k_mdft_c2r_lds");
   }
-  if (p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
+  if (al && p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
     const int n_nt = (N + 31) / 32;
     const bool big = !mdft_switches().tile4;
     const int rt = big ? (n_nt <= 2 ? 4 : (n_nt <= 4 ? 2 : 1)) : (n_nt <= 2 ? 2 : 1);
@@ -1191,7 +1309,7 @@ static int transform_forward_impl(const sc_plan* p, int mode, const float* x, fl
     return run_r2c(p, mode, x, dst, lines, st);
   };
   if (p->nd == 1) return last_pass((cf32*)xhat);
-  if (p->nd == 2 && plane_fwd_ok(p, mode)) return run_plane_fwd(p, mode, x, (cf32*)xhat, lines, st);
+  if (p->nd == 2 && plane_fwd_ok(p, mode, x)) return run_plane_fwd(p, mode, x, (cf32*)xhat, lines, st);
   SC_CHECK_ARG(workspace, "workspace required");
   int64_t s1, s2;
   generic_ws_sizes(p, n_images, &s1, &s2);
@@ -1201,7 +1319,7 @@ static int transform_forward_impl(const sc_plan* p, int mode, const float* x, fl
   cf32* cur = bufA;
   int64_t inner = p->k[L];
   int d_first = L - 1;
-  if (plane_fwd_ok(p, mode)) {               // last two axes in one launch; its result takes the place of
+  if (plane_fwd_ok(p, mode, x)) {            // last two axes in one launch; its result takes the place of
     cur = bufB;                              // the second-to-last axis pass' (bufB)
     rc = run_plane_fwd(p, mode, x, cur, lines, st);
     inner *= p->k[L - 1];
@@ -1301,7 +1419,7 @@ static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat,
     return run_c2r(p, mode, src, y, bias, lines, lpi, channels, st);
   };
   if (p->nd == 1) return last_pass((const cf32*)yhat);
-  if (p->nd == 2 && plane_inv_ok(p, mode))
+  if (p->nd == 2 && plane_inv_ok(p, mode, y))
     return run_plane_inv(p, mode, (const cf32*)yhat, y, bias, lines, lpi, channels, st);
   SC_CHECK_ARG(workspace, "workspace required");
   int64_t s1, s2;
@@ -1311,7 +1429,7 @@ static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat,
   // choose buffers so that the final intermediate lands in bufA
   const cf32* cur = (const cf32*)yhat;
   int64_t outer = n_images;
-  const bool plane = plane_inv_ok(p, mode);
+  const bool plane = plane_inv_ok(p, mode, y);
   const int d_end = plane ? L - 1 : L;
   for (int d = 0; d < d_end; ++d) {
     int64_t inner = 1;
@@ -1919,6 +2037,15 @@ extern "C" int sc_modegemm_pair(const sc_modegemm_desc* d0, const float* A0, con
   return rc ? rc : sc_modegemm(d1, A1, B1, C1, stream);
 }
 
+// which launch(es) a pair with 16-byte aligned operands (B0 and A1 the same array) takes: 2 = ONE pass over the weight
+// (k_modegemm_sb_bwd), 1 = one launch of k_modegemm_dma_bwd, 0 = two launches
+extern "C" int sc_modegemm_pair_path(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1) {
+  if (!d0 || !d1) return 0;
+  static const float* const al = reinterpret_cast<const float*>(uintptr_t(256));   // alignment probe only
+  if (sb_bwd_eligible(d0, al, al, al, d1, al, al, al)) return 2;
+  return sc_modegemm_pair_fused(d0, d1) ? 1 : 0;
+}
+
 extern "C" int sc_modegemm_pair_fused(const sc_modegemm_desc* d0, const sc_modegemm_desc* d1) {
   if (!d0 || !d1) return 0;
 #ifdef SC_G8_NO_PAIR
@@ -2164,7 +2291,9 @@ extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const flo
   ScSide* side = sc_side_get();
   void* ss = side ? (void*)side->stream : stream;
   const char* sync_fail = "sc_tucker_chain_backward: event record / wait failed";
+  ScSideJoinGuard guard(side, main);            // every exit below -- error returns included -- joins the side stream
   if (side && !sc_side_fork(side, main)) return sc_fail(sync_fail);                 // the inputs are ready
+  guard.armed = side != nullptr;
   // yhat = t u_out^T:  gt = gy conj(u_out);  gu_out[o, g] = sum_{b, m} conj(t[b, g, m]) gy[b, o, m]
   sc_modegemm_desc d = tkc_desc(B, R2, Co, M, Co * M, M, 1, R2, 1, 0, R2 * M, M, 1, 0, 1);
   if ((rc = sc_modegemm(&d, gy, u_out, gt, stream))) return rc;
@@ -2190,6 +2319,7 @@ extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const flo
     d = tkc_desc(B, Ci, R1, M, R1 * M, M, 1, 1, R1, 0, Ci * M, M, 1, 0, 1);
     if ((rc = sc_modegemm(&d, gz, u_in, gxhat, stream))) return rc;
   }
+  guard.armed = false;
   if (side && !sc_side_join(side, main)) return sc_fail(sync_fail);                 // gu_in
   return 0;
 }

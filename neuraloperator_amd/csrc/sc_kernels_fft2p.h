@@ -631,3 +631,103 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
   landed();
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Round 4: pass 1 inverse for 1024-point rows with ONE WAVE per packed row pair (k_f2p_c2r_w1024).
+//
+// k_f2p_c2r<32, K2> gives a row pair to a half-wave: 32 points per lane, 208 VGPRs, an 8.4 KB exchange per pair, 76 KB
+// of LDS per workgroup -- two workgroups = 8 waves per compute unit, and the kernel ran at 3.4 TB/s of stores (0.63 ms
+// of the 0.9 ms an inverse-type 1024^2 transform took) with vector, LDS and store time adding up
+// instead of overlapping.  The LDS a pair needs while it is exchanged (8 KB) is the same for any split of the line over
+// lanes, so the way to more waves per unit is FEWER points per lane: a whole wave per pair, 16 points per lane, about
+// 120 VGPRs, four 4-wave workgroups (35 KB + tables each) = 16 waves per unit.
+//
+// The kept columns are |k| <= 128 of 1024, i.e. a quarter of the spectrum.  With n = 4 m + r:
+//     z[4 m + r] = sum_{kappa = 0}^{255} T_r[kappa] w256^(m kappa),   T_r[kappa] = Z[k] w1024^(r k),
+//     k = kappa (kappa < 128), kappa - 256 (kappa > 128), both k = +-128 at kappa = 128
+// -- the pruned radix-4 stage is one twiddle per input (the trick of k_fft2d_inv3) and leaves FOUR independent FULL
+// 256-point transforms, one per r.  Lane = (r = lane >> 4, l = lane & 15): the lane's 16 inputs kappa = l + 16 kappa2
+// come straight from the panel into registers (A[k], B[k] of the two packed rows; the four r lanes of an l read the same
+// addresses), Z = A + i B (k > 0) / conj A + i conj B (k < 0) times the lane constant cs[|k|] w1024^(r k), then
+//     U[ma]  = w256^(ma l) sum_kappa2 T[l + 16 kappa2] w16^(ma kappa2)        16-point DFT in registers
+//     exchange E[r][ma][l] -> lane (r, ma)                                     one 16 x 16 transpose per r in LDS
+//     z[r + 4 ma + 64 mb] = sum_l E[r][ma][l] w16^(mb l)                      16-point DFT in registers
+// and the 64 lanes of a store instruction cover 256 contiguous bytes of a row.  No workgroup barrier inside the loop
+// (the exchange is wave-local).  Persistent workgroups (the lane constants -- 16 twiddles, 16 panel offsets -- are set
+// up once).
+// ------------------------------------------------------------------------------------------
+#define SC_W1K_ES 17                  // exchange row stride (complex): writes (l contiguous) and reads (stride 17) conflict-free
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
+k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ w1024,
+                const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J,
+                int NCB, int64_t n_pairs, int64_t n_items, int gstride) {
+  constexpr int N = 1024;
+  SC_SHARED __attribute__((aligned(16))) cf32 tw2[256];                     // conj w256^(ma l), [ma][l]
+  SC_SHARED __attribute__((aligned(16))) cf32 Eall[4][64 * SC_W1K_ES];      // per wave: [r][ma][l]
+  const int tid = SC_TID, wv = tid >> 6, lane = tid & 63, r = lane >> 4, l = lane & 15;
+  tw2[tid] = cf_conj(w1024[(4 * (tid >> 4) * (tid & 15)) & 1023]);
+  // lane constants: cs[|k|] w1024^(+r k) and the panel offset of column |k| (columns past J: factor 0, offset 0)
+  cf32 twr[16];
+  int off[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = l + 16 * q - (q >= 8 ? 256 : 0);
+    const int ak = k < 0 ? -k : k;
+    const bool live = ak < J;
+    const cf32 w = w1024[(r * k) & 1023];                  // exp(-2 pi i r k / 1024)
+    const float s = live ? cs[ak] : 0.f;
+    twr[q] = cf_make(s * w.x, -s * w.y);
+    off[q] = live ? (ak >> 3) * N0 * SC_F2P_CB + (ak & 7) : 0;
+  }
+  cf32 twx = cf_make(0.f, 0.f);                            // k = +128 joins k = -128 in the lanes l = 0
+  if (l == 0 && 128 < J) {
+    const cf32 w = w1024[(128 * r) & 1023];
+    twx = cf_make(cs[128] * w.x, -cs[128] * w.y);
+  }
+  cf32* E = Eall[wv];
+  SC_SYNC();                                               // tw2
+
+#pragma unroll 1
+  for (int64_t item = SC_BID_X; item < n_items; item += gstride) {
+    // pairs past the end are clamped to the last one (the same values stored again)
+    const int64_t pr = item * 4 + wv < n_pairs ? item * 4 + wv : n_pairs - 1;
+    const int64_t rA = 2 * pr, img = rA / N0;
+    const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+    const float bv = bias ? bias[(img + img0) % channels] : 0.f;
+    cf32 T[16], U[16];
+    sc_static_for<0, 16>([&](auto qt) {
+      constexpr int q = decltype(qt)::value;
+      cf32 A = src[off[q]], B = src[off[q] + SC_F2P_CB];
+      if constexpr (q == 0) {                              // k = 0: the imaginary parts of the DC column are dropped
+        if (l == 0) {
+          A.y = 0.f;
+          B.y = 0.f;
+        }
+      }
+      const cf32 Zp = cf_make(A.x - B.y, A.y + B.x);       // A + i B
+      if constexpr (q < 8) {
+        T[q] = cf_mul_cs(Zp, twr[q]);
+      } else {
+        const cf32 Zn = cf_make(A.x + B.y, B.x - A.y);     // conj A + i conj B
+        T[q] = cf_mul_cs(Zn, twr[q]);
+        if constexpr (q == 8) T[q] = cf_add(T[q], cf_mul_cs(Zp, twx));
+      }
+    });
+    fft16<+1>(T, U);                                       // over kappa2 -> ma
+    E[(r * 16) * SC_W1K_ES + l] = U[0];
+#pragma unroll
+    for (int ma = 1; ma < 16; ++ma)
+      E[(r * 16 + ma) * SC_W1K_ES + l] = cf_mul_cs(U[ma], sc_lds_ld64(tw2 + ma * 16 + l));
+    SC_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T[q] = sc_lds_ld64(E + (r * 16 + l) * SC_W1K_ES + q);   // lane l now plays ma = l
+    SC_WAVE_SYNC();                                        // E is rewritten by the next item
+    fft16<+1>(T, U);                                       // over l -> mb : z[r + 4 ma + 64 mb]
+    float* ya = y + rA * N + r + 4 * l;
+#pragma unroll
+    for (int mb = 0; mb < 16; ++mb) {
+      SC_STORE_STREAM(ya + 64 * mb, U[mb].x + bv);
+      SC_STORE_STREAM(ya + N + 64 * mb, U[mb].y + bv);
+    }
+  }
+}

@@ -24,6 +24,15 @@ class GraphedStep:
             raise RuntimeError("GraphedStep: hipGraph capture needs device tensors (there is no CPU path)")
         self.module, self.x, self.grad_out = module, x, grad_out
         self.params = [p for p in module.parameters() if p.requires_grad]
+        # the capture resets every .grad and each replay OVERWRITES them: gradients accumulated before construction
+        # would be dropped silently -- refuse instead
+        held = [n for n, p in module.named_parameters() if p.requires_grad and p.grad is not None]
+        if x.requires_grad and x.grad is not None:
+            held.append("x")
+        if held:
+            raise RuntimeError("GraphedStep: .grad is already set on " + ", ".join(held[:4]) +
+                               (" ..." if len(held) > 4 else "") + "; a captured step overwrites gradients (no "
+                               "accumulation across replays): apply or clear them before capturing")
         side = torch.cuda.Stream(device=x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(side):                    # plans, tables and workspaces are created outside the capture
@@ -37,6 +46,9 @@ class GraphedStep:
             self.output = module(x)
             self.output.backward(grad_out)
         self.output = self.output.detach()
+        # the tensors every replay writes: optimizers must keep pointing at exactly these
+        self.grads = [p.grad for p in self.params]
+        self.x_grad = x.grad if x.requires_grad else None
 
     def _clear(self):
         if self.x.requires_grad:
@@ -47,6 +59,13 @@ class GraphedStep:
     def replay(self):
         """Run the step again on the current contents of ``x`` / ``grad_out`` / the parameters; returns the (static)
         output tensor.  Gradients are OVERWRITTEN, not accumulated."""
+        for p, g in zip(self.params, self.grads):
+            if p.grad is not g:
+                raise RuntimeError("GraphedStep.replay: a parameter's .grad is no longer the captured tensor "
+                                   "(zero_grad(set_to_none=True) or a reassignment detached it from the memory the "
+                                   "graph writes); use zero_grad(set_to_none=False) or restore step.grads")
+        if self.x_grad is not None and self.x.grad is not self.x_grad:
+            raise RuntimeError("GraphedStep.replay: x.grad is no longer the captured tensor")
         self.graph.replay()
         return self.output
 

@@ -23,9 +23,12 @@ has landed.  NO copy is left around the collectives (round 3): the transforms wr
 all-to-all buffers in place (engine ``*_sharded`` calls: include/sc_engine.h, sc_spectrum_shards), the receive
 buffer of the way out IS the contraction's operand and the contraction's result IS the send buffer of the way back;
 the R-sized real tensors are written in place (``out=`` slices).  With one sample per rank (BASELINE configs[3] on 8
-GPUs) the channels take the place of the batch as the chunked dim, and the default there is ONE chunk: at 4.5 MB per
-rank and exchange the pipeline's extra launches cost more than the overlap wins.  When k1 is not a multiple of P the
-mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
+GPUs) the channels take the place of the batch as the chunked dim.  Round 4: channel chunks are copy-free as well -- a
+chunk's block for rank p is a contiguous slab (channels c0:c1) of the contraction's operand / result, handed to the
+list form of the all-to-all (``_Exchange.exchange_slabs``) -- and TWO channel chunks are the default there, so that
+the second half's transform runs under the first half's exchange on the way out and the first half's inverse under the
+second half's exchange on the way back (budget: DESIGN.md section 6; ``comm_chunks=1`` restores one piece).  When k1 is
+not a multiple of P the mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
 """
 import math
 
@@ -58,6 +61,37 @@ class _Exchange:
     def exchange(self, send, recv):
         return self._a2a(recv, send)
 
+    # Round 4 -- channel chunks without copies (one sample per rank): block p of a chunk is a contiguous SLAB of a larger
+    # tensor (channels c0:c1 of sample / rank p), so the exchange takes P (send slab, receive slab) pairs instead of
+    # one contiguous buffer each way.  RCCL: the list form of all-to-all = one grouped send / receive per peer, the
+    # same transfers all_to_all_single issues, straight out of / into the slabs.  gloo (CPU tests) has no list form:
+    # P - 1 isend / irecv pairs and a local copy of this rank's own slab.
+    def exchange_slabs(self, send_slabs, recv_slabs):
+        A2A_STATS["calls"] += 1
+        A2A_STATS["bytes"] += sum(t.numel() * t.element_size() for t in send_slabs)
+        assert all(t.is_contiguous() for t in send_slabs) and all(t.is_contiguous() for t in recv_slabs)
+        if dist.get_backend(self.group) == "nccl":
+            return _Works([dist.all_to_all(list(recv_slabs), list(send_slabs), group=self.group, async_op=True)])
+        me = dist.get_rank(self.group)
+        ops = []
+        for q in range(self.P):
+            if q == me:
+                recv_slabs[q].copy_(send_slabs[q])
+            else:
+                peer = dist.get_global_rank(self.group, q) if self.group is not None else q
+                ops.append(dist.P2POp(dist.isend, send_slabs[q], peer, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, recv_slabs[q], peer, group=self.group))
+        return _Works(dist.batch_isend_irecv(ops) if ops else [])
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
 
 class _ModeParallelFn(torch.autograd.Function):
     @staticmethod
@@ -70,7 +104,7 @@ class _ModeParallelFn(torch.autograd.Function):
         rest = kept[1:]
         w = weight.detach().contiguous()
         ex = _Exchange(layer._group(), P, rows, kept[0])
-        by_batch = b >= 2 or P == 1
+        by_batch = layer._by_batch(b)
         chunks = _bounds(b, min(layer._chunks(True), b)) if by_batch else _bounds(ci, min(layer._chunks(False), ci))
         ctx.cfg = (layer, spatial, kept, b, ci, co, by_batch)
         dev = x.device
@@ -91,13 +125,13 @@ class _ModeParallelFn(torch.autograd.Function):
                 recv = xhat_all[P * c0:P * c1].view(P, c1 - c0, ci, rows, *rest, 2)
             elif single:
                 recv = xhat_all.view(P, 1, ci, rows, *rest, 2)
-            else:
-                recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
+            else:                                           # channel chunk: straight into the operand's slabs
+                pend.append((ex.exchange_slabs([send[q, 0] for q in range(P)], [xhat_all[q, c0:c1] for q in range(P)]),
+                             send, None, c0, c1))
+                continue
             pend.append((ex.exchange(send, recv), send, recv, c0, c1))
         for work, _send, recv, c0, c1 in pend:
             work.wait()
-            if not by_batch and not single:
-                xhat_all[:, c0:c1] = recv[:, 0]
         xhat_all = torch.view_as_complex(xhat_all)
 
         # ---- contraction on this rank's mode rows, whole batch
@@ -114,8 +148,11 @@ class _ModeParallelFn(torch.autograd.Function):
                 send = yr[P * c0:P * c1].view(P, c1 - c0, co, rows, *rest, 2)
             elif osingle:
                 send = yr.view(P, 1, co, rows, *rest, 2)
-            else:
-                send = yr[:, c0:c1].contiguous().view(P, 1, c1 - c0, rows, *rest, 2)
+            else:                                           # channel chunk: straight out of the result's slabs
+                recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
+                pend.append((ex.exchange_slabs([yr[q, c0:c1] for q in range(P)], [recv[q, 0] for q in range(P)]),
+                             None, recv, c0, c1))
+                continue
             recv = torch.empty_like(send)
             pend.append((ex.exchange(send, recv), send, recv, c0, c1))
         bflat = None if bias is None else bias.detach().reshape(-1)
@@ -159,12 +196,12 @@ class _ModeParallelFn(torch.autograd.Function):
             elif single:
                 recv = ghat_all.view(P, 1, co, rows, *rest, 2)
             else:
-                recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
+                pend.append((ex.exchange_slabs([send[q, 0] for q in range(P)], [ghat_all[q, c0:c1] for q in range(P)]),
+                             send, None, c0, c1))
+                continue
             pend.append((ex.exchange(send, recv), send, recv, c0, c1))
         for work, _send, recv, c0, c1 in pend:
             work.wait()
-            if not by_batch and not single:
-                ghat_all[:, c0:c1] = recv[:, 0]
         ghat_all = torch.view_as_complex(ghat_all)
         gbias = None
         if want_b:
@@ -188,7 +225,10 @@ class _ModeParallelFn(torch.autograd.Function):
                 elif isingle:
                     send = gr.view(P, 1, ci, rows, *rest, 2)
                 else:
-                    send = gr[:, c0:c1].contiguous().view(P, 1, c1 - c0, rows, *rest, 2)
+                    recv = torch.empty((P, 1, c1 - c0, rows, *rest, 2), dtype=torch.float32, device=dev)
+                    pend.append((ex.exchange_slabs([gr[q, c0:c1] for q in range(P)], [recv[q, 0] for q in range(P)]),
+                                 None, recv, c0, c1))
+                    continue
                 recv = torch.empty_like(send)
                 pend.append((ex.exchange(send, recv), send, recv, c0, c1))
             for work, _send, recv, c0, c1 in pend:
@@ -202,7 +242,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
 
     Constructor arguments follow SpectralConv.  ``ops`` (tests only) replaces the local stages (an object with the
     interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in (None: 4 batch chunks,
-    or one piece when a rank holds a single sample).
+    or 2 channel chunks when a rank holds a single sample).
 
     The shard layout follows ``max_n_modes`` (= the construction-time ``n_modes``, or the explicit ``max_n_modes``
     argument): rank p owns rows [p rows, (p + 1) rows) of the STORED weight's first mode dim.  ``n_modes`` may be
@@ -226,8 +266,11 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
                  fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=None,
                  factorization=None, rank=0.5, separable=False, max_n_modes=None, resolution_scaling_factor=None,
-                 agops=None, **unused):
+                 agops=None, chunk_dim=None, **unused):
         super().__init__(device=device)
+        if chunk_dim not in (None, "batch", "channels"):
+            raise ValueError("chunk_dim: None (batch chunks unless a rank holds one sample), 'batch' or 'channels'")
+        self.chunk_dim = chunk_dim
         if unused.get("complex_data"):
             raise NotImplementedError("complex_data=True is not supported by the mode-parallel layer")
         fac = (factorization or "dense").lower()
@@ -256,9 +299,8 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         self._agops = agops
         self.fft_norm = fft_norm
         self.group = group
-        # pieces the exchange is pipelined in: None = 4 batch chunks when a rank holds >= 2 samples, ONE piece when it
-        # holds a single sample (channel chunks would need strided wire buffers, i.e. copies, and 4.5 MB exchanges are
-        # latency-bound: fewer launches win); an explicit number applies to both cases
+        # pieces the exchange is pipelined in: None = 4 batch chunks when a rank holds >= 2 samples, 2 channel chunks when
+        # it holds a single sample (copy-free slabs, round 4); an explicit number applies to both cases
         self.comm_chunks = None if comm_chunks is None else max(1, int(comm_chunks))
         self.P = comm.get_model_parallel_size() if group is None else dist.get_world_size(group)
         self.rank = comm.get_model_parallel_rank() if group is None else dist.get_rank(group)
@@ -314,10 +356,18 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     def _group(self):
         return self.group if self.group is not None else comm.get_model_parallel_group()
 
+    def _by_batch(self, b):
+        """the dim the exchange is chunked over: the local batch, or -- one sample per rank -- the channels"""
+        if self.chunk_dim == "channels":
+            if b != 1:
+                raise ValueError("chunk_dim='channels' is the one-sample-per-rank layout (local batch 1)")
+            return False
+        return self.chunk_dim == "batch" or b >= 2 or self.P == 1
+
     def _chunks(self, by_batch):
         if self.comm_chunks is not None:
             return self.comm_chunks
-        return 4 if by_batch else 1
+        return 4 if by_batch else 2
 
     @property
     def n_modes(self):

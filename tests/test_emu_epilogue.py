@@ -103,7 +103,8 @@ def test_gelu_of_the_epilogue_against_torch(lib, spatial):
     ws2 = torch.empty(lib.layer_workspace_bytes(plan2, L2), dtype=torch.uint8)
     y2 = torch.empty(b, c, *other)
     xhat2 = torch.empty(b, c, *kept2, 2)
-    lib.layer_forward_ex(plan2, L2, torch.zeros(b, c, *other).data_ptr(), wv.data_ptr(), zb.data_ptr(), vo.data_ptr(), 0,
+    x0 = torch.zeros(b, c, *other)              # kept alive across the call (a temporary's storage is freed before it runs)
+    lib.layer_forward_ex(plan2, L2, x0.data_ptr(), wv.data_ptr(), zb.data_ptr(), vo.data_ptr(), 0,
                          _lib.SC_ACT_GELU, y2.data_ptr(), xhat2.data_ptr(), ws2.data_ptr())
     assert torch.equal(y2.reshape(-1)[:m], y.reshape(-1)[:m])
     lib.plan_destroy(plan2)

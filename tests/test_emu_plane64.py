@@ -68,3 +68,46 @@ def test_plane64_scope(lib):
             assert lib.plan_kernel_name(plan, 0) != "k_pl64_fwd"
         finally:
             lib.plan_destroy(plan)
+
+
+@pytest.mark.parametrize("spatial,kept,name", [((64, 64), (32, 17), "k_pl64"), ((128, 128), (32, 17), "k_pl128"),
+                                               ((3, 64, 64), (2, 16, 9), "k_pl64")], ids=["pl64", "pl128", "pl64_3d"])
+def test_misaligned_planes_take_the_size_agnostic_passes(lib, spatial, kept, name):
+    """the one-workgroup plane kernels move rows with 16-byte accesses.  A contiguous view with an odd storage
+    offset (x = flat[1:1 + n].view(...), a gradient handed over out of a bucketed buffer) used to make the 64 x 64 route
+    FAIL the call; the dispatch now falls back to the size-agnostic passes of the same plan -- same results to rounding."""
+    rng = np.random.default_rng(5)
+    n_img = 2
+    n = n_img * int(np.prod(spatial))
+    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+    try:
+        assert lib.plan_kernel_name(plan, 0).startswith(name)
+        ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8)
+        base = torch.from_numpy(rng.standard_normal(n + 4).astype(np.float32))
+        assert base.data_ptr() % 16 == 0
+        want = None
+        x0 = base[:n].clone().view(n_img, *spatial)
+        for off in (0, 1, 3):
+            buf = torch.zeros(n + 4)
+            x = buf[off:off + n].view(n_img, *spatial)
+            x.copy_(x0)
+            assert x.data_ptr() % 16 == (4 * off) % 16
+            xhat = torch.full((n_img, *kept), float("nan"), dtype=torch.complex64)
+            lib.transform_forward(plan, _lib.SC_FWD_SCALED, x.data_ptr(), torch.view_as_real(xhat).data_ptr(), n_img,
+                                  ws.data_ptr(), 0)
+            if want is None:
+                want = xhat.clone()
+                assert rel_l2(xhat.numpy(), _ref_forward(x0.numpy(), kept, 1.0 / int(np.prod(spatial)), False)) < TOL
+            else:
+                assert rel_l2(xhat.numpy(), want.numpy()) < TOL
+        yh = (rng.standard_normal((n_img, *kept)) + 1j * rng.standard_normal((n_img, *kept))).astype(np.complex64)
+        yhat = torch.from_numpy(yh)
+        ref = _ref_inverse(yh, spatial, 1.0, True)
+        for off in (0, 2):
+            buf = torch.full((n + 4,), float("nan"))
+            y = buf[off:off + n].view(n_img, *spatial)
+            lib.transform_inverse(plan, _lib.SC_INV_PADDED, torch.view_as_real(yhat).data_ptr(), 0, n_img, y.data_ptr(), n_img,
+                                  ws.data_ptr(), 0)
+            assert rel_l2(y.numpy(), ref) < TOL
+    finally:
+        lib.plan_destroy(plan)

@@ -73,16 +73,64 @@ def test_layer_vs_oracle_at_config(lib, case):
     assert all(np.isfinite(v) and v < TOL for v in errs.values()), errs
 
 
+def test_c5_literal_shape_vs_oracle(lib):
+    """BASELINE configs[4] LITERALLY: B = 4, 128 -> 128 channels, 1024^2, modes (256, 256) --
+    the two-pass P = 32 transforms, k_modegemm_sb forward and the one-pass backward pair k_modegemm_sb_bwd<4,4,2> over
+    the 4.33 GB weight, exactly as `extra.fno2d_1024_b4` times them.  The oracle (forward_torch + autograd =
+    spectral_convolution.py:417-570) runs one sample at a time to bound host memory: y[b] and gx[b] depend on sample b
+    only, gW and gbias are sums over the samples (accumulated in float64 on the host)."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+
+    b, ci, co, spatial, modes = 4, 128, 128, (1024, 1024), (256, 256)
+    torch.manual_seed(1234)
+    nm = halve_last_mode(modes)
+    std = (2 / (ci + co)) ** 0.5
+    x = torch.randn(b, ci, *spatial)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, std)
+    bias = std * torch.randn(co, 1, 1)
+    g = torch.randn(b, co, *spatial)
+    dev = torch.device("cuda:0")
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x.to(dev), w.to(dev), bias.to(dev), g.to(dev), nm, nm)
+    y, gx, gw, gb = y.cpu(), gx.cpu(), gw.cpu(), gb.cpu()
+    torch.cuda.empty_cache()
+    gw_ref = torch.zeros(ci, co, *nm, dtype=torch.complex128)
+    gb_ref = torch.zeros(co, dtype=torch.float64)
+    num = dict(y=0.0, gx=0.0)
+    den = dict(y=0.0, gx=0.0)
+    for s in range(b):
+        xc = x[s:s + 1].clone().requires_grad_(True)
+        wc = w.clone().requires_grad_(True)
+        bc = bias.clone().requires_grad_(True)
+        yo = so.forward_torch(xc, wc, bc, nm, nm)
+        yo.backward(g[s:s + 1])
+        num["y"] += float((y[s:s + 1].double() - yo.detach().double()).pow(2).sum())
+        den["y"] += float(yo.detach().double().pow(2).sum())
+        num["gx"] += float((gx[s:s + 1].double() - xc.grad.double()).pow(2).sum())
+        den["gx"] += float(xc.grad.double().pow(2).sum())
+        gw_ref += wc.grad
+        gb_ref += bc.grad.reshape(-1).double()
+        del xc, wc, bc, yo
+    errs = dict(y=(num["y"] / den["y"]) ** 0.5, gx=(num["gx"] / den["gx"]) ** 0.5,
+                gw=rel_l2(gw.numpy(), gw_ref.numpy()),
+                gb=rel_l2(gb.numpy().reshape(-1), gb_ref.numpy()))
+    print("C5 literal", " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert all(np.isfinite(v) and v < TOL for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("b", [4, 32], ids=["B4", "B32_bench_batch"])
 @pytest.mark.parametrize("impl", ["factorized", "reconstructed"])
-def test_tfno_tucker_rank01_at_config(impl):
+def test_tfno_tucker_rank01_at_config(impl, b):
     """BASELINE configs[2]: TFNO2d Tucker rank 0.1 at C=64, 256^2, modes (64,64) -> ranks (36,36,36,19), through
-    the drop-in module; reference = the oracle's pairwise contraction (SURVEY 8 row a6 order) with autograd."""
+    the drop-in module; reference = the oracle's pairwise contraction (SURVEY 8 row a6 order) with autograd.
+    B = 32 is the batch `extra.tfno_rank01` of the bench line runs (the per-mode products take other kernel routes
+    than at B = 4)."""
     from oracle import spectral_oracle as so
     from neuraloperator_amd import SpectralConv
 
     dev = torch.device("cuda:0")
     torch.manual_seed(99)
-    b, c, n = 4, 64, 256
+    c, n = 64, 256
     conv = SpectralConv(c, c, (64, 64), factorization="Tucker", rank=0.1, implementation=impl).to(dev)
     assert tuple(conv.weight.core.shape) == (36, 36, 36, 19)
     with torch.no_grad():

@@ -79,3 +79,44 @@ def test_small_factor_gradients_are_reproducible(kw):
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(_flat(a), _flat(b))
+
+
+@needs_gpu
+def test_capture_refuses_pending_gradients_and_detached_grads():
+    """a captured step overwrites .grad -- construction refuses gradients that are already accumulated, and
+    a replay refuses to run once an optimizer's zero_grad(set_to_none=True) detached a parameter from the captured
+    gradient tensor."""
+    from neuraloperator_amd import SpectralConv
+    from neuraloperator_amd.graph import capture_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    conv = SpectralConv(4, 4, (8, 8)).to(dev)
+    x = torch.randn(2, 4, 32, 32, device=dev, requires_grad=True)
+    g = torch.randn(2, 4, 32, 32, device=dev)
+    conv(x).backward(g)                                  # gradients accumulated by the caller
+    with pytest.raises(RuntimeError, match="already set"):
+        capture_step(conv, x, g)
+    conv.zero_grad(set_to_none=True)
+    x.grad = None
+    step = capture_step(conv, x, g)
+    step.replay()
+    assert all(p.grad is gr for p, gr in zip(step.params, step.grads))
+    conv.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="no longer the captured tensor"):
+        step.replay()
+    for p, gr in zip(step.params, step.grads):           # restoring the captured tensors makes it valid again
+        p.grad = gr
+    step.replay()
+
+
+@needs_gpu
+def test_raw_stream_accessor_fallback(monkeypatch):
+    """engine._stream() uses a private torch accessor for the raw hipStream_t; without it the public (slower) route
+    must hand the C-ABI the same handle."""
+    from neuraloperator_amd import engine
+    fast = engine._stream()
+    monkeypatch.delattr(torch._C, "_cuda_getCurrentRawStream")
+    assert engine._stream() == fast == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert engine._stream() == side.cuda_stream

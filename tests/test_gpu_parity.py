@@ -375,6 +375,44 @@ def test_backward_pair_full_size(lib):
         assert rel_l2(gx.cpu().numpy(), torch.einsum("bom,iom->bim", g128, w128.conj()).cpu().numpy()) < TOL
 
 
+@pytest.mark.parametrize("dims", [(1, 128, 128, 8256), (2, 128, 128, 8256), (3, 128, 128, 8256), (4, 128, 128, 8256),
+                                  (4, 128, 64, 8322), (3, 66, 128, 4226)], ids=lambda d: "B%d_Ci%d_Co%d_M%d" % d)
+def test_backward_pair_small_batch_one_pass(lib, dims):
+    """k_modegemm_sb_bwd<BT,4,2> for every BT on the device: the two contractions of a small-batch
+    backward pass in ONE pass over the weight (BASELINE configs[4]: hidden 128; 8 256 of its 33 024 modes = 64 mode
+    tiles of 128 + a ragged one, so the complex128 reference stays small) against a complex128 einsum evaluated on the
+    HOST and, bit for bit, against the two k_modegemm_sb launches it replaces (einsum_utils.py / spectral_convolution.py:21-46
+    and their autograd adjoints)."""
+    from neuraloperator_amd import _lib as L
+    B, Ci, Co, M = dims
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: torch.view_as_real(t).data_ptr()
+    torch.manual_seed(100 + B)
+    xh_c = torch.randn(B, Ci, M, dtype=torch.cfloat)
+    gh_c = torch.randn(B, Co, M, dtype=torch.cfloat)
+    w_c = torch.randn(Ci, Co, M, dtype=torch.cfloat)
+    xh, gh, w = xh_c.to(dev), gh_c.to(dev), w_c.to(dev)
+    kw_w = dict(P=Ci, Q=Co, R=B, n_modes=M, a_sp=M, a_sr=Ci * M, a_sm=1, conj_a=1, b_sr=Co * M, b_sq=M, b_sm=1,
+                c_sp=Co * M, c_sq=M, c_sm=1, flags=L.SC_GEMM_STREAM_C)
+    kw_x = dict(P=B, Q=Ci, R=Co, n_modes=M, a_sp=Co * M, a_sr=M, a_sm=1, b_sr=M, b_sq=Co * M, b_sm=1, conj_b=1,
+                c_sp=Ci * M, c_sq=M, c_sm=1)
+    assert lib.modegemm_path(**kw_w) == 3 and lib.modegemm_path(**kw_x) == 3
+    assert lib.modegemm_pair_path(kw_w, kw_x) == 2, "the one-pass kernel must be the one that runs"
+    gw = torch.full((Ci, Co, M), float("nan"), dtype=torch.cfloat, device=dev)
+    gx = torch.full((B, Ci, M), float("nan"), dtype=torch.cfloat, device=dev)
+    lib.modegemm_pair(kw_w, p(xh), p(gh), p(gw), kw_x, p(gh), p(w), p(gx), st)
+    gw1, gx1 = torch.empty_like(gw), torch.empty_like(gx)
+    lib.modegemm(p(xh), p(gh), p(gw1), st, **kw_w)
+    lib.modegemm(p(gh), p(w), p(gx1), st, **kw_x)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw1))
+    assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx1))
+    x128, g128, w128 = xh_c.to(torch.complex128), gh_c.to(torch.complex128), w_c.to(torch.complex128)
+    assert rel_l2(gw.cpu().numpy(), torch.einsum("bim,bom->iom", x128.conj(), g128).numpy()) < TOL
+    assert rel_l2(gx.cpu().numpy(), torch.einsum("bom,iom->bim", g128, w128.conj()).numpy()) < TOL
+
+
 def test_module_dropin():
     """SpectralConv module: ctor surface, n_modes mutation (incremental FNO), grads for every
     parameter (neuralop/layers/tests/test_spectral_convolution.py:67-70, models/tests/test_fno.py)."""
@@ -721,6 +759,20 @@ def test_mode_parallel_layer_on_device_single_rank():
         assert rel_l2(x.grad.cpu().numpy(), gxo) < TOL
         assert rel_l2(mp_conv.weight.grad.cpu().numpy(), gwo) < TOL
         assert rel_l2(mp_conv.bias.grad.cpu().numpy(), gbo) < TOL
+        # one sample per rank, channel chunks (round 4): the list form of the RCCL all-to-all moves slabs of the
+        # contraction's operand / result in place (ragged chunks: 6 -> 2 + 2 + 2 input, 5 -> 1 + 2 + 2 output channels)
+        cc = ModeParallelSpectralConv(6, 5, (16, 12), comm_chunks=3, chunk_dim="channels").to(dev)
+        with torch.no_grad():
+            cc.weight.copy_(ref.weight.tensor)
+            cc.bias.copy_(ref.bias)
+        x1 = x.detach()[:1].clone().requires_grad_(True)
+        y1 = cc(x1)
+        y1.backward(g[:1])
+        yo1, gxo1, gwo1, gbo1 = _oracle_layer(x1, ref.weight.tensor, ref.bias, g[:1], ref.n_modes)
+        assert rel_l2(y1.detach().cpu().numpy(), yo1) < TOL
+        assert rel_l2(x1.grad.cpu().numpy(), gxo1) < TOL
+        assert rel_l2(cc.weight.grad.cpu().numpy(), gwo1) < TOL
+        assert rel_l2(cc.bias.grad.cpu().numpy(), gbo1) < TOL
         # TFNO weights in the same layer: replicated core / factors, the first mode dim's factor sharded (here: whole)
         from oracle import spectral_oracle as so
         tref = SpectralConv(6, 5, (16, 12), factorization="tucker", rank=0.5, implementation="factorized")
