@@ -52,6 +52,13 @@ WORKLOADS = {
     "fno2d_192_m64_c64_b32": (32, 64, (192, 192), (64, 64)),      # radix-3 lines (32 x 6) on the two-pass route
     "fno3d_64_m16_c32_b8": (8, 32, (64, 64, 64), (16, 16, 16)),
     "fno2d_512_m64_c64_b8": (8, 64, (512, 512), (64, 64)),        # two-pass route, P = 16
+    # the reference's documented Darcy-flow grids (doc/source/theory_guide/fno.rst:384-392: s = 85 / 141 / 211 / 421): lines
+    # that are not 32 P points stay on the direct (pruned, matrix-core) DFT passes -- measured beside gpu_reference_baseline
+    "darcy_85_m32_c32_b32": (32, 32, (85, 85), (32, 32)),
+    "darcy_141_m32_c32_b32": (32, 32, (141, 141), (32, 32)),
+    "darcy_211_m32_c32_b32": (32, 32, (211, 211), (32, 32)),
+    "darcy_421_m32_c32_b16": (16, 32, (421, 421), (32, 32)),
+    "darcy_421_m64_c32_b16": (16, 32, (421, 421), (64, 64)),
     # diagnostic: the per-rank transform load of configs[3] strong-scaled over 8 GPUs (one sample per rank)
     "fno3d_128_m32_c32_b1": (1, 32, (128, 128, 128), (32, 32, 32)),
 }
@@ -335,11 +342,28 @@ def block_extra(B, C, spatial, n_modes, dev):
     return out
 
 
-def measure_traffic_live(workload_shape, kernel_substr, timeout_s=75):
-    """HBM bytes per launch of the dominant kernel, read from the PMC counters IN THIS RUN: two rocprofv3 passes
-    (FETCH_SIZE, WRITE_SIZE -- separate, as MI355X_MICROARCH.md prescribes) over scripts/layer_one.py (the whole layer
-    step through the C-ABI) in subprocesses, gfx950 correction FETCH_SIZE x 2, KB = 1024 B.  Returns (bytes, note) or
-    (None, reason): rocprofv3 wraps a process, so the counters cannot be read inside the timed process itself."""
+def _kernel_key(name):
+    """'void k_fft2d_fwd3<256, float>(float const*, ...)' -> 'k_fft2d_fwd3<256, float>'"""
+    name = name.replace("void ", "").strip()
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def measure_step_traffic(workload_shape, io="f32", kind="dense", reps=2, timeout_s=120):
+    """HBM bytes of EVERY kernel of one layer step, read from the PMC counters IN THIS RUN: two rocprofv3 passes
+    (FETCH_SIZE, WRITE_SIZE -- separate, as MI355X_MICROARCH.md prescribes; --kernel-trace only beside them) over
+    scripts/layer_one.py (the whole step of that workload) in subprocesses; gfx950 correction FETCH_SIZE x 2,
+    KB = 1024 B.  Returns (dict, note) or (None, reason):
+        {"kernels": {name: {"launches_per_step", "fetch_B", "write_B", "traffic_B" (per launch), "ms" (mean duration
+         under the counter pass: ranking only)}}, "step_traffic_B": sum over the step}
+    rocprofv3 wraps a process, so the counters cannot be read inside the timed process itself."""
     import glob
     import shutil
     import sqlite3
@@ -349,31 +373,69 @@ def measure_traffic_live(workload_shape, kernel_substr, timeout_s=75):
     if not os.path.isfile(exe):
         return None, "rocprofv3 not found"
     B, C, spatial, n_modes = workload_shape
-    env = dict(os.environ, TMPDIR="/tmp", LAYER_REPS="2",
+    env = dict(os.environ, TMPDIR="/tmp", LAYER_REPS=str(reps), LAYER_IO=io, LAYER_KIND=kind,
                LAYER_SHAPE=",".join(str(v) for v in (B, C, *spatial, *n_modes)))
-    vals = {}
+    vals, durs = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="sc_pmc_", dir="/tmp")
         try:
             subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--", sys.executable,
                             os.path.join(ROOT, "scripts", "layer_one.py")], cwd="/tmp", env=env, timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            got = []
+            got = {}
             for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
                 cur = sqlite3.connect(db).cursor()
                 for k, n, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
-                    if n == counter and kernel_substr in k:
-                        got.append(float(v))
+                    if n == counter and (k.startswith("k_") or k.startswith("void k_")):
+                        got.setdefault(_kernel_key(k), []).append(float(v))
+                if counter == "FETCH_SIZE":
+                    try:
+                        for k, calls, avg in cur.execute("select name, total_calls, average from top_kernels"):
+                            durs[_kernel_key(k)] = float(avg) / 1e3          # top_kernels.average is in us
+                    except sqlite3.Error:
+                        pass
             if not got:
-                return None, f"no {counter} rows for {kernel_substr}"
-            vals[counter] = sum(got) / len(got)
+                return None, f"no {counter} rows"
+            vals[counter] = got
         except Exception as e:                      # never let the counters kill the bench line
             return None, f"{counter} pass failed: {type(e).__name__}: {str(e)[:120]}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return int(round(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)), \
-        (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
-         f"scripts/layer_one.py, mean of {kernel_substr} launches, FETCH_SIZE x 2 (gfx950), KB = 1024 B")
+    kernels, step = {}, 0.0
+    for k, f in vals["FETCH_SIZE"].items():
+        w = vals["WRITE_SIZE"].get(k, [0.0])
+        fb, wb = sum(f) / len(f) * 1024 * 2, sum(w) / len(w) * 1024
+        kernels[k] = {"launches_per_step": round(len(f) / reps, 2), "fetch_B": int(fb), "write_B": int(wb),
+                      "traffic_B": int(fb + wb), "ms": round(durs.get(k, 0.0), 4)}
+        step += (fb + wb) * len(f) / reps
+    return {"kernels": kernels, "step_traffic_B": int(step)}, \
+        ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+         "scripts/layer_one.py, mean per launch, FETCH_SIZE x 2 (gfx950), KB = 1024 B")
+
+
+def measure_traffic_live(workload_shape, kernel_substr, timeout_s=120):
+    """the dominant kernel's HBM bytes per launch out of measure_step_traffic (+ the whole step's table)"""
+    got, note = measure_step_traffic(workload_shape, timeout_s=timeout_s)
+    if got is None:
+        return None, note, None
+    hits = [v for k, v in got["kernels"].items() if kernel_substr in k]
+    if not hits:
+        return None, f"no counter rows for {kernel_substr}", got
+    return int(sum(h["traffic_B"] for h in hits) / len(hits)), note + f", mean of {kernel_substr} launches", got
+
+
+def _extra_traffic(shape, io, kind, alg_bytes_step):
+    """`traffic` block of an extra.* entry: the step's HBM bytes by the counters, their ratio to the algorithmic bytes and
+    the kernel the step spends most of its time in (by launches x mean duration under the counter pass)."""
+    got, note = measure_step_traffic(shape, io=io, kind=kind)
+    if got is None:
+        return {"traffic": None, "traffic_note": note}
+    ks = got["kernels"]
+    dom = max(ks, key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
+    return {"traffic": got["step_traffic_B"], "traffic_over_alg_bytes": round(got["step_traffic_B"] / alg_bytes_step, 3),
+            "dominant_kernel": {"name": dom, **ks[dom]},
+            "traffic_kernels": {k: v["traffic_B"] for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["traffic_B"])[:8]},
+            "traffic_source": note + "; `traffic` = sum over the step's launches"}
 
 
 def engine_path(names):
@@ -745,6 +807,10 @@ def main():
                     extra[name].pop(k)
             del st_x, conv_x, c
             torch.cuda.empty_cache()
+            if world == 1 and not args.no_pmc:           # live counters for every BASELINE workload
+                torch.cuda.synchronize()
+                extra[name].update(_extra_traffic((bl_x, Cx, sp_x, nm_x), "bf16" if io_x == bf16 else "f32",
+                                                  "tucker" if kw_x is not None else "dense", tot_x))
         if world == 1:
             extra["fno_block"] = block_extra(B, C, spatial, n_modes, dev)
             torch.cuda.empty_cache()
@@ -772,9 +838,10 @@ def main():
         dom_gbs = round(stages[dom]["alg_bytes"] / dom_ms / 1e6, 1)
         traffic_source = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, gfx950 "
                           "corrections applied; not re-measured by this run)")
+        step_tab = None
         if world == 1 and not args.no_pmc and args.io == "f32" and not args.plan_flags and not args.force_generic:
             torch.cuda.synchronize()
-            live, note = measure_traffic_live(WORKLOADS[args.workload], kern)
+            live, note, step_tab = measure_traffic_live(WORKLOADS[args.workload], kern)
             if live is not None:
                 traffic_lookup, traffic, traffic_source = traffic, live, note
                 if traffic_lookup:
@@ -808,7 +875,11 @@ def main():
                               "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_measured_copy": round(step_gbs / copy_gbs, 4),
                               "formula": "4R+3Wb+9S (SURVEY.md 8d), per GPU" +
-                                         (", R at 2 bytes per value" if args.io == "bf16" else "")},
+                                         (", R at 2 bytes per value" if args.io == "bf16" else ""),
+                              **({"traffic": step_tab["step_traffic_B"],
+                                  "traffic_over_alg_bytes": round(step_tab["step_traffic_B"] / total, 3),
+                                  "traffic_kernels": {k: v["traffic_B"] for k, v in step_tab["kernels"].items()}}
+                                 if step_tab else {})},
             "stages": stages,
             "cold_start": {"ms_per_step": round(ms_cold, 4), "value": round(global_batch / (ms_cold / 1e3), 2),
                            "what": f"the same {args.warmup} untimed + {args.steps} timed steps straight after set-up, "

@@ -470,7 +470,7 @@ static int f2p_plan_init(sc_plan* p, bool large_only) {
   }
   int rc = fft_col_scales(p, p->f2p_cs_fwd, p->f2p_cs_inv);
   if (rc) return rc;
-  if (p->n[1] == 1024 && J <= 129) {                     // one wave per row pair (k_f2p_c2r_w1024): kept columns |k| <= 128
+  if (p->n[1] == 1024 && J == 129) {                     // one wave per row pair (k_f2p_c2r_w1024): kept columns k = 0..128
     std::vector<cf32> h(1024);
     for (int m = 0; m < 1024; ++m) h[(size_t)m] = twiddle(m, 1, 1024, -1.0, 1.0);
     DeviceTable dt;
@@ -514,7 +514,8 @@ static int pl64_plan_init(sc_plan* p) {
 
 static int64_t f2p_panel_elems_per_image(const sc_plan* p) { return (int64_t)p->f2p_ncb * p->n[0] * SC_F2P_CB; }
 static int64_t f2p_chunk_images(const sc_plan* p, int64_t n_images) {
-  int64_t c = ((int64_t)SC_F2P_CHUNK_MB << 20) / (f2p_panel_elems_per_image(p) * (int64_t)sizeof(cf32));
+  static const int mb = [] { const char* e = std::getenv("SC_F2P_CHUNK_MB"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : SC_F2P_CHUNK_MB; }();   // A-B
+  int64_t c = ((int64_t)mb << 20) / (f2p_panel_elems_per_image(p) * (int64_t)sizeof(cf32));
   if (c < 1) c = 1;
   return c < n_images ? c : n_images;
 }
@@ -539,15 +540,17 @@ static bool f2p_dispatch(int P, int K2, F&& f) {
   }
 }
 
-// Round 4: the two passes of a transform run as a TWO-STAGE PIPELINE over half-sized chunks on two streams (the caller's
-// and the engine's side stream, sc_device.h): the small pass of chunk c (k_f2p_col_*: latency / L2 bound, a fraction of
-// the chip's bandwidth) runs beside the large pass of its neighbour chunk (k_f2p_r2c / k_f2p_c2r: VALU + HBM), the panel
-// is double-buffered inside the same workspace (two halves), and the dependencies are events only (fork / join: the
-// pattern records into a hipGraph).  SC_F2P_NO_PIPE=1 (environment) or no side stream (emulation, SC_NO_SIDE_STREAM=1):
-// the passes alternate on the caller's stream as before, over full-sized chunks.
+// Round 4, measured and NOT taken as the default: the two passes of a transform as a TWO-STAGE PIPELINE over half-sized
+// chunks on two streams (the caller's and the engine's side stream, sc_device.h) -- the small pass of chunk c
+// (k_f2p_col_*) beside the large pass of its neighbour chunk (k_f2p_r2c / k_f2p_c2r), the panel double-buffered inside
+// the same workspace, dependencies by events only (fork / join).  1024^2, 512 images, same box, interleaved
+// (profiles/r04_f2p_pipeline_ab.txt): forward 0.65 -> 0.71 ms, inverse 0.87 -> 0.97 ms, the adjoints 0.60 -> 0.68 and
+// 0.85 -> 0.95 ms: the column pass beside the row pass takes more from it (L2 / fabric contention, half-sized launches)
+// than its own time.  SC_F2P_PIPE=1 (environment) switches it on for A-B runs; the default alternates the passes on the
+// caller's stream over full-sized chunks.
 static bool f2p_pipe_enabled() {
-  static const bool off = [] { const char* e = std::getenv("SC_F2P_NO_PIPE"); return e && e[0] == '1'; }();
-  return !off;
+  static const bool on = [] { const char* e = std::getenv("SC_F2P_PIPE"); return e && e[0] == '1'; }();
+  return on;
 }
 struct F2pChunks {
   int64_t chunk;      // images per chunk
@@ -605,10 +608,12 @@ static bool f2p_launch_c2r(const sc_plan* p, int mode, const cf32* panel, float*
     const int64_t n_pairs = ni * N0 / 2, n_items = (n_pairs + 3) / 4;
     int64_t grid = (int64_t)(wgs > 0 ? wgs : 4) * sc_cu_count();
     if (grid > n_items) grid = n_items;
-    SC_LAUNCH(k_f2p_c2r_w1024, dim3((unsigned)grid), dim3(256), 0, st, panel, ys, (const cf32*)p->f2p_w1024,
-              (const float*)p->f2p_cs_inv[mode], bias, (int)channels, (int)(i0 % channels), N0, J, NCB, n_pairs, n_items,
-              (int)grid);
-    return true;
+    if (n_pairs < ((int64_t)1 << 30)) {
+      SC_LAUNCH(k_f2p_c2r_w1024, dim3((unsigned)grid), dim3(256), 0, st, panel, ys, (const cf32*)p->f2p_w1024,
+                (const float*)p->f2p_cs_inv[mode], bias, (int)channels, (int)(i0 % channels), N0, NCB, (int)n_pairs,
+                (int)n_items, (int)grid);
+      return true;
+    }
   }
   return f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
     constexpr int G = 32 / decltype(P)::value;

@@ -646,7 +646,7 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
 //     z[4 m + r] = sum_{kappa = 0}^{255} T_r[kappa] w256^(m kappa),   T_r[kappa] = Z[k] w1024^(r k),
 //     k = kappa (kappa < 128), kappa - 256 (kappa > 128), both k = +-128 at kappa = 128
 // -- the pruned radix-4 stage is one twiddle per input (the trick of k_fft2d_inv3) and leaves FOUR independent FULL
-// 256-point transforms, one per r.  Lane = (r = lane >> 4, l = lane & 15): the lane's 16 inputs kappa = l + 16 kappa2
+// 256-point transforms, one per r.  Lane = (r = lane & 3, l = lane >> 2): the lane's 16 inputs kappa = l + 16 kappa2
 // come straight from the panel into registers (A[k], B[k] of the two packed rows; the four r lanes of an l read the same
 // addresses), Z = A + i B (k > 0) / conj A + i conj B (k < 0) times the lane constant cs[|k|] w1024^(r k), then
 //     U[ma]  = w256^(ma l) sum_kappa2 T[l + 16 kappa2] w16^(ma kappa2)        16-point DFT in registers
@@ -656,48 +656,58 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
 // (the exchange is wave-local).  Persistent workgroups (the lane constants -- 16 twiddles, 16 panel offsets -- are set
 // up once).
 // ------------------------------------------------------------------------------------------
-#define SC_W1K_ES 17                  // exchange row stride (complex): writes (l contiguous) and reads (stride 17) conflict-free
+#define SC_W1K_ES 17                  // exchange row stride (complex)
+#define SC_W1K_RS (16 * SC_W1K_ES + 8)  // stride of an r block: with lane = 4 l + r both the writes (r 8 + l mod 32) and the
+                                      // reads (r 8 + 17 ma mod 32) of a half-wave hit 32 different 8-byte slots
+// Scope: N1 = 1024 with exactly the 129 kept columns k = 0..128 (n_modes 256 on the last axis: BASELINE configs[4]),
+// any N0 the column kernels serve; other column ranges keep k_f2p_c2r<32, K2>.  With every column live the panel
+// addresses are (wave-uniform row / column-group part) + (one of two per-lane offsets): no per-input offset registers.
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
 k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ w1024,
-                const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int J,
-                int NCB, int64_t n_pairs, int64_t n_items, int gstride) {
+                const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int NCB,
+                int n_pairs, int n_items, int gstride) {
   constexpr int N = 1024;
   SC_SHARED __attribute__((aligned(16))) cf32 tw2[256];                     // conj w256^(ma l), [ma][l]
-  SC_SHARED __attribute__((aligned(16))) cf32 Eall[4][64 * SC_W1K_ES];      // per wave: [r][ma][l]
-  const int tid = SC_TID, wv = tid >> 6, lane = tid & 63, r = lane >> 4, l = lane & 15;
+  SC_SHARED __attribute__((aligned(16))) cf32 Eall[4][4 * SC_W1K_RS];       // per wave: [r][ma][l]
+  // lane = 4 l + r: the four r lanes of an l are neighbours (one panel address per quad) and a store instruction's lanes
+  // run through 256 contiguous bytes IN LANE ORDER (offset r + 4 l) -- with lane = 16 r + l every 16-lane group wrote a
+  // quarter of each 64-byte piece and the kernel ran 1.07 ms against 0.87 ms (profiles/r04_c2r_w1024_ab.txt)
+  const int tid = SC_TID, wv = SC_UNIFORM(tid >> 6), lane = tid & 63, r = lane & 3, l = lane >> 2;
   tw2[tid] = cf_conj(w1024[(4 * (tid >> 4) * (tid & 15)) & 1023]);
-  // lane constants: cs[|k|] w1024^(+r k) and the panel offset of column |k| (columns past J: factor 0, offset 0)
+  // lane constants: cs[|k|] w1024^(+r k), k = l + 16 q (q < 8) / l + 16 q - 256 (q >= 8)
   cf32 twr[16];
-  int off[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int k = l + 16 * q - (q >= 8 ? 256 : 0);
-    const int ak = k < 0 ? -k : k;
-    const bool live = ak < J;
     const cf32 w = w1024[(r * k) & 1023];                  // exp(-2 pi i r k / 1024)
-    const float s = live ? cs[ak] : 0.f;
+    const float s = cs[k < 0 ? -k : k];
     twr[q] = cf_make(s * w.x, -s * w.y);
-    off[q] = live ? (ak >> 3) * N0 * SC_F2P_CB + (ak & 7) : 0;
   }
   cf32 twx = cf_make(0.f, 0.f);                            // k = +128 joins k = -128 in the lanes l = 0
-  if (l == 0 && 128 < J) {
+  if (l == 0) {
     const cf32 w = w1024[(128 * r) & 1023];
     twx = cf_make(cs[128] * w.x, -cs[128] * w.y);
   }
+  // column |k| of the panel: block |k| >> 3 (N0 x 8 values each), slot |k| & 7.  k > 0: |k| = 16 q + l -> the lane part
+  // is column l; k < 0: |k| = 16 (15 - q) + (16 - l) -> the lane part is column 16 - l (column 16 for l = 0)
+  const int lp = (l >> 3) * N0 * SC_F2P_CB + (l & 7);
+  const int ln = ((16 - l) >> 3) * N0 * SC_F2P_CB + ((16 - l) & 7);
+  const int qs = 2 * N0 * SC_F2P_CB;                       // 16 columns further
   cf32* E = Eall[wv];
   SC_SYNC();                                               // tw2
 
 #pragma unroll 1
-  for (int64_t item = SC_BID_X; item < n_items; item += gstride) {
+  for (int item = SC_BID_X; item < n_items; item += gstride) {
     // pairs past the end are clamped to the last one (the same values stored again)
-    const int64_t pr = item * 4 + wv < n_pairs ? item * 4 + wv : n_pairs - 1;
-    const int64_t rA = 2 * pr, img = rA / N0;
-    const cf32* src = panel + ((img * NCB) * (int64_t)N0 + (rA - img * N0)) * SC_F2P_CB;
+    const int pr = item * 4 + wv < n_pairs ? item * 4 + wv : n_pairs - 1;
+    const int img = pr / (N0 >> 1), rA = 2 * (pr - img * (N0 >> 1));
+    const cf32* src = panel + ((int64_t)img * NCB * N0 + rA) * SC_F2P_CB;
     const float bv = bias ? bias[(img + img0) % channels] : 0.f;
     cf32 T[16], U[16];
     sc_static_for<0, 16>([&](auto qt) {
       constexpr int q = decltype(qt)::value;
-      cf32 A = src[off[q]], B = src[off[q] + SC_F2P_CB];
+      const cf32* sq = src + (q < 8 ? q : 15 - q) * (int64_t)qs + (q < 8 ? lp : ln);
+      cf32 A = sq[0], B = sq[SC_F2P_CB];
       if constexpr (q == 0) {                              // k = 0: the imaginary parts of the DC column are dropped
         if (l == 0) {
           A.y = 0.f;
@@ -714,20 +724,21 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
       }
     });
     fft16<+1>(T, U);                                       // over kappa2 -> ma
-    E[(r * 16) * SC_W1K_ES + l] = U[0];
+    E[r * SC_W1K_RS + l] = U[0];
 #pragma unroll
     for (int ma = 1; ma < 16; ++ma)
-      E[(r * 16 + ma) * SC_W1K_ES + l] = cf_mul_cs(U[ma], sc_lds_ld64(tw2 + ma * 16 + l));
+      E[r * SC_W1K_RS + ma * SC_W1K_ES + l] = cf_mul_cs(U[ma], sc_lds_ld64(tw2 + ma * 16 + l));
     SC_WAVE_SYNC();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) T[q] = sc_lds_ld64(E + (r * 16 + l) * SC_W1K_ES + q);   // lane l now plays ma = l
+    for (int q = 0; q < 16; ++q) T[q] = sc_lds_ld64(E + r * SC_W1K_RS + l * SC_W1K_ES + q);   // lane l now plays ma = l
     SC_WAVE_SYNC();                                        // E is rewritten by the next item
     fft16<+1>(T, U);                                       // over l -> mb : z[r + 4 ma + 64 mb]
-    float* ya = y + rA * N + r + 4 * l;
+    float* ya = y + ((int64_t)img * N0 + rA) * N + lane;       // r + 4 l
+    float* yb = ya + N;
 #pragma unroll
     for (int mb = 0; mb < 16; ++mb) {
       SC_STORE_STREAM(ya + 64 * mb, U[mb].x + bv);
-      SC_STORE_STREAM(ya + N + 64 * mb, U[mb].y + bv);
+      SC_STORE_STREAM(yb + 64 * mb, U[mb].y + bv);
     }
   }
 }

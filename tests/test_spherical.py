@@ -130,3 +130,38 @@ def test_verbatim_fno_drives_the_spherical_plugin():
     assert tuple(y.shape) == (2, 1, 17, 32) and torch.isfinite(y).all()
     grads = [p.grad for c in model.fno_blocks.convs for p in c.parameters()]
     assert all(g is not None and torch.isfinite(torch.view_as_real(g) if g.is_complex() else g).all() for g in grads)
+
+
+@pytest.mark.parametrize("grid,nlat,nlon", [("equiangular", 33, 64), ("legendre-gauss", 24, 48)])
+def test_sht_pinned_by_closed_form_spherical_harmonics(grid, nlat, nlon):
+    """A pin that does not go through this repo's own tables: fields built from scipy's closed-form
+    orthonormal spherical harmonics Y_l^m (Condon-Shortley phase), sampled on the transform's grid.
+
+    With the reference wrapper's conventions (spherical_convolution.py:206-281 -> torch_harmonics RealSHT /
+    InverseRealSHT, norm "ortho", longitude rfft scaled by 2 pi / nlon, synthesis = irfft with norm "forward"):
+        x = Re Y_l^m  ->  c[l, m] = 1/2  (m > 0: the cos(m phi) half of the pair +-m),  c[l, 0] = 1  (m = 0)
+        x = Im Y_l^m  ->  c[l, m] = -i/2
+    and every other coefficient vanishes to quadrature exactness (both rules are exact for the products of
+    band-limited harmonics used here); synthesis of those coefficients returns the field."""
+    from scipy.special import sph_harm_y
+    theta, _ = sp.quadrature(nlat, grid)
+    phi = 2 * math.pi * np.arange(nlon) / nlon
+    TH, PH = np.meshgrid(theta, phi, indexing="ij")
+    lmax = mmax = 10
+    cases = [(0, 0), (1, 0), (1, 1), (3, 2), (5, 5), (7, 0), (9, 4), (9, 9), (6, 1)]
+    fields, want = [], []
+    for l, m in cases:
+        Y = sph_harm_y(l, m, TH, PH)
+        for part in (("re", Y.real), ("im", Y.imag)) if m > 0 else (("re", Y.real),):
+            c = np.zeros((lmax, mmax), dtype=np.complex128)
+            c[l, m] = 1.0 if m == 0 else (0.5 if part[0] == "re" else -0.5j)
+            fields.append(part[1])
+            want.append(c)
+    x = torch.from_numpy(np.stack(fields)).float()
+    cw = np.stack(want)
+    with engine_on_emulation():
+        h = sp.SHT()
+        got = h.sht(x, s=(lmax, mmax), grid=grid)
+        back = h.isht(torch.from_numpy(cw).to(torch.complex64), s=(nlat, nlon), grid=grid)
+    assert np.abs(got.numpy() - cw).max() < 5e-6, np.abs(got.numpy() - cw).max()
+    assert np.abs(back.numpy() - x.numpy()).max() < 5e-6
