@@ -742,3 +742,9 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
     }
   }
 }
+
+// Round 4, measured and NOT kept: the whole inverse-type 1024 x 1024 transform in ONE pass without the panel -- a workgroup
+// per band of 16 output rows n0 = t + 64 j recomputing the zero-padded column transform for its band straight from the
+// spectrum (L2-resident), then the row transforms above out of LDS.  HBM traffic drops to R + S, but the spectrum is read
+// 64 x per image out of L2 (10.8 TB/s of L2 reads) and the kernel ran 0.79-0.82 ms against 0.78 ms for the two passes
+// (1.03 ms with two rounds of its loads in flight): profiles/r04_f2p_band_ab.txt.

@@ -25,9 +25,12 @@ buffer of the way out IS the contraction's operand and the contraction's result 
 the R-sized real tensors are written in place (``out=`` slices).  With one sample per rank (BASELINE configs[3] on 8
 GPUs) the channels take the place of the batch as the chunked dim.  Round 4: channel chunks are copy-free as well -- a
 chunk's block for rank p is a contiguous slab (channels c0:c1) of the contraction's operand / result, handed to the
-list form of the all-to-all (``_Exchange.exchange_slabs``) -- and TWO channel chunks are the default there, so that
-the second half's transform runs under the first half's exchange on the way out and the first half's inverse under the
-second half's exchange on the way back (budget: DESIGN.md section 6; ``comm_chunks=1`` restores one piece).  When k1 is
+list form of the all-to-all (``_Exchange.exchange_slabs``), so ``comm_chunks=2`` lets the second half's transform run
+under the first half's exchange on the way out and the first half's inverse under the second half's exchange on the way
+back.  The DEFAULT there stays one piece per exchange: measured on one MI355X (a one-rank RCCL group,
+profiles/r04_modeshard_host.txt) the per-rank step of configs[3] at 8 GPUs is bound by the HOST's issue time -- 0.57-0.65
+ms per step with one piece, 0.83-0.91 ms with two (each all-to-all call costs ~50 us of host time in torch.distributed),
+against 0.28 ms of kernels -- so more, smaller collectives lose.  When k1 is
 not a multiple of P the mode rows are zero-padded to rows*P on the wire (SURVEY 8e "else pad").
 """
 import math
@@ -242,7 +245,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
 
     Constructor arguments follow SpectralConv.  ``ops`` (tests only) replaces the local stages (an object with the
     interface of engine.EngineRawOps); ``comm_chunks`` = pieces the exchange is pipelined in (None: 4 batch chunks,
-    or 2 channel chunks when a rank holds a single sample).
+    or one piece when a rank holds a single sample).
 
     The shard layout follows ``max_n_modes`` (= the construction-time ``n_modes``, or the explicit ``max_n_modes``
     argument): rank p owns rows [p rows, (p + 1) rows) of the STORED weight's first mode dim.  ``n_modes`` may be
@@ -299,8 +302,10 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         self._agops = agops
         self.fft_norm = fft_norm
         self.group = group
-        # pieces the exchange is pipelined in: None = 4 batch chunks when a rank holds >= 2 samples, 2 channel chunks when
-        # it holds a single sample (copy-free slabs, round 4); an explicit number applies to both cases
+        # pieces the exchange is pipelined in: None = 4 batch chunks when a rank holds >= 2 samples, ONE piece when it
+        # holds a single sample (the step is host-issue bound there: every extra all-to-all call costs ~50 us of host
+        # time, profiles/r04_modeshard_host.txt); an explicit number applies to both cases (channel chunks: copy-free
+        # slabs, round 4)
         self.comm_chunks = None if comm_chunks is None else max(1, int(comm_chunks))
         self.P = comm.get_model_parallel_size() if group is None else dist.get_world_size(group)
         self.rank = comm.get_model_parallel_rank() if group is None else dist.get_rank(group)
@@ -367,7 +372,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     def _chunks(self, by_batch):
         if self.comm_chunks is not None:
             return self.comm_chunks
-        return 4 if by_batch else 2
+        return 4 if by_batch else 1
 
     @property
     def n_modes(self):

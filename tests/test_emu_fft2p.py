@@ -57,6 +57,8 @@ CASES = [
     ((512, 1024), (31, 17), 2),         # odd kept rows, ragged columns
     ((512, 512), (256, 120), 1),        # half of the rows, widest column range the codelets cover
     ((1024, 1024), (2, 1), 1),
+    ((1024, 1024), (101, 129), 2),      # round 4: k_f2p_c2r_w1024 (129 kept columns) behind fewer, odd kept rows
+    ((1024, 1024), (256, 129), 5),      # ... and several images (the persistent item loop of the emulated 4-workgroup grid)
     # round 3: lines of 32 P points, P in {2, 3, 4, 5, 6, 8, 10, 12, 20} (radix 3 / 5 codelets, composite P)
     ((64, 64), (32, 17), 3),            # the common small grid (fno2d_64, modes 32): P = 2
     ((96, 96), (24, 13), 2),            # P = 3
@@ -177,3 +179,4 @@ def test_two_pass_chunking_and_bias_offsets(tmp_path):
             lib.plan_destroy(plan)
     assert res[0][2] < res[1][2], "the small-chunk build asks for a smaller panel workspace"
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+

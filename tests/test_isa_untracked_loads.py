@@ -123,8 +123,8 @@ def test_untracked_load_destinations_are_untouched_until_the_counted_wait():
         asm = open(out).read()
     seen = 0
     for name, lines in _functions(asm):
-        if "k_f2p_c2r" not in name and "k_fft2d_fwd3" not in name:
-            continue
+        if ("k_f2p_c2rI" not in name and "k_fft2d_fwd3" not in name) or "k_f2p_c2r_w1024" in name:
+            continue                                     # (k_f2p_c2r_w1024, round 4, has no untracked loads)
         n, bad = _check(name, lines)
         assert n > 0, f"{name}: no untracked load found (the probe no longer matches the kernels)"
         assert not bad, f"{name}: destination of an untracked load touched before the counted wait: {bad[:4]}"

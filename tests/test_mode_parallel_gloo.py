@@ -96,12 +96,12 @@ def test_mode_parallel_matches_single_process(spatial, modes, bl, chunks):
     _run_world(2, spatial, modes, bl, chunks)
 
 
-@pytest.mark.parametrize("chunks", [None, 1, 3], ids=["default_two_channel_chunks", "one_piece", "three_ragged_chunks"])
+@pytest.mark.parametrize("chunks", [None, 2, 3], ids=["default_one_piece", "two_channel_chunks", "three_ragged_chunks"])
 def test_mode_parallel_world8_one_sample_per_rank(chunks):
     """BASELINE configs[3]'s layout on one node: 8 ranks, B = 8 in total (ONE sample per rank), 32 mode rows ->
-    4 rows per rank, 3-d.  The default (None, round 4) pipelines every exchange over TWO channel chunks whose blocks
-    are slabs of the contraction's operand / result (no copy around the collective: _Exchange.exchange_slabs);
-    1 = one piece per exchange; 3 = ragged channel chunks (3 and 4 channels)."""
+    4 rows per rank, 3-d.  The default (None) exchanges each spectrum in one piece; 2 / 3 pipeline every exchange over
+    channel chunks whose blocks are slabs of the contraction's operand / result (round 4: no copy around the
+    collective, _Exchange.exchange_slabs; 3 = ragged chunks)."""
     _run_world(8, (32, 6, 8), (32, 4, 6), 1, chunks)
 
 
