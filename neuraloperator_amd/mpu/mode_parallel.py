@@ -256,7 +256,9 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     the fixed rows-of-max wire layout, zero elsewhere), the other mode dims use the sub-block's columns -- built from the
     autograd stages of the single-GPU layer (``agops``: engine.EngineOps) and mappings.all_to_all.  It is the
     functional route (one copy on each side of each exchange); the copy-free pipelined route serves the full block on
-    an unchanged grid, which is what the BASELINE configs time.
+    an unchanged grid, which is what the BASELINE configs time.  ``complex_data=True`` (round 4) takes the same general
+    route with complex-to-complex transforms and the reference's centring / last-dim rules (modes.kept_block_complex,
+    analysis_freqs, synthesis_freqs).
 
     Weights: dense (``weight``: this rank's mode rows of the (Cin, Cout, modes...) tensor; ``separable=True``: of the
     (C, modes...) tensor, spectral_convolution.py:49-52), or ``factorization`` "tucker" / "cp" / "tt"
@@ -271,11 +273,12 @@ class ModeParallelSpectralConv(BaseSpectralConv):
                  factorization=None, rank=0.5, separable=False, max_n_modes=None, resolution_scaling_factor=None,
                  agops=None, chunk_dim=None, **unused):
         super().__init__(device=device)
+        # complex_data (spectral_convolution.py:439-441, 475-479, 514-517, 536-538): complex-to-complex transforms in every
+        # dim, every dim centred -- runs on the general route (round 4)
+        self.complex_data = bool(unused.pop("complex_data", False))
         if chunk_dim not in (None, "batch", "channels"):
             raise ValueError("chunk_dim: None (batch chunks unless a rank holds one sample), 'batch' or 'channels'")
         self.chunk_dim = chunk_dim
-        if unused.get("complex_data"):
-            raise NotImplementedError("complex_data=True is not supported by the mode-parallel layer")
         fac = (factorization or "dense").lower()
         if fac not in ("dense", "tucker", "cp", "tt"):
             raise NotImplementedError("mode-parallel layer: dense, Tucker, CP or TT weights")
@@ -286,7 +289,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
                              f"but got in_channels={in_channels} and out_channels={out_channels}")   # :347-353
         self.factorization, self.separable = fac, bool(separable)
         self.in_channels, self.out_channels = in_channels, out_channels
-        self._n_modes = halve_last_mode(n_modes)
+        self._n_modes = halve_last_mode(n_modes, self.complex_data)
         # spectral_convolution.py:317-321: an explicit max_n_modes is stored UN-halved; None = the (halved) n_modes
         self.max_n_modes = list(self._n_modes) if max_n_modes is None else [int(v) for v in max_n_modes]
         self.order = len(self._n_modes)
@@ -381,7 +384,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     @n_modes.setter
     def n_modes(self, value):
         # spectral_convolution.py:400-415; the shard layout follows max_n_modes and does not move
-        nm = halve_last_mode(value)
+        nm = halve_last_mode(value, self.complex_data)
         if len(nm) != self.order or any(n > m for n, m in zip(nm, self.max_n_modes)):
             raise ValueError(f"n_modes {nm} exceeds max_n_modes {self.max_n_modes} (the stored, sharded weight)")
         self._n_modes = nm
@@ -407,6 +410,10 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         if x.shape[1] != self.in_channels:
             raise ValueError(f"input has {x.shape[1]} channels, the layer expects {self.in_channels}")
         out_shape = self._out_shape(spatial, output_shape)
+        if self.complex_data:
+            from ..modes import kept_block_complex
+            kept, w_start = kept_block_complex(spatial, self._n_modes, self.max_n_modes)
+            return self._forward_general(x, spatial, out_shape, kept, w_start)
         kept, w_start = kept_block(spatial, self._n_modes, self.max_n_modes)
         if kept != list(self.max_n_modes) or out_shape != spatial:
             return self._forward_general(x, spatial, out_shape, kept, w_start)
@@ -422,13 +429,15 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         (modes.synthesis_freqs)."""
         from .. import modes as _modes
         from .mappings import all_to_all
+        cplx = self.complex_data
         ag = self._agops
         if ag is None:
-            from ..engine import EngineOps
-            ag = self._agops = EngineOps(self.fft_norm, self.engine_flags)
+            from ..engine import EngineOps, SC_PLAN_COMPLEX
+            ag = self._agops = EngineOps(self.fft_norm, self.engine_flags | (SC_PLAN_COMPLEX if cplx else 0))
         P, rows = self.P, self.rows
-        fs, real_col = _modes.synthesis_freqs(spatial, out_shape, kept)
-        xhat = ag.forward_transform(x, kept, None)                          # (n, Cin, k1', rest')
+        fa = _modes.analysis_freqs(spatial, kept, cplx)                     # complex data: the reference's last-dim quirk
+        fs, real_col = _modes.synthesis_freqs(spatial, out_shape, kept, cplx)
+        xhat = ag.forward_transform(x, kept, fa)                            # (n, Cin, k1', rest')
         w = self._dense_block()                                             # this rank's rows of the stored weight
         lead = 1 if self.separable else 2
         cols = tuple(slice(s0, s0 + k) for s0, k in zip(w_start[1:], kept[1:]))
@@ -445,6 +454,9 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         else:
             wr = w[(slice(None),) * lead + (slice(w_start[0], w_start[0] + kept[0]),)].contiguous()
             yhat = ag.contract_separable(xhat, wr) if self.separable else ag.contract(xhat, wr)
+        if cplx:                          # a real bias added to a complex field: elementwise glue (:567-568)
+            y = ag.inverse_transform(yhat, None, out_shape, fs)
+            return y if self.bias is None else y + self.bias
         return ag.inverse_transform(yhat, self.bias, out_shape, fs, real_col)
 
     def _dense_block(self):

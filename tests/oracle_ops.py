@@ -203,3 +203,40 @@ class OracleAgOps:
             cur = torch.complex(cur.real, cur.imag * mask)
         y = torch.fft.irfftn(cur, s=list(spatial), dim=list(range(-nd, 0)), norm="forward")
         return y + bias if bias is not None else y
+
+
+class OracleAgOpsComplex(OracleAgOps):
+    """complex_data=True: complex-to-complex transforms in every dim (spectral_convolution.py:439-441, 536-538); the
+    frequency maps come from modes.analysis_freqs / synthesis_freqs (the last dim's map is always explicit)."""
+
+    @staticmethod
+    def forward_transform(x, kept, freq=None):
+        nd = x.ndim - 2
+        spatial = list(x.shape[2:])
+        xh = torch.fft.fftn(x, dim=list(range(-nd, 0)), norm="forward")
+        for d, k in enumerate(kept):
+            if freq is not None and freq[d] is not None:
+                ix = [int(f) for f in freq[d]]
+            else:
+                ix = [(r - k // 2) % spatial[d] for r in range(k)]
+            xh = xh.index_select(2 + d, torch.as_tensor(ix))
+        return xh
+
+    @staticmethod
+    def inverse_transform(yhat, bias, spatial, freq=None, real_col=0):
+        nd = len(spatial)
+        kept = list(yhat.shape[2:])
+        cur = yhat
+        for d in range(nd):
+            k = kept[d]
+            if freq is not None and freq[d] is not None:
+                ix = list(freq[d])
+            else:
+                ix = [(r - k // 2) % spatial[d] for r in range(k)]
+            keep = [r for r in range(k) if ix[r] is not None]
+            src = cur.index_select(2 + d, torch.as_tensor(keep))
+            shape = list(cur.shape)
+            shape[2 + d] = spatial[d]
+            cur = torch.zeros(shape, dtype=cur.dtype).index_add(2 + d, torch.as_tensor([int(ix[r]) for r in keep]), src)
+        y = torch.fft.ifftn(cur, dim=list(range(-nd, 0)), norm="forward")
+        return y + bias if bias is not None else y

@@ -690,10 +690,12 @@ def test_block_precision_half_mixed(name):
         SpectralConv(4, 4, (8, 8), fno_block_precision="quarter")
 
 
-@pytest.mark.parametrize("run_modes,out_shape,separable", [((10, 8), None, False), (None, (40, 30), False),
-                                                           ((9, 12), (24, 20), False), ((10, 8), None, True)],
-                         ids=["fewer_modes", "finer_grid", "fewer_modes_coarser_grid", "separable_fewer_modes"])
-def test_mode_parallel_general_path_on_device(run_modes, out_shape, separable):
+@pytest.mark.parametrize("run_modes,out_shape,separable,cplx", [((10, 8), None, False, False), (None, (40, 30), False, False),
+                                                                ((9, 12), (24, 20), False, False), ((10, 8), None, True, False),
+                                                                (None, None, False, True), ((10, 8), None, False, True)],
+                         ids=["fewer_modes", "finer_grid", "fewer_modes_coarser_grid", "separable_fewer_modes",
+                              "complex_data", "complex_data_fewer_modes"])
+def test_mode_parallel_general_path_on_device(run_modes, out_shape, separable, cplx):
     """Runtime-reduced n_modes / a different output grid on the mode-parallel layer (round 3, session 2:
     ModeParallelSpectralConv._forward_general on engine.EngineOps, one rank, no process group: the exchanges
     degenerate; their sharding logic is covered by the world-size-2 gloo tests) against the CPU oracle."""
@@ -703,25 +705,26 @@ def test_mode_parallel_general_path_on_device(run_modes, out_shape, separable):
     torch.manual_seed(4)
     ci = co = 6 if separable else 6
     co = ci if separable else 5
-    conv = ModeParallelSpectralConv(ci, co, (16, 12), separable=separable).to(dev)
+    conv = ModeParallelSpectralConv(ci, co, (16, 12), separable=separable, complex_data=cplx).to(dev)
     if run_modes is not None:
         conv.n_modes = run_modes
-    x = torch.randn(3, ci, 32, 24)
+    x = torch.randn(3, ci, 32, 24, dtype=torch.cfloat if cplx else torch.float32)
     xd = x.to(dev).requires_grad_(True)
     y = conv(xd, output_shape=out_shape)
-    g = torch.randn(*y.shape)
+    g = torch.randn(*y.shape, dtype=y.dtype)
     y.backward(g.to(dev))
     torch.cuda.synchronize()
     xc = x.clone().requires_grad_(True)
     wc = conv.weight.detach().cpu().clone().requires_grad_(True)
     bc = conv.bias.detach().cpu().clone().requires_grad_(True)
-    yo = so.forward_torch(xc, wc, bc, conv.n_modes, conv.max_n_modes, separable=separable, output_shape=out_shape)
+    yo = so.forward_torch(xc, wc, bc, conv.n_modes, conv.max_n_modes, separable=separable, output_shape=out_shape,
+                          complex_data=cplx)
     yo.backward(g)
     assert rel_l2(y.detach().cpu().numpy(), yo.detach().numpy()) < TOL
     assert rel_l2(xd.grad.cpu().numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(conv.weight.grad.cpu().numpy(), wc.grad.numpy()) < TOL
     assert rel_l2(conv.bias.grad.cpu().numpy(), bc.grad.numpy()) < TOL
-    if out_shape is not None:
+    if out_shape is not None and not cplx:
         assert list(conv.transform(xd.detach(), output_shape=out_shape).shape[2:]) == list(out_shape)
 
 

@@ -113,34 +113,37 @@ def _general_worker(rank, world, port, case, ret):
     from neuraloperator_amd.modes import halve_last_mode
     from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
     from oracle import spectral_oracle as so
-    from oracle_ops import OracleAgOps, OracleRawOps
+    from oracle_ops import OracleAgOps, OracleAgOpsComplex, OracleRawOps
 
-    spatial, max_modes, run_modes, out_shape, separable = case
+    spatial, max_modes, run_modes, out_shape, separable = case[:5]
+    cplx = len(case) > 5 and bool(case[5])                         # complex_data=True (round 4)
     comm.init(model_parallel_size=world, backend="gloo")
-    mx = halve_last_mode(max_modes)
+    mx = halve_last_mode(max_modes, cplx)
     bl = 2
     B, ci = bl * world, 3
     co = ci if separable else 4
     torch.manual_seed(0)
-    x = torch.randn(B, ci, *spatial)
+    x = torch.randn(B, ci, *spatial, dtype=torch.cfloat if cplx else torch.float32)
     w = torch.empty(*((ci,) if separable else (ci, co)), *mx, dtype=torch.cfloat).normal_(0, 0.4)
     bias = torch.randn(co, *(1,) * len(spatial))
-    conv = ModeParallelSpectralConv(ci, co, max_modes, ops=OracleRawOps(mx), agops=OracleAgOps(), separable=separable)
+    conv = ModeParallelSpectralConv(ci, co, max_modes, ops=OracleRawOps(mx),
+                                    agops=OracleAgOpsComplex() if cplx else OracleAgOps(), separable=separable,
+                                    complex_data=cplx)
     conv.load_full_state_dict({"weight.tensor": w, "bias": bias})
     if run_modes is not None:
         conv.n_modes = run_modes                                   # fno_block.py:460-464
-        assert conv.n_modes == halve_last_mode(run_modes) and conv.max_n_modes == mx
+        assert conv.n_modes == halve_last_mode(run_modes, cplx) and conv.max_n_modes == mx
         with pytest.raises(ValueError):
             conv.n_modes = [m + 2 for m in max_modes]
         conv.n_modes = run_modes
     xs = x[rank * bl:(rank + 1) * bl].clone().requires_grad_(True)
     y = conv(xs, output_shape=out_shape)
-    g = torch.randn(B, co, *y.shape[2:], generator=torch.Generator().manual_seed(5))
+    g = torch.randn(B, co, *y.shape[2:], generator=torch.Generator().manual_seed(5), dtype=y.dtype)
     y.backward(g[rank * bl:(rank + 1) * bl])
     conv.reduce_replicated_grads()
 
     xf, wf, bf = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-    yf = so.forward_torch(xf, wf, bf, conv.n_modes, mx, separable=separable, output_shape=out_shape)
+    yf = so.forward_torch(xf, wf, bf, conv.n_modes, mx, separable=separable, output_shape=out_shape, complex_data=cplx)
     yf.backward(g)
     rows = -(-mx[0] // world)
     live = min(rows, mx[0] - rank * rows)
@@ -154,7 +157,7 @@ def _general_worker(rank, world, port, case, ret):
         gw=float((gw - gw_ref).abs().max() / max(float(gw_ref.abs().max()), 1e-30)),
     )
     # the skip path's resize is local: every rank resizes its own batch shard
-    if out_shape is not None and len(spatial) == 2:
+    if out_shape is not None and len(spatial) == 2 and not cplx:
         t = conv.transform(xs.detach(), output_shape=out_shape)
         assert list(t.shape[2:]) == list(out_shape)
     ret[rank] = errs
@@ -169,7 +172,11 @@ def _general_worker(rank, world, port, case, ret):
     ((16, 12), (8, 6), (6, 6), (12, 8), False),    # fewer modes AND a coarser output grid
     ((8, 8, 6), (4, 4, 4), (2, 4, 4), None, False),
     ((16, 12), (8, 6), (6, 4), None, True),        # separable weights
-], ids=["m8_to_6x4", "m8_to_5x6", "grid_smaller", "finer_out", "fewer_modes_coarser_out", "3d", "separable"])
+    ((12, 10), (8, 6), None, None, False, True),   # complex_data=True (round 4): every dim centred, the last-dim quirk
+    ((12, 10), (8, 6), (6, 4), None, False, True), # ... with n_modes lowered at run time
+    ((8, 6, 10), (4, 4, 6), None, None, False, True),
+], ids=["m8_to_6x4", "m8_to_5x6", "grid_smaller", "finer_out", "fewer_modes_coarser_out", "3d", "separable",
+        "complex", "complex_fewer_modes", "complex_3d"])
 def test_mode_parallel_general_path_matches_single_process(case):
     port = _free_port()
     mgr = mp.Manager()
