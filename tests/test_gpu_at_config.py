@@ -43,7 +43,9 @@ AT_CONFIG = [
     ("C4_fno3d_128_m32_c32_b2", 2, 32, 32, (128, 128, 128), (32, 32, 32)),
     ("C4_fno3d_128_m32_c32_b8", 8, 32, 32, (128, 128, 128), (32, 32, 32)),      # BASELINE configs[3] at its bench batch
     ("C5_fno2d_1024_m256_c16to128_b1", 1, 16, 128, (1024, 1024), (256, 256)),
-    ("C5_fno2d_1024_m256_c128to16_b2", 2, 128, 16, (1024, 1024), (256, 256)),
+    # (C5 at 128 -> 16 channels, B = 2, was here in round 3: superseded by test_c5_literal_shape_vs_oracle -- the literal
+    #  128 -> 128, B = 4 shape -- and test_backward_pair_small_batch_one_pass, which runs every batch size of the one-pass
+    #  backward kernel; dropped to keep the GPU tier near ten minutes)
 ]
 
 
@@ -98,15 +100,22 @@ def test_c5_literal_shape_vs_oracle(lib):
     gb_ref = torch.zeros(co, dtype=torch.float64)
     num = dict(y=0.0, gx=0.0)
     den = dict(y=0.0, gx=0.0)
-    for s in range(b):
-        xc = x[s:s + 1].clone().requires_grad_(True)
+    # one oracle call for the whole batch where the host has the memory for it (~60 GB of spectra and autograd buffers; the
+    # weight's permutation inside the einsum, the slow part, then happens once), else sample by sample
+    try:
+        import psutil
+        step = b if psutil.virtual_memory().available > 200 * 2 ** 30 else 1
+    except Exception:
+        step = 1
+    for s in range(0, b, step):
+        xc = x[s:s + step].clone().requires_grad_(True)
         wc = w.clone().requires_grad_(True)
         bc = bias.clone().requires_grad_(True)
         yo = so.forward_torch(xc, wc, bc, nm, nm)
-        yo.backward(g[s:s + 1])
-        num["y"] += float((y[s:s + 1].double() - yo.detach().double()).pow(2).sum())
+        yo.backward(g[s:s + step])
+        num["y"] += float((y[s:s + step].double() - yo.detach().double()).pow(2).sum())
         den["y"] += float(yo.detach().double().pow(2).sum())
-        num["gx"] += float((gx[s:s + 1].double() - xc.grad.double()).pow(2).sum())
+        num["gx"] += float((gx[s:s + step].double() - xc.grad.double()).pow(2).sum())
         den["gx"] += float(xc.grad.double().pow(2).sum())
         gw_ref += wc.grad
         gb_ref += bc.grad.reshape(-1).double()
