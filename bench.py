@@ -736,6 +736,9 @@ def main():
         if engine.get_plan_bf16_io(dev, list(spatial), kept_chk, "forward", flags) is None:
             raise SystemExit(f"--io bf16: {args.workload} does not run on the fused 2-D kernels (no bf16 I/O there)")
 
+    if args.graph and dist is not None:
+        from neuraloperator_amd.mpu import rccl_native
+        rccl_native.prefer_native()                      # the exchanges must be plain stream launches to be recorded
     mp_kw = {}
     if args.comm_chunks > 0:
         mp_kw["comm_chunks"] = args.comm_chunks
@@ -746,10 +749,17 @@ def main():
         raise SystemExit(f"{args.workload}: batch {B} not divisible by {world} ranks for the strong-scaling run")
     step, b_local, global_batch, scaling, par, conv = case
     if args.graph:
-        if world > 1:
-            raise SystemExit("--graph: single GPU only (the collectives of the sharded layers are not captured)")
         from neuraloperator_amd.graph import capture_step
-        step = capture_step(conv, step.x, step.g).replay
+        post_g = None
+        if dist is not None:
+            # round 4: with the engine's native RCCL path (mpu/rccl_native.py) the exchanges of the mode-parallel layer
+            # are plain stream-ordered launches and record into the graph; through torch.distributed they do not
+            from neuraloperator_amd.mpu import rccl_native
+            if not par.startswith("modeshard") or rccl_native.get(conv._group()) is None:
+                raise SystemExit("--graph with collectives: the mode-parallel layer on the native RCCL path only "
+                                 f"({rccl_native.LAST_REASON or par})")
+            post_g = conv.reduce_replicated_grads
+        step = capture_step(conv, step.x, step.g, post=post_g).replay
     mappings.A2A_STATS.update(calls=0, bytes=0)
     ms, ms_cold, n_settle = timed_steps(step, args.steps, args.warmup, dist, dev, share, args.settle_ms)
     value = global_batch / (ms / 1e3)
@@ -890,8 +900,14 @@ def main():
                                      "10-25 % slower)"},
         }
         if world > 1 or parallel == "modeshard":
+            from neuraloperator_amd.mpu import rccl_native
+            native = bool(rccl_native._CACHE) and any(c is not None for c in rccl_native._CACHE.values())
             out["collectives"] = {"backend": "gloo (SC_BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL over xGMI)",
-                                  "all_to_all_calls_per_step": round(a2a["calls"] / n_timed, 2),
+                                  "issued_by": "ncclAllToAll / ncclSend+ncclRecv straight on HIP streams (mpu/rccl_native.py)"
+                                               if native else "torch.distributed" +
+                                               (f" ({rccl_native.LAST_REASON})" if rccl_native.LAST_REASON else ""),
+                                  "all_to_all_calls_per_step": (round(a2a["calls"] / n_timed, 2) if not args.graph else
+                                                                "recorded in the graph"),
                                   "all_to_all_bytes_per_step_per_rank": int(a2a["bytes"] / n_timed)}
         if extra:
             out["extra"] = extra

@@ -19,7 +19,10 @@ __all__ = ["GraphedStep", "capture_step"]
 class GraphedStep:
     """One captured forward + backward of ``module`` at ``x`` with the output gradient ``grad_out``."""
 
-    def __init__(self, module, x, grad_out, warmup=3):
+    def __init__(self, module, x, grad_out, warmup=3, post=None):
+        """post: an optional callable recorded behind the backward pass (the mode-parallel layer's
+        ``reduce_replicated_grads``: with the engine's native RCCL path -- mpu/rccl_native.py -- the exchanges and the
+        gradient all-reduce record into the graph like any launch)."""
         if not (x.is_cuda and grad_out.is_cuda):
             raise RuntimeError("GraphedStep: hipGraph capture needs device tensors (there is no CPU path)")
         self.module, self.x, self.grad_out = module, x, grad_out
@@ -39,12 +42,16 @@ class GraphedStep:
             for _ in range(max(int(warmup), 1)):
                 self._clear()
                 module(x).backward(grad_out)
+                if post is not None:
+                    post()
         torch.cuda.current_stream(x.device).wait_stream(side)
         self._clear()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.output = module(x)
             self.output.backward(grad_out)
+            if post is not None:
+                post()
         self.output = self.output.detach()
         # the tensors every replay writes: optimizers must keep pointing at exactly these
         self.grads = [p.grad for p in self.params]
@@ -72,5 +79,5 @@ class GraphedStep:
     __call__ = replay
 
 
-def capture_step(module, x, grad_out, warmup=3):
-    return GraphedStep(module, x, grad_out, warmup)
+def capture_step(module, x, grad_out, warmup=3, post=None):
+    return GraphedStep(module, x, grad_out, warmup, post)

@@ -125,5 +125,7 @@ def init(model_parallel_size=1, backend=None, verbose=False):
 def cleanup():
     global _DATA_PARALLEL_GROUP, _MODEL_PARALLEL_GROUP
     _DATA_PARALLEL_GROUP = _MODEL_PARALLEL_GROUP = None
+    from . import rccl_native
+    rccl_native.shutdown()                    # the engine's own RCCL communicators (round 4), before torch's
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -41,7 +41,7 @@ from torch import nn
 
 from ..modes import halve_last_mode, kept_block
 from ..spectral_conv import BaseSpectralConv
-from . import comm
+from . import comm, rccl_native
 from .mappings import A2A_STATS
 
 
@@ -52,12 +52,34 @@ def _bounds(ext, n):
 class _Exchange:
     """the two all-to-alls of one direction of the pipeline, chunk by chunk (plain tensors, no autograd)"""
 
-    def __init__(self, group, P, rows, k1):
+    def __init__(self, group, P, rows, k1, overlap=True):
         self.group, self.P, self.rows, self.k1 = group, P, rows, k1
+        # round 4: RCCL straight on a HIP stream where it was asked for and is available (rccl_native: plain stream-ordered
+        # launches, capturable into a hipGraph); None = the torch.distributed path (the default of eager steps).
+        # overlap=False (one piece per exchange: nothing to run beside it) issues on the CURRENT stream, no events.
+        self.native = rccl_native.get(group)
+        self.overlap = overlap
+
+    def _native(self, fn, tensors):
+        # inside a hipGraph capture the exchange stays on the capturing stream: RCCL calls on a stream that joined the
+        # capture through an event abort the process on this stack (RCCL 2.26.6), on the capturing stream itself they
+        # record fine (profiles/r04_modeshard_host.txt)
+        if torch.cuda.is_current_stream_capturing():
+            fn(torch.cuda.current_stream().cuda_stream)
+            return _Works([])
+        # eager: always on the communicator's own stream, never on torch's default (the legacy null) stream -- a
+        # communicator that has run on the null stream aborts the process when it is later used inside a capture
+        pending = self.native.launch_async(fn, tensors)
+        if not self.overlap:
+            pending.wait()
+            return _Works([])
+        return pending
 
     def _a2a(self, recv, send):
         A2A_STATS["calls"] += 1
         A2A_STATS["bytes"] += send.numel() * send.element_size()
+        if self.native is not None:
+            return self._native(lambda st: self.native.all_to_all(send, recv, st), (send, recv))
         return dist.all_to_all_single(recv, send, group=self.group, async_op=True)
 
     # send / recv: [P, n, C, rows, rest.., 2] float32, contiguous (block p <-> rank p of the group)
@@ -72,7 +94,11 @@ class _Exchange:
     def exchange_slabs(self, send_slabs, recv_slabs):
         A2A_STATS["calls"] += 1
         A2A_STATS["bytes"] += sum(t.numel() * t.element_size() for t in send_slabs)
-        assert all(t.is_contiguous() for t in send_slabs) and all(t.is_contiguous() for t in recv_slabs)
+        if not (all(t.is_contiguous() for t in send_slabs) and all(t.is_contiguous() for t in recv_slabs)):
+            raise ValueError("exchange_slabs: every slab must be contiguous")
+        if self.native is not None:
+            return self._native(lambda st: self.native.all_to_all_slabs(send_slabs, recv_slabs, st),
+                                list(send_slabs) + list(recv_slabs))
         if dist.get_backend(self.group) == "nccl":
             return _Works([dist.all_to_all(list(recv_slabs), list(send_slabs), group=self.group, async_op=True)])
         me = dist.get_rank(self.group)
@@ -106,9 +132,9 @@ class _ModeParallelFn(torch.autograd.Function):
         co = ci if layer.separable else weight.shape[1]
         rest = kept[1:]
         w = weight.detach().contiguous()
-        ex = _Exchange(layer._group(), P, rows, kept[0])
         by_batch = layer._by_batch(b)
         chunks = _bounds(b, min(layer._chunks(True), b)) if by_batch else _bounds(ci, min(layer._chunks(False), ci))
+        ex = _Exchange(layer._group(), P, rows, kept[0], overlap=len(chunks) > 1)
         ctx.cfg = (layer, spatial, kept, b, ci, co, by_batch)
         dev = x.device
 
@@ -177,10 +203,10 @@ class _ModeParallelFn(torch.autograd.Function):
         xhat_all, w = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         rest = kept[1:]
-        ex = _Exchange(layer._group(), P, rows, kept[0])
         dev = gy.device
         gy = gy.contiguous()
         chunks = _bounds(b, min(layer._chunks(True), b)) if by_batch else _bounds(co, min(layer._chunks(False), co))
+        ex = _Exchange(layer._group(), P, rows, kept[0], overlap=len(chunks) > 1)
         k1 = kept[0]
 
         # ---- adjoint of the inverse transform (+ bias gradient) + exchange (split modes, cat batch)
@@ -482,10 +508,14 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         different batch shard) and, for Tucker weights, the core and the unsharded factors (every rank contracted
         different modes).  The sharded weight / factor rows need nothing."""
         if self.P > 1:
+            native = rccl_native.get(self._group())
             for q in self.replicated_parameters():
                 if q.grad is not None:
                     g = torch.view_as_real(q.grad) if q.grad.is_complex() else q.grad
-                    dist.all_reduce(g, group=self._group())
+                    if native is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+                        native.all_reduce_sum_on_current(g)
+                    else:
+                        dist.all_reduce(g, group=self._group())
 
     def sync_replicated_parameters(self, src=0):
         """Broadcast the replicated parameters from group rank ``src`` (after a per-rank random init)."""

@@ -57,17 +57,19 @@ def timed(fn, n=50):
 
 
 issue, total = timed(step)
-print(f"eager: host issue {issue:.3f} ms/step, wall {total:.3f} ms/step  ({kw})")
+from neuraloperator_amd.mpu import rccl_native  # noqa: E402
+print(f"eager: host issue {issue:.3f} ms/step, wall {total:.3f} ms/step  ({kw}; exchanges: "
+      f"{'native RCCL' if rccl_native.get(conv._group()) is not None else 'torch.distributed (' + rccl_native.LAST_REASON + ')'})")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(50):
     step()
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(32)
+pstats.Stats(pr).sort_stats(os.environ.get("MS_SORT", "cumulative")).print_stats(int(os.environ.get("MS_TOP", 32)))
 sys.stdout.flush()
 if os.environ.get("MS_GRAPH") != "1":
-    dist.destroy_process_group()
+    comm.cleanup()
     sys.exit(0)
 
 # the whole step as ONE hipGraph, collectives included
@@ -101,4 +103,4 @@ try:
     print("replay vs eager: y", float((ye.detach() - y.detach()).abs().max()), "gx", float((xe.grad - x.grad).abs().max()))
 except Exception as e:
     print("graph capture failed:", type(e).__name__, str(e)[:300])
-dist.destroy_process_group()
+comm.cleanup()

@@ -120,3 +120,21 @@ def test_raw_stream_accessor_fallback(monkeypatch):
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         assert engine._stream() == side.cuda_stream
+
+
+@needs_gpu
+@pytest.mark.parametrize("batch,kw", [(1, dict(comm_chunks=1, chunk_dim="channels")), (1, dict(comm_chunks=3, chunk_dim="channels")),
+                                      (4, dict())], ids=["one_piece", "channel_slabs", "batch_chunks"])
+def test_mode_parallel_step_with_native_rccl_records_into_a_graph(batch, kw):
+    """Round 4 (mpu/rccl_native.py): with the exchanges issued by ncclAllToAll / grouped ncclSend + ncclRecv straight on HIP
+    streams, the mode-parallel layer's whole step -- transforms, exchanges, contractions, the bias all-reduce -- records into
+    ONE hipGraph.  One-rank RCCL group (the only multi-process RCCL set-up a 1-GPU box allows): a replay equals the eager
+    native step bit for bit, also after the static inputs were refilled, and the native path's results equal the
+    torch.distributed path's bit for bit.  The case runs in its own process (tests/native_rccl_graph_case.py says why)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "native_rccl_graph_case.py"), str(batch), repr(kw)],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "CASE OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
