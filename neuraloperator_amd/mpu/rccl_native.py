@@ -200,9 +200,9 @@ def get(group):
             if comm is not None and not reason:
                 reason = "another rank failed"
             comm = None
-        if comm is None and mode == "native":
-            raise RcclError("SC_MPU_A2A=native: " + reason)
     LAST_REASON = reason
+    if comm is None and mode == "native":                    # forced: an error, not a silent fallback
+        raise RcclError("SC_MPU_A2A=native: " + reason)
     _CACHE[key] = comm
     return comm
 
