@@ -114,7 +114,9 @@ struct sc_plan {
   int f2p_k2[2] = {0, 0};       // range of the pruned 32-point stage: kept rows / kept columns
   int f2p_ncb = 0;              // panel blocks of 8 kept columns
   cf32* f2p_tw[2] = {nullptr, nullptr};
-  cf32* f2p_w1024 = nullptr;    // exp(-2 pi i m / 1024), m = 0..1023: rows of 1024 points on k_f2p_c2r_w1024 (round 4)
+  cf32* f2p_w1024 = nullptr;    // exp(-2 pi i m / 1024), m = 0..1023: 1024-point lines on k_f2p_c2r_w1024 / k_f2p_col_inv_w1024 (round 4)
+  bool f2p_roww = false;        // rows: N1 = 1024 with the 129 kept columns k = 0..128
+  bool f2p_colw = false;        // columns: N0 = 1024 with <= 256 kept rows
   float* f2p_cs_fwd[2] = {nullptr, nullptr};   // [SC_FWD_SCALED], [SC_FWD_ADJ_C2R]
   float* f2p_cs_inv[2] = {nullptr, nullptr};   // [SC_INV_PADDED], [SC_INV_ADJ_R2C]
   // factorised last-two-axes kernels for 128 x 128 planes (sc_kernels_plane.h)
@@ -470,7 +472,9 @@ static int f2p_plan_init(sc_plan* p, bool large_only) {
   }
   int rc = fft_col_scales(p, p->f2p_cs_fwd, p->f2p_cs_inv);
   if (rc) return rc;
-  if (p->n[1] == 1024 && J == 129) {                     // one wave per row pair (k_f2p_c2r_w1024): kept columns k = 0..128
+  p->f2p_roww = p->n[1] == 1024 && J == 129;             // one wave per row pair (k_f2p_c2r_w1024): kept columns k = 0..128
+  p->f2p_colw = p->n[0] == 1024 && K0 <= 256;            // 64 lanes per column line (k_f2p_col_inv_w1024)
+  if (p->f2p_roww || p->f2p_colw) {
     std::vector<cf32> h(1024);
     for (int m = 0; m < 1024; ++m) h[(size_t)m] = twiddle(m, 1, 1024, -1.0, 1.0);
     DeviceTable dt;
@@ -591,6 +595,21 @@ static bool f2p_launch_col_fwd(const sc_plan* p, const cf32* panel, cf32* dst, i
 static bool f2p_launch_col_inv(const sc_plan* p, const cf32* src, cf32* panel, int64_t ni, sc_stream_t st) {
   const int J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
   const int64_t n_blk = ni * NCB;
+  static const bool no_colw = std::getenv("SC_F2P_NO_COLW") != nullptr;              // A-B: the 32-lane kernel
+  if (p->f2p_colw && !no_colw && n_blk < ((int64_t)1 << 30)) {
+    // columns of 1024 points: 64 lanes per line, two 512-thread workgroups per compute unit, persistent
+    static const int wgs = [] { const char* e = std::getenv("SC_F2P_COLW_WGS"); return e ? std::atoi(e) : 2; }();
+    int64_t grid = (int64_t)(wgs > 0 ? wgs : 2) * sc_cu_count();
+    if (grid > n_blk) grid = n_blk;
+    if (grid >= 8) grid &= ~(int64_t)7;                                              // whole XCD rounds (the kernel's block map)
+    if (K0 == 256)
+      SC_LAUNCH((k_f2p_col_inv_w1024<true>), dim3((unsigned)grid), dim3(512), 0, st, src, panel, (const cf32*)p->f2p_w1024,
+                NCB, J, K0, (int)n_blk, (int)grid);
+    else
+      SC_LAUNCH((k_f2p_col_inv_w1024<false>), dim3((unsigned)grid), dim3(512), 0, st, src, panel, (const cf32*)p->f2p_w1024,
+                NCB, J, K0, (int)n_blk, (int)grid);
+    return true;
+  }
   return f2p_dispatch(p->f2p_p[0], p->f2p_k2[0], [&](auto P, auto K2) {
     constexpr int G = 32 / decltype(P)::value;
     const int pxc = (int)(((n_blk + G - 1) / G + 7) / 8);
@@ -602,7 +621,7 @@ static bool f2p_launch_c2r(const sc_plan* p, int mode, const cf32* panel, float*
                            int64_t i0, int64_t ni, sc_stream_t st) {
   const int N0 = (int)p->n[0], J = (int)p->k[1], NCB = p->f2p_ncb;
   static const bool no_w1024 = std::getenv("SC_F2P_NO_W1024") != nullptr;          // A-B: the half-wave kernel
-  if (p->f2p_w1024 && !no_w1024) {
+  if (p->f2p_roww && !no_w1024) {
     // rows of 1024 points: one wave per packed row pair, four 4-wave workgroups per compute unit (sc_kernels_fft2p.h)
     static const int wgs = [] { const char* e = std::getenv("SC_F2P_W1024_WGS"); return e ? std::atoi(e) : 4; }();
     const int64_t n_pairs = ni * N0 / 2, n_items = (n_pairs + 3) / 4;

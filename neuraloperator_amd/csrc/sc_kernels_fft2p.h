@@ -748,3 +748,88 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
 // spectrum (L2-resident), then the row transforms above out of LDS.  HBM traffic drops to R + S, but the spectrum is read
 // 64 x per image out of L2 (10.8 TB/s of L2 reads) and the kernel ran 0.79-0.82 ms against 0.78 ms for the two passes
 // (1.03 ms with two rounds of its loads in flight): profiles/r04_f2p_band_ab.txt.
+
+// ------------------------------------------------------------------------------------------
+// Round 4: pass 2 inverse for 1024-point COLUMNS with 64 lanes per column line (k_f2p_col_inv_w1024) -- the column
+// analogue of k_f2p_c2r_w1024.  k_f2p_col_inv<32, K2> gives a column line to 32 lanes x 32 points (2 workgroups = 8
+// waves per compute unit) and moved its 0.57 GB panel + the spectrum at 3.1-3.9 TB/s (0.24 ms of the 0.78 ms an
+// inverse-type 1024^2 transform takes).  The kept rows |f| <= 128 are a quarter of the spectrum, so again n0 = 4 m + r
+// makes the pruned radix-4 stage one twiddle per input and leaves four full 256-point transforms (16 x 16).  A workgroup
+// of 512 threads owns one panel block (8 columns x 1024 rows): thread = (column c = tid & 7, line lane L = tid >> 3 =
+// 4 l + r), 16 points per lane; the 16 x 16 exchange of a line spans all 8 waves (two workgroup barriers per block);
+// a store instruction's 64 lanes cover rows 8 w .. 8 w + 7 x 8 columns = 512 contiguous bytes of the panel.  Two
+// workgroups = 16 waves per unit.  Scope: N0 = 1024, kept rows K0 <= 256 (any parity), any J; persistent workgroups.
+// ------------------------------------------------------------------------------------------
+#define SC_CW1K_RS 296                 // r block: 16 rows of 17 + pad, = 8 mod 32
+#define SC_CW1K_CS (4 * SC_CW1K_RS + 1)  // column block, = 1 mod 32: the (c, r) of a half-wave hit 32 different 8-byte slots
+template <bool FULL>                                       // FULL: K0 = 256, every input row is a kept row
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(512, 4)                 // 4 waves per SIMD = two 8-wave workgroups per unit
+k_f2p_col_inv_w1024(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf32* __restrict__ w1024, int NCB,
+                    int J, int K0, int n_blk, int gstride) {
+  constexpr int N0 = 1024;
+  SC_SHARED __attribute__((aligned(16))) cf32 tw2[256];                     // conj w256^(ma l), [ma][l]
+  SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_CW1K_CS];            // [c][r][ma][l]
+  const int tid = SC_TID, c = tid & 7, L = tid >> 3, r = L & 3, l = L >> 2;
+  if (tid < 256) tw2[tid] = cf_conj(w1024[(4 * (tid >> 4) * (tid & 15)) & 1023]);
+  // lane constants: w1024^(+r f) and the kept row of frequency f = l + 16 q (q < 8) / l + 16 q - 256 (q >= 8)
+  cf32 twr[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int f = l + 16 * q - (q >= 8 ? 256 : 0);
+    twr[q] = cf_conj(w1024[(r * f) & 1023]);
+  }
+  const int row0 = l + K0 / 2;                             // kept row of f = l; the others are compile-time steps away
+  cf32* Ew = E + c * SC_CW1K_CS + r * SC_CW1K_RS + l;
+  const cf32* Er = E + c * SC_CW1K_CS + r * SC_CW1K_RS + l * SC_W1K_ES;
+  // persistent: consecutive blocks (the column blocks of one image) on ONE XCD, as in k_f2p_col_inv
+  const bool xmap = (gstride & 7) == 0;
+  SC_SYNC();                                               // tw2
+
+#pragma unroll 1
+  for (int it = 0;; ++it) {
+    int blk;
+    if (xmap) {
+      const int per = gstride >> 3;                        // workgroups per XCD
+      const int per_xcd_blocks = (n_blk + 7) / 8;
+      const int local = it * per + (int)(SC_BID_X >> 3);
+      if (local >= per_xcd_blocks) break;
+      blk = (int)(SC_BID_X & 7) * per_xcd_blocks + local;
+    } else {
+      blk = it * gstride + (int)SC_BID_X;
+      if (blk >= n_blk) break;
+    }
+    const bool have = blk < n_blk;                         // (XCD map: the last XCD's tail)
+    const int bc = have ? blk : n_blk - 1;
+    const int img = bc / NCB, col = (bc - img * NCB) * SC_F2P_CB + c;
+    const bool live = have && col < J;
+    const cf32* src = yhat + (int64_t)img * K0 * J + (col < J ? col : 0);
+    cf32 T[16], U[16];
+    sc_static_for<0, 16>([&](auto qt) {
+      constexpr int q = decltype(qt)::value;
+      constexpr int step = 16 * q - (q >= 8 ? 256 : 0);
+      if constexpr (FULL) {
+        const cf32 v = src[(int64_t)row0 * J + (int64_t)step * J];       // (lane part) + (uniform part)
+        T[q] = live ? cf_mul_cs(v, twr[q]) : cf_make(0.f, 0.f);
+      } else {
+        const int row = row0 + step;
+        const bool ok = row >= 0 && row < K0;
+        const cf32 v = src[(int64_t)(ok ? row : 0) * J];
+        T[q] = (live && ok) ? cf_mul_cs(v, twr[q]) : cf_make(0.f, 0.f);
+      }
+    });
+    fft16<+1>(T, U);                                       // over kappa2 -> ma
+    Ew[0] = U[0];
+#pragma unroll
+    for (int ma = 1; ma < 16; ++ma) Ew[ma * SC_W1K_ES] = cf_mul_cs(U[ma], sc_lds_ld64(tw2 + ma * 16 + l));
+    SC_SYNC();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T[q] = sc_lds_ld64(Er + q);   // lane l now plays ma = l
+    SC_SYNC();                                             // E is rewritten by the next block
+    fft16<+1>(T, U);                                       // over l -> mb : z[r + 4 ma + 64 mb] = z[L + 64 mb]
+    if (live) {
+      cf32* dst = panel + (int64_t)bc * N0 * SC_F2P_CB + L * SC_F2P_CB + c;
+#pragma unroll
+      for (int mb = 0; mb < 16; ++mb) dst[(int64_t)64 * mb * SC_F2P_CB] = U[mb];
+    }
+  }
+}

@@ -180,3 +180,36 @@ def test_two_pass_chunking_and_bias_offsets(tmp_path):
     assert res[0][2] < res[1][2], "the small-chunk build asks for a smaller panel workspace"
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
+
+def test_column_kernel_xcd_block_map():
+    """k_f2p_col_inv_w1024 with a grid that is a multiple of 8 (the real chip: 512 persistent workgroups): XCD x = b % 8 walks
+    the blocks [x ceil(n / 8), (x + 1) ceil(n / 8)) -- the column blocks of one image stay on one XCD.  The emulated chip has
+    one compute unit (grid 2: the plain block order), so the XCD order runs in a subprocess with SC_F2P_COLW_WGS=8: 3 images =
+    51 blocks, 7 per XCD, the last XCD's tail past the end."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+from engine_runner import emu_lib, rel_l2
+from neuraloperator_amd import _lib
+from test_emu_fft2p import _ref_inverse
+lib = emu_lib()
+rng = np.random.default_rng(4)
+for kept in ((256, 129), (77, 20)):
+    n_img, spatial = 3, (1024, 1024)
+    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+    ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8)
+    yh = (rng.standard_normal((n_img, *kept)) + 1j * rng.standard_normal((n_img, *kept))).astype(np.complex64)
+    y = torch.full((n_img, *spatial), float("nan"))
+    lib.transform_inverse(plan, _lib.SC_INV_PADDED, torch.view_as_real(torch.from_numpy(yh)).data_ptr(), 0, n_img,
+                          y.data_ptr(), n_img, ws.data_ptr(), 0)
+    err = rel_l2(y.numpy(), _ref_inverse(yh, spatial, 1.0, True))
+    print("ERR", kept, err)
+    assert err < 2e-6, err
+    lib.plan_destroy(plan)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SC_F2P_COLW_WGS="8", PYTHONPATH=root + os.pathsep + os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and out.stdout.count("ERR") == 2, out.stdout[-2000:] + out.stderr[-2000:]
