@@ -901,7 +901,7 @@ def main():
         }
         if world > 1 or parallel == "modeshard":
             from neuraloperator_amd.mpu import rccl_native
-            native = bool(rccl_native._CACHE) and any(c is not None for c in rccl_native._CACHE.values())
+            native = rccl_native.active()
             out["collectives"] = {"backend": "gloo (SC_BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL over xGMI)",
                                   "issued_by": "ncclAllToAll / ncclSend+ncclRecv straight on HIP streams (mpu/rccl_native.py)"
                                                if native else "torch.distributed" +

@@ -226,6 +226,11 @@ def _self_test(comm):
     return bool(torch.equal(got, want) and torch.equal(got2, want))
 
 
+def active():
+    """True when some process group of this process exchanges through the native path"""
+    return any(c is not None for c in _CACHE.values())
+
+
 def shutdown():
     for c in _CACHE.values():
         if c is not None:
