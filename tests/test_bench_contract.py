@@ -47,3 +47,44 @@ def test_alg_bytes_metric_shape(bench):
     R, Wb, S, total = bench.alg_bytes(32, 64, (256, 256), [64, 33], 4)
     assert (R, Wb, S) == (32 * 64 * 256 * 256 * 4, 64 * 64 * 64 * 33 * 8, 32 * 64 * 64 * 33 * 8)
     assert total == 4 * R + 3 * Wb + 9 * S == 2666528768
+
+
+def test_kernel_key_and_traffic_table_from_a_counter_database(bench, tmp_path, monkeypatch):
+    """measure_step_traffic (round 4: live FETCH_SIZE / WRITE_SIZE of EVERY kernel of a workload's step) on a stand-in for
+    rocprofv3: a fake executable that writes the rocpd sqlite views the real one writes.  Checks the kernel-name
+    normalisation, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, KB = 1024 B, launches per step, the per-step sum and the
+    dominant kernel of an extra.* entry."""
+    assert bench._kernel_key("void k_fft2d_fwd3<256, float>(float const*, cf32*, int)") == "k_fft2d_fwd3<256, float>"
+    assert bench._kernel_key("k_f2p_c2r_w1024(cf32 const*, float*)") == "k_f2p_c2r_w1024"
+    assert bench._kernel_key("k_modegemm_dma<4, 2, 2, 3, false, (bool)1, false>(Gemm8Args)") == \
+        "k_modegemm_dma<4, 2, 2, 3, false, (bool)1, false>"
+    fake = tmp_path / "rocprofv3"
+    fake.write_text('''#!/usr/bin/env python3
+import os, sqlite3, sys
+a = sys.argv
+counter, d = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+os.makedirs(d, exist_ok=True)
+db = sqlite3.connect(os.path.join(d, "run.db"))
+db.execute("create table counters_collection (kernel_name text, counter_name text, value real)")
+db.execute("create table top_kernels (name text, total_calls int, total_duration real, average real, percentage real)")
+rows = {"FETCH_SIZE": [("void k_a<1>(int)", 100.0), ("void k_a<1>(int)", 100.0), ("k_b(float*)", 10.0), ("k_b(float*)", 10.0),
+                       ("k_b(float*)", 10.0), ("k_b(float*)", 10.0), ("at::native::fill", 5.0)],
+        "WRITE_SIZE": [("void k_a<1>(int)", 50.0), ("void k_a<1>(int)", 50.0), ("k_b(float*)", 1.0), ("k_b(float*)", 1.0),
+                       ("k_b(float*)", 1.0), ("k_b(float*)", 1.0)]}
+for k, v in rows[counter]:
+    db.execute("insert into counters_collection values (?, ?, ?)", (k, counter, v))
+db.execute("insert into top_kernels values ('void k_a<1>(int)', 2, 400.0, 200.0, 80.0)")
+db.execute("insert into top_kernels values ('k_b(float*)', 4, 80.0, 20.0, 20.0)")
+db.commit()
+''')
+    fake.chmod(0o755)
+    import shutil
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake) if name == "rocprofv3" else None)
+    got, note = bench.measure_step_traffic((2, 4, (16, 16), (8, 8)), reps=2)
+    assert got is not None, note
+    ka, kb = got["kernels"]["k_a<1>"], got["kernels"]["k_b"]
+    assert ka == {"launches_per_step": 1.0, "fetch_B": 100 * 1024 * 2, "write_B": 50 * 1024, "traffic_B": 250 * 1024, "ms": 0.2}
+    assert kb["launches_per_step"] == 2.0 and kb["traffic_B"] == 21 * 1024 and kb["ms"] == 0.02
+    assert got["step_traffic_B"] == 250 * 1024 + 2 * 21 * 1024            # torch's own kernels are not counted
+    ex = bench._extra_traffic((2, 4, (16, 16), (8, 8)), "f32", "dense", 292 * 1024 // 2)
+    assert ex["traffic"] == 292 * 1024 and ex["traffic_over_alg_bytes"] == 2.0 and ex["dominant_kernel"]["name"] == "k_a<1>"
