@@ -6,7 +6,7 @@ spectral_convolution.py:417-570 and its implicit backward) on the same seeded in
 fp32 (north star).  Sizes:
 
   C2  headline   B=32, C=64, 256^2, modes (64,64)          -- the metric shape at its full batch
-  C4  FNO3d      B=2,  C=32, 128^3, modes (32,32,32)       -- per-GPU share of configs[3] at 4 ranks
+  C4  FNO3d      B=8,  C=32, 128^3, modes (32,32,32)       -- configs[3] at its bench batch (B = 2, the share at 4 ranks, until round 4)
   C5  FNO2d      B=1,  16 -> 128 channels, 1024^2, modes (256,256) -- the large-grid passes at N = 1024,
                  J = 129, K = 256 and the hidden-128 contraction (Q = 128)
   C3  TFNO       B=4,  C=64, 256^2, Tucker rank 0.1 -> (36,36,36,19), factorized and reconstructed,
@@ -19,6 +19,10 @@ Round 3 (VERDICT r2 "what's weak" 1):
       Darcy-like coefficient field lifted to C = 64 -- so the three-real-product contraction (errors scale with
       |A||B|, not with |Re| and |Im| separately) is judged on non-Gaussian spectra; distance to the float64
       restatement (forward_np64 / backward_np64) is reported next to the distance to the fp32 reference path.
+
+Round 4 (VERDICT r3 "what's weak" 1):
+  C5  LITERALLY: B = 4, 128 -> 128 channels, 1024^2, modes (256, 256) (test_c5_literal_shape_vs_oracle)
+  C3  also at the bench batch B = 32
 """
 import numpy as np
 import pytest
@@ -40,7 +44,7 @@ def lib():
 
 AT_CONFIG = [
     ("C2_fno2d_256_m64_c64_b32", 32, 64, 64, (256, 256), (64, 64)),
-    ("C4_fno3d_128_m32_c32_b2", 2, 32, 32, (128, 128, 128), (32, 32, 32)),
+    # (C4 at B = 2 -- the per-GPU share at 4 ranks -- was here until round 4: the B = 8 case below runs the same kernels)
     ("C4_fno3d_128_m32_c32_b8", 8, 32, 32, (128, 128, 128), (32, 32, 32)),      # BASELINE configs[3] at its bench batch
     ("C5_fno2d_1024_m256_c16to128_b1", 1, 16, 128, (1024, 1024), (256, 256)),
     # (C5 at 128 -> 16 channels, B = 2, was here in round 3: superseded by test_c5_literal_shape_vs_oracle -- the literal

@@ -81,12 +81,14 @@ def test_fast_route_matches_size_agnostic_passes(lib, spatial, kept, n_img):
     # adjoint pair carries the C2R column weights instead)
     from test_emu_plane128 import _ref_forward, _ref_inverse
     ntot = float(np.prod(spatial))
-    xn = x.cpu().numpy()
-    yh = torch.view_as_complex(yhat.cpu()).numpy()
-    bn = bias.cpu().numpy().astype(np.float64).reshape((n_img,) + (1,) * len(spatial))
+    nh = min(n_img, 6)                                   # the first images on the host (the rest: the HIP-vs-HIP check above)
+    xn = x[:nh].cpu().numpy()
+    yh = torch.view_as_complex(yhat[:nh].cpu()).numpy()
+    bn = bias[:nh].cpu().numpy().astype(np.float64).reshape((nh,) + (1,) * len(spatial))
     refs = [_ref_forward(xn, kept, 1.0 / ntot, False), _ref_forward(xn, kept, 1.0, True),
             _ref_inverse(yh, spatial, 1.0, True) + bn, _ref_inverse(yh, spatial, 1.0 / ntot, False)]
     for i, (a, r) in enumerate(zip(res["fast"], refs)):
+        a = a[:nh]
         got = a[..., 0] + 1j * a[..., 1] if i < 2 else a
         assert rel_l2(got, r) < TOL, f"output {i}: {names['fast']} against the float64 definition"
 
