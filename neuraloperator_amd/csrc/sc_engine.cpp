@@ -2244,9 +2244,13 @@ static sc_modegemm_desc tkc_gu_in_desc(const sc_tucker_chain_desc* c) {      // 
   const int64_t M = c->n_modes;
   return tkc_desc(c->c_in, c->r_in, c->batch, M, M, c->c_in * M, 1, c->r_in * M, M, 1, c->r_in, 1, 0, 1, 0);
 }
-static sc_modegemm_desc tkc_gu_out_desc(const sc_tucker_chain_desc* c) {     // gu_out[o, g] <- (t^H gy)[g, o]
+// gu_out[o, g] = sum_{b, m} gy[b, o, m] conj(t[b, g, m]) -- A = gy (P = c_out rows), B = t conjugated (Q = r_out columns).
+// Round 4: until then the roles were the other way round (A = t conjugated, P = r_out = 36 rows, the result stored
+// transposed): the accumulating kernel gives each of its four waves a 16-row block of P, so 36 rows kept three waves busy
+// with four column tiles each -- 52 us against 26 us for the mirror-image gu_in launch (profiles/r04_tfno_kernel_stats.txt).
+static sc_modegemm_desc tkc_gu_out_desc(const sc_tucker_chain_desc* c) {
   const int64_t M = c->n_modes;
-  return tkc_desc(c->r_out, c->c_out, c->batch, M, M, c->r_out * M, 1, c->c_out * M, M, 1, 1, c->r_out, 0, 1, 0);
+  return tkc_desc(c->c_out, c->r_out, c->batch, M, M, c->c_out * M, 1, c->r_out * M, M, 1, c->r_out, 1, 0, 0, 1);
 }
 static size_t tkc_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -2323,7 +2327,7 @@ extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const flo
   if ((rc = sc_modegemm(&d, gy, u_out, gt, stream))) return rc;
   if (gu_out) {
     d = tkc_gu_out_desc(c);
-    if ((rc = tkc_factor_grad(&d, t, gy, gu_out, Co * R2, wred, wred_bytes, ss))) return rc;
+    if ((rc = tkc_factor_grad(&d, gy, t, gu_out, Co * R2, wred, wred_bytes, ss))) return rc;
   }
   if (side && !sc_side_fork(side, main)) return sc_fail(sync_fail);                 // gt is ready
   // t = z t3:  gz = gt t3^H;  gt3[f, g, m] = sum_b conj(z[b, f, m]) gt[b, g, m]
