@@ -99,6 +99,13 @@ struct sc_plan {
   float* l_r2c[2] = {nullptr, nullptr};
   cf32* l_r2c_tail[2] = {nullptr, nullptr};
   int l_r2c_ct = 0;                            // MFMA column tiles (tail column excluded)
+  // LDS-staged r2c for any width, table in global memory (k_mdft_r2c_stage; built when l_r2c is not)
+  float* s_r2c[2] = {nullptr, nullptr};
+  cf32* s_r2c_tail[2] = {nullptr, nullptr};
+  int s_r2c_ct = 0;
+  // ... and the c2r of the widths l_c2r does not take (k_mdft_c2r_stage): lane-major float4, JS2 = step pairs per tile
+  float* s_c2r[2] = {nullptr, nullptr};
+  int s_c2r_js2 = 0, s_c2r_s = 0;
   float* l_c2r[2] = {nullptr, nullptr};
   int l_c2r_s = 0;                             // LDS row stride of the c2r tile, floats
   float* m_pl_fwd = nullptr;                   // plane form: row-pass table of dim nd-2, forward ([jt][n1][64])
@@ -206,6 +213,8 @@ static int upload_floats(sc_plan* p, const std::vector<float>& host, float** out
 //   -DSC_MDFT_NOLDS    first-generation last-axis passes (operands straight from global memory)
 //   -DSC_MDFT_NOTAIL   the 2^k + 1-th kept column as an MFMA tile instead of a VALU dot product
 //   -DSC_MDFT_NOPLANE  last two axes as separate passes
+//   -DSC_MDFT_NOSTAGE  widths outside k_mdft_r2c_lds's scope straight from global memory (k_mdft_r2c) instead of the
+//                      LDS-staged k_mdft_r2c_stage
 struct MdftSwitches {
 #ifdef SC_MDFT_TILE4
   static constexpr bool tile4 = true;
@@ -227,6 +236,11 @@ struct MdftSwitches {
 #else
   static constexpr bool noplane = false;
 #endif
+#ifdef SC_MDFT_NOSTAGE
+  static constexpr bool nostage = true;
+#else
+  static constexpr bool nostage = false;
+#endif
 };
 static constexpr MdftSwitches mdft_switches() { return MdftSwitches(); }
 
@@ -235,8 +249,8 @@ static int build_mdft_tables(sc_plan* p) {
   const int L = p->nd - 1;
   const int64_t N = p->n[L], J = p->k[L];
   int rc = 0;
-  if (N % 8 == 0 && !p->cplx) {
-    const int64_t NG = N / 8, CT = (2 * J + 31) / 32;
+  if (!p->cplx) {                       // any N: the last group of 8 points is zero-padded (k_mdft_r2c<.., RAGGED>)
+    const int64_t NG = (N + 7) / 8, CT = (2 * J + 31) / 32;
     for (int v = 0; v < 2 && !rc; ++v) {
       std::vector<float> h((size_t)(CT * NG * 4 * 64), 0.f);
       for (int64_t ct = 0; ct < CT; ++ct)
@@ -255,6 +269,7 @@ static int build_mdft_tables(sc_plan* p) {
           for (int q = 0; q < 4; ++q)
             for (int hh = 0; hh < 2; ++hh) {
               const int64_t n = 8 * t + 4 * hh + q, j = J - 1;
+              if (n >= N) continue;
               const cf32 tw = last_tw(p, j, n, -1.0, v != SC_FWD_SCALED);
               ht[(size_t)(((t * 4 + q) * 2 + hh) * 2 + 0)] = tw.x;
               ht[(size_t)(((t * 4 + q) * 2 + hh) * 2 + 1)] = tw.y;
@@ -313,6 +328,38 @@ static int build_mdft_tables(sc_plan* p) {
       }
     }
   }
+  // LDS-staged r2c of the remaining widths (any N): table in global memory, lane-major float4, NG = 4 ceil(N / 32)
+  if (!rc && !p->cplx && !p->l_r2c[0] && !mdft_switches().nostage) {
+    const bool tail = J > 1 && (2 * J) % 32 == 2 && 2 * J > 32 && !mdft_switches().notail;
+    const int64_t NC = (N + 31) / 32, NG = 4 * NC, CT = tail ? (2 * J - 2) / 32 : (2 * J + 31) / 32;
+    if (CT <= 2 && (!tail || NC * 32 <= 1024)) {
+      p->s_r2c_ct = (int)CT;
+      for (int v = 0; v < 2 && !rc; ++v) {
+        std::vector<float> h((size_t)(CT * NG * 256), 0.f);
+        for (int64_t ct = 0; ct < CT; ++ct)
+          for (int64_t t = 0; t < NG; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int q = 0; q < 4; ++q) {
+                const int64_t f = 32 * ct + (lane & 31), j = f >> 1, n = 8 * t + 4 * (lane >> 5) + q;
+                if (j >= J || n >= N) continue;
+                const cf32 tw = last_tw(p, j, n, -1.0, v != SC_FWD_SCALED);
+                h[(size_t)(((ct * NG + t) * 64 + lane) * 4 + q)] = (f & 1) ? tw.y : tw.x;
+              }
+        rc = upload_floats(p, h, &p->s_r2c[v]);
+        if (!rc && tail) {
+          std::vector<float> ht((size_t)(2 * 32 * NC), 0.f);
+          for (int64_t n = 0; n < N; ++n) {
+            const cf32 tw = last_tw(p, J - 1, n, -1.0, v != SC_FWD_SCALED);
+            ht[(size_t)(2 * n)] = tw.x;
+            ht[(size_t)(2 * n + 1)] = tw.y;
+          }
+          float* dev = nullptr;
+          rc = upload_floats(p, ht, &dev);
+          p->s_r2c_tail[v] = (cf32*)dev;
+        }
+      }
+    }
+  }
   // LDS-staged c2r: table + one 128-line tile of the spectrum within 48 KB (3+ blocks per CU)
   if (!rc && !p->cplx) {
     const int64_t JS = (J + 1) / 2, NT = (N + 31) / 32;
@@ -331,6 +378,28 @@ static int build_mdft_tables(sc_plan* p) {
               h[(size_t)(((nt * JS + t) * 64 + lane) * 2 + 1)] = -tw.y;
             }
         rc = upload_floats(p, h, &p->l_c2r[v]);
+      }
+    }
+  }
+  // LDS-staged c2r of the remaining widths: table in global memory, [((nt * JS2 + p) * 64 + lane) * 4 + e]
+  if (!rc && !p->cplx && !p->l_c2r[0] && !mdft_switches().nostage) {
+    const int64_t JS = (J + 1) / 2, NT = (N + 31) / 32;
+    const int64_t need = (JS + 1) / 2, JS2 = need <= 3 ? 3 : (need <= 5 ? 5 : (need <= 9 ? 9 : 0));
+    if (JS2) {
+      p->s_c2r_js2 = (int)JS2;
+      p->s_c2r_s = (int)((J % 2) ? 2 * J : 2 * J + 2);
+      for (int v = 0; v < 2 && !rc; ++v) {
+        std::vector<float> h((size_t)(NT * JS2 * 256), 0.f);
+        for (int64_t nt = 0; nt < NT; ++nt)
+          for (int64_t pp = 0; pp < JS2; ++pp)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 4; ++e) {
+                const int64_t t = 2 * pp + (e >> 1), n = 32 * nt + (lane & 31), j = 2 * t + (lane >> 5);
+                if (j >= J || n >= N) continue;
+                const cf32 tw = last_tw(p, j, n, +1.0, v == SC_INV_PADDED);
+                h[(size_t)(((nt * JS2 + pp) * 64 + lane) * 4 + e)] = (e & 1) ? -tw.y : tw.x;
+              }
+        rc = upload_floats(p, h, &p->s_c2r[v]);
       }
     }
   }
@@ -928,12 +997,18 @@ static void launch_r2c(const float* in, cf32* out, const DeviceTable& t, int64_t
             t.cols_pad);
 }
 
+// 16-byte aligned tensor storage (the wide loads / stores of the matrix-core and plane passes)
+static bool sc_io_aligned(const void* io) { return !(((uintptr_t)io) & 15); }
+
 template <int RT, int CT, bool TAIL>
 static void launch_mdft_r2c(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
                             int J, int n_ct, sc_stream_t st) {
   const int64_t items = (lines + 32 * RT - 1) / (32 * RT);
-  SC_LAUNCH((k_mdft_r2c<RT, CT, TAIL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, (float*)out, tab,
-            tail, lines, N, J, n_ct);
+  const dim3 grid((unsigned)((items + 3) / 4));
+  if (N % 8 == 0 && sc_io_aligned(in))     // 8-byte loads
+    SC_LAUNCH((k_mdft_r2c<RT, CT, TAIL, false>), grid, dim3(256), 0, st, in, (float*)out, tab, tail, lines, N, J, n_ct);
+  else                                     // any width / any 4-byte aligned view: clamped 4-byte loads
+    SC_LAUNCH((k_mdft_r2c<RT, CT, TAIL, true>), grid, dim3(256), 0, st, in, (float*)out, tab, tail, lines, N, J, n_ct);
 }
 
 template <bool TAIL>
@@ -973,14 +1048,23 @@ static void launch_mdft_r2c_lds(const float* in, cf32* out, const float* tab, co
             (size_t)(N / 8) * CT * 1024, st, in, (float*)out, tab, tail, lines, N, J, tpb, tab1, K1);
 }
 
+template <int CT, bool TAIL>
+static void launch_mdft_r2c_stage(const float* in, cf32* out, const float* tab, const cf32* tail, int64_t lines, int N,
+                                  int J, sc_stream_t st) {
+  const int tpb = mdft_lds_tiles_per_block(lines);
+  const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
+  SC_LAUNCH((k_mdft_r2c_stage<CT, TAIL>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), 0, st, in,
+            (float*)out, tab, tail, lines, N, J, tpb);
+}
+
 #define SC_C2R_NPF 12          // registers per thread holding the next tile's input (k_mdft_c2r_lds)
 // ---- "plane" form: the last TWO axes in one launch when the second-to-last has 128, 64 or 32 rows --------
 static bool plane_rows_ok(int64_t nr) { return nr == 128 || nr == 64 || nr == 32; }
 // io = the real tensor the pass reads (forward) / writes (inverse); nullptr = "aligned".  The plane kernels and the
 // matrix-core DFT passes move its rows with 16-byte accesses.  A contiguous view with an odd storage offset
-// (flat[1:1 + n].view(...), a gradient handed over out of a bucketed buffer) takes the VALU passes with 4-byte accesses
-// for the real-side pass instead (k_last_r2c / k_last_c2r: slow, correct, rare) -- the call does not fail.
-static bool sc_io_aligned(const void* io) { return !(((uintptr_t)io) & 15); }
+// (flat[1:1 + n].view(...), a gradient handed over out of a bucketed buffer) takes the straight-from-global matrix-core
+// passes with 4-byte accesses for the real-side pass instead (k_mdft_r2c<.., RAGGED> / k_mdft_c2r; the VALU passes
+// k_last_r2c / k_last_c2r under SC_PLAN_NO_MDFT) -- the call does not fail.
 static bool plane_fwd_ok(const sc_plan* p, int mode, const void* io = nullptr) {
   if (!sc_io_aligned(io)) return false;
   if (p->pl128 || p->pl64) return true;
@@ -1073,7 +1157,19 @@ static int run_r2c(const sc_plan* p, int mode, const float* in, cf32* out, int64
     }
     return sc_check_launch("k_mdft_r2c_lds");
   }
-  if (al && p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
+  if (p->mdft && p->s_r2c[mode] && lines < ((int64_t)1 << 36)) {       // 4-byte loads: any view
+    const float* tab = p->s_r2c[mode];
+    const cf32* tail = p->s_r2c_tail[mode];
+    if (tail) {
+      if (p->s_r2c_ct == 1) launch_mdft_r2c_stage<1, true>(in, out, tab, tail, lines, N, J, st);
+      else launch_mdft_r2c_stage<2, true>(in, out, tab, tail, lines, N, J, st);
+    } else {
+      if (p->s_r2c_ct == 1) launch_mdft_r2c_stage<1, false>(in, out, tab, tail, lines, N, J, st);
+      else launch_mdft_r2c_stage<2, false>(in, out, tab, tail, lines, N, J, st);
+    }
+    return sc_check_launch("k_mdft_r2c_stage");
+  }
+  if (p->mdft && p->m_r2c[mode] && lines < ((int64_t)1 << 36)) {
     if (p->m_r2c_tail[mode] && !mdft_switches().notail && 2 * J > 32)
       dispatch_mdft_r2c<true>(in, out, p->m_r2c[mode], p->m_r2c_tail[mode], lines, N, J, (2 * J - 2) / 32, st);
     else
@@ -1108,8 +1204,10 @@ template <int RT, int CT>
 static void launch_mdft_c2r(const cf32* in, float* out, const float* tab, const float* bias, int64_t lines, int N,
                             int J, int n_nt, int64_t lpi, int64_t channels, sc_stream_t st) {
   const int64_t items = (lines + 32 * RT - 1) / (32 * RT);
+  // the bias is one scalar per wave when a wave's 32 RT lines cannot straddle two images, a per-row lookup otherwise
+  const int per_line = (bias != nullptr && lpi % (32 * RT) != 0) ? 1 : 0;
   SC_LAUNCH((k_mdft_c2r<RT, CT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, out, tab, bias, lines, N,
-            J, n_nt, lpi, channels);
+            J, n_nt, lpi, channels, per_line);
 }
 
 template <int CT, int NR, int NPF, int CA = 1, bool ATAIL = false>
@@ -1151,6 +1249,22 @@ static void launch_mdft_c2r_lds_npf(const sc_plan* p, int mode, const cf32* in, 
   SC_LAUNCH((k_mdft_c2r_lds<CT, NR, NPF, CA, ATAIL>), dim3((unsigned)((n_tiles + tpb - 1) / tpb)), dim3(256), lds, st, in, out,
             (const float*)p->l_c2r[mode], bias, lines, N, J, n_nt, p->l_c2r_s, lpi, channels, tpb,
             PLANE ? (const float*)p->m_pl_inv : (const float*)nullptr, K1);
+}
+
+template <int JS2>
+static void launch_mdft_c2r_stage(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
+                                  int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
+  const int64_t n_tiles = (lines + SC_MDFT_LB - 1) / SC_MDFT_LB;
+  const int n_nt = (N + 31) / 32;
+  // ranges of column tiles per 128-line tile: ~6 blocks per resident slot (4 per CU), so that the last round of
+  // blocks is a small share of the launch; every range re-reads the tile's spectrum (8 % of the bytes, from L2)
+  int64_t splits = ((int64_t)24 * sc_cu_count() + n_tiles - 1) / n_tiles;
+  if (splits < 1) splits = 1;
+  if (splits > n_nt) splits = n_nt;
+  const int nt_per = (int)((n_nt + splits - 1) / splits);
+  const unsigned gy = (unsigned)((n_nt + nt_per - 1) / nt_per);
+  SC_LAUNCH((k_mdft_c2r_stage<JS2>), dim3((unsigned)n_tiles, gy), dim3(256), (size_t)SC_MDFT_LB * p->s_c2r_s * sizeof(float),
+            st, in, out, (const float*)p->s_c2r[mode], bias, lines, N, J, n_nt, p->s_c2r_s, lpi, channels, nt_per);
 }
 
 // (planes x K1 x J complex) -> y (planes x 128 x N real): second-to-last axis + last axis (+ bias)
@@ -1197,11 +1311,17 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
     else launch_mdft_c2r_lds<1>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
     return sc_check_launch("k_mdft_c2r_lds");
   }
-  if (al && p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {
+  if (p->mdft && p->s_c2r[mode] && lines < ((int64_t)1 << 36) && (lines + SC_MDFT_LB - 1) / SC_MDFT_LB < ((int64_t)1 << 31)) {
+    if (p->s_c2r_js2 == 3) launch_mdft_c2r_stage<3>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else if (p->s_c2r_js2 == 5) launch_mdft_c2r_stage<5>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    else launch_mdft_c2r_stage<9>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    return sc_check_launch("k_mdft_c2r_stage");
+  }
+  if (p->mdft && p->m_c2r[mode] && lines < ((int64_t)1 << 36)) {       // 4-byte stores: any view
     const int n_nt = (N + 31) / 32;
     const bool big = !mdft_switches().tile4;
     const int rt = big ? (n_nt <= 2 ? 4 : (n_nt <= 4 ? 2 : 1)) : (n_nt <= 2 ? 2 : 1);
-    if (bias == nullptr || lpi % (32 * rt) == 0) {     // bias must be uniform per wave (32 rt lines)
+    {
       if (big) {
         if (rt == 4) launch_mdft_c2r<4, 2>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
         else if (rt == 2) launch_mdft_c2r<2, 4>(in, out, p->m_c2r[mode], bias, lines, N, J, n_nt, lpi, channels, st);
@@ -1236,8 +1356,17 @@ template <int JT, int CT>
 static void launch_mdft_axis(const cf32* in, cf32* out, const float* tab, int64_t outer, int N, int J, int64_t inner,
                              int n_jt, sc_stream_t st) {
   const int64_t items = (outer * inner + 32 * CT - 1) / (32 * CT);
-  SC_LAUNCH((k_mdft_axis<JT, CT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, in, out, tab, outer, N, J,
-            inner, n_jt);
+  const unsigned gy = (unsigned)((n_jt + JT - 1) / JT);        // one group of JT j-tiles per block
+  // few items and a long reduction: the four waves of a block share one item and split its N rows (KS)
+  if constexpr (JT * CT <= 4) {                                // (48 KB of partial sums at most)
+    if (N >= 64 && items * gy < (int64_t)8 * sc_cu_count()) {
+      SC_LAUNCH((k_mdft_axis<JT, CT, true>), dim3((unsigned)items, gy), dim3(256), 0, st, in, out, tab, outer, N, J,
+                inner, n_jt);
+      return;
+    }
+  }
+  SC_LAUNCH((k_mdft_axis<JT, CT, false>), dim3((unsigned)((items + 3) / 4), gy), dim3(256), 0, st, in, out, tab,
+            outer, N, J, inner, n_jt);
 }
 
 // 128-point first-axis lines over the plane results (sc_kernels_plane.h)
@@ -3101,8 +3230,9 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   if (p->mdft) {
     if (which == 0 && plane_fwd_ok(p, 0)) return "k_mdft_r2c_lds<plane>";
     if (which == 1 && plane_inv_ok(p, 0)) return "k_mdft_c2r_lds<plane>";
-    if (which == 0) return p->l_r2c[0] ? "k_mdft_r2c_lds" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c");
-    return p->l_c2r[0] ? "k_mdft_c2r_lds" : "k_mdft_c2r";
+    if (which == 0)
+      return p->l_r2c[0] ? "k_mdft_r2c_lds" : (p->s_r2c[0] ? "k_mdft_r2c_stage" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c"));
+    return p->l_c2r[0] ? "k_mdft_c2r_lds" : (p->s_c2r[0] ? "k_mdft_c2r_stage" : "k_mdft_c2r");
   }
   return which == 0 ? "k_last_r2c" : "k_last_c2r";
 }

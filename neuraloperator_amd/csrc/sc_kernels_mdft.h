@@ -37,14 +37,18 @@ SC_HD int mdft_row(const int v, const int half) { return (v & 3) + 8 * (v >> 2) 
 // last axis, real -> complex.  Result tile D[32 lines][32 output floats (2 j + c')].
 //   A operand = data: lane (line, h) holds in[line][8 t + 4 h + q], q = 0..3 (one float4 load);
 //   B operand = table: tab[((ct * NG + t) * 4 + q) * 64 + lane]
-// requires N % 8 == 0 (16-byte aligned float4 loads); RT row tiles x CT column tiles per wave.
+// RT row tiles x CT column tiles per wave.  RAGGED = false: N % 8 == 0, two 8-byte loads per lane and step.
+// RAGGED = true (round 4: any N -- the reference's documented Darcy grids are 85 / 141 / 211 / 421 points wide, and until
+// then every width that is not a multiple of 8 fell to the scalar VALU pass k_last_r2c: 650 us per call at 421^2 where this
+// kernel needs ~190): NG = ceil(N / 8) steps, the table's rows past N are zero, and a lane reads its four points with
+// 4-byte loads whose index is clamped to the line (rows are not 8-byte aligned when N is odd; nothing is read past a line).
 // ------------------------------------------------------------------------------------------
 // TAIL: kept-mode counts of the form 2^k + 1 (n_modes/2 + 1 with power-of-two n_modes: the usual
 // case) put exactly one complex column past a 32-float tile boundary; a whole MFMA column tile for 2
 // of 32 columns was 47 % of this pass's matrix work at J = 17.  That column is a plain dot product
 // per line on the VALU instead (tail[(t*4 + q)*2 + h] = T[8t + 4h + q][J-1]), riding on the operand
 // registers the MFMAs already hold.
-template <int RT, int CT, bool TAIL>
+template <int RT, int CT, bool TAIL, bool RAGGED = false>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
            const cf32* __restrict__ tail, int64_t lines, int N, int J, int n_ct) {
@@ -54,7 +58,7 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
   const int64_t item = (int64_t)SC_BID_X * 4 + w;               // one wave = RT row tiles
   const int64_t l0 = item * (32 * RT);
   if (l0 >= lines) return;
-  const int NG = N / 8;
+  const int NG = (N + 7) / 8;
   cf32 tacc[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) tacc[r] = cf_make(0.f, 0.f);
@@ -85,9 +89,18 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
 #ifdef SC_MDFT_ABL_NOLOAD
         a[r][0] = (float)(n0 + r); a[r][1] = a[r][0] + 1.f; a[r][2] = a[r][0] + 2.f; a[r][3] = a[r][0] + 3.f;
 #else
-        const cf32 lo = *reinterpret_cast<const cf32*>(rowp[r] + n0);
-        const cf32 hi = *reinterpret_cast<const cf32*>(rowp[r] + n0 + 2);
-        a[r][0] = lo.x; a[r][1] = lo.y; a[r][2] = hi.x; a[r][3] = hi.y;
+        if constexpr (RAGGED) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = n0 + q;
+            const float v = rowp[r][n < N ? n : N - 1];           // unconditional, inside the line
+            a[r][q] = n < N ? v : 0.f;
+          }
+        } else {
+          const cf32 lo = *reinterpret_cast<const cf32*>(rowp[r] + n0);
+          const cf32 hi = *reinterpret_cast<const cf32*>(rowp[r] + n0 + 2);
+          a[r][0] = lo.x; a[r][1] = lo.y; a[r][2] = hi.x; a[r][3] = hi.y;
+        }
 #endif
       }
 #pragma unroll
@@ -175,18 +188,27 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
 //   A operand = table: tab[((jt * NS + s) * 2 + comp) * 64 + lane], row = lane & 31, n = 2 s + (lane >> 5)
 //   B operand = data: lane (col, h) holds in[o][2 s + h][i] (one 8-byte load), .x for comp 0, .y for comp 1
 // JT j-tiles (16 j each) x CT column tiles per wave.
+// Round 4: grid.y = group of JT j-tiles (one pass over the input per block: the loop over groups re-read the input anyway,
+// and a zero-padded inverse pass over few columns -- 512 images x 17 kept columns of a 421-row grid: 272 waves on 1024
+// SIMDs, 27 groups each -- was latency bound: 66 us for 29 MB), and KS = true splits the N input rows over the FOUR waves
+// of a block (one item per block instead of four), partial sums meeting in LDS: the forward pass of the same case runs
+// 211 dependent load -> MFMA steps per wave with the chip three quarters empty (74 us for 29 MB).
 // ------------------------------------------------------------------------------------------
-template <int JT, int CT>
+template <int JT, int CT, bool KS = false>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __restrict__ tab,
             int64_t outer, int N, int J, int64_t inner, int n_jt) {
+  SC_SHARED float red[KS ? 3 * JT * CT * 1024 : 1];
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
   const int64_t ncols = outer * inner;
-  const int64_t item = (int64_t)SC_BID_X * 4 + w;
+  const int64_t item = KS ? (int64_t)SC_BID_X : (int64_t)SC_BID_X * 4 + w;
   const int64_t c0 = item * (32 * CT);
   if (c0 >= ncols) return;
   const int NS = (N + 1) / 2;
+  const int nsq = KS ? (NS + 3) / 4 : NS;                      // this wave's steps [s_lo, s_hi)
+  const int s_lo = KS ? w * nsq : 0;
+  const int s_hi = (s_lo + nsq < NS) ? s_lo + nsq : NS;
   const cf32* colp[CT];
   int64_t obase[CT];
   bool cok[CT];
@@ -199,8 +221,8 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
     colp[c] = in + (o * N) * inner + i;
     obase[c] = (o * J) * inner + i;
   }
-#pragma unroll 1
-  for (int jt0 = 0; jt0 < n_jt; jt0 += JT) {
+  {
+    const int jt0 = (int)SC_BID_Y * JT;
     sc_f32x16 acc[JT][CT];
 #pragma unroll
     for (int j = 0; j < JT; ++j)
@@ -231,15 +253,15 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
           MDFT_MFMA(acc[j][c], a[j][1], d[c].y);
         }
     };
-    fetch(0, d0, a0);
-    int s = 0;
+    int s = s_lo;
+    if (s < s_hi) fetch(s, d0, a0);
 #pragma unroll 1
-    for (; s + 1 < NS; s += 2) {
+    for (; s + 1 < s_hi; s += 2) {
       fetch(s + 1, d1, a1);
       SC_SCHED_BARRIER();
       multiply(d0, a0);
       SC_SCHED_BARRIER();
-      if (s + 2 < NS) fetch(s + 2, d0, a0);
+      if (s + 2 < s_hi) fetch(s + 2, d0, a0);
       SC_SCHED_BARRIER();
       multiply(d1, a1);
       SC_SCHED_BARRIER();
@@ -248,7 +270,27 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
 #pragma unroll
         for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[j][c]);
     }
-    if (s < NS) multiply(d0, a0);
+    if (s < s_hi) multiply(d0, a0);
+    if (KS) {                                                  // partial sums of waves 1..3 -> wave 0
+      if (w > 0) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[((((w - 1) * JT + j) * CT + c) * 16 + v) * 64 + lane] = acc[j][c][v];
+      }
+      SC_SYNC();
+      if (w > 0) return;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][c][v] += red[(((k * JT + j) * CT + c) * 16 + v) * 64 + lane];
+    }
     const int64_t zo = sc_opaque(0);
 #pragma unroll
     for (int j = 0; j < JT; ++j)
@@ -274,16 +316,16 @@ template <int RT, int CT>
 SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
 k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
            const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt,
-           int64_t lines_per_image, int64_t channels) {
+           int64_t lines_per_image, int64_t channels, int per_line_bias) {
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
   const int64_t item = (int64_t)SC_BID_X * 4 + w;
   const int64_t l0 = item * (32 * RT);
   if (l0 >= lines) return;
   const int JS = (J + 1) / 2;
-  // the host only takes this kernel with a bias when a wave's 32 RT lines lie inside one image
-  // (lines_per_image % (32 RT) == 0), so the bias is one wave-uniform scalar
-  const float badd = (bias != nullptr) ? bias[(l0 / lines_per_image) % channels] : 0.f;
+  // a wave's 32 RT lines lie inside one image when lines_per_image % (32 RT) == 0: the bias is then one wave-uniform
+  // scalar; otherwise (round 4: image heights such as 421) per_line_bias = 1 and every stored row looks its own value up
+  const float badd = (bias != nullptr && !per_line_bias) ? bias[(l0 / lines_per_image) % channels] : 0.f;
   const cf32* rowp[RT];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
@@ -349,14 +391,15 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
         const int64_t line = l0e + 32 * r + mdft_row(v, half);
         if (line < lines) {
           float* orow = out + line * N;
+          const float bl = (per_line_bias && bias != nullptr) ? bias[(line / lines_per_image) % channels] : badd;
 #pragma unroll
           for (int c = 0; c < CT; ++c) {
             const int n = 32 * (nt0 + c) + col;
             if (nt0 + c < n_nt && n < N && MDFT_STORE_OK(acc[r][c][v])) {
 #ifdef SC_MDFT_PLAIN_STORE
-              orow[n] = acc[r][c][v] + badd;
+              orow[n] = acc[r][c][v] + bl;
 #else
-              SC_STORE_STREAM(&orow[n], acc[r][c][v] + badd);   // 2 GB written once, read by a later kernel
+              SC_STORE_STREAM(&orow[n], acc[r][c][v] + bl);     // 2 GB written once, read by a later kernel
 #endif
             }
           }
@@ -645,6 +688,281 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
     }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) SC_PIN_ACC(acc[ct]);      // both paths leave the accumulators where they are
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// last axis, real -> complex through LDS for ANY width (round 4; k_mdft_r2c_lds above needs N % 32 == 0 and its whole
+// table in LDS).  The straight-from-global kernel k_mdft_r2c reads its A operand "lane = line": one load instruction
+// touches 32 different rows, every 128-byte line is wanted by 16 instructions, and the rows a CU has in flight (RT x 4 KB
+// per wave) do not fit its L1 -- 262 us for the 363 MB of a 16 x 32 x 421^2 tensor (1.4 TB/s).  Here a 256-thread block
+// owns 128 consecutive lines and brings them through LDS in chunks of 32 samples with loads whose 32 lanes run along a
+// ROW (128 contiguous bytes per half wave, 4-byte accesses: rows of an odd width are only 4-byte aligned), each byte
+// exactly once; the waves then read their MFMA operands from LDS (36-float rows: conflict free as float4).  The table
+// (too big for LDS next to useful occupancy at such widths: 56 KB at 421 x 17) stays in global memory in the lane-major
+// float4 layout of k_mdft_r2c_lds, one chunk of it (4 CT float4 per lane) held in registers, each slot re-requested for
+// the next chunk as soon as its MFMAs have read it -- every block reads the same 50-100 KB, which L2 keeps.  Samples past N arrive as zeros (and the table rows are zero there).
+//   tab  [((ct * NG + t) * 64 + lane) * 4 + q] = T[8t + 4(lane>>5) + q][32 ct + (lane & 31)],  NG = 4 ceil(N / 32)
+//   tail [n] = T[n][J - 1], n < 32 ceil(N / 32) <= 1024 (kept in LDS)
+// ------------------------------------------------------------------------------------------
+template <int CT, bool TAIL>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 1 ? 4 : 3))
+k_mdft_r2c_stage(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
+                 const cf32* __restrict__ tail, int64_t lines, int N, int J, int tiles_per_block) {
+  constexpr int LB = SC_MDFT_LB, KC = 32, S4 = 9;            // LDS row = 36 floats = 9 float4
+  SC_SHARED sc_f4 dat[LB * S4];
+  SC_SHARED sc_f4 tailL[TAIL ? 512 : 1];                     // 1024 cf32
+  SC_SHARED cf32 tsum[TAIL ? 128 : 1];
+  float* datf = reinterpret_cast<float*>(dat);
+  const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int NC = (N + KC - 1) / KC, NG = 4 * NC;
+  const int64_t n_tiles = (lines + LB - 1) / LB;
+  const int64_t tile0 = (int64_t)SC_BID_X * tiles_per_block;
+  if (tile0 >= n_tiles) return;
+  const int my_tiles = (int)((n_tiles - tile0 < tiles_per_block) ? n_tiles - tile0 : tiles_per_block);
+  const int total = my_tiles * NC;
+  if (TAIL) {
+    const sc_f4* s4 = reinterpret_cast<const sc_f4*>(tail);
+    for (int i = tid; i < NC * (KC / 2); i += 256) tailL[i] = s4[i];
+  }
+  // loader: lane col = sample of the chunk; the two halves of a wave take rows 8 apart (36-float rows: the two
+  // 32-bank runs of a write then fill the 64 banks), m walks the tile: row = 16 (m >> 1) + 8 half + 2 w + (m & 1).
+  const int lr0 = 8 * half + 2 * w;
+  int ld_c = 0;
+  int64_t ld_l0 = tile0 * LB;
+  float r[16];
+  auto gload = [&]() {
+    const int n = ld_c * KC + col;
+    const bool nok = n < N;
+    const int nn = nok ? n : N - 1;                            // the load itself is unconditional, inside the line
+    // a wave-uniform tile pointer + a 32-bit byte offset per lane (saddr form: sixteen 64-bit row pointers spilled);
+    // the offset is clamped to the tile's last float, so rows past the end of the tensor re-read valid memory
+    const char* tile = reinterpret_cast<const char*>(in + ld_l0 * N);
+    const int64_t left = lines - ld_l0;
+    const uint32_t omax = (uint32_t)(((left < LB ? (int)left : LB) * N - 1) * 4);
+    const uint32_t o0 = (uint32_t)((lr0 * N + nn) * 4);
+    const int n4 = sc_opaque_s(4 * N);                         // (the row terms stay scalar: added where they are used)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      uint32_t o = o0 + (uint32_t)((16 * (m >> 1) + (m & 1)) * n4);
+      o = o < omax ? o : omax;
+      // plain, not streaming: a row's 32-sample chunk straddles two 128-byte lines whenever rows are not line-aligned,
+      // and the neighbouring chunk wants the shared line one iteration later -- from L2, if this load left it there
+      // (421 x 17: 111 us plain, 124 us non-temporal; profiles/r04_mdft_odd_ablation.txt)
+#ifdef SC_STAGE_NT_LOAD
+      const float v = SC_LOAD_STREAM(reinterpret_cast<const float*>(tile + o));
+#else
+      const float v = *reinterpret_cast<const float*>(tile + o);
+#endif
+      r[m] = nok ? v : 0.f;
+    }
+    if (++ld_c == NC) {
+      ld_c = 0;
+      ld_l0 += LB;
+    }
+  };
+  // table: slot s of the NEXT chunk is requested as soon as the MFMAs of step s of this chunk have read theirs
+  const sc_f4* t4 = reinterpret_cast<const sc_f4*>(tab);
+  sc_f4 tc[4][CT];
+  auto tload = [&](const int cc, const int s) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) tc[s][ct] = t4[(ct * NG + 4 * cc + s) * 64 + lane];
+  };
+  gload();
+#pragma unroll
+  for (int s = 0; s < 4; ++s) tload(0, s);
+
+  sc_f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[ct][v] = 0.f;
+  cf32 tacc = cf_make(0.f, 0.f);
+  int c = 0;
+  int64_t l0 = tile0 * LB;
+  const int fmax = TAIL ? 2 * J - 2 : 2 * J;
+#pragma unroll 1
+  for (int g = 0; g < total; ++g) {
+    SC_SYNC();                                   // the previous chunk has been read (g = 0: the tail column is in)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) datf[(16 * (m >> 1) + lr0 + (m & 1)) * (4 * S4) + col] = r[m];
+    SC_SYNC();
+    if (g + 1 < total) gload();
+    const int cn = (c + 1 == NC) ? 0 : c + 1;
+    const sc_f4* arow = dat + (32 * w + col) * S4 + half;
+    const sc_f4* trow = tailL + (32 * c + 4 * half) / 2;
+    sc_f4 a = arow[0];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sc_f4 an = a, tw0, tw1;
+      if (s < 3) an = arow[2 * (s + 1)];
+      if (TAIL) {
+        tw0 = trow[4 * s];
+        tw1 = trow[4 * s + 1];
+      }
+      SC_SCHED_BARRIER();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) MDFT_MFMA(acc[ct], sc_f4_at(a, q), sc_f4_at(tc[s][ct], q));
+      if (TAIL) {
+        tacc.x = fmaf(a.x, tw0.x, tacc.x); tacc.y = fmaf(a.x, tw0.y, tacc.y);
+        tacc.x = fmaf(a.y, tw0.z, tacc.x); tacc.y = fmaf(a.y, tw0.w, tacc.y);
+        tacc.x = fmaf(a.z, tw1.x, tacc.x); tacc.y = fmaf(a.z, tw1.y, tacc.y);
+        tacc.x = fmaf(a.w, tw1.z, tacc.x); tacc.y = fmaf(a.w, tw1.w, tacc.y);
+      }
+      SC_SCHED_BARRIER();
+      tload(cn, s);
+      a = an;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) SC_PIN_ACC(acc[ct]);
+    if (++c == NC) {                             // tile finished: store its 32 x (2J) results per wave
+      const int64_t lw = l0 + 32 * w + sc_opaque(0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int f = 32 * ct + col;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int64_t line = lw + mdft_row(v, half);
+          if (f < fmax && line < lines && MDFT_STORE_OK(acc[ct][v])) out[line * 2 * J + f] = acc[ct][v];
+          acc[ct][v] = 0.f;
+        }
+      }
+      if (TAIL) {
+        if (half == 1) tsum[32 * w + col] = tacc;
+        SC_WAVE_SYNC();
+        if (half == 0) {
+          const int64_t line = lw + col;
+          if (line < lines) reinterpret_cast<cf32*>(out)[line * J + (J - 1)] = cf_add(tacc, tsum[32 * w + col]);
+        }
+        tacc = cf_make(0.f, 0.f);
+      }
+      c = 0;
+      l0 += LB;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// last axis, complex -> real for ANY width with the table in global memory (round 4; k_mdft_c2r_lds below needs its
+// whole table in LDS -- 64 KB at 421 x 17 -- and N % 4 == 0).  What k_mdft_c2r costs on a 16 x 32 x 421^2 tensor
+// (363 MB written, 29 MB read; profiles/r04_mdft_odd_ablation.txt): 247 us, 153 us of it with the MFMAs AND the stores
+// taken out -- the "lane = line" spectrum loads (64 different 128-byte lines per instruction, first touch from HBM, the
+// same rows again for every group of 8 column tiles) and a one-step table prefetch are the bill, not the 363 MB.
+// Here a 256-thread block owns 128 consecutive lines x a range of column tiles: the tile's spectrum (128 x J cf32,
+// one contiguous span) comes in ONCE with coalesced 8-byte loads and is parked in LDS (rows of S floats, S / 2 odd:
+// conflict-free operand reads), every lane then keeps its line's 2 JS2 operand pairs in registers for all its column
+// tiles, and the loop over column tiles only streams the table: JS2 float4 per lane and tile, lane-major, each slot
+// re-requested for the next tile as soon as its MFMAs have read it (all blocks read the same table: L2).
+//   tab [((nt * JS2 + p) * 64 + lane) * 4 + e] : step t = 2p + (e >> 1) of column tile nt, component e & 1
+//        (0 multiplies Re in[l][2t + (lane >> 5)], 1 Im), zero for 2t + (lane >> 5) >= J or 32 nt + lane % 32 >= N
+// The bias is looked up per line (biasL: lines of one tile may belong to two images when heights are odd).
+// Grid: x = tile, y = range of column tiles [y * nt_per, (y + 1) * nt_per): enough blocks to fill the chip several
+// times over when there are few tiles.  Dynamic LDS: 128 * S floats.
+// ------------------------------------------------------------------------------------------
+template <int JS2>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (JS2 <= 5 ? 4 : 3))
+k_mdft_c2r_stage(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
+                 const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
+                 int64_t lines_per_image, int64_t channels, int nt_per) {
+  constexpr int LB = SC_MDFT_LB;
+  SC_DYN_SHARED(float, tileL);
+  SC_SHARED float biasL[LB];
+  const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int64_t l0 = (int64_t)SC_BID_X * LB;
+  const int nt_lo = (int)SC_BID_Y * nt_per;
+  const int nt_hi = (nt_lo + nt_per < n_nt) ? nt_lo + nt_per : n_nt;
+  if (l0 >= lines || nt_lo >= n_nt) return;
+  const int64_t rem = lines - l0;
+  const int rows = (int)(rem < LB ? rem : LB);
+  {
+    // element tid, tid + 256, ... of the tile's span (128 J <= 256 * 2 JS2 of them): all requested, then parked;
+    // (line, j) advance by (256 / J, 256 % J)
+    const int E = rows * J, dq = 256 / J, dr = 256 - dq * J;
+    const cf32* src = in + l0 * J;
+    cf32 pre[2 * JS2];
+#pragma unroll
+    for (int u = 0; u < 2 * JS2; ++u) {
+      const int i = tid + 256 * u;
+      pre[u] = src[i < E ? i : E - 1];                        // (plain: the other column ranges of this tile read it from L2)
+    }
+    int line = tid / J, j = tid - line * J;
+    cf32* datc = reinterpret_cast<cf32*>(tileL);
+    const int SC2 = S / 2;
+#pragma unroll
+    for (int u = 0; u < 2 * JS2; ++u) {
+      if (tid + 256 * u < E) datc[line * SC2 + j] = pre[u];
+      j += dr;
+      line += dq;
+      if (j >= J) {
+        j -= J;
+        ++line;
+      }
+    }
+    if (tid < LB) {
+      const int64_t line_g = l0 + (tid < rows ? tid : rows - 1);
+      biasL[tid] = (bias != nullptr) ? bias[(line_g / lines_per_image) % channels] : 0.f;
+    }
+  }
+  SC_SYNC();
+  // this lane's operands: in[line][2t + half], t < 2 JS2 (zero past J -- the table is zero there too, but the LDS is not)
+  cf32 a[2 * JS2];
+  {
+    const int row = 32 * w + col;
+    const cf32* arow = reinterpret_cast<const cf32*>(tileL) + (row < rows ? row : rows - 1) * (S / 2);
+#pragma unroll
+    for (int t = 0; t < 2 * JS2; ++t) {
+      const int j = 2 * t + half;
+      const cf32 v = arow[j < J ? j : J - 1];
+      a[t] = j < J ? v : cf_make(0.f, 0.f);
+    }
+  }
+  const sc_f4* t4 = reinterpret_cast<const sc_f4*>(tab);
+  sc_f4 tb[JS2];
+#pragma unroll
+  for (int p = 0; p < JS2; ++p) tb[p] = t4[(nt_lo * JS2 + p) * 64 + lane];
+  const int64_t lw = l0 + 32 * w;                            // (rows of a ragged last tile: guarded at the store)
+#pragma unroll 1
+  for (int nt = nt_lo; nt < nt_hi; ++nt) {
+    sc_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    const int ntn = (nt + 1 < nt_hi) ? nt + 1 : nt;
+#pragma unroll
+    for (int p = 0; p < JS2; ++p) {
+      MDFT_MFMA(acc, a[2 * p].x, tb[p].x);
+      MDFT_MFMA(acc, a[2 * p].y, tb[p].y);
+      MDFT_MFMA(acc, a[2 * p + 1].x, tb[p].z);
+      MDFT_MFMA(acc, a[2 * p + 1].y, tb[p].w);
+      SC_SCHED_BARRIER();
+      tb[p] = t4[(ntn * JS2 + p) * 64 + lane];
+    }
+    SC_PIN_ACC(acc);
+    // stores: a wave-uniform pointer to the wave's 32 rows + a 32-bit byte offset per lane (sixteen 64-bit row
+    // addresses would be hoisted out of the loop and spilled)
+    const int n = 32 * nt + col;
+    char* obase = reinterpret_cast<char*>(out + lw * N);
+    const uint32_t so0 = (uint32_t)((4 * half * N + n) * 4);
+    const int n4 = sc_opaque_s(4 * N);
+    const int rleft = rows - 32 * w - 4 * half;              // rows of this wave's tile that exist, from row 4 half on
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int rv = (v & 3) + 8 * (v >> 2);                  // mdft_row(v, half) = rv + 4 half
+      if (rv < rleft && n < N && MDFT_STORE_OK(acc[v])) {
+        float* dst = reinterpret_cast<float*>(obase + so0 + (uint32_t)(rv * n4));
+        // plain, not streaming: a store instruction covers 128 bytes of two rows that are not line-aligned; the rest
+        // of each line arrives with the next column tile, and L2 merges the halves only if the first was not sent
+        // on as a partial write (421 x 17: 191 us plain, 283 us non-temporal)
+#ifdef SC_STAGE_NT_STORE
+        SC_STORE_STREAM(dst, acc[v] + biasL[32 * w + 4 * half + rv]);
+#else
+        *dst = acc[v] + biasL[32 * w + 4 * half + rv];
+#endif
+      }
+    }
   }
 }
 

@@ -5,6 +5,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuraloperator_amd import _lib
 libs = sys.argv[1:] or [_lib.DEFAULT_LIB]
+# MDFT_CASES="N,J,lines;N,J,lines": other line lengths (e.g. 421,17,215552 = one 16 x 32 x 421^2 tensor)
+CASES = [tuple(int(v) for v in c.split(",")) for c in os.environ.get("MDFT_CASES", "").split(";") if c] or \
+    [(128, 17, 8 * 32 * 128 * 128), (1024, 129, 4 * 128 * 1024)]
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 
@@ -24,7 +27,7 @@ def timed(fn, n=6):
 for path in libs:
     lib = _lib.ScEngineLib(path)
     row = [os.path.basename(path)]
-    for (N, J, lines) in [(128, 17, 8 * 32 * 128 * 128), (1024, 129, 4 * 128 * 1024)]:
+    for (N, J, lines) in CASES:
         plan = lib.plan_create([N], [J])
         x = torch.randn(lines, N, device=dev); y = torch.empty_like(x)
         xh = torch.randn(lines, J, 2, device=dev)

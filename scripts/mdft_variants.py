@@ -11,7 +11,12 @@ VARIANTS = {
     "nostore": ["SC_MDFT_ABL_NOSTORE"],
     "nomfma": ["SC_MDFT_ABL_NOMFMA"],
     "nomfma_nostore": ["SC_MDFT_ABL_NOMFMA", "SC_MDFT_ABL_NOSTORE"],
+    "plainstore": ["SC_MDFT_PLAIN_STORE"],
+    "stagent": ["SC_STAGE_NT_LOAD", "SC_STAGE_NT_STORE"],   # k_mdft_*_stage: non-temporal tile loads / stores
+    "nostage": ["SC_MDFT_NOSTAGE"],
 }
+if len(sys.argv) > 1:
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1:]}
 out_dir = os.path.join(ROOT, "scripts", "abl")
 os.makedirs(out_dir, exist_ok=True)
 with ThreadPoolExecutor(4) as ex:

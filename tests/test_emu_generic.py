@@ -144,7 +144,7 @@ def test_emu_library_exports_and_errors(lib):
 def test_mdft_tail_column_matches_oracle(lib, width):
     """last axis keeps 2^k + 1 columns (J = 17): the matrix-core pass does 16 columns as one MFMA tile
     and the 17th as a VALU dot product.  Width 64 takes the LDS-staged kernel (k_mdft_r2c_lds<.., TAIL>),
-    48 and 40 (not multiples of 32) the straight-from-global one (k_mdft_r2c<.., TAIL>)."""
+    48 and 40 (not multiples of 32) the LDS-staged one with its table in global memory (k_mdft_r2c_stage<.., TAIL>)."""
     from oracle import spectral_oracle as so
     from neuraloperator_amd.modes import halve_last_mode
     torch.manual_seed(5)
@@ -159,7 +159,7 @@ def test_mdft_tail_column_matches_oracle(lib, width):
     yo = so.forward_torch(xc, wc, bc, nm, nm)
     yo.backward(g)
     plan = lib.plan_create(list(spatial), list(nm))
-    assert lib.plan_kernel_name(plan, 0) == ("k_mdft_r2c_lds" if width % 32 == 0 else "k_mdft_r2c")
+    assert lib.plan_kernel_name(plan, 0) == ("k_mdft_r2c_lds" if width % 32 == 0 else "k_mdft_r2c_stage")
     assert lib.plan_kernel_name(plan, 1) == "k_mdft_c2r_lds"
     lib.plan_destroy(plan)
     y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
@@ -167,6 +167,49 @@ def test_mdft_tail_column_matches_oracle(lib, width):
     assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
     assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("spatial,modes,b,kern", [
+    ((21, 85), (8, 32), 2, "k_mdft_r2c_stage"), ((13, 141), (6, 64), 1, "k_mdft_r2c_stage"),
+    ((45, 53), (12, 16), 3, "k_mdft_r2c_stage"), ((37, 421), (10, 32), 1, "k_mdft_r2c_stage"),
+    ((5, 7, 43), (4, 4, 10), 2, "k_mdft_r2c_stage"), ((150, 85), (8, 32), 1, "k_mdft_r2c_stage"),
+    ((13, 141), (6, 80), 2, "k_mdft_r2c"), ((9, 211), (4, 140), 1, "k_mdft_r2c"),
+    # few columns under a long first axis: the four waves of a block split its rows (k_mdft_axis<.., KS>)
+    ((70, 9), (8, 4), 2, "k_mdft_r2c_stage"), ((131, 13), (40, 6), 1, "k_mdft_r2c_stage")],
+    ids=["21x85_tail", "13x141_m64_tail", "45x53", "37x421_tail", "5x7x43", "150x85_two_tiles", "13x141_m80", "9x211_m140",
+         "70x9_ksplit", "131x13_ksplit_4jt"])
+def test_mdft_ragged_width_matches_oracle(lib, spatial, modes, b, kern):
+    """widths that are not a multiple of 8 (the reference's Darcy grids: 85 / 141 / 211 / 421) on the matrix cores:
+    k_mdft_r2c_stage brings 128-line tiles through LDS with row-wise 4-byte loads (<= 2 column tiles of kept modes),
+    k_mdft_r2c<.., RAGGED> (more kept modes) pads the last group of 8 points with zeros; k_mdft_c2r_stage parks a
+    128-line tile of the spectrum in LDS and streams the table (<= 36 kept columns), k_mdft_c2r (more) looks the bias
+    up per row when an image's line count (here odd) is not a multiple of a wave's 32 RT lines."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+    torch.manual_seed(7)
+    nm = halve_last_mode(modes)
+    nd = len(spatial)
+    x = torch.randn(b, 3, *spatial)
+    w = torch.empty(3, 2, *nm, dtype=torch.cfloat).normal_(0, 0.5)
+    bias = torch.randn(2, *([1] * nd))
+    g = torch.randn(b, 2, *spatial)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    plan = lib.plan_create(list(spatial), list(nm))
+    assert lib.plan_kernel_name(plan, 0) == kern
+    assert lib.plan_kernel_name(plan, 1) == kern.replace("r2c", "c2r")
+    lib.plan_destroy(plan)
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
+    assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
+    assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
+    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+    # an odd storage offset (4-byte aligned view): same kernels, same numbers
+    buf = torch.zeros(x.numel() + 1)
+    xo = buf[1:].view_as(x).copy_(x)
+    y2, _, _, _, _ = layer_fwd_bwd(lib, xo, w, bias, g, nm, nm, flags=0)
+    assert torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("case", [((128, 128), (32, 32), 2, 2, 3), ((128, 64), (40, 16), 1, 3, 2),

@@ -55,6 +55,13 @@ ORACLE_CASES = [
     (32, 64, 64, (32, 32), (12, 12), (16, 16)),     # ... through the sub-block index tables
     (8, 32, 32, (32, 32, 32), (16, 16, 16), None),  # small batch: gX-hat streams with clamped rows, backward pair launch
     (12, 32, 48, (64, 64), (32, 30), None),         # ... 12 rows, ragged second column tile (kept 32 x 16)
+    # round 4: the reference's Darcy grids (85 / 141 / 211 / 421 points, not multiples of 8) on the matrix cores
+    # (k_mdft_r2c<.., RAGGED>, per-row bias lookup in k_mdft_c2r: image heights are odd)
+    (2, 4, 4, (85, 85), (32, 32), None),
+    (2, 3, 5, (141, 141), (64, 64), None),
+    (1, 4, 4, (211, 211), (32, 32), None),
+    (1, 2, 3, (421, 421), (32, 32), None),
+    (2, 3, 3, (9, 11, 43), (4, 6, 16), None),
     # round 3: two-pass factorised route for lines of 32 P points, P in {2, 3, 4, 5, 6, 8, 10, 12, 20}
     (2, 8, 8, (64, 64), (32, 32), None),            # P = 2
     (2, 4, 6, (96, 96), (24, 24), None),            # P = 3
