@@ -778,7 +778,10 @@ def main():
         todo = [("fno3d_single", "replicas", "fno3d_128_m32_c32_b8", f32, None),          # configs[3], one GPU
                 ("tfno_rank01", "replicas", args.workload, f32, tucker),                  # configs[2]
                 ("fno2d_1024_b4", "replicas", "fno2d_1024_m256_c128_b4", f32, None),      # configs[4]
-                ("bf16_io", "replicas", args.workload, bf16, None)] if world == 1 else \
+                ("bf16_io", "replicas", args.workload, bf16, None),
+                # the reference's full-resolution Darcy grid (421 points: no power-of-two / 32 P route applies; the
+                # any-width matrix-core passes of round 4, profiles/r04_odd_sizes.txt)
+                ("darcy_421", "replicas", "darcy_421_m32_c32_b16", f32, None)] if world == 1 else \
             [("dp_allreduce", "replicas", args.workload, f32, None),
              ("fno3d_modeshard", "modeshard", "fno3d_128_m32_c32_b8", f32, None)]
         for name, par_x, wl, io_x, kw_x in todo:
