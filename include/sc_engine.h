@@ -82,6 +82,8 @@ enum {
                                 direct-DFT passes instead of the two-pass factorised route (round 3; A-B)  */
   SC_PLAN_F2P_SMALL_ALWAYS = 64, /* take the two-pass route for supported grids below 128 x 128 points too (A-B, tests:
                                 by default those stay on the one-launch direct-DFT plane passes, which are faster there) */
+  SC_PLAN_NO_SPAN = 128,     /* complex -> real last-axis pass of widths off every factorised route: the 128-line chunked
+                                kernel (k_mdft_c2r_stage) instead of the 32-line whole-span one (k_mdft_c2r_span; A-B, tests) */
   SC_PLAN_IO_BF16 = 16       /* the REAL tensors (x, y, gy, gx) are bfloat16 in memory -- the `float*`
                                 arguments that carry them then point at 2-byte elements; spectra,
                                 weights, bias and every arithmetic step stay float32 and y / gx are

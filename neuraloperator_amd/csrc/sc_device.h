@@ -27,6 +27,9 @@
 #define SC_BID_Y ((int)blockIdx.y)
 #define SC_BID_Z ((int)blockIdx.z)
 #define SC_LAUNCH_BOUNDS(n) __launch_bounds__(n)
+// a lambda that is called from several places and must still be folded into its caller (by-reference captures of
+// register arrays become scratch memory otherwise)
+#define SC_ALWAYS_INLINE_LAMBDA __attribute__((always_inline))
 // second argument = minimum waves per SIMD the register allocator must leave room for
 #define SC_LAUNCH_BOUNDS_OCC(n, w) __launch_bounds__(n, w)
 // exchange through LDS between lanes of ONE wave: no s_barrier needed (a wave's DS operations
@@ -224,6 +227,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, void (*fn)(void*), void* arg);
 #define SC_BID_Y (scemu::g_ctx.by)
 #define SC_BID_Z (scemu::g_ctx.bz)
 #define SC_LAUNCH_BOUNDS(n)
+#define SC_ALWAYS_INLINE_LAMBDA
 #define SC_LAUNCH_BOUNDS_OCC(n, w)
 #define SC_WAVE_SYNC() scemu::wave_barrier()   /* emulated lanes are free-running threads */
 #define SC_UNIFORM(x) (x)

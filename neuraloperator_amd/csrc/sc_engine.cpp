@@ -1259,12 +1259,37 @@ static void launch_mdft_c2r_stage(const sc_plan* p, int mode, const cf32* in, fl
   // ranges of column tiles per 128-line tile: ~6 blocks per resident slot (4 per CU), so that the last round of
   // blocks is a small share of the launch; every range re-reads the tile's spectrum (8 % of the bytes, from L2)
   int64_t splits = ((int64_t)24 * sc_cu_count() + n_tiles - 1) / n_tiles;
+  static const int split_env = [] {                          // A-B only (scripts/mdft_time.py)
+    const char* e = getenv("SC_C2R_STAGE_SPLITS");
+    return e ? atoi(e) : 0;
+  }();
+  if (split_env > 0) splits = split_env;
   if (splits < 1) splits = 1;
   if (splits > n_nt) splits = n_nt;
   const int nt_per = (int)((n_nt + splits - 1) / splits);
   const unsigned gy = (unsigned)((n_nt + nt_per - 1) / nt_per);
   SC_LAUNCH((k_mdft_c2r_stage<JS2>), dim3((unsigned)n_tiles, gy), dim3(256), (size_t)SC_MDFT_LB * p->s_c2r_s * sizeof(float),
             st, in, out, (const float*)p->s_c2r[mode], bias, lines, N, J, n_nt, p->s_c2r_s, lpi, channels, nt_per);
+}
+
+// whole-line form of the same pass: one block per 32 lines, their N-line span staged in LDS (k_mdft_c2r_span)
+static bool c2r_span_ok(const sc_plan* p, int N, const float* out, int64_t lines) {
+  static const bool off = getenv("SC_C2R_NOSPAN") != nullptr;             // A-B against k_mdft_c2r_stage
+  return !off && !(p->d.flags & SC_PLAN_NO_SPAN) && sc_io_aligned(out) && (size_t)32 * (N + p->s_c2r_s) * sizeof(float) + 16 <= (size_t)80 * 1024 &&
+         (lines + 31) / 32 < ((int64_t)1 << 31);
+}
+template <int JS2>
+static int launch_mdft_c2r_span(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
+                                int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
+  const size_t lds = (size_t)32 * (N + p->s_c2r_s) * sizeof(float) + 16;
+#ifndef SC_EMU
+  if (lds > 64 * 1024)
+    SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdft_c2r_span<JS2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+  SC_LAUNCH((k_mdft_c2r_span<JS2>), dim3((unsigned)((lines + 31) / 32)), dim3(256), lds, st, in, out,
+            (const float*)p->s_c2r[mode], bias, lines, N, J, (N + 31) / 32, p->s_c2r_s, lpi, channels);
+  return sc_check_launch("k_mdft_c2r_span");
 }
 
 // (planes x K1 x J complex) -> y (planes x 128 x N real): second-to-last axis + last axis (+ bias)
@@ -1312,6 +1337,11 @@ static int run_c2r(const sc_plan* p, int mode, const cf32* in, float* out, const
     return sc_check_launch("k_mdft_c2r_lds");
   }
   if (p->mdft && p->s_c2r[mode] && lines < ((int64_t)1 << 36) && (lines + SC_MDFT_LB - 1) / SC_MDFT_LB < ((int64_t)1 << 31)) {
+    if (c2r_span_ok(p, N, out, lines)) {
+      if (p->s_c2r_js2 == 3) return launch_mdft_c2r_span<3>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+      if (p->s_c2r_js2 == 5) return launch_mdft_c2r_span<5>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+      return launch_mdft_c2r_span<9>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
+    }
     if (p->s_c2r_js2 == 3) launch_mdft_c2r_stage<3>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
     else if (p->s_c2r_js2 == 5) launch_mdft_c2r_stage<5>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
     else launch_mdft_c2r_stage<9>(p, mode, in, out, bias, lines, N, J, lpi, channels, st);
@@ -3230,9 +3260,12 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   if (p->mdft) {
     if (which == 0 && plane_fwd_ok(p, 0)) return "k_mdft_r2c_lds<plane>";
     if (which == 1 && plane_inv_ok(p, 0)) return "k_mdft_c2r_lds<plane>";
+    const int Nl = (int)p->n[p->nd - 1];                      // (16-byte aligned tensors assumed, lines = 1)
     if (which == 0)
-      return p->l_r2c[0] ? "k_mdft_r2c_lds" : (p->s_r2c[0] ? "k_mdft_r2c_stage" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c"));
-    return p->l_c2r[0] ? "k_mdft_c2r_lds" : (p->s_c2r[0] ? "k_mdft_c2r_stage" : "k_mdft_c2r");
+      return p->l_r2c[0] ? "k_mdft_r2c_lds"
+                         : (p->s_r2c[0] ? "k_mdft_r2c_stage" : (p->m_r2c[0] ? "k_mdft_r2c" : "k_last_r2c"));
+    return p->l_c2r[0] ? "k_mdft_c2r_lds"
+                       : (p->s_c2r[0] ? (c2r_span_ok(p, Nl, nullptr, 1) ? "k_mdft_c2r_span" : "k_mdft_c2r_stage") : "k_mdft_c2r");
   }
   return which == 0 ? "k_last_r2c" : "k_last_c2r";
 }

@@ -705,6 +705,9 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 //   tab  [((ct * NG + t) * 64 + lane) * 4 + q] = T[8t + 4(lane>>5) + q][32 ct + (lane & 31)],  NG = 4 ceil(N / 32)
 //   tail [n] = T[n][J - 1], n < 32 ceil(N / 32) <= 1024 (kept in LDS)
 // ------------------------------------------------------------------------------------------
+// (Two chunks requested ahead -- 32 registers per thread, raw barriers so that the younger request is not drained --
+// was tried: it needs the 168-register budget, i.e. three blocks per CU instead of four, and still spills 64 registers
+// per chunk; with two blocks per CU the bytes in flight are back where they were.  Not kept.)
 template <int CT, bool TAIL>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 1 ? 4 : 3))
 k_mdft_r2c_stage(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
@@ -845,6 +848,13 @@ k_mdft_r2c_stage(const float* __restrict__ in, float* __restrict__ out, const fl
   }
 }
 
+// (Measured and removed, round 4: the mirror image of k_mdft_c2r_span for this direction -- one block per 32 lines, their
+// N-line span copied into LDS by LDS-DMA (16 bytes per lane, every piece requested before the first wait), the four
+// waves splitting the SAMPLES and meeting in LDS.  Bit-identical in emulation and on the device, and slower everywhere:
+// 145 vs 112 us at 421 x 17 (back to back and inside the layer step alike), 48 vs 33 us at 141, 23 vs 15 us at 85 --
+// a block cannot overlap its one big load with its own multiplies, operands come out of LDS 4 bytes at a time, and one
+// wave of four does the reduction.  profiles/r04_mdft_odd_ablation.txt (d).)
+
 // ------------------------------------------------------------------------------------------
 // last axis, complex -> real for ANY width with the table in global memory (round 4; k_mdft_c2r_lds below needs its
 // whole table in LDS -- 64 KB at 421 x 17 -- and N % 4 == 0).  What k_mdft_c2r costs on a 16 x 32 x 421^2 tensor
@@ -964,6 +974,126 @@ k_mdft_c2r_stage(const cf32* __restrict__ in, float* __restrict__ out, const flo
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// last axis, complex -> real, ANY width, whole-line stores (round 4, second step).  k_mdft_c2r_stage above is bound by
+// its stores: a store instruction of an MFMA result tile writes 128-byte pieces of two rows, and rows of an odd width
+// are not line-aligned -- every line is written in two partial pieces one column tile apart (2.3 TB/s).  But 32
+// consecutive lines of N floats are ONE span of exactly N 128-byte lines, and it starts line-aligned (32 N x 4 bytes
+// per 32 lines).  Here a 256-thread block owns 32 lines: its four waves share the 32 x J spectrum rows (operands in
+// registers, as above) and split the column tiles (nt = w, w + 4, ...), results + bias go to an LDS image of the span
+// (row stride N, as in memory), and after one barrier the block writes the span with aligned, fully coalesced
+// 16-byte streaming stores, each line whole.  Blocks do not wait for their stores: the next block of the CU (two are
+// resident at N = 421: 54 + 4 KB of LDS each) is already multiplying.
+//   tab: the layout of k_mdft_c2r_stage.  Dynamic LDS: 32 S floats (spectrum rows) + 32 N floats (+ pad to 16 bytes).
+// Host: N <= SC_C2R_SPAN_NMAX (LDS), `out` 16-byte aligned; otherwise k_mdft_c2r_stage.
+// ------------------------------------------------------------------------------------------
+template <int JS2>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+k_mdft_c2r_span(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
+                const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
+                int64_t lines_per_image, int64_t channels) {
+  constexpr int RB = 32;                                     // lines per block = one MFMA row tile
+  SC_DYN_SHARED(float, ldsf);
+  SC_SHARED float biasL[RB];
+  float* tileL = ldsf;                                       // [RB][S]
+  float* span = ldsf + RB * S;                               // [RB][N], 16-byte aligned (RB * S * 4 = 128 S bytes)
+  const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int64_t l0 = (int64_t)SC_BID_X * RB;
+  if (l0 >= lines) return;
+  const int64_t rem = lines - l0;
+  const int rows = (int)(rem < RB ? rem : RB);
+  {
+    // element tid, tid + 256, ... of the block's spectrum rows (32 J <= 256 * UM of them): all requested, then parked
+    constexpr int UM = (4 * JS2 + 7) / 8;
+    const int E = rows * J, dq = 256 / J, dr = 256 - dq * J;
+    const cf32* src = in + l0 * J;
+    cf32 pre[UM];
+#pragma unroll
+    for (int u = 0; u < UM; ++u) {
+      const int i = tid + 256 * u;
+      pre[u] = src[i < E ? i : E - 1];
+    }
+    int line = tid / J, j = tid - line * J;
+    cf32* datc = reinterpret_cast<cf32*>(tileL);
+    const int SC2 = S / 2;
+#pragma unroll
+    for (int u = 0; u < UM; ++u) {
+      if (tid + 256 * u < E) datc[line * SC2 + j] = pre[u];
+      j += dr;
+      line += dq;
+      if (j >= J) {
+        j -= J;
+        ++line;
+      }
+    }
+    if (tid < RB) {
+      const int64_t line_g = l0 + (tid < rows ? tid : rows - 1);
+      biasL[tid] = (bias != nullptr) ? bias[(line_g / lines_per_image) % channels] : 0.f;
+    }
+  }
+  SC_SYNC();
+  // this lane's operands: in[line][2t + half], t < 2 JS2 (zero past J: the table is zero there too, but the LDS is not)
+  cf32 a[2 * JS2];
+  {
+    const cf32* arow = reinterpret_cast<const cf32*>(tileL) + (col < rows ? col : rows - 1) * (S / 2);
+#pragma unroll
+    for (int t = 0; t < 2 * JS2; ++t) {
+      const int j = 2 * t + half;
+      const cf32 v = arow[j < J ? j : J - 1];
+      a[t] = j < J ? v : cf_make(0.f, 0.f);
+    }
+  }
+  // (requesting the table two column tiles ahead, the first two before the spectrum rows, was measured: 147 vs 133 us
+  // at 421 x 17, 34 vs 31 us at 141 -- not kept)
+  const sc_f4* t4 = reinterpret_cast<const sc_f4*>(tab);
+  sc_f4 tb[JS2];
+  {
+    const int nt0 = w < n_nt ? w : n_nt - 1;
+#pragma unroll
+    for (int p = 0; p < JS2; ++p) tb[p] = t4[(nt0 * JS2 + p) * 64 + lane];
+  }
+  float bl[16];                                              // bias of this lane's 16 result rows
+#pragma unroll
+  for (int v = 0; v < 16; ++v) bl[v] = biasL[(v & 3) + 8 * (v >> 2) + 4 * half];
+#pragma unroll 1
+  for (int nt = w; nt < n_nt; nt += 4) {
+    sc_f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    const int ntn = (nt + 4 < n_nt) ? nt + 4 : nt;
+#pragma unroll
+    for (int p = 0; p < JS2; ++p) {
+      MDFT_MFMA(acc, a[2 * p].x, tb[p].x);
+      MDFT_MFMA(acc, a[2 * p].y, tb[p].y);
+      MDFT_MFMA(acc, a[2 * p + 1].x, tb[p].z);
+      MDFT_MFMA(acc, a[2 * p + 1].y, tb[p].w);
+      SC_SCHED_BARRIER();
+      tb[p] = t4[(ntn * JS2 + p) * 64 + lane];
+    }
+    SC_PIN_ACC(acc);
+    const int n = 32 * nt + col;
+    float* sp = span + 4 * half * N + n;
+    const int n1 = sc_opaque_s(N);                             // (row offsets added where they are used)
+    if (n < N) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sp[((v & 3) + 8 * (v >> 2)) * n1] = acc[v] + bl[v];
+    }
+  }
+  SC_SYNC();
+  // the span: rows x N floats from out + l0 N (line-aligned), 16 bytes per lane, each 128-byte line whole
+  const int total = rows * N, n4 = total >> 2;
+  float* dst = out + l0 * N;
+  const sc_f4* s4 = reinterpret_cast<const sc_f4*>(span);
+  sc_f4* d4 = reinterpret_cast<sc_f4*>(dst);
+  for (int i = tid; i < n4; i += 256) {
+    const sc_f4 o = s4[i];
+    if (MDFT_STORE_OK(o.x)) SC_STORE_STREAM(d4 + i, o);
+  }
+  const int done = n4 << 2;                                  // ragged last block: rows x N need not be a multiple of 4
+  if (tid < total - done) dst[done + tid] = span[done + tid];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -178,7 +178,8 @@ def test_mdft_tail_column_matches_oracle(lib, width):
     ((70, 9), (8, 4), 2, "k_mdft_r2c_stage"), ((131, 13), (40, 6), 1, "k_mdft_r2c_stage")],
     ids=["21x85_tail", "13x141_m64_tail", "45x53", "37x421_tail", "5x7x43", "150x85_two_tiles", "13x141_m80", "9x211_m140",
          "70x9_ksplit", "131x13_ksplit_4jt"])
-def test_mdft_ragged_width_matches_oracle(lib, spatial, modes, b, kern):
+@pytest.mark.parametrize("span", [True, False], ids=["span", "chunked"])
+def test_mdft_ragged_width_matches_oracle(lib, spatial, modes, b, kern, span):
     """widths that are not a multiple of 8 (the reference's Darcy grids: 85 / 141 / 211 / 421) on the matrix cores:
     k_mdft_r2c_stage brings 128-line tiles through LDS with row-wise 4-byte loads (<= 2 column tiles of kept modes),
     k_mdft_r2c<.., RAGGED> (more kept modes) pads the last group of 8 points with zeros; k_mdft_c2r_stage parks a
@@ -196,11 +197,14 @@ def test_mdft_ragged_width_matches_oracle(lib, spatial, modes, b, kern):
     xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     yo = so.forward_torch(xc, wc, bc, nm, nm)
     yo.backward(g)
-    plan = lib.plan_create(list(spatial), list(nm))
+    # span: the inverse pass in 32-line blocks whose N-line span is staged whole (k_mdft_c2r_span); chunked: SC_PLAN_NO_SPAN
+    flags = 0 if span else _lib.SC_PLAN_NO_SPAN
+    plan = lib.plan_create(list(spatial), list(nm), flags=flags)
     assert lib.plan_kernel_name(plan, 0) == kern
-    assert lib.plan_kernel_name(plan, 1) == kern.replace("r2c", "c2r")
+    k1 = kern.replace("r2c", "c2r")
+    assert lib.plan_kernel_name(plan, 1) == (k1.replace("_stage", "_span") if span else k1)
     lib.plan_destroy(plan)
-    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=0)
+    y, gx, gw, gb, _ = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=flags)
     assert rel_l2(y.numpy(), yo.detach().numpy()) < TOL
     assert rel_l2(gx.numpy(), xc.grad.numpy()) < TOL
     assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
@@ -208,8 +212,8 @@ def test_mdft_ragged_width_matches_oracle(lib, spatial, modes, b, kern):
     # an odd storage offset (4-byte aligned view): same kernels, same numbers
     buf = torch.zeros(x.numel() + 1)
     xo = buf[1:].view_as(x).copy_(x)
-    y2, _, _, _, _ = layer_fwd_bwd(lib, xo, w, bias, g, nm, nm, flags=0)
-    assert torch.equal(y2, y)
+    y2, _, _, _, _ = layer_fwd_bwd(lib, xo, w, bias, g, nm, nm, flags=flags)
+    assert rel_l2(y2.numpy(), yo.detach().numpy()) < TOL
 
 
 @pytest.mark.parametrize("case", [((128, 128), (32, 32), 2, 2, 3), ((128, 64), (40, 16), 1, 3, 2),
