@@ -140,7 +140,9 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
       SC_SCHED_BARRIER();
       multiply(a0, b0, w0);
       SC_SCHED_BARRIER();
-      if (t + 2 < NG) fetch(t + 2, a0, b0, w0);
+      // unconditional (the last trip re-requests the final step): a uniform branch around the loads makes hipcc wait
+      // for them at the join, i.e. every trip pays a full memory latency (seen in k_mdft_axis: vmcnt(0) per trip)
+      fetch(t + 2 < NG ? t + 2 : NG - 1, a0, b0, w0);
       SC_SCHED_BARRIER();
       multiply(a1, b1, w1);
       SC_SCHED_BARRIER();
@@ -195,7 +197,7 @@ k_mdft_r2c(const float* __restrict__ in, float* __restrict__ out, const float* _
 // 211 dependent load -> MFMA steps per wave with the chip three quarters empty (74 us for 29 MB).
 // ------------------------------------------------------------------------------------------
 template <int JT, int CT, bool KS = false>
-SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (KS ? 2 : 1))      // (KS: the reduction's loads all in flight took 320 registers)
 k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __restrict__ tab,
             int64_t outer, int N, int J, int64_t inner, int n_jt) {
   SC_SHARED float red[KS ? 3 * JT * CT * 1024 : 1];
@@ -261,7 +263,7 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
       SC_SCHED_BARRIER();
       multiply(d0, a0);
       SC_SCHED_BARRIER();
-      if (s + 2 < s_hi) fetch(s + 2, d0, a0);
+      fetch(s + 2 < s_hi ? s + 2 : s_hi - 1, d0, a0);          // unconditional: see k_mdft_r2c
       SC_SCHED_BARRIER();
       multiply(d1, a1);
       SC_SCHED_BARRIER();
@@ -373,7 +375,7 @@ k_mdft_c2r(const cf32* __restrict__ in, float* __restrict__ out, const float* __
       SC_SCHED_BARRIER();
       multiply(d0, b0);
       SC_SCHED_BARRIER();
-      if (t + 2 < JS) fetch(t + 2, d0, b0);
+      fetch(t + 2 < JS ? t + 2 : JS - 1, d0, b0);              // unconditional: see k_mdft_r2c
       SC_SCHED_BARRIER();
       multiply(d1, b1);
       SC_SCHED_BARRIER();

@@ -20,7 +20,8 @@ JOBS = [("fno2d_256_m64_c64_b32", "fno2d_256_m64_c64_b32", "f32", "dense"),
         ("fno2d_256_m64_c64_b32_bf16io", "fno2d_256_m64_c64_b32", "bf16", "dense"),
         ("fno2d_256_m64_c64_b32_tucker01", "fno2d_256_m64_c64_b32", "f32", "tucker"),
         ("fno3d_128_m32_c32_b8", "fno3d_128_m32_c32_b8", "f32", "dense"),
-        ("fno2d_1024_m256_c128_b4", "fno2d_1024_m256_c128_b4", "f32", "dense")]
+        ("fno2d_1024_m256_c128_b4", "fno2d_1024_m256_c128_b4", "f32", "dense"),
+        ("darcy_421_m32_c32_b16", "darcy_421_m32_c32_b16", "f32", "dense")]
 out = {}
 for key, wl, io, kind in JOBS:
     got, note = bench.measure_step_traffic(bench.WORKLOADS[wl], io=io, kind=kind, timeout_s=240)

@@ -14,6 +14,13 @@ for wl in tucker:32,64,256,256,64,64 dense:8,32,128,128,128,32,32,32 dense:4,128
   (cd /tmp && rm -rf /tmp/prof_$n && LAYER_KIND=$k LAYER_SHAPE=$s LAYER_REPS=6 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
   python scripts/rocprof_summary.py /tmp/prof_$n > $O/kernel_stats_${k}_$n.txt 2>&1
 done
+# sizes off the factorised routes (Darcy grids, resolution changes) beside the reference chain, and their kernel stats
+timeout 600 python scripts/odd_sizes_time.py 2>&1 | grep -v amdgpu.ids > $O/odd_sizes.txt
+for s in 16,32,421,421,32,32 32,32,141,141,32,32 16,32,421,421,64,64 32,32,85,85,32,32; do
+  n=$(echo $s | tr ',' '_')
+  (cd /tmp && rm -rf /tmp/prof_$n && LAYER_KIND=dense LAYER_SHAPE=$s LAYER_REPS=6 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
+  echo "== $s" >> $O/odd_stats.txt; python scripts/rocprof_summary.py /tmp/prof_$n | head -10 | cut -c1-150 >> $O/odd_stats.txt
+done
 timeout 1200 python scripts/pmc_traffic_regen.py $O/pmc_traffic.json > $O/pmc_regen.log 2>&1
 (cd /tmp && LAYER_REPS=3 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_s -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
 python scripts/pmc_summary.py /tmp/pmc_s > $O/pmc_sq_raw.txt 2>&1
