@@ -1273,15 +1273,18 @@ static void launch_mdft_c2r_stage(const sc_plan* p, int mode, const cf32* in, fl
 }
 
 // whole-line form of the same pass: one block per 32 lines, their N-line span staged in LDS (k_mdft_c2r_span)
+static size_t c2r_span_lds(const sc_plan* p, int N) {         // spectrum rows and span image share the buffer
+  return (size_t)32 * (N > p->s_c2r_s ? N : p->s_c2r_s) * sizeof(float);
+}
 static bool c2r_span_ok(const sc_plan* p, int N, const float* out, int64_t lines) {
   static const bool off = getenv("SC_C2R_NOSPAN") != nullptr;             // A-B against k_mdft_c2r_stage
-  return !off && !(p->d.flags & SC_PLAN_NO_SPAN) && sc_io_aligned(out) && (size_t)32 * (N + p->s_c2r_s) * sizeof(float) + 16 <= (size_t)80 * 1024 &&
+  return !off && !(p->d.flags & SC_PLAN_NO_SPAN) && sc_io_aligned(out) && c2r_span_lds(p, N) <= (size_t)80 * 1024 &&
          (lines + 31) / 32 < ((int64_t)1 << 31);
 }
 template <int JS2>
 static int launch_mdft_c2r_span(const sc_plan* p, int mode, const cf32* in, float* out, const float* bias,
                                 int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
-  const size_t lds = (size_t)32 * (N + p->s_c2r_s) * sizeof(float) + 16;
+  const size_t lds = c2r_span_lds(p, N);
 #ifndef SC_EMU
   if (lds > 64 * 1024)
     SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdft_c2r_span<JS2>),

@@ -232,9 +232,14 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[j][c][v] = 0.f;
-    cf32 d0[CT], d1[CT];
-    float a0[JT][2], a1[JT][2];
-    auto fetch = [&](const int s, cf32 (&d)[CT], float (&a)[JT][2]) {
+    // a ring of four steps: step s + 3 is requested before step s is multiplied (one step ahead left every step
+    // waiting for L2 / HBM with few waves per SIMD: 39 of 74 us at 512 images x 33 columns were the loads alone).
+    // Every request is unconditional -- steps past the end re-read the last one and are multiplied by zero: a uniform
+    // branch around the loads makes hipcc wait for them at the join (vmcnt(0) per trip).
+    cf32 dd[4][CT];
+    float aa[4][JT][2];
+    auto fetch = [&](const int sq, cf32 (&d)[CT], float (&a)[JT][2]) {
+      const int s = sq < s_hi ? sq : s_hi - 1;
       int n = 2 * s + half;
       if (n >= N) n = N - 1;                                  // table entry is zero there
 #pragma unroll
@@ -246,33 +251,33 @@ k_mdft_axis(const cf32* __restrict__ in, cf32* __restrict__ out, const float* __
         a[j][1] = tab[(((int64_t)jt * NS + s) * 2 + 1) * 64 + lane];
       }
     };
-    auto multiply = [&](const cf32 (&d)[CT], const float (&a)[JT][2]) {
+    auto multiply = [&](const bool live, const cf32 (&d)[CT], const float (&a)[JT][2]) {
 #pragma unroll
       for (int j = 0; j < JT; ++j)
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          MDFT_MFMA(acc[j][c], a[j][0], d[c].x);
-          MDFT_MFMA(acc[j][c], a[j][1], d[c].y);
+          MDFT_MFMA(acc[j][c], a[j][0], live ? d[c].x : 0.f);
+          MDFT_MFMA(acc[j][c], a[j][1], live ? d[c].y : 0.f);
         }
     };
-    int s = s_lo;
-    if (s < s_hi) fetch(s, d0, a0);
+    if (s_lo < s_hi) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) fetch(s_lo + u, dd[u], aa[u]);
 #pragma unroll 1
-    for (; s + 1 < s_hi; s += 2) {
-      fetch(s + 1, d1, a1);
-      SC_SCHED_BARRIER();
-      multiply(d0, a0);
-      SC_SCHED_BARRIER();
-      fetch(s + 2 < s_hi ? s + 2 : s_hi - 1, d0, a0);          // unconditional: see k_mdft_r2c
-      SC_SCHED_BARRIER();
-      multiply(d1, a1);
-      SC_SCHED_BARRIER();
+      for (int s = s_lo; s < s_hi; s += 4) {
 #pragma unroll
-      for (int j = 0; j < JT; ++j)
+        for (int u = 0; u < 4; ++u) {
+          fetch(s + u + 3, dd[(u + 3) & 3], aa[(u + 3) & 3]);
+          SC_SCHED_BARRIER();
+          multiply(s + u < s_hi, dd[u], aa[u]);
+          SC_SCHED_BARRIER();
+        }
 #pragma unroll
-        for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[j][c]);
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) SC_PIN_ACC(acc[j][c]);
+      }
     }
-    if (s < s_hi) multiply(d0, a0);
     if (KS) {                                                  // partial sums of waves 1..3 -> wave 0
       if (w > 0) {
 #pragma unroll
@@ -986,9 +991,9 @@ k_mdft_c2r_stage(const cf32* __restrict__ in, float* __restrict__ out, const flo
 // per 32 lines).  Here a 256-thread block owns 32 lines: its four waves share the 32 x J spectrum rows (operands in
 // registers, as above) and split the column tiles (nt = w, w + 4, ...), results + bias go to an LDS image of the span
 // (row stride N, as in memory), and after one barrier the block writes the span with aligned, fully coalesced
-// 16-byte streaming stores, each line whole.  Blocks do not wait for their stores: the next block of the CU (two are
-// resident at N = 421: 54 + 4 KB of LDS each) is already multiplying.
-//   tab: the layout of k_mdft_c2r_stage.  Dynamic LDS: 32 S floats (spectrum rows) + 32 N floats (+ pad to 16 bytes).
+// 16-byte streaming stores, each line whole.  Three blocks are resident per CU at N = 421 (54 KB of LDS each): while
+// one drains its stores the others load and multiply.
+//   tab: the layout of k_mdft_c2r_stage.  Dynamic LDS: 32 max(N, S) floats (spectrum rows, then the span).
 // Host: N <= SC_C2R_SPAN_NMAX (LDS), `out` 16-byte aligned; otherwise k_mdft_c2r_stage.
 // ------------------------------------------------------------------------------------------
 template <int JS2>
@@ -999,8 +1004,11 @@ k_mdft_c2r_span(const cf32* __restrict__ in, float* __restrict__ out, const floa
   constexpr int RB = 32;                                     // lines per block = one MFMA row tile
   SC_DYN_SHARED(float, ldsf);
   SC_SHARED float biasL[RB];
-  float* tileL = ldsf;                                       // [RB][S]
-  float* span = ldsf + RB * S;                               // [RB][N], 16-byte aligned (RB * S * 4 = 128 S bytes)
+  // the spectrum rows [RB][S] and the span image [RB][N] share the buffer: the rows are dead once every lane holds its
+  // operands (one more barrier), and 54 KB instead of 58 KB is three blocks per CU instead of two at N = 421 -- a
+  // block's LDS is only released when its stores have drained, so the third block is what multiplies meanwhile
+  float* tileL = ldsf;
+  float* span = ldsf;
   const int tid = SC_TID, lane = tid & 63, half = lane >> 5, col = lane & 31;
   const int w = SC_UNIFORM(tid >> 6);
   const int64_t l0 = (int64_t)SC_BID_X * RB;
@@ -1060,6 +1068,7 @@ k_mdft_c2r_span(const cf32* __restrict__ in, float* __restrict__ out, const floa
   float bl[16];                                              // bias of this lane's 16 result rows
 #pragma unroll
   for (int v = 0; v < 16; ++v) bl[v] = biasL[(v & 3) + 8 * (v >> 2) + 4 * half];
+  SC_SYNC();                                                 // every wave has its operands: the buffer becomes the span
 #pragma unroll 1
   for (int nt = w; nt < n_nt; nt += 4) {
     sc_f32x16 acc;
