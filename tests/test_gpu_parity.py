@@ -187,6 +187,44 @@ def test_vs_oracle(lib, case, flags):
     assert rel_l2(gb.cpu().numpy(), bc.grad.numpy()) < TOL
 
 
+DARCY_CASES = [c for c in ORACLE_CASES if c[3] in ((85, 85), (141, 141), (211, 211), (421, 421), (9, 11, 43))]
+
+
+@pytest.mark.parametrize("case", DARCY_CASES, ids=lambda c: "x".join(map(str, c[3])) + f"_m{c[4][0]}")
+def test_odd_widths_chunked_inverse_vs_oracle(lib, case):
+    """SC_PLAN_NO_SPAN: the inverse last-axis pass of the odd grids through the 128-line chunked kernel
+    (k_mdft_c2r_stage) instead of the 32-line whole-span one -- the kernel that runs when a tensor is not 16-byte
+    aligned or its span does not fit LDS; and the same layer on a view with an odd storage offset."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd import _lib
+
+    b, ci, co, spatial, modes, _ = case
+    torch.manual_seed(4321)
+    nm = halve_last_mode(modes)
+    std = (2 / (ci + co)) ** 0.5
+    x = torch.randn(b, ci, *spatial)
+    w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, std)
+    bias = std * torch.randn(co, *(1,) * len(spatial))
+    g = torch.randn(b, co, *spatial)
+    xc, wc, bc = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo = so.forward_torch(xc, wc, bc, nm, nm)
+    yo.backward(g)
+    dev = torch.device("cuda:0")
+    plan = lib.plan_create(list(spatial), list(nm), flags=_lib.SC_PLAN_NO_SPAN)
+    assert lib.plan_kernel_name(plan, 1) == "k_mdft_c2r_stage"
+    lib.plan_destroy(plan)
+    xd = x.to(dev)
+    buf = torch.zeros(x.numel() + 1, device=dev)
+    x_odd = buf[1:].view_as(x).copy_(xd)                       # 4-byte aligned only
+    for xin, flags in ((xd, _lib.SC_PLAN_NO_SPAN), (x_odd, 0)):
+        y, gx, gw, gb, _ = layer_fwd_bwd(lib, xin, w.to(dev), bias.to(dev), g.to(dev), nm, nm, flags=flags)
+        assert rel_l2(y.cpu().numpy(), yo.detach().numpy()) < TOL
+        assert rel_l2(gx.cpu().numpy(), xc.grad.numpy()) < TOL
+        assert rel_l2(gw.cpu().numpy(), wc.grad.numpy()) < TOL
+        assert rel_l2(gb.cpu().numpy(), bc.grad.numpy()) < TOL
+
+
 @pytest.mark.parametrize("spatial,kept", [((64, 64), (32, 17)), ((96, 96), (24, 13)), ((192, 192), (64, 33)),
                                           ((384, 640), (48, 25)), ((256, 256), (128, 65)), ((160, 320), (20, 11))])
 def test_factorised_route_for_32p_lines(lib, spatial, kept):
