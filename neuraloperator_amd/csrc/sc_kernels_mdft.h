@@ -15,6 +15,13 @@
 //
 // replacing, like their VALU twins, the per-axis pieces of rfftn/ifftn/irfft restricted to the
 // kept modes (spectral_convolution.py:443-449, 500-519, 531-568).
+//
+// Later generations of the two last-axis passes, all in this file:
+//   k_mdft_r2c_lds / k_mdft_c2r_lds   128-line tiles AND the whole table through LDS (N % 32 == 0, N <= 256, small tables),
+//                                     also in "plane" form (the second-to-last axis in the same launch)
+//   k_mdft_r2c_stage                  any width: 128-line tiles through LDS in 32-sample chunks, table streamed from L2
+//   k_mdft_c2r_span / k_mdft_c2r_stage any width: 32-line blocks whose N-line span is staged in LDS and written as whole
+//                                     aligned lines / 128-line tiles with direct stores; table streamed from L2
 #pragma once
 #include "sc_kernels_mfma.h"
 
