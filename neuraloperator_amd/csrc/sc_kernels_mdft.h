@@ -721,7 +721,9 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // ------------------------------------------------------------------------------------------
 // (Two chunks requested ahead -- 32 registers per thread, raw barriers so that the younger request is not drained --
 // was tried: it needs the 168-register budget, i.e. three blocks per CU instead of four, and still spills 64 registers
-// per chunk; with two blocks per CU the bytes in flight are back where they were.  Not kept.)
+// per chunk; with two blocks per CU the bytes in flight are back where they were.  Not kept.  Nor were 64-sample chunks
+// (one row = 256 contiguous bytes per load instruction, half the shared lines and barriers, 35 KB of LDS, 32 staging
+// registers, three blocks per CU): 118 vs 112 us at 421 x 17, 40 vs 32 us at 141, 18 vs 14 us at 85.)
 template <int CT, bool TAIL>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 1 ? 4 : 3))
 k_mdft_r2c_stage(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
