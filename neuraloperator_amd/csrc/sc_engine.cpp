@@ -1286,9 +1286,16 @@ static int launch_mdft_c2r_span(const sc_plan* p, int mode, const cf32* in, floa
                                 int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
   const size_t lds = c2r_span_lds(p, N);
 #ifndef SC_EMU
-  if (lds > 64 * 1024)
-    SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdft_c2r_span<JS2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 64 * 1024) {                                     // once per instantiation and device: the 80 KB ceiling
+    static bool raised[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised[dev]) {
+      SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdft_c2r_span<JS2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      raised[dev] = true;
+    }
+  }
 #endif
   SC_LAUNCH((k_mdft_c2r_span<JS2>), dim3((unsigned)((lines + 31) / 32)), dim3(256), lds, st, in, out,
             (const float*)p->s_c2r[mode], bias, lines, N, J, (N + 31) / 32, p->s_c2r_s, lpi, channels);

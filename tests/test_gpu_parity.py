@@ -62,6 +62,8 @@ ORACLE_CASES = [
     (1, 4, 4, (211, 211), (32, 32), None),
     (1, 2, 3, (421, 421), (32, 32), None),
     (2, 3, 3, (9, 11, 43), (4, 6, 16), None),
+    (2, 3, 3, (70, 601), (8, 32), None),            # ... a 77 KB span image (dynamic LDS past 64 KB), 3 partial blocks
+    (1, 2, 2, (40, 701), (8, 32), None),            # ... a span that does not fit: the 128-line chunked inverse kernel
     # round 3: two-pass factorised route for lines of 32 P points, P in {2, 3, 4, 5, 6, 8, 10, 12, 20}
     (2, 8, 8, (64, 64), (32, 32), None),            # P = 2
     (2, 4, 6, (96, 96), (24, 24), None),            # P = 3
