@@ -1006,7 +1006,7 @@ k_mdft_c2r_stage(const cf32* __restrict__ in, float* __restrict__ out, const flo
 // Host: N <= SC_C2R_SPAN_NMAX (LDS), `out` 16-byte aligned; otherwise k_mdft_c2r_stage.
 // ------------------------------------------------------------------------------------------
 template <int JS2>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 3)                  // three blocks per CU (LDS at N = 421): <= 168 registers
 k_mdft_c2r_span(const cf32* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
                 const float* __restrict__ bias, int64_t lines, int N, int J, int n_nt, int S,
                 int64_t lines_per_image, int64_t channels) {
