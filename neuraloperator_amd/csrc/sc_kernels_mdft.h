@@ -723,7 +723,12 @@ k_mdft_r2c_lds(const float* __restrict__ in, float* __restrict__ out, const floa
 // was tried: it needs the 168-register budget, i.e. three blocks per CU instead of four, and still spills 64 registers
 // per chunk; with two blocks per CU the bytes in flight are back where they were.  Not kept.  Nor were 64-sample chunks
 // (one row = 256 contiguous bytes per load instruction, half the shared lines and barriers, 35 KB of LDS, 32 staging
-// registers, three blocks per CU): 118 vs 112 us at 421 x 17, 40 vs 32 us at 141, 18 vs 14 us at 85.)
+// registers, three blocks per CU): 118 vs 112 us at 421 x 17, 40 vs 32 us at 141, 18 vs 14 us at 85.  Nor a form that
+// asks for LINES instead of samples (the 128 rows of a tile are one line-aligned span: per step every row brings its next
+// whole 128-byte line with aligned 16-byte loads into a two-slot ring per row, each line once, and the waves read their
+// samples at the row's own phase): bit-identical, 1.07 x instead of 1.28 x the bytes -- and 127 vs 110 us at 421 x 17,
+// 42 vs 32 us at 141: sixteen 4-byte LDS reads at computed addresses per step and one parking trip per tile cost more
+// than the second fetch of the shared half-lines.  profiles/r04_mdft_odd_ablation.txt (f), (g).)
 template <int CT, bool TAIL>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CT == 1 ? 4 : 3))
 k_mdft_r2c_stage(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ tab,
