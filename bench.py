@@ -91,9 +91,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="time hipGraph replays of the step (neuraloperator_amd/graph.py) instead of eager steps: for "
-                         "workloads whose eager step is bound by the host's issue rate; single GPU only")
+                         "workloads whose eager step is bound by the host's issue rate.  Default (neither --graph nor "
+                         "--no-graph): eager, except the mode-parallel layer with ONE sample per rank (configs[3] strong-scaled "
+                         "over 8 GPUs: host-issue bound, DESIGN 6), which takes the native-RCCL hipGraph step when a probe "
+                         "in a child process shows that this stack records and replays it (graph_probe)")
+    ap.add_argument("--no-graph", action="store_true", help="never replay a hipGraph (A-B against the default)")
+    ap.add_argument("--graph-probe", action="store_true",
+                    help="internal: one rank of graph_probe (env RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*): exit code 0 = "
+                         "a mode-parallel step with native RCCL exchanges records into a hipGraph and replays bit-identically")
     ap.add_argument("--no-pmc", action="store_true",
                     help="roofline.traffic from profiles/pmc_traffic.json instead of two live rocprofv3 --pmc passes")
+    ap.add_argument("--pmc-budget-s", type=float, default=300.0,
+                    help="wall-clock budget shared by the live counter passes of the extra.* workloads")
     ap.add_argument("--settle-ms", type=float, default=SETTLE_MS,
                     help="untimed back-to-back steps (this many ms) between the cold timed region and the one `value` "
                          "reports: MI355X clocks settle ~20 ms into sustained load (0 = report the cold region only)")
@@ -424,10 +433,19 @@ def measure_traffic_live(workload_shape, kernel_substr, timeout_s=120):
     return int(sum(h["traffic_B"] for h in hits) / len(hits)), note + f", mean of {kernel_substr} launches", got
 
 
+PMC_BUDGET = {"left_s": 300.0}     # wall-clock budget of ALL live counter passes of one bench line (--pmc-budget-s)
+
+
 def _extra_traffic(shape, io, kind, alg_bytes_step):
     """`traffic` block of an extra.* entry: the step's HBM bytes by the counters, their ratio to the algorithmic bytes and
-    the kernel the step spends most of its time in (by launches x mean duration under the counter pass)."""
-    got, note = measure_step_traffic(shape, io=io, kind=kind)
+    the kernel the step spends most of its time in (by launches x mean duration under the counter pass).  The passes of
+    all extras share one wall-clock budget (each is two rocprofv3 subprocesses of up to 120 s): once it is
+    spent the remaining entries say so instead of stretching the default line by minutes."""
+    if PMC_BUDGET["left_s"] <= 0:
+        return {"traffic": None, "traffic_note": "counter passes skipped: --pmc-budget-s spent"}
+    t0 = time.perf_counter()
+    got, note = measure_step_traffic(shape, io=io, kind=kind, timeout_s=max(min(120.0, PMC_BUDGET["left_s"]), 20.0))
+    PMC_BUDGET["left_s"] -= time.perf_counter() - t0
     if got is None:
         return {"traffic": None, "traffic_note": note}
     ks = got["kernels"]
@@ -680,15 +698,149 @@ def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv
     return step, b_local, global_batch, scaling, par, conv
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port):
+    """The contract's own launch line for N ranks on one node (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks here, through
+    the same `torch.distributed.run` line the driver uses, and hand its exit code on.  The children see WORLD_SIZE
+    and take the ordinary path; rank 0's JSON line is the only thing on stdout (children point fd 1 at fd 2 until
+    they print it; RCCL's banner and torchrun's notes go to stderr).  Fewer than N visible devices is an error, not
+    a quiet one-rank run (SC_BENCH_SHARE_GPU=1: the test mode where every rank uses cuda:0 over gloo)."""
+    import subprocess
+    share = os.environ.get("SC_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if share else n):
+        print(f"bench.py: --gpus {n} needs {n} visible devices, found {have}", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max((os.cpu_count() or n) // n, 1)))
+    cmd = launch_command(n, argv, free_port())
+    print("[bench] starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+GRAPH_PROBE_TIMEOUT_S = 180
+
+
+def graph_probe_child():
+    """One rank of the probe (its own process: an abort, a segfault or a hang of this stack's capture path -- all three
+    were seen in round 4, DESIGN 6 -- must cost the bench nothing but the graph).  The sequence is the bench's own:
+    eager steps of the mode-parallel layer through torch.distributed under a NON-default stream, then the native RCCL
+    communicator, then capture, then replays compared bit for bit with an eager step."""
+    rank, local_rank = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from neuraloperator_amd.graph import capture_step
+    from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm, rccl_native
+    comm.init(model_parallel_size=world)
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    torch.manual_seed(7 + rank)
+    rows = 2
+    conv = ModeParallelSpectralConv(4, 4, (rows * world, 8, 8)).to(dev)
+    conv.sync_replicated_parameters()
+    x = torch.randn(1, 4, 2 * rows * world, 16, 16, device=dev, requires_grad=True)
+    g = torch.randn(1, 4, 2 * rows * world, 16, 16, device=dev)
+    params = [q for q in conv.parameters() if q.requires_grad]
+
+    def eager():
+        x.grad = None
+        for q in params:
+            q.grad = None
+        y = conv(x)
+        y.backward(g)
+        conv.reduce_replicated_grads()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), x.grad.clone()] + [torch.view_as_real(q.grad).clone() if q.grad.is_complex()
+                                                       else q.grad.clone() for q in params]
+
+    eager()                                                  # torch.distributed path, as the bench's earlier workloads
+    rccl_native.prefer_native()
+    if rccl_native.get(conv._group()) is None:
+        print("[graph-probe] native RCCL path unavailable:", rccl_native.LAST_REASON, file=sys.stderr)
+        return 3
+    want = eager()                                           # native path, eager
+    x.grad = None
+    for q in params:
+        q.grad = None
+    st = capture_step(conv, x, g, post=conv.reduce_replicated_grads)
+    for _ in range(3):
+        st.replay()
+    torch.cuda.synchronize()
+    got = [st.output, x.grad] + [torch.view_as_real(q.grad) if q.grad.is_complex() else q.grad for q in params]
+    ok = all(torch.equal(a, b) for a, b in zip(got, want))
+    flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = int(flag.item()) == 1
+    print(f"[graph-probe] rank {rank}: replay {'==' if ok else '!='} eager", file=sys.stderr)
+    sys.stderr.flush()
+    os._exit(0 if ok else 4)                                 # no teardown: ncclCommDestroy blocks once a graph recorded the communicator
+
+
+def graph_probe(dist, world, rank, local_rank):
+    """(ok, note), identical on every rank: every rank starts ONE child on its own GPU (a second process group on a port
+    rank 0 draws), waits for it with a timeout, and the exit codes are MIN-reduced over the parents' group."""
+    import subprocess
+    box = [free_port() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    t0 = time.perf_counter()
+    try:
+        pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--graph-probe"], env=env,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            _, err = pr.communicate(timeout=GRAPH_PROBE_TIMEOUT_S)
+            rc, tail = pr.returncode, err.decode(errors="replace").strip().splitlines()[-1:]
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, 9)                             # exactly the process group this call started
+            pr.communicate()
+            rc, tail = -9, [f"timeout after {GRAPH_PROBE_TIMEOUT_S} s"]
+    except Exception as e:
+        rc, tail = -1, [f"{type(e).__name__}: {e}"]
+    flag = torch.tensor([1 if rc == 0 else 0], device="cuda", dtype=torch.int32)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = int(flag.item()) == 1
+    note = f"probe {'ok' if ok else 'failed'} in {time.perf_counter() - t0:.1f} s" + \
+        ("" if rc == 0 else f" (this rank: exit {rc}{': ' + tail[0][:120] if tail else ''})")
+    return ok, note
+
+
 def main():
     args = parse()
+    if args.graph_probe:
+        raise SystemExit(graph_probe_child())
+    PMC_BUDGET["left_s"] = args.pmc_budget_s
     if args.cpu_baseline_only:
         B, C, spatial, n_modes = WORKLOADS[args.workload]
         print(json.dumps(cpu_baseline(C, spatial, n_modes, args.cpu_threads or min(os.cpu_count() or 1, 32))), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # a line that says n_gpus = WORLD_SIZE while the caller asked for --gpus N would be a wrong scaling point
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # stdout carries exactly ONE line, the JSON: everything libraries print on the way (RCCL's version banner on
     # communicator creation, gloo's connection notes) is sent to stderr by pointing fd 1 at fd 2 until that line
     sys.stdout.flush()
@@ -715,8 +867,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from neuraloperator_amd.mpu import comm
         comm.init(model_parallel_size=world)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from neuraloperator_amd import _lib
     from neuraloperator_amd.modes import halve_last_mode, kept_block
@@ -736,9 +886,61 @@ def main():
         if engine.get_plan_bf16_io(dev, list(spatial), kept_chk, "forward", flags) is None:
             raise SystemExit(f"--io bf16: {args.workload} does not run on the fused 2-D kernels (no bf16 I/O there)")
 
+    if dist is not None and not share:
+        # every step of a run with collectives is issued under a NON-default stream: on this stack a mode-parallel step
+        # whose exchanges were ordered against torch's default (legacy null) stream makes a LATER capture of the layer
+        # segfault in hipStreamEndCapture -- and the default line may capture after eager workloads ran
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if args.graph and dist is not None:
         from neuraloperator_amd.mpu import rccl_native
         rccl_native.prefer_native()                      # the exchanges must be plain stream launches to be recorded
+    probe = {}
+
+    def launch_form(case_x):
+        """(step fn, launch tag) of a built case: eager, or hipGraph replays of the same step (see --graph)"""
+        st_x, bl_x, _gb, _sc, tag_x, conv_x = case_x
+        want = args.graph
+        why = "--graph"
+        if not want and not args.no_graph and dist is not None and not share and tag_x.startswith("modeshard") \
+                and bl_x == 1:
+            if "ok" not in probe:                        # once per run, the same answer on every rank
+                probe["ok"], probe["note"] = graph_probe(dist, world, rank, local_rank)
+                if rank == 0:
+                    print("[bench] graph probe:", probe["note"], file=sys.stderr, flush=True)
+            want, why = probe["ok"], "one sample per rank, " + probe["note"]
+            if not want:
+                return st_x, "eager (" + probe["note"] + ")"
+        if not want:
+            return st_x, "eager"
+        from neuraloperator_amd.graph import capture_step
+        post_g = None
+        if dist is not None:
+            # round 4: with the engine's native RCCL path (mpu/rccl_native.py) the exchanges of the mode-parallel layer
+            # are plain stream-ordered launches and record into the graph; through torch.distributed they do not
+            from neuraloperator_amd.mpu import rccl_native
+            rccl_native.prefer_native()
+            if not tag_x.startswith("modeshard") or rccl_native.get(conv_x._group()) is None:
+                if args.graph:
+                    raise SystemExit("--graph with collectives: the mode-parallel layer on the native RCCL path only "
+                                     f"({rccl_native.LAST_REASON or tag_x})")
+                return st_x, f"eager (native RCCL path unavailable: {rccl_native.LAST_REASON})"
+            post_g = conv_x.reduce_replicated_grads
+        try:
+            gs = capture_step(conv_x, st_x.x, st_x.g, post=post_g)
+        except Exception as e:                           # explicit --graph: an error; the default: the eager step
+            if args.graph:
+                raise
+            print(f"[bench] rank {rank}: capture failed ({type(e).__name__}: {e}); eager step", file=sys.stderr)
+            gs = None
+        if dist is not None and world > 1:               # all ranks replay, or none does
+            flag = torch.tensor([0 if gs is None else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                gs = None
+        if gs is None:
+            return st_x, "eager (capture failed)"
+        return gs.replay, f"hipGraph replay of the step ({why})"
+
     mp_kw = {}
     if args.comm_chunks > 0:
         mp_kw["comm_chunks"] = args.comm_chunks
@@ -748,18 +950,11 @@ def main():
     if case is None:
         raise SystemExit(f"{args.workload}: batch {B} not divisible by {world} ranks for the strong-scaling run")
     step, b_local, global_batch, scaling, par, conv = case
-    if args.graph:
-        from neuraloperator_amd.graph import capture_step
-        post_g = None
-        if dist is not None:
-            # round 4: with the engine's native RCCL path (mpu/rccl_native.py) the exchanges of the mode-parallel layer
-            # are plain stream-ordered launches and record into the graph; through torch.distributed they do not
-            from neuraloperator_amd.mpu import rccl_native
-            if not par.startswith("modeshard") or rccl_native.get(conv._group()) is None:
-                raise SystemExit("--graph with collectives: the mode-parallel layer on the native RCCL path only "
-                                 f"({rccl_native.LAST_REASON or par})")
-            post_g = conv.reduce_replicated_grads
-        step = capture_step(conv, step.x, step.g, post=post_g).replay
+    mappings.A2A_STATS.update(calls=0, bytes=0)
+    step, launch_tag = launch_form(case)
+    # a replay does not pass through Python's exchange calls: what the capture (warm-up + recording) counted, per step
+    a2a_rec = dict(mappings.A2A_STATS)
+    graphed = launch_tag.startswith("hipGraph")
     mappings.A2A_STATS.update(calls=0, bytes=0)
     ms, ms_cold, n_settle = timed_steps(step, args.steps, args.warmup, dist, dev, share, args.settle_ms)
     value = global_batch / (ms / 1e3)
@@ -796,6 +991,7 @@ def main():
                 extra[name] = {"value": None, "note": f"batch of {wl} not divisible by {world} ranks"}
                 continue
             st_x, bl_x, gb_x, sc_x, tag_x, conv_x = c
+            st_x, launch_x = launch_form(c)
             ms_x, cold_x, n_x = timed_steps(st_x, args.steps, args.warmup, dist, dev, share, args.settle_ms)
             Bx, Cx, sp_x, nm_x = WORKLOADS[wl]
             kept_x, _ = kept_block(sp_x, halve_last_mode(nm_x), halve_last_mode(nm_x))
@@ -812,7 +1008,7 @@ def main():
                            "global_batch": gb_x, "ms_per_step": round(ms_x, 4),
                            "value": round(gb_x / (ms_x / 1e3), 2), "unit": "samples/s", "steps": args.steps, "warmup": args.warmup,
                            "cold_start_ms_per_step": round(cold_x, 4), "settle_steps": n_x,
-                           "real_tensor_io": "bf16" if io_x == bf16 else "f32",
+                           "real_tensor_io": "bf16" if io_x == bf16 else "f32", "launch": launch_x,
                            "alg_bytes_per_step": tot_x, "alg_bytes_formula": formula + " (SURVEY.md 8d), per GPU",
                            "achieved_GBs": round(gbs_x, 1), "frac_of_8TBs": round(gbs_x / HBM_PEAK_GBS, 4), **extra_cfg}
             if world > 1:                                # sharded weights: the single-GPU byte model does not apply
@@ -880,7 +1076,7 @@ def main():
             "config": {"workload": args.workload, "B_per_gpu": b_local, "global_batch": global_batch,
                        "channels": C, "grid": list(spatial), "n_modes": list(n_modes), "kept": kept,
                        "parallelism": par, "engine_path": engine_path(names),
-                       "launch": "hipGraph replay of the step" if args.graph else "eager",
+                       "launch": launch_tag,
                        "real_tensor_io": args.io,
                        "weights": "dense complex64, random init"},
             "roofline": roof,
@@ -909,9 +1105,14 @@ def main():
                                   "issued_by": "ncclAllToAll / ncclSend+ncclRecv straight on HIP streams (mpu/rccl_native.py)"
                                                if native else "torch.distributed" +
                                                (f" ({rccl_native.LAST_REASON})" if rccl_native.LAST_REASON else ""),
-                                  "all_to_all_calls_per_step": (round(a2a["calls"] / n_timed, 2) if not args.graph else
-                                                                "recorded in the graph"),
-                                  "all_to_all_bytes_per_step_per_rank": int(a2a["bytes"] / n_timed)}
+                                  # a replay runs the recorded exchanges: counted while the step was captured
+                                  # (capture_step: 3 warm-up steps + the recording = 4 passes through the layer)
+                                  "all_to_all_calls_per_step": round(a2a_rec["calls"] / 4, 2) if graphed
+                                  else round(a2a["calls"] / n_timed, 2),
+                                  "all_to_all_bytes_per_step_per_rank": int(a2a_rec["bytes"] / 4) if graphed
+                                  else int(a2a["bytes"] / n_timed),
+                                  "counted": "while the step was captured (recorded in the graph)" if graphed
+                                  else "during the timed steps"}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_gpu_reference and args.io == "f32":

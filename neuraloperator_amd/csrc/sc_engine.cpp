@@ -3,6 +3,7 @@
 //
 // Built with:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip sc_engine.cpp
 // (tests/emu builds the same file with g++ -DSC_EMU; see sc_device.h).
+#include <atomic>
 #include "../../include/sc_engine.h"
 
 #include <cmath>
@@ -1286,14 +1287,17 @@ static int launch_mdft_c2r_span(const sc_plan* p, int mode, const cf32* in, floa
                                 int64_t lines, int N, int J, int64_t lpi, int64_t channels, sc_stream_t st) {
   const size_t lds = c2r_span_lds(p, N);
 #ifndef SC_EMU
-  if (lds > 64 * 1024) {                                     // once per instantiation and device: the 80 KB ceiling
-    static bool raised[64] = {false};
+  // once per instantiation and device: the 80 KB ceiling.  The kernel also holds 128 B of static LDS (biasL), so the
+  // ceiling is raised as soon as static + dynamic reaches the 64 KB default (N = 512, J = 9..36: dynamic = 65536 exactly;
+  // ADVICE r4).  The flags are atomics: plans of two host threads may take their first launch at the same time.
+  if (lds + 128 >= 64 * 1024) {
+    static std::atomic<bool> raised[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!raised[dev]) {
+    if (!raised[dev].load(std::memory_order_acquire)) {
       SC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mdft_c2r_span<JS2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-      raised[dev] = true;
+      raised[dev].store(true, std::memory_order_release);
     }
   }
 #endif

@@ -56,7 +56,9 @@ class _Exchange:
         self.group, self.P, self.rows, self.k1 = group, P, rows, k1
         # round 4: RCCL straight on a HIP stream where it was asked for and is available (rccl_native: plain stream-ordered
         # launches, capturable into a hipGraph); None = the torch.distributed path (the default of eager steps).
-        # overlap=False (one piece per exchange: nothing to run beside it) issues on the CURRENT stream, no events.
+        # overlap=False (one piece per exchange: nothing to run beside it): the exchange still runs on the communicator's
+        # own stream (never torch's default stream, see _native) and the current stream waits for it at once -- one
+        # wait_stream + one recorded event from the communicator's ring per exchange.
         self.native = rccl_native.get(group)
         self.overlap = overlap
 

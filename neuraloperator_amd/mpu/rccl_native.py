@@ -73,24 +73,32 @@ class RcclError(RuntimeError):
 class NativeComm:
     """One RCCL communicator over the ranks of a torch process group (its own, next to torch's)."""
 
-    def __init__(self, group):
+    def __init__(self, group, lib=None):
+        """Collective over `group`: every rank must call it (get() has already agreed on that, and on a loadable
+        library, before anything here can block).  Rank 0 broadcasts a sentinel when it cannot draw the id, so a failure
+        there is an exception on every rank instead of a hang in the broadcast."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.lib = _load()
+        self.lib = lib if lib is not None else _load()
         uid = _UniqueId()
+        payload = None
         if self.rank == 0:
-            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        box = [ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES) if self.rank == 0 else None]
+            rc = self.lib.ncclGetUniqueId(ctypes.byref(uid))
+            payload = ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES) if rc == 0 else \
+                "ncclGetUniqueId: " + self.lib.ncclGetErrorString(rc).decode()
+        box = [payload]
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)
         if not isinstance(box[0], bytes) or len(box[0]) != NCCL_UNIQUE_ID_BYTES:
-            raise RcclError("unique id did not arrive")
+            raise RcclError(box[0] if isinstance(box[0], str) else "unique id did not arrive")
         ctypes.memmove(ctypes.byref(uid), box[0], NCCL_UNIQUE_ID_BYTES)
         comm = ctypes.c_void_p()
         self._check(self.lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
         self.comm = comm
         self.stream = torch.cuda.Stream()                 # where overlapped exchanges run
+        self._events = [torch.cuda.Event() for _ in range(8)]   # ring reused by launch_async (no Event per call)
+        self._ev_i = 0
 
     def _check(self, rc, what):
         if rc != 0:
@@ -145,7 +153,9 @@ class NativeComm:
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         fn(self.stream.cuda_stream)
-        return _Pending(self.stream, tensors)
+        ev = self._events[self._ev_i]                     # at most a few exchanges are in flight per layer (<= 4 chunks)
+        self._ev_i = (self._ev_i + 1) % len(self._events)
+        return _Pending(self.stream, tensors, ev)
 
     def destroy(self):
         # The communicator is NOT destroyed: ncclCommDestroy blocks for good once a hipGraph that recorded this
@@ -155,9 +165,9 @@ class NativeComm:
 
 
 class _Pending:
-    def __init__(self, stream, keep):
+    def __init__(self, stream, keep, event=None):
         self.keep = keep                                  # alive until waited for
-        self.event = torch.cuda.Event()
+        self.event = event if event is not None else torch.cuda.Event()
         self.event.record(stream)
 
     def wait(self):
@@ -169,41 +179,88 @@ def _mode():
     return os.environ.get("SC_MPU_A2A", "auto").lower()
 
 
+def _pg(group):
+    """the ProcessGroup object behind `group` (None = the default group)"""
+    if group is not None:
+        return group
+    try:
+        return dist.distributed_c10d._get_default_group()
+    except Exception:
+        return None
+
+
+def _agree(ok, group):
+    """MIN over the group of a local 0 / 1 flag (one small all-reduce on the group's own backend)"""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
 def get(group):
-    """NativeComm of `group`, or None (torch path): decided once per group, identically on every rank."""
+    """NativeComm of `group`, or None (torch path): decided once per group, identically on every rank.
+
+    The cache entry remembers WHICH process group it was decided for (a weak reference to the ProcessGroup object plus
+    world size and rank): after destroy_process_group / init_process_group, or when a collected group's id() is reused,
+    the entry no longer matches and the decision is taken again instead of handing out a communicator of another world
+    (ADVICE r4).  A negative decision that only said "not requested" is re-evaluated once prefer_native() has been
+    called.  Order of the collective part: (1) rank-local checks -- mode, request flag, library and symbols -- and ONE
+    all-reduce of that flag, so a rank that cannot load librccl, or ranks that disagree about SC_MPU_A2A /
+    prefer_native(), send everybody to the torch path before anything can block; (2) unique id + ncclCommInitRank;
+    (3) the self-test and a second all-reduce."""
     global LAST_REASON
     key = id(group) if group is not None else 0
-    if key in _CACHE:
-        return _CACHE[key]
-    comm, reason = None, ""
+    pg = _pg(group)
+    ent = _CACHE.get(key)
+    if ent is not None:
+        ref, world, rank, comm, why = ent
+        same = pg is not None and ref() is pg and world == dist.get_world_size(group) and rank == dist.get_rank(group)
+        if same and not (comm is None and why == "not requested" and (_WANT or _mode() == "native")):
+            return comm
+        if comm is not None:
+            comm.destroy()
+        del _CACHE[key]
+    comm, reason, why = None, "", ""
     mode = _mode()
+    lib, local = None, ""
     if mode == "torch":
-        reason = "SC_MPU_A2A=torch"
+        local = "SC_MPU_A2A=torch"
     elif mode != "native" and not _WANT:
-        reason = "not requested (prefer_native() / SC_MPU_A2A=native)"
-    elif not (dist.is_available() and dist.is_initialized()):
-        reason = "no process group"
+        local, why = "not requested (prefer_native() / SC_MPU_A2A=native)", "not requested"
+    if not (dist.is_available() and dist.is_initialized()):
+        reason = local or "no process group"
     elif dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
-        reason = f"backend {dist.get_backend(group)}"
+        reason = local or f"backend {dist.get_backend(group)}"
     else:
-        ok = 1
-        try:
-            comm = NativeComm(group)
-            ok = 1 if _self_test(comm) else 0
-            if not ok:
-                reason = "self-test mismatch against torch.distributed.all_to_all_single"
-        except Exception as e:                               # library / symbol / init failure: the torch path
-            ok, reason = 0, f"{type(e).__name__}: {e}"
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) != 1:
-            if comm is not None and not reason:
-                reason = "another rank failed"
-            comm = None
+        if not local:
+            try:
+                lib = _load()
+            except Exception as e:                           # library / symbol lookup: rank-local, nothing blocks yet
+                local = f"{type(e).__name__}: {e}"
+        if dist.get_world_size(group) == 1:
+            agreed = not local
+        else:
+            agreed = _agree(not local, group)                # (1): also covers ranks that disagree about the request
+        if not agreed:
+            reason = local or "another rank does not take the native path"
+        else:
+            ok = True
+            try:
+                comm = NativeComm(group, lib)                # (2)
+                ok = _self_test(comm)
+                if not ok:
+                    reason = "self-test mismatch against torch.distributed.all_to_all_single"
+            except Exception as e:
+                ok, reason = False, f"{type(e).__name__}: {e}"
+            if not _agree(ok, group):                        # (3)
+                if comm is not None and not reason:
+                    reason = "another rank failed"
+                comm = None
     LAST_REASON = reason
     if comm is None and mode == "native":                    # forced: an error, not a silent fallback
         raise RcclError("SC_MPU_A2A=native: " + reason)
-    _CACHE[key] = comm
+    if pg is not None:
+        import weakref
+        _CACHE[key] = (weakref.ref(pg), dist.get_world_size(group), dist.get_rank(group), comm, why)
     return comm
 
 
@@ -228,11 +285,12 @@ def _self_test(comm):
 
 def active():
     """True when some process group of this process exchanges through the native path"""
-    return any(c is not None for c in _CACHE.values())
+    return any(e[3] is not None for e in _CACHE.values())
 
 
 def shutdown():
-    for c in _CACHE.values():
-        if c is not None:
-            c.destroy()
+    """forget every communicator (mpu.comm.cleanup calls this before destroy_process_group)"""
+    for e in _CACHE.values():
+        if e[3] is not None:
+            e[3].destroy()
     _CACHE.clear()

@@ -88,3 +88,39 @@ db.commit()
     assert got["step_traffic_B"] == 250 * 1024 + 2 * 21 * 1024            # torch's own kernels are not counted
     ex = bench._extra_traffic((2, 4, (16, 16), (8, 8)), "f32", "dense", 292 * 1024 // 2)
     assert ex["traffic"] == 292 * 1024 and ex["traffic_over_alg_bytes"] == 2.0 and ex["dominant_kernel"]["name"] == "k_a<1>"
+
+
+def test_launch_command_is_the_contracts_line(bench):
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks_or_fails(bench, monkeypatch, capsys):
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start N ranks itself and must not
+    quietly run one.  Here (no device): non-zero exit; with devices the launch line is handed to a subprocess."""
+    import subprocess
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("SC_BENCH_SHARE_GPU", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    assert bench.self_launch(8, ["--gpus", "8"]) == 2
+    assert "needs 8 visible devices" in capsys.readouterr().err
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    assert bench.self_launch(8, ["--gpus", "8", "--steps", "2"]) == 0
+    assert "--nproc-per-node=8" in seen["cmd"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main(): a mismatch between --gpus and the launcher's WORLD_SIZE is an error, not a note
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value)
+    # and --gpus N without WORLD_SIZE goes through self_launch and exits with ITS code
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setattr(bench, "self_launch", lambda n, argv: 7)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7

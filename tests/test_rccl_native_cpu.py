@@ -53,3 +53,38 @@ def test_gloo_group_keeps_the_torch_path(tmp_path):
     finally:
         os.environ.pop("SC_MPU_A2A", None)
         dist.destroy_process_group()
+
+
+def test_cache_entry_is_tied_to_the_process_group_and_the_request(tmp_path, monkeypatch):
+    """the per-group decision must not outlive the group it was taken for (destroy + init without
+    comm.cleanup(), a reused id()), and a "not requested" decision is taken again once prefer_native() was called."""
+    monkeypatch.delenv("SC_MPU_A2A", raising=False)
+    store = dist.FileStore(str(tmp_path / "s1"), 1)
+    dist.init_process_group("gloo", store=store, rank=0, world_size=1)
+    try:
+        assert rccl_native.get(None) is None and "not requested" in rccl_native.LAST_REASON
+        ent = rccl_native._CACHE[0]
+        assert ent[0]() is dist.distributed_c10d._get_default_group() and ent[1:3] == (1, 0) and ent[4] == "not requested"
+        rccl_native.LAST_REASON = "stale"
+        assert rccl_native.get(None) is None and rccl_native.LAST_REASON == "stale"      # a hit: nothing re-evaluated
+        rccl_native.prefer_native()
+        assert rccl_native.get(None) is None and "backend gloo" in rccl_native.LAST_REASON   # asked for now: decided again
+    finally:
+        dist.destroy_process_group()
+    # the same key (0 = default group), another process group object: the entry no longer matches
+    marker = object()
+    ent = rccl_native._CACHE[0]
+    rccl_native._CACHE[0] = (ent[0], ent[1], ent[2], marker, ent[4])
+
+    class Fake:
+        destroyed = False
+
+        def destroy(self):
+            Fake.destroyed = True
+    rccl_native._CACHE[0] = (ent[0], ent[1], ent[2], Fake(), "")
+    store = dist.FileStore(str(tmp_path / "s2"), 1)
+    dist.init_process_group("gloo", store=store, rank=0, world_size=1)
+    try:
+        assert rccl_native.get(None) is None and Fake.destroyed and "backend gloo" in rccl_native.LAST_REASON
+    finally:
+        dist.destroy_process_group()
