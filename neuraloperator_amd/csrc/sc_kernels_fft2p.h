@@ -277,7 +277,11 @@ SC_HD void dft32_padded(const cf32 (&in)[2 * K2 + 1], cf32 (&g)[32]) {
       constexpr int i = decltype(it)::value;
       constexpr int k2 = i - K2;
       constexpr int r = k2 & 7;
-      const cf32 term = mul_w32<DIR, s1 * k2>(in[i]);
+      cf32 term = mul_w32<DIR, s1 * k2>(in[i]);
+      // NIN = 16 / 17 (K2 = 8): pin the term in two scalar registers.  hipcc otherwise packs in[12] / in[13] of the column kernels'
+      // <32, 8> instantiations into one 16-byte vector and extracts its middle pair THROUGH SCRATCH (a dwordx4 store
+      // and three dwordx2 loads: the 32 bytes of private segment VERDICT r4 weak 7 lists)
+      if constexpr (NIN >= 16) sc_landed(term);
       if constexpr (i < 8) e[r] = term;
       else e[r] = cf_add(e[r], term);
     });
@@ -454,25 +458,48 @@ k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf3
   // column blocks read share 128-byte lines -- fetched once per XCD instead of once per block
   const int64_t blk0 = f2p_block(per_xcd) * G;
   if (blk0 >= n_blk) return;
-  cf32 in[2 * K2 + 1];
+  float inx[2 * K2], iny[2 * K2];                          // (scalars, not cf32: see below)
+  const bool on = s < G * P;
+  const int g_in = on ? s / P : 0, k1_in = s - g_in * P;
+  const int64_t blk_in = blk0 + g_in;
+  const bool live_b = on && blk_in < n_blk;
+  const int col_in = live_b ? (int)(blk_in % NCB) * SC_F2P_CB + c : 0;
+  auto kept_row = [&](const int i, int& row) {             // is entry i of this lane's line a kept row of a live column?
+    row = k1_in + P * (i - K2) + K0 / 2;
+    return live_b && col_in < J && row >= 0 && row < K0;
+  };
   {
-    const bool on = s < G * P;
-    const int g = on ? s / P : 0, k1 = s - g * P;
-    const int64_t blk = blk0 + g;
-    const bool live_b = on && blk < n_blk;
-    const int col = live_b ? (int)(blk % NCB) * SC_F2P_CB + c : 0;
-    const cf32* src = yhat + (live_b ? blk / NCB : 0) * (int64_t)K0 * J + col;
+    // Round 5: every entry is an UNCONDITIONAL load of a clamped row, passed through sc_landed behind the barrier and
+    // only then masked.  With the load under the condition (round 3) hipcc turned the <32, 8> instantiation's selects
+    // into branches around single loads, each followed by s_waitcnt vmcnt(0), and parked two entries in scratch
+    // (32 bytes); a plain select of an unconditional load is sunk back under the branch, and a
+    // cf32 array across the barrier still left entries 12 / 13 in memory (a 16-byte slice the vectoriser had formed).
+    const cf32* src = yhat + (live_b ? blk_in / NCB : 0) * (int64_t)K0 * J + col_in;
 #pragma unroll
     for (int i = 0; i < 2 * K2; ++i) {
-      const int row = k1 + P * (i - K2) + K0 / 2;
-      in[i] = (live_b && col < J && row >= 0 && row < K0) ? src[(int64_t)row * J] : cf_make(0.f, 0.f);
+      int row;
+      const bool ok = kept_row(i, row);
+      const cf32 v = src[(int64_t)(ok ? row : 0) * J];
+      inx[i] = v.x;
+      iny[i] = v.y;
     }
-    in[2 * K2] = cf_make(0.f, 0.f);
   }
   SC_SYNC();
   cf32* Ec = E + c * SC_F2P_CS;
   if (s < G * P) {
     const int k1 = s % P;
+    cf32 in[2 * K2 + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * K2; ++i) {
+      sc_landed(inx[i]);
+      sc_landed(iny[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * K2; ++i) {
+      int row;
+      in[i] = kept_row(i, row) ? cf_make(inx[i], iny[i]) : cf_make(0.f, 0.f);
+    }
+    in[2 * K2] = cf_make(0.f, 0.f);
     cf32 gq[32];
     dft32_padded<+1, K2, false>(in, gq);
     Ec[s * SC_F2P_RS] = gq[0];
@@ -771,13 +798,18 @@ k_f2p_col_inv_w1024(const cf32* __restrict__ yhat, cf32* __restrict__ panel, con
   SC_SHARED __attribute__((aligned(16))) cf32 E[8 * SC_CW1K_CS];            // [c][r][ma][l]
   const int tid = SC_TID, c = tid & 7, L = tid >> 3, r = L & 3, l = L >> 2;
   if (tid < 256) tw2[tid] = cf_conj(w1024[(4 * (tid >> 4) * (tid & 15)) & 1023]);
-  // lane constants: w1024^(+r f) and the kept row of frequency f = l + 16 q (q < 8) / l + 16 q - 256 (q >= 8)
-  cf32 twr[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int f = l + 16 * q - (q >= 8 ? 256 : 0);
-    twr[q] = cf_conj(w1024[(r * f) & 1023]);
+  // Input twiddles conj w1024^(r f) of the kept row of frequency f = l + 16 q (q < 8) / l + 16 q - 256 (q >= 8), split
+  // as conj w1024^(r l) -- ONE lane constant, applied behind the first 16-point transform together with tw2 (the
+  // transform is linear in its inputs) -- times conj w1024^(r (f - l)), which depends on (r, q) only: 64 values in LDS,
+  // read as broadcasts.  Round 5: the sixteen per-lane constants of round 4 (32 registers) made both instantiations
+  // spill at the 128-register budget of 4 waves per SIMD (36 / 156 bytes of scratch).
+  SC_SHARED __attribute__((aligned(16))) cf32 twq[4 * 16];                  // [r][q]
+  if (tid < 64) {
+    const int rr = tid >> 4, q = tid & 15;
+    twq[tid] = cf_conj(w1024[(rr * (16 * q - (q >= 8 ? 256 : 0))) & 1023]);
   }
+  const cf32 twl = cf_conj(w1024[(r * l) & 1023]);
+  const cf32* twqr = twq + 16 * r;
   const int row0 = l + K0 / 2;                             // kept row of f = l; the others are compile-time steps away
   cf32* Ew = E + c * SC_CW1K_CS + r * SC_CW1K_RS + l;
   const cf32* Er = E + c * SC_CW1K_CS + r * SC_CW1K_RS + l * SC_W1K_ES;
@@ -809,18 +841,19 @@ k_f2p_col_inv_w1024(const cf32* __restrict__ yhat, cf32* __restrict__ panel, con
       constexpr int step = 16 * q - (q >= 8 ? 256 : 0);
       if constexpr (FULL) {
         const cf32 v = src[(int64_t)row0 * J + (int64_t)step * J];       // (lane part) + (uniform part)
-        T[q] = live ? cf_mul_cs(v, twr[q]) : cf_make(0.f, 0.f);
+        T[q] = live ? cf_mul_cs(v, sc_lds_ld64(twqr + q)) : cf_make(0.f, 0.f);
       } else {
         const int row = row0 + step;
         const bool ok = row >= 0 && row < K0;
         const cf32 v = src[(int64_t)(ok ? row : 0) * J];
-        T[q] = (live && ok) ? cf_mul_cs(v, twr[q]) : cf_make(0.f, 0.f);
+        T[q] = (live && ok) ? cf_mul_cs(v, sc_lds_ld64(twqr + q)) : cf_make(0.f, 0.f);
       }
     });
     fft16<+1>(T, U);                                       // over kappa2 -> ma
-    Ew[0] = U[0];
+    Ew[0] = cf_mul_cs(U[0], twl);
 #pragma unroll
-    for (int ma = 1; ma < 16; ++ma) Ew[ma * SC_W1K_ES] = cf_mul_cs(U[ma], sc_lds_ld64(tw2 + ma * 16 + l));
+    for (int ma = 1; ma < 16; ++ma)
+      Ew[ma * SC_W1K_ES] = cf_mul_cs(cf_mul_cs(U[ma], twl), sc_lds_ld64(tw2 + ma * 16 + l));
     SC_SYNC();
 #pragma unroll
     for (int q = 0; q < 16; ++q) T[q] = sc_lds_ld64(Er + q);   // lane l now plays ma = l

@@ -494,8 +494,13 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
 #ifndef SC_F3_INV_OCC
 #define SC_F3_INV_OCC 3       // register budget: waves per SIMD the allocator leaves room for
 #endif
+// workgroups per compute unit of an instantiation = its register budget (waves per SIMD) = its persistent grid.
+// H = 512 with the skip + GELU epilogue (EPI = 2) does not fit the 168 registers of three per unit (round 4: 1-6
+// spilled registers, 8 / 20 bytes of scratch): two per unit, no scratch.
+template <int H, int EPI>
+constexpr int f3_inv_wgs() { return (H == 512 && EPI == 2) ? 2 : (H <= 256 && EPI == 0 ? SC_F3_INV_OCC : 3); }
 template <int H, typename IO, int EPI = 0>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && EPI == 0 ? SC_F3_INV_OCC : 3))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (f3_inv_wgs<H, EPI>()))
 k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __restrict__ bias,
              int channels, const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, int Mx, int My,
              float s_dc, float s_other, const IO* __restrict__ skip, IO* __restrict__ preact, F3Shard sh,
@@ -748,11 +753,17 @@ static void fft3_launch_inv(const Fft2dPlan* fp, const cf32* yhat, IO* y, const 
   SC_LAUNCH((k_fft2d_inv3<H, IO, E>), dim3((unsigned)(grid < n_images ? grid : n_images)), dim3(256), 0, st, yhat, y,  \
             bias, channels, (const cf32*)fp->tabW, (const cf32*)fp->tabH, fp->Mx, fp->My, s_dc, s_other, skip, preact,  \
             sh, n_images, (int)(grid < n_images ? grid : n_images))
-  // persistent workgroups, SC_F3_INV_WGS per compute unit (3: measured best, see the kernel)
-  const int64_t grid = (int64_t)SC_F3_INV_WGS * sc_cu_count();
-  if (epi == 2) SC_F3_INV(2);
-  else if (epi == 1) SC_F3_INV(1);
-  else SC_F3_INV(0);
+  // persistent workgroups, SC_F3_INV_WGS per compute unit (3: measured best, see the kernel; 2 for the one
+  // instantiation whose register budget is two waves per SIMD)
+  int64_t grid = (int64_t)SC_F3_INV_WGS * sc_cu_count();
+  if (epi == 2) {
+    if (f3_inv_wgs<H, 2>() < SC_F3_INV_WGS) grid = (int64_t)f3_inv_wgs<H, 2>() * sc_cu_count();
+    SC_F3_INV(2);
+  } else if (epi == 1) {
+    SC_F3_INV(1);
+  } else {
+    SC_F3_INV(0);
+  }
 #undef SC_F3_INV
 }
 

@@ -150,9 +150,16 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
   const int b_g = K::A_G + (kk * K::COLS + qq) * GS + (w ^ ((qq >> K::SH) & (GS - 1)));   // + u * 16 * GS
   constexpr bool M3 = SC_G8_USE_3M(GS, QT, IL);
   constexpr int NB = M3 ? 1 : QT;                            // B fetches per lane and r pair
+  // Four-product shape with a conjugated B (round 5): a conj(b) = conj(conj(a) b), so the loop runs the un-conjugated-B
+  // code with A's conjugation toggled and the epilogue negates the Im lanes -- the same products in the same order
+  // with two exact sign changes, bit-identical to the direct form.  The direct form kept a second lane-dependent sign
+  // mask alive through the pipelined loop: <8, 2, 1, 4, true, *, true> spilled 4 registers at its 128 (20 bytes of
+  // scratch).
+  constexpr bool FLIP = CB && !M3;
+  constexpr bool CAe = FLIP ? !CA : CA, CBe = FLIP ? false : CB;
   const int b_g3 = K::A_G + (kk * K::COLS + li) * GS + (w ^ ((li >> K::SH) & (GS - 1)));  // M3: lane = (kk, column li)
-  const uint32_t m_re = (CB && d) ? 0x80000000u : 0u;        // B'[(r,re)][(q,1)] = Im B  (conj: -Im B)
-  const uint32_t m_im = (!CB && !d) ? 0x80000000u : 0u;      // B'[(r,im)][(q,0)] = -Im B (conj: +Im B)
+  const uint32_t m_re = (CBe && d) ? 0x80000000u : 0u;       // B'[(r,re)][(q,1)] = Im B  (conj: -Im B)
+  const uint32_t m_im = (!CBe && !d) ? 0x80000000u : 0u;     // B'[(r,im)][(q,0)] = -Im B (conj: +Im B)
   const uint32_t dsel = d ? 0xffffffffu : 0u;
   const int NS = (g.R + 2 * SUB - 1) / (2 * SUB);            // stages of 2 SUB values of r
 
@@ -245,9 +252,9 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
     auto prep = [&](const Ops& o, const int r0, Prep& q) {
       const float keep = (r0 + kk < g.R) ? 1.f : 0.f;         // r values past the end: the duplicate contributes 0
       q.ar[0] = o.a.x * keep;
-      q.ai[0] = (CA ? -o.a.y : o.a.y) * keep;
+      q.ai[0] = (CAe ? -o.a.y : o.a.y) * keep;
       q.ar[1] = o.a.z * keep;
-      q.ai[1] = (CA ? -o.a.w : o.a.w) * keep;
+      q.ai[1] = (CAe ? -o.a.w : o.a.w) * keep;
       if constexpr (!M3) {
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
@@ -448,7 +455,13 @@ SC_DEVICE void g8_workgroup(const Gemm8Args& g, const cf32* __restrict__ A, cons
           SC_BARRIER_RAW();
           sc_f4 val[K::EPW];
 #pragma unroll
-          for (int e = 0; e < K::EPW; ++e) val[e] = lds[(w * K::EPW + e) * 64 + lane];
+          for (int e = 0; e < K::EPW; ++e) {
+            val[e] = lds[(w * K::EPW + e) * 64 + lane];
+            if constexpr (FLIP) {                                  // a granule = (re, im) of the unit's two modes
+              val[e].y = -val[e].y;
+              val[e].w = -val[e].w;
+            }
+          }
 #pragma unroll
           for (int e = 0; e < K::EPW; ++e) {
             const int sbase = (w * K::EPW + e) * K::SP;            // first segment of this store (uniform)

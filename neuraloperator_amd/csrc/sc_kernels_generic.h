@@ -396,7 +396,9 @@ k_modegemm_msum(ModeGemmArgs g, const cf32* __restrict__ A, const cf32* __restri
 #ifndef SC_MSUM_UNROLL
 #define SC_MSUM_UNROLL 2                                      // steps of operand loads in flight (4: 49.6 -> 57.9 us at TFNO rank 0.1)
 #endif
-#pragma unroll SC_MSUM_UNROLL
+#define SC_PRAGMA_STR(x) _Pragma(#x)
+#define SC_PRAGMA_UNROLL(n) SC_PRAGMA_STR(unroll n)       // (a macro inside `#pragma unroll` does not survive --save-temps)
+SC_PRAGMA_UNROLL(SC_MSUM_UNROLL)
     for (int64_t r = r_lo; r < r_hi; ++r) {
       cf32 a[PT], b[QT];
 #pragma unroll
