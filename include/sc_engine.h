@@ -270,6 +270,30 @@ int sc_tucker_chain_backward(const sc_tucker_chain_desc* d, const float* xhat, c
                              float* gu_in, float* gt3, float* gu_out, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* ---- the same nine products as ONE kernel launch each way (round 5, csrc/sc_kernels_tkchain.h) -----------------------
+ * Replaces the three einsum steps of _contract_tucker's pairwise order and their autograd
+ * (neuralop/layers/spectral_convolution.py:76-103) for shapes inside sc_tucker_chain_fused_supported: batch <= 32,
+ * channels <= 64, ranks <= 48, every extent and the number of modes a multiple of 4 (BASELINE configs[2]: 32 x 64 -> 64
+ * channels, ranks 36, 2112 modes).  A workgroup owns four modes for the whole batch and walks x̂ -> z -> t -> ŷ
+ * (backward: ĝ -> gt -> gz -> gx̂ with the factor gradients accumulated per workgroup and reduced in fixed order) out of
+ * LDS; z and t are written once for the backward pass and never re-read by the forward call.
+ *   t3m: a mode-major copy of t3, (n_modes, r_in, r_out) complex64 = sc_tucker_chain_t3m_bytes -- WRITTEN by the forward
+ *        call (one transposing launch) and READ by the backward call: the caller keeps it between the two.
+ *   backward workspace: sc_tucker_chain_backward_fused_workspace_bytes (the mode-major gradient of t3 + one partial
+ *        sum of both factor gradients per workgroup).  gt3 is required; gxhat / gu_in / gu_out may be null.
+ * Same arithmetic as the nine launches (exact-fp32 16 x 16 x 4 matrix tiles, three real products per complex product);
+ * the factor gradients are summed in a different (fixed) order.  All tensors 16-byte aligned.  SC_TKC_OFF=1
+ * (environment) makes sc_tucker_chain_fused_supported return 0. */
+int sc_tucker_chain_fused_supported(const sc_tucker_chain_desc* d);
+size_t sc_tucker_chain_t3m_bytes(const sc_tucker_chain_desc* d);
+int sc_tucker_chain_forward_fused(const sc_tucker_chain_desc* d, const float* xhat, const float* u_in, const float* t3,
+                                  const float* u_out, float* t3m, float* z, float* t, float* yhat, void* stream);
+size_t sc_tucker_chain_backward_fused_workspace_bytes(const sc_tucker_chain_desc* d);
+int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* d, const float* xhat, const float* u_in, const float* t3m,
+                                   const float* u_out, const float* z, const float* t, const float* gy, float* gxhat,
+                                   float* gu_in, float* gt3, float* gu_out, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
 /* ---- pointwise half of an FNO block in one pass ("next" row f1 of SURVEY.md section 8) -------------------
  *   out = act( W2 gelu(W1 x + b1) + b2 + gate (.) skip_src )
  * replaces ChannelMLP.forward (neuralop/layers/channel_mlp.py:82-119: two Conv1d with kernel size 1 and a GELU),

@@ -153,7 +153,9 @@ class ScEngineLib:
                "sc_tucker_modes_backward", "sc_tucker_modes_workspace_bytes", "sc_modegemm_pair",
                "sc_modegemm_pair_fused", "sc_modegemm_pair_path", "sc_plan_workspace_bytes_sharded", "sc_transform_forward_sharded",
                "sc_transform_inverse_sharded", "sc_bias_grad_sharded", "sc_tucker_chain_forward",
-               "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes"]
+               "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes", "sc_tucker_chain_fused_supported",
+               "sc_tucker_chain_t3m_bytes", "sc_tucker_chain_forward_fused", "sc_tucker_chain_backward_fused",
+               "sc_tucker_chain_backward_fused_workspace_bytes"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -262,6 +264,16 @@ class ScEngineLib:
         L.sc_tucker_chain_workspace_bytes.restype = c_size_t
         L.sc_tucker_chain_backward.argtypes = [POINTER(TuckerChainDesc)] + [c_void_p] * 12 + [c_size_t, c_void_p]
         L.sc_tucker_chain_backward.restype = c_int
+        L.sc_tucker_chain_fused_supported.argtypes = [POINTER(TuckerChainDesc)]
+        L.sc_tucker_chain_fused_supported.restype = c_int
+        L.sc_tucker_chain_t3m_bytes.argtypes = [POINTER(TuckerChainDesc)]
+        L.sc_tucker_chain_t3m_bytes.restype = c_size_t
+        L.sc_tucker_chain_forward_fused.argtypes = [POINTER(TuckerChainDesc)] + [c_void_p] * 9
+        L.sc_tucker_chain_forward_fused.restype = c_int
+        L.sc_tucker_chain_backward_fused_workspace_bytes.argtypes = [POINTER(TuckerChainDesc)]
+        L.sc_tucker_chain_backward_fused_workspace_bytes.restype = c_size_t
+        L.sc_tucker_chain_backward_fused.argtypes = [POINTER(TuckerChainDesc)] + [c_void_p] * 12 + [c_size_t, c_void_p]
+        L.sc_tucker_chain_backward_fused.restype = c_int
         L.sc_round_f16.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.sc_round_f16.restype = c_int
         L.sc_last_error.restype = c_char_p
@@ -438,6 +450,27 @@ class ScEngineLib:
         self._check(self.lib.sc_tucker_chain_backward(byref(TuckerChainDesc(*dims)), xhat, u_in, t3, u_out, z, t, gy, gxhat,
                                                       gu_in, gt3, gu_out, ws, ws_bytes, stream))
 
+    # ---- the chain as one launch each way (round 5; include/sc_engine.h)
+    def tucker_chain_fused_supported(self, dims):
+        return bool(self.lib.sc_tucker_chain_fused_supported(byref(TuckerChainDesc(*dims))))
+
+    def tucker_chain_t3m_bytes(self, dims):
+        return int(self.lib.sc_tucker_chain_t3m_bytes(byref(TuckerChainDesc(*dims))))
+
+    def tucker_chain_forward_fused(self, dims, xhat, u_in, t3, u_out, t3m, z, t, yhat, stream=0):
+        """t3m (n_modes, r_in, r_out): written here, read by tucker_chain_backward_fused"""
+        self._check(self.lib.sc_tucker_chain_forward_fused(byref(TuckerChainDesc(*dims)), xhat, u_in, t3, u_out, t3m, z, t,
+                                                           yhat, stream))
+
+    def tucker_chain_backward_fused_workspace_bytes(self, dims):
+        return int(self.lib.sc_tucker_chain_backward_fused_workspace_bytes(byref(TuckerChainDesc(*dims))))
+
+    def tucker_chain_backward_fused(self, dims, xhat, u_in, t3m, u_out, z, t, gy, gxhat, gu_in, gt3, gu_out, ws, ws_bytes,
+                                    stream=0):
+        """gt3 is required; null (0) gxhat / gu_in / gu_out skip that gradient"""
+        self._check(self.lib.sc_tucker_chain_backward_fused(byref(TuckerChainDesc(*dims)), xhat, u_in, t3m, u_out, z, t, gy,
+                                                            gxhat, gu_in, gt3, gu_out, ws, ws_bytes, stream))
+
     def round_f16(self, in_ptr, out_ptr, n, stream=0):
         """out = float16(in) in fp32 storage (the cast points of fno_block_precision half / mixed)."""
         self._check(self.lib.sc_round_f16(in_ptr, out_ptr, n, stream))
@@ -521,5 +554,7 @@ def get_lib():
     """The product's engine library (HIP build); raises EngineError when it is not built."""
     global _LIB
     if _LIB is None:
-        _LIB = ScEngineLib(DEFAULT_LIB)
+        # SC_ENGINE_LIB: another BUILD of the same engine (scripts/build_variants.py: A-B measurements of compile-time
+        # switches through the whole module stack); a missing file fails as loudly as a missing default library
+        _LIB = ScEngineLib(os.environ.get("SC_ENGINE_LIB") or DEFAULT_LIB)
     return _LIB

@@ -29,6 +29,7 @@
 #include "sc_kernels_tucker.h"
 #include "sc_kernels_sb.h"
 #include "sc_kernels_fmx.h"
+#include "sc_kernels_tkchain.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -2523,6 +2524,104 @@ extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const flo
   guard.armed = false;
   if (side && !sc_side_join(side, main)) return sc_fail(sync_fail);                 // gu_in
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 5: the same nine products as ONE launch each way (sc_kernels_tkchain.h): a workgroup owns four modes for the
+// whole batch and walks the chain out of LDS; T3 travels as a mode-major copy T3m[m][f][g] the forward call writes and
+// the backward call reads.
+// ------------------------------------------------------------------------------------------
+static uint32_t tkc_inv(int64_t n) { return (uint32_t)((((uint64_t)1 << 32) + (uint64_t)n - 1) / (uint64_t)n); }
+static bool tkc_aligned(const void* p) { return ((uintptr_t)p & 15) == 0; }
+extern "C" int sc_tucker_chain_fused_supported(const sc_tucker_chain_desc* c) {
+  static const bool off = std::getenv("SC_TKC_OFF") != nullptr;          // A-B against the nine launches
+  if (off || !tkc_valid(c)) return 0;
+  if (c->batch > 32 || c->c_in > 64 || c->c_out > 64 || c->r_in > 48 || c->r_out > 48) return 0;
+  if ((c->batch | c->c_in | c->c_out | c->r_in | c->r_out | c->n_modes) & 3) return 0;
+  if (c->n_modes / 4 >= ((int64_t)1 << 30)) return 0;
+  const size_t lf = (size_t)tkc_layout((int)c->batch, (int)c->c_in, (int)c->c_out, (int)c->r_in, (int)c->r_out, false).total,
+               lb = (size_t)tkc_layout((int)c->batch, (int)c->c_in, (int)c->c_out, (int)c->r_in, (int)c->r_out, true).total;
+  return (lf > lb ? lf : lb) * sizeof(cf32) <= (size_t)160 * 1024 ? 1 : 0;
+}
+static void tkc_args(const sc_tucker_chain_desc* c, TkcArgs& g) {
+  std::memset(&g, 0, sizeof(g));
+  g.B = (int)c->batch; g.Ci = (int)c->c_in; g.Co = (int)c->c_out; g.R1 = (int)c->r_in; g.R2 = (int)c->r_out;
+  g.M = c->n_modes;
+  g.n_tiles = (int)(c->n_modes / 4);
+  // persistent: one workgroup per compute unit (a tile needs ~147 KB of LDS); SC_TKC_WGS (environment, A-B)
+  static const int env = [] { const char* e = std::getenv("SC_TKC_WGS"); return e ? std::atoi(e) : 0; }();
+  const int cap = env > 0 ? env : sc_cu_count();
+  g.n_wg = g.n_tiles < cap ? g.n_tiles : cap;
+  g.inv_ci = tkc_inv(g.Ci); g.inv_co = tkc_inv(g.Co); g.inv_r1 = tkc_inv(g.R1); g.inv_r2 = tkc_inv(g.R2);
+  g.inv_r12 = tkc_inv((int64_t)g.R1 * g.R2);
+}
+static int tkc_transpose(const cf32* in, cf32* out, int64_t rows, int64_t cols, sc_stream_t st) {
+  const int64_t tr = (rows + 31) / 32, tc = (cols + 31) / 32;
+  if (tr * tc >= ((int64_t)1 << 31)) return sc_fail("sc_tucker_chain: transpose grid too large");
+  SC_LAUNCH(k_tkc_transpose, dim3((unsigned)(tr * tc)), dim3(256), 0, st, in, out, rows, cols, (int)tc);
+  return sc_check_launch("k_tkc_transpose");
+}
+extern "C" size_t sc_tucker_chain_t3m_bytes(const sc_tucker_chain_desc* c) {
+  return tkc_valid(c) ? (size_t)c->n_modes * c->r_in * c->r_out * sizeof(cf32) : 0;
+}
+extern "C" int sc_tucker_chain_forward_fused(const sc_tucker_chain_desc* c, const float* xhat, const float* u_in,
+                                             const float* t3, const float* u_out, float* t3m, float* z, float* t,
+                                             float* yhat, void* stream) {
+  SC_CHECK_ARG(tkc_valid(c), "sc_tucker_chain: null or empty descriptor");
+  SC_CHECK_ARG(xhat && u_in && t3 && u_out && t3m && z && t && yhat, "null argument");
+  SC_CHECK_ARG(sc_tucker_chain_fused_supported(c), "sc_tucker_chain_forward_fused: shape outside the fused kernels' limits");
+  SC_CHECK_ARG(tkc_aligned(xhat) && tkc_aligned(t3m) && tkc_aligned(z) && tkc_aligned(t) && tkc_aligned(yhat),
+               "sc_tucker_chain_forward_fused: 16-byte aligned tensors");
+  sc_stream_t st = (sc_stream_t)stream;
+  int rc = tkc_transpose((const cf32*)t3, (cf32*)t3m, c->r_in * c->r_out, c->n_modes, st);
+  if (rc) return rc;
+  TkcArgs g;
+  tkc_args(c, g);
+  g.xhat = (const cf32*)xhat; g.u_in = (const cf32*)u_in; g.t3m = (const cf32*)t3m; g.u_out = (const cf32*)u_out;
+  g.z = (cf32*)z; g.t = (cf32*)t; g.yhat = (cf32*)yhat;
+  const size_t lds = (size_t)tkc_layout(g.B, g.Ci, g.Co, g.R1, g.R2, false).total * sizeof(cf32);
+  SC_FMX_ATTR((k_tkc_fwd<16, 18>), lds);
+  SC_LAUNCH((k_tkc_fwd<16, 18>), dim3((unsigned)g.n_wg), dim3(256), lds, st, g);
+  return sc_check_launch("k_tkc_fwd");
+}
+extern "C" size_t sc_tucker_chain_backward_fused_workspace_bytes(const sc_tucker_chain_desc* c) {
+  if (!tkc_valid(c)) return 0;
+  TkcArgs g;
+  tkc_args(c, g);
+  return tkc_align(sc_tucker_chain_t3m_bytes(c)) +
+         tkc_align((size_t)g.n_wg * ((size_t)c->c_out * c->r_out + (size_t)c->c_in * c->r_in) * sizeof(cf32)) + 512;
+}
+extern "C" int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* c, const float* xhat, const float* u_in,
+                                              const float* t3m, const float* u_out, const float* z, const float* t,
+                                              const float* gy, float* gxhat, float* gu_in, float* gt3, float* gu_out,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  SC_CHECK_ARG(tkc_valid(c), "sc_tucker_chain: null or empty descriptor");
+  SC_CHECK_ARG(xhat && u_in && t3m && u_out && z && t && gy && gt3 && workspace, "null argument");
+  SC_CHECK_ARG(sc_tucker_chain_fused_supported(c), "sc_tucker_chain_backward_fused: shape outside the fused kernels' limits");
+  SC_CHECK_ARG(workspace_bytes >= sc_tucker_chain_backward_fused_workspace_bytes(c), "workspace too small");
+  SC_CHECK_ARG(tkc_aligned(xhat) && tkc_aligned(t3m) && tkc_aligned(z) && tkc_aligned(t) && tkc_aligned(gy) &&
+               (!gxhat || tkc_aligned(gxhat)), "sc_tucker_chain_backward_fused: 16-byte aligned tensors");
+  sc_stream_t st = (sc_stream_t)stream;
+  unsigned char* w0 = (unsigned char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  TkcArgs g;
+  tkc_args(c, g);
+  g.xhat = (const cf32*)xhat; g.u_in = (const cf32*)u_in; g.t3m = (const cf32*)t3m; g.u_out = (const cf32*)u_out;
+  g.zin = (const cf32*)z; g.tin = (const cf32*)t; g.gy = (const cf32*)gy; g.gxhat = (cf32*)gxhat;
+  g.gt3m = (cf32*)w0;
+  g.partial = (cf32*)(w0 + tkc_align(sc_tucker_chain_t3m_bytes(c)));
+  const size_t lds = (size_t)tkc_layout(g.B, g.Ci, g.Co, g.R1, g.R2, true).total * sizeof(cf32);
+  SC_FMX_ATTR((k_tkc_bwd<16, 12, 18>), lds);
+  SC_LAUNCH((k_tkc_bwd<16, 12, 18>), dim3((unsigned)g.n_wg), dim3(256), lds, st, g);
+  int rc = sc_check_launch("k_tkc_bwd");
+  if (rc) return rc;
+  if ((rc = tkc_transpose((const cf32*)g.gt3m, (cf32*)gt3, c->n_modes, c->r_in * c->r_out, st))) return rc;
+  if (gu_in || gu_out) {
+    const int n_out = g.Co * g.R2, n_all = n_out + g.Ci * g.R1;
+    SC_LAUNCH(k_tkc_reduce, dim3((unsigned)((n_all + 15) / 16)), dim3(256), 0, st, (const cf32*)g.partial, g.n_wg, n_out,
+              n_all, (cf32*)gu_out, (cf32*)gu_in);
+    rc = sc_check_launch("k_tkc_reduce");
+  }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -265,10 +265,19 @@ SC_DEVICE void tk_zero(TkAcc& t) {
 // and  Re C = P1 - sa sb P2,  Im C = P3 - P1 - sa sb P2  (tk_result).
 // The operands of step s + 1 are requested before the MFMAs of step s are issued -- without a branch around the
 // requests (the compiler would wait for every outstanding read at the join): the last step re-reads itself.
-template <int NT, bool SHARE_A, bool CA, bool CB>
+// Round 5 (sc_kernels_tkchain.h): GA / GB = that operand lives in GLOBAL memory (a small table every workgroup reads:
+// the channel factor matrices, L1 / L2 resident) and is loaded straight into the MFMA operand layout -- same loop, the
+// request one k step ahead covers an L1 / L2 hit (a step is 3 NT matrix instructions = 96 NT cycles).
+template <bool G>
+SC_DEVICE cf32 tk_ld(const cf32* p) {
+  if constexpr (G) return *p;
+  else return sc_lds_ld64(p);
+}
+template <int NT, bool SHARE_A, bool CA, bool CB, bool GA = false, bool GB = false>
 SC_DEVICE void tk_multi(const cf32* A, const int a_si, const int a_sk, const cf32* B, const int b_sk, const int b_sj,
                         const int i0, const int j0, const int M, const int N, const int K, const int lane,
                         TkAcc (&acc)[NT], const int abl = 0) {
+  constexpr bool GSH = SHARE_A ? GA : GB, GMU = SHARE_A ? GB : GA;   // where the shared / the NT other operands live
   const int li = lane & 15, kq = lane >> 4;
   const int ns = (abl & 1) ? 0 : (K + 3) >> 2;
   if (ns == 0) return;
@@ -301,19 +310,19 @@ SC_DEVICE void tk_multi(const cf32* A, const int a_si, const int a_sk, const cf3
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int u = 0; u < 3; ++u) p[t][u] = acc[t].p[u];
-  cf32 sv = sc_lds_ld64(sp), mv[NT];
+  cf32 sv = tk_ld<GSH>(sp), mv[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) mv[t] = sc_lds_ld64(mp[t]);
+  for (int t = 0; t < NT; ++t) mv[t] = tk_ld<GMU>(mp[t]);
   constexpr bool CS = SHARE_A ? CA : CB, CM = SHARE_A ? CB : CA;    // conjugation of the shared / the other operand
   for (int st = 0; st < ns; ++st) {
     const int adv = st + 1 < ns ? 1 : 0;                     // uniform select
     sp += adv * s_step;
-    const cf32 sn = sc_lds_ld64(sp);
+    const cf32 sn = tk_ld<GSH>(sp);
     cf32 mn[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       mp[t] += adv * m_step;
-      mn[t] = sc_lds_ld64(mp[t]);
+      mn[t] = tk_ld<GMU>(mp[t]);
     }
     const float s3 = CS ? sv.x - sv.y : sv.x + sv.y;
     float m3[NT];

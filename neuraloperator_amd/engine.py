@@ -627,18 +627,35 @@ class TuckerChainFn(torch.autograd.Function):
         t = torch.empty((b, r2, m), dtype=torch.complex64, device=dev)
         yhat = torch.empty((b, co, m), dtype=torch.complex64, device=dev)
         ctx.dims = (b, ci, co, r1, r2, m)
+        ctx.fused = False
+        t3m = None
         if b and m:
-            # ONE host call for the three products (round 3, session 2: sc_tucker_chain_forward issues the same three
-            # sc_modegemm launches from C++; a factorized step was ~0.6-0.76 ms of interpreter time per 0.76 ms of device time)
+            lib = _lib.get_lib()
             with torch.cuda.device(dev):
-                _lib.get_lib().tucker_chain_forward(ctx.dims, xhat.data_ptr(), u_in.data_ptr(), t3.data_ptr(), u_out.data_ptr(),
-                                                    z.data_ptr(), t.data_ptr(), yhat.data_ptr(), _stream())
-        ctx.save_for_backward(xhat, u_in, t3, u_out, z, t)
+                # round 5: ONE launch for the three products where the shape fits (batch <= 32, <= 64 channels, ranks <= 48,
+                # extents multiples of 4 -- BASELINE configs[2]): a workgroup walks xhat -> z -> t -> yhat for four modes out of
+                # LDS (csrc/sc_kernels_tkchain.h); t3m = the mode-major copy of t3 that call writes and the backward call reads
+                ctx.fused = lib.tucker_chain_fused_supported(ctx.dims) and all(
+                    v.data_ptr() % 16 == 0 for v in (xhat, z, t, yhat))
+                if ctx.fused:
+                    t3m = torch.empty((m, r1, r2), dtype=torch.complex64, device=dev)
+                    lib.tucker_chain_forward_fused(ctx.dims, xhat.data_ptr(), u_in.data_ptr(), t3.data_ptr(), u_out.data_ptr(),
+                                                   t3m.data_ptr(), z.data_ptr(), t.data_ptr(), yhat.data_ptr(), _stream())
+                else:
+                    # ONE host call for the three products (round 3, session 2: sc_tucker_chain_forward issues the same three
+                    # sc_modegemm launches from C++; a factorized step was ~0.6-0.76 ms of interpreter time per 0.76 ms of
+                    # device time)
+                    lib.tucker_chain_forward(ctx.dims, xhat.data_ptr(), u_in.data_ptr(), t3.data_ptr(), u_out.data_ptr(),
+                                             z.data_ptr(), t.data_ptr(), yhat.data_ptr(), _stream())
+        if t3m is not None:
+            ctx.save_for_backward(xhat, u_in, t3, u_out, z, t, t3m)
+        else:
+            ctx.save_for_backward(xhat, u_in, t3, u_out, z, t)
         return yhat
 
     @staticmethod
     def backward(ctx, gy):
-        xhat, u_in, t3, u_out, z, t = ctx.saved_tensors
+        xhat, u_in, t3, u_out, z, t = ctx.saved_tensors[:6]
         b, ci, co, r1, r2, m = ctx.dims
         gy = (gy if gy.dtype == torch.complex64 else gy.to(torch.complex64)).contiguous()
         need = ctx.needs_input_grad
@@ -651,6 +668,19 @@ class TuckerChainFn(torch.autograd.Function):
         if b and m:
             lib = _lib.get_lib()
             p = lambda v: 0 if v is None else v.data_ptr()
+            if ctx.fused and gy.data_ptr() % 16 == 0:
+                # one launch: gy -> gt -> gz -> gxhat per four-mode tile, the t3 gradient mode-major (transposed back by the
+                # call), the two factor gradients as per-workgroup partial sums reduced in fixed order.  The kernel always
+                # forms the t3 gradient, so a scratch tensor stands in when autograd does not ask for it.
+                t3m = ctx.saved_tensors[6]
+                with torch.cuda.device(dev):
+                    nb = lib.tucker_chain_backward_fused_workspace_bytes(ctx.dims)
+                    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    gt3_out = gt3 if gt3 is not None else new(r1, r2, m)
+                    lib.tucker_chain_backward_fused(ctx.dims, xhat.data_ptr(), u_in.data_ptr(), t3m.data_ptr(), u_out.data_ptr(),
+                                                    z.data_ptr(), t.data_ptr(), gy.data_ptr(), p(gx), p(gu_in),
+                                                    gt3_out.data_ptr(), p(gu_out), ws.data_ptr(), nb, _stream())
+                return gx, gu_in, gt3, gu_out
             with torch.cuda.device(dev):
                 nb = lib.tucker_chain_workspace_bytes(ctx.dims)
                 ws = torch.empty(nb, dtype=torch.uint8, device=dev)
