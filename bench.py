@@ -1082,6 +1082,8 @@ def main():
             "roofline": roof,
             "step_roofline": {"alg_bytes_per_step": total, "achieved_GBs": round(step_gbs, 1),
                               "frac_of_8TBs": round(step_gbs / HBM_PEAK_GBS, 4),
+                              # the same figure for the contract's FIRST timed region (before the clocks have settled)
+                              "frac_of_8TBs_cold_start": round(total / ms_cold / 1e6 / HBM_PEAK_GBS, 4),
                               "frac_of_measured_copy": round(step_gbs / copy_gbs, 4),
                               "formula": "4R+3Wb+9S (SURVEY.md 8d), per GPU" +
                                          (", R at 2 bytes per value" if args.io == "bf16" else ""),

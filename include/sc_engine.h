@@ -282,8 +282,11 @@ int sc_tucker_chain_backward(const sc_tucker_chain_desc* d, const float* xhat, c
  *   backward workspace: sc_tucker_chain_backward_fused_workspace_bytes (the mode-major gradient of t3 + one partial
  *        sum of both factor gradients per workgroup).  gt3 is required; gxhat / gu_in / gu_out may be null.
  * Same arithmetic as the nine launches (exact-fp32 16 x 16 x 4 matrix tiles, three real products per complex product);
- * the factor gradients are summed in a different (fixed) order.  All tensors 16-byte aligned.  SC_TKC_OFF=1
- * (environment) makes sc_tucker_chain_fused_supported return 0. */
+ * the factor gradients are summed in a different (fixed) order.  All tensors 16-byte aligned.
+ * OPT-IN: sc_tucker_chain_fused_supported returns 0 unless SC_TKC=1 is set in the environment -- measured on MI355X
+ * at configs[2] the fused kernels are as accurate as the nine launches and slower (forward 104-114 us against 68.6 us,
+ * backward 182-195 us against 139 us; profiles/r05_tkchain_ab.txt), so callers keep the nine
+ * launches by default. */
 int sc_tucker_chain_fused_supported(const sc_tucker_chain_desc* d);
 size_t sc_tucker_chain_t3m_bytes(const sc_tucker_chain_desc* d);
 int sc_tucker_chain_forward_fused(const sc_tucker_chain_desc* d, const float* xhat, const float* u_in, const float* t3,

@@ -2534,8 +2534,12 @@ extern "C" int sc_tucker_chain_backward(const sc_tucker_chain_desc* c, const flo
 static uint32_t tkc_inv(int64_t n) { return (uint32_t)((((uint64_t)1 << 32) + (uint64_t)n - 1) / (uint64_t)n); }
 static bool tkc_aligned(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int sc_tucker_chain_fused_supported(const sc_tucker_chain_desc* c) {
-  static const bool off = std::getenv("SC_TKC_OFF") != nullptr;          // A-B against the nine launches
-  if (off || !tkc_valid(c)) return 0;
+  // OPT-IN (SC_TKC=1): measured on MI355X at configs[2] the one-launch-each-way kernels are as accurate as the nine
+  // launches and SLOWER -- forward 104-114 us against 68.6 us, backward 182-195 us against 139 us
+  // (profiles/r05_tkchain_ab.txt: 55 / 80 us of that is the staging / emit skeleton of 32-byte pieces with one
+  // workgroup per compute unit, and 528 four-mode tiles on 256 units are three rounds where 2.06 would do).
+  const char* e = std::getenv("SC_TKC");                  // read per call: tests switch it inside one process
+  if (!(e && std::atoi(e) != 0) || !tkc_valid(c)) return 0;
   if (c->batch > 32 || c->c_in > 64 || c->c_out > 64 || c->r_in > 48 || c->r_out > 48) return 0;
   if ((c->batch | c->c_in | c->c_out | c->r_in | c->r_out | c->n_modes) & 3) return 0;
   if (c->n_modes / 4 >= ((int64_t)1 << 30)) return 0;
@@ -2554,6 +2558,7 @@ static void tkc_args(const sc_tucker_chain_desc* c, TkcArgs& g) {
   g.n_wg = g.n_tiles < cap ? g.n_tiles : cap;
   g.inv_ci = tkc_inv(g.Ci); g.inv_co = tkc_inv(g.Co); g.inv_r1 = tkc_inv(g.R1); g.inv_r2 = tkc_inv(g.R2);
   g.inv_r12 = tkc_inv((int64_t)g.R1 * g.R2);
+  g.abl = tucker_abl();
 }
 static int tkc_transpose(const cf32* in, cf32* out, int64_t rows, int64_t cols, sc_stream_t st) {
   const int64_t tr = (rows + 31) / 32, tc = (cols + 31) / 32;

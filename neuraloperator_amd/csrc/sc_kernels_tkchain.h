@@ -49,6 +49,7 @@ struct TkcArgs {
   int64_t M;
   int n_tiles, n_wg;
   uint32_t inv_ci, inv_co, inv_r1, inv_r2, inv_r12;   // ceil(2^32 / n)
+  int abl;                         // measurement only (SC_TK_ABL): 1 = no k loops, 2 = no tile stores, 4 = no staging loads / emits
 };
 
 struct TkcLayout {       // complex elements
@@ -223,9 +224,9 @@ k_tkc_fwd(TkcArgs g) {
       TkAcc a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) tk_zero(a[k]);
-      tk_multi<3, true, false, false, false, true>(Xw, L.ldi, 1, g.u_in, g.R1, 1, 16 * rt, 0, g.B, g.R1, g.Ci, lane, a);
+      tk_multi<3, true, false, false, false, true>(Xw, L.ldi, 1, g.u_in, g.R1, 1, 16 * rt, 0, g.B, g.R1, g.Ci, lane, a, g.abl);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tk_store<false>(a[k], Zw, L.ld1, 16 * rt, 16 * k, g.B, g.R1, lane);
+      for (int k = 0; k < 3; ++k) tk_store<false>(a[k], Zw, L.ld1, 16 * rt, 16 * k, g.B, g.R1, lane, g.abl);
     }
     SC_WAVE_SYNC();
     // ---- t_w = z_w T3_w  (B(k = f, j = g) = T3[g][f])
@@ -234,9 +235,9 @@ k_tkc_fwd(TkcArgs g) {
       TkAcc a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) tk_zero(a[k]);
-      tk_multi<3, true, false, false>(Zw, L.ld1, 1, T3 + w * L.PT, 1, L.ldt, 16 * rt, 0, g.B, g.R2, g.R1, lane, a);
+      tk_multi<3, true, false, false>(Zw, L.ld1, 1, T3 + w * L.PT, 1, L.ldt, 16 * rt, 0, g.B, g.R2, g.R1, lane, a, g.abl);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tk_store<false>(a[k], Tw, L.ld2, 16 * rt, 16 * k, g.B, g.R2, lane);
+      for (int k = 0; k < 3; ++k) tk_store<false>(a[k], Tw, L.ld2, 16 * rt, 16 * k, g.B, g.R2, lane, g.abl);
     }
     SC_SYNC();                                       // every wave's z and t planes are complete
     { const int tid = sc_opaque(SC_TID);
@@ -249,9 +250,9 @@ k_tkc_fwd(TkcArgs g) {
       TkAcc a[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) tk_zero(a[k]);
-      tk_multi<4, true, false, false, false, true>(Tw, L.ld2, 1, g.u_out, 1, g.R2, 16 * rt, 0, g.B, g.Co, g.R2, lane, a);
+      tk_multi<4, true, false, false, false, true>(Tw, L.ld2, 1, g.u_out, 1, g.R2, 16 * rt, 0, g.B, g.Co, g.R2, lane, a, g.abl);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tk_store<false>(a[k], YP + w * PY, L.ldo, 16 * rt, 16 * k, g.B, g.Co, lane);
+      for (int k = 0; k < 4; ++k) tk_store<false>(a[k], YP + w * PY, L.ldo, 16 * rt, 16 * k, g.B, g.Co, lane, g.abl);
     }
     SC_SYNC();
     tkc_emit(YP, PY, L.ldo, g.B * g.Co, g.Co, g.inv_co, g.yhat, g.M, m0, sc_opaque(SC_TID));
@@ -301,15 +302,15 @@ k_tkc_bwd(TkcArgs g) {
       TkAcc a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) tk_zero(a[k]);
-      tk_multi<3, true, false, true, false, true>(RA + w * L.PA, L.ldo, 1, g.u_out, g.R2, 1, 16 * rt, 0, g.B, g.R2, g.Co, lane, a);
+      tk_multi<3, true, false, true, false, true>(RA + w * L.PA, L.ldo, 1, g.u_out, g.R2, 1, 16 * rt, 0, g.B, g.R2, g.Co, lane, a, g.abl);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tk_store<true>(a[k], RC + w * PC, L.ld2, 16 * rt, 16 * k, g.B, g.R2, lane);
+      for (int k = 0; k < 3; ++k) tk_store<true>(a[k], RC + w * PC, L.ld2, 16 * rt, 16 * k, g.B, g.R2, lane, g.abl);
     }
     // ---- gu_out[o][g] += sum_b gy_m[b][o] conj(t_m[b][g]), rows o = 16 w .., all four modes
     if (own_o) {
 #pragma unroll 1
       for (int m = 0; m < 4; ++m)
-        tk_multi<3, true, false, true>(RA + m * L.PA, 1, L.ldo, RB + m * L.PB, L.ld2, 1, 16 * w, 0, g.Co, g.R2, g.B, lane, auo);
+        tk_multi<3, true, false, true>(RA + m * L.PA, 1, L.ldo, RB + m * L.PB, L.ld2, 1, 16 * w, 0, g.Co, g.R2, g.B, lane, auo, g.abl);
     }
     SC_SYNC();                                       // gy and t are dead (gt planes are wave-private)
     // ---- z -> B [b][ld1], T3 -> A [f][ldt]
@@ -330,9 +331,9 @@ k_tkc_bwd(TkcArgs g) {
         TkAcc a[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) tk_zero(a[k]);
-        tk_multi<3, true, true, false>(RB + w * L.PB, 1, L.ld1, RC + w * PC, L.ld2, 1, 16 * ft, 0, g.R1, g.R2, g.B, lane, a);
+        tk_multi<3, true, true, false>(RB + w * L.PB, 1, L.ld1, RC + w * PC, L.ld2, 1, 16 * ft, 0, g.R1, g.R2, g.B, lane, a, g.abl);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tk_store<true>(a[k], dst, g.R2, 16 * ft, 16 * k, g.R1, g.R2, lane);
+        for (int k = 0; k < 3; ++k) tk_store<true>(a[k], dst, g.R2, 16 * ft, 16 * k, g.R1, g.R2, lane, g.abl);
       }
     }
     SC_WAVE_SYNC();
@@ -342,10 +343,10 @@ k_tkc_bwd(TkcArgs g) {
       TkAcc a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) tk_zero(a[k]);
-      tk_multi<3, true, false, true>(RC + w * PC, L.ld2, 1, RA + w * L.PA, 1, L.ldt, 16 * rt, 0, g.B, g.R1, g.R2, lane, a);
+      tk_multi<3, true, false, true>(RC + w * PC, L.ld2, 1, RA + w * L.PA, 1, L.ldt, 16 * rt, 0, g.B, g.R1, g.R2, lane, a, g.abl);
       SC_WAVE_SYNC();                                // (rt = 0: every lane's reads of z_w in the product above are done)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tk_store<true>(a[k], RB + w * L.PB, L.ld1, 16 * rt, 16 * k, g.B, g.R1, lane);
+      for (int k = 0; k < 3; ++k) tk_store<true>(a[k], RB + w * L.PB, L.ld1, 16 * rt, 16 * k, g.B, g.R1, lane, g.abl);
     }
     SC_SYNC();                                       // T3 is dead, every gz plane is complete
     // ---- X -> A [b][ldi]
@@ -360,7 +361,7 @@ k_tkc_bwd(TkcArgs g) {
     if (own_i) {
 #pragma unroll 1
       for (int m = 0; m < 4; ++m)
-        tk_multi<3, true, true, false>(RA + m * L.PA, 1, L.ldi, RB + m * L.PB, L.ld1, 1, 16 * w, 0, g.Ci, g.R1, g.B, lane, aui);
+        tk_multi<3, true, true, false>(RA + m * L.PA, 1, L.ldi, RB + m * L.PB, L.ld1, 1, 16 * w, 0, g.Ci, g.R1, g.B, lane, aui, g.abl);
     }
     // ---- gxhat_w = gz_w u_in^H  (B(k = f, j = i) = conj u_in[i][f])  -> A_w [b][ldi] once X is dead
     if (g.gxhat) {
@@ -370,9 +371,9 @@ k_tkc_bwd(TkcArgs g) {
         TkAcc a[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) tk_zero(a[k]);
-        tk_multi<4, true, false, true, false, true>(RB + w * L.PB, L.ld1, 1, g.u_in, 1, g.R1, 16 * rt, 0, g.B, g.Ci, g.R1, lane, a);
+        tk_multi<4, true, false, true, false, true>(RB + w * L.PB, L.ld1, 1, g.u_in, 1, g.R1, 16 * rt, 0, g.B, g.Ci, g.R1, lane, a, g.abl);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tk_store<true>(a[k], RA + w * L.PA, L.ldi, 16 * rt, 16 * k, g.B, g.Ci, lane);
+        for (int k = 0; k < 4; ++k) tk_store<true>(a[k], RA + w * L.PA, L.ldi, 16 * rt, 16 * k, g.B, g.Ci, lane, g.abl);
       }
       SC_SYNC();
       tkc_emit(RA, L.PA, L.ldi, g.B * g.Ci, g.Ci, g.inv_ci, g.gxhat, g.M, m0, sc_opaque(SC_TID));
@@ -384,8 +385,8 @@ k_tkc_bwd(TkcArgs g) {
   cf32* pi = po + g.Co * g.R2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    if (own_o) tk_store<true>(auo[k], po, g.R2, 16 * w, 16 * k, g.Co, g.R2, lane);
-    if (own_i) tk_store<true>(aui[k], pi, g.R1, 16 * w, 16 * k, g.Ci, g.R1, lane);
+    if (own_o) tk_store<true>(auo[k], po, g.R2, 16 * w, 16 * k, g.Co, g.R2, lane, g.abl);
+    if (own_i) tk_store<true>(aui[k], pi, g.R1, 16 * w, 16 * k, g.Ci, g.R1, lane, g.abl);
   }
 }
 

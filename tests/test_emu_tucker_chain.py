@@ -73,6 +73,8 @@ def test_tucker_chain_matches_einsum(lib, dims):
                          ids=lambda d: "B%d_Ci%d_Co%d_R%d_%d_M%d" % d)
 def test_fused_chain_matches_einsum_and_the_nine_launches(lib, dims, monkeypatch):
     B, Ci, Co, R1, R2, M = dims
+    assert not lib.tucker_chain_fused_supported(dims)          # opt-in: the nine launches are the (faster) default
+    monkeypatch.setenv("SC_TKC", "1")
     assert lib.tucker_chain_fused_supported(dims)
     xhat, u_in, t3, u_out = _rand(B, Ci, M, seed=1), _rand(Ci, R1, seed=2), _rand(R1, R2, M, seed=3), _rand(Co, R2, seed=4)
     gy = _rand(B, Co, M, seed=5)
@@ -118,5 +120,6 @@ def test_fused_chain_matches_einsum_and_the_nine_launches(lib, dims, monkeypatch
 
 @pytest.mark.parametrize("dims", [(3, 16, 12, 9, 7, 130), (64, 64, 64, 36, 36, 8), (4, 8, 8, 4, 8, 18), (4, 128, 8, 4, 8, 16)],
                          ids=lambda d: "B%d_Ci%d_Co%d_R%d_%d_M%d" % d)
-def test_fused_chain_refuses_shapes_outside_its_limits(lib, dims):
+def test_fused_chain_refuses_shapes_outside_its_limits(lib, dims, monkeypatch):
+    monkeypatch.setenv("SC_TKC", "1")
     assert not lib.tucker_chain_fused_supported(dims)

@@ -126,8 +126,8 @@ def test_c5_literal_shape_vs_oracle(lib):
 
 
 @pytest.mark.parametrize("b", [4, 32], ids=["B4", "B32_bench_batch"])
-@pytest.mark.parametrize("impl", ["factorized", "reconstructed"])
-def test_tfno_tucker_rank01_at_config(impl, b):
+@pytest.mark.parametrize("impl", ["factorized", "factorized_fused_chain", "reconstructed"])
+def test_tfno_tucker_rank01_at_config(impl, b, monkeypatch):
     """BASELINE configs[2]: TFNO2d Tucker rank 0.1 at C=64, 256^2, modes (64,64) -> ranks (36,36,36,19), through
     the drop-in module; reference = the oracle's pairwise contraction (SURVEY 8 row a6 order) with autograd.
     B = 32 is the batch `extra.tfno_rank01` of the bench line runs (the per-mode products take other kernel routes
@@ -138,6 +138,9 @@ def test_tfno_tucker_rank01_at_config(impl, b):
     dev = torch.device("cuda:0")
     torch.manual_seed(99)
     c, n = 64, 256
+    if impl == "factorized_fused_chain":                  # round 5: the opt-in one-launch-each-way chain through the module
+        monkeypatch.setenv("SC_TKC", "1")
+        impl = "factorized"
     conv = SpectralConv(c, c, (64, 64), factorization="Tucker", rank=0.1, implementation=impl).to(dev)
     assert tuple(conv.weight.core.shape) == (36, 36, 36, 19)
     with torch.no_grad():
@@ -166,6 +169,57 @@ def test_tfno_tucker_rank01_at_config(impl, b):
         errs[f"g_factor_{i}"] = rel_l2(conv.weight.factors[i].grad.cpu().numpy(), f.grad.numpy())
     print(impl, " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     assert all(np.isfinite(v) and v < TOL for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("dims", [(32, 64, 64, 36, 36, 2112), (4, 64, 64, 36, 36, 2112), (16, 32, 48, 20, 28, 1000)],
+                         ids=lambda d: "B%d_Ci%d_Co%d_R%d_%d_M%d" % d)
+def test_fused_tucker_chain_on_device(dims, monkeypatch):
+    """The fused chain kernels (csrc/sc_kernels_tkchain.h) through the C-ABI at configs[2]'s literal extents (persistent
+    workgroups over 528 four-mode tiles, three rounds on some units) against a complex128 einsum on the device: z, t,
+    yhat and all four gradients; two backward calls give identical bits (fixed-order reduction of the factor
+    gradients); the nine launches of rounds 3-4 agree to round-off."""
+    from neuraloperator_amd import _lib
+    lib = _lib.get_lib()
+    dev = torch.device("cuda:0")
+    B, Ci, Co, R1, R2, M = dims
+    monkeypatch.setenv("SC_TKC", "1")                     # opt-in path (slower than the nine launches: DESIGN 8)
+    assert lib.tucker_chain_fused_supported(dims)
+    torch.manual_seed(5)
+    rnd = lambda *sh: torch.randn(*sh, dtype=torch.complex64, device=dev)
+    xhat, u_in, t3, u_out, gy = rnd(B, Ci, M), rnd(Ci, R1), rnd(R1, R2, M), rnd(Co, R2), rnd(B, Co, M)
+    new = lambda *sh: torch.full(sh, float("nan"), dtype=torch.complex64, device=dev)
+    p = lambda v: v.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    z, t, yhat, t3m = new(B, R1, M), new(B, R2, M), new(B, Co, M), new(M, R1, R2)
+    lib.tucker_chain_forward_fused(dims, p(xhat), p(u_in), p(t3), p(u_out), p(t3m), p(z), p(t), p(yhat), st)
+    assert torch.equal(torch.view_as_real(t3m), torch.view_as_real(t3.permute(2, 0, 1).contiguous()))
+    c = lambda v: v.to(torch.complex128)
+    Z = torch.einsum("bim,if->bfm", c(xhat), c(u_in))
+    T = torch.einsum("bfm,fgm->bgm", Z, c(t3))
+    Y = torch.einsum("bgm,og->bom", T, c(u_out))
+    rel = lambda a, b: float((c(a) - b).norm() / b.norm())
+    errs = dict(z=rel(z, Z), t=rel(t, T), yhat=rel(yhat, Y))
+    gT = torch.einsum("bom,og->bgm", c(gy), c(u_out).conj())
+    gZ = torch.einsum("bgm,fgm->bfm", gT, c(t3).conj())
+    ref = dict(gx=torch.einsum("bfm,if->bim", gZ, c(u_in).conj()), gt3=torch.einsum("bfm,bgm->fgm", Z.conj(), gT),
+               gu_in=torch.einsum("bim,bfm->if", c(xhat).conj(), gZ), gu_out=torch.einsum("bgm,bom->og", T.conj(), c(gy)))
+    nb = lib.tucker_chain_backward_fused_workspace_bytes(dims)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    runs = []
+    for _ in range(2):
+        got = dict(gx=new(B, Ci, M), gu_in=new(Ci, R1), gt3=new(R1, R2, M), gu_out=new(Co, R2))
+        lib.tucker_chain_backward_fused(dims, p(xhat), p(u_in), p(t3m), p(u_out), p(z), p(t), p(gy), p(got["gx"]), p(got["gu_in"]),
+                                        p(got["gt3"]), p(got["gu_out"]), ws.data_ptr(), nb, st)
+        runs.append(got)
+    torch.cuda.synchronize()
+    for k in ref:
+        errs[k] = rel(runs[0][k], ref[k])
+        assert torch.equal(torch.view_as_real(runs[0][k]), torch.view_as_real(runs[1][k])), k
+    z9, t9, y9 = new(B, R1, M), new(B, R2, M), new(B, Co, M)
+    lib.tucker_chain_forward(dims, p(xhat), p(u_in), p(t3), p(u_out), p(z9), p(t9), p(y9), st)
+    errs["yhat_vs_nine_launches"] = rel(yhat, c(y9))
+    print(dims, " ".join(f"{k}={v:.1e}" for k, v in errs.items()))
+    assert all(np.isfinite(v) and v < 3e-6 for v in errs.values()), errs
 
 
 def _structured(kind, b, c, n, gen):
