@@ -81,6 +81,10 @@ def parse():
                          "`--parallel modeshard --workload fno3d_128_m32_c32_b1 --chunk-dim channels` on ONE GPU = the "
                          "per-rank compute of configs[3] strong-scaled over 8 GPUs, chunked launches included "
                          "(a one-rank RCCL group: the exchanges degenerate to device copies)")
+    ap.add_argument("--a2a", default="auto", choices=["auto", "torch", "native", "peer"],
+                    help="modeshard: who moves the exchanges -- auto (torch.distributed, the engine's own RCCL binding inside "
+                         "hipGraph steps), torch, native (mpu/rccl_native.py), peer (round 5, opt-in: direct stores into the "
+                         "peers' HIP-IPC-mapped windows, mpu/peer_exchange.py; unmeasured on more than one GPU)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra.* measurements")
     ap.add_argument("--no-gpu-reference", action="store_true", help="skip gpu_reference_baseline")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
@@ -886,6 +890,8 @@ def main():
         if engine.get_plan_bf16_io(dev, list(spatial), kept_chk, "forward", flags) is None:
             raise SystemExit(f"--io bf16: {args.workload} does not run on the fused 2-D kernels (no bf16 I/O there)")
 
+    if args.a2a != "auto":
+        os.environ["SC_MPU_A2A"] = args.a2a               # read by mpu/rccl_native.py and mpu/peer_exchange.py
     if dist is not None and not share:
         # every step of a run with collectives is issued under a NON-default stream: on this stack a mode-parallel step
         # whose exchanges were ordered against torch's default (legacy null) stream makes a LATER capture of the layer
@@ -1101,10 +1107,12 @@ def main():
                                      "10-25 % slower)"},
         }
         if world > 1 or parallel == "modeshard":
-            from neuraloperator_amd.mpu import rccl_native
+            from neuraloperator_amd.mpu import peer_exchange, rccl_native
             native = rccl_native.active()
             out["collectives"] = {"backend": "gloo (SC_BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL over xGMI)",
-                                  "issued_by": "ncclAllToAll / ncclSend+ncclRecv straight on HIP streams (mpu/rccl_native.py)"
+                                  "issued_by": "peer stores into HIP-IPC-mapped windows, two engine launches per exchange "
+                                               "(mpu/peer_exchange.py)" if peer_exchange.active() else
+                                               "ncclAllToAll / ncclSend+ncclRecv straight on HIP streams (mpu/rccl_native.py)"
                                                if native else "torch.distributed" +
                                                (f" ({rccl_native.LAST_REASON})" if rccl_native.LAST_REASON else ""),
                                   # a replay runs the recorded exchanges: counted while the step was captured

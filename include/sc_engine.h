@@ -297,6 +297,31 @@ int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* d, const float* x
                                    float* gu_in, float* gt3, float* gu_out, void* workspace, size_t workspace_bytes,
                                    void* stream);
 
+/* ---- peer-store exchange of the mode-parallel layer (round 5, csrc/sc_kernels_peer.h; OPT-IN) ---------------------------
+ * The all-to-all "split modes, cat batch" of the mode-sharded layer (the shape contract of neuralop/mpu/helpers.py:81-99,
+ * which the reference defines and never calls) as direct stores into the peers' memory: every rank of ONE node owns a
+ * window -- fine-grained device memory, sc_peer_window_alloc -- whose 64-byte HIP IPC handle the host side hands to the
+ * other ranks (any transport), which map it with sc_peer_window_open.  sc_peer_all_to_all then issues two plain kernel
+ * launches on `stream`: block p of `send` ([world][block_bytes]) is stored into slot `rank` of peer p's window and this
+ * rank's epoch is written to slot `rank` of every peer's flags with system-scope release; the second launch waits until
+ * all `world` flags of THIS rank carry the epoch and copies the window into `recv` ([world][block_bytes], block p from
+ * rank p).  No host synchronisation, capturable into a hipGraph (the epoch lives in the window's header and advances
+ * per call).  Every rank must call it for every exchange, in the same order; a window may serve the next exchange of
+ * the same kind one layer step later (the layer's exchanges alternate directions -- csrc/sc_kernels_peer.h), the host
+ * side rotates a few windows.  peer_window[p] = the mapped base of rank p's window (own entry: the local pointer);
+ * world <= 8, block_bytes a multiple of 16, send / recv 16-byte aligned.  Unmeasured on more than one GPU (no multi-GPU
+ * tier in the build environment); self-tested with two processes on one device. */
+typedef struct sc_peer_exchange {
+  int32_t world, rank;
+  int64_t block_bytes;
+  void* peer_window[8];
+} sc_peer_exchange;
+int sc_peer_window_alloc(size_t data_bytes, void** ptr, void* handle64);
+int sc_peer_window_open(const void* handle64, void** ptr);
+int sc_peer_window_close(void* ptr);
+int sc_peer_window_free(void* ptr);
+int sc_peer_all_to_all(const sc_peer_exchange* d, const void* send, void* recv, void* stream);
+
 /* ---- pointwise half of an FNO block in one pass ("next" row f1 of SURVEY.md section 8) -------------------
  *   out = act( W2 gelu(W1 x + b1) + b2 + gate (.) skip_src )
  * replaces ChannelMLP.forward (neuralop/layers/channel_mlp.py:82-119: two Conv1d with kernel size 1 and a GELU),

@@ -92,6 +92,10 @@ class TuckerChainDesc(Structure):
                 ("n_modes", c_int64)]
 
 
+class PeerExchangeDesc(Structure):
+    _fields_ = [("world", c_int32), ("rank", c_int32), ("block_bytes", c_int64), ("peer_window", c_void_p * 8)]
+
+
 class PlinDesc(Structure):
     _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("spatial", c_int64)]
 
@@ -155,7 +159,8 @@ class ScEngineLib:
                "sc_transform_inverse_sharded", "sc_bias_grad_sharded", "sc_tucker_chain_forward",
                "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes", "sc_tucker_chain_fused_supported",
                "sc_tucker_chain_t3m_bytes", "sc_tucker_chain_forward_fused", "sc_tucker_chain_backward_fused",
-               "sc_tucker_chain_backward_fused_workspace_bytes"]
+               "sc_tucker_chain_backward_fused_workspace_bytes", "sc_peer_window_alloc", "sc_peer_window_open",
+               "sc_peer_window_close", "sc_peer_window_free", "sc_peer_all_to_all"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -264,6 +269,16 @@ class ScEngineLib:
         L.sc_tucker_chain_workspace_bytes.restype = c_size_t
         L.sc_tucker_chain_backward.argtypes = [POINTER(TuckerChainDesc)] + [c_void_p] * 12 + [c_size_t, c_void_p]
         L.sc_tucker_chain_backward.restype = c_int
+        L.sc_peer_window_alloc.argtypes = [c_size_t, POINTER(c_void_p), c_void_p]
+        L.sc_peer_window_alloc.restype = c_int
+        L.sc_peer_window_open.argtypes = [c_void_p, POINTER(c_void_p)]
+        L.sc_peer_window_open.restype = c_int
+        L.sc_peer_window_close.argtypes = [c_void_p]
+        L.sc_peer_window_close.restype = c_int
+        L.sc_peer_window_free.argtypes = [c_void_p]
+        L.sc_peer_window_free.restype = c_int
+        L.sc_peer_all_to_all.argtypes = [POINTER(PeerExchangeDesc), c_void_p, c_void_p, c_void_p]
+        L.sc_peer_all_to_all.restype = c_int
         L.sc_tucker_chain_fused_supported.argtypes = [POINTER(TuckerChainDesc)]
         L.sc_tucker_chain_fused_supported.restype = c_int
         L.sc_tucker_chain_t3m_bytes.argtypes = [POINTER(TuckerChainDesc)]
@@ -449,6 +464,30 @@ class ScEngineLib:
         """null (0) gradient pointers skip that gradient"""
         self._check(self.lib.sc_tucker_chain_backward(byref(TuckerChainDesc(*dims)), xhat, u_in, t3, u_out, z, t, gy, gxhat,
                                                       gu_in, gt3, gu_out, ws, ws_bytes, stream))
+
+    # ---- peer-store exchange (round 5; include/sc_engine.h)
+    def peer_window_alloc(self, data_bytes):
+        """-> (device pointer, 64-byte IPC handle) of a fresh fine-grained window"""
+        import ctypes
+        ptr, handle = c_void_p(), ctypes.create_string_buffer(64)
+        self._check(self.lib.sc_peer_window_alloc(data_bytes, byref(ptr), handle))
+        return int(ptr.value), handle.raw
+
+    def peer_window_open(self, handle):
+        import ctypes
+        ptr, buf = c_void_p(), ctypes.create_string_buffer(bytes(handle), 64)
+        self._check(self.lib.sc_peer_window_open(buf, byref(ptr)))
+        return int(ptr.value)
+
+    def peer_window_close(self, ptr):
+        self._check(self.lib.sc_peer_window_close(ptr))
+
+    def peer_window_free(self, ptr):
+        self._check(self.lib.sc_peer_window_free(ptr))
+
+    def peer_all_to_all(self, world, rank, block_bytes, peer_windows, send, recv, stream=0):
+        d = PeerExchangeDesc(world, rank, block_bytes, (c_void_p * 8)(*(list(peer_windows) + [None] * (8 - len(peer_windows)))))
+        self._check(self.lib.sc_peer_all_to_all(byref(d), send, recv, stream))
 
     # ---- the chain as one launch each way (round 5; include/sc_engine.h)
     def tucker_chain_fused_supported(self, dims):

@@ -30,6 +30,7 @@
 #include "sc_kernels_sb.h"
 #include "sc_kernels_fmx.h"
 #include "sc_kernels_tkchain.h"
+#include "sc_kernels_peer.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -2627,6 +2628,92 @@ extern "C" int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* c, con
     rc = sc_check_launch("k_tkc_reduce");
   }
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 5: peer-store exchange (sc_kernels_peer.h).  A window = 512 header bytes (flags [8] at 0, this rank's epoch at
+// 256, its workgroup ticket at 264) + the data; fine-grained device memory so that stores from a peer GPU and the flag
+// loads of the owner are coherent inside running kernels; shared through HIP IPC handles.
+// ------------------------------------------------------------------------------------------
+#define SC_PEER_HEADER 512
+extern "C" int sc_peer_window_alloc(size_t data_bytes, void** ptr, void* handle64) {
+  SC_CHECK_ARG(ptr && handle64 && data_bytes > 0, "null argument");
+  const size_t bytes = SC_PEER_HEADER + ((data_bytes + 255) & ~(size_t)255);
+  void* p = nullptr;
+#ifndef SC_EMU
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handle size");
+  SC_CHECK_HIP(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+  SC_CHECK_HIP(hipMemset(p, 0, bytes));
+  SC_CHECK_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  SC_CHECK_HIP(hipIpcGetMemHandle(&h, p));
+  std::memcpy(handle64, &h, 64);
+#else
+  p = std::calloc(bytes, 1);
+  std::memset(handle64, 0, 64);
+  std::memcpy(handle64, &p, sizeof(p));               // emulation: one process, the handle is the pointer
+#endif
+  *ptr = p;
+  return 0;
+}
+extern "C" int sc_peer_window_open(const void* handle64, void** ptr) {
+  SC_CHECK_ARG(ptr && handle64, "null argument");
+#ifndef SC_EMU
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle64, 64);
+  SC_CHECK_HIP(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+#else
+  std::memcpy(ptr, handle64, sizeof(*ptr));
+#endif
+  return 0;
+}
+extern "C" int sc_peer_window_close(void* ptr) {
+#ifndef SC_EMU
+  if (ptr) SC_CHECK_HIP(hipIpcCloseMemHandle(ptr));
+#endif
+  return 0;
+}
+extern "C" int sc_peer_window_free(void* ptr) {
+#ifndef SC_EMU
+  if (ptr) SC_CHECK_HIP(hipFree(ptr));
+#else
+  std::free(ptr);
+#endif
+  return 0;
+}
+extern "C" int sc_peer_all_to_all(const sc_peer_exchange* d, const void* send, void* recv, void* stream) {
+  SC_CHECK_ARG(d && send && recv, "null argument");
+  SC_CHECK_ARG(d->world >= 1 && d->world <= 8 && d->rank >= 0 && d->rank < d->world, "sc_peer_all_to_all: 1..8 ranks of one node");
+  SC_CHECK_ARG(d->block_bytes > 0 && d->block_bytes % 16 == 0, "sc_peer_all_to_all: blocks of whole 16-byte units");
+  SC_CHECK_ARG((((uintptr_t)send | (uintptr_t)recv) & 15) == 0, "sc_peer_all_to_all: 16-byte aligned buffers");
+  PeerArgs g;
+  std::memset((void*)&g, 0, sizeof(g));
+  for (int p = 0; p < d->world; ++p) {
+    SC_CHECK_ARG(d->peer_window[p], "sc_peer_all_to_all: a peer window is not mapped");
+    unsigned char* base = (unsigned char*)d->peer_window[p];
+    g.peer_flag[p] = (unsigned long long*)base;
+    g.peer_win[p] = (sc_f4*)(base + SC_PEER_HEADER);
+  }
+  unsigned char* mine = (unsigned char*)d->peer_window[d->rank];
+  g.my_flag = (unsigned long long*)mine;
+  g.epoch = (unsigned long long*)(mine + 256);
+  g.ticket = (unsigned int*)(mine + 264);
+  g.my_win = (const sc_f4*)(mine + SC_PEER_HEADER);
+  g.send = (const sc_f4*)send;
+  g.recv = (sc_f4*)recv;
+  g.block16 = d->block_bytes / 16;
+  g.P = d->world;
+  g.rank = d->rank;
+  // 557 KB per peer at configs[3] on 8 ranks: 16 workgroups of 256 lanes per peer = 9 rounds of 4 KB each
+  const int64_t want = (g.block16 + 2047) / 2048;
+  g.wg_per_peer = (int)(want < 1 ? 1 : (want > 32 ? 32 : want));
+  sc_stream_t st = (sc_stream_t)stream;
+  SC_LAUNCH(k_peer_put, dim3((unsigned)(g.P * g.wg_per_peer)), dim3(256), 0, st, g);
+  int rc = sc_check_launch("k_peer_put");
+  if (rc) return rc;
+  const int n_wg = g.P * g.wg_per_peer;
+  SC_LAUNCH(k_peer_take, dim3((unsigned)n_wg), dim3(256), 0, st, g, n_wg);
+  return sc_check_launch("k_peer_take");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Model-parallel utilities: process groups, autograd-aware collectives, and the
 mode-parallel and the spatially decomposed spectral convolution (RCCL all-to-all over xGMI), multigrid patching."""
-from . import comm, rccl_native  # noqa: F401
+from . import comm, peer_exchange, rccl_native  # noqa: F401
 from .mappings import (all_to_all, copy_to_model_parallel_region,  # noqa: F401
                        gather_from_model_parallel_region, reduce_from_model_parallel_region,
                        scatter_to_model_parallel_region)

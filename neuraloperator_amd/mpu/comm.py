@@ -125,7 +125,8 @@ def init(model_parallel_size=1, backend=None, verbose=False):
 def cleanup():
     global _DATA_PARALLEL_GROUP, _MODEL_PARALLEL_GROUP
     _DATA_PARALLEL_GROUP = _MODEL_PARALLEL_GROUP = None
-    from . import rccl_native
+    from . import peer_exchange, rccl_native
+    peer_exchange.shutdown()                  # unmap / free the peer windows (round 5) while the group still exists
     rccl_native.shutdown()                    # the engine's own RCCL communicators (round 4), before torch's
     if dist.is_initialized():
         dist.destroy_process_group()

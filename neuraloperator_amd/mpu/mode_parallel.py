@@ -41,7 +41,7 @@ from torch import nn
 
 from ..modes import halve_last_mode, kept_block
 from ..spectral_conv import BaseSpectralConv
-from . import comm, rccl_native
+from . import comm, peer_exchange, rccl_native
 from .mappings import A2A_STATS
 
 
@@ -80,6 +80,13 @@ class _Exchange:
     def _a2a(self, recv, send):
         A2A_STATS["calls"] += 1
         A2A_STATS["bytes"] += send.numel() * send.element_size()
+        # round 5, opt-in (SC_MPU_A2A=peer / peer_exchange.prefer_peer()): direct stores into the peers' windows, two plain
+        # engine launches on the current stream (mpu/peer_exchange.py); anything it cannot take falls through
+        if peer_exchange.wanted() and send.is_cuda:
+            px = peer_exchange.get(self.group, send.numel() * send.element_size())
+            if px is not None and (send.numel() * send.element_size() // self.P) % 16 == 0:
+                px.all_to_all(send, recv, torch.cuda.current_stream().cuda_stream)
+                return _Works([])
         if self.native is not None:
             return self._native(lambda st: self.native.all_to_all(send, recv, st), (send, recv))
         return dist.all_to_all_single(recv, send, group=self.group, async_op=True)

@@ -1,0 +1,42 @@
+"""CPU tier: the peer-store exchange kernels (csrc/sc_kernels_peer.h) in host emulation with ONE rank -- window header
+layout, the workgroup ticket, the epoch advancing per call, ragged block sizes, argument checks.  (Several ranks need
+several processes on a device: tests/test_gpu_peer_exchange.py.)"""
+import pytest
+import torch
+
+from engine_runner import emu_lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+@pytest.mark.parametrize("n", [4, 1028, 40000])
+def test_one_rank_exchange_is_a_copy_and_epochs_advance(lib, n):
+    ptr, handle = lib.peer_window_alloc(n * 4)
+    assert len(handle) == 64 and lib.peer_window_open(handle) == ptr           # emulation: the handle is the pointer
+    send = torch.randn(1, n)
+    for rep in range(3):
+        recv = torch.full_like(send, float("nan"))
+        lib.peer_all_to_all(1, 0, n * 4, [ptr], send.data_ptr(), recv.data_ptr())
+        assert torch.equal(recv, send)
+        send = send + 1.0
+    import ctypes
+    flags = (ctypes.c_uint64 * 8).from_address(ptr)
+    epoch = ctypes.c_uint64.from_address(ptr + 256).value
+    ticket = ctypes.c_uint32.from_address(ptr + 264).value
+    assert epoch == 3 and flags[0] == 3 and ticket == 0
+    lib.peer_window_free(ptr)
+
+
+def test_argument_checks(lib):
+    ptr, _ = lib.peer_window_alloc(1024)
+    a, b = torch.zeros(1, 64), torch.zeros(1, 64)
+    with pytest.raises(RuntimeError):
+        lib.peer_all_to_all(1, 0, 24, [ptr], a.data_ptr(), b.data_ptr())          # not a multiple of 16
+    with pytest.raises(RuntimeError):
+        lib.peer_all_to_all(9, 0, 16, [ptr], a.data_ptr(), b.data_ptr())          # more than one node's 8 ranks
+    with pytest.raises(RuntimeError):
+        lib.peer_all_to_all(2, 0, 16, [ptr], a.data_ptr(), b.data_ptr())          # peer 1's window is not mapped
+    lib.peer_window_free(ptr)
