@@ -812,7 +812,13 @@ def graph_probe(dist, world, rank, local_rank):
                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
         try:
             _, err = pr.communicate(timeout=GRAPH_PROBE_TIMEOUT_S)
-            rc, tail = pr.returncode, err.decode(errors="replace").strip().splitlines()[-1:]
+            lines = [ln for ln in err.decode(errors="replace").strip().splitlines() if "amdgpu.ids" not in ln]
+            rc, tail = pr.returncode, lines[-1:]
+            if rc != 0:                                  # the whole story goes to stderr, one line onto the bench line
+                print(f"[bench] graph probe child of rank {rank} exited {rc}:\n  " + "\n  ".join(lines[-25:]), file=sys.stderr,
+                      flush=True)
+                first = [ln for ln in lines if "rror" in ln or "terminate" in ln or "what()" in ln]
+                tail = first[:1] or tail
         except subprocess.TimeoutExpired:
             os.killpg(pr.pid, 9)                             # exactly the process group this call started
             pr.communicate()
@@ -1110,7 +1116,7 @@ def main():
             from neuraloperator_amd.mpu import peer_exchange, rccl_native
             native = rccl_native.active()
             out["collectives"] = {"backend": "gloo (SC_BENCH_SHARE_GPU test mode)" if share else "nccl (RCCL over xGMI)",
-                                  "issued_by": "peer stores into HIP-IPC-mapped windows, two engine launches per exchange "
+                                  "issued_by": "peer stores into HIP-IPC-mapped windows, three engine launches per exchange "
                                                "(mpu/peer_exchange.py)" if peer_exchange.active() else
                                                "ncclAllToAll / ncclSend+ncclRecv straight on HIP streams (mpu/rccl_native.py)"
                                                if native else "torch.distributed" +

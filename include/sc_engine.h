@@ -301,10 +301,10 @@ int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* d, const float* x
  * The all-to-all "split modes, cat batch" of the mode-sharded layer (the shape contract of neuralop/mpu/helpers.py:81-99,
  * which the reference defines and never calls) as direct stores into the peers' memory: every rank of ONE node owns a
  * window -- fine-grained device memory, sc_peer_window_alloc -- whose 64-byte HIP IPC handle the host side hands to the
- * other ranks (any transport), which map it with sc_peer_window_open.  sc_peer_all_to_all then issues two plain kernel
+ * other ranks (any transport), which map it with sc_peer_window_open.  sc_peer_all_to_all then issues three plain kernel
  * launches on `stream`: block p of `send` ([world][block_bytes]) is stored into slot `rank` of peer p's window and this
- * rank's epoch is written to slot `rank` of every peer's flags with system-scope release; the second launch waits until
- * all `world` flags of THIS rank carry the epoch and copies the window into `recv` ([world][block_bytes], block p from
+ * rank's epoch is written to slot `rank` of every peer's flags with system-scope release; a one-workgroup launch waits until
+ * all `world` flags of THIS rank carry the epoch and the third copies the window into `recv` ([world][block_bytes], block p from
  * rank p).  No host synchronisation, capturable into a hipGraph (the epoch lives in the window's header and advances
  * per call).  Every rank must call it for every exchange, in the same order; a window may serve the next exchange of
  * the same kind one layer step later (the layer's exchanges alternate directions -- csrc/sc_kernels_peer.h), the host

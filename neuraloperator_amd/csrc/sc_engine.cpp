@@ -2704,16 +2704,20 @@ extern "C" int sc_peer_all_to_all(const sc_peer_exchange* d, const void* send, v
   g.block16 = d->block_bytes / 16;
   g.P = d->world;
   g.rank = d->rank;
-  // 557 KB per peer at configs[3] on 8 ranks: 16 workgroups of 256 lanes per peer = 9 rounds of 4 KB each
-  const int64_t want = (g.block16 + 2047) / 2048;
-  g.wg_per_peer = (int)(want < 1 ? 1 : (want > 32 ? 32 : want));
+  // 557 KB per peer at configs[3] on 8 ranks: 17 workgroups of 256 lanes per peer, 8 rounds of 4 KB each; at most ~512
+  // workgroups in all (few ranks, large blocks: more per peer)
+  const int64_t want = (g.block16 + 2047) / 2048, cap = 512 / g.P;
+  g.wg_per_peer = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   sc_stream_t st = (sc_stream_t)stream;
   SC_LAUNCH(k_peer_put, dim3((unsigned)(g.P * g.wg_per_peer)), dim3(256), 0, st, g);
   int rc = sc_check_launch("k_peer_put");
   if (rc) return rc;
-  const int n_wg = g.P * g.wg_per_peer;
-  SC_LAUNCH(k_peer_take, dim3((unsigned)n_wg), dim3(256), 0, st, g, n_wg);
-  return sc_check_launch("k_peer_take");
+  SC_LAUNCH(k_peer_wait, dim3(1), dim3(64), 0, st, g);
+  if ((rc = sc_check_launch("k_peer_wait"))) return rc;
+  const int64_t want_c = ((int64_t)g.P * g.block16 + 1023) / 1024;          // four 16-byte units per lane and workgroup pass
+  const int n_wg = (int)(want_c < 1 ? 1 : (want_c > 512 ? 512 : want_c));
+  SC_LAUNCH(k_peer_copy, dim3((unsigned)n_wg), dim3(256), 0, st, g, n_wg);
+  return sc_check_launch("k_peer_copy");
 }
 
 // ------------------------------------------------------------------------------------------

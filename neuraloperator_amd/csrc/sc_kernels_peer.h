@@ -6,12 +6,12 @@
 //   k_peer_put   block p of the send buffer -> slot `rank` of peer p's window, 16 bytes per lane straight over the
 //                fabric; the LAST workgroup (device-scope ticket) advances this rank's epoch and writes it, with
 //                system-scope release, into slot `rank` of every peer's flag array;
-//   k_peer_take  every workgroup waits (system-scope acquire loads + s_sleep) until all P flags of THIS rank carry the
-//                epoch, then copies its share of the window into the caller's receive tensor.
-// Two plain launches on the caller's stream: stream-ordered like any kernel, capturable into a hipGraph (the epoch
+//   k_peer_wait  ONE workgroup waits (system-scope acquire loads + s_sleep) until all P flags of THIS rank carry the epoch;
+//   k_peer_copy  the window -> the caller's receive tensor.
+// Three plain launches on the caller's stream: stream-ordered like any kernel, capturable into a hipGraph (the epoch
 // lives in device memory and advances per launch, so a replay signals a fresh value).  The window may be overwritten
 // by a peer's NEXT exchange of the same kind only after that peer has waited for data this rank sent AFTER its
-// k_peer_take (the layer's exchanges alternate directions), and the two parities of a window alternate anyway.
+// k_peer_copy (the layer's exchanges alternate directions), and the two parities of a window alternate anyway.
 // No reference counterpart (neuralop/mpu/helpers.py:81-99 is an unused torch.distributed all-to-all).
 #pragma once
 #include "sc_device.h"
@@ -20,7 +20,7 @@ struct PeerArgs {
   const sc_f4* send;            // [P][block16] 16-byte units
   sc_f4* peer_win[8];           // peer p's window base for this parity (own included): [P][block16]
   unsigned long long* peer_flag[8];   // peer p's flag array [P]
-  const sc_f4* my_win;          // this rank's window (k_peer_take)
+  const sc_f4* my_win;          // this rank's window (k_peer_copy)
   unsigned long long* my_flag;  // this rank's flag array [P]
   unsigned long long* epoch;    // this rank's epoch counter (device memory)
   unsigned int* ticket;         // workgroup ticket of k_peer_put
@@ -67,7 +67,7 @@ k_peer_put(PeerArgs g) {
     if (tid == 0) {
       *g.ticket = 0;                                   // (the next launch on this stream starts behind this one)
       e_sh = *g.epoch + 1;
-      *g.epoch = e_sh;                                 // read by k_peer_take, the next launch on this stream
+      *g.epoch = e_sh;                                 // read by k_peer_wait, the next launch on this stream
     }
     SC_SYNC();
     peer_fence_system();
@@ -75,15 +75,32 @@ k_peer_put(PeerArgs g) {
   }
 }
 
-SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
-k_peer_take(PeerArgs g, int n_wg) {
+// ONE workgroup waits for the P flags of this rank (system-scope acquire loads + s_sleep): a spinning kernel must not
+// fill the device -- on a shared device (tests: several ranks on one GPU) the peers' k_peer_put could not start behind
+// a grid of spinning workgroups, and on its own device it would starve the rank's other streams
+SC_GLOBAL void SC_LAUNCH_BOUNDS(64)
+k_peer_wait(PeerArgs g) {
   const int tid = SC_TID;
   const unsigned long long want = *g.epoch;            // advanced by this rank's k_peer_put, earlier on this stream
   if (tid < g.P) {
     while (peer_flag_load(g.my_flag + tid) < want) peer_sleep();
   }
-  SC_SYNC();
   peer_fence_system();
-  const long long total = (long long)g.P * g.block16;
-  for (long long i = (long long)SC_BID_X * 256 + tid; i < total; i += (long long)n_wg * 256) g.recv[i] = g.my_win[i];
+}
+
+// window -> receive tensor (behind k_peer_wait on the stream): four 16-byte loads in flight per lane -- the window is
+// fine-grained (uncached) memory, its read latency is the copy's time
+SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+k_peer_copy(PeerArgs g, int n_wg) {
+  const int tid = SC_TID;
+  const long long total = (long long)g.P * g.block16, stride = (long long)n_wg * 256;
+  long long i = (long long)SC_BID_X * 256 + tid;
+  for (; i + 3 * stride < total; i += 4 * stride) {
+    const sc_f4 a = g.my_win[i], b = g.my_win[i + stride], c = g.my_win[i + 2 * stride], d = g.my_win[i + 3 * stride];
+    g.recv[i] = a;
+    g.recv[i + stride] = b;
+    g.recv[i + 2 * stride] = c;
+    g.recv[i + 3 * stride] = d;
+  }
+  for (; i < total; i += stride) g.recv[i] = g.my_win[i];
 }

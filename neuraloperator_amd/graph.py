@@ -46,6 +46,7 @@ class GraphedStep:
                     post()
         torch.cuda.current_stream(x.device).wait_stream(side)
         self._clear()
+        _quiesce_process_groups()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.output = module(x)
@@ -77,6 +78,23 @@ class GraphedStep:
         return self.output
 
     __call__ = replay
+
+
+def _quiesce_process_groups():
+    """Before a capture in a process that has used torch.distributed on the device: drain the GPU and give the process
+    group's watchdog thread time to retire the collectives it still tracks.  Its event queries on work that finished
+    moments ago race with the start of a (global-mode) capture and abort the process -- seen as one probe child in a few
+    dying with SIGABRT 2.5 s after start (round 5).  SC_GRAPH_QUIESCE_MS overrides the 800 ms."""
+    import os
+    import time
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+    except Exception:
+        return
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get("SC_GRAPH_QUIESCE_MS", "800")) / 1e3)
 
 
 def capture_step(module, x, grad_out, warmup=3, post=None):

@@ -80,7 +80,7 @@ class _Exchange:
     def _a2a(self, recv, send):
         A2A_STATS["calls"] += 1
         A2A_STATS["bytes"] += send.numel() * send.element_size()
-        # round 5, opt-in (SC_MPU_A2A=peer / peer_exchange.prefer_peer()): direct stores into the peers' windows, two plain
+        # round 5, opt-in (SC_MPU_A2A=peer / peer_exchange.prefer_peer()): direct stores into the peers' windows, three plain
         # engine launches on the current stream (mpu/peer_exchange.py); anything it cannot take falls through
         if peer_exchange.wanted() and send.is_cuda:
             px = peer_exchange.get(self.group, send.numel() * send.element_size())

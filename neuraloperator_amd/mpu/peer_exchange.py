@@ -2,10 +2,10 @@
 
 The exchange step of BASELINE configs[3] on 8 GPUs is 4.46 MB per rank and direction, 557 KB per peer -- 3.6 us on one
 xGMI link: latency, not bandwidth, and four of them sit on the critical path of a ~0.3 ms per-rank step (DESIGN.md
-section 6).  Through RCCL each is a collective kernel with its own proxy / channel set-up; here it is two plain launches
+section 6).  Through RCCL each is a collective kernel with its own proxy / channel set-up; here it is three plain launches
 of the engine (csrc/sc_kernels_peer.h, ``sc_peer_all_to_all``): every rank stores its blocks straight into the peers'
 windows (fine-grained device memory mapped through HIP IPC), signals with a system-scope flag per peer, waits for its own
-P flags and copies its window into the receive tensor.  Stream-ordered, no host synchronisation, records into a hipGraph.
+P flags (ONE spinning workgroup) and copies its window into the receive tensor.  Stream-ordered, no host synchronisation, records into a hipGraph.
 
 Set-up (collective over the group, once per window size): every rank allocates ``SLOTS`` windows, the 64-byte IPC handles
 travel through the torch process group (``all_gather_object``), every rank maps every peer's windows.  The slots rotate

@@ -455,9 +455,12 @@ def test_backward_pair_small_batch_one_pass(lib, dims):
     torch.cuda.synchronize()
     assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw1))
     assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx1))
-    x128, g128, w128 = xh_c.to(torch.complex128), gh_c.to(torch.complex128), w_c.to(torch.complex128)
-    assert rel_l2(gw.cpu().numpy(), torch.einsum("bim,bom->iom", x128.conj(), g128).numpy()) < TOL
-    assert rel_l2(gx.cpu().numpy(), torch.einsum("bom,iom->bim", g128, w128.conj()).numpy()) < TOL
+    # host reference on every 11th mode, the first mode tile and the ragged last one (round 5: the full complex128 einsum
+    # took 35-87 s per case on the host; every element is already compared bit for bit with the two launches above)
+    sel = torch.unique(torch.cat([torch.arange(0, M, 11), torch.arange(0, 128), torch.arange(M - 130, M)]))
+    x128, g128, w128 = (v[..., sel].to(torch.complex128) for v in (xh_c, gh_c, w_c))
+    assert rel_l2(gw.cpu()[..., sel].numpy(), torch.einsum("bim,bom->iom", x128.conj(), g128).numpy()) < TOL
+    assert rel_l2(gx.cpu()[..., sel].numpy(), torch.einsum("bom,iom->bim", g128, w128.conj()).numpy()) < TOL
 
 
 def test_module_dropin():
