@@ -196,10 +196,20 @@ SC_HD cf32 cf_rot_i(const cf32 a, const int n) {
 #define SC_F3_PS 286    // pair 1 of a wave inside the wave's exchange area: 8 * XRS - 2 (lands in pair 0's row padding;
                         // shifts its banks by two 8-byte slots: the transposed reads of both pairs are conflict-free)
 template <int H, typename IO>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 && sizeof(IO) == 4 ? SC_F3_FWD_OCC : 3))   // bf16 loads need 4 more VGPRs
+#ifndef SC_F3_FWD_OCC_BF16
+#define SC_F3_FWD_OCC_BF16 4   // with SC_F3_PF_DEPTH_BF16 = 1: 126 registers (round 4: 3 / depth 2)
+#endif
+#ifndef SC_F3_PF_DEPTH_BF16
+#define SC_F3_PF_DEPTH_BF16 1
+#endif
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (H <= 256 ? (sizeof(IO) == 4 ? SC_F3_FWD_OCC : SC_F3_FWD_OCC_BF16) : 3))
 k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
              const cf32* __restrict__ tabH, int Mx, int My, float s_dc, float s_other, F3Shard sh) {
   constexpr int P = H / 64;
+  // prefetch depth in row rounds: 2 for fp32 (three workgroups per unit), 1 for bf16 storage with FOUR workgroups per unit
+  // (round 5: 91.8 -> 88.3 us at the metric shape, 126 registers, profiles/r05_bf16_fwd_ab.txt: with half the bytes per
+  // round the kernel is bound by its arithmetic -- 70 us with the loads removed -- and a fourth workgroup overlaps more of it)
+  constexpr int PFD = sizeof(IO) == 4 ? SC_F3_PF_DEPTH : SC_F3_PF_DEPTH_BF16;
   typedef F3Lds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
   cf32* xch = reinterpret_cast<cf32*>(smem + L::off_xch);
@@ -299,11 +309,11 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     SC_WAVE_SYNC();                                      // cb is rewritten by the next task
   };
 
-  // software prefetch, SC_F3_PF_DEPTH rounds deep: the values of round t + depth are requested while round t
+  // software prefetch, PFD rounds deep: the values of round t + depth are requested while round t
   // is transformed (depth register sets, rounds alternate between them).  A round is short (~1 us), about the
   // loaded HBM latency: depth 2 covers it alone at 3 workgroups per CU, depth 1 relies on the other resident
   // workgroups (4 per CU) and frees the 16 registers that make the fourth one fit
-  cf32 pz[SC_F3_PF_DEPTH][8];                            // .x = row A, .y = row B of the pair
+  cf32 pz[PFD][8];                            // .x = row A, .y = row B of the pair
   auto prefetch = [&](const int t, cf32 (&q)[8]) {        // t = 4 a + r
     if (t < 4 * P) {
       const int a = t >> 2, p = (t & 3) * 8 + hw;
@@ -323,10 +333,10 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
   SC_COMPILER_FENCE();                                   // the table requests stay ahead of the row rounds (the compiler
                                                          // had sunk one below them and then drained everything for it)
 #pragma unroll
-  for (int d = 0; d < SC_F3_PF_DEPTH; ++d) prefetch(d, pz[d]);        // depth 1, 2 or 4 (4 rounds = one row group)
+  for (int d = 0; d < PFD; ++d) prefetch(d, pz[d]);        // depth 1, 2 or 4 (4 rounds = one row group)
   SC_COMPILER_FENCE();
   // the tables (requested ahead of the row rounds: vmcnt is in order, so waiting for them leaves the rounds in flight)
-  sc_wait_vmcnt<(16 * SC_F3_PF_DEPTH < 63 ? 16 * SC_F3_PF_DEPTH : 63)>();
+  sc_wait_vmcnt<(16 * PFD < 63 ? 16 * PFD : 63)>();
 #pragma unroll
   for (int q = 0; q < NTH; ++q) sc_landed(rH[q]);
   sc_landed(r64);
@@ -345,8 +355,8 @@ k_fft2d_fwd3(const IO* __restrict__ x, cf32* __restrict__ xhat, const cf32* __re
     for (int r = 0; r < 4; ++r) {
       const int p = r * 8 + hw;
       cf32 v[8], o[8];
-      dft8<-1>(pz[r % SC_F3_PF_DEPTH], o);               // over n1 (n = 32 n1 + lam) -> k1
-      prefetch(4 * a + r + SC_F3_PF_DEPTH, pz[r % SC_F3_PF_DEPTH]);   // refill the consumed register set
+      dft8<-1>(pz[r % PFD], o);               // over n1 (n = 32 n1 + lam) -> k1
+      prefetch(4 * a + r + PFD, pz[r % PFD]);   // refill the consumed register set
 #ifdef SC_F3_ABL_NOROW
       if (o[0].x == 1234.5f) T[tid] = o[1];
       continue;
