@@ -26,6 +26,10 @@ CASES = [  # B, C, spatial, n_modes, output_shape
     (32, 64, (128, 128), (32, 32), (256, 256)),       # resolution-changing layer (super-resolution decoder block)
     (32, 64, (256, 256), (64, 64), (128, 128)),       # ... and the coarsening direction
     (32, 64, (256, 256), (64, 64), None),             # the metric shape for scale
+    # round 5: lines above 1024 points stay on the pruned direct DFT (matrix cores) -- measured beside
+    # the reference's O(N log N) chain
+    (2, 16, (2048, 2048), (64, 64), None),
+    (2, 16, (2048, 2048), (256, 256), None),
 ]
 
 
