@@ -805,7 +805,9 @@ def graph_probe(dist, world, rank, local_rank):
         dist.broadcast_object_list(box, src=0)
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(box[0]))
-    env.pop("TORCHELASTIC_RUN_ID", None)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                                       "GROUP_WORLD_SIZE", "LOCAL_WORLD_SIZE")]:
+        env.pop(k)            # (TORCHELASTIC_USE_AGENT_STORE would send the child's rendezvous to the parents' store)
     t0 = time.perf_counter()
     try:
         pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--graph-probe"], env=env,

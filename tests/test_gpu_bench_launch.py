@@ -53,3 +53,25 @@ def test_one_sample_per_rank_takes_the_graph_step_by_default():
     line, _ = _run(["--parallel", "modeshard", "--workload", "fno3d_128_m32_c32_b1", "--steps", "3", "--warmup", "1",
                     "--no-graph"] + QUIET)
     assert line["config"]["launch"] == "eager"
+
+
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_graph_probe_under_torchrun_environment():
+    """The driver starts the ranks through torch.distributed.run: its TORCHELASTIC_* variables must not leak into the
+    probe children (TORCHELASTIC_USE_AGENT_STORE would send their rendezvous to the parents' store and the probe would
+    time out into the eager step)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--parallel",
+                          "modeshard", "--workload", "fno3d_64_m16_c32_b8", "--steps", "3", "--warmup", "1"] + QUIET +
+                         ["--chunk-dim", "batch"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                          "127.0.0.1", "--master-port", "29732", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--parallel",
+                          "modeshard", "--workload", "fno3d_128_m32_c32_b1", "--steps", "3", "--warmup", "1"] + QUIET,
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert line["config"]["launch"].startswith("hipGraph replay"), (line["config"]["launch"], out.stderr[-2000:])
