@@ -85,6 +85,10 @@ def parse():
                     help="modeshard: who moves the exchanges -- auto (torch.distributed, the engine's own RCCL binding inside "
                          "hipGraph steps), torch, native (mpu/rccl_native.py), peer (round 5, opt-in: direct stores into the "
                          "peers' HIP-IPC-mapped windows, mpu/peer_exchange.py; unmeasured on more than one GPU)")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="modeshard on ONE device, TIMING ONLY: the contraction of the mode-parallel layer runs on 1 / V of the "
+                         "mode rows for V times the local batch -- the per-rank load of a V-rank group (transforms and the "
+                         "degenerate exchanges are this rank's real ones; the numbers it computes are not the layer's)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra.* measurements")
     ap.add_argument("--no-gpu-reference", action="store_true", help="skip gpu_reference_baseline")
     ap.add_argument("--force-generic", action="store_true", help="A/B: skip the fused FFT kernels")
@@ -960,6 +964,10 @@ def main():
         mp_kw["comm_chunks"] = args.comm_chunks
     if args.chunk_dim:
         mp_kw["chunk_dim"] = args.chunk_dim
+    if args.emulate_world > 1:
+        if world != 1:
+            raise SystemExit("--emulate-world: a one-device timing emulation (WORLD_SIZE must be 1)")
+        mp_kw["emulate_world"] = args.emulate_world
     case = build_case(parallel, args.workload, world, dev, flags, io_dtype, dist, 1234 + rank, mp_kwargs=mp_kw)
     if case is None:
         raise SystemExit(f"{args.workload}: batch {B} not divisible by {world} ranks for the strong-scaling run")
@@ -1091,6 +1099,8 @@ def main():
                        "channels": C, "grid": list(spatial), "n_modes": list(n_modes), "kept": kept,
                        "parallelism": par, "engine_path": engine_path(names),
                        "launch": launch_tag,
+                       **({"emulate_world": f"TIMING ONLY: contraction of a {args.emulate_world}-rank group's rank on one device"}
+                          if args.emulate_world > 1 else {}),
                        "real_tensor_io": args.io,
                        "weights": "dense complex64, random init"},
             "roofline": roof,

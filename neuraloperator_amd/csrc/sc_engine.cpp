@@ -1422,17 +1422,22 @@ static bool ax128_ok(const sc_plan* p, int d) {
 static bool ax64_ok(const sc_plan* p, int d) {
   return p->pl64 && d < p->nd - 2 && p->n[d] == SC_P64_N && p->k[d] <= SC_P64_KMAX;
 }
+// sh.rows > 0: the kept-row side (forward: the result, inverse: the operand) is a sharded spectrum (first axis only)
 static int run_ax128(const sc_plan* p, int dir, const cf32* in, cf32* out, int64_t outer, int K, int64_t inner,
-                     sc_stream_t st) {
+                     sc_stream_t st, F3Shard sh = F3Shard{0, 0}) {
   const dim3 grid((unsigned)((inner + 31) / 32), (unsigned)outer);
   if (p->pl64) {
-    if (dir < 0) SC_LAUNCH((k_ax64<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
-    else SC_LAUNCH((k_ax64<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
+    if (dir < 0) SC_LAUNCH((k_ax64<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K, sh);
+    else SC_LAUNCH((k_ax64<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K, sh);
     return sc_check_launch("k_ax64");
   }
-  if (dir < 0) SC_LAUNCH((k_ax128<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
-  else SC_LAUNCH((k_ax128<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K);
+  if (dir < 0) SC_LAUNCH((k_ax128<-1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K, sh);
+  else SC_LAUNCH((k_ax128<+1>), grid, dim3(256), 0, st, in, out, (const cf32*)p->pl_tab128, inner, K, sh);
   return sc_check_launch("k_ax128");
+}
+// plans whose FIRST-axis pass is k_ax128 / k_ax64 address a sharded spectrum natively there (round 5)
+static bool ax_native_shards(const sc_plan* p, int64_t n_images) {
+  return !p->fast && !p->cplx && p->nd >= 3 && (ax128_ok(p, 0) || ax64_ok(p, 0)) && n_images <= 65535;
 }
 
 static int run_axis_mdft(const float* tab, const cf32* in, cf32* out, int64_t outer, int N, int J, int64_t inner,
@@ -1532,7 +1537,7 @@ static int transform_forward_impl(const sc_plan* p, int mode, const float* x, fl
     for (int e = 0; e < d; ++e) outer *= p->n[e];
     cf32* dst = (d == 0) ? (cf32*)xhat : (cur == bufA ? bufB : bufA);
     if ((ax128_ok(p, d) || ax64_ok(p, d)) && outer <= 65535)
-      rc = run_ax128(p, -1, cur, dst, outer, (int)p->k[d], inner, st);
+      rc = run_ax128(p, -1, cur, dst, outer, (int)p->k[d], inner, st, d == 0 ? sh : F3Shard{0, 0});
     else if (p->mdft && p->m_ax_fwd[d])
       rc = run_axis_mdft(p->m_ax_fwd[d], cur, dst, outer, (int)p->n[d], (int)p->k[d], inner, st);
     else
@@ -1637,7 +1642,7 @@ static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat,
     cf32* dst = (remaining % 2 == 0) ? bufA : bufB;
     int rc;
     if ((ax128_ok(p, d) || ax64_ok(p, d)) && outer <= 65535)
-      rc = run_ax128(p, +1, cur, dst, outer, (int)p->k[d], inner, st);
+      rc = run_ax128(p, +1, cur, dst, outer, (int)p->k[d], inner, st, d == 0 ? sh : F3Shard{0, 0});
     else if (p->mdft && p->m_ax_inv[d])
       rc = run_axis_mdft(p->m_ax_inv[d], cur, dst, outer, (int)p->k[d], (int)p->n[d], inner, st);
     else
@@ -3157,7 +3162,7 @@ extern "C" int sc_transform_forward_sharded(const sc_plan* p, int mode, const fl
   if (n_images <= 0) return 0;
   if (int rc = check_shards(p, sh, n_images)) return rc;
   sc_stream_t st = (sc_stream_t)stream;
-  if (native_shards(p)) {
+  if (native_shards(p) || ax_native_shards(p, n_images)) {
     // rows past k1 (k1 not a multiple of the block size) are zeros on the wire: clear the one block that has them
     if (sh->n_blocks * sh->rows != p->k[0]) {
       cf32* last = (cf32*)xhat + (sh->n_blocks - 1) * sh->block_stride;
@@ -3177,7 +3182,7 @@ extern "C" int sc_transform_inverse_sharded(const sc_plan* p, int mode, const fl
                                             const sc_spectrum_shards* sh, void* workspace, void* stream) {
   if (n_images <= 0) return 0;
   if (int rc = check_shards(p, sh, n_images)) return rc;
-  if (native_shards(p))
+  if (native_shards(p) || ax_native_shards(p, n_images))
     return transform_inverse_impl(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream,
                                   F3Shard{(int)sh->rows, sh->block_stride});
   SC_CHECK_ARG(workspace, "workspace required (sc_plan_workspace_bytes_sharded)");

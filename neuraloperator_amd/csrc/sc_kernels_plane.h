@@ -364,9 +364,19 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
 // The size-agnostic matrix-core pass it replaces took 80-94 us per launch for 0.18 GB at FNO3d 128^3
 // (profiles/r02_fno3d_128_plane_fft_kernel_stats.txt).
 // ------------------------------------------------------------------------------------------
+// Round 5: the kept-row side of the first-axis pass addresses a SHARDED spectrum natively (sh.rows > 0: the rank-major
+// all-to-all buffer [block][image][rows][rest] of the mode-parallel layer, include/sc_engine.h sc_spectrum_shards) --
+// until then the 3-D routes went through a staging buffer and one permutation launch per transform (k_spectrum_shard:
+// 5.5 us + a kernel boundary, four times per layer step; a tenth of the ~0.3 ms per-rank step of configs[3] on 8 ranks)
+SC_HD int64_t ax_row_offset(const F3Shard sh, const int64_t o, const int r, const int K, const int64_t inner) {
+  if (sh.rows <= 0) return (o * K + r) * inner;
+  const int blk = r / sh.rows;
+  return (int64_t)blk * sh.block_stride + (o * sh.rows + (r - blk * sh.rows)) * inner;
+}
 template <int DIR>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
-k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ tab128, int64_t inner, int K) {
+k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ tab128, int64_t inner, int K,
+        F3Shard sh) {
   SC_SHARED __attribute__((aligned(16))) cf32 lds[4 * 8 * 148 + SC_PL_N];
   const int tid = SC_TID, w = tid >> 6, lane = tid & 63, c = lane & 7, t = lane >> 3;
   cf32* tabl = lds + 4 * 8 * 148;                        // w128^m in LDS (session 2): 15 LDS reads per lane instead of 15 global loads
@@ -386,7 +396,7 @@ k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restr
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) E2[k1 * 9 + t] = cf_mul_cs(u[k1], sc_lds_ld64(tabl + ((t * k1) & 127)));
     SC_WAVE_SYNC();
-    cf32* dst = out + o * K * inner + col;
+    cf32* dst = out + col;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k1 = t + 8 * h;
@@ -395,20 +405,20 @@ k_ax128(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restr
       for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + k1 * 9 + q);
       dft8<-1>(y, r);
       const int rp = k1 + K / 2, rn = k1 - 16 + K / 2;
-      if (live && rp < K) dst[(int64_t)rp * inner] = r[0];
-      if (live && rn >= 0) dst[(int64_t)rn * inner] = r[7];
+      if (live && rp < K) dst[ax_row_offset(sh, o, rp, K, inner)] = r[0];
+      if (live && rn >= 0) dst[ax_row_offset(sh, o, rn, K, inner)] = r[7];
     }
   } else {
-    const cf32* src = in + o * K * inner + col;
+    const cf32* src = in + col;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k1 = t + 8 * h;
       const int rp = k1 + K / 2, rn = k1 - 16 + K / 2;
       cf32 e[8], g[8];
-      e[0] = (live && rp < K) ? src[(int64_t)rp * inner] : cf_make(0.f, 0.f);
+      e[0] = (live && rp < K) ? src[ax_row_offset(sh, o, rp, K, inner)] : cf_make(0.f, 0.f);
 #pragma unroll
       for (int q = 1; q < 7; ++q) e[q] = cf_make(0.f, 0.f);
-      e[7] = (live && rn >= 0) ? src[(int64_t)rn * inner] : cf_make(0.f, 0.f);
+      e[7] = (live && rn >= 0) ? src[ax_row_offset(sh, o, rn, K, inner)] : cf_make(0.f, 0.f);
       if (h == 0) SC_SYNC();                             // the table (uniform: h is the unrolled loop's index)
       dft8<+1>(e, g);
       E2[k1 * 9] = g[0];

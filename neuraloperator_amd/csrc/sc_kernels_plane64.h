@@ -292,7 +292,8 @@ k_pl64_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __res
 // ------------------------------------------------------------------------------------------
 template <int DIR>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
-k_ax64(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ tab64, int64_t inner, int K) {
+k_ax64(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restrict__ tab64, int64_t inner, int K,
+       F3Shard sh) {                                     // sh: as k_ax128 (sc_kernels_plane.h, round 5)
   SC_SHARED __attribute__((aligned(16))) cf32 lds[4 * 8 * 76 + SC_P64_N];
   const int tid = SC_TID, w = tid >> 6, lane = tid & 63, c = lane & 7, t = lane >> 3;
   cf32* tabl = lds + 4 * 8 * 76;
@@ -313,24 +314,24 @@ k_ax64(const cf32* __restrict__ in, cf32* __restrict__ out, const cf32* __restri
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) E2[k1 * SC_P64_ES + t] = cf_mul_cs(u[k1], sc_lds_ld64(tabl + ((t * k1) & 63)));
     SC_WAVE_SYNC();
-    cf32* dst = out + o * K * inner + col;
+    cf32* dst = out + col;
     cf32 y[8], r[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) y[q] = sc_lds_ld64(E2 + t * SC_P64_ES + q);
     dft8<-1>(y, r);
-    if (live && r0 < K) dst[(int64_t)r0 * inner] = r[0];
-    if (live && r0 + 8 < K) dst[(int64_t)(r0 + 8) * inner] = r[1];
-    if (live && r0 - 8 >= 0) dst[(int64_t)(r0 - 8) * inner] = r[7];
-    if (live && r0 - 16 >= 0) dst[(int64_t)(r0 - 16) * inner] = r[6];
+    if (live && r0 < K) dst[ax_row_offset(sh, o, r0, K, inner)] = r[0];
+    if (live && r0 + 8 < K) dst[ax_row_offset(sh, o, r0 + 8, K, inner)] = r[1];
+    if (live && r0 - 8 >= 0) dst[ax_row_offset(sh, o, r0 - 8, K, inner)] = r[7];
+    if (live && r0 - 16 >= 0) dst[ax_row_offset(sh, o, r0 - 16, K, inner)] = r[6];
   } else {
-    const cf32* src = in + o * K * inner + col;
+    const cf32* src = in + col;
     cf32 e[8], g[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) e[q] = cf_make(0.f, 0.f);
-    if (live && r0 < K) e[0] = src[(int64_t)r0 * inner];
-    if (live && r0 + 8 < K) e[1] = src[(int64_t)(r0 + 8) * inner];
-    if (live && r0 - 8 >= 0) e[7] = src[(int64_t)(r0 - 8) * inner];
-    if (live && r0 - 16 >= 0) e[6] = src[(int64_t)(r0 - 16) * inner];
+    if (live && r0 < K) e[0] = src[ax_row_offset(sh, o, r0, K, inner)];
+    if (live && r0 + 8 < K) e[1] = src[ax_row_offset(sh, o, r0 + 8, K, inner)];
+    if (live && r0 - 8 >= 0) e[7] = src[ax_row_offset(sh, o, r0 - 8, K, inner)];
+    if (live && r0 - 16 >= 0) e[6] = src[ax_row_offset(sh, o, r0 - 16, K, inner)];
     SC_SYNC();                                           // the table
     dft8<+1>(e, g);
     E2[t * SC_P64_ES] = g[0];

@@ -171,9 +171,14 @@ class _ModeParallelFn(torch.autograd.Function):
         for work, _send, recv, c0, c1 in pend:
             work.wait()
         xhat_all = torch.view_as_complex(xhat_all)
+        V = layer.emulate_world
+        if V > 1:                                           # timing emulation: V x the batch on 1 / V of the rows
+            xhat_all = xhat_all.reshape(V * xhat_all.shape[0], ci, rows // V, *rest)
 
         # ---- contraction on this rank's mode rows, whole batch
         yhat_all = (ops.contract_separable(xhat_all, w) if layer.separable else ops.contract(xhat_all, w)).contiguous()
+        if V > 1:
+            yhat_all = yhat_all.reshape(-1, co, rows, *rest)
 
         # ---- exchange back (split batch, cat modes) + zero-padded inverse reading the receive buffer in place
         y = torch.empty((b, co, *spatial), dtype=torch.float32, device=dev)
@@ -241,6 +246,9 @@ class _ModeParallelFn(torch.autograd.Function):
         for work, _send, recv, c0, c1 in pend:
             work.wait()
         ghat_all = torch.view_as_complex(ghat_all)
+        V = layer.emulate_world
+        if V > 1:
+            ghat_all = ghat_all.reshape(V * ghat_all.shape[0], co, rows // V, *rest)
         gbias = None
         if want_b:
             gbias = (torch.stack(gb_parts).sum(0) if by_batch else torch.cat(gb_parts)).reshape(ctx.bias_shape)
@@ -248,6 +256,8 @@ class _ModeParallelFn(torch.autograd.Function):
         # ---- the two gradient contractions on this rank's mode rows (gW is complete: no all-reduce)
         cbwd = ops.contract_separable_bwd if layer.separable else ops.contract_bwd
         gxhat_all, gw = cbwd(xhat_all, w, ghat_all, need_x, need_w)
+        if V > 1 and gxhat_all is not None:
+            gxhat_all = gxhat_all.reshape(-1, ci, rows, *rest)
 
         # ---- exchange back + adjoint of the forward transform reading the receive buffer in place
         gx = None
@@ -306,7 +316,7 @@ class ModeParallelSpectralConv(BaseSpectralConv):
     def __init__(self, in_channels, out_channels, n_modes, bias=True, init_std="auto",
                  fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, comm_chunks=None,
                  factorization=None, rank=0.5, separable=False, max_n_modes=None, resolution_scaling_factor=None,
-                 agops=None, chunk_dim=None, **unused):
+                 agops=None, chunk_dim=None, emulate_world=1, **unused):
         super().__init__(device=device)
         # complex_data (spectral_convolution.py:439-441, 475-479, 514-517, 536-538): complex-to-complex transforms in every
         # dim, every dim centred -- runs on the general route (round 4)
@@ -314,6 +324,10 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         if chunk_dim not in (None, "batch", "channels"):
             raise ValueError("chunk_dim: None (batch chunks unless a rank holds one sample), 'batch' or 'channels'")
         self.chunk_dim = chunk_dim
+        # TIMING ONLY (bench.py --emulate-world V on one device): the contraction runs on 1 / V of the mode rows for V
+        # times the local batch -- the per-rank load of a V-rank group -- by reinterpreting the exchanged spectrum's bytes;
+        # transforms and exchanges are the real ones of this rank, the RESULTS ARE NOT THE LAYER'S
+        self.emulate_world = max(1, int(emulate_world))
         fac = (factorization or "dense").lower()
         if fac not in ("dense", "tucker", "cp", "tt"):
             raise NotImplementedError("mode-parallel layer: dense, Tucker, CP or TT weights")
@@ -349,16 +363,19 @@ class ModeParallelSpectralConv(BaseSpectralConv):
         self.rank = comm.get_model_parallel_rank() if group is None else dist.get_rank(group)
         # rows of the first mode dim per rank; k1 not divisible by P: the last rank(s) carry zero rows
         self.rows = -(-self.max_n_modes[0] // self.P)
+        if self.emulate_world > 1 and (fac != "dense" or separable or self.rows % self.emulate_world):
+            raise ValueError("emulate_world: dense weights, mode rows divisible by the emulated group size")
         if init_std == "auto":
             init_std = (2 / (in_channels + out_channels)) ** 0.5
         live = min(self.rows, max(0, self.max_n_modes[0] - self.rank * self.rows))
         self.core = self.cp_weights = None
         if fac == "dense":
             lead = (in_channels,) if self.separable else (in_channels, out_channels)
-            w = torch.empty(*lead, self.rows, *self.max_n_modes[1:], dtype=torch.cfloat, device=device)
+            w = torch.empty(*lead, self.rows // self.emulate_world, *self.max_n_modes[1:], dtype=torch.cfloat, device=device)
             w.normal_(0, init_std)
             with torch.no_grad():
-                w[(slice(None),) * len(lead) + (slice(live, None),)] = 0
+                if self.emulate_world == 1:
+                    w[(slice(None),) * len(lead) + (slice(live, None),)] = 0
             self.weight = nn.Parameter(w)
             self.weight.mode_sharded = True          # exclude from data-parallel all-reduce within the group
         else:

@@ -34,6 +34,8 @@ CASES = [
     ((12, 10), (5, 6), 2),         # ... padded
     ((6, 8, 10), (4, 4, 4), 4),    # 3-d: one row per block
     ((9, 8, 10), (5, 4, 6), 3),    # 3-d padded, odd first dim
+    ((64, 64, 64), (8, 8, 8), 4),  # round 5: k_ax64 addresses the shards natively (no staging buffer, no permutation launch)
+    ((64, 64, 64), (7, 8, 8), 4),  # ... 7 rows over 4 blocks of 2: a zero row on the wire
 ]
 
 
