@@ -19,6 +19,7 @@
 #include "sc_kernels_generic.h"
 #include "sc_kernels_fft.h"
 #include "sc_kernels_fft3.h"
+#include "sc_kernels_fft3mx.h"
 #include "sc_kernels_mfma.h"
 #include "sc_kernels_gemm8.h"
 #include "sc_kernels_mdft.h"
@@ -931,6 +932,22 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     std::string why;
     if (fft2d_plan_init(&p->fft2d, p->nd, p->n, p->k, p->sf, p->si, &p->owned, &why)) p->fast = true;
   }
+  // bfloat16 I/O on the fused kernels: the operand fragments of the matrix-core row pass (12 KB, sc_kernels_fft3mx.h)
+  if (!rc && p->fast && (desc->flags & SC_PLAN_IO_BF16) && !(desc->flags & (SC_PLAN_FFT_GEN2 | SC_PLAN_NO_MX_FFT)) &&
+      p->fft2d.H <= 256 && !getenv("SC_PLAN_NO_MX_FFT")) {
+    std::vector<uint16_t> h;
+    fft3mx_build_table(&h);
+    void* dev = nullptr;
+    if (hipMalloc(&dev, h.size() * sizeof(uint16_t)) != hipSuccess) {
+      rc = sc_fail("sc_engine: table allocation failed");
+    } else {
+      p->owned.push_back(dev);
+      if (hipMemcpy(dev, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+        rc = sc_fail("sc_engine: table upload failed");
+      else
+        p->fft2d.tabF = (uint16_t*)dev;
+    }
+  }
   if (!rc && !p->fast && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !(desc->flags & SC_PLAN_IO_BF16))
     rc = f2p_plan_init(p, true);
   if (!rc && !p->fast && !p->f2p && !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT)))
@@ -1498,8 +1515,11 @@ static int transform_forward_impl(const sc_plan* p, int mode, const float* x, fl
   if (p->fast) {
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
-    if (p->d.flags & SC_PLAN_IO_BF16)
+    if (p->d.flags & SC_PLAN_IO_BF16) {
+      if (p->fft2d.tabF)                                   // round 5: the row pass on the matrix cores
+        return fft3mx_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error, sh);
       return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error, sh);
+    }
     return fft3_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, st, &g_last_error, sh);
   }
   if (p->f2p) return f2p_forward(p, mode, x, (cf32*)xhat, n_images, workspace, st);
@@ -3465,7 +3485,7 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   if (!p) return "";
   if (p->fast) {
     if (p->d.flags & SC_PLAN_FFT_GEN2) return fft2d_kernel_name(which);
-    return which == 0 ? "k_fft2d_fwd3" : "k_fft2d_inv3";
+    return which == 0 ? (p->fft2d.tabF ? "k_fft2d_fwd_mx" : "k_fft2d_fwd3") : "k_fft2d_inv3";
   }
   if (p->cplx) return "k_axis_pass";
   if (p->f2p) return which == 0 ? "k_f2p_r2c" : "k_f2p_c2r";

@@ -418,6 +418,7 @@ struct Fft2dPlan {
   int H = 0, Mx = 0, My = 0;
   float sf = 0.f, si = 0.f;
   cf32 *tabW = nullptr, *tabH = nullptr, *tab64 = nullptr;
+  uint16_t* tabF = nullptr;     // bf16 operand fragments of the matrix-core row pass (sc_kernels_fft3mx.h); null = not built
 };
 
 static inline bool fft2d_upload(std::vector<void*>* owned, int n, cf32** out) {

@@ -115,6 +115,13 @@ def test_fused_fft_bf16_io_matches_oracle(lib, case):
         lib.plan_create([48, 40], [8, 5], flags=_lib.SC_PLAN_IO_BF16)
     with pytest.raises(_lib.EngineError):
         lib.plan_create([H, 256], kept, flags=_lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_FFT_GEN2)
+    # round 5: forward-type transforms of bf16 tensors run their row pass on the matrix cores (k_fft2d_fwd_mx: the bf16
+    # input is exact in the MFMA's input format, the twiddles are three bf16 terms); SC_PLAN_NO_MX_FFT = the
+    # vector-ALU kernel.  Both against the same oracle, the matrix-core one no further from the fp64 spectrum
+    for fl, name in ((_lib.SC_PLAN_IO_BF16, "k_fft2d_fwd_mx"), (_lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT, "k_fft2d_fwd3")):
+        plan = lib.plan_create([H, 256], kept, flags=fl)
+        assert lib.plan_kernel_name(plan, 0) == name
+        lib.plan_destroy(plan)
     x = torch.randn(b, ci, H, 256).bfloat16()
     w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.5)
     bias = torch.randn(co, 1, 1)
@@ -122,13 +129,17 @@ def test_fused_fft_bf16_io_matches_oracle(lib, case):
     xc, wc, bc = x.float().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     yo = so.forward_torch(xc, wc, bc, nm, nm)
     yo.backward(g.float())
-    y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=_lib.SC_PLAN_IO_BF16)
-    bf16_checks(y, yo.detach(), "y")
-    bf16_checks(gx, xc.grad, "gx")
-    assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
-    assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
     _, xk = so.forward_np64(x.float().numpy(), w.numpy(), bias.numpy(), nm, nm)
-    assert rel_l2(xh.numpy(), xk) < TOL
+    errs = {}
+    for fl in (_lib.SC_PLAN_IO_BF16, _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT):
+        y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=fl)
+        bf16_checks(y, yo.detach(), "y")
+        bf16_checks(gx, xc.grad, "gx")
+        assert rel_l2(gw.numpy(), wc.grad.numpy()) < TOL
+        assert rel_l2(gb.numpy(), bc.grad.numpy()) < TOL
+        errs[fl] = rel_l2(xh.numpy(), xk)
+        assert errs[fl] < TOL
+    assert errs[_lib.SC_PLAN_IO_BF16] < 2e-6, errs           # fp32 round-off class (the vector-ALU kernel: ~3e-7)
 
 
 def test_emu_library_exports_and_errors(lib):

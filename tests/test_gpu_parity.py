@@ -129,9 +129,17 @@ def test_bf16_io_vs_oracle(lib, case):
     _bf16_checks(gx, xc.grad, "gx")
     assert rel_l2(gw.cpu().numpy(), wc.grad.numpy()) < TOL
     assert rel_l2(gb.cpu().numpy(), bc.grad.numpy()) < TOL
-    # and the fp32-I/O kernels on the same values give the same fp32 spectrum bit for bit (same arithmetic)
+    # the fp32-I/O kernels on the same values: the same fp32 spectrum bit for bit from the vector-ALU kernel (same
+    # arithmetic; SC_PLAN_NO_MX_FFT, and H = 512 always), fp32 round-off apart from the matrix-core row pass (round 5:
+    # k_fft2d_fwd_mx -- the bf16 input is exact in the MFMA's input format, the twiddles are three bf16 terms)
     _, _, _, _, xh32 = layer_fwd_bwd(lib, x.float().to(dev), w.to(dev), bias.to(dev), g.float().to(dev), nm, nm)
-    assert torch.equal(xh, xh32)
+    _, _, _, _, xhv = layer_fwd_bwd(lib, x.to(dev), w.to(dev), bias.to(dev), g.to(dev), nm, nm,
+                                    flags=_lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT)
+    assert torch.equal(xhv, xh32)
+    if H == 512:
+        assert torch.equal(xh, xh32)
+    else:
+        assert rel_l2(xh.cpu().numpy(), xh32.cpu().numpy()) < 1e-6
 
 
 def test_module_bf16_activations():
