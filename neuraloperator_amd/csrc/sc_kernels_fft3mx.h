@@ -18,16 +18,19 @@
 //   * w64^((m + 32) k) = (-1)^k w64^(m k): both halves of the m range use the SAME 32 x 64 operand (48 registers per
 //     lane for the three terms) -- the even tiles add the two halves in one accumulator, the odd tiles take the second
 //     half with its sign bits flipped (one v_xor per register of the fragment);
-//   * the A operand of v_mfma_f32_16x16x32_bf16 wants 8 k-values per lane: lane (row i, group g) loads the 64
+//   * the A operand of v_mfma_f32_16x16x32_bf16 wants 8 k-values per lane: lane (row i, group g) takes the 64
 //     contiguous bytes 256 ks + 64 g of its row -- 32 consecutive samples -- and splits them by r with v_perm_b32
-//     (16 per 64 bytes); the sum over m is order independent, so no other data movement exists between HBM and the
-//     matrix core: no LDS staging, no transposes;
+//     (16 per 64 bytes); the sum over m is order independent, so the only data movement between HBM and the matrix
+//     core is the hop of whole rows through a per-wave LDS image (coalesced loads in, 16-byte pieces out);
 //   * the 16 x 16 accumulator tile of a wave IS 16 rows x 16 frequencies: Y goes to the group tile T2[row][k]
 //     unpacked (no two-rows-as-one-complex trick to undo) and the column phase of k_fft2d_fwd3 runs unchanged on it.
 //
-// Per image: 1536 MFMAs of 16 passes (6.5 k cycles per compute unit), ~1.3 k vector instructions per wave for the
-// row pass instead of ~9 k.  Two workgroups per compute unit (the operand tables, the prefetched rows and the
-// accumulators take ~200 registers), persistent, the rows of the next group requested one group ahead.
+// Per image: 1536 MFMAs of 16 cycles (6.5 k cycles per compute unit), ~1.3 k vector instructions per wave for the
+// row pass instead of ~9 k.  Two workgroups per compute unit (the operand fragments, the prefetched rows and the
+// accumulators take 237 registers), persistent, the rows of the next group requested one group ahead.
+// Measured (MI355X, metric shape, profiles/r05_mx_fft_ab.txt): 76-78 us against 94-98 us for k_fft2d_fwd3<256, sc_bf16>,
+// 1.2e-7 against a float64 transform (the vector-ALU kernel: 1.3e-7).  At two waves per SIMD the matrix time (23.5 us),
+// the vector / LDS time (~41 us) and the load wait (12.6 us) add up rather than overlap.
 // Reference lines: spectral_convolution.py:443-449 (rfftn), :500-519 (kept block).
 #pragma once
 #include "sc_kernels_fft3.h"
@@ -97,37 +100,16 @@ inline sc_mx_u4 sc_mx_load16(const void* p) { return sc_mx_load16_stream(p); }
 #ifndef SC_MX_TERMS
 #define SC_MX_TERMS 3     // bf16 terms of a twiddle (3: 24 bits; 2 would leave 2^-17 -- measured)
 #endif
-// how the rows reach the MFMA A layout (lane (row i, group g) wants the 64 contiguous bytes 256 ks + 64 g of row i):
-//   2  full rows by coalesced 16-byte loads (a half-wave = one 512-byte row), through a per-wave LDS image whose row
-//      stride of 528 bytes makes both the 16-byte writes and the 16-byte reads in MFMA order conflict-free;
-//   0 / 1  straight from global memory (non-temporal / ordinary): every lane of an instruction then touches its own
-//      16-byte piece, neighbouring lanes in different rows -- measured 106 us against 93 us for the vector-ALU kernel
-//      (profiles/r05_mx_fft_ab.txt)
-#ifndef SC_MX_LOADS
-#define SC_MX_LOADS 1
-#endif
-#define SC_MX_SS 528
-// groups of rows in flight per wave ahead of the one being transformed.  One group (8 KB per wave, 64 KB per compute
-// unit) leaves the kernel waiting for memory: 86 us with real loads against NN us without (profiles/r05_mx_fft_ab.txt).
-// Two need 32 more registers: the operand fragments then come from LDS (SC_MX_F_LDS), 12 KB per workgroup.
-#ifndef SC_MX_PF
-#define SC_MX_PF 1
-#endif
-// SC_MX_LAZY: the fragments of one r at a time (8 registers instead of 32) straight out of the loaded rows, the next
-// group's request behind the MFMA phase instead of ahead of it -- what lets a THIRD workgroup per compute unit fit
-// (168 registers).  The kernel is bound by the issue rate of its vector / LDS instructions between the MFMA phases
-// (two waves per SIMD: 78 us with real loads, 74 without, 65 without MFMAs), not by memory: occupancy is the lever.
-#ifndef SC_MX_LAZY
-#define SC_MX_LAZY 0
-#endif
-#ifndef SC_MX_WGS
-#define SC_MX_WGS (SC_MX_LAZY ? 3 : 2)
-#endif
-#ifndef SC_MX_F_LDS
-#define SC_MX_F_LDS (SC_MX_PF == 2)
-#endif
+// Measured and dropped (profiles/r05_mx_fft_ab.txt): rows straight from global memory into MFMA order (non-temporal:
+// 106 us, every lane's 16-byte piece its own request; ordinary loads: 76-84 us, but the step loses in its contractions
+// what the transform gains -- see the row requests below), two groups of rows in flight with the operand fragments
+// read from LDS (91 us), one r's fragments at a time to fit 168 registers (spills), the MFMAs of group a + 1
+// interleaved with the column phase of group a (92-95 us).
 #define SC_MX_RS 36       // row stride (complex) of the unpacked group tile T2[64 rows][33 columns + 3 parked k = 32 columns]:
                           // the accumulator stores and the column-phase reads are both conflict-free per half-wave
+#define SC_MX_SS 528      // row stride (bytes) of a wave's staged rows: 16-byte writes of whole rows and 16-byte reads in MFMA
+                          // order (16 rows at one column offset) are both conflict-free
+#define SC_MX_WGS 2       // persistent workgroups per compute unit = the kernel's register budget (two waves per SIMD)
 
 template <int H>
 struct F3MxLds {
@@ -139,14 +121,11 @@ struct F3MxLds {
   static constexpr int off_twH = off_T + T_c * 8;
   static constexpr int off_tw64 = off_twH + H * 8;
   static constexpr int off_twr = off_tw64 + 64 * 8;        // w256^(r k), [r - 1][u][j], k = 2 j + u
-  static constexpr int off_F = off_twr + 96 * 8;           // operand fragments [tile][term][lane] (SC_MX_F_LDS)
-  static constexpr int off_stg = off_F + (SC_MX_F_LDS ? 4 * SC_MX_TERMS * 64 * 16 : 0);   // staged rows: [wave][16 rows][SC_MX_SS bytes]
-  static constexpr int total = off_stg + (SC_MX_LOADS == 2 ? 4 * 16 * SC_MX_SS : 0);
-  static_assert(SC_MX_PF == 1 || SC_MX_LOADS != 2, "two groups in flight: the direct load path");
-  static_assert(SC_MX_WGS * total <= 160 * 1024, "workgroups per compute unit");
-  static_assert(!SC_MX_LAZY || SC_MX_LOADS != 2, "lazy fragments: the direct load path");
+  static constexpr int off_stg = off_twr + 96 * 8;         // staged rows: [wave][16 rows][SC_MX_SS bytes]
+  static constexpr int total = off_stg + 4 * 16 * SC_MX_SS;
   static_assert(P <= 4, "k = 32 of group a is parked in column 32 + a of its row (H <= 256)");
   static_assert(SC_F2D_KX * SC_F2D_KY <= T_c, "output tile aliases the group tile");
+  static_assert(SC_MX_WGS * total <= 160 * 1024, "workgroups per compute unit");
 };
 
 // the operand table of one plan: [tile 4][term][lane 64][8 bf16], MFMA B layout (lane (j, g): F[m = 8 g + e][column j]);
@@ -196,40 +175,36 @@ SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, SC_MX_WGS)
 k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
                const cf32* __restrict__ tabH, const uint16_t* __restrict__ tabF, int Mx, int My, float s_dc,
                float s_other, F3Shard sh, int64_t n_images, int gstride) {
-  constexpr int P = H / 64, RS = SC_MX_RS;
+  constexpr int P = H / 64, RS = SC_MX_RS, NT = SC_MX_TERMS;
   typedef F3MxLds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
   cf32* xch = reinterpret_cast<cf32*>(smem + L::off_xch);
   cf32* T = reinterpret_cast<cf32*>(smem + L::off_T);
   cf32* twH = reinterpret_cast<cf32*>(smem + L::off_twH);
   cf32* tw64 = reinterpret_cast<cf32*>(smem + L::off_tw64);
+  cf32* twr = reinterpret_cast<cf32*>(smem + L::off_twr);  // (as 12 register constants per lane the kernel spilled)
 
   const int tid = SC_TID;
   const int w = SC_UNIFORM(tid >> 6);
   const int lane = tid & 63;
   const int j = lane & 15, g = lane >> 4;                 // MFMA roles: (row i = j, k group g) of A, (column j, k group g) of B
-  // ---- tables: w_H and w64 to LDS, the lane's operand fragments and row twiddles to registers
+  const int cl = lane >> 3, mu = lane & 7;                // column phase: wave w owns columns 8 w .. 8 w + 7, 8 lanes each
+  // ---- tables: w_H, w64 and the row twiddles to LDS, the lane's operand fragments to registers
   for (int q = tid; q < H; q += 256) twH[q] = tabH[q];
   if (tid < 64) tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];          // w64^(mu q1), [mu][q1]
-#if SC_MX_F_LDS
-  sc_mx_u4* Fl = reinterpret_cast<sc_mx_u4*>(smem + L::off_F);
-  for (int q = tid; q < 4 * SC_MX_TERMS * 64; q += 256) Fl[q] = sc_mx_load16(tabF + (size_t)q * 8);
-  Fl += lane;
-#else
-  sc_mx_u4 F[4][SC_MX_TERMS];
+  if (tid < 96) twr[tid] = tabW[((tid / 32 + 1) * (2 * (tid & 15) + ((tid >> 4) & 1))) & 255];
+  sc_mx_u4 F[4][NT];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int term = 0; term < SC_MX_TERMS; ++term)
-      F[t][term] = sc_mx_load16(tabF + ((size_t)(t * SC_MX_TERMS + term) * 64 + lane) * 8);
-#endif
-  cf32* twr = reinterpret_cast<cf32*>(smem + L::off_twr);  // (12 registers per lane as constants: the kernel spilled)
-  if (tid < 96) twr[tid] = tabW[((tid / 32 + 1) * (2 * (tid & 15) + ((tid >> 4) & 1))) & 255];
+    for (int term = 0; term < NT; ++term) F[t][term] = sc_mx_load16(tabF + ((size_t)(t * NT + term) * 64 + lane) * 8);
   const bool lane_k0 = (j == 0);
 
-  // ---- column phase roles (as k_fft2d_fwd3): wave w owns columns 8 w .. 8 w + 7, 8 lanes per column
-  const int cl = lane >> 3, mu = lane & 7;
-  auto column = [&](const cf32* src, cf32* cb, const int a, auto extra_tag, cf32* dst, cf32 (&acc)[8], const bool act) {
+  // ---- one column task of group a (lane = (column slot, mu)), as in k_fft2d_fwd3 but on the unpacked tile: rows
+  //      b = 8 b1 + mu; cb = the column's private exchange patch; F_a[q1 + 8 q2] w_H^(a fx) goes to acc (+=) or, for the
+  //      deferred 33rd column, to dst[q]
+  cf32 acc[8];
+  auto column = [&](const cf32* src, cf32* cb, const int a, auto extra_tag, cf32* dst, const bool act) {
     constexpr bool EXTRA = decltype(extra_tag)::value != 0;
     cf32 v[8], o[8];
 #pragma unroll
@@ -240,117 +215,84 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
       const cf32 y = (q1 == 0) ? o[0] : cf_mul_pk(o[q1], tw64[mu * 8 + q1]);
       if (act) cb[q1 * 8 + mu] = y;
     }
-    SC_WAVE_SYNC();
+    SC_WAVE_SYNC();                                        // the 8 lanes of a column share a wave
 #pragma unroll
-    for (int m = 0; m < 8; m += 2) SC_F3_LD128(cb + mu * 8 + m, v[m], v[m + 1]);
+    for (int m = 0; m < 8; m += 2) SC_F3_LD128(cb + mu * 8 + m, v[m], v[m + 1]);   // lane mu now plays q1 = mu
     dft8<-1>(v, o);                                        // over mu -> q2 : F_a[q1 + 8 q2]
 #pragma unroll
     for (int q2 = 0; q2 < 8; ++q2) {
-      const int fx = f2d_fx(mu + 8 * q2);
-      int idx = (a * fx) % H;
-      if (idx < 0) idx += H;
+      const int idx = (a * f2d_fx(mu + 8 * q2)) & (H - 1);    // (H is a power of two)
       if (EXTRA) {
         if (act) dst[mu + 8 * q2] = cf_mul(twH[idx], o[q2]);
       } else {
         cf_mac(acc[q2], twH[idx], o[q2]);
       }
     }
-    SC_WAVE_SYNC();
+    SC_WAVE_SYNC();                                        // cb is rewritten by the next task
   };
 
-  // ---- row requests: group a of image im = rows h = P b + a, b = 16 w + i
-  constexpr int PF = SC_MX_PF;
-  sc_mx_u4 xq[PF][8];
-#ifdef SC_MX_ABL_NOLOAD
-  for (int d = 0; d < PF; ++d)
-    for (int q = 0; q < 8; ++q) xq[d][q] = sc_mx_u4{(uint32_t)(0x3f803f80u + lane), 0x3f80bf80u, 0x40003f00u, 0x3e803f80u};
-#endif
-#if SC_MX_LOADS == 2
-  // instruction q of a wave = its rows i = 2 q, 2 q + 1 (a half-wave each: 512 contiguous bytes)
+  // ---- row requests: group a of image im = rows h = P b + a, b = 16 w + i.  The MFMA A layout wants lane (i = j, g)
+  //      to hold the 64 bytes 256 ks + 64 g of row i -- straight from global memory that is a 16-byte piece per lane with
+  //      neighbouring lanes in different rows: as non-temporal loads 103-106 us (every piece its own request), as
+  //      ordinary loads 76-84 us for the kernel but the 268 MB of x then pass through the Infinity Cache, evict the
+  //      weights and cost the two contractions of a step what the transform gains (0.4178 vs 0.422 ms per bf16 step,
+  //      profiles/r05_mx_fft_ab.txt).  So: whole rows by coalesced NON-TEMPORAL 16-byte loads (instruction q of a wave =
+  //      its rows 2 q, 2 q + 1, a half-wave each: 512 contiguous bytes), through a per-wave LDS image, out in MFMA order.
   unsigned char* stg = smem + L::off_stg + w * (16 * SC_MX_SS);
-  auto request = [&](const int64_t im, const int a, sc_mx_u4 (&xr)[8]) {
+  sc_mx_u4 xq[8];
+#ifdef SC_MX_ABL_NOLOAD
+  for (int q = 0; q < 8; ++q) xq[q] = sc_mx_u4{(uint32_t)(0x3f803f80u + lane), 0x3f80bf80u, 0x40003f00u, 0x3e803f80u};
+#endif
+  auto request = [&](const int64_t im, const int a) {
     const int64_t imc = im < n_images ? im : n_images - 1;           // past the end: a harmless re-read
     const unsigned char* base = reinterpret_cast<const unsigned char*>(x + (imc * H + (P * (16 * w + (lane >> 5)) + a)) * SC_F2D_W) +
                                 16 * (lane & 31);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
 #ifdef SC_MX_ABL_NOLOAD
-      if (im == -12345) xr[q] = sc_mx_load16_stream(base + (size_t)q * (2 * P * SC_F2D_W * 2));   // measurement build only
+      if (im == -12345) xq[q] = sc_mx_load16_stream(base + (size_t)q * (2 * P * SC_F2D_W * 2));   // measurement build only
 #else
-      xr[q] = sc_mx_load16_stream(base + (size_t)q * (2 * P * SC_F2D_W * 2));
+      xq[q] = sc_mx_load16_stream(base + (size_t)q * (2 * P * SC_F2D_W * 2));
 #endif
     }
   };
-#else
-  // lane (i = j, g) takes the 64 bytes 256 ks + 64 g of its row for ks = 0, 1 (samples 128 ks + 32 g .. + 31): the
-  // four lanes of a row cover 256 contiguous bytes per ks, an instruction 16-byte pieces of 32 cache lines -- ordinary
-  // loads, so that the line a piece misses on serves the seven pieces that follow from L1
-  auto request = [&](const int64_t im, const int a, sc_mx_u4 (&xr)[8]) {
-    const int64_t imc = im < n_images ? im : n_images - 1;           // past the end: a harmless re-read
-    const unsigned char* row = reinterpret_cast<const unsigned char*>(x + (imc * H + (P * (16 * w + j) + a)) * SC_F2D_W);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#ifdef SC_MX_ABL_NOLOAD
-        if (im == -12345) xr[4 * ks + q] = sc_mx_load16(row + 256 * ks + 64 * g + 16 * q);       // measurement build only
-#else
-        xr[4 * ks + q] = SC_MX_LOADS == 0 ? sc_mx_load16_stream(row + 256 * ks + 64 * g + 16 * q)
-                                           : sc_mx_load16(row + 256 * ks + 64 * g + 16 * q);
-#endif
-      }
-  };
-#endif
-  // the group PF steps behind (img, a) in the workgroup's sequence of groups
-  auto ahead_img = [&](const int64_t img, const int a) { return img + (int64_t)((a + PF) / P) * gstride; };
-  auto ahead_a = [&](const int a) { return (a + PF) % P; };
-  request(SC_BID_X, 0, xq[0]);
-  if (PF == 2) request(P > 1 ? SC_BID_X : SC_BID_X + gstride, P > 1 ? 1 : 0, xq[PF - 1]);
+  request(SC_BID_X, 0);
   SC_SYNC();                                               // tables
 
-  cf32 acc[8];
-  auto group = [&](const int64_t img, const int a, sc_mx_u4 (&xr)[8]) SC_ALWAYS_INLINE_LAMBDA {
+#pragma unroll 1
+  for (int64_t img = SC_BID_X; img < n_images; img += gstride) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = cf_make(0.f, 0.f);
+#pragma unroll 1
+    for (int a = 0; a < P; ++a) {
       // ---------------- rows of group a on the matrix cores ----------------
-      // split the lane's 2 x 32 samples by r = n mod 4: fragment [r][ks] = x[4 m + r], m = 32 ks + 8 g + e
-#if !SC_MX_LAZY
+      // split the lane's 2 x 32 samples by r = n mod 4: fragment [r][ks] = x[4 m + r], m = 32 ks + 8 g + e;
+      // element e sits at local sample 4 e + r = dword 2 e + (r >> 1), half r & 1
       sc_mx_u4 A[4][2];
-#if SC_MX_LOADS == 2
-      // registers -> the wave's LDS image -> MFMA order; the registers are free for the next group's request at once
+      // registers -> the wave's LDS image; the registers are free for the next group's request at once (the rows of the
+      // next image behind the last group)
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        *reinterpret_cast<sc_mx_u4*>(stg + (2 * q + (lane >> 5)) * SC_MX_SS + 16 * (lane & 31)) = xr[q];
-      request(ahead_img(img, a), ahead_a(a), xr);          // (selects, no branch around the loads)
+        *reinterpret_cast<sc_mx_u4*>(stg + (2 * q + (lane >> 5)) * SC_MX_SS + 16 * (lane & 31)) = xq[q];
+      request(a + 1 < P ? img : img + gstride, a + 1 < P ? a + 1 : 0);     // (selects, no branch around the loads)
       SC_WAVE_SYNC();
-#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         sc_mx_u4 dq[4];
-#if SC_MX_LOADS == 2
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           dq[q] = *reinterpret_cast<const sc_mx_u4*>(stg + j * SC_MX_SS + 256 * ks + 64 * g + 16 * q);
-#else
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dq[q] = xr[4 * ks + q];
-#endif
         const uint32_t d[16] = {dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w,
                                 dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          // element e sits at local sample 4 e + r = dword 2 e + (r >> 1), half r & 1
           A[r][ks].x = sc_mx_pick(d[2 + (r >> 1)], d[0 + (r >> 1)], r & 1);
           A[r][ks].y = sc_mx_pick(d[6 + (r >> 1)], d[4 + (r >> 1)], r & 1);
           A[r][ks].z = sc_mx_pick(d[10 + (r >> 1)], d[8 + (r >> 1)], r & 1);
           A[r][ks].w = sc_mx_pick(d[14 + (r >> 1)], d[12 + (r >> 1)], r & 1);
         }
       }
-#if SC_MX_LOADS == 2
       SC_WAVE_SYNC();                                      // the image is rewritten at the next group
-#else
-      // the rows of the group PF steps on (of a later image behind the last group) while this one is transformed
-      request(ahead_img(img, a), ahead_a(a), xr);          // (selects, no branch around the loads)
-#endif
-#endif
       float yre[2][4], yim[2][4], ere[4], eim[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -359,41 +301,19 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int v = 0; v < 4; ++v) c[t][v] = 0.f;
-#if SC_MX_LAZY
-        // fragments of this r: element e of k step ks sits at local sample 4 e + r = dword 2 e + (r >> 1), half r & 1
-        sc_mx_u4 Ar[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const uint32_t d[16] = {xr[4 * ks].x, xr[4 * ks].y, xr[4 * ks].z, xr[4 * ks].w,
-                                  xr[4 * ks + 1].x, xr[4 * ks + 1].y, xr[4 * ks + 1].z, xr[4 * ks + 1].w,
-                                  xr[4 * ks + 2].x, xr[4 * ks + 2].y, xr[4 * ks + 2].z, xr[4 * ks + 2].w,
-                                  xr[4 * ks + 3].x, xr[4 * ks + 3].y, xr[4 * ks + 3].z, xr[4 * ks + 3].w};
-          Ar[ks].x = sc_mx_pick(d[2 + (r >> 1)], d[0 + (r >> 1)], r & 1);
-          Ar[ks].y = sc_mx_pick(d[6 + (r >> 1)], d[4 + (r >> 1)], r & 1);
-          Ar[ks].z = sc_mx_pick(d[10 + (r >> 1)], d[8 + (r >> 1)], r & 1);
-          Ar[ks].w = sc_mx_pick(d[14 + (r >> 1)], d[12 + (r >> 1)], r & 1);
-        }
-        const sc_mx_u4 A0 = Ar[0], A1 = Ar[1];
-#else
-        const sc_mx_u4 A0 = A[r][0], A1 = A[r][1];
-#endif
         // second half of the m range: w64^(32 k) = (-1)^k -- the odd-k tiles take it negated
-        sc_mx_u4 An = A1;
+        sc_mx_u4 An = A[r][1];
         An.x ^= 0x80008000u;
         An.y ^= 0x80008000u;
         An.z ^= 0x80008000u;
         An.w ^= 0x80008000u;
 #pragma unroll
-        for (int term = SC_MX_TERMS - 1; term >= 0; --term)          // small terms first
+        for (int term = NT - 1; term >= 0; --term)                   // small terms first
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int t = 0; t < 4; ++t)                                // four accumulators in turn: no back-to-back dependence
-#if SC_MX_F_LDS
-              sc_mfma_16x16x32_bf16(c[t], hf == 0 ? A0 : (t < 2 ? A1 : An), Fl[(t * SC_MX_TERMS + term) * 64]);
-#else
-              sc_mfma_16x16x32_bf16(c[t], hf == 0 ? A0 : (t < 2 ? A1 : An), F[t][term]);
-#endif
+              sc_mfma_16x16x32_bf16(c[t], hf == 0 ? A[r][0] : (t < 2 ? A[r][1] : An), F[t][term]);
         // Y += w256^(r k) S_r (u = 0: k = 2 j, u = 1: k = 2 j + 1);  k = 32 (the Im column of k = 0): E += w8^r S_r[32]
         constexpr float h = 0.70710678118654752440f;
         const float er = (r == 0) ? 1.f : (r == 1) ? h : (r == 2) ? 0.f : -h;
@@ -401,7 +321,7 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           cf32 tw = cf_make(1.f, 0.f);
-          if (r > 0) tw = SC_F3_LD64(twr + (r - 1) * 32 + u * 16 + j);
+          if (r > 0) tw = SC_F3_LD64(twr + (r > 0 ? r - 1 : 0) * 32 + u * 16 + j);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             const float sre = c[2 * u][v], sim = c[2 * u + 1][v];
@@ -427,9 +347,6 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
         }
         SC_SCHED_BARRIER();                                // one r at a time: two sets of accumulators do not fit
       }
-#if SC_MX_LAZY
-      request(ahead_img(img, a), ahead_a(a), xr);          // the rows are consumed: the next group's while the columns run
-#endif
       SC_SYNC();                                           // the column phase of the group before has read T2
       {
         cf32* tr = T + (16 * w + 4 * g) * RS;
@@ -442,13 +359,8 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
       }
       SC_SYNC();
       // ---------------- 32 column FFTs of 64 points on T2 (k = 32: behind the group loop) ----------------
-#ifndef SC_MX_ABL_NOCOL
-      column(T + (8 * w + cl), xch + (8 * w + cl) * SC_F3_CCS, a, sc_int<0>(), nullptr, acc, true);
-#else
-      acc[a & 7].x += T[tid].x;                            // measurement build only
-#endif
-  };
-  auto finish = [&](const int64_t img) SC_ALWAYS_INLINE_LAMBDA {
+      column(T + (8 * w + cl), xch + (8 * w + cl) * SC_F3_CCS, a, sc_int<0>(), nullptr, true);
+    }
     SC_SYNC();
     // ---------------- 33rd column (k = 32): one 8-lane task per group, all groups at once ----------
     cf32* part = xch + (P + 1) * SC_F3_CCS;                // [P][64] partial spectra, summed below
@@ -456,7 +368,7 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
       constexpr int ABLK = (P + 3) / 4;
       const int a = ((cl % ABLK) << 2) | w;
       const int ac = a < P ? a : 0;
-      column(T + 32 + ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), part + ac * 64, acc, cl < ABLK && a < P);
+      column(T + 32 + ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), part + ac * 64, cl < ABLK && a < P);
     }
     SC_SYNC();
     // ---------------- kept block -> LDS -> one contiguous store ----------------
@@ -487,38 +399,9 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
       for (int i = tid; i < Mx * My; i += 256) xhat[f3_shard_index(sh, img, i, My)] = OUT[i];
     }
     // (the next image's first T2 write sits behind a workgroup barrier: OUT has been read by then)
-  };
-  auto clear = [&]() {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = cf_make(0.f, 0.f);
-  };
-  if constexpr (PF == 1 || P % 2 == 0) {
-#pragma unroll 1
-    for (int64_t img = SC_BID_X; img < n_images; img += gstride) {
-      clear();
-#pragma unroll 1
-      for (int a = 0; a < P; a += PF) {
-        group(img, a, xq[0]);
-        if (PF == 2) group(img, a + 1, xq[PF - 1]);
-      }
-      finish(img);
-    }
-  } else {                                                 // one group per image: the two register sets alternate over images
-#pragma unroll 1
-    for (int64_t img = SC_BID_X; img < n_images; img += 2 * (int64_t)gstride) {
-      clear();
-      group(img, 0, xq[0]);
-      finish(img);
-      if (img + gstride < n_images) {                      // uniform
-        clear();
-        group(img + gstride, 0, xq[PF - 1]);
-        finish(img + gstride);
-      }
-    }
   }
 }
 
-// persistent: SC_MX_WGS workgroups per compute unit (the kernel's register budget)
 template <int H>
 static void fft3mx_launch_fwd(const Fft2dPlan* fp, const sc_bf16* x, cf32* xhat, int64_t n_images, float s_dc,
                               float s_other, sc_stream_t st, F3Shard sh) {
