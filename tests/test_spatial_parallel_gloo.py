@@ -97,3 +97,93 @@ def test_single_rank_equals_dense_layer_maths():
     y = conv(x)
     yo = so.forward_torch(x, conv.weight.detach(), conv.bias.detach(), nm, nm)
     assert so.rel_l2(y.detach().numpy(), yo.numpy()) < 1e-5
+
+
+def _worker_variants(rank, world, port, spatial, modes, fac, out_shape, ret):
+    """round 5: factorized weights (factors replicated, each rank reconstructs its mode columns) and a change of
+    resolution (output_shape = the FULL output grid, whose first dim is sharded like the input's)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import SpatialParallelSpectralConv, comm
+    from oracle import spectral_oracle as so
+    from oracle_ops import OracleOps
+
+    comm.init(model_parallel_size=world, backend="gloo")
+    nm = halve_last_mode(modes)
+    B, ci, co = 2, 3, 4
+    torch.manual_seed(100 + rank)             # a DIFFERENT init per rank: sync_replicated_parameters makes them one
+    conv = SpatialParallelSpectralConv(ci, co, modes, ops=OracleOps(nm[1:]), factorization=fac, rank=0.6)
+    if fac != "dense":
+        conv.sync_replicated_parameters()
+        w = conv.weight.to_tensor().detach().clone()
+    else:
+        torch.manual_seed(5)
+        w = torch.empty(ci, co, *nm, dtype=torch.cfloat).normal_(0, 0.4)
+        with torch.no_grad():
+            conv.weight.copy_(SpatialParallelSpectralConv.shard_dense_weight(w, rank, world))
+        conv.sync_replicated_parameters()     # the bias
+    bias = conv.bias.detach().clone()
+    torch.manual_seed(0)                      # identical full tensors on every rank
+    x = torch.randn(B, ci, *spatial)
+    og = list(out_shape) if out_shape is not None else list(spatial)
+    g = torch.randn(B, co, *og)
+    hl, ho = spatial[0] // world, og[0] // world
+    xs = x[:, :, rank * hl:(rank + 1) * hl].clone().requires_grad_(True)
+    y = conv(xs, output_shape=out_shape)
+    assert list(y.shape) == [B, co, ho, *og[1:]]
+    y.backward(g[:, :, rank * ho:(rank + 1) * ho])
+    conv.reduce_replicated_grads()
+
+    xf, bf = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    if fac != "dense":
+        # single-process reference: the same factors (leaf copies), dense reconstruction, the oracle
+        from neuraloperator_amd.factorized import SpectralWeight
+        ref = SpectralWeight.new((ci, co, *nm), rank=0.6, factorization=fac)
+        with torch.no_grad():
+            for q, r in zip(ref.parameters(), conv.weight.parameters()):
+                q.copy_(r)
+        wf = ref.to_tensor()
+    else:
+        wf = w.clone().requires_grad_(True)
+    yf = so.forward_torch(xf, wf, bf, nm, nm, output_shape=out_shape)
+    yf.backward(g)
+    errs = dict(
+        y=so.rel_l2(y.detach().numpy(), yf.detach()[:, :, rank * ho:(rank + 1) * ho].numpy()),
+        gx=so.rel_l2(xs.grad.numpy(), xf.grad[:, :, rank * hl:(rank + 1) * hl].numpy()),
+        gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()),
+    )
+    if fac != "dense":
+        for i, (q, r) in enumerate(zip(conv.weight.parameters(), ref.parameters())):
+            errs[f"gfac{i}"] = so.rel_l2(torch.view_as_real(q.grad).numpy(), torch.view_as_real(r.grad).numpy())
+    else:
+        gw_ref = SpatialParallelSpectralConv.shard_dense_weight(wf.grad, rank, world)
+        errs["gw"] = float(np.linalg.norm((conv.weight.grad - gw_ref).numpy().ravel()) /
+                           np.linalg.norm(wf.grad.numpy().ravel()))
+    ret[rank] = errs
+    comm.cleanup()
+
+
+@pytest.mark.parametrize("spatial,modes,fac,out_shape", [
+    ((16, 12), (8, 6), "tucker", None),
+    ((16, 12), (8, 6), "cp", None),
+    ((16, 12), (6, 6), "tt", None),                 # k2 = 4 over 2 ranks
+    ((8, 8, 6), (4, 3, 4), "tucker", None),         # 3-d, k2 = 3 over 2 ranks: a padded column
+    ((16, 12), (8, 6), "dense", (24, 20)),          # finer output grid
+    ((16, 12), (8, 6), "tucker", (12, 10)),         # coarser output grid, factorized weight
+])
+def test_spatial_parallel_variants(spatial, modes, fac, out_shape):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_variants, args=(r, world, port, spatial, modes, fac, out_shape, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    for r in range(world):
+        assert all(v < 1e-5 for v in ret[r].values()), (r, dict(ret[r]))
