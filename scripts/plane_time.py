@@ -12,8 +12,8 @@ x = torch.randn(planes, N1, N2, device=dev); y = torch.empty_like(x)
 z = torch.randn(planes, K1, J, 2, device=dev)
 
 
-def timed(fn, n=6):
-    for _ in range(2):
+def timed(fn, n=20):
+    for _ in range(30):
         fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -24,7 +24,7 @@ def timed(fn, n=6):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for path in libs:
+for path in libs * (3 if len(libs) > 1 else 1):      # interleaved repetitions: the clocks of a fresh box settle over the first passes
     lib = _lib.ScEngineLib(path)
     plan = lib.plan_create([N1, N2], [K1, J])
     ws = torch.empty(max(lib.plan_workspace_bytes(plan, planes), 256), dtype=torch.uint8, device=dev)
