@@ -1516,7 +1516,7 @@ static int transform_forward_impl(const sc_plan* p, int mode, const float* x, fl
     if (p->d.flags & SC_PLAN_FFT_GEN2)
       return fft2d_forward(&p->fft2d, mode, x, (cf32*)xhat, n_images, workspace, st, &g_last_error);
     if (p->d.flags & SC_PLAN_IO_BF16) {
-      if (p->fft2d.tabF)                                   // round 5: the row pass on the matrix cores
+      if (p->fft2d.tabF && !((uintptr_t)x & 15))           // round 5: the row pass on the matrix cores (16-byte row loads)
         return fft3mx_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error, sh);
       return fft3_forward(&p->fft2d, mode, (const sc_bf16*)x, (cf32*)xhat, n_images, st, &g_last_error, sh);
     }

@@ -14,6 +14,12 @@ for wl in tucker:32,64,256,256,64,64 dense:8,32,128,128,128,32,32,32 dense:4,128
   (cd /tmp && rm -rf /tmp/prof_$n && LAYER_KIND=$k LAYER_SHAPE=$s LAYER_REPS=6 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$n -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
   python scripts/rocprof_summary.py /tmp/prof_$n > $O/kernel_stats_${k}_$n.txt 2>&1
 done
+# bf16 real-tensor I/O at the metric shape (BASELINE configs[1]): kernel stats and the matrix-pipe counters of its step
+# (round 5: the forward-type transforms run their row pass on the matrix cores, k_fft2d_fwd_mx)
+(cd /tmp && rm -rf /tmp/prof_bf16 && LAYER_IO=bf16 LAYER_REPS=6 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf16 -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
+python scripts/rocprof_summary.py /tmp/prof_bf16 > $O/kernel_stats_bf16.txt 2>&1
+(cd /tmp && rm -rf /tmp/pmc_b && LAYER_IO=bf16 LAYER_REPS=3 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_b -o run -- python $GRAFT_REPO_ROOT/scripts/layer_one.py > /dev/null 2>&1)
+python scripts/pmc_summary.py /tmp/pmc_b > $O/pmc_sq_raw_bf16.txt 2>&1
 # sizes off the factorised routes (Darcy grids, resolution changes) beside the reference chain, and their kernel stats
 timeout 600 python scripts/odd_sizes_time.py 2>&1 | grep -v amdgpu.ids > $O/odd_sizes.txt
 for s in 16,32,421,421,32,32 32,32,141,141,32,32 16,32,421,421,64,64 32,32,85,85,32,32; do

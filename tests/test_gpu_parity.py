@@ -142,6 +142,35 @@ def test_bf16_io_vs_oracle(lib, case):
         assert rel_l2(xh.cpu().numpy(), xh32.cpu().numpy()) < 1e-6
 
 
+def test_bf16_forward_on_a_4_byte_aligned_view(lib):
+    """k_fft2d_fwd_mx (round 5) loads whole rows 16 bytes per lane: a bf16 tensor that starts 4 bytes into an allocation
+    (legal for the vector-ALU kernel's 4-byte accesses) takes k_fft2d_fwd3 -- same bits as a plan with
+    SC_PLAN_NO_MX_FFT; the aligned tensor takes the matrix-core kernel, fp32 round-off away."""
+    from neuraloperator_amd import _lib
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    n, H = 6, 128
+    flat = torch.randn(n * H * 256 + 8, device=dev).bfloat16()
+    x_odd = flat[2:2 + n * H * 256].view(n, H, 256)
+    assert x_odd.data_ptr() % 16 == 4
+    x_al = x_odd.clone()
+    assert x_al.data_ptr() % 16 == 0
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for tag, fl, xin in (("mx_aligned", _lib.SC_PLAN_IO_BF16, x_al), ("mx_odd", _lib.SC_PLAN_IO_BF16, x_odd),
+                         ("valu", _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT, x_al)):
+        plan = lib.plan_create([H, 256], [64, 33], flags=fl)
+        xh = torch.zeros(n, 64, 33, 2, device=dev)
+        lib.transform_forward(plan, _lib.SC_FWD_SCALED, xin.data_ptr(), xh.data_ptr(), n, 0, st)
+        torch.cuda.synchronize()
+        out[tag] = xh
+        lib.plan_destroy(plan)
+    assert torch.equal(out["mx_odd"], out["valu"])
+    assert not torch.equal(out["mx_aligned"], out["valu"])
+    assert rel_l2(out["mx_aligned"].cpu().numpy(), out["valu"].cpu().numpy()) < 1e-6
+
+
 def test_module_bf16_activations():
     """bfloat16 in -> bfloat16 out through the drop-in module: native bf16 I/O on the fused kernels, conversion
     around the fp32 engine everywhere else; gradients arrive in the dtypes autograd expects."""
