@@ -134,6 +134,10 @@ enum {
   SC_GEMM_NO_STREAM = 16,    /* never take the LDS-DMA streamed kernel (k_modegemm_s8): generation 1 (A-B) */
   SC_GEMM_NO_SB = 64,        /* never take the small-extent streaming kernel (k_modegemm_sb; A-B / tests)  */
   SC_GEMM_SB_WM4 = 128,      /* k_modegemm_sb: the four waves over 512 contiguous modes of one tile (A-B / tests) */
+  SC_GEMM_SB_ALT_ORDER = 1 << 25, /* small-batch kernels: the OTHER work-item order (round 5; A-B / tests).  Default: k_modegemm_sb
+                                walks its mode tiles slowest (the tiles of a mode tile share the small operand in one L2), the
+                                one-pass backward pair k_modegemm_sb_bwd mode tiles FASTEST (neighbouring workgroups stream
+                                neighbouring pieces of the same weight rows: 5.78 -> 5.54 ms per step at configs[4]) */
   SC_GEMM_NO_FMX = 1 << 24,  /* never take the matrix-core factor-matrix / mode-sum kernels (sc_kernels_fmx.h; A-B / tests) */
   SC_GEMM_F16 = 32           /* the reference's complex-half contraction (fno_block_precision "half" / "mixed",
                               * einsum_utils.py:10-36): operands rounded to float16, four real products summed in

@@ -34,6 +34,7 @@ SC_GEMM_F16 = 32
 SC_GEMM_NO_SB = 64
 SC_GEMM_SB_WM4 = 128
 SC_GEMM_NO_FMX = 1 << 24
+SC_GEMM_SB_ALT_ORDER = 1 << 25
 
 
 def SC_GEMM_GRID(n):

@@ -1715,6 +1715,14 @@ static int sb_max_extent() {
   }();
   return v;
 }
+// work-item order of the small-batch kernels (sc_kernels_sb.h, SbGemmArgs::mt_fastest).  Defaults (round 5, measured at
+// configs[4], profiles/r05_sb_order_ab.txt): k_modegemm_sb mode tiles slowest, the one-pass pair k_modegemm_sb_bwd mode
+// tiles fastest.  SC_GEMM_SB_ALT_ORDER on a descriptor and SC_SB_ALT_ORDER (environment, read once: bit 0 = single
+// launches, bit 1 = the pair) each flip it.
+static int sb_alt_order_env() {
+  static const int v = [] { const char* e = std::getenv("SC_SB_ALT_ORDER"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
 static bool sb_gemm_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
   if (d->flags & (SC_GEMM_F16 | SC_GEMM_NO_SB)) return false;
   if (d->accumulate || d->b_idx || d->c_idx || d->a_sg || d->b_sg || d->c_sg) return false;
@@ -1737,6 +1745,7 @@ static int run_sb_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   const int64_t total = (int64_t)g.n_mt * ((g.n_pt + WP - 1) / WP) * ((g.n_qt + WQ - 1) / WQ);
   if (total >= ((int64_t)1 << 30)) return -1;
   g.per_xcd = (int)((total + 7) / 8);
+  g.mt_fastest = (0 ^ (sb_alt_order_env() & 1) ^ ((d->flags & SC_GEMM_SB_ALT_ORDER) ? 1 : 0)) & 1;
   // an operand that exactly one tile reads crosses the chip once: keep it out of the caches the shared one lives in
   g.nt_a = g.n_qt == 1;
   g.nt_b = g.n_pt == 1;
@@ -1805,6 +1814,7 @@ static int run_sb_bwd(const sc_modegemm_desc* d0, const cf32* A0, const cf32* B0
   const int64_t total = (int64_t)g.n_mt * g.n_itg;
   if (total >= ((int64_t)1 << 30)) return -1;
   g.per_xcd = (int)((total + 7) / 8);
+  g.mt_fastest = (1 ^ ((sb_alt_order_env() >> 1) & 1) ^ (((d0->flags | d1->flags) & SC_GEMM_SB_ALT_ORDER) ? 1 : 0)) & 1;
   static const bool plain_c = std::getenv("SC_SB_PLAIN_C") != nullptr;                 // A-B
   g.nt_gw = (d0->flags & SC_GEMM_STREAM_C) && !plain_c ? 1 : 0;
   switch (g.B) {

@@ -28,6 +28,7 @@ struct SbGemmArgs {
   int64_t P, Q, R, M;
   int64_t a_sp, a_sr, b_sr, b_sq, c_sp, c_sq;     // complex elements; mode stride 1
   int n_mt, n_pt, n_qt, per_xcd;                  // mode tiles of 128 WM, row tiles of PT, column tiles of QT
+  int mt_fastest;                                 // work-item order (see the kernel)
   int nt_a, nt_b, nt_c;                           // non-temporal access to A / B (read once) and C (not read next)
 };
 
@@ -85,8 +86,12 @@ k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__
   const int n_ptg = (g.n_pt + WP - 1) / WP, n_qtg = (g.n_qt + WQ - 1) / WQ;
   const int64_t per_mt = (int64_t)n_ptg * n_qtg;
   if (item >= (int64_t)g.n_mt * per_mt) return;
-  const int mt = (int)(item / per_mt);
-  const int rem = (int)(item - (int64_t)mt * per_mt);
+  // mt_fastest (round 5, weight-sized operands): the workgroups that run side by side on an XCD take NEIGHBOURING mode
+  // tiles of the SAME rows and columns, so that at any moment the chip reads a few dozen rows of the weight in
+  // contiguous runs of ~100 KB instead of 1 KB pieces of thousands of rows (pages) -- the small operand is then shared
+  // through the Infinity Cache rather than an XCD's L2
+  const int mt = g.mt_fastest ? (int)(item % g.n_mt) : (int)(item / per_mt);
+  const int rem = g.mt_fastest ? (int)(item / g.n_mt) : (int)(item - (int64_t)mt * per_mt);
   const int qt = (rem / n_ptg) * WQ + wq, pt = (rem - (rem / n_ptg) * n_ptg) * WP + wp;
   if (pt >= g.n_pt || qt >= g.n_qt) return;                         // whole wave idle (no barriers in this kernel)
   const int64_t m = (((int64_t)mt * WM + wm) * 64 + lane) * 2;      // first of this lane's two modes
@@ -176,6 +181,7 @@ struct SbBwdArgs {
   int64_t gw_si, gw_so;        // gW[i, o, m]
   int64_t gx_sb, gx_si;        // gxhat[b, i, m]
   int n_mt, n_itg, per_xcd;    // mode tiles of 128, groups of 4 row tiles
+  int mt_fastest;              // work-item order (k_modegemm_sb)
   int nt_gw;                   // non-temporal stores for gW (not read by the next kernel)
 };
 
@@ -188,8 +194,8 @@ k_modegemm_sb_bwd(SbBwdArgs g, const cf32* __restrict__ xhat, const cf32* __rest
   const int bid = SC_BID_X;
   const int64_t item = (int64_t)(bid & 7) * g.per_xcd + (bid >> 3);
   if (item >= (int64_t)g.n_mt * g.n_itg) return;
-  const int mt = (int)(item / g.n_itg);
-  const int64_t i0 = ((item - (int64_t)mt * g.n_itg) * 4 + w) * IT;
+  const int mt = g.mt_fastest ? (int)(item % g.n_mt) : (int)(item / g.n_itg);
+  const int64_t i0 = ((g.mt_fastest ? item / g.n_mt : item - (int64_t)mt * g.n_itg) * 4 + w) * IT;
   if (i0 >= g.Ci) return;                                              // whole wave idle (no barriers in this kernel)
   const int64_t m = ((int64_t)mt * 64 + lane) * 2;                     // first of this lane's two modes
   const bool active = m < g.M;

@@ -170,3 +170,16 @@ def test_backward_pair_one_pass_over_the_weight(lib, dims):
         assert lib.modegemm_path(**kw_w) == 3 and lib.modegemm_path(**kw_x) == 3
     assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw2))
     assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx2))
+    # round 5: the pair walks its mode tiles FASTEST by default (neighbouring workgroups stream neighbouring pieces of the
+    # same weight rows), the single launches slowest; SC_GEMM_SB_ALT_ORDER flips either -- a different assignment of the
+    # same work items: same bits
+    alt = _lib.SC_GEMM_SB_ALT_ORDER
+    gw3, gx3 = nan(Ci, Co, M), nan(B, Ci, M)
+    lib.modegemm_pair(dict(kw_w, flags=kw_w["flags"] | alt), p(xh), p(gh), p(gw3), kw_x, p(gh), p(w), p(gx3))
+    assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw3))
+    assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx3))
+    gw4, gx4 = nan(Ci, Co, M), nan(B, Ci, M)
+    lib.modegemm(p(xh), p(gh), p(gw4), 0, **dict(kw_w, flags=kw_w["flags"] | alt))
+    lib.modegemm(p(gh), p(w), p(gx4), 0, **dict(kw_x, flags=alt))
+    assert torch.equal(torch.view_as_real(gw), torch.view_as_real(gw4))
+    assert torch.equal(torch.view_as_real(gx), torch.view_as_real(gx4))
