@@ -707,10 +707,8 @@ def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv
 
 
 def free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+    from neuraloperator_amd.mpu import comm
+    return comm.free_port()                              # outside the ephemeral range (see there)
 
 
 def launch_command(n, argv, port):

@@ -107,8 +107,9 @@ inline sc_mx_u4 sc_mx_load16(const void* p) { return sc_mx_load16_stream(p); }
 // interleaved with the column phase of group a (92-95 us).
 #define SC_MX_RS 36       // row stride (complex) of the unpacked group tile T2[64 rows][33 columns + 3 parked k = 32 columns]:
                           // the accumulator stores and the column-phase reads are both conflict-free per half-wave
-#define SC_MX_SS 528      // row stride (bytes) of a wave's staged rows: 16-byte writes of whole rows and 16-byte reads in MFMA
-                          // order (16 rows at one column offset) are both conflict-free
+#define SC_MX_SS 144      // a wave's staged rows, four planes (r = n mod 4) of [16 rows][64 samples = 128 bytes + 16]: the
+#define SC_MX_PS (16 * SC_MX_SS)   // 4-byte writes of a half-wave (one row of a plane) and the 16-byte reads of 16 rows at
+                          // one offset are both conflict-free
 #define SC_MX_WGS 2       // persistent workgroups per compute unit = the kernel's register budget (two waves per SIMD)
 
 template <int H>
@@ -122,7 +123,7 @@ struct F3MxLds {
   static constexpr int off_tw64 = off_twH + H * 8;
   static constexpr int off_twr = off_tw64 + 64 * 8;        // w256^(r k), [r - 1][u][j], k = 2 j + u
   static constexpr int off_stg = off_twr + 96 * 8;         // staged rows: [wave][16 rows][SC_MX_SS bytes]
-  static constexpr int total = off_stg + 4 * 16 * SC_MX_SS;
+  static constexpr int total = off_stg + 4 * 4 * SC_MX_PS;
   static_assert(P <= 4, "k = 32 of group a is parked in column 32 + a of its row (H <= 256)");
   static_assert(SC_F2D_KX * SC_F2D_KY <= T_c, "output tile aliases the group tile");
   static_assert(SC_MX_WGS * total <= 160 * 1024, "workgroups per compute unit");
@@ -204,7 +205,7 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
   //      b = 8 b1 + mu; cb = the column's private exchange patch; F_a[q1 + 8 q2] w_H^(a fx) goes to acc (+=) or, for the
   //      deferred 33rd column, to dst[q]
   cf32 acc[8];
-  auto column = [&](const cf32* src, cf32* cb, const int a, auto extra_tag, cf32* dst, const bool act) {
+  auto column = [&](const cf32* src, cf32* cb, const int a, auto extra_tag, cf32* dst, const bool act) SC_ALWAYS_INLINE_LAMBDA {
     constexpr bool EXTRA = decltype(extra_tag)::value != 0;
     cf32 v[8], o[8];
 #pragma unroll
@@ -238,12 +239,12 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
   //      weights and cost the two contractions of a step what the transform gains (0.4178 vs 0.422 ms per bf16 step,
   //      profiles/r05_mx_fft_ab.txt).  So: whole rows by coalesced NON-TEMPORAL 16-byte loads (instruction q of a wave =
   //      its rows 2 q, 2 q + 1, a half-wave each: 512 contiguous bytes), through a per-wave LDS image, out in MFMA order.
-  unsigned char* stg = smem + L::off_stg + w * (16 * SC_MX_SS);
+  unsigned char* stg = smem + L::off_stg + w * (4 * SC_MX_PS);
   sc_mx_u4 xq[8];
 #ifdef SC_MX_ABL_NOLOAD
   for (int q = 0; q < 8; ++q) xq[q] = sc_mx_u4{(uint32_t)(0x3f803f80u + lane), 0x3f80bf80u, 0x40003f00u, 0x3e803f80u};
 #endif
-  auto request = [&](const int64_t im, const int a) {
+  auto request = [&](const int64_t im, const int a) SC_ALWAYS_INLINE_LAMBDA {
     const int64_t imc = im < n_images ? im : n_images - 1;           // past the end: a harmless re-read
     const unsigned char* base = reinterpret_cast<const unsigned char*>(x + (imc * H + (P * (16 * w + (lane >> 5)) + a)) * SC_F2D_W) +
                                 16 * (lane & 31);
@@ -266,33 +267,19 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
 #pragma unroll 1
     for (int a = 0; a < P; ++a) {
       // ---------------- rows of group a on the matrix cores ----------------
-      // split the lane's 2 x 32 samples by r = n mod 4: fragment [r][ks] = x[4 m + r], m = 32 ks + 8 g + e;
-      // element e sits at local sample 4 e + r = dword 2 e + (r >> 1), half r & 1
-      sc_mx_u4 A[4][2];
-      // registers -> the wave's LDS image; the registers are free for the next group's request at once (the rows of the
-      // next image behind the last group)
+      // registers -> the wave's LDS image, split by r = n mod 4 on the way: a loaded 16-byte piece = samples 8 c .. 8 c + 7
+      // of its row = elements m = 2 c, 2 c + 1 of each r; (s_r, s_{r+4}) is one dword of plane r (v_perm_b32).  The
+      // registers are free for the next group's request at once (the rows of the next image behind the last group).
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        *reinterpret_cast<sc_mx_u4*>(stg + (2 * q + (lane >> 5)) * SC_MX_SS + 16 * (lane & 31)) = xq[q];
+      for (int q = 0; q < 8; ++q) {
+        uint32_t* dst = reinterpret_cast<uint32_t*>(stg + (2 * q + (lane >> 5)) * SC_MX_SS) + (lane & 31);
+        dst[0 * (SC_MX_PS / 4)] = sc_mx_pick(xq[q].z, xq[q].x, 0);      // r = 0: low halves of dwords 0 and 2
+        dst[1 * (SC_MX_PS / 4)] = sc_mx_pick(xq[q].z, xq[q].x, 1);      // r = 1: high halves
+        dst[2 * (SC_MX_PS / 4)] = sc_mx_pick(xq[q].w, xq[q].y, 0);      // r = 2
+        dst[3 * (SC_MX_PS / 4)] = sc_mx_pick(xq[q].w, xq[q].y, 1);      // r = 3
+      }
       request(a + 1 < P ? img : img + gstride, a + 1 < P ? a + 1 : 0);     // (selects, no branch around the loads)
       SC_WAVE_SYNC();
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        sc_mx_u4 dq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          dq[q] = *reinterpret_cast<const sc_mx_u4*>(stg + j * SC_MX_SS + 256 * ks + 64 * g + 16 * q);
-        const uint32_t d[16] = {dq[0].x, dq[0].y, dq[0].z, dq[0].w, dq[1].x, dq[1].y, dq[1].z, dq[1].w,
-                                dq[2].x, dq[2].y, dq[2].z, dq[2].w, dq[3].x, dq[3].y, dq[3].z, dq[3].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          A[r][ks].x = sc_mx_pick(d[2 + (r >> 1)], d[0 + (r >> 1)], r & 1);
-          A[r][ks].y = sc_mx_pick(d[6 + (r >> 1)], d[4 + (r >> 1)], r & 1);
-          A[r][ks].z = sc_mx_pick(d[10 + (r >> 1)], d[8 + (r >> 1)], r & 1);
-          A[r][ks].w = sc_mx_pick(d[14 + (r >> 1)], d[12 + (r >> 1)], r & 1);
-        }
-      }
-      SC_WAVE_SYNC();                                      // the image is rewritten at the next group
       float yre[2][4], yim[2][4], ere[4], eim[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -301,8 +288,11 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int v = 0; v < 4; ++v) c[t][v] = 0.f;
+        // fragment [ks] = x[4 m + r], m = 32 ks + 8 g + e: 16 contiguous bytes of plane r, row j
+        const sc_mx_u4 A0 = *reinterpret_cast<const sc_mx_u4*>(stg + r * SC_MX_PS + j * SC_MX_SS + 16 * g);
+        const sc_mx_u4 A1 = *reinterpret_cast<const sc_mx_u4*>(stg + r * SC_MX_PS + j * SC_MX_SS + 64 + 16 * g);
         // second half of the m range: w64^(32 k) = (-1)^k -- the odd-k tiles take it negated
-        sc_mx_u4 An = A[r][1];
+        sc_mx_u4 An = A1;
         An.x ^= 0x80008000u;
         An.y ^= 0x80008000u;
         An.z ^= 0x80008000u;
@@ -313,7 +303,7 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
           for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int t = 0; t < 4; ++t)                                // four accumulators in turn: no back-to-back dependence
-              sc_mfma_16x16x32_bf16(c[t], hf == 0 ? A[r][0] : (t < 2 ? A[r][1] : An), F[t][term]);
+              sc_mfma_16x16x32_bf16(c[t], hf == 0 ? A0 : (t < 2 ? A1 : An), F[t][term]);
         // Y += w256^(r k) S_r (u = 0: k = 2 j, u = 1: k = 2 j + 1);  k = 32 (the Im column of k = 0): E += w8^r S_r[32]
         constexpr float h = 0.70710678118654752440f;
         const float er = (r == 0) ? 1.f : (r == 1) ? h : (r == 2) ? 0.f : -h;
@@ -347,7 +337,8 @@ k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf3
         }
         SC_SCHED_BARRIER();                                // one r at a time: two sets of accumulators do not fit
       }
-      SC_SYNC();                                           // the column phase of the group before has read T2
+      SC_SYNC();                                           // the column phase of the group before has read T2 (and every
+                                                           // lane of the wave its fragments: the image is free)
       {
         cf32* tr = T + (16 * w + 4 * g) * RS;
 #pragma unroll

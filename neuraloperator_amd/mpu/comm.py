@@ -130,3 +130,31 @@ def cleanup():
     rccl_native.shutdown()                    # the engine's own RCCL communicators (round 4), before torch's
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def free_port():
+    """A TCP port for a single-node rendezvous (MASTER_PORT), free right now and OUTSIDE the kernel's ephemeral range.
+
+    A port taken from ``bind(("127.0.0.1", 0))`` lies INSIDE that range: between closing the probe socket and the
+    store's own bind, any client socket of the same job (a rank connecting to the store, RCCL's bootstrap) can be
+    handed the very same number as its source port -- the rendezvous then dies with EADDRINUSE (seen on the GPU tier,
+    round 5: tests/test_gpu_graph.py on a busy box)."""
+    import random
+    import socket
+    lo = 32768
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo = int(f.read().split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    hi = max(min(lo, 32768), 12000)
+    rng = random.Random(os.getpid() * 7919 + int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        port = rng.randrange(10000, hi)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError("no free port below the ephemeral range")

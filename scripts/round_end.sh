@@ -4,7 +4,7 @@
 # matrix-pipe busy cycles of the contraction kernels).  Writes gpurun_out/$1 (default rz); copy the summaries to profiles/.
 O=gpurun_out/${1:-rz}; mkdir -p $O
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > $O/pytest.log
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -60) > $O/pytest.log
 (python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -12) > $O/smoke.log
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gpu-reference --no-extras --no-pmc > $GRAFT_REPO_ROOT/$O/bench_prof.json 2> $GRAFT_REPO_ROOT/$O/bench_prof.err)

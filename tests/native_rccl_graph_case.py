@@ -20,10 +20,7 @@ def _flat(t):
 
 
 def main(batch, kw):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = comm.free_port()                               # outside the ephemeral range (EADDRINUSE otherwise, now and then)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     dev = torch.device("cuda:0")
     comm.init(model_parallel_size=1, backend="nccl")

@@ -825,10 +825,7 @@ def test_mode_parallel_layer_on_device_single_rank():
     import torch.distributed as dist
     from neuraloperator_amd import SpectralConv
     from neuraloperator_amd.mpu import ModeParallelSpectralConv, comm
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = comm.free_port()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     dev = torch.device("cuda:0")
     comm.init(model_parallel_size=1, backend="nccl")

@@ -17,9 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize("world", [1, 2, 4])
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
 def test_peer_exchange_processes_on_one_device(world):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = str(s.getsockname()[1])
+    from neuraloperator_amd.mpu import comm
+    port = str(comm.free_port())                          # outside the ephemeral range
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)

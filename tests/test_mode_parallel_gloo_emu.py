@@ -18,11 +18,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from neuraloperator_amd.mpu import comm
+    return comm.free_port()                 # outside the ephemeral range: no client socket can be handed it
 
 
 def _worker(rank, world, port, spatial, modes, bl, ci, co, ret):
