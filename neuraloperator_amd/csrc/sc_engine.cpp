@@ -2414,7 +2414,7 @@ extern "C" int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, co
     int rc = sc_check_launch("k_modegemm_msum<slots>");
     if (rc) return rc;
     const int npc = (int)(d->P * d->Q);
-    SC_LAUNCH(k_fmx_reduce, dim3((unsigned)((npc + 15) / 16)), dim3(256), 0, st, (const cf32*)partial, (int)slots, npc,
+    SC_LAUNCH(k_fmx_reduce, dim3((unsigned)((npc + 15) / 16)), dim3(16 * SC_FMX_RED_RG), 0, st, (const cf32*)partial, (int)slots, npc,
               (int)d->Q, (cf32*)C, d->c_sp, d->c_sq);
     return sc_check_launch("k_fmx_reduce");
   }
@@ -2428,7 +2428,7 @@ extern "C" int sc_modegemm_msum_ws(const sc_modegemm_desc* d, const float* A, co
   else rc = run_fmx_msum_t<16, 16, 4>(d, g, lds, a, b, partial, st);
   if (rc) return rc;
   const int npc = (int)(d->P * d->Q);
-  SC_LAUNCH(k_fmx_reduce, dim3((unsigned)((npc + 15) / 16)), dim3(256), 0, st, (const cf32*)partial, g.n_wg, npc, (int)d->Q,
+  SC_LAUNCH(k_fmx_reduce, dim3((unsigned)((npc + 15) / 16)), dim3(16 * SC_FMX_RED_RG), 0, st, (const cf32*)partial, g.n_wg, npc, (int)d->Q,
             (cf32*)C, d->c_sp, d->c_sq);
   return sc_check_launch("k_fmx_reduce");
 }

@@ -157,16 +157,21 @@ k_modegemm_msum_mx(FmxArgs g, const cf32* __restrict__ A, const cf32* __restrict
   }
 }
 
-// C[p, q] = sum_k partial[k][p Q + q] (fixed order); a block takes 16 entries x 16 row groups
-SC_GLOBAL void SC_LAUNCH_BOUNDS(256)
+// C[p, q] = sum_k partial[k][p Q + q] (fixed order); a block takes 16 entries x RG row groups (RG x 16 threads).
+// Round 5: 64 row groups (1024 threads) instead of 16 -- the launch is a latency chain (each thread's n / RG loads, then
+// the column's RG partial sums added in order by one thread), not bandwidth: 13.9 -> 11.2 us at TFNO rank 0.1 (partials
+// of 64 x 36).  The order of the additions is fixed by (k mod RG, then the row groups ascending): reproducible.
+#define SC_FMX_RED_RG 64
+SC_GLOBAL void SC_LAUNCH_BOUNDS(16 * SC_FMX_RED_RG)
 k_fmx_reduce(const cf32* __restrict__ partial, int n, int npc, int Q, cf32* __restrict__ C, int64_t c_sp, int64_t c_sq) {
-  SC_SHARED cf32 red[16][17];
+  constexpr int RG = SC_FMX_RED_RG;
+  SC_SHARED cf32 red[RG][17];
   const int tid = SC_TID, cx = tid & 15, rg = tid >> 4;
   const int col = SC_BID_X * 16 + cx;
   cf32 acc = cf_make(0.f, 0.f);
   if (col < npc) {
-#pragma unroll 8
-    for (int k = rg; k < n; k += 16) {
+#pragma unroll 4
+    for (int k = rg; k < n; k += RG) {
       const cf32 v = partial[(int64_t)k * npc + col];
       acc.x += v.x;
       acc.y += v.y;
@@ -176,7 +181,7 @@ k_fmx_reduce(const cf32* __restrict__ partial, int n, int npc, int Q, cf32* __re
   SC_SYNC();
   if (rg == 0 && col < npc) {
     cf32 t = red[0][cx];
-    for (int r = 1; r < 16; ++r) {
+    for (int r = 1; r < RG; ++r) {
       t.x += red[r][cx].x;
       t.y += red[r][cx].y;
     }
