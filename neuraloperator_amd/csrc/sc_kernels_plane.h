@@ -85,6 +85,9 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
   float* stg = reinterpret_cast<float*>(lds + PlLds::off_E + wv * (4 * 8 * SC_PL_ES));
   sc_f4 ldq[SC_PL_PF_DEPTH][4];
   auto request = [&](const int n, sc_f4 (&q)[4]) {
+#ifdef SC_PL_ABL_NOLOAD                                   // measurement build only
+    if (n >= -1) return;
+#endif
     if (n >= n_rounds) return;
     int64_t pl = plane0 + (n >> 2);
     pl = pl < n_planes ? pl : n_planes - 1;              // past the end: a harmless re-read
@@ -185,7 +188,11 @@ k_pl128_fwd(const float* __restrict__ x, cf32* __restrict__ out, const cf32* __r
     // ---------------- columns: 8 lanes per kept column ----------------
     {
       const int c = tid >> 3, tc = tid & 7;
+#ifdef SC_PL_ABL_NOCOL                                    // measurement build only
+      const bool act = c < 0;
+#else
       const bool act = c < SC_PL_JMAX;                   // waves 0, 1 and the first group of wave 2
+#endif
       cf32* E2 = lds + PlLds::off_E + (act ? c : 0) * 148;
       if (act) {
         cf32 v[16], u[16];
