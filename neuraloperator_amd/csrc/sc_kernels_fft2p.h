@@ -731,10 +731,45 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
     const cf32* src = panel + ((int64_t)img * NCB * N0 + rA) * SC_F2P_CB;
     const float bv = bias ? bias[(img + img0) % channels] : 0.f;
     cf32 T[16], U[16];
+#ifndef SC_W1K_DIRECT_LOADS
+    // Round 5, session 2: the pair's panel rows through the wave's exchange area.  The pair needs 17 blocks x (2 rows x 8
+    // columns) = 17 x 128 contiguous bytes; read lane by lane in FFT order that was 32 load instructions of 8 bytes per
+    // lane, each touching two 64-byte pieces (the four r lanes of an l share an address) -- the kernel runs 188 us WITHOUT
+    // its stores (profiles/r05_c2r_w1024_ab.txt): bound by its load instructions, not by the 730 MB it writes.  Now
+    // three 16-byte accesses per lane (1 KB per instruction) land in LDS and the lanes pick their values up from there
+    // (conflict-free 8-byte reads, the r lanes broadcast).  The image aliases E: it is consumed before the first
+    // transform's results are exchanged.
+    // LDS-DMA (16 bytes per lane straight into LDS, lane l at base + 16 l: exactly the image's granule order) -- as register
+    // loads the three granules cost 12 registers the kernel does not have at four workgroups per unit (20 bytes of scratch)
+    // granule c = 64 i + lane: block 8 i + (lane >> 3), granule lane & 7 (2 complex) -> a lane part + a wave-uniform part;
+    // 17 blocks = 136 granules: the third access is live in lanes 0..7 only (the rest re-read granule 135 into the
+    // unused tail of the area)
+    {
+      const int lo = sc_opaque((lane >> 3) * N0 * SC_F2P_CB + 2 * (lane & 7));
+      SC_GLDS16(src + lo, E);
+      SC_GLDS16(src + lo + (int64_t)8 * N0 * SC_F2P_CB, E + 128);
+      const int lo2 = lane < 8 ? 2 * lane : 14;
+      SC_GLDS16(src + (int64_t)16 * N0 * SC_F2P_CB + lo2, E + 256);
+    }
+    sc_wait_vmcnt<0>();                                    // (in order behind the previous item's stores, as the loads were)
+    SC_WAVE_SYNC();
+    const cf32* Pi = reinterpret_cast<const cf32*>(E);     // [block][row A: 8 columns | row B: 8 columns]
+    const int lpi = (l >> 3) * 16 + (l & 7), lni = ((16 - l) >> 3) * 16 + ((16 - l) & 7);
+#endif
     sc_static_for<0, 16>([&](auto qt) {
       constexpr int q = decltype(qt)::value;
+#ifndef SC_W1K_DIRECT_LOADS
+      const cf32* sq = Pi + (q < 8 ? q : 15 - q) * 32 + (q < 8 ? lpi : lni);   // 16 columns further = two blocks of 16 values
+      cf32 A = sc_lds_ld64(sq), B = sc_lds_ld64(sq + SC_F2P_CB);
+#else
       const cf32* sq = src + (q < 8 ? q : 15 - q) * (int64_t)qs + (q < 8 ? lp : ln);
+#ifdef SC_W1K_ABL_NOLOAD                                  // measurement build only
+      cf32 A = cf_make((float)(lane + q), (float)(item & 7)), B = cf_make((float)q, (float)lane);
+      if (item == -12345) { A = sq[0]; B = sq[SC_F2P_CB]; }
+#else
       cf32 A = sq[0], B = sq[SC_F2P_CB];
+#endif
+#endif
       if constexpr (q == 0) {                              // k = 0: the imaginary parts of the DC column are dropped
         if (l == 0) {
           A.y = 0.f;
@@ -750,6 +785,9 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
         if constexpr (q == 8) T[q] = cf_add(T[q], cf_mul_cs(Zp, twx));
       }
     });
+#ifndef SC_W1K_DIRECT_LOADS
+    SC_WAVE_SYNC();                                        // every lane has its inputs: the exchange may overwrite the image
+#endif
     fft16<+1>(T, U);                                       // over kappa2 -> ma
     E[r * SC_W1K_RS + l] = U[0];
 #pragma unroll
@@ -764,8 +802,13 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
     float* yb = ya + N;
 #pragma unroll
     for (int mb = 0; mb < 16; ++mb) {
+#ifdef SC_W1K_ABL_NOSTORE                                 // measurement build only
+      if (U[mb].x == 12345.678f) SC_STORE_STREAM(ya + 64 * mb, U[mb].x + bv);
+      if (U[mb].y == 12345.678f) SC_STORE_STREAM(yb + 64 * mb, U[mb].y + bv);
+#else
       SC_STORE_STREAM(ya + 64 * mb, U[mb].x + bv);
       SC_STORE_STREAM(yb + 64 * mb, U[mb].y + bv);
+#endif
     }
   }
 }
