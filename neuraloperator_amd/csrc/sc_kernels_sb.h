@@ -118,12 +118,30 @@ k_modegemm_sb(SbGemmArgs g, const cf32* __restrict__ A, const cf32* __restrict__
   // clamped re-reads of the last one (requested, never used), whole blocks of ST steps run unguarded, the
   // R % ST remaining steps use what the ring already holds.
   sc_f4 ra[ST][PT], rb[ST][QT];
+#if defined(SC_SB_ABL_NOA) || defined(SC_SB_ABL_NOB)
+  for (int s_ = 0; s_ < ST; ++s_) {
+    for (int pp = 0; pp < PT; ++pp) ra[s_][pp] = sc_f4{1.f, (float)lane, 2.f, 3.f};
+    for (int qq = 0; qq < QT; ++qq) rb[s_][qq] = sc_f4{(float)lane, 1.f, 0.5f, 2.f};
+  }
+#endif
   auto request = [&](const int64_t r, sc_f4 (&a)[PT], sc_f4 (&b)[QT]) {
     const int64_t rr = r < g.R ? r : g.R - 1;
 #pragma unroll
-    for (int pp = 0; pp < PT; ++pp) a[pp] = sb_load(Ap[pp] + rr * g.a_sr, g.nt_a);
+    for (int pp = 0; pp < PT; ++pp) {
+#ifdef SC_SB_ABL_NOA                                       // measurement builds only: one operand's loads removed
+      if (r == -12345) a[pp] = sb_load(Ap[pp] + rr * g.a_sr, g.nt_a);
+#else
+      a[pp] = sb_load(Ap[pp] + rr * g.a_sr, g.nt_a);
+#endif
+    }
 #pragma unroll
-    for (int qq = 0; qq < QT; ++qq) b[qq] = sb_load(Bq[qq] + rr * g.b_sr, g.nt_b);
+    for (int qq = 0; qq < QT; ++qq) {
+#ifdef SC_SB_ABL_NOB
+      if (r == -12345) b[qq] = sb_load(Bq[qq] + rr * g.b_sr, g.nt_b);
+#else
+      b[qq] = sb_load(Bq[qq] + rr * g.b_sr, g.nt_b);
+#endif
+    }
   };
   auto multiply = [&](const sc_f4 (&a)[PT], const sc_f4 (&b)[QT]) {
 #pragma unroll
