@@ -325,8 +325,13 @@ k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __r
     const float* xa = x + 2 * pr * N + t;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
+#ifdef SC_R2C_ABL_NOLOAD                                  // measurement build only
+      z[g][j] = cf_make(1.f + 0.01f * j, 0.5f);
+      if (n_pairs == -12345) z[g][j].x = SC_LOAD_STREAM(xa + 32 * j);
+#else
       z[g][j].x = SC_LOAD_STREAM(xa + 32 * j);
       z[g][j].y = SC_LOAD_STREAM(xa + N + 32 * j);
+#endif
     }
   }
   float sc[NI];
@@ -375,8 +380,12 @@ k_f2p_r2c(const float* __restrict__ x, cf32* __restrict__ panel, const cf32* __r
         const float s = sc[i];
         // A = (Z[k] + conj Z[-k]) / 2,  B = -i (Z[k] - conj Z[-k]) / 2
         cf32* d = dst + (int64_t)(k >> 3) * N0 * SC_F2P_CB + (k & 7);
+#ifdef SC_R2C_ABL_NOSTORE                                 // measurement build only
+        if (zk.x == 12345.678f) d[0] = zk;
+#else
         d[0] = cf_make(s * (zk.x + zm.x), s * (zk.y - zm.y));
         d[SC_F2P_CB] = cf_make(s * (zk.y + zm.y), s * (zm.x - zk.x));
+#endif
       }
     }
   }
