@@ -822,6 +822,12 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
   }
 }
 
+// Round 5, session 2, measured and NOT kept: the forward analogue k_f2p_r2c_w1024 (one wave per packed row pair, the pair's
+// 8 KB of rows through the exchange area, four 256-point transforms + a four-term twiddled sum per kept k through LDS):
+// 194 us with the rows fetched by LDS-DMA at the top of an item, 186 us with register loads one item ahead, against 161-164 us
+// for k_f2p_r2c<32, 4> (whose phases add up -- 118 us without its loads, 132 us without its stores -- but which needs one
+// exchange where this form needs three LDS round trips): profiles/r05_r2c_w1024_ab.txt.
+
 // Round 4, measured and NOT kept: the whole inverse-type 1024 x 1024 transform in ONE pass without the panel -- a workgroup
 // per band of 16 output rows n0 = t + 64 j recomputing the zero-padded column transform for its band straight from the
 // spectrum (L2-resident), then the row transforms above out of LDS.  HBM traffic drops to R + S, but the spectrum is read
