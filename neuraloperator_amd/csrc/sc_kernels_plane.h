@@ -354,8 +354,13 @@ k_pl128_inv(const cf32* __restrict__ in, float* __restrict__ y, const cf32* __re
       float* ra = yp + (2 * p) * SC_PL_N + t;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+#ifdef SC_PL_ABL_NOSTORE                                  // measurement build only
+        if (z[j].x == 12345.678f) SC_STORE_STREAM(ra + 16 * j, z[j].x + bv);
+        if (z[j].y == 12345.678f) SC_STORE_STREAM(ra + SC_PL_N + 16 * j, z[j].y + bv);
+#else
         SC_STORE_STREAM(ra + 16 * j, z[j].x + bv);
         SC_STORE_STREAM(ra + SC_PL_N + 16 * j, z[j].y + bv);
+#endif
       }
 #endif
       SC_WAVE_SYNC();                                    // Zs / E are rewritten by the next round
