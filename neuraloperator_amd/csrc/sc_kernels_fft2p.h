@@ -873,40 +873,64 @@ k_f2p_col_inv_w1024(const cf32* __restrict__ yhat, cf32* __restrict__ panel, con
   const cf32* Er = E + c * SC_CW1K_CS + r * SC_CW1K_RS + l * SC_W1K_ES;
   // persistent: consecutive blocks (the column blocks of one image) on ONE XCD, as in k_f2p_col_inv
   const bool xmap = (gstride & 7) == 0;
-  SC_SYNC();                                               // tw2
+  const int per = gstride >> 3;                            // workgroups per XCD
+  const int per_xcd_blocks = (n_blk + 7) / 8;
+  auto block_of = [&](const int it) {                      // -1: past this workgroup's last block
+    if (xmap) {
+      const int local = it * per + (int)(SC_BID_X >> 3);
+      return local >= per_xcd_blocks ? -1 : (int)(SC_BID_X & 7) * per_xcd_blocks + local;
+    }
+    const int bb = it * gstride + (int)SC_BID_X;
+    return bb >= n_blk ? -1 : bb;
+  };
+  // Round 5, session 2: the sixteen inputs of a thread are requested ONE BLOCK AHEAD.  The kernel ran 65.6 us per launch,
+  // 37.5 us without its stores and 37.7 us without its loads (profiles/r05_col_inv_w1024_ab.txt): the loads at the top
+  // of a block (two 64-byte pieces of two kept rows per wave instruction) were waited for with nothing else in flight.
+  cf32 raw[16];
+  auto request = [&](const int blk) SC_ALWAYS_INLINE_LAMBDA {
+    const int bc = blk < 0 ? 0 : (blk < n_blk ? blk : n_blk - 1);           // past the end: a harmless re-read
+    const int img = bc / NCB, col = (bc - img * NCB) * SC_F2P_CB + c;
+    const cf32* src = yhat + (int64_t)img * K0 * J + (col < J ? col : 0);
+    sc_static_for<0, 16>([&](auto qt) {
+      constexpr int q = decltype(qt)::value;
+      constexpr int step = 16 * q - (q >= 8 ? 256 : 0);
+      if constexpr (FULL) {
+#ifdef SC_CW1K_ABL_NOLOAD                                 // measurement build only
+        raw[q] = (blk == -12345) ? src[(int64_t)row0 * J + (int64_t)step * J] : cf_make(1.f, 0.5f);
+#else
+        raw[q] = src[(int64_t)row0 * J + (int64_t)step * J];                // (lane part) + (uniform part)
+#endif
+      } else {
+        const int row = row0 + step;
+        raw[q] = src[(int64_t)((row >= 0 && row < K0) ? row : 0) * J];
+      }
+    });
+  };
+  if constexpr (FULL) request(block_of(0));                // (K0 < 256: no room for the 32 registers at four waves per SIMD --
+  SC_SYNC();                                               //  that instantiation requests at the top of the block as before)
 
 #pragma unroll 1
   for (int it = 0;; ++it) {
-    int blk;
-    if (xmap) {
-      const int per = gstride >> 3;                        // workgroups per XCD
-      const int per_xcd_blocks = (n_blk + 7) / 8;
-      const int local = it * per + (int)(SC_BID_X >> 3);
-      if (local >= per_xcd_blocks) break;
-      blk = (int)(SC_BID_X & 7) * per_xcd_blocks + local;
-    } else {
-      blk = it * gstride + (int)SC_BID_X;
-      if (blk >= n_blk) break;
-    }
+    const int blk = block_of(it);
+    if (blk < 0) break;
     const bool have = blk < n_blk;                         // (XCD map: the last XCD's tail)
     const int bc = have ? blk : n_blk - 1;
     const int img = bc / NCB, col = (bc - img * NCB) * SC_F2P_CB + c;
     const bool live = have && col < J;
-    const cf32* src = yhat + (int64_t)img * K0 * J + (col < J ? col : 0);
+    if constexpr (!FULL) request(blk);
     cf32 T[16], U[16];
     sc_static_for<0, 16>([&](auto qt) {
       constexpr int q = decltype(qt)::value;
       constexpr int step = 16 * q - (q >= 8 ? 256 : 0);
       if constexpr (FULL) {
-        const cf32 v = src[(int64_t)row0 * J + (int64_t)step * J];       // (lane part) + (uniform part)
-        T[q] = live ? cf_mul_cs(v, sc_lds_ld64(twqr + q)) : cf_make(0.f, 0.f);
+        T[q] = live ? cf_mul_cs(raw[q], sc_lds_ld64(twqr + q)) : cf_make(0.f, 0.f);
       } else {
         const int row = row0 + step;
         const bool ok = row >= 0 && row < K0;
-        const cf32 v = src[(int64_t)(ok ? row : 0) * J];
-        T[q] = (live && ok) ? cf_mul_cs(v, sc_lds_ld64(twqr + q)) : cf_make(0.f, 0.f);
+        T[q] = (live && ok) ? cf_mul_cs(raw[q], sc_lds_ld64(twqr + q)) : cf_make(0.f, 0.f);
       }
     });
+    if constexpr (FULL) request(block_of(it + 1));         // the next block's inputs while this one is transformed
     fft16<+1>(T, U);                                       // over kappa2 -> ma
     Ew[0] = cf_mul_cs(U[0], twl);
 #pragma unroll
@@ -920,7 +944,13 @@ k_f2p_col_inv_w1024(const cf32* __restrict__ yhat, cf32* __restrict__ panel, con
     if (live) {
       cf32* dst = panel + (int64_t)bc * N0 * SC_F2P_CB + L * SC_F2P_CB + c;
 #pragma unroll
-      for (int mb = 0; mb < 16; ++mb) dst[(int64_t)64 * mb * SC_F2P_CB] = U[mb];
+      for (int mb = 0; mb < 16; ++mb) {
+#ifdef SC_CW1K_ABL_NOSTORE                                // measurement build only
+        if (U[mb].x == 12345.678f) dst[(int64_t)64 * mb * SC_F2P_CB] = U[mb];
+#else
+        dst[(int64_t)64 * mb * SC_F2P_CB] = U[mb];
+#endif
+      }
     }
   }
 }
