@@ -131,7 +131,7 @@ def test_fused_fft_bf16_io_matches_oracle(lib, case):
     yo.backward(g.float())
     _, xk = so.forward_np64(x.float().numpy(), w.numpy(), bias.numpy(), nm, nm)
     errs = {}
-    for fl in (_lib.SC_PLAN_IO_BF16, _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT):
+    for fl in (_lib.SC_PLAN_IO_BF16, _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT)[:2 if H <= 64 else 1]:   # (CPU-tier time)
         y, gx, gw, gb, xh = layer_fwd_bwd(lib, x, w, bias, g, nm, nm, flags=fl)
         bf16_checks(y, yo.detach(), "y")
         bf16_checks(gx, xc.grad, "gx")
