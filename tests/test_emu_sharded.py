@@ -47,7 +47,7 @@ def test_sharded_transforms_match_plain_plus_permutation(lib, case):
     kept, _ = kept_block(list(spatial), nm, nm)
     k1, rest = kept[0], int(np.prod(kept[1:]))
     rows = -(-k1 // P)
-    n, c = 2, 3
+    n, c = (1, 2) if int(np.prod(spatial)) >= 64 ** 3 else (2, 3)      # (64^3 volumes in host emulation: CPU-tier time)
     ni = n * c
     plan = lib.plan_create(list(spatial), kept)
     x = torch.randn(n, c, *spatial)
