@@ -468,7 +468,8 @@ int sc_layer_forward_ex(const sc_plan* plan, const sc_layer_desc* L, const float
  * unused `_transpose`: split dim0, all-to-all, concatenate dim1).  Here the transforms on either side of that
  * all-to-all write / read its rank-major buffer IN PLACE, so that no permutation copy is left around the collective:
  * the kept block of every image is cut along its FIRST mode dim into n_blocks blocks of `rows` rows
- * (n_blocks * rows >= k1; rows past k1 are zeros on the wire) and block p of image i lives at
+ * (n_blocks * rows >= k1; rows past k1 are zeros on the wire -- round 5: also whole blocks, e.g. k1 = 6 over 4 ranks =
+ * three blocks of 2 rows and an empty one) and block p of image i lives at
  *     xhat + p * block_stride + (i * rows + r) * rest + j        (complex elements; rest = k2 * .. * kN)
  * i.e. xhat is the tensor [n_blocks][n_images][rows][rest] (block_stride >= n_images * rows * rest).  The fused 2-D
  * kernels address this layout natively; every other shape runs the plain transform through a staging copy in the

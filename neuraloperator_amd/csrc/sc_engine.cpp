@@ -3162,7 +3162,8 @@ static int check_shards(const sc_plan* p, const sc_spectrum_shards* sh, int64_t 
   SC_CHECK_ARG(!p->cplx, "sharded spectra: real-data plans");
   SC_CHECK_ARG(sh->n_blocks >= 1 && sh->rows >= 1 && sh->n_blocks * sh->rows >= p->k[0],
                "shards must cover the first kept dim: n_blocks * rows >= k1");
-  SC_CHECK_ARG((sh->n_blocks - 1) * sh->rows < p->k[0], "a whole block past the first kept dim");
+  // (whole blocks past the first kept dim are legal since round 5: k1 = 6 over 4 ranks is three blocks of 2 rows and an
+  // empty one -- the rank that owns it holds zero rows of the weight and sees zeros on the wire)
   SC_CHECK_ARG(sh->block_stride >= n_images * sh->rows * shard_rest(p), "block_stride smaller than a block");
   SC_CHECK_ARG(sh->rows < ((int64_t)1 << 30), "rows too large");
   return 0;
@@ -3193,10 +3194,11 @@ extern "C" int sc_transform_forward_sharded(const sc_plan* p, int mode, const fl
   if (int rc = check_shards(p, sh, n_images)) return rc;
   sc_stream_t st = (sc_stream_t)stream;
   if (native_shards(p) || ax_native_shards(p, n_images)) {
-    // rows past k1 (k1 not a multiple of the block size) are zeros on the wire: clear the one block that has them
-    if (sh->n_blocks * sh->rows != p->k[0]) {
-      cf32* last = (cf32*)xhat + (sh->n_blocks - 1) * sh->block_stride;
-      if (hipMemsetAsync(last, 0, (size_t)(n_images * sh->rows * shard_rest(p)) * sizeof(cf32), st) != hipSuccess)
+    // rows past k1 (k1 not a multiple of the block size, or fewer rows than blocks) are zeros on the wire: clear every
+    // block that has some -- the one k1 ends in and the empty ones behind it
+    for (int64_t b = p->k[0] / sh->rows; b < sh->n_blocks; ++b) {
+      cf32* blk = (cf32*)xhat + b * sh->block_stride;
+      if (hipMemsetAsync(blk, 0, (size_t)(n_images * sh->rows * shard_rest(p)) * sizeof(cf32), st) != hipSuccess)
         return sc_fail("sc_engine: hipMemsetAsync failed");
     }
     return transform_forward_impl(p, mode, x, xhat, n_images, workspace, stream, F3Shard{(int)sh->rows, sh->block_stride});

@@ -36,6 +36,8 @@ CASES = [
     ((9, 8, 10), (5, 4, 6), 3),    # 3-d padded, odd first dim
     ((64, 64, 64), (8, 8, 8), 4),  # round 5: k_ax64 addresses the shards natively (no staging buffer, no permutation launch)
     ((64, 64, 64), (7, 8, 8), 4),  # ... 7 rows over 4 blocks of 2: a zero row on the wire
+    ((64, 256), (6, 12), 4),       # round 5: 6 rows over 4 blocks of 2 -- the last block is EMPTY (fused kernels, native)
+    ((12, 10), (5, 6), 4),         # ... 5 rows over 4 blocks of 2: a half-empty and an empty block (permutation launch)
 ]
 
 
@@ -82,9 +84,10 @@ def test_sharded_transforms_match_plain_plus_permutation(lib, case):
     sh2 = lib.shards(P, rows, 2 * ni * rows * rest)
     lib.transform_forward_sharded(plan, _lib.SC_FWD_ADJ_C2R, x.data_ptr(), big.data_ptr(), ni, sh2, ws.data_ptr())
     assert torch.equal(big[:, :ni], buf)
-    with pytest.raises(RuntimeError):              # blocks must cover the first kept dim
-        lib.transform_forward_sharded(plan, _lib.SC_FWD_SCALED, x.data_ptr(), buf.data_ptr(), ni,
-                                      lib.shards(P - 1, rows, ni * rows * rest), ws.data_ptr())
+    if (P - 1) * rows < k1:
+        with pytest.raises(RuntimeError):          # blocks must cover the first kept dim
+            lib.transform_forward_sharded(plan, _lib.SC_FWD_SCALED, x.data_ptr(), buf.data_ptr(), ni,
+                                          lib.shards(P - 1, rows, ni * rows * rest), ws.data_ptr())
     with pytest.raises(RuntimeError):              # block stride smaller than a block
         lib.transform_forward_sharded(plan, _lib.SC_FWD_SCALED, x.data_ptr(), buf.data_ptr(), ni,
                                       lib.shards(P, rows, ni * rows * rest - 1), ws.data_ptr())

@@ -941,7 +941,9 @@ def test_mode_parallel_variants_on_device_single_rank(kind):
                                              ((12, 16, 20), (5, 8, 8), 3),
                                              # round 5: k_ax128 / k_ax64 address the shards natively
                                              ((128, 128, 128), (32, 32, 32), 8), ((128, 128, 128), (20, 32, 32), 7),
-                                             ((64, 64, 64), (16, 16, 16), 4)])
+                                             ((64, 64, 64), (16, 16, 16), 4),
+                                             # ... and fewer kept rows than blocks can fill: the last block(s) EMPTY
+                                             ((128, 128, 128), (20, 32, 32), 8), ((64, 256), (6, 12), 4), ((24, 20), (5, 10), 4)])
 def test_sharded_transforms_on_device(spatial, modes, P):
     """The engine's sharded-spectrum stages (round 3: the transforms of a mode-parallel layer write / read the
     rank-major all-to-all buffer [P][n][c][rows][rest] in place) on the GPU: bit-identical to the plain stage plus the

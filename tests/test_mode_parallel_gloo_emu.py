@@ -54,11 +54,13 @@ def _worker(rank, world, port, spatial, modes, bl, ci, co, ret):
     yf = so.forward_torch(xf, wf, bf, nm, nm)
     yf.backward(g)
     rows = -(-nm[0] // world)
-    live = min(rows, nm[0] - rank * rows)
+    live = max(0, min(rows, nm[0] - rank * rows))
     ret[rank] = dict(
         y=so.rel_l2(y.detach().numpy(), yf.detach()[rank * bl:(rank + 1) * bl].numpy()),
         gx=so.rel_l2(xs.grad.numpy(), xf.grad[rank * bl:(rank + 1) * bl].numpy()),
-        gw=so.rel_l2(conv.weight.grad[:, :, :live].numpy(), wf.grad[:, :, rank * rows:rank * rows + live].numpy()),
+        # (a rank whose block lies wholly past the kept rows holds inert zero rows: its weight gradient is zero)
+        gw=so.rel_l2(conv.weight.grad[:, :, :live].numpy(), wf.grad[:, :, rank * rows:rank * rows + live].numpy())
+        if live > 0 else float(conv.weight.grad.abs().max()),
         gb=so.rel_l2(conv.bias.grad.numpy(), bf.grad.numpy()),
     )
     comm.cleanup()
@@ -71,9 +73,17 @@ def _worker(rank, world, port, spatial, modes, bl, ci, co, ret):
     ((64, 256), (16, 12), 1, 2, 2),     # the fused 256-wide kernels address the sharded spectrum natively
 ])
 def test_mode_parallel_on_the_emulated_engine(spatial, modes, bl, ci, co):
+    _run(2, spatial, modes, bl, ci, co)
+
+
+def test_mode_parallel_on_the_emulated_engine_world4():
+    """four ranks, 6 mode rows over 4 blocks of 2 (the last block half empty: zero rows on the wire), one sample per rank"""
+    _run(4, (16, 12), (6, 6), 1, 2, 3)
+
+
+def _run(world, spatial, modes, bl, ci, co):
     from engine_runner import emu_lib
     emu_lib()                                   # build the emulation library once, before the workers race for it
-    world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
