@@ -935,17 +935,24 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
   // bfloat16 I/O on the fused kernels: the operand fragments of the matrix-core row pass (12 KB, sc_kernels_fft3mx.h)
   if (!rc && p->fast && (desc->flags & SC_PLAN_IO_BF16) && !(desc->flags & (SC_PLAN_FFT_GEN2 | SC_PLAN_NO_MX_FFT)) &&
       p->fft2d.H <= 256 && !getenv("SC_PLAN_NO_MX_FFT")) {
-    std::vector<uint16_t> h;
-    fft3mx_build_table(&h);
-    void* dev = nullptr;
-    if (hipMalloc(&dev, h.size() * sizeof(uint16_t)) != hipSuccess) {
-      rc = sc_fail("sc_engine: table allocation failed");
-    } else {
-      p->owned.push_back(dev);
-      if (hipMemcpy(dev, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
-        rc = sc_fail("sc_engine: table upload failed");
-      else
-        p->fft2d.tabF = (uint16_t*)dev;
+    for (int which = 0; which < 2 && !rc; ++which) {       // forward-type rows in, inverse-type rows out
+      std::vector<uint16_t> h;
+      // (inverse-type kernel: H = 128 / 256 only.  At H = 64 -- one row group per image -- its results were NOT repeatable on
+      //  hardware with two workgroups per compute unit: single spectrum entries of later images lose their real part, in
+      //  12 % of the images, never in host emulation, never with one workgroup per unit, never without the MFMAs, never
+      //  at H >= 128 (200 x 2048 images each).  Unexplained: k_fft2d_inv3<64, sc_bf16> keeps that size.)
+      if (which == 1 && p->fft2d.H < 128) break;
+      if (which == 0) fft3mx_build_table(&h); else fft3mxi_build_table(&h);
+      void* dev = nullptr;
+      if (hipMalloc(&dev, h.size() * sizeof(uint16_t)) != hipSuccess) {
+        rc = sc_fail("sc_engine: table allocation failed");
+      } else {
+        p->owned.push_back(dev);
+        if (hipMemcpy(dev, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess)
+          rc = sc_fail("sc_engine: table upload failed");
+        else
+          (which == 0 ? p->fft2d.tabF : p->fft2d.tabG) = (uint16_t*)dev;
+      }
     }
   }
   if (!rc && !p->fast && !(desc->flags & SC_PLAN_FORCE_GENERIC) && !(desc->flags & SC_PLAN_IO_BF16))
@@ -1620,6 +1627,9 @@ static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat,
                               &g_last_error);
       return (rc2 || !ep) ? rc2 : run_epilogue_pass(p, ep, y, n_images, st);
     }
+    if ((p->d.flags & SC_PLAN_IO_BF16) && p->fft2d.tabG && epi == 0 && !((uintptr_t)y & 7))   // 8-byte row stores
+      return fft3mxi_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
+                             &g_last_error, sh);
     if (p->d.flags & SC_PLAN_IO_BF16)
       return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, (sc_bf16*)y, n_images, st,
                           &g_last_error, epi, ep ? (const sc_bf16*)ep->skip : nullptr,
@@ -3497,7 +3507,7 @@ extern "C" const char* sc_plan_kernel_name(const sc_plan* p, int which) {
   if (!p) return "";
   if (p->fast) {
     if (p->d.flags & SC_PLAN_FFT_GEN2) return fft2d_kernel_name(which);
-    return which == 0 ? (p->fft2d.tabF ? "k_fft2d_fwd_mx" : "k_fft2d_fwd3") : "k_fft2d_inv3";
+    return which == 0 ? (p->fft2d.tabF ? "k_fft2d_fwd_mx" : "k_fft2d_fwd3") : (p->fft2d.tabG ? "k_fft2d_inv_mx" : "k_fft2d_inv3");
   }
   if (p->cplx) return "k_axis_pass";
   if (p->f2p) return which == 0 ? "k_f2p_r2c" : "k_f2p_c2r";

@@ -418,3 +418,344 @@ static inline int fft3mx_forward(const Fft2dPlan* fp, int mode, const sc_bf16* x
   }
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// inverse-type transform WRITING bfloat16, row pass on the matrix cores (round 5, session 2)
+// ------------------------------------------------------------------------------------------
+// k_fft2d_inv3<H, sc_bf16> is bound by its arithmetic as well (84 us for 303 MB at the metric shape), again mostly
+// the 256-point row transforms: a zero-padded, Hermitian-extended C2R of 33 coefficients per row.  As a product:
+//
+//   y[4 m + r] = Re c_0 + bias + 2 sum_{k = 1..32} Re(c_k w256^(-k (4 m + r)))           (w = exp(-2 pi i / .))
+//              = sum_k Re(c'_k w64^(-k m)),  c'_k = c_k w256^(-k r)                         r = 0..3, m = 0..63
+//
+//   * per r the 33 rotated coefficients of 16 rows are the A operand ([16 rows] x [K = 32]: the 16 even k as (Re, Im)
+//     pairs, or the 16 odd k), the cosines / sines (with the factor 2) the B operand ([K = 32] x [16 values of m]);
+//     Im c'_0 never contributes and its slot carries Re c'_32, whose column is 2 (-1)^m;
+//   * w64^(-k (m + 32)) = (-1)^k w64^(-k m): E = even-k sum, O = odd-k sum for m < 32 give y[m] = E + O and
+//     y[m + 32] = E - O -- two tiles of m instead of four;
+//   * the OUTPUT is bfloat16 (8 significant bits), so coefficients and table are split in TWO bf16 terms each and the
+//     three products hi.hi + hi.lo + lo.hi are kept: 2^-16 relative to a row's magnitude, ~100 times below the
+//     rounding of the store.  12 MFMAs per r and 16 rows; 48 per 16 rows against 96 for the forward kernel;
+//   * the accumulator tile of a wave is [16 rows] x [16 m]: after the four r a lane holds 4 consecutive points
+//     (4 m .. 4 m + 3) of 4 rows in 4 places (m, m + 16, m + 32, m + 48) -- sixteen 8-byte stores, 128 contiguous bytes
+//     per 16 lanes (the vector-ALU kernel: 2-byte stores, 64 contiguous bytes per half-wave).
+// Column phase, spectrum requests and scaling are those of k_fft2d_inv3 (its tile with a row stride of 38 complex so
+// that a lane's 8 consecutive coefficients are one aligned 64-byte read, conflict-free over 16 rows).
+// Reference lines: spectral_convolution.py:520-568 (zero-filled spectrum, ifftn / irfft, bias).
+#define SC_MXI_URS 38     // row stride (complex) of T[64 rows][32 columns | . | 33 + a: the group's k = 32 column]
+#ifndef SC_MXI_WGS
+#define SC_MXI_WGS 2      // persistent workgroups per compute unit = register budget (waves per SIMD)
+#endif
+
+template <int H>
+struct F3MxiLds {
+  static constexpr int P = H / 64;
+  static constexpr int xch_c = 33 * SC_F3_CCS;            // the column tasks' private exchange patches
+  static constexpr int T_c = 64 * SC_MXI_URS;
+  static constexpr int off_xch = 0;
+  static constexpr int off_T = off_xch + xch_c * 8;
+  static constexpr int off_twH = off_T + T_c * 8;
+  static constexpr int off_tw64 = off_twH + H * 8;
+  static constexpr int off_c32 = off_tw64 + 64 * 8;        // 33rd column of the spectrum (64 entries)
+  static constexpr int off_G = off_c32 + 64 * 8;           // operand fragments [r 4][tile 4][term 2][lane 64][16 bytes]
+  static constexpr int total = off_G + 32 * 1024;
+  static_assert(P <= 4 && 33 + P <= SC_MXI_URS, "k = 32 of group a is parked in column 33 + a of its row (H <= 256)");
+  static_assert(off_T % 16 == 0 && off_G % 16 == 0, "16-byte reads");
+  static_assert(SC_MXI_WGS * total <= 160 * 1024, "workgroups per compute unit");
+};
+
+// operand table of the inverse row pass: [r 4][tile 4 = (parity u, m tile t)][term 2][lane 64][8 bf16], MFMA B layout:
+// lane (j, g) holds rows K = 8 g + e of column m = 16 t + j; K = (k index kk = 4 g + (e >> 1), part e & 1),
+// k = 2 kk + u; part 0 multiplies Re c, part 1 Im c:  f cos(2 pi k n / 256), -f sin(...), n = 4 m + r, f = 2 (k = 0: 1);
+// (u = 0, kk = 0, part 1) is the k = 32 slot: 2 (-1)^m, multiplying Re(c_32 exp(i pi r / 4)) (the kernel rotates that one)
+static inline void fft3mxi_build_table(std::vector<uint16_t>* out) {
+  const double two_pi = 6.283185307179586476925286766559;
+  out->assign((size_t)4 * 4 * 2 * 64 * 8, 0);
+  auto to_bf16 = [](double v) {
+    const float f = (float)v;
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto from_bf16 = [](uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return (double)f;
+  };
+  for (int r = 0; r < 4; ++r)
+    for (int tile = 0; tile < 4; ++tile)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int u = tile >> 1, t = tile & 1, j = lane & 15, g = lane >> 4;
+          const int m = 16 * t + j, kk = 4 * g + (e >> 1), part = e & 1, k = 2 * kk + u;
+          double v;
+          if (k == 0) {
+            v = part ? ((m & 1) ? -2.0 : 2.0) : 1.0;
+          } else {
+            const int idx = (k * (4 * m + r)) & 255;         // exact phase reduction
+            const double th = two_pi * (double)idx / 256.0;
+            v = part ? -2.0 * std::sin(th) : 2.0 * std::cos(th);
+            if (idx % 64 == 0) v = std::round(v);
+          }
+          double rest = v;
+          for (int term = 0; term < 2; ++term) {
+            const uint16_t b = to_bf16(rest);
+            (*out)[((((size_t)r * 4 + tile) * 2 + term) * 64 + lane) * 8 + e] = b;
+            rest -= from_bf16(b);
+          }
+        }
+}
+
+#ifndef SC_EMU
+typedef uint32_t sc_mx_u2 __attribute__((ext_vector_type(2)));
+SC_DEVICE uint32_t sc_mx_pack_bf16(const float a, const float b) {     // {bf16(a), bf16(b)}, nearest even: v_cvt_pk_bf16_f32
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const f2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
+}
+SC_DEVICE void sc_mx_store8_stream(void* p, const uint32_t a, const uint32_t b) {
+  const sc_mx_u2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<sc_mx_u2*>(p));
+}
+#else
+inline uint32_t sc_mx_pack_bf16(const float a, const float b) {
+  return (uint32_t)sc_f32_to_bf16_bits(a) | ((uint32_t)sc_f32_to_bf16_bits(b) << 16);
+}
+inline void sc_mx_store8_stream(void* p, const uint32_t a, const uint32_t b) {
+  const uint32_t v[2] = {a, b};
+  std::memcpy(p, v, 8);
+}
+#endif
+// (a, b) -> one dword of the leading bf16 terms and one of the remainders' (a = hi + lo to 16 bits)
+SC_DEVICE void sc_mx_split2(const float a, const float b, uint32_t& hi, uint32_t& lo) {
+  hi = sc_mx_pack_bf16(a, b);
+  lo = sc_mx_pack_bf16(a - sc_bits_to_f32(hi << 16), b - sc_bits_to_f32(hi & 0xffff0000u));
+}
+
+template <int H>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, SC_MXI_WGS)
+k_fft2d_inv_mx(const cf32* __restrict__ yhat, sc_bf16* __restrict__ y, const float* __restrict__ bias, int channels,
+               const cf32* __restrict__ tabW, const cf32* __restrict__ tabH, const uint16_t* __restrict__ tabG, int Mx,
+               int My, float s_dc, float s_other, F3Shard sh, int64_t n_images, int gstride) {
+  constexpr int P = H / 64, URS = SC_MXI_URS;
+  typedef F3MxiLds<H> L;
+  SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
+  cf32* xch = reinterpret_cast<cf32*>(smem + L::off_xch);
+  cf32* T = reinterpret_cast<cf32*>(smem + L::off_T);
+  cf32* twH = reinterpret_cast<cf32*>(smem + L::off_twH);
+  cf32* tw64 = reinterpret_cast<cf32*>(smem + L::off_tw64);
+  cf32* y32 = reinterpret_cast<cf32*>(smem + L::off_c32);
+  sc_mx_u4* Gl = reinterpret_cast<sc_mx_u4*>(smem + L::off_G);
+
+  const int tid = SC_TID;
+  const int w = SC_UNIFORM(tid >> 6);
+  const int lane = tid & 63;
+  const int j = lane & 15, g = lane >> 4;                 // MFMA roles: (row j, k group g) of A, (column j, k group g) of B
+  const int cl = lane >> 3, mu = lane & 7;                // column phase: wave w owns columns 8 w .. 8 w + 7, 8 lanes each
+
+  for (int i = tid; i < H; i += 256) twH[i] = tabH[i];
+  if (tid < 64) tw64[tid] = tabW[(4 * (tid >> 3) * (tid & 7)) & 255];
+  for (int i = tid; i < 32 * 64; i += 256) Gl[i] = sc_mx_load16(tabG + (size_t)i * 8);
+
+  // spectrum entries of a lane (column c = 8 w + cl, rows q = mu + 8 q2) and the parked 33rd column: straight from
+  // global memory into registers, those of the next image requested behind the last group's column transforms
+  // (k_fft2d_inv3)
+  cf32 yh[8], y32r;
+  auto request = [&](const int64_t im) SC_ALWAYS_INLINE_LAMBDA {
+    const int c = 8 * w + sc_opaque(cl);
+    const int mu_o = sc_opaque(mu), t_o = sc_opaque(tid);
+    if (sh.rows <= 0) {
+      const cf32* src = yhat + im * (int64_t)Mx * My;
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int row = f2d_fx(mu_o + 8 * q2) + Mx / 2;
+        yh[q2] = src[(row >= 0 && row < Mx && c < My) ? row * My + c : 0];
+      }
+      const int row = f2d_fx(t_o & 63) + Mx / 2;
+      y32r = src[(row >= 0 && row < Mx && 32 < My) ? row * My + 32 : 0];
+    } else {                                             // sharded spectrum (include/sc_engine.h, sc_spectrum_shards)
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int row = f2d_fx(mu_o + 8 * q2) + Mx / 2;
+        yh[q2] = yhat[f3_shard_index(sh, im, (row >= 0 && row < Mx && c < My) ? row * My + c : 0, My)];
+      }
+      const int row = f2d_fx(t_o & 63) + Mx / 2;
+      y32r = yhat[f3_shard_index(sh, im, (row >= 0 && row < Mx && 32 < My) ? row * My + 32 : 0, My)];
+    }
+  };
+  if ((int64_t)SC_BID_X < n_images) request(SC_BID_X);
+  SC_SYNC();                                             // tables
+
+#pragma unroll 1
+  for (int64_t img = SC_BID_X; img < n_images; img += gstride) {
+    sc_bf16* yo = y + img * (int64_t)H * SC_F2D_W;
+    const float badd = (bias != nullptr) ? bias[img % channels] : 0.f;
+    {
+      const int c = 8 * w + sc_opaque(cl);
+      const int mu_o = sc_opaque(mu), t_o = sc_opaque(tid);
+      const float sc_c = (c == 0) ? s_dc : s_other;
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int row = f2d_fx(mu_o + 8 * q2) + Mx / 2;
+        yh[q2] = (row >= 0 && row < Mx && c < My) ? cf_scale(yh[q2], sc_c) : cf_make(0.f, 0.f);
+      }
+      if (tid < 64) {
+        const int row = f2d_fx(t_o) + Mx / 2;
+        y32[tid] = (row >= 0 && row < Mx && 32 < My) ? cf_scale(y32r, s_other) : cf_make(0.f, 0.f);
+      }
+    }
+    SC_SYNC();
+
+    // one inverse column task of group a (k_fft2d_inv3): spectrum column -> 64 rows b of T[b][cdst]
+    auto column = [&](const int cdst, cf32* cb, const int a, auto extra_tag, const bool act) SC_ALWAYS_INLINE_LAMBDA {
+      constexpr bool EXTRA = decltype(extra_tag)::value != 0;
+      cf32 v[8], o[8];
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int fx = f2d_fx(mu + 8 * q2);
+        int idx = (a * fx) % H;
+        if (idx < 0) idx += H;
+        v[q2] = cf_mul_pk(EXTRA ? y32[mu + 8 * q2] : yh[q2], cf_conj(twH[idx]));
+      }
+      dft8<+1>(v, o);                                      // over q2 -> m (row b = m + 8 b1)
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const cf32 val = (m == 0) ? o[0] : cf_mul_pk(o[m], cf_conj(SC_F3_LD64(tw64 + m * 8 + mu)));
+        if (act) cb[m * 8 + mu] = val;
+      }
+      SC_WAVE_SYNC();
+#pragma unroll
+      for (int q1 = 0; q1 < 8; q1 += 2) SC_F3_LD128(cb + mu * 8 + q1, v[q1], v[q1 + 1]);
+      dft8<+1>(v, o);                                      // over q1 -> b1
+      if (act) {
+#pragma unroll
+        for (int b1 = 0; b1 < 8; ++b1) T[(mu + 8 * b1) * URS + cdst] = o[b1];
+      }
+      SC_WAVE_SYNC();
+    };
+
+    if (My > 32) {                                         // k = 32 of every group up front, parked in column 33 + a
+      constexpr int ABLK = (P + 3) / 4;
+      const int a = ((cl % ABLK) << 2) | w;
+      const int ac = a < P ? a : 0;
+      column(33 + ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), cl < ABLK && a < P);
+    } else if (tid < 64) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) T[tid * URS + 33 + a] = cf_make(0.f, 0.f);
+    }
+    SC_SYNC();
+
+#pragma unroll 1
+    for (int a = 0; a < P; ++a) {
+#ifndef SC_MXI_ABL_NOCOL                                   /* (measurement builds) */
+      column(8 * w + cl, xch + (8 * w + cl) * SC_F3_CCS, a, sc_int<0>(), true);
+#endif
+      if (a == P - 1) request(img + gstride < n_images ? img + gstride : img);
+      SC_SYNC();
+      // ---------------- rows b = 16 w + j of the group on the matrix cores ----------------
+      // coefficients k = 8 g + q of the lane's row, split ONCE into two bf16 terms: the rotation by r lives in the
+      // operand fragments (one set per r, read from LDS: 32 x 16 bytes per lane and 16 rows)
+      cf32 cr[8];
+      const cf32* trow = T + (16 * w + j) * URS;
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) SC_F3_LD128(trow + 8 * g + q, cr[q], cr[q + 1]);
+      const cf32 c32 = SC_F3_LD64(trow + 33 + a);
+      cr[0].x += (g == 0) ? badd : 0.f;                    // k = 0: its column of the operand is 1 for every point
+      uint32_t outp[4][4][2];                              // [row v][place][dword]: 4 consecutive points as bf16
+      float keep[4][4];
+#ifdef SC_MXI_ABL_NOROW
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+          outp[v][pl][0] = __float_as_uint(cr[v].x) ^ pl;
+          outp[v][pl][1] = __float_as_uint(cr[4 + v].y + c32.x) ^ pl;
+        }
+#else
+      uint32_t fh[2][4], fl[2][4];                         // [parity u]: even k = cr[0], cr[2], cr[4], cr[6]; odd k = cr[1], ...
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc_mx_split2(cr[2 * i + u].x, cr[2 * i + u].y, fh[u][i], fl[u][i]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        {                                                  // the k = 32 slot: Re(c_32 exp(i pi r / 4)) beside Re c_0
+          constexpr float hh = 0.70710678118654752440f;
+          const float e32 = (r == 0) ? c32.x : (r == 1) ? hh * (c32.x - c32.y) : (r == 2) ? -c32.y : -hh * (c32.x + c32.y);
+          sc_mx_split2(cr[0].x, g == 0 ? e32 : cr[0].y, fh[0][0], fl[0][0]);     // (all lanes: no branch)
+        }
+        const sc_mx_u4 Ah[2] = {sc_mx_u4{fh[0][0], fh[0][1], fh[0][2], fh[0][3]}, sc_mx_u4{fh[1][0], fh[1][1], fh[1][2], fh[1][3]}};
+        const sc_mx_u4 Al[2] = {sc_mx_u4{fl[0][0], fl[0][1], fl[0][2], fl[0][3]}, sc_mx_u4{fl[1][0], fl[1][1], fl[1][2], fl[1][3]}};
+        sc_mx_f4 acc[4];                                   // [2 u + t]
+        sc_mx_u4 b0[4], b1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          b0[t] = Gl[((r * 4 + t) * 2 + 0) * 64 + lane];
+          b1[t] = Gl[((r * 4 + t) * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[t][v] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sc_mfma_16x16x32_bf16(acc[t], Al[t >> 1], b0[t]);     // small products first
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sc_mfma_16x16x32_bf16(acc[t], Ah[t >> 1], b1[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sc_mfma_16x16x32_bf16(acc[t], Ah[t >> 1], b0[t]);
+        // y[4 (16 t + j) + r] = E + O,  y[4 (16 t + j + 32) + r] = E - O
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int pl = 0; pl < 4; ++pl) {
+            const int t = pl & 1;
+            const float val = (pl < 2) ? acc[t][v] + acc[2 + t][v] : acc[t][v] - acc[2 + t][v];
+            if ((r & 1) == 0)
+              keep[v][pl] = val;
+            else
+              outp[v][pl][r >> 1] = sc_mx_pack_bf16(keep[v][pl], val);
+          }
+      }
+#endif
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        sc_bf16* row = yo + (int64_t)(P * (16 * w + 4 * g + v) + a) * SC_F2D_W + 4 * j;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#ifdef SC_MXI_ABL_NOSTORE
+          if (outp[v][pl][0] == 0x12345678u && outp[v][pl][1] == 0x9abcdef0u)
+#endif
+          sc_mx_store8_stream(row + 64 * (pl & 1) + 128 * (pl >> 1), outp[v][pl][0], outp[v][pl][1]);
+      }
+      SC_SYNC();                                           // T is rewritten by the next group
+    }
+  }
+}
+
+template <int H>
+static void fft3mxi_launch_inv(const Fft2dPlan* fp, const cf32* yhat, sc_bf16* y, const float* bias, int channels,
+                               int64_t n_images, float s_dc, float s_other, sc_stream_t st, F3Shard sh) {
+  int64_t grid = (int64_t)SC_MXI_WGS * sc_cu_count();
+  if (grid > n_images) grid = n_images;
+  SC_LAUNCH((k_fft2d_inv_mx<H>), dim3((unsigned)grid), dim3(256), 0, st, yhat, y, bias, channels,
+            (const cf32*)fp->tabW, (const cf32*)fp->tabH, (const uint16_t*)fp->tabG, fp->Mx, fp->My, s_dc, s_other, sh,
+            n_images, (int)grid);
+}
+
+static inline int fft3mxi_inverse(const Fft2dPlan* fp, int mode, const cf32* yhat, const float* bias, int64_t channels,
+                                  sc_bf16* y, int64_t n_images, sc_stream_t st, std::string* err,
+                                  F3Shard sh = F3Shard{0, 0}) {
+  const float s_dc = (mode == 0) ? fp->si : fp->sf;
+  const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
+  switch (fp->H) {
+    case 128: fft3mxi_launch_inv<128>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
+    case 256: fft3mxi_launch_inv<256>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
+    default: *err = "sc_engine: fft2d (matrix-core row pass): unsupported H"; return 1;
+  }
+  if (hipGetLastError() != hipSuccess) {
+    *err = "sc_engine: launch of k_fft2d_inv_mx failed";
+    return 1;
+  }
+  return 0;
+}

@@ -69,3 +69,73 @@ def test_mx_forward_sharded_layout(lib):
     want = plain.unflatten(1, (P, rows)).movedim(1, 0).contiguous()
     assert torch.equal(buf, want)
     lib.plan_destroy(plan)
+
+
+def _ref_inv(yh, H, Mx, My, mode, bias):
+    # mode SC_INV_PADDED: the kept block zero-padded into the half spectrum, unscaled irfft2 (the C2R ignores the
+    # imaginary parts of the DC column), + bias; SC_INV_ADJ_R2C: the adjoint of rfft2(norm="forward"): interior columns
+    # count half, 1 / (H W)
+    n = yh.shape[0]
+    full = np.zeros((n, H, 129), dtype=np.complex128)
+    rows = np.r_[np.arange(H - Mx // 2, H), np.arange(0, Mx - Mx // 2)] if Mx > 1 else np.array([0])
+    full[:, rows, :My] = yh
+    if mode == _lib.SC_INV_ADJ_R2C:
+        s = np.full(129, 0.5)
+        s[0] = 1.0
+        full = full * s / (H * 256)
+    y = np.fft.irfft2(full, s=(H, 256), axes=(-2, -1)) * (H * 256)
+    return y + (0.0 if bias is None else bias[:, None, None])
+
+
+@pytest.mark.parametrize("H,Mx,My,n_img", [(256, 64, 33, 3), (256, 20, 9, 3), (128, 64, 33, 5), (128, 12, 33, 4),
+                                            (64, 64, 33, 3)])
+def test_mx_inverse_vs_float64_and_valu(lib, H, Mx, My, n_img):
+    """k_fft2d_inv_mx (round 5, session 2: the row pass of the inverse-type transform writing bfloat16 on the matrix
+    cores) against a float64 transform -- the bf16 rounding of the store is the only visible error -- and against
+    k_fft2d_inv3<H, sc_bf16>: the two may differ where the fp32 value sits on a rounding boundary (one bf16 ulp)."""
+    torch.manual_seed(H + Mx + n_img)
+    yh = torch.randn(n_img, Mx, My, 2)
+    bias = torch.randn(n_img)                              # channels = n_img: one bias value per image
+    yc = torch.view_as_complex(yh).numpy().astype(np.complex128)
+    for mode, b in ((_lib.SC_INV_PADDED, bias), (_lib.SC_INV_ADJ_R2C, None)):
+        got = {}
+        routes = (("mx", _lib.SC_PLAN_IO_BF16), ("valu", _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT))
+        for tag, fl in routes[:2 if H * n_img <= 512 else 1]:
+            plan = lib.plan_create([H, 256], [Mx, My], flags=fl)
+            # (H = 64 stays on the vector-ALU kernel: sc_engine.cpp, DESIGN 3.5)
+            assert lib.plan_kernel_name(plan, 1) == ("k_fft2d_inv_mx" if tag == "mx" and H >= 128 else "k_fft2d_inv3")
+            y = torch.full((n_img, H, 256), float("nan")).bfloat16()
+            lib.transform_inverse(plan, mode, yh.data_ptr(), 0 if b is None else b.data_ptr(), n_img, y.data_ptr(),
+                                  n_img, 0)
+            got[tag] = y.float().numpy().astype(np.float64)
+            lib.plan_destroy(plan)
+        ref = _ref_inv(yc, H, Mx, My, mode, None if b is None else b.numpy().astype(np.float64))
+        ref_b = torch.from_numpy(ref).float().bfloat16().float().numpy().astype(np.float64)
+        for tag, g in got.items():
+            assert np.isfinite(g).all(), (tag, mode)
+            e = np.linalg.norm(g - ref) / np.linalg.norm(ref)
+            assert e < 3e-3, (tag, mode, e)                # bf16 storage: 2^-9 relative per value
+            # ... and nothing but that rounding: against the float64 result rounded the same way, at most one ulp (values near zero:
+            # the arithmetic's error, relative to the row's magnitude), rarely
+            d = np.abs(g - ref_b)
+            assert (d <= np.abs(ref_b) * 2.0 ** -7 + 1e-4 * np.abs(ref).max()).all(), (tag, mode, d.max())
+            assert (d > 0).mean() < 0.02, (tag, mode, (d > 0).mean())
+        if "valu" in got:
+            assert (got["mx"] != got["valu"]).mean() < 0.02
+
+
+def test_mx_inverse_sharded_layout(lib):
+    H, Mx, My, n_img, P = 128, 64, 33, 3, 8
+    rows = Mx // P
+    torch.manual_seed(10)
+    yh = torch.randn(n_img, Mx, My, 2)
+    plan = lib.plan_create([H, 256], [Mx, My], flags=_lib.SC_PLAN_IO_BF16)
+    assert lib.plan_kernel_name(plan, 1) == "k_fft2d_inv_mx"
+    y0 = torch.zeros(n_img, H, 256).bfloat16()
+    lib.transform_inverse(plan, _lib.SC_INV_PADDED, yh.data_ptr(), 0, 1, y0.data_ptr(), n_img, 0)
+    buf = yh.unflatten(1, (P, rows)).movedim(1, 0).contiguous()
+    sh = lib.shards(P, rows, n_img * rows * My)
+    y1 = torch.full((n_img, H, 256), float("nan")).bfloat16()
+    lib.transform_inverse_sharded(plan, _lib.SC_INV_PADDED, buf.data_ptr(), 0, 1, y1.data_ptr(), n_img, sh, 0)
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16))
+    lib.plan_destroy(plan)
