@@ -637,11 +637,11 @@ k_fft2d_inv_mx(const cf32* __restrict__ yhat, sc_bf16* __restrict__ y, const flo
       SC_WAVE_SYNC();
     };
 
-    if (My > 32) {                                         // k = 32 of every group up front, parked in column 33 + a
-      constexpr int ABLK = (P + 3) / 4;
-      const int a = ((cl % ABLK) << 2) | w;
-      const int ac = a < P ? a : 0;
-      column(33 + ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), cl < ABLK && a < P);
+    if (My > 32) {                                         // k = 32 of every group up front, parked in column 33 + a:
+      if (w == 0) {                                        // P tasks of 8 lanes, all in wave 0 (k_fft2d_inv3 gives one to each
+        const int ac = cl < P ? cl : 0;                    // wave: four instruction streams for the work of half a wave)
+        column(33 + ac, xch + ac * SC_F3_CCS, ac, sc_int<1>(), cl < P);
+      }
     } else if (tid < 64) {
 #pragma unroll
       for (int a = 0; a < P; ++a) T[tid * URS + 33 + a] = cf_make(0.f, 0.f);
@@ -749,6 +749,7 @@ static inline int fft3mxi_inverse(const Fft2dPlan* fp, int mode, const cf32* yha
   const float s_dc = (mode == 0) ? fp->si : fp->sf;
   const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
   switch (fp->H) {
+    case 64: fft3mxi_launch_inv<64>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;   // (diagnostic)
     case 128: fft3mxi_launch_inv<128>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
     case 256: fft3mxi_launch_inv<256>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
     default: *err = "sc_engine: fft2d (matrix-core row pass): unsupported H"; return 1;

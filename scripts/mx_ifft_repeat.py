@@ -1,4 +1,6 @@
-"""Repeatability stress of k_fft2d_inv_mx: N launches at 2048 images, every result compared bit for bit with the first\n(round 5, session 2: H = 64 failed this on hardware -- the kernel is not used there; H = 128 / 256: 0 of 200).\nUsage: python scripts/mx_ifft_repeat.py H repeats"""
+"""Repeatability stress of k_fft2d_inv_mx: N launches at 2048 images, every result compared bit for bit with the first
+(round 5, session 2: H = 64 failed this on hardware -- the kernel is not used there; H = 128 / 256: 0 of 200).
+Usage: python scripts/mx_ifft_repeat.py H repeats"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuraloperator_amd import _lib
