@@ -84,8 +84,9 @@ enum {
                                 by default those stay on the one-launch direct-DFT plane passes, which are faster there) */
   SC_PLAN_NO_SPAN = 128,     /* complex -> real last-axis pass of widths off every factorised route: the 128-line chunked
                                 kernel (k_mdft_c2r_stage) instead of the 32-line whole-span one (k_mdft_c2r_span; A-B, tests) */
-  SC_PLAN_NO_MX_FFT = 256,   /* bfloat16 I/O: forward-type transforms on the vector-ALU kernel k_fft2d_fwd3 instead of the
-                                matrix-core row pass k_fft2d_fwd_mx (round 5; A-B and tests) */
+  SC_PLAN_NO_MX_FFT = 256,   /* bfloat16 I/O: the transforms on the vector-ALU kernels k_fft2d_fwd3 / k_fft2d_inv3 instead of
+                                the matrix-core row passes k_fft2d_fwd_mx (H <= 256) / k_fft2d_inv_mx (H = 128, 256; round 5;
+                                A-B and tests) */
   SC_PLAN_IO_BF16 = 16       /* the REAL tensors (x, y, gy, gx) are bfloat16 in memory -- the `float*`
                                 arguments that carry them then point at 2-byte elements; spectra,
                                 weights, bias and every arithmetic step stay float32 and y / gx are
