@@ -1059,7 +1059,7 @@ def main():
         if os.path.isfile(tpath):
             try:
                 tkey = args.workload + ("_bf16io" if args.io == "bf16" else "")
-                traffic = json.load(open(tpath)).get(tkey, {}).get(dom)
+                traffic = json.load(open(tpath)).get(tkey, {}).get(dom) or None     # (0 = the regeneration did not see the kernel)
             except Exception:
                 traffic = None
         # the dominant kernel's own duration: back-to-back launches where that is measured (transforms), else in sequence

@@ -36,8 +36,8 @@ for key, wl, io, kind in JOBS:
         return int(sum(v["traffic_B"] * v["launches_per_step"] for k, v in ks.items() if any(s in k for s in subs)))
     if kind == "dense":
         # a transform stage = every launch of its kernels in one step / the number of transforms of that type (2)
-        fwd = total("k_fft2d_fwd3", "k_f2p_r2c", "k_f2p_col_fwd", "k_pl128_fwd", "k_ax128<-1>") // 2
-        inv = total("k_fft2d_inv3", "k_f2p_c2r", "k_f2p_col_inv", "k_pl128_inv", "k_ax128<1>") // 2
+        fwd = total("k_fft2d_fwd3", "k_fft2d_fwd_mx", "k_f2p_r2c", "k_f2p_col_fwd", "k_pl128_fwd", "k_ax128<-1>") // 2
+        inv = total("k_fft2d_inv3", "k_fft2d_inv_mx", "k_f2p_c2r", "k_f2p_col_inv", "k_pl128_inv", "k_ax128<1>") // 2
         ent.update(fwd_transform=fwd, adj_c2r_transform=fwd, inv_transform=inv, adj_r2c_transform=inv)
         cf = [v["traffic_B"] for k, v in ks.items() if k.startswith(("k_modegemm_dma<", "k_modegemm_sb<", "k_modegemm<"))]
         cb = [v["traffic_B"] for k, v in ks.items() if k.startswith(("k_modegemm_dma_bwd", "k_modegemm_sb_bwd"))]
