@@ -422,16 +422,20 @@ static inline int fft3mx_forward(const Fft2dPlan* fp, int mode, const sc_bf16* x
 // ------------------------------------------------------------------------------------------
 // inverse-type transform WRITING bfloat16, row pass on the matrix cores (round 5, session 2)
 // ------------------------------------------------------------------------------------------
-// k_fft2d_inv3<H, sc_bf16> is bound by its arithmetic as well (84 us for 303 MB at the metric shape), again mostly
-// the 256-point row transforms: a zero-padded, Hermitian-extended C2R of 33 coefficients per row.  As a product:
+// k_fft2d_inv3<H, sc_bf16> is bound by its arithmetic as well (84-92 us by box for 303 MB at the metric shape), again
+// mostly the 256-point row transforms: a zero-padded, Hermitian-extended C2R of 33 coefficients per row.  As a product:
 //
-//   y[4 m + r] = Re c_0 + bias + 2 sum_{k = 1..32} Re(c_k w256^(-k (4 m + r)))           (w = exp(-2 pi i / .))
-//              = sum_k Re(c'_k w64^(-k m)),  c'_k = c_k w256^(-k r)                         r = 0..3, m = 0..63
+//   y[n] = Re c_0 + bias + 2 sum_{k = 1..32} Re(c_k exp(2 pi i k n / 256)),   n = 4 m + r,  r = 0..3,  m = 0..63
 //
-//   * per r the 33 rotated coefficients of 16 rows are the A operand ([16 rows] x [K = 32]: the 16 even k as (Re, Im)
-//     pairs, or the 16 odd k), the cosines / sines (with the factor 2) the B operand ([K = 32] x [16 values of m]);
-//     Im c'_0 never contributes and its slot carries Re c'_32, whose column is 2 (-1)^m;
-//   * w64^(-k (m + 32)) = (-1)^k w64^(-k m): E = even-k sum, O = odd-k sum for m < 32 give y[m] = E + O and
+//   * per r: A = the coefficients of 16 rows ([16 rows] x [K = 32]: the 16 even k as (Re, Im) pairs, or the 16 odd k),
+//     B = f cos / -f sin of 2 pi k (4 m + r) / 256 ([K = 32] x [16 values of m], f = 2, k = 0: 1) -- the rotation by r
+//     lives in the OPERAND: one set of fragments per r (4 x 8 KB, LDS resident, 32 x 16 bytes read per lane and 16
+//     rows), so a row's coefficients are split into bf16 terms ONCE.  (First form, measured: rotation and split on the
+//     vector ALUs for every r with one operand set in registers -- 83 us, bound by ~370 vector instructions per 16 rows;
+//     this form: 66-68 us.  profiles/r05_mx_ifft_ab.txt.)
+//   * Im c_0 never contributes and its slot carries Re(c_32 exp(i pi r / 4)) -- the one value still rotated by hand --
+//     whose column is 2 (-1)^m; the bias rides on Re c_0, whose column is 1;
+//   * exp(2 pi i k (m + 32) / 64) = (-1)^k: E = even-k sum, O = odd-k sum for m < 32 give y[m] = E + O and
 //     y[m + 32] = E - O -- two tiles of m instead of four;
 //   * the OUTPUT is bfloat16 (8 significant bits), so coefficients and table are split in TWO bf16 terms each and the
 //     three products hi.hi + hi.lo + lo.hi are kept: 2^-16 relative to a row's magnitude, ~100 times below the
@@ -440,7 +444,8 @@ static inline int fft3mx_forward(const Fft2dPlan* fp, int mode, const sc_bf16* x
 //     (4 m .. 4 m + 3) of 4 rows in 4 places (m, m + 16, m + 32, m + 48) -- sixteen 8-byte stores, 128 contiguous bytes
 //     per 16 lanes (the vector-ALU kernel: 2-byte stores, 64 contiguous bytes per half-wave).
 // Column phase, spectrum requests and scaling are those of k_fft2d_inv3 (its tile with a row stride of 38 complex so
-// that a lane's 8 consecutive coefficients are one aligned 64-byte read, conflict-free over 16 rows).
+// that a lane's 8 consecutive coefficients are one aligned 64-byte read, conflict-free over 16 rows); the k = 32 column
+// tasks of all groups run in wave 0.  Served: H = 128 / 256, no epilogue (sc_engine.cpp; H = 64: DESIGN 3.5).
 // Reference lines: spectral_convolution.py:520-568 (zero-filled spectrum, ifftn / irfft, bias).
 #define SC_MXI_URS 38     // row stride (complex) of T[64 rows][32 columns | . | 33 + a: the group's k = 32 column]
 #ifndef SC_MXI_WGS
