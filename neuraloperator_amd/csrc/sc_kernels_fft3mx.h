@@ -742,6 +742,7 @@ template <int H>
 static void fft3mxi_launch_inv(const Fft2dPlan* fp, const cf32* yhat, sc_bf16* y, const float* bias, int channels,
                                int64_t n_images, float s_dc, float s_other, sc_stream_t st, F3Shard sh) {
   int64_t grid = (int64_t)SC_MXI_WGS * sc_cu_count();
+  if (const char* e = getenv("SC_MXI_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;      // (diagnostic: scripts/mx_ifft_repeat.py)
   if (grid > n_images) grid = n_images;
   SC_LAUNCH((k_fft2d_inv_mx<H>), dim3((unsigned)grid), dim3(256), 0, st, yhat, y, bias, channels,
             (const cf32*)fp->tabW, (const cf32*)fp->tabH, (const uint16_t*)fp->tabG, fp->Mx, fp->My, s_dc, s_other, sh,
