@@ -937,11 +937,6 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
       p->fft2d.H <= 256 && !getenv("SC_PLAN_NO_MX_FFT")) {
     for (int which = 0; which < 2 && !rc; ++which) {       // forward-type rows in, inverse-type rows out
       std::vector<uint16_t> h;
-      // (inverse-type kernel: H = 128 / 256 only.  At H = 64 -- one row group per image -- its results were NOT repeatable on
-      //  hardware with two workgroups per compute unit: single spectrum entries of later images lose their real part, in
-      //  12 % of the images, never in host emulation, never with one workgroup per unit, never without the MFMAs, never
-      //  at H >= 128 (200 x 2048 images each).  Unexplained: k_fft2d_inv3<64, sc_bf16> keeps that size.)
-      if (which == 1 && p->fft2d.H < 128 && !getenv("SC_MXI_H64")) break;    // (SC_MXI_H64: scripts/mx_ifft_repeat.py only)
       if (which == 0) fft3mx_build_table(&h); else fft3mxi_build_table(&h);
       void* dev = nullptr;
       if (hipMalloc(&dev, h.size() * sizeof(uint16_t)) != hipSuccess) {

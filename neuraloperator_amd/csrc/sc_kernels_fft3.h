@@ -609,10 +609,15 @@ k_fft2d_inv3(const cf32* __restrict__ yhat, IO* __restrict__ y, const float* __r
     cf32 v[8], o[8];
 #pragma unroll
     for (int q2 = 0; q2 < 8; ++q2) {
-      const int fx = f2d_fx(mu + 8 * q2);
-      int idx = (a * fx) % H;
-      if (idx < 0) idx += H;
-      v[q2] = cf_mul_pk(EXTRA ? y32[mu + 8 * q2] : yh[q2], cf_conj(twH[idx]));
+      const cf32 src = EXTRA ? y32[mu + 8 * q2] : yh[q2];
+      if constexpr (P == 1) {                              // a = 0: the group twiddle is 1 (F3_NOTE_PK_MUL_LX, sc_kernels_fft3mx.h)
+        v[q2] = src;
+      } else {
+        const int fx = f2d_fx(mu + 8 * q2);
+        int idx = (a * fx) % H;
+        if (idx < 0) idx += H;
+        v[q2] = cf_mul_pk(src, cf_conj(twH[idx]));
+      }
     }
     dft8<+1>(v, o);                                      // over q2 -> m (row b = m + 8 b1)
 #pragma unroll

@@ -445,7 +445,22 @@ static inline int fft3mx_forward(const Fft2dPlan* fp, int mode, const sc_bf16* x
 //     per 16 lanes (the vector-ALU kernel: 2-byte stores, 64 contiguous bytes per half-wave).
 // Column phase, spectrum requests and scaling are those of k_fft2d_inv3 (its tile with a row stride of 38 complex so
 // that a lane's 8 consecutive coefficients are one aligned 64-byte read, conflict-free over 16 rows); the k = 32 column
-// tasks of all groups run in wave 0.  Served: H = 128 / 256, no epilogue (sc_engine.cpp; H = 64: DESIGN 3.5).
+// tasks of all groups run in wave 0.  Served: H = 64 / 128 / 256, no epilogue (sc_engine.cpp).
+//
+// F3_NOTE_PK_MUL_LX (round 6, DESIGN 3.5 -- what made H = 64 non-repeatable in round 5).  On MI355X a packed-fp32
+// instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) whose operand selects are op_sel:[0,1,.] -- low lane: LOW half
+// of src0, HIGH half of src1; op_sel_hi does not matter -- returns 0 in the LOW result of lanes 48-63 while another
+// wave of the same SIMD executes v_mfma_f32_16x16x32_bf16 (18 % of such executions in scripts/ubench_pk_forms.hip; never
+// with 32x32x2 f32, 16x16x4 f32, 16x16x16 f16, 32x32x16 bf16 or vector work in the other wave; never for the other three
+// op_sel combinations).  At P = 1 hipcc's SLP vectoriser kept the scaled spectrum entries as (im, re) register pairs and
+// emitted the group-twiddle product of the column task as `v_pk_mul_f32 vD, vTw, vY op_sel:[0,1] op_sel_hi:[0,0]`: with two
+// workgroups per unit the other workgroup's row pass zeroed the real part of 16 entries now and then.  Replacing exactly
+// those eight instructions in the generated assembly by two v_mul_f32 each, by the commuted product (op_sel:[1,0]) or
+// by natural halves with the exchange moved to the consumer's src2: 0 of 2000 / 100 / 100 launches differ
+// (profiles/r06_mxi_h64_root_cause.txt).  Source-level: at P = 1 the group twiddle is 1 and the product is gone
+// (`if constexpr (P == 1)` in the column task, here and in k_fft2d_inv3); tests/test_isa_pk_forms.py disassembles the
+// shipped code object and fails if any kernel that executes v_mfma_f32_16x16x32_bf16 holds a packed-fp32 instruction
+// with op_sel:[0,1,.].
 // Reference lines: spectral_convolution.py:520-568 (zero-filled spectrum, ifftn / irfft, bias).
 #define SC_MXI_URS 38     // row stride (complex) of T[64 rows][32 columns | . | 33 + a: the group's k = 32 column]
 #ifndef SC_MXI_WGS
@@ -620,10 +635,15 @@ k_fft2d_inv_mx(const cf32* __restrict__ yhat, sc_bf16* __restrict__ y, const flo
       cf32 v[8], o[8];
 #pragma unroll
       for (int q2 = 0; q2 < 8; ++q2) {
-        const int fx = f2d_fx(mu + 8 * q2);
-        int idx = (a * fx) % H;
-        if (idx < 0) idx += H;
-        v[q2] = cf_mul_pk(EXTRA ? y32[mu + 8 * q2] : yh[q2], cf_conj(twH[idx]));
+        const cf32 src = EXTRA ? y32[mu + 8 * q2] : yh[q2];
+        if constexpr (P == 1) {                            // a = 0: the group twiddle is 1 (and see F3_NOTE_PK_MUL_LX)
+          v[q2] = src;
+        } else {
+          const int fx = f2d_fx(mu + 8 * q2);
+          int idx = (a * fx) % H;
+          if (idx < 0) idx += H;
+          v[q2] = cf_mul_pk(src, cf_conj(twH[idx]));
+        }
       }
       dft8<+1>(v, o);                                      // over q2 -> m (row b = m + 8 b1)
 #pragma unroll
@@ -742,7 +762,6 @@ template <int H>
 static void fft3mxi_launch_inv(const Fft2dPlan* fp, const cf32* yhat, sc_bf16* y, const float* bias, int channels,
                                int64_t n_images, float s_dc, float s_other, sc_stream_t st, F3Shard sh) {
   int64_t grid = (int64_t)SC_MXI_WGS * sc_cu_count();
-  if (const char* e = getenv("SC_MXI_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;      // (diagnostic: scripts/mx_ifft_repeat.py)
   if (grid > n_images) grid = n_images;
   SC_LAUNCH((k_fft2d_inv_mx<H>), dim3((unsigned)grid), dim3(256), 0, st, yhat, y, bias, channels,
             (const cf32*)fp->tabW, (const cf32*)fp->tabH, (const uint16_t*)fp->tabG, fp->Mx, fp->My, s_dc, s_other, sh,
@@ -755,7 +774,7 @@ static inline int fft3mxi_inverse(const Fft2dPlan* fp, int mode, const cf32* yha
   const float s_dc = (mode == 0) ? fp->si : fp->sf;
   const float s_other = (mode == 0) ? fp->si : 0.5f * fp->sf;
   switch (fp->H) {
-    case 64: fft3mxi_launch_inv<64>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;   // (diagnostic)
+    case 64: fft3mxi_launch_inv<64>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
     case 128: fft3mxi_launch_inv<128>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
     case 256: fft3mxi_launch_inv<256>(fp, yhat, y, bias, (int)channels, n_images, s_dc, s_other, st, sh); break;
     default: *err = "sc_engine: fft2d (matrix-core row pass): unsupported H"; return 1;

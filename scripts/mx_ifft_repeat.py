@@ -1,19 +1,30 @@
-"""Repeatability stress of k_fft2d_inv_mx: N launches at 2048 images, every result compared bit for bit with the first
-(round 5, session 2: H = 64 failed this on hardware -- the kernel is not used there; H = 128 / 256: 0 of 200).
-Usage: python scripts/mx_ifft_repeat.py H repeats [Mx My images]"""
+"""Repeatability soak of k_fft2d_inv_mx through the shipped library: N launches at 2048 images, every result compared bit
+for bit with the first AND with the vector-ALU kernel of the same plan shape (one bf16 ulp, < 1 % of the outputs off).
+Round 5: H = 64 failed this on hardware (5-12 % of the images, different ones every launch); round 6 found the
+instruction (a packed-fp32 multiply with op_sel:[0,1] beside the other workgroup's bf16 MFMAs) -- all three
+heights are served since.  profiles/r06_mx_ifft_soak.txt holds 1000+ launches x {64, 128, 256} x both modes.
+Usage: python scripts/mx_ifft_repeat.py H repeats [mode 0|1] [Mx My images]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neuraloperator_amd import _lib
 lib = _lib.get_lib(); dev = torch.device("cuda:0"); torch.manual_seed(3)
-H = int(sys.argv[1]); reps = int(sys.argv[2])
-MX, MY, n = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (64, 33, 2048)
+H = int(sys.argv[1]); reps = int(sys.argv[2]); mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+MX, MY, n = (int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (64, 33, 2048)
 yh = torch.randn(n, MX, MY, 2, device=dev); bias = torch.randn(64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 plan = lib.plan_create([H, 256], [MX, MY], flags=_lib.SC_PLAN_IO_BF16)
-y0 = torch.zeros(n, H, 256, device=dev, dtype=torch.bfloat16); y = torch.zeros_like(y0)
-lib.transform_inverse(plan, 0, yh.data_ptr(), bias.data_ptr(), 64, y0.data_ptr(), n, 0, st)
+pv = lib.plan_create([H, 256], [MX, MY], flags=_lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT)
+assert lib.plan_kernel_name(plan, 1) == "k_fft2d_inv_mx", lib.plan_kernel_name(plan, 1)
+m, b = ((_lib.SC_INV_PADDED, bias.data_ptr()), (_lib.SC_INV_ADJ_R2C, 0))[mode]
+y0 = torch.zeros(n, H, 256, device=dev, dtype=torch.bfloat16); y = torch.zeros_like(y0); yv = torch.zeros_like(y0)
+lib.transform_inverse(plan, m, yh.data_ptr(), b, 64, y0.data_ptr(), n, 0, st)
+lib.transform_inverse(pv, m, yh.data_ptr(), b, 64, yv.data_ptr(), n, 0, st)
+d = (y0.float() - yv.float()).abs()
+one_ulp = bool((d <= yv.float().abs() * 2.0 ** -7 + 1e-4 * yv.float().abs().max()).all())
+off = float((y0 != yv).float().mean())
 bad = 0
 for it in range(reps):
-    lib.transform_inverse(plan, 0, yh.data_ptr(), bias.data_ptr(), 64, y.data_ptr(), n, 0, st)
+    lib.transform_inverse(plan, m, yh.data_ptr(), b, 64, y.data_ptr(), n, 0, st)
     bad += int(not torch.equal(y.view(torch.int16), y0.view(torch.int16)))
-print(f"H {H} kept {MX} x {MY}, {n} images ({lib.plan_kernel_name(plan, 1)}): {bad} of {reps} repeats differ from the first run")
+print(f"H {H} mode {mode} kept {MX} x {MY}, {n} images ({lib.plan_kernel_name(plan, 1)}): {bad} of {reps} repeats differ from the first run; "
+      f"first run within one bf16 ulp of the vector-ALU kernel: {one_ulp}, differs from it on {off:.2e} of the outputs")

@@ -102,8 +102,7 @@ def test_mx_inverse_vs_float64_and_valu(lib, H, Mx, My, n_img):
         routes = (("mx", _lib.SC_PLAN_IO_BF16), ("valu", _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT))
         for tag, fl in routes[:2 if H * n_img <= 512 else 1]:
             plan = lib.plan_create([H, 256], [Mx, My], flags=fl)
-            # (H = 64 stays on the vector-ALU kernel: sc_engine.cpp)
-            assert lib.plan_kernel_name(plan, 1) == ("k_fft2d_inv_mx" if tag == "mx" and H >= 128 else "k_fft2d_inv3")
+            assert lib.plan_kernel_name(plan, 1) == ("k_fft2d_inv_mx" if tag == "mx" else "k_fft2d_inv3")
             y = torch.full((n_img, H, 256), float("nan")).bfloat16()
             lib.transform_inverse(plan, mode, yh.data_ptr(), 0 if b is None else b.data_ptr(), n_img, y.data_ptr(),
                                   n_img, 0)

@@ -142,12 +142,14 @@ def test_bf16_io_vs_oracle(lib, case):
         assert rel_l2(xh.cpu().numpy(), xh32.cpu().numpy()) < 1e-6
 
 
-@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("H", [64, 128, 256])
 def test_bf16_inverse_on_the_matrix_cores_is_repeatable_and_one_rounding_from_fp32(lib, H):
     """k_fft2d_inv_mx (round 5, session 2: the row pass of the inverse-type transform writing bfloat16 as bf16 MFMA
-    products, two terms per operand) at the metric's image count: thirty launches bit for bit the same (the kernel is
-    NOT used at H = 64, where its results were not repeatable on hardware -- sc_engine.cpp), within one bf16
-    ulp of the vector-ALU kernel everywhere and different from it on < 1 % of the outputs, both inverse-type modes."""
+    products, two terms per operand) at the metric's image count: thirty launches bit for bit the same, within one bf16
+    ulp of the vector-ALU kernel everywhere and different from it on < 1 % of the outputs, both inverse-type modes.
+    H = 64 since round 6: round 5's build of that height was not repeatable on hardware -- a packed-fp32 instruction with
+    op_sel:[0,1] beside the other workgroup's bf16 MFMAs (tests/test_isa_pk_forms.py guards the encoding,
+    scripts/mx_ifft_repeat.py is the long soak)."""
     from neuraloperator_amd import _lib
 
     dev = torch.device("cuda:0")
@@ -164,7 +166,7 @@ def test_bf16_inverse_on_the_matrix_cores_is_repeatable_and_one_rounding_from_fp
         yv, y = torch.zeros_like(y0), torch.zeros_like(y0)
         lib.transform_inverse(pm, mode, yh.data_ptr(), b, C, y0.data_ptr(), n, 0, st)
         lib.transform_inverse(pv, mode, yh.data_ptr(), b, C, yv.data_ptr(), n, 0, st)
-        for _ in range(30 if mode == _lib.SC_INV_PADDED else 5):
+        for _ in range(30 if mode == _lib.SC_INV_PADDED else 10):
             lib.transform_inverse(pm, mode, yh.data_ptr(), b, C, y.data_ptr(), n, 0, st)
             assert torch.equal(y.view(torch.int16), y0.view(torch.int16))
         d = (y0.float() - yv.float()).abs()
@@ -172,9 +174,6 @@ def test_bf16_inverse_on_the_matrix_cores_is_repeatable_and_one_rounding_from_fp
         assert float((y0 != yv).float().mean()) < 0.01
     lib.plan_destroy(pm)
     lib.plan_destroy(pv)
-    p64 = lib.plan_create([64, 256], [64, 33], flags=_lib.SC_PLAN_IO_BF16)
-    assert lib.plan_kernel_name(p64, 0) == "k_fft2d_fwd_mx" and lib.plan_kernel_name(p64, 1) == "k_fft2d_inv3"
-    lib.plan_destroy(p64)
 
 
 def test_bf16_forward_on_a_4_byte_aligned_view(lib):
