@@ -464,6 +464,48 @@ def _extra_traffic(shape, io, kind, alg_bytes_step):
             "traffic_source": note + "; `traffic` = sum over the step's launches"}
 
 
+def compact_configs(out, extra, world):
+    """The LAST key of the JSON line: every BASELINE config in <= 1500 characters, so that a record that
+    keeps only the tail of the line still shows them.  Per entry: ms = ms per step of the settled region, cold = of the
+    contract's first region, frac = algorithmic bytes / ms / 8 TB/s, toa = counter traffic / algorithmic bytes (null = not
+    measured in this run), sps = samples/s of the whole job.  c1 = configs[1] (the headline workload, fp32 and bf16 real
+    tensors), c2 = configs[2] TFNO Tucker rank 0.1, c3 = configs[3] FNO3d 128^3 B = 8 (one GPU: `c3_single`; N GPUs:
+    `c3_modeshard` strong-scaled next to the one-GPU replica step and their ratio), c4 = configs[4] 1024^2."""
+    def ent(e, frac_key="frac_of_8TBs"):
+        if not e or e.get("ms_per_step") is None:
+            return None
+        r = {"ms": e["ms_per_step"], "cold": e.get("cold_start_ms_per_step"), "sps": e.get("value")}
+        if e.get(frac_key) is not None:
+            r["frac"] = e[frac_key]
+        if "traffic_over_alg_bytes" in e:
+            r["toa"] = e["traffic_over_alg_bytes"]
+        return r
+    sr = out.get("step_roofline", {})
+    head = {"ms": out["ms_per_step"], "cold": out["cold_start"]["ms_per_step"], "sps": out["value"],
+            "frac": sr.get("frac_of_8TBs"), "toa": sr.get("traffic_over_alg_bytes")}
+    io = out["config"].get("real_tensor_io", "f32")
+    wl = out["config"]["workload"]
+    c = {"n_gpus": world, "head": f"{wl}/{io}/{out['config'].get('parallelism')}"}
+    key = {("fno2d_256_m64_c64_b32", "f32"): "c1_f32", ("fno2d_256_m64_c64_b32", "bf16"): "c1_bf16",
+           ("fno3d_128_m32_c32_b8", "f32"): "c3_single", ("fno2d_1024_m256_c128_b4", "f32"): "c4_1024"}.get((wl, io), "head")
+    par = str(out["config"].get("parallelism", ""))
+    if world > 1 or par.startswith(("modeshard", "pencil")):   # N GPUs: the headline is a parallel form of its workload
+        key = ("c3_" if wl.startswith("fno3d") else "c1_" if wl == "fno2d_256_m64_c64_b32" else "head_") + \
+            (par.split("-")[0].rstrip("0123456789") or "parallel")
+    c[key] = head
+    for name, k in (("bf16_io", "c1_bf16"), ("tfno_rank01", "c2_tfno"), ("fno3d_single", "c3_single"),
+                    ("fno2d_1024_b4", "c4_1024"), ("fno3d_modeshard", "c3_modeshard"), ("dp_allreduce", "c1_dp")):
+        e = ent(extra.get(name))
+        if e:
+            c[k] = e
+    if "c3_modeshard" in c and "c3_single" in c:           # configs[3]'s >= 6 x question on one line (strong scaling, B = 8 in all)
+        c["c3_speedup"] = round(c["c3_single"]["ms"] / c["c3_modeshard"]["ms"], 3)
+    fb = extra.get("fno_block")
+    if fb and fb.get("fused_ms") is not None:
+        c["block"] = {"fused_ms": fb["fused_ms"], "ref_ms": fb.get("reference_op_sequence_ms")}
+    return c
+
+
 def engine_path(names):
     """Which transform kernels the plan of this workload runs (sc_plan_kernel_name): the fused one-image-per-workgroup
     FFT (256-wide grids), the two-pass factorised FFT (512 / 1024 per axis), the factorised plane kernels (128 x 128 or 64 x 64
@@ -684,7 +726,9 @@ def build_case(parallel, workload, world, dev, flags, io_dtype, dist, seed, conv
         conv = SpectralConv(C, C, n_modes, engine_flags=flags, **(conv_kwargs or {})).to(dev)
         b_local, scaling, global_batch = B, "weak", B * world
         par = f"dp{world}-allreduce" if world > 1 else "single"
-        if world > 1:
+        if parallel == "replicas_single":                # one GPU's step, measured on every rank of an N-GPU run
+            global_batch, par = B, "single (a replica per rank, no collective; value = ONE GPU's samples/s)"
+        elif world > 1:
             def post():                                  # data parallel: the dense weight's gradient crosses xGMI
                 for prm in conv.parameters():
                     if prm.grad is not None:
@@ -998,7 +1042,10 @@ def main():
                 # any-width matrix-core passes of round 4, profiles/r04_odd_sizes.txt)
                 ("darcy_421", "replicas", "darcy_421_m32_c32_b16", f32, None)] if world == 1 else \
             [("dp_allreduce", "replicas", args.workload, f32, None),
-             ("fno3d_modeshard", "modeshard", "fno3d_128_m32_c32_b8", f32, None)]
+             ("fno3d_modeshard", "modeshard", "fno3d_128_m32_c32_b8", f32, None),
+             # the same B = 8 step on ONE GPU (every rank runs a replica, no collective): the denominator of the
+             # strong-scaling ratio, measured in the same run on the same node (`configs.c3_speedup`)
+             ("fno3d_single", "replicas_single", "fno3d_128_m32_c32_b8", f32, None)]
         for name, par_x, wl, io_x, kw_x in todo:
             if par_x == parallel and wl == args.workload and io_x == io_dtype and kw_x is None:
                 continue
@@ -1145,6 +1192,7 @@ def main():
             out["gpu_reference_baseline"] = gpu_reference_baseline(b_local, C, spatial, n_modes, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
+        out["configs"] = compact_configs(out, extra, world)   # LAST key: <= 1500 characters (tests/test_bench_contract.py)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)

@@ -124,3 +124,29 @@ def test_gpus_n_without_a_launcher_starts_n_ranks_or_fails(bench, monkeypatch, c
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+
+
+def test_compact_configs_is_the_last_key_and_fits_the_record_tail(bench):
+    """the driver's record keeps the last 2000 characters of the line -- the `configs` object (every
+    BASELINE config: ms, cold ms, samples/s, fraction of 8 TB/s, counter traffic over algorithmic bytes) must be the last key
+    and fit with room to spare, for a one-GPU line and for an N-GPU line."""
+    import json
+    ex = lambda ms: {"ms_per_step": ms, "cold_start_ms_per_step": ms * 1.1234, "value": 61234.56, "frac_of_8TBs": 0.5123,
+                     "traffic_over_alg_bytes": 1.234, "traffic": 123456789012, "workload": "x" * 40}
+    out = {"ms_per_step": 0.5197, "value": 61575.31, "cold_start": {"ms_per_step": 0.5934},
+           "step_roofline": {"frac_of_8TBs": 0.6413, "traffic_over_alg_bytes": 1.029},
+           "config": {"workload": "fno2d_256_m64_c64_b32", "real_tensor_io": "f32", "parallelism": "single"}}
+    extra = {"bf16_io": ex(0.3722), "tfno_rank01": ex(0.7259), "fno3d_single": ex(1.904), "fno2d_1024_b4": ex(5.37),
+             "darcy_421": ex(0.9), "fno_block": {"fused_ms": 2.79, "reference_op_sequence_ms": 12.3}}
+    c = bench.compact_configs(out, extra, 1)
+    assert set(c) >= {"c1_f32", "c1_bf16", "c2_tfno", "c3_single", "c4_1024", "block"}
+    assert c["c1_f32"] == {"ms": 0.5197, "cold": 0.5934, "sps": 61575.31, "frac": 0.6413, "toa": 1.029}
+    out["configs"] = c
+    line = json.dumps(out)
+    assert list(out)[-1] == "configs" and line.rstrip().endswith("}}")
+    assert len(json.dumps(c)) <= 1500 and '"configs": ' + json.dumps(c) in line[-2000:]
+    # an 8-GPU line: mode-sharded configs[3] strong-scaled beside the one-GPU replica step and their ratio
+    out8 = dict(out, config={"workload": "fno2d_256_m64_c64_b32", "real_tensor_io": "f32", "parallelism": "dp8-allreduce"})
+    e8 = {"dp_allreduce": ex(0.9), "fno3d_modeshard": ex(0.30), "fno3d_single": ex(1.92)}
+    c8 = bench.compact_configs(out8, e8, 8)
+    assert c8["n_gpus"] == 8 and c8["c3_speedup"] == 6.4 and len(json.dumps(c8)) <= 1500
