@@ -317,7 +317,12 @@ int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* d, const float* x
  * the same kind one layer step later (the layer's exchanges alternate directions -- csrc/sc_kernels_peer.h), the host
  * side rotates a few windows.  peer_window[p] = the mapped base of rank p's window (own entry: the local pointer);
  * world <= 8, block_bytes a multiple of 16, send / recv 16-byte aligned.  Unmeasured on more than one GPU (no multi-GPU
- * tier in the build environment); self-tested with two processes on one device. */
+ * tier in the build environment); self-tested with two processes on one device.
+ * sc_peer_window_control (round 6): the wait launch spins without bound by default -- a peer that is merely late must not
+ * corrupt a step -- which turns a dead peer or a non-coherent mapping into a stream that never drains.  A rank may give
+ * the waits on ITS window a budget (milliseconds of the device's 100 MHz wall clock; 0 = unbounded, negative = unchanged)
+ * and read the error word a timed-out wait leaves behind (0 = none, 1 + p = the flag of peer p never came; reading
+ * clears it).  The host side runs its set-up self-test under a 2 s budget and falls back to the collective path on error. */
 typedef struct sc_peer_exchange {
   int32_t world, rank;
   int64_t block_bytes;
@@ -328,6 +333,7 @@ int sc_peer_window_open(const void* handle64, void** ptr);
 int sc_peer_window_close(void* ptr);
 int sc_peer_window_free(void* ptr);
 int sc_peer_all_to_all(const sc_peer_exchange* d, const void* send, void* recv, void* stream);
+int sc_peer_window_control(void* own_window, int64_t spin_budget_ms, int32_t* error_out);
 
 /* ---- pointwise half of an FNO block in one pass ("next" row f1 of SURVEY.md section 8) -------------------
  *   out = act( W2 gelu(W1 x + b1) + b2 + gate (.) skip_src )

@@ -162,7 +162,7 @@ class ScEngineLib:
                "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes", "sc_tucker_chain_fused_supported",
                "sc_tucker_chain_t3m_bytes", "sc_tucker_chain_forward_fused", "sc_tucker_chain_backward_fused",
                "sc_tucker_chain_backward_fused_workspace_bytes", "sc_peer_window_alloc", "sc_peer_window_open",
-               "sc_peer_window_close", "sc_peer_window_free", "sc_peer_all_to_all"]
+               "sc_peer_window_close", "sc_peer_window_free", "sc_peer_all_to_all", "sc_peer_window_control"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -281,6 +281,8 @@ class ScEngineLib:
         L.sc_peer_window_free.restype = c_int
         L.sc_peer_all_to_all.argtypes = [POINTER(PeerExchangeDesc), c_void_p, c_void_p, c_void_p]
         L.sc_peer_all_to_all.restype = c_int
+        L.sc_peer_window_control.argtypes = [c_void_p, c_int64, POINTER(ctypes.c_int32)]
+        L.sc_peer_window_control.restype = c_int
         L.sc_tucker_chain_fused_supported.argtypes = [POINTER(TuckerChainDesc)]
         L.sc_tucker_chain_fused_supported.restype = c_int
         L.sc_tucker_chain_t3m_bytes.argtypes = [POINTER(TuckerChainDesc)]
@@ -486,6 +488,14 @@ class ScEngineLib:
 
     def peer_window_free(self, ptr):
         self._check(self.lib.sc_peer_window_free(ptr))
+
+    def peer_window_control(self, own_window, spin_budget_ms=-1):
+        """set the spin budget of the waits on this rank's window (ms; 0 = unbounded, < 0 = unchanged); -> the error word a
+        timed-out wait left (0 = none, 1 + p = peer p's flag never came), cleared by the read"""
+        import ctypes
+        err = ctypes.c_int32(0)
+        self._check(self.lib.sc_peer_window_control(own_window, spin_budget_ms, byref(err)))
+        return int(err.value)
 
     def peer_all_to_all(self, world, rank, block_bytes, peer_windows, send, recv, stream=0):
         d = PeerExchangeDesc(world, rank, block_bytes, (c_void_p * 8)(*(list(peer_windows) + [None] * (8 - len(peer_windows)))))

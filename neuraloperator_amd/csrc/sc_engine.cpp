@@ -16,6 +16,15 @@
 #include <vector>
 
 #include "sc_device.h"
+// Diagnostic / A-B switches of the measurement scripts (kernel shapes, grid sizes, routes switched off): read from the
+// environment only in builds with -DSC_DIAG (scripts/build_diag.py, the emulation tier).  The product library holds
+// neither the reads nor the names: `strings libsc_engine.so | grep '^SC_'` shows the documented public switches only
+// (SC_NO_SIDE_STREAM, SC_PLAN_NO_MX_FFT, SC_TKC), each read once per process except SC_TKC.
+#ifdef SC_DIAG
+#define SC_DIAG_ENV(name) std::getenv(name)
+#else
+#define SC_DIAG_ENV(name) ((const char*)nullptr)
+#endif
 #include "sc_kernels_generic.h"
 #include "sc_kernels_fft.h"
 #include "sc_kernels_fft3.h"
@@ -591,7 +600,7 @@ static int pl64_plan_init(sc_plan* p) {
 
 static int64_t f2p_panel_elems_per_image(const sc_plan* p) { return (int64_t)p->f2p_ncb * p->n[0] * SC_F2P_CB; }
 static int64_t f2p_chunk_images(const sc_plan* p, int64_t n_images) {
-  static const int mb = [] { const char* e = std::getenv("SC_F2P_CHUNK_MB"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : SC_F2P_CHUNK_MB; }();   // A-B
+  static const int mb = [] { const char* e = SC_DIAG_ENV("SC_F2P_CHUNK_MB"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : SC_F2P_CHUNK_MB; }();   // A-B
   int64_t c = ((int64_t)mb << 20) / (f2p_panel_elems_per_image(p) * (int64_t)sizeof(cf32));
   if (c < 1) c = 1;
   return c < n_images ? c : n_images;
@@ -626,7 +635,7 @@ static bool f2p_dispatch(int P, int K2, F&& f) {
 // than its own time.  SC_F2P_PIPE=1 (environment) switches it on for A-B runs; the default alternates the passes on the
 // caller's stream over full-sized chunks.
 static bool f2p_pipe_enabled() {
-  static const bool on = [] { const char* e = std::getenv("SC_F2P_PIPE"); return e && e[0] == '1'; }();
+  static const bool on = [] { const char* e = SC_DIAG_ENV("SC_F2P_PIPE"); return e && e[0] == '1'; }();
   return on;
 }
 struct F2pChunks {
@@ -668,10 +677,10 @@ static bool f2p_launch_col_fwd(const sc_plan* p, const cf32* panel, cf32* dst, i
 static bool f2p_launch_col_inv(const sc_plan* p, const cf32* src, cf32* panel, int64_t ni, sc_stream_t st) {
   const int J = (int)p->k[1], K0 = (int)p->k[0], NCB = p->f2p_ncb;
   const int64_t n_blk = ni * NCB;
-  static const bool no_colw = std::getenv("SC_F2P_NO_COLW") != nullptr;              // A-B: the 32-lane kernel
+  static const bool no_colw = SC_DIAG_ENV("SC_F2P_NO_COLW") != nullptr;              // A-B: the 32-lane kernel
   if (p->f2p_colw && !no_colw && n_blk < ((int64_t)1 << 30)) {
     // columns of 1024 points: 64 lanes per line, two 512-thread workgroups per compute unit, persistent
-    static const int wgs = [] { const char* e = std::getenv("SC_F2P_COLW_WGS"); return e ? std::atoi(e) : 2; }();
+    static const int wgs = [] { const char* e = SC_DIAG_ENV("SC_F2P_COLW_WGS"); return e ? std::atoi(e) : 2; }();
     int64_t grid = (int64_t)(wgs > 0 ? wgs : 2) * sc_cu_count();
     if (grid > n_blk) grid = n_blk;
     if (grid >= 8) grid &= ~(int64_t)7;                                              // whole XCD rounds (the kernel's block map)
@@ -693,10 +702,10 @@ static bool f2p_launch_col_inv(const sc_plan* p, const cf32* src, cf32* panel, i
 static bool f2p_launch_c2r(const sc_plan* p, int mode, const cf32* panel, float* ys, const float* bias, int64_t channels,
                            int64_t i0, int64_t ni, sc_stream_t st) {
   const int N0 = (int)p->n[0], J = (int)p->k[1], NCB = p->f2p_ncb;
-  static const bool no_w1024 = std::getenv("SC_F2P_NO_W1024") != nullptr;          // A-B: the half-wave kernel
+  static const bool no_w1024 = SC_DIAG_ENV("SC_F2P_NO_W1024") != nullptr;          // A-B: the half-wave kernel
   if (p->f2p_roww && !no_w1024) {
     // rows of 1024 points: one wave per packed row pair, four 4-wave workgroups per compute unit (sc_kernels_fft2p.h)
-    static const int wgs = [] { const char* e = std::getenv("SC_F2P_W1024_WGS"); return e ? std::atoi(e) : 4; }();
+    static const int wgs = [] { const char* e = SC_DIAG_ENV("SC_F2P_W1024_WGS"); return e ? std::atoi(e) : 4; }();
     const int64_t n_pairs = ni * N0 / 2, n_items = (n_pairs + 3) / 4;
     int64_t grid = (int64_t)(wgs > 0 ? wgs : 4) * sc_cu_count();
     if (grid > n_items) grid = n_items;
@@ -956,7 +965,7 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
     rc = pl128_plan_init(p);
   if (!rc && !p->fast && !p->f2p && !p->pl128 &&
       !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT | SC_PLAN_F2P_SMALL_ALWAYS)) &&
-      !getenv("SC_PLAN_NO_PL64"))
+      !SC_DIAG_ENV("SC_PLAN_NO_PL64"))
     rc = pl64_plan_init(p);
   if (!rc && !p->fast && !p->f2p && !p->pl128 && !p->pl64 &&
       !(desc->flags & (SC_PLAN_FORCE_GENERIC | SC_PLAN_IO_BF16 | SC_PLAN_NO_MDFT | SC_PLAN_NO_F2P_SMALL)))
@@ -1133,7 +1142,7 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
   if (p->pl128) {
     const int L = p->nd - 1;
     // planes per workgroup: the next plane's first rows are in flight while this one is finished (A-B: SC_PL_PPW)
-    static const int ppw_env = [] { const char* e = std::getenv("SC_PL_PPW"); return e ? std::atoi(e) : 0; }();
+    static const int ppw_env = [] { const char* e = SC_DIAG_ENV("SC_PL_PPW"); return e ? std::atoi(e) : 0; }();
     const int64_t n_planes = lines / SC_PL_N;
     int ppw = ppw_env > 0 ? ppw_env : SC_PL_PPW_DEFAULT;
     while (ppw > 1 && n_planes / ppw < (int64_t)6 * sc_cu_count()) --ppw;     // keep two full rounds of workgroups
@@ -1144,7 +1153,7 @@ static int run_plane_fwd(const sc_plan* p, int mode, const float* in, cf32* out,
   if (p->pl64) {
     const int L = p->nd - 1;
     // planes per workgroup: the next plane's rows are in flight while this one is transformed (A-B: SC_P64_PPW)
-    static const int ppw_env = [] { const char* e = std::getenv("SC_P64_PPW"); return e ? std::atoi(e) : 0; }();
+    static const int ppw_env = [] { const char* e = SC_DIAG_ENV("SC_P64_PPW"); return e ? std::atoi(e) : 0; }();
     const int64_t n_planes = lines / SC_P64_N;
     int ppw = ppw_env > 0 ? ppw_env : SC_P64_PPW_DEFAULT;
     while (ppw > 1 && n_planes / ppw < (int64_t)8 * sc_cu_count()) --ppw;     // keep two full rounds of workgroups
@@ -1282,7 +1291,7 @@ static void launch_mdft_c2r_stage(const sc_plan* p, int mode, const cf32* in, fl
   // blocks is a small share of the launch; every range re-reads the tile's spectrum (8 % of the bytes, from L2)
   int64_t splits = ((int64_t)24 * sc_cu_count() + n_tiles - 1) / n_tiles;
   static const int split_env = [] {                          // A-B only (scripts/mdft_time.py)
-    const char* e = getenv("SC_C2R_STAGE_SPLITS");
+    const char* e = SC_DIAG_ENV("SC_C2R_STAGE_SPLITS");
     return e ? atoi(e) : 0;
   }();
   if (split_env > 0) splits = split_env;
@@ -1299,7 +1308,7 @@ static size_t c2r_span_lds(const sc_plan* p, int N) {         // spectrum rows a
   return (size_t)32 * (N > p->s_c2r_s ? N : p->s_c2r_s) * sizeof(float);
 }
 static bool c2r_span_ok(const sc_plan* p, int N, const float* out, int64_t lines) {
-  static const bool off = getenv("SC_C2R_NOSPAN") != nullptr;             // A-B against k_mdft_c2r_stage
+  static const bool off = SC_DIAG_ENV("SC_C2R_NOSPAN") != nullptr;             // A-B against k_mdft_c2r_stage
   return !off && !(p->d.flags & SC_PLAN_NO_SPAN) && sc_io_aligned(out) && c2r_span_lds(p, N) <= (size_t)80 * 1024 &&
          (lines + 31) / 32 < ((int64_t)1 << 31);
 }
@@ -1714,7 +1723,7 @@ static int sb_max_extent() {
   // default 4: the regime where both older kernels are known to be slow.  SC_SB_MAX=n (environment,
   // read once) moves the bound for A-B runs: 0 switches the path off, 8 also takes FNO3d's B = 8 launches
   static const int v = [] {
-    const char* e = std::getenv("SC_SB_MAX");
+    const char* e = SC_DIAG_ENV("SC_SB_MAX");
     const int n = e ? std::atoi(e) : 4;
     return n < 0 ? 0 : (n > 8 ? 8 : n);
   }();
@@ -1725,7 +1734,7 @@ static int sb_max_extent() {
 // tiles fastest.  SC_GEMM_SB_ALT_ORDER on a descriptor and SC_SB_ALT_ORDER (environment, read once: bit 0 = single
 // launches, bit 1 = the pair) each flip it.
 static int sb_alt_order_env() {
-  static const int v = [] { const char* e = std::getenv("SC_SB_ALT_ORDER"); return e ? std::atoi(e) : 0; }();
+  static const int v = [] { const char* e = SC_DIAG_ENV("SC_SB_ALT_ORDER"); return e ? std::atoi(e) : 0; }();
   return v;
 }
 static bool sb_gemm_eligible(const sc_modegemm_desc* d, const void* A, const void* B, const void* C) {
@@ -1754,7 +1763,7 @@ static int run_sb_gemm_t(const sc_modegemm_desc* d, const cf32* A, const cf32* B
   // an operand that exactly one tile reads crosses the chip once: keep it out of the caches the shared one lives in
   g.nt_a = g.n_qt == 1;
   g.nt_b = g.n_pt == 1;
-  static const bool plain_c = std::getenv("SC_SB_PLAIN_C") != nullptr;               // A-B
+  static const bool plain_c = SC_DIAG_ENV("SC_SB_PLAIN_C") != nullptr;               // A-B
   g.nt_c = (d->flags & SC_GEMM_STREAM_C) && !plain_c ? 1 : 0;
   const dim3 grid((unsigned)(8 * g.per_xcd));
 #define SC_SB_LAUNCH(CA, CB) SC_LAUNCH((k_modegemm_sb<PT, QT, ST, WM, WP, WQ, CA, CB>), grid, dim3(SC_BLOCK), 0, st, g, A, B, C)
@@ -1771,7 +1780,7 @@ static int run_sb_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B, 
   // flight; short reduction (weight gradient): 4 x 4 outputs per lane, two steps in flight.  Wave arrangement
   // (sc_kernels_sb.h): the four waves over four column tiles (2 x 2 tiles for the weight gradient) of one 128-mode
   // tile; SC_GEMM_SB_WM4 / SC_SB_WM=4 (flag / environment, A-B) = four neighbouring 128-mode tiles of one tile instead
-  static const bool wm4_env = [] { const char* e = std::getenv("SC_SB_WM"); return e && std::atoi(e) == 4; }();
+  static const bool wm4_env = [] { const char* e = SC_DIAG_ENV("SC_SB_WM"); return e && std::atoi(e) == 4; }();
   const bool wm4 = wm4_env || (d->flags & SC_GEMM_SB_WM4);
   if (d->P <= 4)
     return wm4 ? run_sb_gemm_t<4, 4, 3, 4, 1, 1>(d, A, B, C, st) : run_sb_gemm_t<4, 4, 3, 1, 1, 4>(d, A, B, C, st);
@@ -1793,7 +1802,7 @@ static int run_sb_bwd_t(const SbBwdArgs& g, const cf32* xhat, const cf32* ghat, 
 
 static bool sb_bwd_eligible(const sc_modegemm_desc* d0, const void* A0, const void* B0, const void* C0,
                             const sc_modegemm_desc* d1, const void* A1, const void* B1, const void* C1) {
-  static const bool off = std::getenv("SC_SB_NO_PAIR") != nullptr;                     // A-B
+  static const bool off = SC_DIAG_ENV("SC_SB_NO_PAIR") != nullptr;                     // A-B
   if (off) return false;
   if (!sb_gemm_eligible(d0, A0, B0, C0) || !sb_gemm_eligible(d1, A1, B1, C1)) return false;
   if (!(d0->conj_a && !d0->conj_b && !d1->conj_a && d1->conj_b)) return false;
@@ -1820,7 +1829,7 @@ static int run_sb_bwd(const sc_modegemm_desc* d0, const cf32* A0, const cf32* B0
   if (total >= ((int64_t)1 << 30)) return -1;
   g.per_xcd = (int)((total + 7) / 8);
   g.mt_fastest = (1 ^ ((sb_alt_order_env() >> 1) & 1) ^ (((d0->flags | d1->flags) & SC_GEMM_SB_ALT_ORDER) ? 1 : 0)) & 1;
-  static const bool plain_c = std::getenv("SC_SB_PLAIN_C") != nullptr;                 // A-B
+  static const bool plain_c = SC_DIAG_ENV("SC_SB_PLAIN_C") != nullptr;                 // A-B
   g.nt_gw = (d0->flags & SC_GEMM_STREAM_C) && !plain_c ? 1 : 0;
   switch (g.B) {
     case 1: return run_sb_bwd_t<1>(g, A0, B0, B1, C0, C1, st);
@@ -1872,12 +1881,12 @@ static int run_bfac_gemm(const sc_modegemm_desc* d, const cf32* A, const cf32* B
 #define SC_FMX_ATTR(kern, lds) (void)0
 #endif
 static int tucker_abl() {
-  static const int v = [] { const char* e = std::getenv("SC_TK_ABL"); return e ? std::atoi(e) : 0; }();
+  static const int v = [] { const char* e = SC_DIAG_ENV("SC_TK_ABL"); return e ? std::atoi(e) : 0; }();
   return v;
 }
 // ---- factor-matrix products and mode-summed contractions on the matrix cores (sc_kernels_fmx.h) ---------------
 static bool fmx_off() {
-  static const bool off = std::getenv("SC_FMX_OFF") != nullptr;                        // A-B against the VALU kernels
+  static const bool off = SC_DIAG_ENV("SC_FMX_OFF") != nullptr;                        // A-B against the VALU kernels
   return off;
 }
 // workgroups for n chunks with `cap` co-resident: every workgroup the same number of rounds
@@ -1888,7 +1897,7 @@ static int fmx_wgs(int64_t chunks, int64_t cap) {
   // of the unit count when that costs the busiest workgroup at most one more chunk: TFNO rank 0.1 has 1056 chunks
   // (32 rows x 33 mode blocks): 528 workgroups of 2 chunks put three workgroups = 6 chunks on 16 units (average 4.1),
   // 512 workgroups (32 of them with 3 chunks) put 5 on the busiest.  SC_FMX_WGS_EXACT=1 (environment, A-B): the old rule
-  static const bool exact = std::getenv("SC_FMX_WGS_EXACT") != nullptr;
+  static const bool exact = SC_DIAG_ENV("SC_FMX_WGS_EXACT") != nullptr;
   const int64_t cus = sc_cu_count();
   const int64_t m = (wgs / cus) * cus;
   if (!exact && m >= cus && m < wgs && (chunks + m - 1) / m <= rounds + 1) wgs = m;
@@ -2084,7 +2093,7 @@ static bool gemm8_eligible(const sc_modegemm_desc* d, const void* A, const void*
   // (profiles/r03_tfno_kernel_stats_g8fill2.txt): the operand stream, not the matrix pipe, is what a tile costs
   const int64_t cols = 32;
   const int64_t Pp = (d->P + 31) / 32 * 32, Qp = (d->Q + cols - 1) / cols * cols;
-  static const int64_t fill4 = [] { const char* e = std::getenv("SC_G8_FILL4"); return e ? (int64_t)std::atoi(e) : (int64_t)2; }();
+  static const int64_t fill4 = [] { const char* e = SC_DIAG_ENV("SC_G8_FILL4"); return e ? (int64_t)std::atoi(e) : (int64_t)2; }();
   bool rows_ok = 4 * d->P >= fill4 * Pp;
   // a small batch against a weight read ACROSS its rows (the gradient of the spectrum: B[r, q] = W[q, r], q stride >
   // r stride): the lanes-are-modes VALU kernel gathers 512-byte pieces of W there (FNO3d 128^3, B = 8: 115 us), the
@@ -2323,7 +2332,7 @@ static int64_t msum_geometry(ModeGemmArgs& g, bool* wide_out) {
   // when the mode tiles alone do not fill the chip (TFNO rank 0.1: 33 tiles x 20 output tiles = 660 workgroups, 2.8 waves
   // per SIMD, 45 % of the wave cycles issue-stalled: profiles/r03_tfno_pmc.txt) the reduction index is cut as well;
   // SC_MSUM_RSPLIT (environment, A-B) overrides
-  static const int rsplit_env = [] { const char* e = std::getenv("SC_MSUM_RSPLIT"); return e ? std::atoi(e) : 0; }();
+  static const int rsplit_env = [] { const char* e = SC_DIAG_ENV("SC_MSUM_RSPLIT"); return e ? std::atoi(e) : 0; }();
   int64_t rsplit = rsplit_env > 0 ? rsplit_env : 1;
   if (rsplit > g.R) rsplit = g.R;
   g.r_split = (int)rsplit;
@@ -2594,7 +2603,7 @@ static void tkc_args(const sc_tucker_chain_desc* c, TkcArgs& g) {
   g.M = c->n_modes;
   g.n_tiles = (int)(c->n_modes / 4);
   // persistent: one workgroup per compute unit (a tile needs ~147 KB of LDS); SC_TKC_WGS (environment, A-B)
-  static const int env = [] { const char* e = std::getenv("SC_TKC_WGS"); return e ? std::atoi(e) : 0; }();
+  static const int env = [] { const char* e = SC_DIAG_ENV("SC_TKC_WGS"); return e ? std::atoi(e) : 0; }();
   const int cap = env > 0 ? env : sc_cu_count();
   g.n_wg = g.n_tiles < cap ? g.n_tiles : cap;
   g.inv_ci = tkc_inv(g.Ci); g.inv_co = tkc_inv(g.Co); g.inv_r1 = tkc_inv(g.R1); g.inv_r2 = tkc_inv(g.R2);
@@ -2672,7 +2681,7 @@ extern "C" int sc_tucker_chain_backward_fused(const sc_tucker_chain_desc* c, con
 
 // ------------------------------------------------------------------------------------------
 // Round 5: peer-store exchange (sc_kernels_peer.h).  A window = 512 header bytes (flags [8] at 0, this rank's epoch at
-// 256, its workgroup ticket at 264) + the data; fine-grained device memory so that stores from a peer GPU and the flag
+// 256, its workgroup ticket at 264, the wait kernel's error word at 272 and spin budget at 280: round 6) + the data; fine-grained device memory so that stores from a peer GPU and the flag
 // loads of the owner are coherent inside running kernels; shared through HIP IPC handles.
 // ------------------------------------------------------------------------------------------
 #define SC_PEER_HEADER 512
@@ -2721,6 +2730,33 @@ extern "C" int sc_peer_window_free(void* ptr) {
 #endif
   return 0;
 }
+// spin budget of k_peer_wait on THIS rank's window (milliseconds; 0 = unbounded, < 0 = leave as it is) and the error word it
+// leaves behind when the budget runs out (0 = none, 1 + p = the flag of peer p never came); reading clears it.
+// Synchronous with respect to the device (the header is fine-grained memory read through a blocking copy).
+extern "C" int sc_peer_window_control(void* own_window, int64_t spin_budget_ms, int32_t* error_out) {
+  SC_CHECK_ARG(own_window, "null argument");
+  unsigned char* mine = (unsigned char*)own_window;
+  if (spin_budget_ms >= 0) {
+    const unsigned long long ticks = (unsigned long long)spin_budget_ms * 100000ull;      // 100 MHz wall clock
+#ifndef SC_EMU
+    SC_CHECK_HIP(hipMemcpy(mine + 280, &ticks, 8, hipMemcpyHostToDevice));
+#else
+    std::memcpy(mine + 280, &ticks, 8);
+#endif
+  }
+  if (error_out) {
+    unsigned int e = 0, zero = 0;
+#ifndef SC_EMU
+    SC_CHECK_HIP(hipMemcpy(&e, mine + 272, 4, hipMemcpyDeviceToHost));
+    if (e) SC_CHECK_HIP(hipMemcpy(mine + 272, &zero, 4, hipMemcpyHostToDevice));
+#else
+    std::memcpy(&e, mine + 272, 4);
+    std::memcpy(mine + 272, &zero, 4);
+#endif
+    *error_out = (int32_t)e;
+  }
+  return 0;
+}
 extern "C" int sc_peer_all_to_all(const sc_peer_exchange* d, const void* send, void* recv, void* stream) {
   SC_CHECK_ARG(d && send && recv, "null argument");
   SC_CHECK_ARG(d->world >= 1 && d->world <= 8 && d->rank >= 0 && d->rank < d->world, "sc_peer_all_to_all: 1..8 ranks of one node");
@@ -2738,6 +2774,8 @@ extern "C" int sc_peer_all_to_all(const sc_peer_exchange* d, const void* send, v
   g.my_flag = (unsigned long long*)mine;
   g.epoch = (unsigned long long*)(mine + 256);
   g.ticket = (unsigned int*)(mine + 264);
+  g.error = (unsigned int*)(mine + 272);
+  g.spin_budget = (const unsigned long long*)(mine + 280);
   g.my_win = (const sc_f4*)(mine + SC_PEER_HEADER);
   g.send = (const sc_f4*)send;
   g.recv = (sc_f4*)recv;
@@ -2793,7 +2831,7 @@ extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, c
   g.n_tiles = d->batch * g.tiles_per_sample;
   const int64_t wgs = (g.n_tiles + 3) / 4;
   // persistent: the weight tables are built once per workgroup (SC_PMLP_FWD_WGS = workgroup count, A-B)
-  static const int wgs_env = [] { const char* e = std::getenv("SC_PMLP_FWD_WGS"); return e ? std::atoi(e) : 0; }();
+  static const int wgs_env = [] { const char* e = SC_DIAG_ENV("SC_PMLP_FWD_WGS"); return e ? std::atoi(e) : 0; }();
   const int64_t resident = wgs_env > 0 ? wgs_env : 2048;     // 2048 / 768 / 512 workgroups: 0.381 / 0.407 / 0.437 ms (session 2)
   g.n_wg = (int)(wgs < resident ? wgs : resident);
   sc_stream_t st = (sc_stream_t)stream;
@@ -2836,7 +2874,7 @@ extern "C" int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* co
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
   const int64_t wgs = (g.n_tiles + 3) / 4;
-  static const int wgs_env = [] { const char* e = std::getenv("SC_PBLOCK_FWD_WGS"); return e ? std::atoi(e) : 0; }();
+  static const int wgs_env = [] { const char* e = SC_DIAG_ENV("SC_PBLOCK_FWD_WGS"); return e ? std::atoi(e) : 0; }();
   const int64_t cap = wgs_env > 0 ? wgs_env : 2048;          // persistent: the weight tables are built once per workgroup
   g.n_wg = (int)(wgs < cap ? wgs : cap);
   sc_stream_t st = (sc_stream_t)stream;
@@ -2944,7 +2982,7 @@ static int plin_shape_id(const sc_plin_desc* d) {
   return (int)(d->c_in / 32) * 10 + (int)(d->c_out / 32);
 }
 static int plin_bwd_wgs(const sc_plin_desc* d) {
-  static const int env = [] { const char* e = std::getenv("SC_PLIN_BWD_WGS"); return e ? std::atoi(e) : 0; }();   // A-B
+  static const int env = [] { const char* e = SC_DIAG_ENV("SC_PLIN_BWD_WGS"); return e ? std::atoi(e) : 0; }();   // A-B
   const int64_t cap = env > 0 ? env : 512;
   const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
   return (int)(wgs < cap ? wgs : cap);
@@ -2968,7 +3006,7 @@ extern "C" int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x
   const int64_t lds = (int64_t)(d->c_in / 32) * 16 * (d->c_out / 32) * 64 * 4 + d->c_out * 4;
   int64_t per_cu = 160 * 1024 / lds;
   per_cu = per_cu > 2 ? 2 : (per_cu < 1 ? 1 : per_cu);
-  static const int plin_wgs_env = [] { const char* e = std::getenv("SC_PLIN_FWD_WGS"); return e ? std::atoi(e) : 0; }();
+  static const int plin_wgs_env = [] { const char* e = SC_DIAG_ENV("SC_PLIN_FWD_WGS"); return e ? std::atoi(e) : 0; }();
   const int64_t resident = plin_wgs_env > 0 ? plin_wgs_env : per_cu * sc_cu_count();
   g.n_wg = (int)(wgs < resident ? wgs : resident);
   sc_stream_t st = (sc_stream_t)stream;
@@ -3028,7 +3066,7 @@ extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* 
 // matrix-core form (round 3) unless SC_TK_VALU is set (environment, A-B against the round-2 VALU kernels)
 // (also VALU where the padded, conflict-free LDS layout of the matrix-core kernels does not fit: every extent near 64)
 static bool tucker_use_mx(const sc_tucker_desc* d) {
-  static const bool valu = std::getenv("SC_TK_VALU") != nullptr;
+  static const bool valu = SC_DIAG_ENV("SC_TK_VALU") != nullptr;
   return !valu && (size_t)tkm_layout((int)d->rx, (int)d->ry, (int)d->mx, (int)d->my, true).total * sizeof(cf32) <= 150 * 1024;
 }
 static size_t tucker_lds_bytes(const sc_tucker_desc* d, bool bwd) {
@@ -3043,7 +3081,7 @@ static void tucker_invs(TuckerModesArgs& g) {
 }
 static int tucker_wgs(const sc_tucker_desc* d) {
   // workgroups of the two mode-factor kernels (each walks slices wg, wg + n, ...); SC_TK_WGS (environment, A-B)
-  static const int env = [] { const char* e = std::getenv("SC_TK_WGS"); return e ? std::atoi(e) : 0; }();
+  static const int env = [] { const char* e = SC_DIAG_ENV("SC_TK_WGS"); return e ? std::atoi(e) : 0; }();
   const int64_t cap = env > 0 ? env : 512;
   return (int)(d->fg < cap ? d->fg : cap);
 }

@@ -483,7 +483,9 @@ k_f2p_col_inv(const cf32* __restrict__ yhat, cf32* __restrict__ panel, const cf3
     // into branches around single loads, each followed by s_waitcnt vmcnt(0), and parked two entries in scratch
     // (32 bytes); a plain select of an unconditional load is sunk back under the branch, and a
     // cf32 array across the barrier still left entries 12 / 13 in memory (a 16-byte slice the vectoriser had formed).
-    const cf32* src = yhat + (live_b ? blk_in / NCB : 0) * (int64_t)K0 * J + col_in;
+    // (the column is clamped like the row: col_in can be >= J in the last, padded column block, and the last row of the
+    //  last image would then be read up to 7 entries past the end of yhat -- masked afterwards, but out of bounds)
+    const cf32* src = yhat + (live_b ? blk_in / NCB : 0) * (int64_t)K0 * J + (col_in < J ? col_in : 0);
 #pragma unroll
     for (int i = 0; i < 2 * K2; ++i) {
       int row;

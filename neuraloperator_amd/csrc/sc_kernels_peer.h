@@ -24,6 +24,8 @@ struct PeerArgs {
   unsigned long long* my_flag;  // this rank's flag array [P]
   unsigned long long* epoch;    // this rank's epoch counter (device memory)
   unsigned int* ticket;         // workgroup ticket of k_peer_put
+  unsigned int* error;          // set by k_peer_wait when its spin budget ran out (read by sc_peer_window_control)
+  const unsigned long long* spin_budget;   // ticks of the 100 MHz wall clock k_peer_wait may spin; 0 = no bound
   sc_f4* recv;                  // [P][block16]
   long long block16;            // 16-byte units per block
   int P, rank, wg_per_peer;
@@ -39,12 +41,14 @@ SC_DEVICE unsigned long long peer_flag_load(const unsigned long long* p) {
 SC_DEVICE void peer_fence_system() { __threadfence_system(); }
 SC_DEVICE unsigned int peer_ticket(unsigned int* t) { return atomicAdd(t, 1u); }
 SC_DEVICE void peer_sleep() { __builtin_amdgcn_s_sleep(8); }
+SC_DEVICE unsigned long long peer_clock() { return wall_clock64(); }      // constant 100 MHz
 #else
 inline void peer_flag_store(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline unsigned long long peer_flag_load(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 inline void peer_fence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline unsigned int peer_ticket(unsigned int* t) { return __atomic_fetch_add(t, 1u, __ATOMIC_SEQ_CST); }
 inline void peer_sleep() {}
+inline unsigned long long peer_clock() { static unsigned long long t = 0; return __atomic_add_fetch(&t, 1ull, __ATOMIC_RELAXED); }
 #endif
 
 // grid = P * wg_per_peer workgroups: workgroup (p, c) copies chunk c of block p
@@ -83,7 +87,17 @@ k_peer_wait(PeerArgs g) {
   const int tid = SC_TID;
   const unsigned long long want = *g.epoch;            // advanced by this rank's k_peer_put, earlier on this stream
   if (tid < g.P) {
-    while (peer_flag_load(g.my_flag + tid) < want) peer_sleep();
+    // bounded when the host set a budget (a dead peer or a window that is not coherent must end in an error
+    // the host can read, not in a stream that never drains): the set-up self-test runs with 2 s, steps with the
+    // budget the layer was given (default: none -- a peer that is merely late must not corrupt a step)
+    const unsigned long long budget = *g.spin_budget, t0 = peer_clock();
+    while (peer_flag_load(g.my_flag + tid) < want) {
+      peer_sleep();
+      if (budget && peer_clock() - t0 > budget) {
+        *g.error = 1u + (unsigned)tid;                 // which peer's flag never came (any of them, if several)
+        break;
+      }
+    }
   }
   peer_fence_system();
 }

@@ -114,7 +114,7 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         hi = min(lo + self.k2_loc, k2)
         if hi <= lo:                                                   # a rank that holds padding only
             return torch.zeros(self.in_channels, self.out_channels, self._n_modes[0], self.k2_loc, *self._n_modes[2:],
-                               dtype=torch.cfloat, device=self.bias.device if self.bias is not None else None)
+                               dtype=torch.cfloat, device=next(self.weight.parameters()).device)   # (bias=False: ADVICE r5)
         w = self.weight[:, :, :, lo:hi].to_tensor()
         return _pad_dim(w, 3, self.k2_loc - (hi - lo)) if hi - lo != self.k2_loc else w
 

@@ -40,3 +40,21 @@ def test_argument_checks(lib):
     with pytest.raises(RuntimeError):
         lib.peer_all_to_all(2, 0, 16, [ptr], a.data_ptr(), b.data_ptr())          # peer 1's window is not mapped
     lib.peer_window_free(ptr)
+
+
+def test_a_wait_under_a_spin_budget_ends_with_an_error_word_instead_of_hanging(lib):
+    """k_peer_wait spun without bound, so a dead peer (or a window that is not coherent) turned the set-up
+    self-test into a synchronize that never returns.  With a budget on the window (sc_peer_window_control) the wait gives
+    up and leaves 1 + the index of the peer whose flag never came; reading the word clears it.  Here: two "ranks" in one
+    emulated process, only rank 0 ever calls the exchange."""
+    w0, _ = lib.peer_window_alloc(1024)
+    w1, _ = lib.peer_window_alloc(1024)
+    assert lib.peer_window_control(w0) == 0                                         # fresh window: no error, budget unbounded
+    lib.peer_window_control(w0, 1)                                                  # 1 ms of the (emulated) clock
+    send, recv = torch.ones(2, 8), torch.zeros(2, 8)
+    lib.peer_all_to_all(2, 0, 32, [w0, w1], send.data_ptr(), recv.data_ptr())       # returns: the wait timed out on peer 1
+    assert lib.peer_window_control(w0) == 2                                         # 1 + peer 1
+    assert lib.peer_window_control(w0) == 0                                         # cleared by the read
+    assert torch.equal(recv[0], send[0])                                            # its own block did arrive
+    lib.peer_window_free(w0)
+    lib.peer_window_free(w1)

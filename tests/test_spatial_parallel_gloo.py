@@ -184,3 +184,23 @@ def test_spatial_parallel_variants(spatial, modes, fac, out_shape):
         assert p.exitcode == 0, f"worker exit code {p.exitcode}"
     for r in range(world):
         assert all(v < 1e-5 for v in ret[r].values()), (r, dict(ret[r]))
+
+
+def test_padding_only_rank_builds_its_zero_block_on_the_weight_device_without_a_bias():
+    """_local_weight() took the device of its zero block from the bias -- with bias=False the default (CPU)
+    device against a GPU spectrum.  A padding-only rank (k2_pad / P * rank >= k2) of a factorized layer, checked on the
+    `meta` device so that the CPU tier can tell the devices apart."""
+    import torch.distributed as dist
+    from neuraloperator_amd.mpu import SpatialParallelSpectralConv
+    from oracle_ops import OracleOps
+    port = _free_port()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        conv = SpatialParallelSpectralConv(3, 4, (8, 2), ops=OracleOps([2]), factorization="tucker", rank=0.6, bias=False,
+                                           group=dist.group.WORLD)
+        conv.P, conv.rank, conv.k2_pad, conv.k2_loc = 4, 3, 4, 1        # k2 = 2 over 4 ranks: rank 3 holds padding only
+        conv = conv.to("meta")
+        w = conv._local_weight()
+        assert w.device.type == "meta" and list(w.shape) == [3, 4, 8, 1]
+    finally:
+        dist.destroy_process_group()
