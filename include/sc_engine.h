@@ -398,6 +398,35 @@ int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* x, const fl
                                  const float* gx_addend, float* gx, float* gw, float* gbias, void* workspace,
                                  void* stream);
 
+/* ---- the same maps with the block's pointwise operations in their load / store paths (round 6, csrc/sc_kernels_plinx.h) ----
+ * Channel counts 32 / 64 / 128 in any combination.  A ChannelMLP whose channel counts have no one-pass kernel (hidden 128,
+ * configs[4]'s width: channel_mlp.py:82-119) is two of these passes each way, the hidden activations crossing memory once
+ * as their pre-activation; the soft-gating skip (skip_connections.py:53-130), the GELUs (fno_block.py:392-414) and their
+ * derivatives ride in the passes, so nothing elementwise is left for the caller:
+ *   forward   out = act(W xin + bias + gate (.) skip);  xin = gelu(x) with SC_PLX_XACT (x = the previous pass' pre_out);
+ *             act = gelu with SC_PLX_ACT; pre_out (optional) receives the value before act
+ *   backward  g = gout (.) gelu'(pre) with SC_PLX_PRO;  gskip = gate (.) g, ggate = sum g (.) skip when gated;
+ *             gx = (W^T g + gx_addend) (.) gelu'(xg) (addend optional; the last factor with SC_PLX_XGRAD: for an XACT pass
+ *             xg = x and gx is the gradient of the pre-activation);  gw = g xin^T;  gbias = sum g (null = not wanted).
+ *             gx == NULL: the weight / bias / gate gradients only.
+ * The backward call issues ceil(C_out / n) kernel launches (n output tiles of weight-gradient accumulators fit the
+ * register file) + fixed-order reductions; workspace sc_pointwise_linear_workspace_bytes_ex(d) bytes. */
+#define SC_PLX_XACT 1
+#define SC_PLX_ACT 2
+#define SC_PLX_PRO 4
+#define SC_PLX_XGRAD 8
+typedef struct sc_plinx_desc {
+  int64_t batch, c_in, c_out, spatial;
+  int32_t flags;
+} sc_plinx_desc;
+int sc_pointwise_linear_forward_ex(const sc_plinx_desc* d, const float* x, const float* w, const float* bias,
+                                   const float* skip, const float* gate, float* out, float* pre_out, void* stream);
+size_t sc_pointwise_linear_workspace_bytes_ex(const sc_plinx_desc* d);
+int sc_pointwise_linear_backward_ex(const sc_plinx_desc* d, const float* x, const float* w, const float* gout,
+                                    const float* pre, const float* xg, const float* skip, const float* gate,
+                                    const float* gx_addend, float* gx, float* gw, float* gbias, float* gskip,
+                                    float* ggate, void* workspace, void* stream);
+
 /* ---- fused AdamW step of the spectral weights ("next" row f2 of SURVEY.md section 8) -----------------
  * One pass over (param, grad, exp_avg, exp_avg_sq) instead of the ~10 elementwise launches of
  * neuralop/training/adamw.py:155-200 (non-GaLore branch), same arithmetic in the same order:

@@ -82,6 +82,7 @@ class Epilogue(Structure):
     _fields_ = [("skip", c_void_p), ("preact", c_void_p), ("act", c_int32), ("reserved", c_int32)]
 
 
+SC_PLX_XACT, SC_PLX_ACT, SC_PLX_PRO, SC_PLX_XGRAD = 1, 2, 4, 8     # sc_plinx_desc.flags
 SC_ACT_NONE, SC_ACT_GELU = 0, 1
 
 
@@ -100,6 +101,10 @@ class PeerExchangeDesc(Structure):
 
 class PlinDesc(Structure):
     _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("spatial", c_int64)]
+
+
+class PlinxDesc(Structure):                                 # sc_plinx_desc (round 6)
+    _fields_ = [("batch", c_int64), ("c_in", c_int64), ("c_out", c_int64), ("spatial", c_int64), ("flags", c_int32)]
 
 
 class PmlpDesc(Structure):
@@ -162,7 +167,8 @@ class ScEngineLib:
                "sc_tucker_chain_backward", "sc_tucker_chain_workspace_bytes", "sc_tucker_chain_fused_supported",
                "sc_tucker_chain_t3m_bytes", "sc_tucker_chain_forward_fused", "sc_tucker_chain_backward_fused",
                "sc_tucker_chain_backward_fused_workspace_bytes", "sc_peer_window_alloc", "sc_peer_window_open",
-               "sc_peer_window_close", "sc_peer_window_free", "sc_peer_all_to_all", "sc_peer_window_control"]
+               "sc_peer_window_close", "sc_peer_window_free", "sc_peer_all_to_all", "sc_peer_window_control", "sc_pointwise_linear_forward_ex",
+               "sc_pointwise_linear_workspace_bytes_ex", "sc_pointwise_linear_backward_ex"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -255,6 +261,12 @@ class ScEngineLib:
         L.sc_pointwise_linear_forward.restype = c_int
         L.sc_pointwise_linear_workspace_bytes.argtypes = [POINTER(PlinDesc)]
         L.sc_pointwise_linear_workspace_bytes.restype = c_size_t
+        L.sc_pointwise_linear_forward_ex.argtypes = [POINTER(PlinxDesc)] + [c_void_p] * 8
+        L.sc_pointwise_linear_forward_ex.restype = c_int
+        L.sc_pointwise_linear_workspace_bytes_ex.argtypes = [POINTER(PlinxDesc)]
+        L.sc_pointwise_linear_workspace_bytes_ex.restype = c_size_t
+        L.sc_pointwise_linear_backward_ex.argtypes = [POINTER(PlinxDesc)] + [c_void_p] * 15
+        L.sc_pointwise_linear_backward_ex.restype = c_int
         L.sc_pointwise_linear_backward.argtypes = [POINTER(PlinDesc)] + [c_void_p] * 9
         L.sc_pointwise_linear_backward.restype = c_int
         L.sc_tucker_modes_supported.argtypes = [POINTER(TuckerDesc)]
@@ -443,6 +455,20 @@ class ScEngineLib:
     def pointwise_linear_backward(self, batch, c_in, c_out, spatial, x, w, gout, gx, gw, gbias, ws, stream=0, addend=0):
         d = PlinDesc(batch, c_in, c_out, spatial)
         self._check(self.lib.sc_pointwise_linear_backward(byref(d), x, w, gout, addend, gx, gw, gbias, ws, stream))
+
+    # ---- 1 x 1 maps with the block's pointwise operations in their load / store paths (round 6; include/sc_engine.h)
+    def pointwise_linear_forward_ex(self, batch, c_in, c_out, spatial, flags, x, w, bias, skip, gate, out, pre_out=0, stream=0):
+        d = PlinxDesc(batch, c_in, c_out, spatial, flags)
+        self._check(self.lib.sc_pointwise_linear_forward_ex(byref(d), x, w, bias, skip, gate, out, pre_out, stream))
+
+    def pointwise_linear_workspace_bytes_ex(self, batch, c_in, c_out, spatial):
+        return int(self.lib.sc_pointwise_linear_workspace_bytes_ex(byref(PlinxDesc(batch, c_in, c_out, spatial, 0))))
+
+    def pointwise_linear_backward_ex(self, batch, c_in, c_out, spatial, flags, x, w, gout, pre, xg, skip, gate, addend, gx, gw,
+                                     gbias, gskip, ggate, ws, stream=0):
+        d = PlinxDesc(batch, c_in, c_out, spatial, flags)
+        self._check(self.lib.sc_pointwise_linear_backward_ex(byref(d), x, w, gout, pre, xg, skip, gate, addend, gx, gw, gbias,
+                                                             gskip, ggate, ws, stream))
 
     def tucker_modes_supported(self, fg, rx, ry, mx, my):
         return bool(self.lib.sc_tucker_modes_supported(byref(TuckerDesc(fg, rx, ry, mx, my))))

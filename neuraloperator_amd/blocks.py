@@ -109,15 +109,125 @@ class PointwiseLinearFn(torch.autograd.Function):
         return gx, gw.reshape(w_shape), gb
 
 
+_PLX_CH = (32, 64, 128)                                   # channel counts of the extended passes (sc_kernels_plinx.h)
+
+
+def _plx_ok(*cs):
+    return all(c in _PLX_CH for c in cs)
+
+
+class PointwiseLinearXFn(torch.autograd.Function):
+    """out = conv1x1(x, w, bias) for any channel counts in {32, 64, 128} (round 6: sc_pointwise_linear_forward_ex /
+    _backward_ex -- rectangular maps and the 128-channel gradient the square kernels of PointwiseLinearFn lack)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        _require_gpu(x, "x")
+        shape = x.shape
+        b, ci, co = int(shape[0]), int(shape[1]), int(w.shape[0])
+        s = x[0, 0].numel()
+        xc, wc = x.contiguous(), w.reshape(co, ci).contiguous()
+        bc = None if bias is None else bias.contiguous()
+        out = torch.empty((b, co, *shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.get_lib().pointwise_linear_forward_ex(b, ci, co, s, 0, xc.data_ptr(), wc.data_ptr(),
+                                                       0 if bc is None else bc.data_ptr(), 0, 0, out.data_ptr(), 0, _stream())
+        ctx.save_for_backward(xc, wc)
+        ctx.cfg = (b, ci, co, s, tuple(w.shape), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, wc = ctx.saved_tensors
+        b, ci, co, s, w_shape, has_bias = ctx.cfg
+        lib = _lib.get_lib()
+        gout = gout.contiguous()
+        gx, gw = torch.empty_like(xc), torch.empty_like(wc)
+        gb = torch.empty(co, dtype=torch.float32, device=xc.device) if has_bias else None
+        ws = torch.empty(lib.pointwise_linear_workspace_bytes_ex(b, ci, co, s), dtype=torch.uint8, device=xc.device)
+        with torch.cuda.device(xc.device):
+            lib.pointwise_linear_backward_ex(b, ci, co, s, 0, xc.data_ptr(), wc.data_ptr(), gout.data_ptr(), 0, 0, 0, 0, 0,
+                                             gx.data_ptr(), gw.data_ptr(), 0 if gb is None else gb.data_ptr(), 0, 0,
+                                             ws.data_ptr(), _stream())
+        return gx, gw.reshape(w_shape), gb
+
+
+class PointwiseMLP2Fn(torch.autograd.Function):
+    """The ChannelMLP pass of PointwiseMLPFn as TWO engine passes each way (round 6): channel counts without a one-pass
+    kernel -- hidden 128, configs[4]'s width.  The hidden activations cross memory once, as their pre-activation; the
+    GELUs, the soft-gating skip and their derivatives ride in the passes (csrc/sc_kernels_plinx.h):
+
+        h_pre = W1 x + b1                                  out = act(W2 gelu(h_pre) + b2 + gate (.) skip_src)
+        ghp   = (W2^T g) (.) gelu'(h_pre), g = gout (.) act'(z_pre);  gx = W1^T ghp;  weight / bias / gate gradients in the
+        same two passes."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, skip_src, gate, act):
+        _require_gpu(x, "x")
+        lib = _lib.get_lib()
+        shape = x.shape
+        b, ci = int(shape[0]), int(shape[1])
+        s = x[0, 0].numel()
+        ch, co = int(w1.shape[0]), int(w2.shape[0])
+        xc = x.contiguous()
+        w1c, w2c = w1.reshape(ch, ci).contiguous(), w2.reshape(co, ch).contiguous()
+        b1c = None if b1 is None else b1.contiguous()
+        b2c = None if b2 is None else b2.contiguous()
+        skc = None if skip_src is None else skip_src.contiguous()
+        gtc = None if gate is None else gate.reshape(co).contiguous()
+        dev = x.device
+        hpre = torch.empty((b, ch, *shape[2:]), dtype=torch.float32, device=dev)
+        out = torch.empty((b, co, *shape[2:]), dtype=torch.float32, device=dev)
+        zpre = torch.empty_like(out) if act == _lib.SC_ACT_GELU else None
+        p = lambda t: 0 if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            st = _stream()
+            lib.pointwise_linear_forward_ex(b, ci, ch, s, 0, p(xc), p(w1c), p(b1c), 0, 0, p(hpre), 0, st)
+            fl = _lib.SC_PLX_XACT | (_lib.SC_PLX_ACT if zpre is not None else 0)
+            lib.pointwise_linear_forward_ex(b, ch, co, s, fl, p(hpre), p(w2c), p(b2c), p(skc), p(gtc), p(out), p(zpre), st)
+        ctx.save_for_backward(xc, w1c, w2c, skc, gtc, hpre, zpre)
+        ctx.cfg = (b, ci, ch, co, s, tuple(w1.shape), tuple(w2.shape), None if gate is None else tuple(gate.shape),
+                   b1 is not None, b2 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, w1c, w2c, skc, gtc, hpre, zpre = ctx.saved_tensors
+        b, ci, ch, co, s, w1_shape, w2_shape, gate_shape, has_b1, has_b2 = ctx.cfg
+        lib = _lib.get_lib()
+        dev = xc.device
+        gout = gout.contiguous()
+        new = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        ghp, gx = torch.empty_like(hpre), torch.empty_like(xc)
+        gw1, gw2 = torch.empty_like(w1c), torch.empty_like(w2c)
+        gb1, gb2 = (new(ch) if has_b1 else None), (new(co) if has_b2 else None)
+        gsk = None if skc is None else torch.empty_like(skc)
+        ggt = None if gtc is None else torch.empty_like(gtc)
+        ws = torch.empty(max(lib.pointwise_linear_workspace_bytes_ex(b, ch, co, s), lib.pointwise_linear_workspace_bytes_ex(b, ci, ch, s)),
+                         dtype=torch.uint8, device=dev)
+        p = lambda t: 0 if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            st = _stream()
+            fl = _lib.SC_PLX_XACT | _lib.SC_PLX_XGRAD | (_lib.SC_PLX_PRO if zpre is not None else 0)
+            lib.pointwise_linear_backward_ex(b, ch, co, s, fl, p(hpre), p(w2c), p(gout), p(zpre), p(hpre), p(skc), p(gtc), 0,
+                                             p(ghp), p(gw2), p(gb2), p(gsk), p(ggt), p(ws), st)
+            lib.pointwise_linear_backward_ex(b, ci, ch, s, 0, p(xc), p(w1c), p(ghp), 0, 0, 0, 0, 0, p(gx), p(gw1), p(gb1), 0, 0,
+                                             p(ws), st)
+        return (gx, gw1.reshape(w1_shape), gb1, gw2.reshape(w2_shape), gb2, gsk,
+                None if ggt is None else ggt.reshape(gate_shape), None)
+
+
 def fused_linear(x, w, bias=None):
-    """1 x 1 convolution over the channels: the engine pass for 32 / 64 (with gradients) or 32 / 64 / 128 (inference)
-    equal input / output channels and a pixel count that is a multiple of 32, ``F.conv1d`` otherwise."""
+    """1 x 1 convolution over the channels on the engine for 32 / 64 / 128 input and output channels (any pair, with
+    gradients: round 6) and a pixel count that is a multiple of 32, ``F.conv1d`` otherwise."""
     ci, co = int(x.shape[1]), int(w.shape[0])
     s = x[0, 0].numel()
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, bias))
     ok = (32, 64) if needs_grad else (32, 64, 128)
     if _on_engine(x) and x.dtype == torch.float32 and ci == co and ci in ok and s % 32 == 0:
         return PointwiseLinearFn.apply(x, w, bias)
+    if _on_engine(x) and x.dtype == torch.float32 and _plx_ok(ci, co) and s % 32 == 0:       # round 6: any pair of 32 / 64 / 128
+        return PointwiseLinearXFn.apply(x, w, bias)
     shape = x.shape
     return F.conv1d(x.reshape(shape[0], ci, -1), w.reshape(co, ci, 1), bias).reshape(shape[0], co, *shape[2:])
 
@@ -133,8 +243,9 @@ def _on_engine(t):
 def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=None):
     """``act(conv1x1(gelu(conv1x1(x, w1, b1)), w2, b2) + gate * skip_src)``: w1 / w2 are Conv1d weights
     (out, in[, 1]); gate a per-channel weight of any broadcastable shape with ``out`` elements; activation None or
-    "gelu".  One engine pass when the channel counts have a kernel and the pixel count is a multiple of 32, the plain
-    composition of the same operations otherwise."""
+    "gelu".  One engine pass when the channel counts have a one-pass kernel and the pixel count is a multiple of 32, two
+    engine passes each way for any other channel counts in {32, 64, 128} (round 6), the plain composition of the same
+    operations otherwise."""
     ci, ch, co = int(x.shape[1]), int(w1.shape[0]), int(w2.shape[0])
     s = x[0, 0].numel()
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
@@ -144,6 +255,10 @@ def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=No
     if fits:
         act = _lib.SC_ACT_GELU if activation == "gelu" else _lib.SC_ACT_NONE
         return PointwiseMLPFn.apply(x, w1, b1, w2, b2, skip_src, gate, act)
+    if _on_engine(x) and x.dtype == torch.float32 and s % 32 == 0 and (skip_src is None) == (gate is None) and \
+            _plx_ok(ci, ch, co):                         # round 6: two engine passes each way (hidden 128, 128 channels)
+        act = _lib.SC_ACT_GELU if activation == "gelu" else _lib.SC_ACT_NONE
+        return PointwiseMLP2Fn.apply(x, w1, b1, w2, b2, skip_src, gate, act)
     shape = x.shape
     h = F.gelu(F.conv1d(x.reshape(shape[0], ci, -1), w1.reshape(ch, ci, 1), b1))
     z = F.conv1d(h, w2.reshape(co, ch, 1), b2).reshape(shape[0], co, *shape[2:])
@@ -195,7 +310,22 @@ class FusedBlockFn(torch.autograd.Function):
             pre = None if last else torch.empty_like(x)
             xhat = torch.empty((b, c, *kept, 2), dtype=torch.float32, device=dev)
             out = torch.empty_like(x)
-            if (c, ch) in _PBLOCK_SHAPES and not _NO_PBLOCK:
+            hpre = zpre = None
+            if (c, ch, c) not in _SHAPES_BWD:
+                # round 6: channel counts without a one-pass kernel (hidden 128, 128 channels): the same block as engine
+                # passes of csrc/sc_kernels_plinx.h -- skip, Fourier layer with the add + GELU in its store path, fc1, fc2
+                # with the GELUs and the soft-gating skip in their load / store paths; nothing elementwise in between
+                skip = torch.empty_like(x)
+                lib.pointwise_linear_forward_ex(b, c, c, s, 0, p(x), p(lwc), p(lbc), 0, 0, p(skip), 0, st)
+                lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), p(skip), p(pre), act, p(y),
+                                     p(xhat), p(ws), st)
+                del skip
+                hpre = torch.empty((b, ch, *spatial), dtype=torch.float32, device=dev)
+                zpre = None if last else torch.empty_like(x)
+                lib.pointwise_linear_forward_ex(b, c, ch, s, 0, p(y), p(w1c), p(b1c), 0, 0, p(hpre), 0, st)
+                lib.pointwise_linear_forward_ex(b, ch, c, s, _lib.SC_PLX_XACT | (0 if last else _lib.SC_PLX_ACT), p(hpre), p(w2c),
+                                                p(b2c), p(x), p(gtc), p(out), p(zpre), st)
+            elif (c, ch) in _PBLOCK_SHAPES and not _NO_PBLOCK:
                 # session 2: a plain inverse transform, then ONE pointwise pass for skip + add + GELU + MLP + gate (the
                 # skip is never written, y is not read back: 1 + 5 tensor-sized passes instead of 8); y and pre are
                 # the same tensors as before, so the backward below does not change
@@ -210,7 +340,7 @@ class FusedBlockFn(torch.autograd.Function):
                 lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), p(skip), p(pre), act, p(y),
                                      p(xhat), p(ws), st)
                 lib.pointwise_mlp_forward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(out), st)
-        ctx.save_for_backward(x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc)
+        ctx.save_for_backward(x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc, hpre, zpre)
         ctx.cfg = (plan, L, b, c, ch, s, act, tuple(cw.shape), None if cb is None else tuple(cb.shape), tuple(lw.shape),
                    lb is not None, tuple(w1.shape), tuple(w2.shape), tuple(gate.shape))
         return out
@@ -218,7 +348,7 @@ class FusedBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         from . import engine
-        x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc = ctx.saved_tensors
+        x, y, pre, xhat, cwc, lwc, w1c, b1c, w2c, b2c, gtc, hpre, zpre = ctx.saved_tensors
         plan, L, b, c, ch, s, act, cw_shape, cb_shape, lw_shape, has_lb, w1_shape, w2_shape, gate_shape = ctx.cfg
         lib = _lib.get_lib()
         dev = x.device
@@ -232,16 +362,33 @@ class FusedBlockFn(torch.autograd.Function):
             gb1 = None if b1c is None else torch.empty_like(b1c)
             gb2 = None if b2c is None else torch.empty_like(b2c)
             ggt = torch.empty_like(gtc)
-            ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, c, ch, c, s, act), dtype=torch.uint8, device=dev)
-            # (with the Fourier layer's pre-activation the pass returns the gradient THROUGH its GELU: gy is gz)
-            lib.pointwise_mlp_backward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(gout), p(gy),
-                                       p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(ws), st, x_pre=p(pre))
-            gz = gy
-            # linear skip: W^T gz + acc
             acc2, glw = torch.empty_like(x), torch.empty_like(lwc)
             glb = torch.empty(c, dtype=torch.float32, device=dev) if has_lb else None
-            ws2 = torch.empty(lib.pointwise_linear_workspace_bytes(b, c, c, s), dtype=torch.uint8, device=dev)
-            lib.pointwise_linear_backward(b, c, c, s, p(x), p(lwc), p(gz), p(acc2), p(glw), p(glb), p(ws2), st, addend=p(acc))
+            if hpre is not None:
+                # round 6, the two-pass form: fc2 (gradient through the closing GELU, the soft-gating branch -> acc, ghp =
+                # the gradient of the hidden PRE-activation), fc1 (gz = the gradient through the Fourier layer's GELU),
+                # the linear skip with acc as its addend -- three calls of sc_pointwise_linear_backward_ex
+                ghp = torch.empty_like(hpre)
+                wsx = torch.empty(max(lib.pointwise_linear_workspace_bytes_ex(b, ch, c, s),
+                                      lib.pointwise_linear_workspace_bytes_ex(b, c, ch, s),
+                                      lib.pointwise_linear_workspace_bytes_ex(b, c, c, s)), dtype=torch.uint8, device=dev)
+                fl2 = _lib.SC_PLX_XACT | _lib.SC_PLX_XGRAD | (_lib.SC_PLX_PRO if zpre is not None else 0)
+                lib.pointwise_linear_backward_ex(b, ch, c, s, fl2, p(hpre), p(w2c), p(gout), p(zpre), p(hpre), p(x), p(gtc), 0,
+                                                 p(ghp), p(gw2), p(gb2), p(acc), p(ggt), p(wsx), st)
+                lib.pointwise_linear_backward_ex(b, c, ch, s, _lib.SC_PLX_XGRAD if pre is not None else 0, p(y), p(w1c), p(ghp),
+                                                 0, p(pre), 0, 0, 0, p(gy), p(gw1), p(gb1), 0, 0, p(wsx), st)
+                gz = gy
+                lib.pointwise_linear_backward_ex(b, c, c, s, 0, p(x), p(lwc), p(gz), 0, 0, 0, 0, p(acc), p(acc2), p(glw), p(glb),
+                                                 0, 0, p(wsx), st)
+            else:
+                ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, c, ch, c, s, act), dtype=torch.uint8, device=dev)
+                # (with the Fourier layer's pre-activation the pass returns the gradient THROUGH its GELU: gy is gz)
+                lib.pointwise_mlp_backward(b, c, ch, c, s, act, p(y), p(w1c), p(b1c), p(w2c), p(b2c), p(x), p(gtc), p(gout),
+                                           p(gy), p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(ws), st, x_pre=p(pre))
+                gz = gy
+                # linear skip: W^T gz + acc
+                ws2 = torch.empty(lib.pointwise_linear_workspace_bytes(b, c, c, s), dtype=torch.uint8, device=dev)
+                lib.pointwise_linear_backward(b, c, c, s, p(x), p(lwc), p(gz), p(acc2), p(glw), p(glb), p(ws2), st, addend=p(acc))
             # spectral convolution: its input gradient + acc2 in the store path of the last transform
             gx = torch.empty_like(x)
             full = all(L.w_start[d] == 0 for d in range(len(cw_shape) - 2)) and tuple(xhat.shape[2:-1]) == tuple(cw_shape[2:])
@@ -336,7 +483,7 @@ def fused_block_forward(blocks, x, index=0, output_shape=None):
     c, ch = int(x.shape[1]), int(fc1.weight.shape[0])
     from .factorized import DenseWeight
     one_node = _on_engine(x) and x.dtype == torch.float32 and x[0, 0].numel() % 32 == 0 and \
-        (c, ch, c) in _SHAPES_BWD and c in (32, 64) and int(lin.weight.shape[0]) == c and \
+        (((c, ch, c) in _SHAPES_BWD and c in (32, 64)) or _plx_ok(c, ch)) and int(lin.weight.shape[0]) == c and \
         isinstance(conv.weight, DenseWeight) and not conv.separable and conv.fno_block_precision == "full" and \
         conv.in_channels == conv.out_channels == c
     if one_node:

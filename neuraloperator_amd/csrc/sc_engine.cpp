@@ -36,6 +36,7 @@
 #include "sc_kernels_plane.h"
 #include "sc_kernels_plane64.h"
 #include "sc_kernels_pmlp.h"
+#include "sc_kernels_plinx.h"
 #include "sc_kernels_tucker.h"
 #include "sc_kernels_sb.h"
 #include "sc_kernels_fmx.h"
@@ -3060,6 +3061,123 @@ extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* 
     default: return sc_fail("sc_engine: pointwise linear map backward: c_in = c_out must be 32 or 64");
   }
   return sc_check_launch("k_plin_bwd");
+}
+
+// ---- 1 x 1 linear maps with the block's pointwise operations in their load / store paths (sc_kernels_plinx.h, round 6):
+//      any channel counts in {32, 64, 128}, the two-pass form of a ChannelMLP whose channel counts have no one-pass kernel
+static int plinx_ok(const sc_plinx_desc* d) {
+  auto okc = [](int64_t c) { return c == 32 || c == 64 || c == 128; };
+  return d && okc(d->c_in) && okc(d->c_out);
+}
+static int plinx_bwd_wgs(const sc_plinx_desc* d) {
+  const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
+  const int64_t cap = sc_cu_count();                       // one workgroup per compute unit (launch bound)
+  return (int)(wgs < cap ? wgs : cap);
+}
+static int plinx_omn(int ci, int co) { const int cap = 8 / ci; return co < cap ? co : cap; }   // accumulator tiles <= 8
+
+template <int CI, int CO>
+static void launch_plinx_fwd(const PlinxArgs& g, sc_stream_t st) {
+  SC_LAUNCH((k_plinx_fwd<CI, CO>), dim3((unsigned)g.n_wg), dim3(256), 0, st, g);
+}
+
+extern "C" int sc_pointwise_linear_forward_ex(const sc_plinx_desc* d, const float* x, const float* w, const float* bias,
+                                              const float* skip, const float* gate, float* out, float* pre_out,
+                                              void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  if (d->batch <= 0 || d->spatial <= 0) return 0;
+  SC_CHECK_ARG(x && w && out, "null argument");
+  SC_CHECK_ARG(plinx_ok(d), "pointwise linear map: channel counts must be 32, 64 or 128");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG((skip == nullptr) == (gate == nullptr), "skip and gate come together");
+  SC_CHECK_ARG((d->flags & ~(SC_PLX_XACT | SC_PLX_ACT)) == 0, "forward flags: SC_PLX_XACT | SC_PLX_ACT");
+  PlinxArgs g;
+  std::memset((void*)&g, 0, sizeof(g));
+  g.x = x; g.w = w; g.bias = bias; g.skip = skip; g.gate = gate; g.out = out; g.pre_out = pre_out; g.flags = d->flags;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  const int ci = (int)(d->c_in / 32), co = (int)(d->c_out / 32);
+  const int64_t wgs = (g.n_tiles + 3) / 4, resident = (int64_t)(ci * co > 8 ? 1 : 2) * sc_cu_count();
+  g.n_wg = (int)(wgs < resident ? wgs : resident);
+  sc_stream_t st = (sc_stream_t)stream;
+  switch (ci * 10 + co) {
+    case 11: launch_plinx_fwd<1, 1>(g, st); break;
+    case 12: launch_plinx_fwd<1, 2>(g, st); break;
+    case 14: launch_plinx_fwd<1, 4>(g, st); break;
+    case 21: launch_plinx_fwd<2, 1>(g, st); break;
+    case 22: launch_plinx_fwd<2, 2>(g, st); break;
+    case 24: launch_plinx_fwd<2, 4>(g, st); break;
+    case 41: launch_plinx_fwd<4, 1>(g, st); break;
+    case 42: launch_plinx_fwd<4, 2>(g, st); break;
+    default: launch_plinx_fwd<4, 4>(g, st); break;
+  }
+  return sc_check_launch("k_plinx_fwd");
+}
+
+extern "C" size_t sc_pointwise_linear_workspace_bytes_ex(const sc_plinx_desc* d) {
+  if (!plinx_ok(d) || d->batch <= 0 || d->spatial <= 0) return 0;
+  const int omn = plinx_omn((int)(d->c_in / 32), (int)(d->c_out / 32));
+  const size_t np = (size_t)omn * 32 * d->c_in + 2 * (size_t)omn * 32;
+  return (size_t)(plinx_bwd_wgs(d) + SC_PMLP_RED_GROUPS) * np * sizeof(float) + 256;
+}
+
+template <int CI, int CO, int OMN>
+static void launch_plinx_bwd(PlinxArgs g, float* ws, bool want_gx, float* gw, float* gb, float* ggate, sc_stream_t st) {
+  typedef PlinxDims<CI, OMN> D;
+  g.partial = ws;
+  float* stage = ws + (size_t)g.n_wg * D::NP;
+  const unsigned nb = (unsigned)((D::NP + 255) / 256);
+  const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
+  for (int om0 = 0; om0 < CO; om0 += OMN) {                 // (stream-ordered: the launches share the partial buffer)
+    g.do_gx = (want_gx && om0 == 0) ? 1 : 0;
+    SC_LAUNCH((k_plinx_bwd<CI, CO, OMN>), dim3((unsigned)g.n_wg), dim3(256), 0, st, g, om0);
+    SC_LAUNCH(k_pmlp_reduce1, dim3(nb, (unsigned)groups), dim3(256), 0, st, (const float*)g.partial, g.n_wg, groups, (int)D::NP,
+              stage);
+    SC_LAUNCH(k_plinx_reduce, dim3(nb), dim3(256), 0, st, (const float*)stage, groups, (int)D::NP, (int)D::oB, (int)D::oG,
+              (int)D::C_IN, 32 * om0, gw, gb, ggate);
+  }
+}
+
+extern "C" int sc_pointwise_linear_backward_ex(const sc_plinx_desc* d, const float* x, const float* w, const float* gout,
+                                               const float* pre, const float* xg, const float* skip, const float* gate,
+                                               const float* gx_addend, float* gx, float* gw, float* gbias, float* gskip,
+                                               float* ggate, void* workspace, void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise linear map backward: empty input");
+  SC_CHECK_ARG(x && w && gout && gw && workspace, "null argument");
+  SC_CHECK_ARG(plinx_ok(d), "pointwise linear map: channel counts must be 32, 64 or 128");
+  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG((skip == nullptr) == (gate == nullptr), "skip and gate come together");
+  SC_CHECK_ARG(!gate || ggate, "a gated forward needs ggate");
+  SC_CHECK_ARG(!gate || !gx || gskip, "a gated forward needs gskip beside gx");
+  SC_CHECK_ARG((d->flags & ~(SC_PLX_XACT | SC_PLX_PRO | SC_PLX_XGRAD)) == 0, "backward flags: SC_PLX_XACT | SC_PLX_PRO | SC_PLX_XGRAD");
+  SC_CHECK_ARG(!(d->flags & SC_PLX_PRO) || pre, "SC_PLX_PRO needs the pre-activation");
+  SC_CHECK_ARG(!(d->flags & SC_PLX_XGRAD) || xg, "SC_PLX_XGRAD needs xg");
+  SC_CHECK_ARG(gx || !gx_addend, "an addend without gx");
+  PlinxArgs g;
+  std::memset((void*)&g, 0, sizeof(g));
+  g.x = x; g.w = w; g.gout = gout; g.pre = pre; g.xg = xg; g.skip = skip; g.gate = gate; g.addend = gx_addend;
+  g.out = gx; g.gskip = gskip; g.flags = d->flags;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  g.n_wg = plinx_bwd_wgs(d);
+  sc_stream_t st = (sc_stream_t)stream;
+  float* ws = (float*)workspace;
+  const bool want_gx = gx != nullptr;
+  switch ((int)(d->c_in / 32) * 10 + (int)(d->c_out / 32)) {
+    case 11: launch_plinx_bwd<1, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 12: launch_plinx_bwd<1, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 14: launch_plinx_bwd<1, 4, 4>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 21: launch_plinx_bwd<2, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 22: launch_plinx_bwd<2, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 24: launch_plinx_bwd<2, 4, 4>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 41: launch_plinx_bwd<4, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 42: launch_plinx_bwd<4, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    default: launch_plinx_bwd<4, 4, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
+  }
+  return sc_check_launch("k_plinx_bwd");
 }
 
 // ---- Tucker mode factors (sc_kernels_tucker.h)

@@ -348,6 +348,8 @@ struct PmlpBwdArgs {
   const float* w2;
   const float* x_pre;      // optional: x = gelu(x_pre) was produced by the previous fused pass; gx is then the gradient
                            // with respect to x_pre (the gelu backward of the Fourier layer folded into this store path)
+  const float* lw;         // LIN kernels (round 6): the block's linear skip W_s (C, C); `gskip` then receives
+                           // W_s^T gx + gate (.) gz -- the whole gradient of the block input outside the spectral convolution
   float* gx;
   float* gskip;
   float* partial;          // [n_wg][NP]
@@ -355,16 +357,27 @@ struct PmlpBwdArgs {
   int tiles_per_sample, n_wg;
 };
 
-template <int CI, int CH, int CO, bool GATE, int ACT, int NW>
+// LIN (round 6, the fused block backward): the data path of the block's 1 x 1 linear skip rides along -- the gradient of the
+// Fourier layer's pre-activation (this kernel's gx with x_pre) is the B operand of one more product, W_s^T gx, accumulated
+// on top of the soft-gating branch's gate (.) gz: `gskip` leaves as the complete gradient of the block input outside the
+// spectral convolution (the addend of sc_layer_backward_ex) instead of crossing HBM three more times
+// (k_pmlp_bwd writes it, k_plin_bwd reads it and gx and writes the sum: 10 tensor passes -> 5 + the 2 of k_plin_bwd<.., false>,
+// which is left with the skip's weight gradient).
+template <int CI, int CH, int CO, bool GATE, int ACT, int NW, bool LIN = false>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(64 * NW, 1)
 k_pmlp_bwd(PmlpBwdArgs g) {
   typedef PmlpDims<CI, CH, CO> D;
   constexpr int S1 = D::S1, TS = 32 * 33, NT = 64 * NW;
-  static_assert((D::nTab + NW * (1 + CH) * TS + D::NP + D::C_HID + 2 * D::C_OUT) * 4 <= 160 * 1024, "LDS budget");
+  constexpr int nA5 = LIN ? CI * CO * 16 * 64 : 0;
+  // one wave per SIMD (NW = 4) hides memory latency by requesting the next output tile's rows / the x rows of phase E a
+  // phase ahead (48 registers); with two waves per SIMD (NW = 8, round 6) the other wave covers it and the registers go
+  constexpr bool PF = NW <= 4;
+  static_assert(!LIN || (CI == CO && GATE), "LIN: the block's shape (gated skip of the block input, C -> hidden -> C)");
+  static_assert((D::nTab + nA5 + NW * (1 + CH) * TS + D::NP + D::C_HID + 2 * D::C_OUT) * 4 <= 160 * 1024, "LDS budget");
   // one workgroup of NW (8, or 4 for the larger tables) waves per CU: the four operand tables (W1, W2, W2^T, W1^T in MFMA lane order) live in LDS once
   // for all of them (read from the workspace they cost an L2 round trip per group of MFMAs: 1.7 ms per launch at the
   // metric shape, profiles/r02_block_kernel_stats_v1.txt)
-  SC_SHARED float tabs[D::nTab];
+  SC_SHARED float tabs[D::nTab + nA5];
   SC_SHARED float scr[NW * (1 + CH) * TS];                // per wave: T_A and one T_B per hidden tile (h)
   SC_SHARED float red[D::NP];
   SC_SHARED float B1[D::C_HID], B2[D::C_OUT], GT[D::C_OUT];
@@ -376,6 +389,11 @@ k_pmlp_bwd(PmlpBwdArgs g) {
   const float* A2 = tabs + D::oA2;
   const float* A3 = tabs + D::oA3;
   const float* A4 = tabs + D::oA4;
+  const float* A5 = tabs + D::nTab;                       // LIN: W_s^T, K in accumulator row order (k_plin_bwd's AT)
+  for (int i = tid; i < nA5; i += NT) {
+    const int l = i & 63, v = (i >> 6) & 15, om = (i >> 10) % CO, ci = (i >> 10) / CO;
+    tabs[D::nTab + i] = g.lw[(32 * om + pmlp_row(v, l >> 5)) * D::C_IN + 32 * ci + (l & 31)];
+  }
   for (int i = tid; i < D::nTab; i += NT) {
     const int l = i & 63, m = l & 31, kk = l >> 5;
     float val;
@@ -446,11 +464,13 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       // software pipeline over the tile: the gout / skip rows of output tile om + 1 are requested before tile om is
       // worked on (tile 0 here, next to x), the x rows of phase E before phase D -- one exposed memory latency per
       // pixel tile instead of one per phase
+      if (PF) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int64_t ro = (int64_t)pmlp_row(v, 0) * sp + lo_c;
-        gzn[v] = SC_LOAD_STREAM(gs + ro);
-        skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+        for (int v = 0; v < 16; ++v) {
+          const int64_t ro = (int64_t)pmlp_row(v, 0) * sp + lo_c;
+          gzn[v] = SC_LOAD_STREAM(gs + ro);
+          skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+        }
       }
       SC_SCHED_BARRIER();
 #pragma unroll
@@ -474,6 +494,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       }
     }
     // ---- B: one output tile at a time: gz, gskip, ggate / gb2 sums, gW2 += gz h^T, gh += W2^T gz
+    sc_f32x16 a2[LIN ? CO : 1];                            // LIN: gate (.) gz now, + W_s^T gx in phase D
     sc_f32x16 gh[CH];
 #pragma unroll
     for (int hm = 0; hm < CH; ++hm)
@@ -483,17 +504,26 @@ k_pmlp_bwd(PmlpBwdArgs g) {
     for (int om = 0; om < CO; ++om) {
       const int ln2 = sc_opaque(lane), hq2 = sc_opaque(half);
       float gz[16], sk[16];
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        gz[v] = gzn[v];
-        sk[v] = skn[v];
-      }
-      if (om + 1 < CO) {
+      if (PF) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int64_t ro = (int64_t)(32 * (om + 1) + pmlp_row(v, 0)) * sp + lo_c;
-          gzn[v] = SC_LOAD_STREAM(gs + ro);
-          skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+          gz[v] = gzn[v];
+          sk[v] = skn[v];
+        }
+        if (om + 1 < CO) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int64_t ro = (int64_t)(32 * (om + 1) + pmlp_row(v, 0)) * sp + lo_c;
+            gzn[v] = SC_LOAD_STREAM(gs + ro);
+            skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
+          gz[v] = SC_LOAD_STREAM(gs + ro);
+          sk[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
         }
       }
       SC_SCHED_BARRIER();
@@ -506,7 +536,9 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
           for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
-            for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(acc, A2[((om * CH + hm) * 16 + v) * 64 + ln2], h[hm][v]);
+            for (int v = v0; v < v0 + 8; ++v)             // (two waves per SIMD: h comes back from the wave's own LDS copy)
+              PMLP_MFMA(acc, A2[((om * CH + hm) * 16 + v) * 64 + ln2],
+                        PF ? h[hm][v] : TH[hm * TS + pmlp_row(v, hq2) * 33 + sc_opaque(n)]);
             SC_SCHED_BARRIER();
           }
 #pragma unroll
@@ -521,7 +553,8 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const int r = 32 * om + pmlp_row(v, hq2);
-          PMLP_STORE(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[r] * gz[v]);
+          if (LIN) a2[LIN ? om : 0][v] = GT[r] * gz[v];
+          else PMLP_STORE(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[r] * gz[v]);
           TA[pmlp_row(v, half) * 33 + n] = gz[v] * sk[v];
         }
         SC_WAVE_SYNC();
@@ -563,7 +596,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       for (int v = 0; v < 16; ++v) ghp[hm][v] = gh[hm][v] * PMLP_GELU_GRAD(hp[hm][v]);
     SC_SCHED_BARRIER();
     float xe[16];
-    {
+    if (PF) {
       const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);     // a second read of x (L2), not phase A's values kept alive
 #pragma unroll
       for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(2 * t) * sp + lo_e];
@@ -598,6 +631,26 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) PMLP_STORE(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
       SC_SCHED_BARRIER();
+      if (LIN) {                                           // W_s^T gx: this gx tile is the B operand for every input tile
+        const int ln5 = sc_opaque(lane);
+#pragma unroll
+        for (int cip = 0; cip < CI; ++cip)
+#pragma unroll
+          for (int v0 = 0; v0 < 16; v0 += 8) {
+#pragma unroll
+            for (int v = v0; v < v0 + 8; ++v)
+              PMLP_MFMA(a2[LIN ? cip : 0], A5[((cip * CO + ci) * 16 + v) * 64 + ln5], acc[v]);
+            SC_SCHED_BARRIER();
+          }
+      }
+    }
+    if (LIN) {
+#pragma unroll
+      for (int cip = 0; cip < CI; ++cip) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) PMLP_STORE(gks + (int64_t)(32 * cip + pmlp_row(v, 0)) * sp + lo_c, a2[LIN ? cip : 0][v]);
+        SC_SCHED_BARRIER();
+      }
     }
     // ---- E: gW1 += ghp x^T over the pixels: ghp transposed in T_A, the x tile (re-read: L2 resident) in the first
     //         T_H buffer as X[c][px]
@@ -607,10 +660,15 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       for (int v = 0; v < 16; ++v) TA[pmlp_row(v, half) * 33 + n] = ghp[hm][v];
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
+        if (!PF) {
+          const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(32 * ci + 2 * t) * sp + lo_e];
+        }
         SC_WAVE_SYNC();                                    // readers of the previous X tile (and of h, first round)
 #pragma unroll
         for (int t = 0; t < 16; ++t) TH[(2 * t + half) * 33 + n] = xe[t];
-        if (ci + 1 < CI || hm + 1 < CH) {                  // next x rows while this tile's products run
+        if (PF && (ci + 1 < CI || hm + 1 < CH)) {          // next x rows while this tile's products run
           const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);
           const int cn = (ci + 1 < CI) ? ci + 1 : 0;
 #pragma unroll

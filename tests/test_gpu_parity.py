@@ -1344,6 +1344,86 @@ def test_fused_block_forward_matches_op_sequence(pre):
                 assert rel_l2(a.numpy(), b.numpy()) < 2e-5, n
 
 
+@pytest.mark.parametrize("hidden,expansion", [(128, 0.5), (128, 1.0), (64, 2.0)], ids=["128-64-128", "128-128-128", "64-128-64"])
+def test_fused_block_hidden_128_matches_the_oracle(hidden, expansion):
+    """a configs[4]-width block (128 channels; also hidden 128) as ONE autograd node on the two-pass engine
+    form (csrc/sc_kernels_plinx.h) against the reference's op sequence evaluated by the CPU oracle -- output, input gradient
+    and every parameter gradient, first and last block.  (The unfused op sequence is not run on the GPU here: F.conv1d's
+    fp32 backward at 128 channels lands on MIOpen's naive kernels, 338 ms per call -- profiles/r06_block128_before.txt.)"""
+    from block_standin import Blocks
+    from neuraloperator_amd import blocks as nb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    blk = Blocks(hidden, (12, 12), expansion=expansion).to(dev)
+    with torch.no_grad():
+        for q in blk.parameters():
+            if q.is_complex():
+                q.mul_(4.0)
+        for i in (0, 1):
+            blk.channel_mlp_skips[i].weight.copy_(torch.randn_like(blk.channel_mlp_skips[i].weight))
+    x = torch.randn(2, hidden, 32, 48, device=dev)
+    g = torch.randn(2, hidden, 32, 48, device=dev)
+    for index in (0, 1):
+        nodes = []
+        orig = nb.FusedBlockFn.apply
+        nb.FusedBlockFn.apply = staticmethod(lambda *a: (nodes.append(1), orig(*a))[1])
+        try:
+            blk.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            y = nb.fused_block_forward(blk, xi, index)
+            y.backward(g)
+        finally:
+            nb.FusedBlockFn.apply = orig
+        assert nodes == [1]
+        gp1 = {n: q.grad.clone() for n, q in blk.named_parameters() if q.grad is not None}
+        yo, gxo, gpo = _block_oracle(blk, x, g, index)
+        assert rel_l2(y.detach().cpu().numpy(), yo.numpy()) < TOL and rel_l2(xi.grad.cpu().numpy(), gxo.numpy()) < TOL
+        assert set(gpo) == set(gp1)
+        for n in gpo:
+            a, b = gp1[n].cpu(), gpo[n]
+            a, b = (torch.view_as_real(a), torch.view_as_real(b)) if a.is_complex() else (a, b)
+            assert rel_l2(a.numpy(), b.numpy()) < 2e-5, n
+
+
+@pytest.mark.parametrize("ci,ch,co", [(128, 64, 128), (128, 128, 128), (32, 128, 64)], ids=str)
+def test_two_pass_channel_mlp_and_rectangular_linear_maps(ci, ch, co):
+    """blocks.fused_channel_mlp on channel counts without a one-pass kernel (PointwiseMLP2Fn: two engine passes each way)
+    and blocks.fused_linear on a rectangular map (PointwiseLinearXFn) against torch autograd in float64."""
+    import torch.nn.functional as F
+    from neuraloperator_amd import blocks as nb
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(ci + ch)
+    B, H, W = 3, 24, 40
+    x, skip, go = torch.randn(B, ci, H, W, generator=g), torch.randn(B, co, H, W, generator=g), torch.randn(B, co, H, W, generator=g)
+    w1, b1 = torch.randn(ch, ci, 1, generator=g) / ci ** 0.5, torch.randn(ch, generator=g)
+    w2, b2 = torch.randn(co, ch, 1, generator=g) / ch ** 0.5, torch.randn(co, generator=g)
+    gate = torch.randn(1, co, 1, 1, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2, skip, gate)]
+    xd, w1d, b1d, w2d, b2d, sd, gd = leaves
+    h = F.gelu(F.conv1d(xd.reshape(B, ci, -1), w1d, b1d))
+    ref = F.gelu(F.conv1d(h, w2d, b2d).reshape(B, co, H, W) + gd * sd)
+    ref.backward(go.double())
+    dl = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2, skip, gate)]
+    seen = []
+    orig = nb.PointwiseMLP2Fn.apply
+    nb.PointwiseMLP2Fn.apply = staticmethod(lambda *a: (seen.append(1), orig(*a))[1])
+    try:
+        out = nb.fused_channel_mlp(dl[0], dl[1], dl[2], dl[3], dl[4], skip_src=dl[5], gate=dl[6], activation="gelu")
+    finally:
+        nb.PointwiseMLP2Fn.apply = orig
+    assert seen == [1]
+    out.backward(go.to(dev))
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+    for a, b in zip(dl, leaves):
+        assert rel_l2(a.grad.cpu().numpy(), b.grad.numpy()) < TOL
+    # rectangular 1 x 1 map
+    xl, wl, bl = (t.to(dev).requires_grad_(True) for t in (x, w1, b1))
+    o2 = nb.fused_linear(xl, wl, bl)
+    r2 = F.conv1d(x.double().reshape(B, ci, -1), w1.double(), b1.double()).reshape(B, ch, H, W)
+    assert o2.grad_fn is not None and "PointwiseLinear" in type(o2.grad_fn).__name__
+    assert rel_l2(o2.detach().cpu().numpy(), r2.numpy()) < TOL
+
+
 @pytest.mark.parametrize("c", [32, 64])
 def test_pointwise_linear_pass(c):
     """The block's 1 x 1 linear skip (k_plin_fwd / k_plin_bwd) through blocks.fused_linear against torch float64."""
