@@ -46,9 +46,9 @@ class GraphedStep:
                     post()
         torch.cuda.current_stream(x.device).wait_stream(side)
         self._clear()
-        _quiesce_process_groups()
+        mode = _quiesce_process_groups()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.output = module(x)
             self.output.backward(grad_out)
             if post is not None:
@@ -81,20 +81,29 @@ class GraphedStep:
 
 
 def _quiesce_process_groups():
-    """Before a capture in a process that has used torch.distributed on the device: drain the GPU and give the process
-    group's watchdog thread time to retire the collectives it still tracks.  Its event queries on work that finished
-    moments ago race with the start of a (global-mode) capture and abort the process -- seen as one probe child in a few
-    dying with SIGABRT 2.5 s after start (round 5).  SC_GRAPH_QUIESCE_MS overrides the 800 ms."""
+    """Before a capture in a process that has used torch.distributed on the device; returns the capture error mode.
+
+    What raced in round 5: ProcessGroupNCCL's watchdog THREAD polls the events of the collectives it
+    still tracks (hipEventQuery); under the default *global* capture mode an event query from ANY thread of the process
+    while a stream is capturing is an error, the watchdog turns it into an abort -- one probe child in a few died with
+    SIGABRT out of Watchdog::run().  Round 5 slept 0.8 s so that the watchdog had retired its work before the capture
+    began: a heuristic.  Round 6: the capture runs in *thread_local* mode -- only the capturing thread's own calls are
+    checked, the watchdog's queries are legal whenever they come -- after a real drain (device synchronize: every
+    collective this process enqueued has finished, so nothing the watchdog still holds can be touched by the captured
+    work).  SC_GRAPH_QUIESCE_MS (default 0) adds a pause on top for stacks where that is not enough."""
     import os
     import time
     try:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
-            return
+            return "global"
     except Exception:
-        return
+        return "global"
     torch.cuda.synchronize()
-    time.sleep(float(os.environ.get("SC_GRAPH_QUIESCE_MS", "800")) / 1e3)
+    ms = float(os.environ.get("SC_GRAPH_QUIESCE_MS", "0"))
+    if ms > 0:
+        time.sleep(ms / 1e3)
+    return "thread_local"
 
 
 def capture_step(module, x, grad_out, warmup=3, post=None):
