@@ -85,8 +85,11 @@ enum {
   SC_PLAN_NO_SPAN = 128,     /* complex -> real last-axis pass of widths off every factorised route: the 128-line chunked
                                 kernel (k_mdft_c2r_stage) instead of the 32-line whole-span one (k_mdft_c2r_span; A-B, tests) */
   SC_PLAN_NO_MX_FFT = 256,   /* bfloat16 I/O: the transforms on the vector-ALU kernels k_fft2d_fwd3 / k_fft2d_inv3 instead of
-                                the matrix-core row passes k_fft2d_fwd_mx (H <= 256) / k_fft2d_inv_mx (H = 128, 256; round 5;
-                                A-B and tests) */
+                                the matrix-core row passes k_fft2d_fwd_mx / k_fft2d_inv_mx (H <= 256; round 5; A-B and tests) */
+  SC_PLAN_MX_FFT_3TERM = 512, /* bfloat16 I/O: the twiddles of k_fft2d_fwd_mx as THREE bf16 terms (24 bits: the spectrum of
+                                fp32 round-off class, 1.2e-7 from a float64 transform of the same values) instead of the
+                                default two (16 bits: 1.3e-6 -- 3000 x below the 2^-9 the bf16 input carries per value, 8 x
+                                below the 1e-5 bar of the fp32 gradients; 10 us per launch faster at the metric shape; round 6) */
   SC_PLAN_IO_BF16 = 16       /* the REAL tensors (x, y, gy, gx) are bfloat16 in memory -- the `float*`
                                 arguments that carry them then point at 2-byte elements; spectra,
                                 weights, bias and every arithmetic step stay float32 and y / gx are

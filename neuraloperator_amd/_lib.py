@@ -24,6 +24,7 @@ SC_PLAN_NO_F2P_SMALL = 32
 SC_PLAN_F2P_SMALL_ALWAYS = 64
 SC_PLAN_NO_SPAN = 128
 SC_PLAN_NO_MX_FFT = 256
+SC_PLAN_MX_FFT_3TERM = 512
 SC_FREQ_DROPPED = -(1 << 63)
 SC_GEMM_FORCE_VALU = 1
 SC_GEMM_STREAM_C = 2

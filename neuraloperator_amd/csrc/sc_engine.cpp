@@ -947,7 +947,8 @@ extern "C" int sc_plan_create(sc_plan** out, const sc_plan_desc* desc) {
       p->fft2d.H <= 256 && !getenv("SC_PLAN_NO_MX_FFT")) {
     for (int which = 0; which < 2 && !rc; ++which) {       // forward-type rows in, inverse-type rows out
       std::vector<uint16_t> h;
-      if (which == 0) fft3mx_build_table(&h); else fft3mxi_build_table(&h);
+      p->fft2d.mx_terms = (desc->flags & SC_PLAN_MX_FFT_3TERM) ? 3 : 2;
+      if (which == 0) fft3mx_build_table(&h, p->fft2d.mx_terms); else fft3mxi_build_table(&h);
       void* dev = nullptr;
       if (hipMalloc(&dev, h.size() * sizeof(uint16_t)) != hipSuccess) {
         rc = sc_fail("sc_engine: table allocation failed");

@@ -419,6 +419,7 @@ struct Fft2dPlan {
   float sf = 0.f, si = 0.f;
   cf32 *tabW = nullptr, *tabH = nullptr, *tab64 = nullptr;
   uint16_t* tabF = nullptr;     // bf16 operand fragments of the matrix-core row pass (sc_kernels_fft3mx.h); null = not built
+  int mx_terms = 2;             // ... bf16 terms per twiddle in tabF (2: default of bf16-I/O plans, 3: SC_PLAN_MX_FFT_3TERM)
   uint16_t* tabG = nullptr;     // ... of the inverse-type kernel's row pass (k_fft2d_inv_mx); null = not built
 };
 

@@ -97,9 +97,11 @@ inline sc_mx_u4 sc_mx_load16_stream(const void* p) {
 inline sc_mx_u4 sc_mx_load16(const void* p) { return sc_mx_load16_stream(p); }
 #endif
 
-#ifndef SC_MX_TERMS
-#define SC_MX_TERMS 3     // bf16 terms of a twiddle (3: 24 bits; 2 would leave 2^-17 -- measured)
-#endif
+// bf16 terms of a twiddle of the forward-type kernel (Fft2dPlan::mx_terms, round 6): 2 = the default of bfloat16-I/O plans
+// (16 bits: the spectrum 1.3e-6 from a float64 transform of the same bf16 values -- 3000 times below the 2^-9 the bf16
+// INPUT already carries per value and 8 times below the 1e-5 bar of the fp32 gradients it feeds; 72-75 us per launch at
+// the metric shape, bf16 step 0.395 -> 0.368 ms, profiles/r06_mx_terms_ab.txt); 3 = SC_PLAN_MX_FFT_3TERM (24 bits: fp32
+// round-off class, 1.2e-7, 81-83 us)
 // Measured and dropped (profiles/r05_mx_fft_ab.txt): rows straight from global memory into MFMA order (non-temporal:
 // 106 us, every lane's 16-byte piece its own request; ordinary loads: 76-84 us, but the step loses in its contractions
 // what the transform gains -- see the row requests below), two groups of rows in flight with the operand fragments
@@ -131,9 +133,9 @@ struct F3MxLds {
 
 // the operand table of one plan: [tile 4][term][lane 64][8 bf16], MFMA B layout (lane (j, g): F[m = 8 g + e][column j]);
 // tile 0 / 2: cos(2 pi m k / 64), tile 1 / 3: -sin(...), k = 2 j + (tile >> 1); tile 1, j = 0: (-1)^m  (k = 32)
-static inline void fft3mx_build_table(std::vector<uint16_t>* out) {
+static inline void fft3mx_build_table(std::vector<uint16_t>* out, const int n_terms = 3) {
   const double two_pi = 6.283185307179586476925286766559;
-  out->assign((size_t)4 * SC_MX_TERMS * 64 * 8, 0);
+  out->assign((size_t)4 * n_terms * 64 * 8, 0);
   // nearest-even onto the bf16 grid (through float: a double rounding can only move a tie, and whatever a term
   // misses the next term picks up -- the remainder below is exact in double)
   auto to_bf16 = [](double v) {
@@ -163,20 +165,20 @@ static inline void fft3mx_build_table(std::vector<uint16_t>* out) {
           if (idx % 16 == 0) v = std::round(v);            // 0, +-1 exactly
         }
         double rest = v;
-        for (int term = 0; term < SC_MX_TERMS; ++term) {
+        for (int term = 0; term < n_terms; ++term) {
           const uint16_t b = to_bf16(rest);
-          (*out)[(((size_t)t * SC_MX_TERMS + term) * 64 + lane) * 8 + e] = b;
+          (*out)[(((size_t)t * n_terms + term) * 64 + lane) * 8 + e] = b;
           rest -= from_bf16(b);
         }
       }
 }
 
-template <int H>
+template <int H, int NT>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, SC_MX_WGS)
 k_fft2d_fwd_mx(const sc_bf16* __restrict__ x, cf32* __restrict__ xhat, const cf32* __restrict__ tabW,
                const cf32* __restrict__ tabH, const uint16_t* __restrict__ tabF, int Mx, int My, float s_dc,
                float s_other, F3Shard sh, int64_t n_images, int gstride) {
-  constexpr int P = H / 64, RS = SC_MX_RS, NT = SC_MX_TERMS;
+  constexpr int P = H / 64, RS = SC_MX_RS;
   typedef F3MxLds<H> L;
   SC_SHARED __attribute__((aligned(16))) unsigned char smem[L::total];
   cf32* xch = reinterpret_cast<cf32*>(smem + L::off_xch);
@@ -398,8 +400,12 @@ static void fft3mx_launch_fwd(const Fft2dPlan* fp, const sc_bf16* x, cf32* xhat,
                               float s_other, sc_stream_t st, F3Shard sh) {
   int64_t grid = (int64_t)SC_MX_WGS * sc_cu_count();
   if (grid > n_images) grid = n_images;
-  SC_LAUNCH((k_fft2d_fwd_mx<H>), dim3((unsigned)grid), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
-            (const cf32*)fp->tabH, (const uint16_t*)fp->tabF, fp->Mx, fp->My, s_dc, s_other, sh, n_images, (int)grid);
+  if (fp->mx_terms == 2)
+    SC_LAUNCH((k_fft2d_fwd_mx<H, 2>), dim3((unsigned)grid), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
+              (const cf32*)fp->tabH, (const uint16_t*)fp->tabF, fp->Mx, fp->My, s_dc, s_other, sh, n_images, (int)grid);
+  else
+    SC_LAUNCH((k_fft2d_fwd_mx<H, 3>), dim3((unsigned)grid), dim3(256), 0, st, x, xhat, (const cf32*)fp->tabW,
+              (const cf32*)fp->tabH, (const uint16_t*)fp->tabF, fp->Mx, fp->My, s_dc, s_other, sh, n_images, (int)grid);
 }
 
 static inline int fft3mx_forward(const Fft2dPlan* fp, int mode, const sc_bf16* x, cf32* xhat, int64_t n_images,

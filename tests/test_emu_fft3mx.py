@@ -40,10 +40,13 @@ def test_mx_forward_vs_float64_and_valu(lib, H, Mx, My, n_img):
     for mode in (_lib.SC_FWD_SCALED, _lib.SC_FWD_ADJ_C2R):
         got = {}
         # (the vector-ALU kernel beside it on the small cases only: CPU-tier time)
-        routes = (("mx", _lib.SC_PLAN_IO_BF16), ("valu", _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT))
-        for tag, fl in routes[:2 if H * n_img <= 512 else 1]:
+        # mx = the default of bf16-I/O plans since round 6: TWO bf16 terms per twiddle (1.3e-6: 3000 x below the 2^-9 of the bf16
+        # input, 8 x below the 1e-5 bar of the fp32 gradients it feeds); mx3 = SC_PLAN_MX_FFT_3TERM: fp32 round-off class
+        routes = (("mx", _lib.SC_PLAN_IO_BF16), ("mx3", _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_MX_FFT_3TERM),
+                  ("valu", _lib.SC_PLAN_IO_BF16 | _lib.SC_PLAN_NO_MX_FFT))
+        for tag, fl in routes[:3 if H * n_img <= 512 else 2]:
             plan = lib.plan_create([H, 256], [Mx, My], flags=fl)
-            assert lib.plan_kernel_name(plan, 0) == ("k_fft2d_fwd_mx" if tag == "mx" else "k_fft2d_fwd3")
+            assert lib.plan_kernel_name(plan, 0) == ("k_fft2d_fwd_mx" if tag.startswith("mx") else "k_fft2d_fwd3")
             xh = torch.full((n_img, Mx, My, 2), float("nan"))
             lib.transform_forward(plan, mode, x.data_ptr(), xh.data_ptr(), n_img, 0)
             got[tag] = torch.view_as_complex(xh).numpy()
@@ -51,7 +54,7 @@ def test_mx_forward_vs_float64_and_valu(lib, H, Mx, My, n_img):
         ref = _ref(xf, H, Mx, My, mode)
         for tag, g in got.items():
             e = np.linalg.norm(g - ref) / np.linalg.norm(ref)
-            assert e < 1e-6, (tag, mode, e)
+            assert e < (3e-6 if tag == "mx" else 1e-6), (tag, mode, e)
 
 
 def test_mx_forward_sharded_layout(lib):
