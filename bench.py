@@ -359,6 +359,50 @@ def block_extra(B, C, spatial, n_modes, dev):
     return out
 
 
+def sfno_extra(dev, B=8, C=32, nlat=128, nlon=256, L=64, M=64):
+    """one SphericalConv (spherical_convolution.py:284-484: real SHT -> per-degree channel
+    contraction -> inverse SHT) forward + backward on the engine's launches against the SAME operations as a torch op
+    sequence on the GPU (rfft, two Legendre einsums with the layer's own tables, the channel einsum, irfft).  Parity
+    against torch_harmonics itself is unpinned (absent); the restatement is pinned by closed-form harmonics on the CPU
+    tier (tests/test_spherical.py)."""
+    import math
+    from neuraloperator_amd.spherical import SphericalConv, legendre_table, quadrature
+    torch.manual_seed(5)
+    conv = SphericalConv(C, C, (L, 2 * M), factorization=None, sht_grids="equiangular").to(dev)
+    x = torch.randn(B, C, nlat, nlon, device=dev, requires_grad=True)
+    g = torch.randn(B, C, nlat, nlon, device=dev)
+    theta, wq = quadrature(nlat, "equiangular")
+    cplx = lambda a: torch.from_numpy(a).to(torch.complex64).to(dev)
+    Pf = cplx(legendre_table(M, L, theta, "ortho") * wq[None, None, :])                    # [m, l, k]
+    Pi = cplx(legendre_table(M, L, theta, "ortho", inverse=True))
+
+    def ref(t):
+        X = torch.fft.rfft(t, dim=-1, norm="forward")[..., :M] * (2.0 * math.pi)           # (B, C, k, m)
+        c = torch.einsum("bckm,mlk->bclm", X, Pf)
+        y = torch.einsum("bilm,iol->bolm", c, conv.weight.tensor[..., :L])
+        Y = torch.einsum("bolm,mlk->bokm", y, Pi)
+        return torch.fft.irfft(Y, n=nlon, dim=-1, norm="forward") + conv.bias
+    out = {"workload": f"SphericalConv B={B} C={C} {nlat}x{nlon} equiangular, l < {L}, m < {M}, dense weight, forward + backward"}
+    with torch.no_grad():
+        a, b = conv(x), ref(x)
+        out["rel_l2_vs_op_sequence"] = float((a - b).norm() / b.norm())
+    for tag, fn in (("op_sequence_ms", ref), ("engine_ms", conv)):
+        def step():
+            conv.zero_grad(set_to_none=True)
+            x.grad = None
+            fn(x).backward(g)
+        settle_clocks(step)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        out[tag] = round(e0.elapsed_time(e1) / 5, 4)
+    return out
+
+
 def _kernel_key(name):
     """'void k_fft2d_fwd3<256, float>(float const*, ...)' -> 'k_fft2d_fwd3<256, float>'"""
     name = name.replace("void ", "").strip()
@@ -503,6 +547,9 @@ def compact_configs(out, extra, world):
     fb = extra.get("fno_block")
     if fb and fb.get("fused_ms") is not None:
         c["block"] = {"fused_ms": fb["fused_ms"], "ref_ms": fb.get("reference_op_sequence_ms")}
+    sf = extra.get("sfno")
+    if sf and sf.get("engine_ms") is not None:
+        c["sfno"] = {"engine_ms": sf["engine_ms"], "ref_ms": sf.get("op_sequence_ms")}
     return c
 
 
@@ -1089,6 +1136,11 @@ def main():
                                                   "tucker" if kw_x is not None else "dense", tot_x))
         if world == 1:
             extra["fno_block"] = block_extra(B, C, spatial, n_modes, dev)
+            torch.cuda.empty_cache()
+            try:
+                extra["sfno"] = sfno_extra(dev)
+            except Exception as e:                           # an extra never kills the line
+                extra["sfno"] = {"engine_ms": None, "note": f"failed: {type(e).__name__}: {str(e)[:160]}"}
             torch.cuda.empty_cache()
 
     if rank == 0:
