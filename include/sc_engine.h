@@ -362,7 +362,7 @@ int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, const float*
  * sc_pointwise_linear_backward and sc_layer_backward_ex) read them.  Replaces sc_pointwise_linear_forward + the block
  * epilogue of sc_layer_forward_ex + sc_pointwise_mlp_forward (8 tensor-sized passes) by 1 + 5: the skip is never
  * written and y is not read back.  d->c_in == d->c_out in {32, 64} channels with c_hid as for the MLP pass; bs, b1, b2
- * optional; `pre` is required with SC_ACT_GELU and ignored otherwise. */
+ * optional; `pre` is required with SC_ACT_GELU (receives s) or SC_ACT_GELU_DGRAD (receives gelu'(s), see the enum) and ignored otherwise. */
 int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* conv, const float* x, const float* ws, const float* bs,
                                const float* w1, const float* b1, const float* w2, const float* b2, const float* gate,
                                float* y, float* pre, float* out, void* stream);
@@ -378,7 +378,9 @@ int sc_pointwise_mlp_backward(const sc_pmlp_desc* d, const float* x, const float
                               float* gw1, float* gb1, float* gw2, float* gb2, float* gskip_src, float* ggate,
                               void* workspace, void* stream);
 /* the same with x_pre (optional, like x): x = gelu(x_pre) came out of sc_layer_forward_ex; gx is then the gradient with
- * respect to x_pre -- the GELU backward of the Fourier layer in this pass' store path instead of a pass of its own. */
+ * respect to x_pre -- the GELU backward of the Fourier layer in this pass' store path instead of a pass of its own.
+ * d->act == SC_ACT_GELU_DGRAD: the MLP's closing activation is GELU and x_pre holds gelu'(pre-activation) (what
+ * sc_pointwise_block_forward stored under the same code). */
 int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* x, const float* x_pre, const float* w1,
                                  const float* b1, const float* w2, const float* b2, const float* skip_src,
                                  const float* gate, const float* gout, float* gx, float* gw1, float* gb1, float* gw2,
@@ -488,7 +490,13 @@ int sc_layer_backward_ex(const sc_plan* plan, const sc_layer_desc* layer, const 
  * (rel-L2 ~1e-7 on N(0,1) data; pinned in tests/test_emu_epilogue.py for |v| <= 6).  The fused store path and the stand-alone
  * pass evaluate the SAME function (identical bits for every grid shape).
  * preact: written if and only if act == SC_ACT_GELU; preact != NULL together with SC_ACT_NONE is rejected. */
-enum { SC_ACT_NONE = 0, SC_ACT_GELU = 1 };
+enum { SC_ACT_NONE = 0, SC_ACT_GELU = 1,
+       /* round 6, sc_pointwise_block_forward / sc_pointwise_mlp_backward_ex only: as SC_ACT_GELU, but the `pre` buffer of the
+          forward call receives gelu'(s) -- the DERIVATIVE of the Fourier layer's activation, which comes out of the same
+          evaluation of the two transcendentals as gelu(s) itself -- and `x_pre` of the backward call holds that
+          derivative: the backward multiplies by it instead of evaluating gelu' per value (on MI355X the vector work of
+          these fp32 kernels runs in front of their matrix instructions, not beside them: DESIGN 3.16 b) */
+       SC_ACT_GELU_DGRAD = 2 };
 typedef struct {
   const float* skip;        /* device, (n_images, d1..dN); NULL = no epilogue at all          */
   float* preact;            /* device, optional                                                 */

@@ -84,7 +84,7 @@ class Epilogue(Structure):
 
 
 SC_PLX_XACT, SC_PLX_ACT, SC_PLX_PRO, SC_PLX_XGRAD = 1, 2, 4, 8     # sc_plinx_desc.flags
-SC_ACT_NONE, SC_ACT_GELU = 0, 1
+SC_ACT_NONE, SC_ACT_GELU, SC_ACT_GELU_DGRAD = 0, 1, 2
 
 
 class TuckerDesc(Structure):

@@ -332,6 +332,10 @@ class FusedBlockFn(torch.autograd.Function):
                 conv = torch.empty_like(x)
                 lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), 0, 0, _lib.SC_ACT_NONE, p(conv),
                                      p(xhat), p(ws), st)
+                # round 6: `pre` receives gelu'(conv + skip) (SC_ACT_GELU_DGRAD: one evaluation of the transcendentals gives
+                # the activation and its derivative), the backward pass multiplies by it instead of evaluating gelu' again
+                if not last:
+                    act = _lib.SC_ACT_GELU_DGRAD
                 lib.pointwise_block_forward(b, c, ch, s, act, p(conv), p(x), p(lwc), p(lbc), p(w1c), p(b1c), p(w2c), p(b2c),
                                             p(gtc), p(y), p(pre), p(out), st)
             else:

@@ -589,4 +589,26 @@ SC_DEVICE float sc_gelu(const float v) {
   const float q = sc_erfc_abs_fast(v * 0.70710678118654752440f);
   return 0.5f * v * (v < 0.f ? q : 2.f - q);
 }
+// gelu(v) AND its derivative Phi(v) + v phi(v) from ONE evaluation of the two transcendentals (round 6): the exponential
+// of the erfc approximation at z = |v| / sqrt 2 is exp(-v^2 / 2) -- the density's own -- so the derivative costs four
+// more vector instructions instead of a second reciprocal + two exponentials.  On MI355X every vector instruction of the
+// fp32 pointwise kernels runs IN FRONT OF their matrix instructions, not beside them (DESIGN 3.16 b).
+SC_DEVICE void sc_gelu_both(const float v, float& gelu, float& grad) {
+  const float ax = fabsf(v) * 0.70710678118654752440f;
+#ifndef SC_EMU
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  const float e = __expf(-ax * ax);
+#else
+  const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
+  const float e = expf(-ax * ax);
+#endif
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float q = p * t * e;                               // erfc(|v| / sqrt 2)
+  const float two_cdf = v < 0.f ? q : 2.f - q;             // 1 + erf(v / sqrt 2)
+  gelu = 0.5f * v * two_cdf;
+  grad = fmaf(v, 0.39894228040143267794f * e, 0.5f * two_cdf);
+}
 

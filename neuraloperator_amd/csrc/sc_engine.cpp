@@ -2865,13 +2865,14 @@ extern "C" int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* co
   SC_CHECK_ARG(d, "null argument");
   if (d->batch <= 0 || d->spatial <= 0) return 0;
   SC_CHECK_ARG(conv && x && ws && w1 && w2 && gate && y && out, "null argument");
-  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU, "unknown activation");
-  SC_CHECK_ARG(d->act == SC_ACT_NONE || pre, "the pre-activation buffer is required with SC_ACT_GELU");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU || d->act == SC_ACT_GELU_DGRAD, "unknown activation");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || pre, "the pre-activation buffer is required with SC_ACT_GELU / SC_ACT_GELU_DGRAD");
   SC_CHECK_ARG(d->c_in == d->c_out, "pointwise block pass: c_in == c_out (the linear skip maps the block's channels onto themselves)");
   SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise block pass: the spatial size must be a multiple of 32");
   PblockArgs g;
   g.conv = conv; g.x = x; g.ws = ws; g.bs = bs; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.gate = gate;
-  g.y = y; g.pre = d->act == SC_ACT_GELU ? pre : nullptr; g.out = out;
+  g.y = y; g.pre = d->act != SC_ACT_NONE ? pre : nullptr; g.out = out;
+  g.pre_is_grad = d->act == SC_ACT_GELU_DGRAD ? 1 : 0;
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
@@ -2881,9 +2882,9 @@ extern "C" int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* co
   g.n_wg = (int)(wgs < cap ? wgs : cap);
   sc_stream_t st = (sc_stream_t)stream;
   switch (pmlp_shape_id(d)) {
-    case 111: launch_pblock_fwd<1, 1>(g, d->act == SC_ACT_GELU, st); break;
-    case 212: launch_pblock_fwd<2, 1>(g, d->act == SC_ACT_GELU, st); break;
-    case 222: launch_pblock_fwd<2, 2>(g, d->act == SC_ACT_GELU, st); break;
+    case 111: launch_pblock_fwd<1, 1>(g, d->act != SC_ACT_NONE, st); break;
+    case 212: launch_pblock_fwd<2, 1>(g, d->act != SC_ACT_NONE, st); break;
+    case 222: launch_pblock_fwd<2, 2>(g, d->act != SC_ACT_NONE, st); break;
     default:
       return sc_fail("sc_engine: pointwise block pass: (c, c_hid, c) must be (32,32,32), (64,32,64) or (64,64,64)");
   }
@@ -2951,14 +2952,17 @@ extern "C" int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* 
   SC_CHECK_ARG(d, "null argument");
   SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise MLP backward: empty input");
   SC_CHECK_ARG(x && w1 && w2 && gout && gx && gw1 && gw2 && workspace, "null argument");
-  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU, "unknown activation");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU || d->act == SC_ACT_GELU_DGRAD, "unknown activation");
+  SC_CHECK_ARG(d->act != SC_ACT_GELU_DGRAD || x_pre, "SC_ACT_GELU_DGRAD: x_pre (the stored derivative) is required");
   SC_CHECK_ARG((skip_src == nullptr) == (gate == nullptr), "skip_src and gate come together");
   SC_CHECK_ARG(!gate || (gskip_src && ggate), "a gated forward needs gskip_src and ggate");
   SC_CHECK_ARG((b1 != nullptr || gb1 == nullptr) && (b2 != nullptr || gb2 == nullptr), "bias gradient without a bias");
   SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
   PmlpBwdArgs g;
   g.x = x; g.b1 = b1; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.gout = gout; g.gx = gx; g.gskip = gskip_src;
-  g.w1 = w1; g.w2 = w2; g.x_pre = x_pre; g.partial = nullptr;
+  g.w1 = w1; g.w2 = w2; g.x_pre = x_pre; g.partial = nullptr; g.lw = nullptr;
+  g.x_pre_is_grad = d->act == SC_ACT_GELU_DGRAD ? 1 : 0;
+  const int act = d->act == SC_ACT_NONE ? 0 : 1;           // the MLP's own closing activation
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
@@ -2967,9 +2971,9 @@ extern "C" int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* 
   float* ws = (float*)workspace;
   const bool gt = gate != nullptr;
   switch (pmlp_shape_id(d)) {
-    case 111: launch_pmlp_bwd<1, 1, 1, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
-    case 212: launch_pmlp_bwd<2, 1, 2, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
-    case 222: launch_pmlp_bwd<2, 2, 2, 4>(g, ws, gt, d->act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 111: launch_pmlp_bwd<1, 1, 1, 4>(g, ws, gt, act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 212: launch_pmlp_bwd<2, 1, 2, 4>(g, ws, gt, act, gw1, gb1, gw2, gb2, ggate, st); break;
+    case 222: launch_pmlp_bwd<2, 2, 2, 4>(g, ws, gt, act, gw1, gb1, gw2, gb2, ggate, st); break;
     default:
       return sc_fail("sc_engine: pointwise MLP backward: channel counts (c_in, c_hid, c_out) must be one of (32,32,32), "
                      "(64,32,64), (64,64,64); (128,64,128) has the forward pass only (operand tables + gradient image "
@@ -3099,7 +3103,7 @@ extern "C" int sc_pointwise_linear_forward_ex(const sc_plinx_desc* d, const floa
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
   const int ci = (int)(d->c_in / 32), co = (int)(d->c_out / 32);
-  const int64_t wgs = (g.n_tiles + 3) / 4, resident = (int64_t)(ci * co > 8 ? 1 : 2) * sc_cu_count();
+  const int64_t wgs = (g.n_tiles + 3) / 4, resident = (int64_t)2 * sc_cu_count();
   g.n_wg = (int)(wgs < resident ? wgs : resident);
   sc_stream_t st = (sc_stream_t)stream;
   switch (ci * 10 + co) {

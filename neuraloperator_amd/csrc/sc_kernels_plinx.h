@@ -52,8 +52,10 @@ struct PlinxArgs {
   int tiles_per_sample, n_wg, flags, do_gx;
 };
 
+// two workgroups per compute unit for every channel pair (the 128 -> 128 table is 64 KB): a wave's loads wait behind the
+// other wave's products -- the matrix and vector work of the two do not overlap (see the header), the memory latency does
 template <int CI, int CO>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, (CI * CO > 8 ? 1 : 2))
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 2)
 k_plinx_fwd(PlinxArgs g) {
   constexpr int C_IN = 32 * CI, C_OUT = 32 * CO, S1 = 16 * CI;
   SC_SHARED float A[CO * S1 * 64];

@@ -36,9 +36,11 @@
 #ifdef SC_PMLP_ABL_NOGELU
 #define PMLP_GELU(x) ((x) * 0.5f)
 #define PMLP_GELU_GRAD(x) ((x) * 0.25f + 0.5f)
+#define PMLP_GELU_BOTH(x, g, d) do { (g) = (x) * 0.5f; (d) = (x) * 0.25f + 0.5f; } while (0)
 #else
 #define PMLP_GELU(x) sc_gelu(x)
 #define PMLP_GELU_GRAD(x) sc_gelu_grad(x)
+#define PMLP_GELU_BOTH(x, g, d) sc_gelu_both((x), (g), (d))
 #endif
 #ifdef SC_PMLP_ABL_NOSTORE
 #define PMLP_STORE(ptr, val) do { if ((val) == 12345.678f) SC_STORE_STREAM((ptr), (val)); } while (0)
@@ -49,15 +51,12 @@
 // accumulator register v of a lane in half `half` holds this row of the 32 x 32 tile
 SC_HD int pmlp_row(const int v, const int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
 
-// d/dx gelu(x) = Phi(x) + x phi(x)
+// d/dx gelu(x) = Phi(x) + x phi(x)  (round 6: one reciprocal + one exponential -- sc_gelu_both, sc_device.h -- instead of the
+// erf approximation's two transcendentals plus a second exponential for the density)
 SC_DEVICE float sc_gelu_grad(const float x) {
-  const float cdf = 0.5f * (1.f + sc_erf_fast(x * 0.70710678118654752440f));
-#ifndef SC_EMU
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-#else
-  const float pdf = 0.39894228040143267794f * std::exp(-0.5f * x * x);
-#endif
-  return cdf + x * pdf;
+  float g, d;
+  sc_gelu_both(x, g, d);
+  return d;
 }
 
 struct PmlpArgs {
@@ -185,6 +184,7 @@ struct PblockArgs {
   const float* gate;      // (C)
   float* y;               // (batch, C, spatial)
   float* pre;             // (batch, C, spatial) with ACT 1, else null
+  int pre_is_grad;        // SC_ACT_GELU_DGRAD: `pre` receives gelu'(s) instead of s
   float* out;
   int64_t n_tiles, spatial;
   int tiles_per_sample, n_wg;
@@ -257,8 +257,14 @@ k_pblock_fwd(PblockArgs g) {
         const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
         float sv = cv[v] + (yv[om][v] + BS[32 * om + pmlp_row(v, hq)]);   // conv + skip, as the epilogue adds them
         if (ACT == 1) {
-          SC_STORE_STREAM(ps + ro, sv);
-          sv = sc_gelu(sv);
+          if (g.pre_is_grad) {                             // (wave-uniform) gelu and gelu' from one evaluation
+            float dv;
+            sc_gelu_both(sv, sv, dv);
+            SC_STORE_STREAM(ps + ro, dv);
+          } else {
+            SC_STORE_STREAM(ps + ro, sv);
+            sv = sc_gelu(sv);
+          }
         }
         SC_STORE_STREAM(ys + ro, sv);
         yv[om][v] = sv;
@@ -348,6 +354,7 @@ struct PmlpBwdArgs {
   const float* w2;
   const float* x_pre;      // optional: x = gelu(x_pre) was produced by the previous fused pass; gx is then the gradient
                            // with respect to x_pre (the gelu backward of the Fourier layer folded into this store path)
+  int x_pre_is_grad;       // SC_ACT_GELU_DGRAD: x_pre holds gelu'(pre-activation): multiply, do not evaluate
   const float* lw;         // LIN kernels (round 6): the block's linear skip W_s (C, C); `gskip` then receives
                            // W_s^T gx + gate (.) gz -- the whole gradient of the block input outside the spectral convolution
   float* gx;
@@ -486,8 +493,8 @@ k_pmlp_bwd(PmlpBwdArgs g) {
         }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          hp[hm][v] = acc[v] + B1[32 * hm + pmlp_row(v, hq1)];
-          h[hm][v] = PMLP_GELU(hp[hm][v]);
+          // (hp holds gelu'(h_pre) from here on: both come out of one evaluation, phase C needs nothing else of h_pre)
+          PMLP_GELU_BOTH(acc[v] + B1[32 * hm + pmlp_row(v, hq1)], h[hm][v], hp[hm][v]);
           TH[hm * TS + pmlp_row(v, half) * 33 + n] = h[hm][v];
         }
         SC_SCHED_BARRIER();
@@ -593,7 +600,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
     for (int hm = 0; hm < CH; ++hm)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) ghp[hm][v] = gh[hm][v] * PMLP_GELU_GRAD(hp[hm][v]);
+      for (int v = 0; v < 16; ++v) ghp[hm][v] = gh[hm][v] * hp[hm][v];
     SC_SCHED_BARRIER();
     float xe[16];
     if (PF) {
@@ -622,10 +629,15 @@ k_pmlp_bwd(PmlpBwdArgs g) {
         float pv[16];
 #pragma unroll
         for (int v = 0; v < 16; ++v) pv[v] = SC_LOAD_STREAM(ps + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+        if (g.x_pre_is_grad) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          acc[v] *= PMLP_GELU_GRAD(pv[v]);
-          if ((v & 3) == 3) SC_SCHED_BARRIER();
+          for (int v = 0; v < 16; ++v) acc[v] *= pv[v];
+        } else {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            acc[v] *= PMLP_GELU_GRAD(pv[v]);
+            if ((v & 3) == 3) SC_SCHED_BARRIER();
+          }
         }
       }
 #pragma unroll

@@ -186,3 +186,39 @@ def test_pointwise_block_argument_checks(lib):
     with pytest.raises(_lib.EngineError):                # 128 channels: no kernel
         lib.pointwise_block_forward(1, 128, 64, 32, 0, z.data_ptr(), z.data_ptr(), w.data_ptr(), 0, w.data_ptr(), 0, w.data_ptr(), 0,
                                     w.data_ptr(), z.data_ptr(), 0, z.data_ptr(), 0)
+
+
+@pytest.mark.parametrize("chans", [(64, 32), (32, 32)], ids=str)
+def test_block_pass_stores_the_derivative_and_the_backward_multiplies_by_it(lib, chans):
+    """SC_ACT_GELU_DGRAD (round 6): sc_pointwise_block_forward writes gelu'(s) where SC_ACT_GELU writes s -- y and out are the
+    same bits -- and sc_pointwise_mlp_backward_ex with that buffer as x_pre returns what it returns for the pre-activation
+    itself (the derivative from the shared evaluation and the one sc_gelu_grad computes are the same expression)."""
+    c, ch = chans
+    g = torch.Generator().manual_seed(c + ch)
+    B, S = 2, 96
+    mk = lambda *sh: torch.randn(*sh, generator=g)
+    x, conv, gout = mk(B, c, S), mk(B, c, S), mk(B, c, S)
+    ws, w1, w2 = mk(c, c) / c ** 0.5, mk(ch, c) / c ** 0.5, mk(c, ch) / ch ** 0.5
+    bs, b1, b2, gt = mk(c), mk(ch), mk(c), mk(c)
+    p = lambda t: 0 if t is None else t.data_ptr()
+    res = {}
+    for act in (_lib.SC_ACT_GELU, _lib.SC_ACT_GELU_DGRAD):
+        y, pre, out = (torch.full((B, c, S), float("nan")) for _ in range(3))
+        lib.pointwise_block_forward(B, c, ch, S, act, p(conv), p(x), p(ws), p(bs), p(w1), p(b1), p(w2), p(b2), p(gt), p(y),
+                                    p(pre), p(out), 0)
+        gx, acc = torch.empty_like(x), torch.empty_like(x)
+        gw1, gw2, gb1, gb2, ggt = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(b1), torch.empty_like(b2), torch.empty_like(gt)
+        wsb = torch.empty(lib.pointwise_mlp_workspace_bytes(B, c, ch, c, S, 1), dtype=torch.uint8)
+        lib.pointwise_mlp_backward(B, c, ch, c, S, act, p(y), p(w1), p(b1), p(w2), p(b2), p(x), p(gt), p(gout), p(gx), p(gw1), p(gb1),
+                                   p(gw2), p(gb2), p(acc), p(ggt), p(wsb), 0, x_pre=p(pre))
+        res[act] = (y, pre, out, gx, acc, gw1, gw2, gb1, gb2, ggt)
+    a, d = res[_lib.SC_ACT_GELU], res[_lib.SC_ACT_GELU_DGRAD]
+    assert torch.equal(a[0], d[0]) and torch.equal(a[2], d[2])                       # y, out
+    t = a[1].double().requires_grad_(True)                                           # s -> gelu'(s)
+    F.gelu(t).backward(torch.ones_like(t))
+    assert rel_l2(d[1].numpy(), t.grad.numpy()) < TOL
+    for i in range(3, 10):
+        assert torch.equal(a[i], d[i]), i
+    with pytest.raises(_lib.EngineError):                # the derivative buffer is required
+        lib.pointwise_mlp_backward(B, c, ch, c, S, _lib.SC_ACT_GELU_DGRAD, p(a[0]), p(w1), p(b1), p(w2), p(b2), p(x), p(gt), p(gout),
+                                   p(gx), p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(wsb), 0)

@@ -52,3 +52,39 @@ def test_block_pass_on_device(lib, c, ch, B, S, act):
     od = F.gelu(zd) if act else zd
     assert rel_l2(y[:nb].cpu().numpy(), yd.cpu().numpy()) < TOL
     assert rel_l2(out[:nb].cpu().numpy(), od.cpu().numpy()) < TOL
+
+
+def test_block_pass_derivative_form_on_device(lib):
+    """SC_ACT_GELU_DGRAD at the metric shape's channel counts: `pre` = gelu'(s), y / out unchanged, and the backward pass
+    with that buffer as x_pre returns what it returns with the pre-activation (round 6)."""
+    dev = torch.device("cuda:0")
+    c, ch, B, S = 64, 32, 4, 4096
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    x, conv, gout = mk(B, c, S), mk(B, c, S), mk(B, c, S)
+    ws, w1, w2 = mk(c, c) / c ** 0.5, mk(ch, c) / c ** 0.5, mk(c, ch) / ch ** 0.5
+    bs, b1, b2, gt = mk(c), mk(ch), mk(c), mk(c)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()
+    res = {}
+    for act in (_lib.SC_ACT_GELU, _lib.SC_ACT_GELU_DGRAD):
+        y, pre, out = (torch.full((B, c, S), float("nan"), device=dev) for _ in range(3))
+        lib.pointwise_block_forward(B, c, ch, S, act, p(conv), p(x), p(ws), p(bs), p(w1), p(b1), p(w2), p(b2), p(gt), p(y), p(pre),
+                                    p(out), st)
+        gx, acc = torch.empty_like(x), torch.empty_like(x)
+        gw1, gw2, gb1, gb2, ggt = (torch.empty_like(t) for t in (w1, w2, b1, b2, gt))
+        wsb = torch.empty(lib.pointwise_mlp_workspace_bytes(B, c, ch, c, S, 1), dtype=torch.uint8, device=dev)
+        lib.pointwise_mlp_backward(B, c, ch, c, S, act, p(y), p(w1), p(b1), p(w2), p(b2), p(x), p(gt), p(gout), p(gx), p(gw1), p(gb1),
+                                   p(gw2), p(gb2), p(acc), p(ggt), p(wsb), st, x_pre=p(pre))
+        torch.cuda.synchronize()
+        res[act] = (y, pre, out, gx, acc, gw1, gw2, gb1, gb2, ggt)
+    a, d = res[_lib.SC_ACT_GELU], res[_lib.SC_ACT_GELU_DGRAD]
+    # (the two forms evaluate the same expressions in different kernels: hipcc may contract them differently -- last-bit
+    #  differences on the device, identical bits in host emulation, tests/test_emu_pmlp.py)
+    close = lambda u, v: rel_l2(u.cpu().numpy(), v.cpu().numpy()) < 1e-6
+    assert close(a[0], d[0]) and close(a[2], d[2])
+    t = a[1].double().requires_grad_(True)
+    F.gelu(t).backward(torch.ones_like(t))
+    assert rel_l2(d[1].cpu().numpy(), t.grad.cpu().numpy()) < TOL
+    for i in range(3, 10):
+        assert close(a[i], d[i]), i
