@@ -386,6 +386,24 @@ int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* x, const fl
                                  const float* gate, const float* gout, float* gx, float* gw1, float* gb1, float* gw2,
                                  float* gb2, float* gskip_src, float* ggate, void* workspace, void* stream);
 
+/* Round 6 -- the backward of sc_pointwise_block_forward's pointwise side with the DATA path of the linear skip riding along
+ * (fno_block.py:392-414 backwards: closing GELU, soft-gating skip, ChannelMLP, the Fourier layer's GELU, and the linear skip's
+ * W_s^T product): one pass reads y, y_pre, x, gout and writes
+ *     gz  = the gradient of the Fourier layer's pre-activation s (= the gradient of the spectral convolution's output and
+ *           of the linear skip's output),
+ *     gin = W_s^T gz + gate (.) g_z  = the whole gradient of the block input outside the spectral convolution (the addend
+ *           of sc_layer_backward_ex),
+ * and the gradients of w1 / b1 / w2 / b2 / gate -- instead of sc_pointwise_mlp_backward_ex + sc_pointwise_linear_backward
+ * (10 tensor-sized reads / writes -> 5; the skip's own weight gradient is then sc_pointwise_linear_backward_ex with
+ * gx = NULL: 2 more).  d->act: SC_ACT_NONE (last block: y_pre NULL), SC_ACT_GELU (y_pre = s) or SC_ACT_GELU_DGRAD
+ * (y_pre = gelu'(s), as stored by the forward call under the same code).  (channels, hidden) in {(32, 32), (64, 32)}
+ * (sc_pointwise_block_backward_supported); workspace sc_pointwise_mlp_workspace_bytes(d) bytes. */
+int sc_pointwise_block_backward_supported(const sc_pmlp_desc* d);
+int sc_pointwise_block_backward(const sc_pmlp_desc* d, const float* y, const float* y_pre, const float* x,
+                                const float* ws_lin, const float* w1, const float* b1, const float* w2, const float* b2,
+                                const float* gate, const float* gout, float* gz, float* gin, float* gw1, float* gb1,
+                                float* gw2, float* gb2, float* ggate, void* workspace, void* stream);
+
 /* 1 x 1 linear map over the channels in one pass each way: out = W x (+ bias) -- the block's linear skip
  * (neuralop/layers/skip_connections.py:119-169: Flattened1dConv = Conv1d with kernel size 1 on the flattened grid).
  * x (batch, c_in, spatial), out (batch, c_out, spatial), w (c_out, c_in) row-major, bias (c_out) or null.

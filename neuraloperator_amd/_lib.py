@@ -169,7 +169,8 @@ class ScEngineLib:
                "sc_tucker_chain_t3m_bytes", "sc_tucker_chain_forward_fused", "sc_tucker_chain_backward_fused",
                "sc_tucker_chain_backward_fused_workspace_bytes", "sc_peer_window_alloc", "sc_peer_window_open",
                "sc_peer_window_close", "sc_peer_window_free", "sc_peer_all_to_all", "sc_peer_window_control", "sc_pointwise_linear_forward_ex",
-               "sc_pointwise_linear_workspace_bytes_ex", "sc_pointwise_linear_backward_ex"]
+               "sc_pointwise_linear_workspace_bytes_ex", "sc_pointwise_linear_backward_ex", "sc_pointwise_block_backward",
+               "sc_pointwise_block_backward_supported"]
 
     def __init__(self, path=DEFAULT_LIB):
         if not os.path.isfile(path):
@@ -262,6 +263,10 @@ class ScEngineLib:
         L.sc_pointwise_linear_forward.restype = c_int
         L.sc_pointwise_linear_workspace_bytes.argtypes = [POINTER(PlinDesc)]
         L.sc_pointwise_linear_workspace_bytes.restype = c_size_t
+        L.sc_pointwise_block_backward_supported.argtypes = [POINTER(PmlpDesc)]
+        L.sc_pointwise_block_backward_supported.restype = c_int
+        L.sc_pointwise_block_backward.argtypes = [POINTER(PmlpDesc)] + [c_void_p] * 19
+        L.sc_pointwise_block_backward.restype = c_int
         L.sc_pointwise_linear_forward_ex.argtypes = [POINTER(PlinxDesc)] + [c_void_p] * 8
         L.sc_pointwise_linear_forward_ex.restype = c_int
         L.sc_pointwise_linear_workspace_bytes_ex.argtypes = [POINTER(PlinxDesc)]
@@ -444,6 +449,16 @@ class ScEngineLib:
         d = PmlpDesc(batch, c_in, c_hid, c_out, spatial, act, 0)
         self._check(self.lib.sc_pointwise_mlp_backward_ex(byref(d), x, x_pre, w1, b1, w2, b2, skip, gate, gout, gx, gw1,
                                                           gb1, gw2, gb2, gskip, ggate, ws, stream))
+
+    def pointwise_block_backward_supported(self, batch, c, c_hid, spatial):
+        return bool(self.lib.sc_pointwise_block_backward_supported(byref(PmlpDesc(batch, c, c_hid, c, spatial, 0, 0))))
+
+    def pointwise_block_backward(self, batch, c, c_hid, spatial, act, y, y_pre, x, ws_lin, w1, b1, w2, b2, gate, gout, gz, gin,
+                                 gw1, gb1, gw2, gb2, ggate, ws, stream=0):
+        """the MLP pass of a block's backward + the data path of its linear skip (include/sc_engine.h, round 6)"""
+        d = PmlpDesc(batch, c, c_hid, c, spatial, act, 0)
+        self._check(self.lib.sc_pointwise_block_backward(byref(d), y, y_pre, x, ws_lin, w1, b1, w2, b2, gate, gout, gz, gin,
+                                                         gw1, gb1, gw2, gb2, ggate, ws, stream))
 
     def pointwise_linear_forward(self, batch, c_in, c_out, spatial, x, w, bias, out, stream=0):
         d = PlinDesc(batch, c_in, c_out, spatial)

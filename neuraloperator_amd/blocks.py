@@ -361,7 +361,9 @@ class FusedBlockFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream()
             # pointwise MLP pass: gy, and the soft-gating branch's gradient of the block input (acc)
-            gy, acc = torch.empty_like(x), torch.empty_like(x)
+            gy = torch.empty_like(x)
+            fused_bwd = hpre is None and lib.pointwise_block_backward_supported(b, c, ch, s)
+            acc = None if fused_bwd else torch.empty_like(x)
             gw1, gw2 = torch.empty_like(w1c), torch.empty_like(w2c)
             gb1 = None if b1c is None else torch.empty_like(b1c)
             gb2 = None if b2c is None else torch.empty_like(b2c)
@@ -384,6 +386,17 @@ class FusedBlockFn(torch.autograd.Function):
                 gz = gy
                 lib.pointwise_linear_backward_ex(b, c, c, s, 0, p(x), p(lwc), p(gz), 0, 0, 0, 0, p(acc), p(acc2), p(glw), p(glb),
                                                  0, 0, p(wsx), st)
+            elif fused_bwd:
+                # round 6: the data path of the linear skip rides in the MLP pass (acc2 = W_s^T gz + the soft-gating
+                # branch's gradient never crosses memory as two tensors); the skip's weight gradient is a pass of its own
+                # over gz and x (sc_pointwise_linear_backward_ex without gx): 10 tensor-sized reads / writes -> 7
+                ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, c, ch, c, s, act), dtype=torch.uint8, device=dev)
+                lib.pointwise_block_backward(b, c, ch, s, act, p(y), p(pre), p(x), p(lwc), p(w1c), p(b1c), p(w2c), p(b2c), p(gtc),
+                                             p(gout), p(gy), p(acc2), p(gw1), p(gb1), p(gw2), p(gb2), p(ggt), p(ws), st)
+                gz = gy
+                wsl = torch.empty(lib.pointwise_linear_workspace_bytes_ex(b, c, c, s), dtype=torch.uint8, device=dev)
+                lib.pointwise_linear_backward_ex(b, c, c, s, 0, p(x), p(lwc), p(gz), 0, 0, 0, 0, 0, 0, p(glw), p(glb), 0, 0,
+                                                 p(wsl), st)
             else:
                 ws = torch.empty(lib.pointwise_mlp_workspace_bytes(b, c, ch, c, s, act), dtype=torch.uint8, device=dev)
                 # (with the Fourier layer's pre-activation the pass returns the gradient THROUGH its GELU: gy is gz)

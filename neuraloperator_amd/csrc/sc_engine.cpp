@@ -2982,6 +2982,61 @@ extern "C" int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* 
   return sc_check_launch("k_pmlp_bwd");
 }
 
+// ---- round 6: the MLP pass of a block's backward with the DATA path of the linear skip riding along (k_pmlp_bwd<.., LIN>):
+//      gz = the gradient of the Fourier layer's pre-activation, gin = W_s^T gz + gate (.) g_z -- the whole gradient of the
+//      block input outside the spectral convolution, i.e. the addend of sc_layer_backward_ex.  What is left of the linear
+//      skip's backward is its weight gradient: sc_pointwise_linear_backward_ex(gx = NULL).
+template <int CI, int CH, int CO>
+static void launch_pblock_bwd(PmlpBwdArgs g, float* ws, int act, float* gw1, float* gb1, float* gw2, float* gb2, float* ggate,
+                              sc_stream_t st) {
+  typedef PmlpDims<CI, CH, CO> D;
+  g.partial = ws;
+  float* stage = ws + (size_t)g.n_wg * D::NP;
+  const dim3 grid((unsigned)g.n_wg), block(256);
+  if (act) SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 1, 4, true>), grid, block, 0, st, g);
+  else SC_LAUNCH((k_pmlp_bwd<CI, CH, CO, true, 0, 4, true>), grid, block, 0, st, g);
+  const unsigned nb = (unsigned)((D::NP + 255) / 256);
+  const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
+  SC_LAUNCH(k_pmlp_reduce1, dim3(nb, (unsigned)groups), dim3(256), 0, st, (const float*)g.partial, g.n_wg, groups, (int)D::NP,
+            stage);
+  SC_LAUNCH(k_pmlp_reduce, dim3(nb), dim3(256), 0, st, (const float*)stage, groups, (int)D::NP, (int)D::oW1, (int)D::oB1,
+            (int)D::oB2, (int)D::oG, gw2, gw1, gb1, gb2, ggate);
+}
+
+extern "C" int sc_pointwise_block_backward_supported(const sc_pmlp_desc* d) {
+  if (!d || d->c_in != d->c_out || d->spatial % 32) return 0;
+  const int id = pmlp_shape_id(d);
+  return (id == 111 || id == 212) ? 1 : 0;                 // (64, 64, 64): tables + scratch + gradient image exceed 160 KB of LDS
+}
+
+extern "C" int sc_pointwise_block_backward(const sc_pmlp_desc* d, const float* y, const float* y_pre, const float* x,
+                                           const float* ws_lin, const float* w1, const float* b1, const float* w2,
+                                           const float* b2, const float* gate, const float* gout, float* gz, float* gin,
+                                           float* gw1, float* gb1, float* gw2, float* gb2, float* ggate, void* workspace,
+                                           void* stream) {
+  SC_CHECK_ARG(d, "null argument");
+  SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise block backward: empty input");
+  SC_CHECK_ARG(y && x && ws_lin && w1 && w2 && gate && gout && gz && gin && gw1 && gw2 && ggate && workspace, "null argument");
+  SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU || d->act == SC_ACT_GELU_DGRAD, "unknown activation");
+  SC_CHECK_ARG((d->act == SC_ACT_NONE) == (y_pre == nullptr), "y_pre comes with SC_ACT_GELU / SC_ACT_GELU_DGRAD (the block's y = gelu(y_pre))");
+  SC_CHECK_ARG((b1 != nullptr || gb1 == nullptr) && (b2 != nullptr || gb2 == nullptr), "bias gradient without a bias");
+  SC_CHECK_ARG(sc_pointwise_block_backward_supported(d), "pointwise block backward: (channels, hidden) must be (32, 32) or (64, 32)");
+  PmlpBwdArgs g;
+  std::memset((void*)&g, 0, sizeof(g));
+  g.x = y; g.b1 = b1; g.b2 = b2; g.skip = x; g.gate = gate; g.gout = gout; g.gx = gz; g.gskip = gin;
+  g.w1 = w1; g.w2 = w2; g.x_pre = y_pre; g.lw = ws_lin;
+  g.x_pre_is_grad = d->act == SC_ACT_GELU_DGRAD ? 1 : 0;
+  g.spatial = d->spatial;
+  g.tiles_per_sample = (int)(d->spatial / 32);
+  g.n_tiles = d->batch * g.tiles_per_sample;
+  g.n_wg = pmlp_bwd_wgs(d);
+  const int act = d->act == SC_ACT_NONE ? 0 : 1;
+  sc_stream_t st = (sc_stream_t)stream;
+  if (pmlp_shape_id(d) == 111) launch_pblock_bwd<1, 1, 1>(g, (float*)workspace, act, gw1, gb1, gw2, gb2, ggate, st);
+  else launch_pblock_bwd<2, 1, 2>(g, (float*)workspace, act, gw1, gb1, gw2, gb2, ggate, st);
+  return sc_check_launch("k_pmlp_bwd<LIN>");
+}
+
 // ---- 1 x 1 linear map (the block's linear skip)
 static int plin_shape_id(const sc_plin_desc* d) {
   if (d->c_in % 32 || d->c_out % 32) return 0;
@@ -3074,12 +3129,13 @@ static int plinx_ok(const sc_plinx_desc* d) {
   auto okc = [](int64_t c) { return c == 32 || c == 64 || c == 128; };
   return d && okc(d->c_in) && okc(d->c_out);
 }
-static int plinx_bwd_wgs(const sc_plinx_desc* d) {
+static int plinx_omn(int ci, int co) { const int cap = 8 / ci; return co < cap ? co : cap; }   // accumulator tiles <= 8
+static int plinx_bwd_wgs(const sc_plinx_desc* d, bool lean = false) {
+  const int ci = (int)(d->c_in / 32), co = (int)(d->c_out / 32);
   const int64_t wgs = (d->batch * (d->spatial / 32) + 3) / 4;
-  const int64_t cap = sc_cu_count();                       // one workgroup per compute unit (launch bound)
+  const int64_t cap = (int64_t)SC_PLX_BWD_OCC(ci, co, plinx_omn(ci, co), lean) * sc_cu_count();     // the kernel's launch bound
   return (int)(wgs < cap ? wgs : cap);
 }
-static int plinx_omn(int ci, int co) { const int cap = 8 / ci; return co < cap ? co : cap; }   // accumulator tiles <= 8
 
 template <int CI, int CO>
 static void launch_plinx_fwd(const PlinxArgs& g, sc_stream_t st) {
@@ -3124,11 +3180,12 @@ extern "C" size_t sc_pointwise_linear_workspace_bytes_ex(const sc_plinx_desc* d)
   if (!plinx_ok(d) || d->batch <= 0 || d->spatial <= 0) return 0;
   const int omn = plinx_omn((int)(d->c_in / 32), (int)(d->c_out / 32));
   const size_t np = (size_t)omn * 32 * d->c_in + 2 * (size_t)omn * 32;
-  return (size_t)(plinx_bwd_wgs(d) + SC_PMLP_RED_GROUPS) * np * sizeof(float) + 256;
+  return (size_t)(plinx_bwd_wgs(d, true) + SC_PMLP_RED_GROUPS) * np * sizeof(float) + 256;    // (the larger of the two grids)
 }
 
 template <int CI, int CO, int OMN>
-static void launch_plinx_bwd(PlinxArgs g, float* ws, bool want_gx, float* gw, float* gb, float* ggate, sc_stream_t st) {
+static void launch_plinx_bwd(PlinxArgs g, float* ws, bool want_gx, float* gw, float* gb, float* ggate, sc_stream_t st,
+                             bool lean) {
   typedef PlinxDims<CI, OMN> D;
   g.partial = ws;
   float* stage = ws + (size_t)g.n_wg * D::NP;
@@ -3136,7 +3193,8 @@ static void launch_plinx_bwd(PlinxArgs g, float* ws, bool want_gx, float* gw, fl
   const int groups = g.n_wg < SC_PMLP_RED_GROUPS ? g.n_wg : SC_PMLP_RED_GROUPS;
   for (int om0 = 0; om0 < CO; om0 += OMN) {                 // (stream-ordered: the launches share the partial buffer)
     g.do_gx = (want_gx && om0 == 0) ? 1 : 0;
-    SC_LAUNCH((k_plinx_bwd<CI, CO, OMN>), dim3((unsigned)g.n_wg), dim3(256), 0, st, g, om0);
+    if (lean) SC_LAUNCH((k_plinx_bwd<CI, CO, OMN, true>), dim3((unsigned)g.n_wg), dim3(256), 0, st, g, om0);
+    else SC_LAUNCH((k_plinx_bwd<CI, CO, OMN>), dim3((unsigned)g.n_wg), dim3(256), 0, st, g, om0);
     SC_LAUNCH(k_pmlp_reduce1, dim3(nb, (unsigned)groups), dim3(256), 0, st, (const float*)g.partial, g.n_wg, groups, (int)D::NP,
               stage);
     SC_LAUNCH(k_plinx_reduce, dim3(nb), dim3(256), 0, st, (const float*)stage, groups, (int)D::NP, (int)D::oB, (int)D::oG,
@@ -3167,20 +3225,21 @@ extern "C" int sc_pointwise_linear_backward_ex(const sc_plinx_desc* d, const flo
   g.spatial = d->spatial;
   g.tiles_per_sample = (int)(d->spatial / 32);
   g.n_tiles = d->batch * g.tiles_per_sample;
-  g.n_wg = plinx_bwd_wgs(d);
+  const bool want_gx = gx != nullptr;
+  const bool lean = !want_gx && d->flags == 0 && !gate;    // the weight / bias gradient alone: k_plinx_bwd<.., LEAN>
+  g.n_wg = plinx_bwd_wgs(d, lean);
   sc_stream_t st = (sc_stream_t)stream;
   float* ws = (float*)workspace;
-  const bool want_gx = gx != nullptr;
   switch ((int)(d->c_in / 32) * 10 + (int)(d->c_out / 32)) {
-    case 11: launch_plinx_bwd<1, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 12: launch_plinx_bwd<1, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 14: launch_plinx_bwd<1, 4, 4>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 21: launch_plinx_bwd<2, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 22: launch_plinx_bwd<2, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 24: launch_plinx_bwd<2, 4, 4>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 41: launch_plinx_bwd<4, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    case 42: launch_plinx_bwd<4, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
-    default: launch_plinx_bwd<4, 4, 2>(g, ws, want_gx, gw, gbias, ggate, st); break;
+    case 11: launch_plinx_bwd<1, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 12: launch_plinx_bwd<1, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 14: launch_plinx_bwd<1, 4, 4>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 21: launch_plinx_bwd<2, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 22: launch_plinx_bwd<2, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 24: launch_plinx_bwd<2, 4, 4>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 41: launch_plinx_bwd<4, 1, 1>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    case 42: launch_plinx_bwd<4, 2, 2>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
+    default: launch_plinx_bwd<4, 4, 2>(g, ws, want_gx, gw, gbias, ggate, st, lean); break;
   }
   return sc_check_launch("k_plinx_bwd");
 }

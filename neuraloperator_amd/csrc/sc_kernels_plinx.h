@@ -130,13 +130,19 @@ struct PlinxDims {
 };
 
 // OM0 = first output tile whose weight gradient this launch owns (runtime), OMN = how many (template)
-template <int CI, int CO, int OMN>
-SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 1)
+// two workgroups per unit where four accumulator tiles and a 16 KB table leave room (<= 64 channels each way: the weight
+// gradient of the metric block's linear skip runs through <2, 2, 2>): the second wave's loads wait behind the first's products
+// LEAN = the weight / bias gradient alone with no option set (gx == NULL, flags == 0, no gate: what is left of the metric
+// block's linear skip once its data path rides in k_pmlp_bwd<.., LIN>): the options fold away at compile time, the W^T
+// table is not built, and two workgroups per unit fit where four accumulator tiles leave room.
+#define SC_PLX_BWD_OCC(CI, CO, OMN, LEAN) (((LEAN) && (CI) * (OMN) <= 4) ? 2 : 1)
+template <int CI, int CO, int OMN, bool LEAN = false>
+SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, SC_PLX_BWD_OCC(CI, CO, OMN, LEAN))
 k_plinx_bwd(PlinxArgs g, int om0) {
   typedef PlinxDims<CI, OMN> D;
   constexpr int C_IN = 32 * CI, C_OUT = 32 * CO, TS = 32 * 33, NW = 4, NT = 256;
   static_assert((CI * CO * 16 * 64 + NW * 2 * TS + D::NP + C_OUT) * 4 <= 160 * 1024, "LDS budget");
-  SC_SHARED float AT[CI * CO * 16 * 64];                  // W^T as the A operand, K in accumulator row order
+  SC_SHARED float AT[LEAN ? 64 : CI * CO * 16 * 64];      // W^T as the A operand, K in accumulator row order
   SC_SHARED float scr[NW * 2 * TS];
   SC_SHARED float red[D::NP];
   SC_SHARED float GT[C_OUT];
@@ -144,7 +150,7 @@ k_plinx_bwd(PlinxArgs g, int om0) {
   const int w = SC_UNIFORM(tid >> 6);
   float* TA = scr + w * 2 * TS;
   float* TB = TA + TS;
-  const bool do_gx = g.do_gx != 0;
+  const bool do_gx = !LEAN && g.do_gx != 0;
   if (do_gx) {
     for (int i = tid; i < CI * CO * 16 * 64; i += NT) {
       const int l = i & 63, v = (i >> 6) & 15, om = (i >> 10) % CO, ci = (i >> 10) / CO;
@@ -154,8 +160,8 @@ k_plinx_bwd(PlinxArgs g, int om0) {
   for (int i = tid; i < D::NP; i += NT) red[i] = 0.f;
   for (int i = tid; i < C_OUT; i += NT) GT[i] = g.gate ? g.gate[i] : 0.f;
   SC_SYNC();
-  const bool xact = (g.flags & SC_PLX_XACT) != 0, pro = (g.flags & SC_PLX_PRO) != 0, xgrad = (g.flags & SC_PLX_XGRAD) != 0;
-  const bool gated = g.gate != nullptr;
+  const bool xact = !LEAN && (g.flags & SC_PLX_XACT) != 0, pro = !LEAN && (g.flags & SC_PLX_PRO) != 0;
+  const bool xgrad = !LEAN && (g.flags & SC_PLX_XGRAD) != 0, gated = !LEAN && g.gate != nullptr;
   const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
   const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
   sc_f32x16 aW[OMN][CI];
@@ -235,8 +241,8 @@ k_plinx_bwd(PlinxArgs g, int om0) {
         float ad[16], xv[16];                              // requested ahead of the products that hide them
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        if (ads) {
-#pragma unroll
+        if (ads && !xgrad) {                               // (both at once: the addend is requested behind the products --
+#pragma unroll                                             //  sixteen registers less at the kernel's widest point)
           for (int v = 0; v < 16; ++v) ad[v] = SC_LOAD_STREAM(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
         }
         if (xgrad) {
@@ -252,6 +258,10 @@ k_plinx_bwd(PlinxArgs g, int om0) {
             for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc, AT[((ci * CO + om) * 16 + v) * 64 + ln], gz[om][v]);
             SC_SCHED_BARRIER();
           }
+        if (ads && xgrad) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) ad[v] = SC_LOAD_STREAM(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+        }
         if (ads) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) acc[v] += ad[v];

@@ -108,12 +108,16 @@ def test_backward(lib, ci, co, flags, gated, addend):
     assert rel_l2(gb.numpy(), gz.sum((0, 2)).numpy()) < TOL
     if gated:
         assert rel_l2(gsk.numpy(), sd.grad.numpy()) < TOL and rel_l2(ggt.numpy(), gd.grad.numpy()) < TOL
-    # the weight gradients alone (gx = NULL): same bits
+    # the weight gradients alone (gx = NULL): same bits -- except for the plain map (no option, no gate), which takes the LEAN
+    # instantiation on twice the workgroups (another order of the partial sums)
     gw2, gb2 = torch.full_like(w, float("nan")), torch.full((co,), float("nan"))
     ggt2 = torch.full((co,), float("nan")) if gated else None
     lib.pointwise_linear_backward_ex(B, ci, co, S, flags & ~XGRAD, p(x), p(w), p(gout), p(pre), 0, p(skip), p(gate), 0, 0, p(gw2),
                                      p(gb2), 0, p(ggt2), p(ws), 0)
-    assert torch.equal(gw2, gw) and torch.equal(gb2, gb) and (not gated or torch.equal(ggt2, ggt))
+    if (flags & ~XGRAD) == 0 and not gated:
+        assert rel_l2(gw2.numpy(), gw.numpy()) < 1e-6 and rel_l2(gb2.numpy(), gb.numpy()) < 1e-6
+    else:
+        assert torch.equal(gw2, gw) and torch.equal(gb2, gb) and (not gated or torch.equal(ggt2, ggt))
 
 
 @pytest.mark.parametrize("chans", [(128, 64, 128), (128, 128, 128), (64, 128, 64)], ids=str)

@@ -222,3 +222,48 @@ def test_block_pass_stores_the_derivative_and_the_backward_multiplies_by_it(lib,
     with pytest.raises(_lib.EngineError):                # the derivative buffer is required
         lib.pointwise_mlp_backward(B, c, ch, c, S, _lib.SC_ACT_GELU_DGRAD, p(a[0]), p(w1), p(b1), p(w2), p(b2), p(x), p(gt), p(gout),
                                    p(gx), p(gw1), p(gb1), p(gw2), p(gb2), p(acc), p(ggt), p(wsb), 0)
+
+
+@pytest.mark.parametrize("chans", [(64, 32), (32, 32)], ids=str)
+@pytest.mark.parametrize("act", [_lib.SC_ACT_GELU_DGRAD, _lib.SC_ACT_GELU, _lib.SC_ACT_NONE])
+def test_block_backward_with_the_linear_skip_riding_along(lib, chans, act):
+    """sc_pointwise_block_backward (round 6: k_pmlp_bwd<.., LIN>) against the two passes it replaces -- the MLP pass
+    (sc_pointwise_mlp_backward_ex) and the linear skip's backward with the soft-gating gradient as its addend
+    (sc_pointwise_linear_backward): gz and the MLP's parameter gradients to the bit, gin = W_s^T gz + gate (.) g_z up to the
+    order of its additions; the skip's weight gradient from sc_pointwise_linear_backward_ex(gx = NULL) to the bit."""
+    c, ch = chans
+    g = torch.Generator().manual_seed(c + ch + act)
+    B, S = 2, 96
+    mk = lambda *sh: torch.randn(*sh, generator=g)
+    x, conv, gout = mk(B, c, S), mk(B, c, S), mk(B, c, S)
+    ws, w1, w2 = mk(c, c) / c ** 0.5, mk(ch, c) / c ** 0.5, mk(c, ch) / ch ** 0.5
+    bs, b1, b2, gt = mk(c), mk(ch), mk(c), mk(c)
+    p = lambda t: 0 if t is None else t.data_ptr()
+    y, out = torch.empty(B, c, S), torch.empty(B, c, S)
+    pre = torch.empty(B, c, S) if act else None
+    lib.pointwise_block_forward(B, c, ch, S, act, p(conv), p(x), p(ws), p(bs), p(w1), p(b1), p(w2), p(b2), p(gt), p(y), p(pre), p(out), 0)
+    new = lambda t: torch.full_like(t, float("nan"))
+    wsb = torch.empty(lib.pointwise_mlp_workspace_bytes(B, c, ch, c, S, 1), dtype=torch.uint8)
+    # the two passes
+    gz0, acc, gin0 = new(x), new(x), new(x)
+    a = [new(t) for t in (w1, b1, w2, b2, gt)]
+    lib.pointwise_mlp_backward(B, c, ch, c, S, act, p(y), p(w1), p(b1), p(w2), p(b2), p(x), p(gt), p(gout), p(gz0), p(a[0]), p(a[1]),
+                               p(a[2]), p(a[3]), p(acc), p(a[4]), p(wsb), 0, x_pre=p(pre))
+    glw0, glb0 = new(ws), new(bs)
+    wl = torch.empty(lib.pointwise_linear_workspace_bytes(B, c, c, S), dtype=torch.uint8)
+    lib.pointwise_linear_backward(B, c, c, S, p(x), p(ws), p(gz0), p(gin0), p(glw0), p(glb0), p(wl), 0, addend=p(acc))
+    # the fused pass + the skip's weight gradient
+    assert lib.pointwise_block_backward_supported(B, c, ch, S)
+    gz1, gin1 = new(x), new(x)
+    d = [new(t) for t in (w1, b1, w2, b2, gt)]
+    lib.pointwise_block_backward(B, c, ch, S, act, p(y), p(pre), p(x), p(ws), p(w1), p(b1), p(w2), p(b2), p(gt), p(gout), p(gz1), p(gin1),
+                                 p(d[0]), p(d[1]), p(d[2]), p(d[3]), p(d[4]), p(wsb), 0)
+    glw1, glb1 = new(ws), new(bs)
+    wx = torch.empty(lib.pointwise_linear_workspace_bytes_ex(B, c, c, S), dtype=torch.uint8)
+    lib.pointwise_linear_backward_ex(B, c, c, S, 0, p(x), p(ws), p(gz1), 0, 0, 0, 0, 0, 0, p(glw1), p(glb1), 0, 0, p(wx), 0)
+    assert torch.equal(gz1, gz0)
+    for u, v in zip(d, a):
+        assert torch.equal(u, v)
+    assert rel_l2(gin1.numpy(), gin0.numpy()) < 1e-6
+    assert rel_l2(glw1.numpy(), glw0.numpy()) < 1e-6 and rel_l2(glb1.numpy(), glb0.numpy()) < 1e-6
+    assert not lib.pointwise_block_backward_supported(B, 64, 64, S)                    # tables + scratch + gradients > 160 KB
