@@ -315,11 +315,17 @@ class FusedBlockFn(torch.autograd.Function):
                 # round 6: channel counts without a one-pass kernel (hidden 128, 128 channels): the same block as engine
                 # passes of csrc/sc_kernels_plinx.h -- skip, Fourier layer with the add + GELU in its store path, fc1, fc2
                 # with the GELUs and the soft-gating skip in their load / store paths; nothing elementwise in between
-                skip = torch.empty_like(x)
-                lib.pointwise_linear_forward_ex(b, c, c, s, 0, p(x), p(lwc), p(lbc), 0, 0, p(skip), 0, st)
-                lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), p(skip), p(pre), act, p(y),
+                # the linear skip and the Fourier layer's add + GELU as ONE pass: y = act(W_s x + b_s + 1 (.) conv) through the
+                # map's gated-skip path (gate = ones, skip = the plain spectral convolution) -- the skip tensor is never
+                # written and, where the transform has no fused epilogue (two-pass routes: configs[4]'s 1024^2), the
+                # streaming k_epilogue pass goes too: 6 tensor-sized reads / writes -> 4
+                conv = torch.empty_like(x)
+                lib.layer_forward_ex(plan, L, p(x), torch.view_as_real(cwc).data_ptr(), p(cbf), 0, 0, _lib.SC_ACT_NONE, p(conv),
                                      p(xhat), p(ws), st)
-                del skip
+                ones = torch.ones(c, dtype=torch.float32, device=dev)
+                lib.pointwise_linear_forward_ex(b, c, c, s, 0 if last else _lib.SC_PLX_ACT, p(x), p(lwc), p(lbc), p(conv), p(ones),
+                                                p(y), p(pre), st)
+                del conv
                 hpre = torch.empty((b, ch, *spatial), dtype=torch.float32, device=dev)
                 zpre = None if last else torch.empty_like(x)
                 lib.pointwise_linear_forward_ex(b, c, ch, s, 0, p(y), p(w1c), p(b1c), 0, 0, p(hpre), 0, st)
