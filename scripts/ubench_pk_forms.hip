@@ -75,6 +75,30 @@ __global__ void __launch_bounds__(512) k_forms(unsigned* counters, int iters, in
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, hb, acc[t], 0, 0, 0);
       }
+    } else if (with_mfma == 6) {                          // v_mfma_f32_16x16x32_f16 (gfx950)
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      h8 ha, hb;
+      for (int e = 0; e < 8; ++e) { ha[e] = (_Float16)(0.01f * (lane + e)); hb[e] = (_Float16)(0.02f * (lane - e)); }
+      for (int it = 0; it < iters * 24; ++it) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[t], 0, 0, 0);
+      }
+    } else if (with_mfma == 7) {                          // v_mfma_i32_16x16x64_i8 (gfx950)
+      typedef int i4v __attribute__((ext_vector_type(4)));
+      i4v ia = {lane, lane + 1, lane + 2, lane + 3}, ib = {lane * 3, 7, lane, 11}, iacc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      for (int it = 0; it < iters * 24; ++it) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) iacc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ia, ib, iacc[t], 0, 0, 0);
+      }
+      acc[0][0] = (float)(iacc[0][0] + iacc[1][1] + iacc[2][2] + iacc[3][3]);
+    } else if (with_mfma == 8) {                          // v_mfma_f32_16x16x16_bf16 (the gfx942-era 16 x 16 bf16 shape, 4 values per lane)
+      typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+      b4 ba, bb;
+      for (int e = 0; e < 4; ++e) { ba[e] = (__bf16)(0.01f * (lane + e)); bb[e] = (__bf16)(0.02f * (lane - e)); }
+      for (int it = 0; it < iters * 24; ++it) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short __attribute__((ext_vector_type(4))), ba), __builtin_bit_cast(short __attribute__((ext_vector_type(4))), bb), acc[t], 0, 0, 0);
+      }
     } else if (with_mfma == 5) {                          // v_mfma_f32_32x32x16_bf16 (gfx950)
       typedef float f16v __attribute__((ext_vector_type(16)));
       f16v big = {0};
@@ -137,7 +161,7 @@ int main(int argc, char** argv) {
   hipMemcpy(h.data(), cnt, h.size() * 4, hipMemcpyDeviceToHost);
   const char* ops[3] = {"mul", "add", "fma"}; const char code[4] = {'L', 'X', 'N', 'H'};      // (sel, hi): (0,0) L, (1,0) X, (0,1) N, (1,1) H
   long total = 0;
-  printf("grid %d x 512 threads, %d iterations per test wave, matrix waves run %s\n", grid, iters, with_mfma == 1 ? "v_mfma_f32_16x16x32_bf16" : with_mfma == 2 ? "v_mfma_f32_32x32x2_f32" : with_mfma == 3 ? "v_mfma_f32_16x16x4_f32" : with_mfma == 4 ? "v_mfma_f32_16x16x16_f16" : with_mfma == 5 ? "v_mfma_f32_32x32x16_bf16" : "vector ALU work");
+  printf("grid %d x 512 threads, %d iterations per test wave, matrix waves run %s\n", grid, iters, with_mfma == 1 ? "v_mfma_f32_16x16x32_bf16" : with_mfma == 2 ? "v_mfma_f32_32x32x2_f32" : with_mfma == 3 ? "v_mfma_f32_16x16x4_f32" : with_mfma == 4 ? "v_mfma_f32_16x16x16_f16" : with_mfma == 5 ? "v_mfma_f32_32x32x16_bf16" : with_mfma == 6 ? "v_mfma_f32_16x16x32_f16" : with_mfma == 7 ? "v_mfma_i32_16x16x64_i8" : with_mfma == 8 ? "v_mfma_f32_16x16x16_bf16" : "vector ALU work");
   for (int op = 0; op < 3; ++op)
     for (int F = 0; F < 16; ++F) {
       const int s0 = F & 1, s1 = (F >> 1) & 1, h0 = (F >> 2) & 1, h1 = (F >> 3) & 1;
