@@ -4,7 +4,8 @@ a packed-fp32 instruction with operand selects op_sel:[0,1,.].
 Round 6 (sc_kernels_fft3mx.h F3_NOTE_PK_MUL_LX): on MI355X `v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32` with
 op_sel:[0,1,.] -- the low lane takes the LOW half of src0 and the HIGH half of src1 -- return 0 in the low result of lanes
 48-63 while another wave of the same SIMD executes v_mfma_f32_16x16x32_bf16 (scripts/ubench_pk_forms.hip: 18 % of such
-executions; no other matrix instruction of the library, no other op_sel combination).  That was round 5's
+executions; no other matrix instruction of the library -- 16x16x32_f16 and, rarely, i32_16x16x64_i8 do the same and are
+watched too -- and no other op_sel combination).  That was round 5's
 "non-repeatable k_fft2d_inv_mx<64>": hipcc had emitted the group-twiddle product of its column task in that encoding.
 The kernels that run this matrix instruction are persistent with two workgroups per compute unit, i.e. the other wave of
 the SIMD is the SAME kernel: their own code must be free of the encoding.  (Nothing else of the engine runs beside them:
