@@ -11,6 +11,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 
 #ifndef SC_EMU
 // --------------------------------------------------------------------------- HIP (product)
@@ -563,52 +564,114 @@ SC_HD cf32 cf_conj(const cf32 a) { return cf_make(a.x, -a.y); }
 SC_HD cf32 cf_mul_mi(const cf32 a) { return cf_make(a.y, -a.x); }
 SC_HD cf32 cf_mul_pi(const cf32 a) { return cf_make(-a.y, a.x); }
 
+// base + a 32-bit BYTE offset of the lane: with a wave-uniform base the access takes the scalar-base form
+// (global_load_dword v, v_off, s[base:base+1]) -- written as base + 4 * (zero-extended index) the compiler cannot prove
+// that the shifted offset still fits in 32 bits and spends a v_lshl_add_u64 per access (217 per tile in k_pblock_fwd)
+template <typename T>
+SC_HD T* sc_at(T* base, const uint32_t byte_off) {
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+  return (T*)((B*)base + byte_off);
+}
+
 // --------------------------------------------------------------------------- activation of the block epilogue
 // erfc(|x|) by A&S 7.1.26: (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p |x|); |error| <= 1.5e-7 absolute.
-SC_DEVICE float sc_erfc_abs_fast(const float x) {
-  const float ax = fabsf(x);
+//
+// Round 6, second pass: the instruction count of the activation IS the run time of the fp32 pointwise kernels -- every
+// vector instruction runs in front of their matrix instructions, not beside them (DESIGN 3.16 b), and k_pblock_fwd held
+// 3400 vector instructions for 128 MFMAs.  Two changes, same function:
+//   * t = v_rcp_f32 + one Newton step (3 instructions, <= 1 ulp) instead of the correctly rounded quotient of __frcp_rn
+//     (v_div_scale x 2, v_rcp, 5 fma / mul, v_div_fmas, v_div_fixup: 11); exp(-x^2) = v_exp_f32(x^2 (-log2 e)) as before;
+//   * the PAIR forms (sc_gelu_pair / sc_gelu_both_pair) evaluate two values with packed-fp32 instructions: the
+//     polynomial, the Newton step and the products of two values per instruction; the two transcendentals and the sign
+//     select stay per value.  12 / 13 instructions per value instead of 27 / 33.
+// Every operation is an IEEE fma / mul / add or one of the two transcendentals, in the same order in the scalar and the
+// pair form: the bits do not depend on which form a kernel uses (tests/test_emu_pmlp.py compares routes bit for bit).
+// 1 + erf(z) = erfc(|z|) for z < 0 and 2 - erfc(|z|) for z >= 0: the negative tail is taken from erfc DIRECTLY, so it does
+// not cancel (1 + erf loses every digit for v < -4) -- as fma(-cs, q, 1 + cs) with cs = copysign(1, v), exact.
+#define SC_GELU_P   0.23164189298270723f      // 0.3275911 / sqrt 2: t = 1 / (1 + P |v|)
+#define SC_GELU_E  (-0.72134752044448170368f) // -log2(e) / 2: exp(-v^2 / 2) = exp2(v v E)
+#define SC_GELU_D   0.39894228040143267794f   // 1 / sqrt(2 pi)
 #ifndef SC_EMU
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  const float e = __expf(-ax * ax);
+SC_DEVICE float sc_rcp_nr(const float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+SC_DEVICE float sc_exp2_hw(const float s) { return __builtin_amdgcn_exp2f(s); }
 #else
-  const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
-  const float e = expf(-ax * ax);
+inline float sc_rcp_nr(const float d) { return 1.f / d; }
+inline float sc_exp2_hw(const float s) { return exp2f(s); }
 #endif
+// erfc(|v| / sqrt 2) and exp(-v^2 / 2)
+SC_DEVICE void sc_erfc_core(const float v, float& q, float& e) {
+  const float t = sc_rcp_nr(fmaf(fabsf(v), SC_GELU_P, 1.f));
+  e = sc_exp2_hw((v * v) * SC_GELU_E);
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
-  return p * t * e;
+  q = (p * t) * e;
 }
-// gelu(v) = 0.5 v (1 + erf(v / sqrt 2)).  1 + erf(z) = erfc(|z|) for z < 0 and 2 - erfc(|z|) for z >= 0: the
-// negative tail is taken from erfc DIRECTLY, so it does not cancel (1 + erf loses every digit for v < -4).
-// Absolute error of the activation <= 0.5 |v| 1.5e-7 (+ fp32 round-off); both engine paths -- the fused store path and
-// the stand-alone k_epilogue pass -- evaluate this one function, so a shape change never changes the activation's bits.
-SC_DEVICE float sc_erf_fast(const float x) { return copysignf(1.f - sc_erfc_abs_fast(x), x); }
+// gelu(v) = 0.5 v (1 + erf(v / sqrt 2)).  Absolute error of the activation <= 0.5 |v| 1.5e-7 (+ fp32 round-off); every
+// engine path -- the fused store paths, the pointwise kernels, the stand-alone k_epilogue pass -- evaluates this one
+// function, so a shape change never changes the activation's bits.
 SC_DEVICE float sc_gelu(const float v) {
-  const float q = sc_erfc_abs_fast(v * 0.70710678118654752440f);
-  return 0.5f * v * (v < 0.f ? q : 2.f - q);
+  float q, e;
+  sc_erfc_core(v, q, e);
+  const float cs = copysignf(1.f, v);
+  const float h2 = 0.5f * fmaf(-cs, q, 1.f + cs);          // (1 + erf(v / sqrt 2)) / 2
+  return v * h2;
 }
 // gelu(v) AND its derivative Phi(v) + v phi(v) from ONE evaluation of the two transcendentals (round 6): the exponential
-// of the erfc approximation at z = |v| / sqrt 2 is exp(-v^2 / 2) -- the density's own -- so the derivative costs four
-// more vector instructions instead of a second reciprocal + two exponentials.  On MI355X every vector instruction of the
-// fp32 pointwise kernels runs IN FRONT OF their matrix instructions, not beside them (DESIGN 3.16 b).
+// of the erfc approximation at z = |v| / sqrt 2 is exp(-v^2 / 2) -- the density's own -- so the derivative costs two
+// more vector instructions instead of a second reciprocal + two exponentials.
 SC_DEVICE void sc_gelu_both(const float v, float& gelu, float& grad) {
-  const float ax = fabsf(v) * 0.70710678118654752440f;
-#ifndef SC_EMU
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  const float e = __expf(-ax * ax);
-#else
-  const float t = 1.f / fmaf(0.3275911f, ax, 1.f);
-  const float e = expf(-ax * ax);
-#endif
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float q = p * t * e;                               // erfc(|v| / sqrt 2)
-  const float two_cdf = v < 0.f ? q : 2.f - q;             // 1 + erf(v / sqrt 2)
-  gelu = 0.5f * v * two_cdf;
-  grad = fmaf(v, 0.39894228040143267794f * e, 0.5f * two_cdf);
+  float q, e;
+  sc_erfc_core(v, q, e);
+  const float cs = copysignf(1.f, v);
+  const float h2 = 0.5f * fmaf(-cs, q, 1.f + cs);
+  gelu = v * h2;
+  grad = fmaf(v, SC_GELU_D * e, h2);
 }
+// two values at a time
+#ifndef SC_EMU
+SC_DEVICE void sc_erfc_core2(const sc_f2 v, sc_f2& q, sc_f2& e) {
+  const sc_f2 av = {fabsf(v.x), fabsf(v.y)};
+  const sc_f2 one = {1.f, 1.f};
+  const sc_f2 d = __builtin_elementwise_fma(av, sc_f2{SC_GELU_P, SC_GELU_P}, one);
+  const sc_f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const sc_f2 t = __builtin_elementwise_fma(__builtin_elementwise_fma(-d, r, one), r, r);
+  const sc_f2 s = (v * v) * sc_f2{SC_GELU_E, SC_GELU_E};
+  e = sc_f2{__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)};
+  sc_f2 p = __builtin_elementwise_fma(sc_f2{1.061405429f, 1.061405429f}, t, sc_f2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, sc_f2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, sc_f2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, sc_f2{0.254829592f, 0.254829592f});
+  q = (p * t) * e;
+}
+SC_DEVICE void sc_gelu_pair(float& a, float& b) {
+  const sc_f2 v = {a, b};
+  sc_f2 q, e;
+  sc_erfc_core2(v, q, e);
+  const sc_f2 cs = {copysignf(1.f, v.x), copysignf(1.f, v.y)};
+  const sc_f2 h2 = sc_f2{0.5f, 0.5f} * __builtin_elementwise_fma(-cs, q, sc_f2{1.f, 1.f} + cs);
+  const sc_f2 g = v * h2;
+  a = g.x; b = g.y;
+}
+SC_DEVICE void sc_gelu_both_pair(const float va, const float vb, float& ga, float& gb, float& da, float& db) {
+  const sc_f2 v = {va, vb};
+  sc_f2 q, e;
+  sc_erfc_core2(v, q, e);
+  const sc_f2 cs = {copysignf(1.f, v.x), copysignf(1.f, v.y)};
+  const sc_f2 h2 = sc_f2{0.5f, 0.5f} * __builtin_elementwise_fma(-cs, q, sc_f2{1.f, 1.f} + cs);
+  const sc_f2 g = v * h2;
+  const sc_f2 d = __builtin_elementwise_fma(v, sc_f2{SC_GELU_D, SC_GELU_D} * e, h2);
+  ga = g.x; gb = g.y; da = d.x; db = d.y;
+}
+#else
+inline void sc_gelu_pair(float& a, float& b) { a = sc_gelu(a); b = sc_gelu(b); }
+inline void sc_gelu_both_pair(const float va, const float vb, float& ga, float& gb, float& da, float& db) {
+  sc_gelu_both(va, ga, da);
+  sc_gelu_both(vb, gb, db);
+}
+#endif
 

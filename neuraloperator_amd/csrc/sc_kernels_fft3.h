@@ -102,7 +102,7 @@ SC_DEVICE void f3_store_plain(sc_bf16* row, const int lam, const int j, const fl
 //      Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 in erf, i.e. fp32 round-off class for the activation; 14
 //      instructions with v_rcp_f32 / v_exp_f32).  preact is written only with EPI 2 (SC_ACT_NONE + preact is
 //      rejected at the C-ABI, include/sc_engine.h).
-// (sc_erfc_abs_fast / sc_erf_fast / sc_gelu live in sc_device.h: the stand-alone epilogue pass uses them too)
+// (sc_erfc_core / sc_gelu live in sc_device.h: the stand-alone epilogue pass uses them too)
 template <int EPI, typename IO>
 SC_DEVICE void f3_store_epi(IO* row, const float sk, IO* prow, const int lam, const int j, float v) {
   if (EPI >= 1) v += sk;

@@ -72,8 +72,8 @@ k_plinx_fwd(PlinxArgs g) {
   }
   SC_SYNC();
   const bool xact = (g.flags & SC_PLX_XACT) != 0, act = (g.flags & SC_PLX_ACT) != 0, gated = g.gate != nullptr;
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);
 #pragma unroll 1
   for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
     const int64_t b = tile / g.tiles_per_sample;
@@ -86,10 +86,10 @@ k_plinx_fwd(PlinxArgs g) {
     float* ps = g.pre_out ? g.pre_out + b * C_OUT * sp + px0 : nullptr;
     float xr[CI * 16];
 #pragma unroll
-    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(2 * s) * sp, lo_b));
     if (xact) {
 #pragma unroll
-      for (int s = 0; s < CI * 16; ++s) xr[s] = sc_gelu(xr[s]);
+      for (int s = 0; s < CI * 16; s += 2) sc_gelu_pair(xr[s], xr[s + 1]);
     }
     SC_SCHED_BARRIER();
 #pragma unroll
@@ -100,7 +100,7 @@ k_plinx_fwd(PlinxArgs g) {
       float sk[16];
       if (gated) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(sc_at(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       }
 #pragma unroll
       for (int s0 = 0; s0 < S1; s0 += 8) {
@@ -109,14 +109,18 @@ k_plinx_fwd(PlinxArgs g) {
         SC_SCHED_BARRIER();
       }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int r = 32 * om + pmlp_row(v, hq);
-        const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
-        float val = acc[v] + Bv[r];
-        if (gated) val = fmaf(GT[r], sk[v], val);
-        if (ps) SC_STORE_STREAM(ps + ro, val);
-        if (act) val = sc_gelu(val);
-        SC_STORE_STREAM(os + ro, val);
+      for (int v = 0; v < 16; v += 2) {
+        float val[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = 32 * om + pmlp_row(v + u, hq);
+          val[u] = acc[v + u] + Bv[r];
+          if (gated) val[u] = fmaf(GT[r], sk[v + u], val[u]);
+          if (ps) SC_STORE_STREAM(sc_at(ps + (int64_t)(32 * om + pmlp_row(v + u, 0)) * sp, lo_c), val[u]);
+        }
+        if (act) sc_gelu_pair(val[0], val[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) SC_STORE_STREAM(sc_at(os + (int64_t)(32 * om + pmlp_row(v + u, 0)) * sp, lo_c), val[u]);
       }
       SC_SCHED_BARRIER();
     }
@@ -162,8 +166,8 @@ k_plinx_bwd(PlinxArgs g, int om0) {
   SC_SYNC();
   const bool xact = !LEAN && (g.flags & SC_PLX_XACT) != 0, pro = !LEAN && (g.flags & SC_PLX_PRO) != 0;
   const bool xgrad = !LEAN && (g.flags & SC_PLX_XGRAD) != 0, gated = !LEAN && g.gate != nullptr;
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);
   sc_f32x16 aW[OMN][CI];
   float sB[OMN], sG[OMN];
 #pragma unroll
@@ -199,25 +203,30 @@ k_plinx_bwd(PlinxArgs g, int om0) {
       const bool need_sk = gated && (do_gx || mine);
       float pr[16], sk[16];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(sc_at(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       if (pro) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) pr[v] = SC_LOAD_STREAM(prs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+        for (int v = 0; v < 16; ++v) pr[v] = SC_LOAD_STREAM(sc_at(prs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       }
       if (need_sk) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(sc_at(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       }
       SC_SCHED_BARRIER();
       if (pro) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) gz[om][v] *= sc_gelu_grad(pr[v]);
+        for (int v = 0; v < 16; v += 2) {
+          float d0, d1;
+          PMLP_GELU_GRAD2(pr[v], pr[v + 1], d0, d1);
+          gz[om][v] *= d0;
+          gz[om][v + 1] *= d1;
+        }
       }
       if (need_sk) {
         if (do_gx) {
 #pragma unroll
           for (int v = 0; v < 16; ++v)
-            SC_STORE_STREAM(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[32 * om + pmlp_row(v, hq)] * gz[om][v]);
+            SC_STORE_STREAM(sc_at(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c), GT[32 * om + pmlp_row(v, hq)] * gz[om][v]);
         }
         if (mine) {                                        // ggate: row sums of g (.) skip through the wave's LDS patch
 #pragma unroll
@@ -243,11 +252,11 @@ k_plinx_bwd(PlinxArgs g, int om0) {
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
         if (ads && !xgrad) {                               // (both at once: the addend is requested behind the products --
 #pragma unroll                                             //  sixteen registers less at the kernel's widest point)
-          for (int v = 0; v < 16; ++v) ad[v] = SC_LOAD_STREAM(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+          for (int v = 0; v < 16; ++v) ad[v] = SC_LOAD_STREAM(sc_at(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c));
         }
         if (xgrad) {
 #pragma unroll
-          for (int v = 0; v < 16; ++v) xv[v] = SC_LOAD_STREAM(xgs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+          for (int v = 0; v < 16; ++v) xv[v] = SC_LOAD_STREAM(sc_at(xgs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c));
         }
         SC_SCHED_BARRIER();
 #pragma unroll
@@ -260,7 +269,7 @@ k_plinx_bwd(PlinxArgs g, int om0) {
           }
         if (ads && xgrad) {
 #pragma unroll
-          for (int v = 0; v < 16; ++v) ad[v] = SC_LOAD_STREAM(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+          for (int v = 0; v < 16; ++v) ad[v] = SC_LOAD_STREAM(sc_at(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c));
         }
         if (ads) {
 #pragma unroll
@@ -268,10 +277,15 @@ k_plinx_bwd(PlinxArgs g, int om0) {
         }
         if (xgrad) {
 #pragma unroll
-          for (int v = 0; v < 16; ++v) acc[v] *= sc_gelu_grad(xv[v]);
+          for (int v = 0; v < 16; v += 2) {
+            float d0, d1;
+            PMLP_GELU_GRAD2(xv[v], xv[v + 1], d0, d1);
+            acc[v] *= d0;
+            acc[v + 1] *= d1;
+          }
         }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) SC_STORE_STREAM(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
+        for (int v = 0; v < 16; ++v) SC_STORE_STREAM(sc_at(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c), acc[v]);
         SC_SCHED_BARRIER();
       }
     }
@@ -280,10 +294,10 @@ k_plinx_bwd(PlinxArgs g, int om0) {
     for (int ci = 0; ci < CI; ++ci) {
       float xe[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(xs + (int64_t)(32 * ci + 2 * t) * sp + lo_b);
+      for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(32 * ci + 2 * t) * sp, lo_b));
       if (xact) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) xe[t] = sc_gelu(xe[t]);
+        for (int t = 0; t < 16; t += 2) sc_gelu_pair(xe[t], xe[t + 1]);
       }
       SC_WAVE_SYNC();
 #pragma unroll

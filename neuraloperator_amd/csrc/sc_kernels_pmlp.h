@@ -37,10 +37,29 @@
 #define PMLP_GELU(x) ((x) * 0.5f)
 #define PMLP_GELU_GRAD(x) ((x) * 0.25f + 0.5f)
 #define PMLP_GELU_BOTH(x, g, d) do { (g) = (x) * 0.5f; (d) = (x) * 0.25f + 0.5f; } while (0)
+#define PMLP_GELU_BOTH2(x0, x1, g0, g1, d0, d1) do { PMLP_GELU_BOTH(x0, g0, d0); PMLP_GELU_BOTH(x1, g1, d1); } while (0)
 #else
 #define PMLP_GELU(x) sc_gelu(x)
 #define PMLP_GELU_GRAD(x) sc_gelu_grad(x)
 #define PMLP_GELU_BOTH(x, g, d) sc_gelu_both((x), (g), (d))
+#define PMLP_GELU_BOTH2(x0, x1, g0, g1, d0, d1) sc_gelu_both_pair((x0), (x1), (g0), (g1), (d0), (d1))
+#endif
+#ifdef SC_PMLP_ABL_NOGELU
+#define PMLP_GELU2(a, b) do { (a) *= 0.5f; (b) *= 0.5f; } while (0)
+#else
+#define PMLP_GELU2(a, b) sc_gelu_pair((a), (b))
+#endif
+#ifdef SC_PMLP_ABL_NOLOAD
+#define PMLP_LOAD_PLAIN(ptr) ((float)((uintptr_t)(ptr) & 1023u) * 1e-3f)
+#else
+#define PMLP_LOAD_PLAIN(ptr) (*(ptr))
+#endif
+// gelu'(x0), gelu'(x1) (the two activations of the pair form are dead code here)
+#define PMLP_GELU_GRAD2(x0, x1, d0, d1) do { float g0_, g1_; PMLP_GELU_BOTH2((x0), (x1), g0_, g1_, (d0), (d1)); } while (0)
+#ifdef SC_PMLP_ABL_NOLOAD
+#define PMLP_LOAD(ptr) ((float)((uintptr_t)(ptr) & 1023u) * 1e-3f)
+#else
+#define PMLP_LOAD(ptr) SC_LOAD_STREAM(ptr)
 #endif
 #ifdef SC_PMLP_ABL_NOSTORE
 #define PMLP_STORE(ptr, val) do { if ((val) == 12345.678f) SC_STORE_STREAM((ptr), (val)); } while (0)
@@ -97,8 +116,8 @@ k_pmlp_fwd(PmlpArgs g) {
   SC_SYNC();
   // addressing: a wave-uniform base (sample, first pixel of the tile, channel row of the step) + ONE 32-bit lane offset
   // per operand layout, so the ~100 loads / stores of a tile share two address registers
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
 #pragma unroll 1
   for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
     const int64_t b = tile / g.tiles_per_sample;
@@ -110,7 +129,7 @@ k_pmlp_fwd(PmlpArgs g) {
     const int hq = sc_opaque(half);                        // bias / gate reads are loop invariant: keep them in the loop
     float xr[CI * 16];
 #pragma unroll
-    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(2 * s) * sp, lo_b));
     SC_SCHED_BARRIER();
     sc_f32x16 acc1[CH];
 #pragma unroll
@@ -124,9 +143,12 @@ k_pmlp_fwd(PmlpArgs g) {
         SC_SCHED_BARRIER();
       }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        acc1[hm][v] = sc_gelu(acc1[hm][v] + B1[32 * hm + pmlp_row(v, hq)]);
-        if ((v & 3) == 3) SC_SCHED_BARRIER();              // four evaluations in flight, not sixteen
+      for (int v = 0; v < 16; v += 2) {
+        float h0 = acc1[hm][v] + B1[32 * hm + pmlp_row(v, hq)], h1 = acc1[hm][v + 1] + B1[32 * hm + pmlp_row(v + 1, hq)];
+        sc_gelu_pair(h0, h1);
+        acc1[hm][v] = h0;
+        acc1[hm][v + 1] = h1;
+        if ((v & 3) == 2) SC_SCHED_BARRIER();              // four evaluations in flight, not sixteen
       }
     }
 #pragma unroll
@@ -134,7 +156,7 @@ k_pmlp_fwd(PmlpArgs g) {
       float sk[16];
       if (GATE) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+        for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(sc_at(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       }
       sc_f32x16 acc2;
 #pragma unroll
@@ -148,13 +170,18 @@ k_pmlp_fwd(PmlpArgs g) {
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int r = 32 * om + pmlp_row(v, hq);
-        float val = acc2[v] + B2[r];
-        if (GATE) val = fmaf(GT[r], sk[v], val);
-        if (ACT == 1) val = sc_gelu(val);
-        SC_STORE_STREAM(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, val);
-        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      for (int v = 0; v < 16; v += 2) {
+        float val[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = 32 * om + pmlp_row(v + u, hq);
+          val[u] = acc2[v + u] + B2[r];
+          if (GATE) val[u] = fmaf(GT[r], sk[v + u], val[u]);
+        }
+        if (ACT == 1) sc_gelu_pair(val[0], val[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) SC_STORE_STREAM(sc_at(os + (int64_t)(32 * om + pmlp_row(v + u, 0)) * sp, lo_c), val[u]);
+        if ((v & 3) == 2) SC_SCHED_BARRIER();
       }
     }
   }
@@ -219,8 +246,8 @@ k_pblock_fwd(PblockArgs g) {
     GT[i] = g.gate[i];
   }
   SC_SYNC();
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
 #pragma unroll 1
   for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
     const int64_t b = tile / g.tiles_per_sample;
@@ -235,7 +262,7 @@ k_pblock_fwd(PblockArgs g) {
     const int hq = sc_opaque(half);
     float xr[CC * 16];
 #pragma unroll
-    for (int s = 0; s < CC * 16; ++s) xr[s] = xs[(int64_t)(2 * s) * sp + lo_b];   // ordinary loads: read again below
+    for (int s = 0; s < CC * 16; ++s) xr[s] = PMLP_LOAD_PLAIN(sc_at(xs + (int64_t)(2 * s) * sp, lo_b));   // ordinary loads: read again below
     SC_SCHED_BARRIER();
     // ---- linear skip + conv -> s, y (both stored); y stays in the accumulator registers
     sc_f32x16 yv[CC];
@@ -243,32 +270,37 @@ k_pblock_fwd(PblockArgs g) {
     for (int om = 0; om < CC; ++om) {
       float cv[16];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) cv[v] = SC_LOAD_STREAM(cs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+      for (int v = 0; v < 16; ++v) cv[v] = PMLP_LOAD(sc_at(cs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
 #pragma unroll
       for (int v = 0; v < 16; ++v) yv[om][v] = 0.f;
 #pragma unroll
       for (int s0 = 0; s0 < S1; s0 += 8) {
 #pragma unroll
-        for (int s = s0; s < s0 + 8; ++s) sc_mfma_32x32x2(yv[om], AS[(om * S1 + s) * 64 + lane], xr[s]);
+        for (int s = s0; s < s0 + 8; ++s) PMLP_MFMA(yv[om], AS[(om * S1 + s) * 64 + lane], xr[s]);
         SC_SCHED_BARRIER();
       }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
-        float sv = cv[v] + (yv[om][v] + BS[32 * om + pmlp_row(v, hq)]);   // conv + skip, as the epilogue adds them
+      for (int v = 0; v < 16; v += 2) {
+        const int64_t ro0 = (int64_t)(32 * om + pmlp_row(v, 0)) * sp, ro1 = (int64_t)(32 * om + pmlp_row(v + 1, 0)) * sp;
+        float s0 = cv[v] + (yv[om][v] + BS[32 * om + pmlp_row(v, hq)]);   // conv + skip, as the epilogue adds them
+        float s1 = cv[v + 1] + (yv[om][v + 1] + BS[32 * om + pmlp_row(v + 1, hq)]);
         if (ACT == 1) {
           if (g.pre_is_grad) {                             // (wave-uniform) gelu and gelu' from one evaluation
-            float dv;
-            sc_gelu_both(sv, sv, dv);
-            SC_STORE_STREAM(ps + ro, dv);
+            float d0, d1;
+            PMLP_GELU_BOTH2(s0, s1, s0, s1, d0, d1);
+            PMLP_STORE(sc_at(ps + ro0, lo_c), d0);
+            PMLP_STORE(sc_at(ps + ro1, lo_c), d1);
           } else {
-            SC_STORE_STREAM(ps + ro, sv);
-            sv = sc_gelu(sv);
+            PMLP_STORE(sc_at(ps + ro0, lo_c), s0);
+            PMLP_STORE(sc_at(ps + ro1, lo_c), s1);
+            PMLP_GELU2(s0, s1);
           }
         }
-        SC_STORE_STREAM(ys + ro, sv);
-        yv[om][v] = sv;
-        if ((v & 3) == 3) SC_SCHED_BARRIER();
+        PMLP_STORE(sc_at(ys + ro0, lo_c), s0);
+        PMLP_STORE(sc_at(ys + ro1, lo_c), s1);
+        yv[om][v] = s0;
+        yv[om][v + 1] = s1;
+        if ((v & 3) == 2) SC_SCHED_BARRIER();
       }
     }
     // ---- hidden layer: h = gelu(W1 y + b1), y as the B operand straight from its accumulators
@@ -282,13 +314,16 @@ k_pblock_fwd(PblockArgs g) {
 #pragma unroll
         for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
-          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc1[hm], A1[((hm * CC + om) * 16 + v) * 64 + lane], yv[om][v]);
+          for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(acc1[hm], A1[((hm * CC + om) * 16 + v) * 64 + lane], yv[om][v]);
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        acc1[hm][v] = sc_gelu(acc1[hm][v] + B1[32 * hm + pmlp_row(v, hq)]);
-        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      for (int v = 0; v < 16; v += 2) {
+        float h0 = acc1[hm][v] + B1[32 * hm + pmlp_row(v, hq)], h1 = acc1[hm][v + 1] + B1[32 * hm + pmlp_row(v + 1, hq)];
+        PMLP_GELU2(h0, h1);
+        acc1[hm][v] = h0;
+        acc1[hm][v + 1] = h1;
+        if ((v & 3) == 2) SC_SCHED_BARRIER();
       }
     }
     // ---- output layer + soft-gating skip + closing activation (as k_pmlp_fwd)
@@ -297,7 +332,7 @@ k_pblock_fwd(PblockArgs g) {
       float sk[16];
 #pragma unroll
       for (int v = 0; v < 16; ++v)                                      // second (last) read of x: out of L2
-        sk[v] = SC_LOAD_STREAM(xs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+        sk[v] = PMLP_LOAD(sc_at(xs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       sc_f32x16 acc2;
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc2[v] = 0.f;
@@ -306,16 +341,21 @@ k_pblock_fwd(PblockArgs g) {
 #pragma unroll
         for (int v0 = 0; v0 < 16; v0 += 8) {
 #pragma unroll
-          for (int v = v0; v < v0 + 8; ++v) sc_mfma_32x32x2(acc2, A2[((om * CH + hm) * 16 + v) * 64 + lane], acc1[hm][v]);
+          for (int v = v0; v < v0 + 8; ++v) PMLP_MFMA(acc2, A2[((om * CH + hm) * 16 + v) * 64 + lane], acc1[hm][v]);
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int r = 32 * om + pmlp_row(v, hq);
-        float val = fmaf(GT[r], sk[v], acc2[v] + B2[r]);
-        if (ACT == 1) val = sc_gelu(val);
-        SC_STORE_STREAM(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, val);
-        if ((v & 3) == 3) SC_SCHED_BARRIER();
+      for (int v = 0; v < 16; v += 2) {
+        float val[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = 32 * om + pmlp_row(v + u, hq);
+          val[u] = fmaf(GT[r], sk[v + u], acc2[v + u] + B2[r]);
+        }
+        if (ACT == 1) PMLP_GELU2(val[0], val[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) PMLP_STORE(sc_at(os + (int64_t)(32 * om + pmlp_row(v + u, 0)) * sp, lo_c), val[u]);
+        if ((v & 3) == 2) SC_SCHED_BARRIER();
       }
     }
   }
@@ -419,8 +459,8 @@ k_pmlp_bwd(PmlpBwdArgs g) {
     }
     tabs[i] = val;
   }
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);        // B-operand rows 2 s + half
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);    // accumulator rows pmlp_row(v, half)
   // weight-gradient tiles: MFMA accumulators that live across the whole tile loop (one wave per SIMD: the register file
   // has room; adding every tile's contribution into a shared LDS image with ds_add_f32 cost 0.85 of 1.8 ms,
   // profiles/r02_pmlp_ablation.txt)
@@ -467,16 +507,16 @@ k_pmlp_bwd(PmlpBwdArgs g) {
       const int ln1 = sc_opaque(lane), hq1 = sc_opaque(half);
       float xr[CI * 16];
 #pragma unroll
-      for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+      for (int s = 0; s < CI * 16; ++s) xr[s] = PMLP_LOAD(sc_at(xs + (int64_t)(2 * s) * sp, lo_b));
       // software pipeline over the tile: the gout / skip rows of output tile om + 1 are requested before tile om is
       // worked on (tile 0 here, next to x), the x rows of phase E before phase D -- one exposed memory latency per
       // pixel tile instead of one per phase
       if (PF) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int64_t ro = (int64_t)pmlp_row(v, 0) * sp + lo_c;
-          gzn[v] = SC_LOAD_STREAM(gs + ro);
-          skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+          const int64_t ro = (int64_t)pmlp_row(v, 0) * sp;
+          gzn[v] = PMLP_LOAD(sc_at(gs + ro, lo_c));
+          skn[v] = GATE ? PMLP_LOAD(sc_at(ss + ro, lo_c)) : 0.f;
         }
       }
       SC_SCHED_BARRIER();
@@ -492,10 +532,12 @@ k_pmlp_bwd(PmlpBwdArgs g) {
           SC_SCHED_BARRIER();
         }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < 16; v += 2) {
           // (hp holds gelu'(h_pre) from here on: both come out of one evaluation, phase C needs nothing else of h_pre)
-          PMLP_GELU_BOTH(acc[v] + B1[32 * hm + pmlp_row(v, hq1)], h[hm][v], hp[hm][v]);
+          PMLP_GELU_BOTH2(acc[v] + B1[32 * hm + pmlp_row(v, hq1)], acc[v + 1] + B1[32 * hm + pmlp_row(v + 1, hq1)],
+                          h[hm][v], h[hm][v + 1], hp[hm][v], hp[hm][v + 1]);
           TH[hm * TS + pmlp_row(v, half) * 33 + n] = h[hm][v];
+          TH[hm * TS + pmlp_row(v + 1, half) * 33 + n] = h[hm][v + 1];
         }
         SC_SCHED_BARRIER();
       }
@@ -520,17 +562,17 @@ k_pmlp_bwd(PmlpBwdArgs g) {
         if (om + 1 < CO) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
-            const int64_t ro = (int64_t)(32 * (om + 1) + pmlp_row(v, 0)) * sp + lo_c;
-            gzn[v] = SC_LOAD_STREAM(gs + ro);
-            skn[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+            const int64_t ro = (int64_t)(32 * (om + 1) + pmlp_row(v, 0)) * sp;
+            gzn[v] = PMLP_LOAD(sc_at(gs + ro, lo_c));
+            skn[v] = GATE ? PMLP_LOAD(sc_at(ss + ro, lo_c)) : 0.f;
           }
         }
       } else {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c;
-          gz[v] = SC_LOAD_STREAM(gs + ro);
-          sk[v] = GATE ? SC_LOAD_STREAM(ss + ro) : 0.f;
+          const int64_t ro = (int64_t)(32 * om + pmlp_row(v, 0)) * sp;
+          gz[v] = PMLP_LOAD(sc_at(gs + ro, lo_c));
+          sk[v] = GATE ? PMLP_LOAD(sc_at(ss + ro, lo_c)) : 0.f;
         }
       }
       SC_SCHED_BARRIER();
@@ -549,11 +591,17 @@ k_pmlp_bwd(PmlpBwdArgs g) {
             SC_SCHED_BARRIER();
           }
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int r = 32 * om + pmlp_row(v, hq2);
-          float z = acc[v] + B2[r];
-          if (GATE) z = fmaf(GT[r], sk[v], z);
-          gz[v] *= PMLP_GELU_GRAD(z);
+        for (int v = 0; v < 16; v += 2) {
+          float z[2], d[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int r = 32 * om + pmlp_row(v + u, hq2);
+            z[u] = acc[v + u] + B2[r];
+            if (GATE) z[u] = fmaf(GT[r], sk[v + u], z[u]);
+          }
+          PMLP_GELU_GRAD2(z[0], z[1], d[0], d[1]);
+          gz[v] *= d[0];
+          gz[v + 1] *= d[1];
         }
       }
       if (GATE) {
@@ -561,7 +609,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
         for (int v = 0; v < 16; ++v) {
           const int r = 32 * om + pmlp_row(v, hq2);
           if (LIN) a2[LIN ? om : 0][v] = GT[r] * gz[v];
-          else PMLP_STORE(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, GT[r] * gz[v]);
+          else PMLP_STORE(sc_at(gks + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c), GT[r] * gz[v]);
           TA[pmlp_row(v, half) * 33 + n] = gz[v] * sk[v];
         }
         SC_WAVE_SYNC();
@@ -606,7 +654,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
     if (PF) {
       const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);     // a second read of x (L2), not phase A's values kept alive
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(2 * t) * sp + lo_e];
+      for (int t = 0; t < 16; ++t) xe[t] = PMLP_LOAD_PLAIN(sc_at(xs + (int64_t)(2 * t) * sp, lo_e));
     }
     SC_SCHED_BARRIER();
     // ---- D: gx = W1^T ghp
@@ -628,20 +676,23 @@ k_pmlp_bwd(PmlpBwdArgs g) {
         const float* ps = g.x_pre + b * D::C_IN * sp + px0;
         float pv[16];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) pv[v] = SC_LOAD_STREAM(ps + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+        for (int v = 0; v < 16; ++v) pv[v] = PMLP_LOAD(sc_at(ps + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c));
         if (g.x_pre_is_grad) {
 #pragma unroll
           for (int v = 0; v < 16; ++v) acc[v] *= pv[v];
         } else {
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            acc[v] *= PMLP_GELU_GRAD(pv[v]);
-            if ((v & 3) == 3) SC_SCHED_BARRIER();
+          for (int v = 0; v < 16; v += 2) {
+            float d0, d1;
+            PMLP_GELU_GRAD2(pv[v], pv[v + 1], d0, d1);
+            acc[v] *= d0;
+            acc[v + 1] *= d1;
+            if ((v & 3) == 2) SC_SCHED_BARRIER();
           }
         }
       }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) PMLP_STORE(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
+      for (int v = 0; v < 16; ++v) PMLP_STORE(sc_at(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c), acc[v]);
       SC_SCHED_BARRIER();
       if (LIN) {                                           // W_s^T gx: this gx tile is the B operand for every input tile
         const int ln5 = sc_opaque(lane);
@@ -660,7 +711,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
 #pragma unroll
       for (int cip = 0; cip < CI; ++cip) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) PMLP_STORE(gks + (int64_t)(32 * cip + pmlp_row(v, 0)) * sp + lo_c, a2[LIN ? cip : 0][v]);
+        for (int v = 0; v < 16; ++v) PMLP_STORE(sc_at(gks + (int64_t)(32 * cip + pmlp_row(v, 0)) * sp, lo_c), a2[LIN ? cip : 0][v]);
         SC_SCHED_BARRIER();
       }
     }
@@ -675,7 +726,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
         if (!PF) {
           const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);
 #pragma unroll
-          for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(32 * ci + 2 * t) * sp + lo_e];
+          for (int t = 0; t < 16; ++t) xe[t] = PMLP_LOAD_PLAIN(sc_at(xs + (int64_t)(32 * ci + 2 * t) * sp, lo_e));
         }
         SC_WAVE_SYNC();                                    // readers of the previous X tile (and of h, first round)
 #pragma unroll
@@ -684,7 +735,7 @@ k_pmlp_bwd(PmlpBwdArgs g) {
           const uint32_t lo_e = (uint32_t)sc_opaque((int)lo_b);
           const int cn = (ci + 1 < CI) ? ci + 1 : 0;
 #pragma unroll
-          for (int t = 0; t < 16; ++t) xe[t] = xs[(int64_t)(32 * cn + 2 * t) * sp + lo_e];
+          for (int t = 0; t < 16; ++t) xe[t] = PMLP_LOAD_PLAIN(sc_at(xs + (int64_t)(32 * cn + 2 * t) * sp, lo_e));
         }
         SC_WAVE_SYNC();
 #pragma unroll
@@ -796,8 +847,8 @@ k_plin_fwd(PlinArgs g) {
   }
   for (int i = tid; i < C_OUT; i += 256) Bv[i] = g.bias ? g.bias[i] : 0.f;
   SC_SYNC();
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);
 #pragma unroll 1
   for (int64_t tile = (int64_t)SC_BID_X * 4 + w; tile < g.n_tiles; tile += (int64_t)g.n_wg * 4) {
     const int64_t b = tile / g.tiles_per_sample;
@@ -808,7 +859,7 @@ k_plin_fwd(PlinArgs g) {
     float* os = g.out + b * C_OUT * sp + px0;
     float xr[CI * 16];
 #pragma unroll
-    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(xs + (int64_t)(2 * s) * sp + lo_b);
+    for (int s = 0; s < CI * 16; ++s) xr[s] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(2 * s) * sp, lo_b));
     SC_SCHED_BARRIER();
 #pragma unroll
     for (int om = 0; om < CO; ++om) {
@@ -823,7 +874,7 @@ k_plin_fwd(PlinArgs g) {
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v)
-        SC_STORE_STREAM(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c, acc[v] + Bv[32 * om + pmlp_row(v, hq)]);
+        SC_STORE_STREAM(sc_at(os + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c), acc[v] + Bv[32 * om + pmlp_row(v, hq)]);
       SC_SCHED_BARRIER();
     }
   }
@@ -846,8 +897,8 @@ k_plin_bwd(PlinArgs g) {
   }
   for (int i = tid; i < NP; i += NT) red[i] = 0.f;
   SC_SYNC();
-  const uint32_t lo_b = (uint32_t)(n + half * g.spatial);
-  const uint32_t lo_c = (uint32_t)(n + 4 * half * g.spatial);
+  const uint32_t lo_b = 4u * (uint32_t)(n + half * g.spatial);
+  const uint32_t lo_c = 4u * (uint32_t)(n + 4 * half * g.spatial);
   sc_f32x16 aW[CO][CI];
   float sB[CO];
 #pragma unroll
@@ -872,7 +923,7 @@ k_plin_bwd(PlinArgs g) {
 #pragma unroll
     for (int om = 0; om < CO; ++om)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp + lo_c);
+      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(sc_at(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
     SC_SCHED_BARRIER();
     // gx = W^T g
 #pragma unroll
@@ -890,10 +941,10 @@ k_plin_bwd(PlinArgs g) {
         }
       if (ads) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] += SC_LOAD_STREAM(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c);
+        for (int v = 0; v < 16; ++v) acc[v] += SC_LOAD_STREAM(sc_at(ads + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c));
       }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) SC_STORE_STREAM(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp + lo_c, acc[v]);
+      for (int v = 0; v < 16; ++v) SC_STORE_STREAM(sc_at(gxs + (int64_t)(32 * ci + pmlp_row(v, 0)) * sp, lo_c), acc[v]);
       SC_SCHED_BARRIER();
     }
     // gW += g x^T over the pixels of the tile (operands transposed through LDS), gb += row sums of g
@@ -901,7 +952,7 @@ k_plin_bwd(PlinArgs g) {
     for (int ci = 0; ci < CI; ++ci) {
       float xe[16];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(xs + (int64_t)(32 * ci + 2 * t) * sp + lo_b);
+      for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(32 * ci + 2 * t) * sp, lo_b));
       SC_WAVE_SYNC();
 #pragma unroll
       for (int t = 0; t < 16; ++t) TB[(2 * t + half) * 33 + n] = xe[t];
