@@ -21,6 +21,12 @@ contracts it on the engine; the factor gradients are summed over the group by `r
 of resolution (`forward(x, output_shape)` / `resolution_scaling_factor`: the two inverse stages run to the output grid,
 whose first dim is sharded the same way).
 
+Round 6: runtime ``n_modes`` (<= the constructed ones: the used centred sub-block of the stored weight, modes.kept_block --
+the used columns keep their place in the padded column layout, so the shard ownership never moves), grids smaller than
+the modes, ``complex_data=True`` (complex-to-complex local transforms, modes.kept_block_complex and the reference's
+last-dim rule, modes.analysis_freqs) and a change of resolution along EVERY dim (the synthesis maps of
+modes.synthesis_freqs on the local transform and on the axis pass).
+
 Every local stage is an engine transform over fewer dims (a (N-1)-d real plan with the local rows folded into the
 channel count, and a 1-d complex plan with an explicit centred frequency map -- include/sc_engine.h,
 sc_plan_desc.freq); the separable N-d transform of spectral_convolution.py:443-449 / :531-559 is the product of
@@ -31,7 +37,7 @@ gradient is summed over the group (every rank saw different rows).
 import torch
 from torch import nn
 
-from ..modes import halve_last_mode, kept_block
+from ..modes import analysis_freqs, halve_last_mode, kept_block, kept_block_complex, synthesis_freqs
 from ..spectral_conv import BaseSpectralConv
 from . import comm
 from .mappings import all_to_all
@@ -53,16 +59,16 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
                  fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, factorization=None, rank=0.5,
                  fixed_rank_modes=None, resolution_scaling_factor=None, **unused):
         super().__init__(device=device)
-        for k in ("complex_data", "separable"):
-            if unused.get(k):
-                raise NotImplementedError(f"{k}=True is not supported by the spatially decomposed layer")
+        if unused.get("separable"):
+            raise NotImplementedError("separable=True is not supported by the spatially decomposed layer")
+        self.complex_data = bool(unused.get("complex_data", False))
         fac = (factorization or "dense").lower()
         if fac not in ("dense", "tucker", "cp", "tt"):
             raise NotImplementedError("spatially decomposed layer: dense, Tucker, CP or TT weights")
         if fft_norm != "forward":
             raise NotImplementedError("spatially decomposed layer: fft_norm='forward' (the reference default)")
         self.in_channels, self.out_channels = in_channels, out_channels
-        self._n_modes = halve_last_mode(n_modes)
+        self._n_modes = halve_last_mode(n_modes, self.complex_data)
         self.max_n_modes = list(self._n_modes)
         self.order = len(self._n_modes)
         if self.order < 2:
@@ -76,7 +82,7 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         self.group = group
         self.P = comm.get_model_parallel_size() if group is None else torch.distributed.get_world_size(group)
         self.rank = comm.get_model_parallel_rank() if group is None else torch.distributed.get_rank(group)
-        k2 = self._n_modes[1]
+        k2 = self.max_n_modes[1]
         self.k2_pad = -(-k2 // self.P) * self.P                      # columns after padding
         self.k2_loc = self.k2_pad // self.P                          # columns this rank contracts
         if init_std == "auto":
@@ -101,21 +107,30 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         self.bias = nn.Parameter(init_std * torch.randn(out_channels, *(1,) * self.order, device=device)) \
             if bias else None
         if ops is None:
-            from ..engine import EngineOps
-            ops = EngineOps(fft_norm, engine_flags)
+            from ..engine import EngineOps, SC_PLAN_COMPLEX
+            ops = EngineOps(fft_norm, engine_flags | (SC_PLAN_COMPLEX if self.complex_data else 0))
         self.ops = ops
 
-    def _local_weight(self):
-        """(Cin, Cout, k1, k2p / P, ..) dense block of this rank's mode columns (zero columns past k2)"""
+    def _local_weight(self, kept=None, w_start=None):
+        """(Cin, Cout, k1', k2p / P, k3', ..) dense block of this rank's mode columns (zero columns past k2) restricted
+        to the used centred sub-block of every UNSHARDED mode dim (rows w_start[d] .. + kept[d], modes.kept_block)"""
+        mx = self.max_n_modes
+        if kept is None:
+            kept, w_start = list(mx), [0] * self.order
+        sub = [slice(None), slice(None)] + [slice(s0, s0 + k) for s0, k in zip(w_start, kept)]
         if self.factorization == "dense":
-            return self.weight
-        k2 = self._n_modes[1]
+            sub[3] = slice(None)
+            whole = all(k == m for d, (k, m) in enumerate(zip(kept, mx)) if d != 1)
+            return self.weight if whole else self.weight[tuple(sub)]
+        k2 = mx[1]
         lo = self.rank * self.k2_loc
         hi = min(lo + self.k2_loc, k2)
+        shape = [self.in_channels, self.out_channels, *kept]
+        shape[3] = self.k2_loc
         if hi <= lo:                                                   # a rank that holds padding only
-            return torch.zeros(self.in_channels, self.out_channels, self._n_modes[0], self.k2_loc, *self._n_modes[2:],
-                               dtype=torch.cfloat, device=next(self.weight.parameters()).device)   # (bias=False: ADVICE r5)
-        w = self.weight[:, :, :, lo:hi].to_tensor()
+            return torch.zeros(shape, dtype=torch.cfloat, device=next(self.weight.parameters()).device)   # (bias=False: ADVICE r5)
+        sub[3] = slice(lo, hi)
+        w = self.weight[tuple(sub)].to_tensor()
         return _pad_dim(w, 3, self.k2_loc - (hi - lo)) if hi - lo != self.k2_loc else w
 
     def replicated_parameters(self):
@@ -131,7 +146,12 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
 
     @n_modes.setter
     def n_modes(self, value):
-        raise NotImplementedError("the spatially decomposed layer fixes n_modes at construction (shard layout)")
+        # spectral_convolution.py:400-415; the shard layout belongs to max_n_modes and does not move
+        nm = halve_last_mode(value, self.complex_data)
+        if len(nm) != self.order or any(n > m for n, m in zip(nm, self.max_n_modes)) or any(n < 1 for n in nm):
+            raise ValueError(f"n_modes {list(value)} must have {self.order} entries within the constructed "
+                             f"max_n_modes {self.max_n_modes}")
+        self._n_modes = nm
 
     def transform(self, x, output_shape=None):
         if output_shape is not None or self.resolution_scaling_factor is not None:
@@ -154,59 +174,68 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         """``output_shape``: the FULL output grid (all ranks pass the same one); this rank returns its rows of it."""
         if x.ndim != self.order + 2:
             raise ValueError(f"expected a (B, C, {self.order} spatial dims) input, got {tuple(x.shape)}")
+        if x.is_complex() != self.complex_data:
+            raise ValueError("complex_data=True takes complex inputs (and only those)")
+        cplx = self.complex_data
         b, c, h_loc = x.shape[:3]
         rest = list(x.shape[3:])
         d1 = h_loc * self.P
-        kept, _ = kept_block([d1] + rest, self._n_modes, self.max_n_modes)
-        if kept != list(self._n_modes):
-            raise ValueError(f"grid {[d1] + rest} is too small for n_modes {self._n_modes}")
-        k1, k2 = kept[0], kept[1]
+        in_grid = [d1] + rest
+        kept, w_start = (kept_block_complex if cplx else kept_block)(in_grid, self._n_modes, self.max_n_modes)
+        k1, k2, c0 = kept[0], kept[1], w_start[1]
         co = self.out_channels
-        out_grid = self._out_grid([d1] + rest, output_shape)
-        kept_o, _ = kept_block(out_grid, self._n_modes, self.max_n_modes)
-        if kept_o[1:] != kept[1:]:
-            raise ValueError(f"output grid {out_grid} is too small for n_modes {self._n_modes}")
-        if out_grid[1:-1] != rest[:-1]:
-            raise NotImplementedError("resolution change on the spatially decomposed layer: the first and the last "
-                                      "spatial dim (the reference's non-centred maps of the middle dims: the "
-                                      "mode-parallel layer serves those)")
+        out_grid = self._out_grid(in_grid, output_shape)
+        # which FFT index each kept row reads / lands on (None = the default centred / plain maps; a synthesis entry
+        # None = the row falls off a coarser output grid and is dropped: spectral_convolution.py:524-559)
+        fa = analysis_freqs(in_grid, kept, cplx)
+        fs, real_col = synthesis_freqs(in_grid, out_grid, kept, cplx)
         d1_o, rest_o, h_out = out_grid[0], out_grid[1:], out_grid[0] // self.P
-        # 1. local rows: pruned real transform over d2..dN (rows folded into the channel count)
-        xh = self.ops.forward_transform(x.reshape(b, c * h_loc, *rest), kept[1:])
+        # 1. local rows: pruned transform over d2..dN (rows folded into the channel count)
+        xr = x.reshape(b, c * h_loc, *rest)
+        xh = self.ops.forward_transform(xr, kept[1:]) if fa is None else self.ops.forward_transform(xr, kept[1:], fa[1:])
         xh = xh.reshape(b, c, h_loc, *kept[1:])
-        # 2. exchange: every rank gets ALL rows of its k2p / P columns
-        if self.k2_pad != k2:
-            xh = _pad_dim(xh, 3, self.k2_pad - k2)
+        # 2. exchange: every rank gets ALL rows of its k2p / P columns; the used columns sit at their place in the
+        #    stored weight's (padded) column layout
+        xh = _place_dim(xh, 3, c0, self.k2_pad)
         xh = all_to_all(xh, split_dim=3, cat_dim=2, group=self.group)          # (B, Cin, d1, k2p/P, ..)
         # 3. pruned complex DFT over d1 (moved last: the engine's 1-d plans run over the contiguous dim)
         xt = xh.movedim(2, -1).contiguous()
         lead = xt.shape[:-1]
-        xa = self.ops.forward_axis(xt.reshape(b, -1, d1), k1, centred_rows(k1, d1))
+        rows_a = fa[0] if fa is not None and fa[0] is not None else centred_rows(k1, d1)
+        xa = self.ops.forward_axis(xt.reshape(b, -1, d1), k1, rows_a)
         xa = xa.reshape(*lead, k1).movedim(-1, 2).contiguous()                   # (B, Cin, k1, k2p/P, ..)
         # 4. contraction with this rank's mode columns
-        yh = self.ops.contract(xa, self._local_weight())                        # (B, Cout, k1, k2p/P, ..)
+        yh = self.ops.contract(xa, self._local_weight(kept, w_start).contiguous())   # (B, Cout, k1, k2p/P, ..)
         # 5. zero-padded inverse DFT over d1 (to the OUTPUT grid's rows)
         yt = yh.movedim(2, -1).contiguous()
         lead = yt.shape[:-1]
         # (a different output grid: the reference pads / trims the UNSHIFTED spectrum at its end, ifftn(s=...) behind
         # the ifftshift, spectral_convolution.py:524-559 -- kept row r stays at FFT index (r - k1 // 2) mod d1 of the
         # INPUT grid; on a coarser grid the rows whose index falls off the end are dropped)
-        rows_o = centred_rows(k1, d1)
-        if d1_o < d1:
-            keep = [r for r in range(k1) if rows_o[r] < d1_o]
+        rows_o = list(fs[0]) if fs is not None and fs[0] is not None else centred_rows(k1, d1)
+        if any(r is None for r in rows_o):
+            keep = [r for r in range(k1) if rows_o[r] is not None]
             yt = yt.index_select(-1, torch.as_tensor(keep, device=yt.device))
             rows_o = [rows_o[r] for r in keep]
         ya = self.ops.inverse_axis(yt.reshape(b, -1, len(rows_o)), d1_o, rows_o)
         ya = ya.reshape(*lead, d1_o).movedim(-1, 2).contiguous()                 # (B, Cout, d1', k2p/P, ..)
-        # 6. exchange back: local rows, all columns; drop the padding
+        # 6. exchange back: local rows, all columns; keep the used ones
         ya = all_to_all(ya, split_dim=2, cat_dim=3, group=self.group)          # (B, Cout, d1/P, k2p, ..)
-        if self.k2_pad != k2:
-            ya = ya.narrow(3, 0, k2)
-        # 7. zero-padded C2R over d2..dN on the local rows, bias per (channel, row) image
+        if c0 or self.k2_pad != k2:
+            ya = ya.narrow(3, c0, k2)
+        # 7. zero-padded inverse transform over d2..dN on the local rows, bias per (channel, row) image
+        ya = ya.reshape(b, co * h_out, *kept[1:]).contiguous()
+        fl = None if fs is None else list(fs[1:])
+        if cplx:                          # a real bias added to a complex field: elementwise glue (:567-568)
+            y = self.ops.inverse_transform(ya, None, rest_o, fl).reshape(b, co, h_out, *rest_o)
+            return y if self.bias is None else y + self.bias
         bias = None
         if self.bias is not None:
             bias = self.bias.reshape(co, 1).expand(co, h_out).reshape(co * h_out, *(1,) * len(rest))
-        y = self.ops.inverse_transform(ya.reshape(b, co * h_out, *kept[1:]).contiguous(), bias, rest_o)
+        if fl is None:
+            y = self.ops.inverse_transform(ya, bias, rest_o)
+        else:
+            y = self.ops.inverse_transform(ya, bias, rest_o, fl, real_col)
         return y.reshape(b, co, h_out, *rest_o)
 
     # ---- helpers for the training loop -----------------------------------------------------------
@@ -235,6 +264,26 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         loc = -(-k2 // world)
         w = _pad_dim(full_weight, 3, loc * world - k2) if loc * world != k2 else full_weight
         return w.narrow(3, rank * loc, loc).contiguous()
+
+
+def _place_dim(t, dim, offset, total):
+    """``t`` at ``offset`` of a zero tensor with ``total`` entries along ``dim`` (autograd: a narrow of the gradient)"""
+    k = t.shape[dim]
+    if offset == 0 and k == total:
+        return t
+    parts = []
+    if offset:
+        parts.append(_zeros_like_dim(t, dim, offset))
+    parts.append(t)
+    if total - offset - k:
+        parts.append(_zeros_like_dim(t, dim, total - offset - k))
+    return torch.cat(parts, dim=dim)
+
+
+def _zeros_like_dim(t, dim, n):
+    shape = list(t.shape)
+    shape[dim] = n
+    return torch.zeros(shape, dtype=t.dtype, device=t.device)
 
 
 def _pad_dim(t, dim, n):

@@ -240,3 +240,25 @@ class OracleAgOpsComplex(OracleAgOps):
             cur = torch.zeros(shape, dtype=cur.dtype).index_add(2 + d, torch.as_tensor([int(ix[r]) for r in keep]), src)
         y = torch.fft.ifftn(cur, dim=list(range(-nd, 0)), norm="forward")
         return y + bias if bias is not None else y
+
+
+class _AxisMixin:
+    """one complex axis (last dim) with an explicit row -> FFT index map; norm="forward" like the layer"""
+
+    @staticmethod
+    def forward_axis(x, k, rows):
+        assert len(rows) == k
+        return torch.fft.fft(x, dim=-1, norm="forward").index_select(-1, torch.as_tensor(list(rows)))
+
+    @staticmethod
+    def inverse_axis(xhat, n, rows):
+        z = torch.zeros(*xhat.shape[:-1], n, dtype=xhat.dtype)
+        return torch.fft.ifft(z.index_add(-1, torch.as_tensor(list(rows)), xhat), dim=-1, norm="forward")
+
+
+class PencilOracleOps(_AxisMixin, OracleAgOps):
+    """local stages of mpu.SpatialParallelSpectralConv (round 6: frequency maps on the local transform), real data"""
+
+
+class PencilOracleOpsComplex(_AxisMixin, OracleAgOpsComplex):
+    """... complex_data=True"""

@@ -1105,6 +1105,66 @@ def test_spatial_parallel_variants_on_device_single_rank(spatial, modes, fac, ou
             assert rel_l2(torch.view_as_real(q.grad).cpu().numpy(), torch.view_as_real(r.grad).numpy()) < TOL
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(spatial=(32, 24), modes=(16, 12), run_modes=(12, 8)),                       # runtime n_modes
+    dict(spatial=(12, 16, 20), modes=(6, 8, 8), run_modes=(5, 6, 6)),                # 3-d: the column dim is a centred one
+    dict(spatial=(12, 16, 20), modes=(6, 8, 8), run_modes=(4, 4, 6), fac="tucker"),
+    dict(spatial=(8, 24), modes=(16, 12)),                                           # the grid is smaller than the modes
+    dict(spatial=(32, 24), modes=(16, 12), complex=True),
+    dict(spatial=(12, 16, 10), modes=(6, 8, 5), complex=True, run_modes=(4, 6, 3)),
+    dict(spatial=(32, 24), modes=(16, 12), complex=True, out_shape=(48, 20)),
+    dict(spatial=(12, 16, 20), modes=(6, 8, 8), out_shape=(12, 24, 20)),             # the middle dim changes
+    dict(spatial=(12, 16, 20), modes=(8, 12, 8), out_shape=(16, 10, 28)),            # every dim, the middle one coarser than its modes
+], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()).replace(" ", ""))
+def test_spatial_parallel_round6_variants_on_device_single_rank(cfg):
+    """Round 6: the spatially decomposed layer with runtime n_modes (the used centred sub-block of the stored weight, the
+    used columns at their place of the padded column layout), a grid smaller than the modes, complex_data (complex
+    local plans + the reference's last-dim rule) and a change of resolution along every dim (synthesis maps on the local
+    plan and on the axis plan) -- engine stage ops, one rank, against the CPU oracle.  Sharding: world-2 gloo test."""
+    from oracle import spectral_oracle as so
+    from neuraloperator_amd.modes import halve_last_mode
+    from neuraloperator_amd.mpu import SpatialParallelSpectralConv
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(24)
+    spatial, modes, cplx, fac = cfg["spatial"], cfg["modes"], cfg.get("complex", False), cfg.get("fac", "dense")
+    out_shape = cfg.get("out_shape")
+    mx = halve_last_mode(modes, cplx)
+    sp = SpatialParallelSpectralConv(4, 3, modes, factorization=fac, rank=0.5, complex_data=cplx).to(dev)
+    if cfg.get("run_modes") is not None:
+        sp.n_modes = cfg["run_modes"]
+    nm = list(sp.n_modes)
+    dt = torch.cfloat if cplx else torch.float32
+    x = torch.randn(2, 4, *spatial, device=dev, dtype=dt, requires_grad=True)
+    og = list(out_shape) if out_shape is not None else list(spatial)
+    g = torch.randn(2, 3, *og, device=dev, dtype=dt)
+    y = sp(x, output_shape=out_shape)
+    assert list(y.shape) == [2, 3, *og]
+    y.backward(g)
+    xc = x.detach().cpu().requires_grad_(True)
+    bc = sp.bias.detach().cpu().requires_grad_(True)
+    if fac == "dense":
+        wc = sp.weight.detach().cpu().clone().requires_grad_(True)
+    else:
+        from neuraloperator_amd.factorized import SpectralWeight
+        ref = SpectralWeight.new((4, 3, *mx), rank=0.5, factorization=fac)
+        with torch.no_grad():
+            for q, r in zip(ref.parameters(), sp.weight.parameters()):
+                q.copy_(r.cpu())
+        wc = ref.to_tensor()
+    yo = so.forward_torch(xc, wc, bc, nm, mx, output_shape=out_shape, complex_data=cplx)
+    yo.backward(g.cpu())
+    num = lambda t: torch.view_as_real(t.detach().cpu().contiguous()).numpy() if t.is_complex() else t.detach().cpu().numpy()
+    assert rel_l2(num(y), num(yo)) < TOL
+    assert rel_l2(num(x.grad), num(xc.grad)) < TOL
+    assert rel_l2(num(sp.bias.grad), num(bc.grad)) < TOL
+    if fac == "dense":
+        assert rel_l2(num(sp.weight.grad), num(wc.grad)) < TOL
+    else:
+        for q, r in zip(sp.weight.parameters(), ref.parameters()):
+            assert rel_l2(num(q.grad), num(r.grad)) < TOL
+
+
 @pytest.mark.parametrize("name", golden_names("adamw_"))
 def test_optimizer_matches_reference_trajectory(name):
     """neuraloperator_amd.AdamW (one fused launch per parameter) against the verbatim reference optimizer's
