@@ -243,6 +243,13 @@ k_plinx_bwd(PlinxArgs g, int om0) {
       SC_SCHED_BARRIER();
     }
     SC_SCHED_BARRIER();
+    // the x rows of the weight-gradient phase are requested a step ahead (round 6, second pass): one wave per SIMD, so a
+    // load issued where it is used costs its whole round trip -- four per tile at 128 input channels, 16 tiles per wave
+    // at B = 8, 256^2: half of the launch that only owns weight-gradient tiles (profiles/r06_plinx_prefetch.txt)
+    float xe[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(2 * t) * sp, lo_b));
+    SC_SCHED_BARRIER();
     if (do_gx) {                                           // gx = (W^T g + addend) (.) gelu'(xg)
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) {
@@ -292,9 +299,6 @@ k_plinx_bwd(PlinxArgs g, int om0) {
     // gW += g xin^T over the pixels of the tile (operands transposed through LDS), gb += row sums of g
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) {
-      float xe[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(32 * ci + 2 * t) * sp, lo_b));
       if (xact) {
 #pragma unroll
         for (int t = 0; t < 16; t += 2) sc_gelu_pair(xe[t], xe[t + 1]);
@@ -302,6 +306,11 @@ k_plinx_bwd(PlinxArgs g, int om0) {
       SC_WAVE_SYNC();
 #pragma unroll
       for (int t = 0; t < 16; ++t) TB[(2 * t + half) * 33 + n] = xe[t];
+      if (ci + 1 < CI) {                                   // the next rows while this tile's products run
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xe[t] = SC_LOAD_STREAM(sc_at(xs + (int64_t)(32 * (ci + 1) + 2 * t) * sp, lo_b));
+        SC_SCHED_BARRIER();
+      }
 #pragma unroll
       for (int o = 0; o < OMN; ++o) {
         SC_WAVE_SYNC();
