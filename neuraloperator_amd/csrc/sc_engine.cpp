@@ -700,8 +700,9 @@ static bool f2p_launch_col_inv(const sc_plan* p, const cf32* src, cf32* panel, i
               src, panel, (const cf32*)p->f2p_tw[0], NCB, J, K0, n_blk, pxc);
   });
 }
+// skip != NULL: ys = (transform + bias) + skip (the 1024-point row kernel only: f2p_fused_add)
 static bool f2p_launch_c2r(const sc_plan* p, int mode, const cf32* panel, float* ys, const float* bias, int64_t channels,
-                           int64_t i0, int64_t ni, sc_stream_t st) {
+                           int64_t i0, int64_t ni, sc_stream_t st, const float* skip = nullptr) {
   const int N0 = (int)p->n[0], J = (int)p->k[1], NCB = p->f2p_ncb;
   static const bool no_w1024 = SC_DIAG_ENV("SC_F2P_NO_W1024") != nullptr;          // A-B: the half-wave kernel
   if (p->f2p_roww && !no_w1024) {
@@ -711,12 +712,18 @@ static bool f2p_launch_c2r(const sc_plan* p, int mode, const cf32* panel, float*
     int64_t grid = (int64_t)(wgs > 0 ? wgs : 4) * sc_cu_count();
     if (grid > n_items) grid = n_items;
     if (n_pairs < ((int64_t)1 << 30)) {
-      SC_LAUNCH(k_f2p_c2r_w1024, dim3((unsigned)grid), dim3(256), 0, st, panel, ys, (const cf32*)p->f2p_w1024,
-                (const float*)p->f2p_cs_inv[mode], bias, (int)channels, (int)(i0 % channels), N0, NCB, (int)n_pairs,
-                (int)n_items, (int)grid);
+      if (skip)
+        SC_LAUNCH(k_f2p_c2r_w1024<true>, dim3((unsigned)grid), dim3(256), 0, st, panel, ys, (const cf32*)p->f2p_w1024,
+                  (const float*)p->f2p_cs_inv[mode], bias, (int)channels, (int)(i0 % channels), N0, NCB, (int)n_pairs,
+                  (int)n_items, (int)grid, skip);
+      else
+        SC_LAUNCH(k_f2p_c2r_w1024<false>, dim3((unsigned)grid), dim3(256), 0, st, panel, ys, (const cf32*)p->f2p_w1024,
+                  (const float*)p->f2p_cs_inv[mode], bias, (int)channels, (int)(i0 % channels), N0, NCB, (int)n_pairs,
+                  (int)n_items, (int)grid, (const float*)nullptr);
       return true;
     }
   }
+  if (skip) return false;                                  // (callers ask f2p_fused_add first)
   return f2p_dispatch(p->f2p_p[1], p->f2p_k2[1], [&](auto P, auto K2) {
     constexpr int G = 32 / decltype(P)::value;
     const int64_t n_items = (ni * N0 / 2 + 8 * G - 1) / (8 * G);
@@ -766,8 +773,13 @@ static int f2p_forward(const sc_plan* p, int mode, const float* x, cf32* xhat, i
   return sc_check_launch("k_f2p_r2c / k_f2p_col_fwd");
 }
 
+// the shapes whose row pass adds the epilogue's skip in its store path (f2p_launch_c2r: the one-wave-per-row-pair kernel)
+static bool f2p_fused_add(const sc_plan* p, int64_t n_images) {
+  static const bool no_w1024 = SC_DIAG_ENV("SC_F2P_NO_W1024") != nullptr;
+  return p->f2p && p->f2p_roww && !no_w1024 && n_images * p->n[0] / 2 < ((int64_t)1 << 30);
+}
 static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float* bias, int64_t channels, float* y,
-                       int64_t n_images, void* workspace, sc_stream_t st) {
+                       int64_t n_images, void* workspace, sc_stream_t st, const float* skip = nullptr) {
   SC_CHECK_ARG(workspace, "workspace required");
   ScSide* side = sc_side_get();
   const F2pChunks ck = f2p_chunks(p, n_images, side);
@@ -779,7 +791,7 @@ static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float
     for (int64_t c = 0; c < ck.n_chunks; ++c) {
       const int64_t i0 = c * ck.chunk, ni = ni_of(c);
       if (!f2p_launch_col_inv(p, yhat + i0 * p->modes, buf[0], ni, st) ||
-          !f2p_launch_c2r(p, mode, buf[0], y + i0 * p->ntot, bias, channels, i0, ni, st))
+          !f2p_launch_c2r(p, mode, buf[0], y + i0 * p->ntot, bias, channels, i0, ni, st, skip ? skip + i0 * p->ntot : nullptr))
         return sc_fail(nok);
     }
     return sc_check_launch("k_f2p_col_inv / k_f2p_c2r");
@@ -800,7 +812,8 @@ static int f2p_inverse(const sc_plan* p, int mode, const cf32* yhat, const float
       guard.armed = true;
       if (!f2p_launch_col_inv(p, yhat + (i0 + ck.chunk) * p->modes, buf[(c + 1) & 1], ni_of(c + 1), ss)) return sc_fail(nok);
     }
-    if (!f2p_launch_c2r(p, mode, buf[c & 1], y + i0 * p->ntot, bias, channels, i0, ni, st)) return sc_fail(nok);
+    if (!f2p_launch_c2r(p, mode, buf[c & 1], y + i0 * p->ntot, bias, channels, i0, ni, st, skip ? skip + i0 * p->ntot : nullptr))
+      return sc_fail(nok);
   }
   return sc_check_launch("k_f2p_col_inv / k_f2p_c2r");
 }
@@ -1643,6 +1656,8 @@ static int transform_inverse_impl(const sc_plan* p, int mode, const float* yhat,
     return fft3_inverse(&p->fft2d, mode, (const cf32*)yhat, bias, channels, y, n_images, st, &g_last_error, epi,
                         ep ? ep->skip : nullptr, ep ? ep->preact : nullptr, sh);
   }
+  if (ep && epi == 1 && f2p_fused_add(p, n_images))   // 1024-point rows: the addend rides in the row pass's stores
+    return f2p_inverse(p, mode, (const cf32*)yhat, bias, channels, y, n_images, workspace, st, ep->skip);
   if (ep) {                                  // size-agnostic passes: the plain transform, then one streaming pass
     int rc2 = sc_transform_inverse_ex(p, mode, yhat, bias, channels, nullptr, y, n_images, workspace, stream);
     return rc2 ? rc2 : run_epilogue_pass(p, ep, y, n_images, st);

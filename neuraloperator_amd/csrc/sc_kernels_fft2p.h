@@ -700,10 +700,14 @@ k_f2p_c2r(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __r
 // Scope: N1 = 1024 with exactly the 129 kept columns k = 0..128 (n_modes 256 on the last axis: BASELINE configs[4]),
 // any N0 the column kernels serve; other column ranges keep k_f2p_c2r<32, K2>.  With every column live the panel
 // addresses are (wave-uniform row / column-group part) + (one of two per-lane offsets): no per-input offset registers.
+// ADD (round 6, second pass): y = (transform + bias) + skip in the store path -- the block backward's addend (the gradient that
+// reaches the block input around the spectral convolution) at configs[4]'s width; until then a streaming k_epilogue pass
+// behind the transform (3 R: 1.27 ms of a 19.5 ms block at B = 4, 1024^2).  Same order of the two additions as that pass.
+template <bool ADD>
 SC_GLOBAL void SC_LAUNCH_BOUNDS_OCC(256, 4)
 k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf32* __restrict__ w1024,
                 const float* __restrict__ cs, const float* __restrict__ bias, int channels, int img0, int N0, int NCB,
-                int n_pairs, int n_items, int gstride) {
+                int n_pairs, int n_items, int gstride, const float* __restrict__ skip) {
   constexpr int N = 1024;
   SC_SHARED __attribute__((aligned(16))) cf32 tw2[256];                     // conj w256^(ma l), [ma][l]
   SC_SHARED __attribute__((aligned(16))) cf32 Eall[4][4 * SC_W1K_RS];       // per wave: [r][ma][l]
@@ -811,6 +815,25 @@ k_f2p_c2r_w1024(const cf32* __restrict__ panel, float* __restrict__ y, const cf3
     fft16<+1>(T, U);                                       // over l -> mb : z[r + 4 ma + 64 mb]
     float* ya = y + ((int64_t)img * N0 + rA) * N + lane;       // r + 4 l
     float* yb = ya + N;
+    if (ADD) {                                             // four rounds of eight loads: the kernel has 128 registers at four
+      const float* ka = skip + ((int64_t)img * N0 + rA) * N + lane;      // workgroups per unit and the other 15 waves hide the trips
+#pragma unroll
+      for (int m0 = 0; m0 < 16; m0 += 4) {
+        float sa[4], sb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          sa[u] = SC_LOAD_STREAM(ka + 64 * (m0 + u));
+          sb[u] = SC_LOAD_STREAM(ka + N + 64 * (m0 + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          SC_STORE_STREAM(ya + 64 * (m0 + u), (U[m0 + u].x + bv) + sa[u]);
+          SC_STORE_STREAM(yb + 64 * (m0 + u), (U[m0 + u].y + bv) + sb[u]);
+        }
+        SC_SCHED_BARRIER();
+      }
+      continue;
+    }
 #pragma unroll
     for (int mb = 0; mb < 16; ++mb) {
 #ifdef SC_W1K_ABL_NOSTORE                                 // measurement build only

@@ -213,3 +213,30 @@ for kept in ((256, 129), (77, 20)):
     env = dict(os.environ, SC_F2P_COLW_WGS="8", PYTHONPATH=root + os.pathsep + os.path.join(root, "tests"))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0 and out.stdout.count("ERR") == 2, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kept,n_img,mode", [((101, 129), 2, "padded"), ((256, 129), 5, "adjoint")])
+def test_row_pass_adds_the_epilogue_skip_in_its_stores(lib, kept, n_img, mode):
+    """Round 6: at 1024-point rows with 129 kept columns (configs[4]) the addend of sc_transform_inverse_ex (SC_ACT_NONE: the
+    block backward's gradient around the spectral convolution, sc_layer_backward_ex) rides in k_f2p_c2r_w1024<true>'s store
+    path instead of a streaming k_epilogue pass behind the transform: same two additions in the same order -> the same bits
+    as the plain transform followed by the sum; other shapes keep the separate pass."""
+    rng = np.random.default_rng(11)
+    spatial = (1024, 1024)
+    md = _lib.SC_INV_PADDED if mode == "padded" else _lib.SC_INV_ADJ_R2C
+    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+    try:
+        assert lib.plan_kernel_name(plan, 0) == "k_f2p_r2c"
+        ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8)
+        yhat = torch.from_numpy((rng.standard_normal((n_img, *kept)) + 1j * rng.standard_normal((n_img, *kept))).astype(np.complex64))
+        bias = torch.from_numpy(rng.standard_normal(n_img).astype(np.float32)) if mode == "padded" else None
+        bp = 0 if bias is None else bias.data_ptr()
+        skip = torch.from_numpy(rng.standard_normal((n_img, *spatial)).astype(np.float32))
+        plain = torch.full((n_img, *spatial), float("nan"), dtype=torch.float32)
+        lib.transform_inverse(plan, md, torch.view_as_real(yhat).data_ptr(), bp, n_img, plain.data_ptr(), n_img, ws.data_ptr(), 0)
+        fused = torch.full((n_img, *spatial), float("nan"), dtype=torch.float32)
+        lib.transform_inverse_ex(plan, md, torch.view_as_real(yhat).data_ptr(), bp, n_img, skip.data_ptr(), 0, _lib.SC_ACT_NONE,
+                                 fused.data_ptr(), n_img, ws.data_ptr(), 0)
+        assert torch.equal(fused, plain + skip)
+    finally:
+        lib.plan_destroy(plan)
