@@ -194,25 +194,39 @@ k_plinx_bwd(PlinxArgs g, int om0) {
     const float* xgs = xgrad ? g.xg + b * C_IN * sp + px0 : nullptr;
     // the output-channel gradient of the tiles this launch needs: all of them for gx, its own OMN for the weight gradient
     float gz[CO][16];
-#pragma unroll
-    for (int om = 0; om < CO; ++om) {
-      const bool mine = om >= om0 && om < om0 + OMN;
-      if (!do_gx && !mine) continue;
-      // all rows of the tile requested before the first is used (one wave per SIMD: every exposed round trip counts --
-      // with the loads inside the arithmetic hipcc waited for each one: 64 us per tile, profiles/r06_plinx_batched_loads.txt)
-      const bool need_sk = gated && (do_gx || mine);
-      float pr[16], sk[16];
-#pragma unroll
-      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(sc_at(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
+    // every row of g the tile needs is requested before the first is used, the rows of `pre` / `skip` one output tile ahead of
+    // their use (one wave per SIMD: every exposed round trip counts -- with the loads inside the arithmetic hipcc waited for
+    // each one: 64 us per tile, profiles/r06_plinx_batched_loads.txt; second pass: one exposed trip per 32-pixel tile, not one
+    // per output tile -- at 64 -> 128 channels the trips were 45 % of the launch, profiles/r06_plinx_prefetch.txt)
+    float prb[2][16], skb[2][16];
+    auto wanted = [&](const int om) { return do_gx || (om >= om0 && om < om0 + OMN); };
+    auto request = [&](const int om, float (&pr)[16], float (&sk)[16]) {
       if (pro) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) pr[v] = SC_LOAD_STREAM(sc_at(prs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       }
-      if (need_sk) {
+      if (gated) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) sk[v] = SC_LOAD_STREAM(sc_at(ss + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
       }
+    };
+#pragma unroll
+    for (int om = 0; om < CO; ++om) {
+      if (!wanted(om)) continue;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) gz[om][v] = SC_LOAD_STREAM(sc_at(gs + (int64_t)(32 * om + pmlp_row(v, 0)) * sp, lo_c));
+    }
+    if (wanted(0)) request(0, prb[0], skb[0]);
+    SC_SCHED_BARRIER();
+#pragma unroll
+    for (int om = 0; om < CO; ++om) {
+      const bool mine = om >= om0 && om < om0 + OMN;
+      float (&pr)[16] = prb[om & 1];
+      float (&sk)[16] = skb[om & 1];
+      if (om + 1 < CO && wanted(om + 1)) request(om + 1, prb[(om + 1) & 1], skb[(om + 1) & 1]);
       SC_SCHED_BARRIER();
+      if (!do_gx && !mine) continue;
+      const bool need_sk = gated && (do_gx || mine);
       if (pro) {
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
