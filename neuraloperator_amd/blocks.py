@@ -112,6 +112,12 @@ class PointwiseLinearFn(torch.autograd.Function):
 _PLX_CH = (32, 64, 128)                                   # channel counts of the extended passes (sc_kernels_plinx.h)
 
 
+def _pw_size(s):
+    """points per (sample, channel) image the pointwise kernels take: 32-pixel tiles, lane offsets as 32-bit byte counts
+    (csrc/sc_engine.cpp SC_PW_MAX_SPATIAL); anything else keeps the ATen route"""
+    return s % 32 == 0 and s < (1 << 28)
+
+
 def _plx_ok(*cs):
     return all(c in _PLX_CH for c in cs)
 
@@ -224,9 +230,9 @@ def fused_linear(x, w, bias=None):
     s = x[0, 0].numel()
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, bias))
     ok = (32, 64) if needs_grad else (32, 64, 128)
-    if _on_engine(x) and x.dtype == torch.float32 and ci == co and ci in ok and s % 32 == 0:
+    if _on_engine(x) and x.dtype == torch.float32 and ci == co and ci in ok and _pw_size(s):
         return PointwiseLinearFn.apply(x, w, bias)
-    if _on_engine(x) and x.dtype == torch.float32 and _plx_ok(ci, co) and s % 32 == 0:       # round 6: any pair of 32 / 64 / 128
+    if _on_engine(x) and x.dtype == torch.float32 and _plx_ok(ci, co) and _pw_size(s):       # round 6: any pair of 32 / 64 / 128
         return PointwiseLinearXFn.apply(x, w, bias)
     shape = x.shape
     return F.conv1d(x.reshape(shape[0], ci, -1), w.reshape(co, ci, 1), bias).reshape(shape[0], co, *shape[2:])
@@ -250,12 +256,12 @@ def fused_channel_mlp(x, w1, b1, w2, b2, skip_src=None, gate=None, activation=No
     s = x[0, 0].numel()
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
                                                    for t in (x, w1, b1, w2, b2, skip_src, gate))
-    fits = _on_engine(x) and x.dtype == torch.float32 and s % 32 == 0 and (skip_src is None) == (gate is None) and \
+    fits = _on_engine(x) and x.dtype == torch.float32 and _pw_size(s) and (skip_src is None) == (gate is None) and \
         (ci, ch, co) in (_SHAPES_BWD if needs_grad else _SHAPES)
     if fits:
         act = _lib.SC_ACT_GELU if activation == "gelu" else _lib.SC_ACT_NONE
         return PointwiseMLPFn.apply(x, w1, b1, w2, b2, skip_src, gate, act)
-    if _on_engine(x) and x.dtype == torch.float32 and s % 32 == 0 and (skip_src is None) == (gate is None) and \
+    if _on_engine(x) and x.dtype == torch.float32 and _pw_size(s) and (skip_src is None) == (gate is None) and \
             _plx_ok(ci, ch, co):                         # round 6: two engine passes each way (hidden 128, 128 channels)
         act = _lib.SC_ACT_GELU if activation == "gelu" else _lib.SC_ACT_NONE
         return PointwiseMLP2Fn.apply(x, w1, b1, w2, b2, skip_src, gate, act)
@@ -505,7 +511,7 @@ def fused_block_forward(blocks, x, index=0, output_shape=None):
         return _fused_block_variant(blocks, x, index, last, conv, fc1, fc2, lin, pre, norm)
     c, ch = int(x.shape[1]), int(fc1.weight.shape[0])
     from .factorized import DenseWeight
-    one_node = _on_engine(x) and x.dtype == torch.float32 and x[0, 0].numel() % 32 == 0 and \
+    one_node = _on_engine(x) and x.dtype == torch.float32 and _pw_size(x[0, 0].numel()) and \
         (((c, ch, c) in _SHAPES_BWD and c in (32, 64)) or _plx_ok(c, ch)) and int(lin.weight.shape[0]) == c and \
         isinstance(conv.weight, DenseWeight) and not conv.separable and conv.fno_block_precision == "full" and \
         conv.in_channels == conv.out_channels == c

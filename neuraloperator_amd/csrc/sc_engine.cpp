@@ -2832,6 +2832,9 @@ static int pmlp_shape_id(const sc_pmlp_desc* d) {
   return (int)(d->c_in / 32) * 100 + (int)(d->c_hid / 32) * 10 + (int)(d->c_out / 32);
 }
 
+// the pointwise kernels address a lane as (wave-uniform row base) + a 32-bit BYTE offset of up to 4 * (31 + 4 * spatial)
+// (sc_at, sc_device.h)
+#define SC_PW_MAX_SPATIAL ((int64_t)1 << 28)
 extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, const float* w1, const float* b1,
                                         const float* w2, const float* b2, const float* skip_src, const float* gate,
                                         float* out, void* stream) {
@@ -2840,7 +2843,7 @@ extern "C" int sc_pointwise_mlp_forward(const sc_pmlp_desc* d, const float* x, c
   SC_CHECK_ARG(x && w1 && w2 && out, "null argument");
   SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU, "unknown activation");
   SC_CHECK_ARG((skip_src == nullptr) == (gate == nullptr), "skip_src and gate come together");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise MLP: the spatial size must be a multiple of 32 below 2^28 points");
   PmlpArgs g;
   g.x = x; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.out = out;
   g.spatial = d->spatial;
@@ -2883,7 +2886,7 @@ extern "C" int sc_pointwise_block_forward(const sc_pmlp_desc* d, const float* co
   SC_CHECK_ARG(d->act == SC_ACT_NONE || d->act == SC_ACT_GELU || d->act == SC_ACT_GELU_DGRAD, "unknown activation");
   SC_CHECK_ARG(d->act == SC_ACT_NONE || pre, "the pre-activation buffer is required with SC_ACT_GELU / SC_ACT_GELU_DGRAD");
   SC_CHECK_ARG(d->c_in == d->c_out, "pointwise block pass: c_in == c_out (the linear skip maps the block's channels onto themselves)");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise block pass: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise block pass: the spatial size must be a multiple of 32 below 2^28 points");
   PblockArgs g;
   g.conv = conv; g.x = x; g.ws = ws; g.bs = bs; g.w1 = w1; g.b1 = b1; g.w2 = w2; g.b2 = b2; g.gate = gate;
   g.y = y; g.pre = d->act != SC_ACT_NONE ? pre : nullptr; g.out = out;
@@ -2972,7 +2975,7 @@ extern "C" int sc_pointwise_mlp_backward_ex(const sc_pmlp_desc* d, const float* 
   SC_CHECK_ARG((skip_src == nullptr) == (gate == nullptr), "skip_src and gate come together");
   SC_CHECK_ARG(!gate || (gskip_src && ggate), "a gated forward needs gskip_src and ggate");
   SC_CHECK_ARG((b1 != nullptr || gb1 == nullptr) && (b2 != nullptr || gb2 == nullptr), "bias gradient without a bias");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise MLP: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise MLP: the spatial size must be a multiple of 32 below 2^28 points");
   PmlpBwdArgs g;
   g.x = x; g.b1 = b1; g.b2 = b2; g.skip = skip_src; g.gate = gate; g.gout = gout; g.gx = gx; g.gskip = gskip_src;
   g.w1 = w1; g.w2 = w2; g.x_pre = x_pre; g.partial = nullptr; g.lw = nullptr;
@@ -3019,7 +3022,7 @@ static void launch_pblock_bwd(PmlpBwdArgs g, float* ws, int act, float* gw1, flo
 }
 
 extern "C" int sc_pointwise_block_backward_supported(const sc_pmlp_desc* d) {
-  if (!d || d->c_in != d->c_out || d->spatial % 32) return 0;
+  if (!d || d->c_in != d->c_out || d->spatial % 32 || d->spatial >= SC_PW_MAX_SPATIAL) return 0;
   const int id = pmlp_shape_id(d);
   return (id == 111 || id == 212) ? 1 : 0;                 // (64, 64, 64): tables + scratch + gradient image exceed 160 KB of LDS
 }
@@ -3069,7 +3072,7 @@ extern "C" int sc_pointwise_linear_forward(const sc_plin_desc* d, const float* x
   SC_CHECK_ARG(d, "null argument");
   if (d->batch <= 0 || d->spatial <= 0) return 0;
   SC_CHECK_ARG(x && w && out, "null argument");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise linear map: the spatial size must be a multiple of 32 below 2^28 points");
   PlinArgs g;
   g.x = x; g.w = w; g.bias = bias; g.gout = nullptr; g.addend = nullptr; g.out = out; g.partial = nullptr;
   g.spatial = d->spatial;
@@ -3122,7 +3125,7 @@ extern "C" int sc_pointwise_linear_backward(const sc_plin_desc* d, const float* 
   SC_CHECK_ARG(d, "null argument");
   SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise linear map backward: empty input");
   SC_CHECK_ARG(x && w && gout && gx && gw && workspace, "null argument");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise linear map: the spatial size must be a multiple of 32 below 2^28 points");
   PlinArgs g;
   g.x = x; g.w = w; g.bias = nullptr; g.gout = gout; g.addend = gx_addend; g.out = gx; g.partial = nullptr;
   g.spatial = d->spatial;
@@ -3164,7 +3167,7 @@ extern "C" int sc_pointwise_linear_forward_ex(const sc_plinx_desc* d, const floa
   if (d->batch <= 0 || d->spatial <= 0) return 0;
   SC_CHECK_ARG(x && w && out, "null argument");
   SC_CHECK_ARG(plinx_ok(d), "pointwise linear map: channel counts must be 32, 64 or 128");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise linear map: the spatial size must be a multiple of 32 below 2^28 points");
   SC_CHECK_ARG((skip == nullptr) == (gate == nullptr), "skip and gate come together");
   SC_CHECK_ARG((d->flags & ~(SC_PLX_XACT | SC_PLX_ACT)) == 0, "forward flags: SC_PLX_XACT | SC_PLX_ACT");
   PlinxArgs g;
@@ -3225,7 +3228,7 @@ extern "C" int sc_pointwise_linear_backward_ex(const sc_plinx_desc* d, const flo
   SC_CHECK_ARG(d->batch > 0 && d->spatial > 0, "pointwise linear map backward: empty input");
   SC_CHECK_ARG(x && w && gout && gw && workspace, "null argument");
   SC_CHECK_ARG(plinx_ok(d), "pointwise linear map: channel counts must be 32, 64 or 128");
-  SC_CHECK_ARG(d->spatial % 32 == 0, "pointwise linear map: the spatial size must be a multiple of 32");
+  SC_CHECK_ARG(d->spatial % 32 == 0 && d->spatial < SC_PW_MAX_SPATIAL, "pointwise linear map: the spatial size must be a multiple of 32 below 2^28 points");
   SC_CHECK_ARG((skip == nullptr) == (gate == nullptr), "skip and gate come together");
   SC_CHECK_ARG(!gate || ggate, "a gated forward needs ggate");
   SC_CHECK_ARG(!gate || !gx || gskip, "a gated forward needs gskip beside gx");

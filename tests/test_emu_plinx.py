@@ -161,6 +161,8 @@ def test_argument_checks(lib):
         lib.pointwise_linear_forward_ex(1, 48, 128, 32, 0, p(x), p(w), 0, 0, 0, p(out), 0, 0)
     with pytest.raises(_lib.EngineError):                # spatial not a multiple of 32
         lib.pointwise_linear_forward_ex(1, 64, 128, 40, 0, p(x), p(w), 0, 0, 0, p(out), 0, 0)
+    with pytest.raises(_lib.EngineError):                # 2^28 points per image: lane offsets are 32-bit byte counts (no launch)
+        lib.pointwise_linear_forward_ex(1, 64, 128, 1 << 28, 0, p(x), p(w), 0, 0, 0, p(out), 0, 0)
     with pytest.raises(_lib.EngineError):                # a gate without its source
         lib.pointwise_linear_forward_ex(1, 64, 128, 32, 0, p(x), p(w), 0, 0, p(w), p(out), 0, 0)
     with pytest.raises(_lib.EngineError):                # a backward flag in a forward call
