@@ -346,7 +346,7 @@ int sc_peer_window_control(void* own_window, int64_t spin_budget_ms, int32_t* er
  * x (batch, c_in, spatial), skip_src / out (batch, c_out, spatial) contiguous float32; w1 (c_hid, c_in), w2 (c_out,
  * c_hid) row-major (= Conv1d weights with the trailing 1 dropped); b1, b2, skip_src + gate optional (null).
  * Channel counts: multiples of 32 with (c_in, c_hid, c_out) / 32 in {(1,1,1), (2,1,2), (2,2,2), (4,2,4)};
- * spatial a multiple of 32. */
+ * spatial a multiple of 32 below 2^28 points per image (all sc_pointwise_* entry points: lane offsets are 32-bit byte counts). */
 typedef struct sc_pmlp_desc {
   int64_t batch, c_in, c_hid, c_out, spatial;
   int32_t act;               /* SC_ACT_NONE / SC_ACT_GELU on the result */
