@@ -24,7 +24,8 @@ whose first dim is sharded the same way).
 Round 6: runtime ``n_modes`` (<= the constructed ones: the used centred sub-block of the stored weight, modes.kept_block --
 the used columns keep their place in the padded column layout, so the shard ownership never moves), grids smaller than
 the modes, ``complex_data=True`` (complex-to-complex local transforms, modes.kept_block_complex and the reference's
-last-dim rule, modes.analysis_freqs) and a change of resolution along EVERY dim (the synthesis maps of
+last-dim rule, modes.analysis_freqs), ``separable=True`` (one (C, modes) weight, spectral_convolution.py:49-52) and a change of
+resolution along EVERY dim (the synthesis maps of
 modes.synthesis_freqs on the local transform and on the axis pass).
 
 Every local stage is an engine transform over fewer dims (a (N-1)-d real plan with the local rows folded into the
@@ -59,8 +60,10 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
                  fft_norm="forward", device=None, engine_flags=0, group=None, ops=None, factorization=None, rank=0.5,
                  fixed_rank_modes=None, resolution_scaling_factor=None, **unused):
         super().__init__(device=device)
-        if unused.get("separable"):
-            raise NotImplementedError("separable=True is not supported by the spatially decomposed layer")
+        self.separable = bool(unused.get("separable", False))          # spectral_convolution.py:123-131, 49-52
+        if self.separable and in_channels != out_channels:
+            raise ValueError("To use separable Fourier Conv, in_channels must be equal to out_channels, "
+                             f"but got in_channels={in_channels} and out_channels={out_channels}")
         self.complex_data = bool(unused.get("complex_data", False))
         fac = (factorization or "dense").lower()
         if fac not in ("dense", "tucker", "cp", "tt"):
@@ -88,20 +91,21 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         if init_std == "auto":
             init_std = (2 / (in_channels + out_channels)) ** 0.5
         lo = self.rank * self.k2_loc
+        lead = (in_channels,) if self.separable else (in_channels, out_channels)       # (C, modes) when separable
+        self._md = len(lead)                                         # index of the first mode dim of the weight
         if fac == "dense":
-            w = torch.empty(in_channels, out_channels, self._n_modes[0], self.k2_loc, *self._n_modes[2:],
-                            dtype=torch.cfloat, device=device)
+            w = torch.empty(*lead, self._n_modes[0], self.k2_loc, *self._n_modes[2:], dtype=torch.cfloat, device=device)
             w.normal_(0, init_std)
             if lo + self.k2_loc > k2:                                # inert padding columns of the last rank(s)
                 with torch.no_grad():
-                    w[:, :, :, max(k2 - lo, 0):] = 0
+                    w.narrow(self._md + 1, max(k2 - lo, 0), self.k2_loc - max(k2 - lo, 0)).zero_()
             self.weight = nn.Parameter(w)
             self.weight.mode_sharded = True
         else:
             # the whole factorized weight on every rank (a Tucker weight of rank 0.1 is 1 / 35 of the dense one); the
             # per-rank random init is made identical by sync_replicated_parameters()
             from ..factorized import SpectralWeight
-            self.weight = SpectralWeight.new((in_channels, out_channels, *self._n_modes), rank=rank, factorization=fac,
+            self.weight = SpectralWeight.new((*lead, *self._n_modes), rank=rank, factorization=fac,
                                              fixed_rank_modes=fixed_rank_modes, device=device)
             self.weight.normal_(0, init_std)
         self.bias = nn.Parameter(init_std * torch.randn(out_channels, *(1,) * self.order, device=device)) \
@@ -112,26 +116,27 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         self.ops = ops
 
     def _local_weight(self, kept=None, w_start=None):
-        """(Cin, Cout, k1', k2p / P, k3', ..) dense block of this rank's mode columns (zero columns past k2) restricted
-        to the used centred sub-block of every UNSHARDED mode dim (rows w_start[d] .. + kept[d], modes.kept_block)"""
-        mx = self.max_n_modes
+        """(Cin, Cout, k1', k2p / P, k3', ..) -- (C, k1', k2p / P, ..) when separable -- dense block of this rank's mode
+        columns (zero columns past k2) restricted to the used centred sub-block of every UNSHARDED mode dim (rows
+        w_start[d] .. + kept[d], modes.kept_block)"""
+        mx, md = self.max_n_modes, self._md
         if kept is None:
             kept, w_start = list(mx), [0] * self.order
-        sub = [slice(None), slice(None)] + [slice(s0, s0 + k) for s0, k in zip(w_start, kept)]
+        sub = [slice(None)] * md + [slice(s0, s0 + k) for s0, k in zip(w_start, kept)]
         if self.factorization == "dense":
-            sub[3] = slice(None)
+            sub[md + 1] = slice(None)
             whole = all(k == m for d, (k, m) in enumerate(zip(kept, mx)) if d != 1)
             return self.weight if whole else self.weight[tuple(sub)]
         k2 = mx[1]
         lo = self.rank * self.k2_loc
         hi = min(lo + self.k2_loc, k2)
-        shape = [self.in_channels, self.out_channels, *kept]
-        shape[3] = self.k2_loc
+        shape = ([self.in_channels] if self.separable else [self.in_channels, self.out_channels]) + list(kept)
+        shape[md + 1] = self.k2_loc
         if hi <= lo:                                                   # a rank that holds padding only
             return torch.zeros(shape, dtype=torch.cfloat, device=next(self.weight.parameters()).device)   # (bias=False: ADVICE r5)
-        sub[3] = slice(lo, hi)
+        sub[md + 1] = slice(lo, hi)
         w = self.weight[tuple(sub)].to_tensor()
-        return _pad_dim(w, 3, self.k2_loc - (hi - lo)) if hi - lo != self.k2_loc else w
+        return _pad_dim(w, md + 1, self.k2_loc - (hi - lo)) if hi - lo != self.k2_loc else w
 
     def replicated_parameters(self):
         """parameters every rank holds a full copy of: the bias and the factors of a factorized weight"""
@@ -205,7 +210,8 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
         xa = self.ops.forward_axis(xt.reshape(b, -1, d1), k1, rows_a)
         xa = xa.reshape(*lead, k1).movedim(-1, 2).contiguous()                   # (B, Cin, k1, k2p/P, ..)
         # 4. contraction with this rank's mode columns
-        yh = self.ops.contract(xa, self._local_weight(kept, w_start).contiguous())   # (B, Cout, k1, k2p/P, ..)
+        wl = self._local_weight(kept, w_start).contiguous()
+        yh = self.ops.contract_separable(xa, wl) if self.separable else self.ops.contract(xa, wl)   # (B, Cout, k1, k2p/P, ..)
         # 5. zero-padded inverse DFT over d1 (to the OUTPUT grid's rows)
         yt = yh.movedim(2, -1).contiguous()
         lead = yt.shape[:-1]
@@ -258,12 +264,13 @@ class SpatialParallelSpectralConv(BaseSpectralConv):
                                             group=grp)
 
     @staticmethod
-    def shard_dense_weight(full_weight, rank, world):
+    def shard_dense_weight(full_weight, rank, world, separable=False):
         """Columns (second mode dim, zero-padded to a multiple of ``world``) of a full weight that ``rank`` owns."""
-        k2 = full_weight.shape[3]
+        dim = 2 if separable else 3
+        k2 = full_weight.shape[dim]
         loc = -(-k2 // world)
-        w = _pad_dim(full_weight, 3, loc * world - k2) if loc * world != k2 else full_weight
-        return w.narrow(3, rank * loc, loc).contiguous()
+        w = _pad_dim(full_weight, dim, loc * world - k2) if loc * world != k2 else full_weight
+        return w.narrow(dim, rank * loc, loc).contiguous()
 
 
 def _place_dim(t, dim, offset, total):

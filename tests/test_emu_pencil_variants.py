@@ -31,6 +31,7 @@ def _num(t):
     dict(spatial=(16, 12), modes=(8, 6), complex=True, out_shape=(24, 10)),
     dict(spatial=(8, 8, 6), modes=(4, 4, 4), out_shape=(8, 12, 6)),
     dict(spatial=(8, 8, 6), modes=(6, 6, 4), out_shape=(12, 5, 10)),
+    dict(spatial=(16, 12), modes=(8, 6), separable=True, run_modes=(6, 4)),
 ], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()).replace(" ", ""))
 def test_pencil_layer_variants_on_the_emulated_engine(cfg):
     from emu_engine import engine_on_emulation
@@ -39,20 +40,21 @@ def test_pencil_layer_variants_on_the_emulated_engine(cfg):
 
     torch.manual_seed(31)
     spatial, modes, cplx, fac = cfg["spatial"], cfg["modes"], cfg.get("complex", False), cfg.get("fac", "dense")
-    out_shape = cfg.get("out_shape")
+    out_shape, sep = cfg.get("out_shape"), cfg.get("separable", False)
+    co = 4 if sep else 3
     mx = halve_last_mode(modes, cplx)
     dt = torch.cfloat if cplx else torch.float32
     with engine_on_emulation():
-        sp = SpatialParallelSpectralConv(4, 3, modes, factorization=fac, rank=0.5, complex_data=cplx)
+        sp = SpatialParallelSpectralConv(4, co, modes, factorization=fac, rank=0.5, complex_data=cplx, separable=sep)
         assert sp.P == 1
         if cfg.get("run_modes") is not None:
             sp.n_modes = cfg["run_modes"]
         nm = list(sp.n_modes)
         x = torch.randn(2, 4, *spatial, dtype=dt, requires_grad=True)
         og = list(out_shape) if out_shape is not None else list(spatial)
-        g = torch.randn(2, 3, *og, dtype=dt)
+        g = torch.randn(2, co, *og, dtype=dt)
         y = sp(x, output_shape=out_shape)
-        assert list(y.shape) == [2, 3, *og]
+        assert list(y.shape) == [2, co, *og]
         y.backward(g)
     xc = x.detach().clone().requires_grad_(True)
     bc = sp.bias.detach().clone().requires_grad_(True)
@@ -60,12 +62,12 @@ def test_pencil_layer_variants_on_the_emulated_engine(cfg):
         wc = sp.weight.detach().clone().requires_grad_(True)
     else:
         from neuraloperator_amd.factorized import SpectralWeight
-        ref = SpectralWeight.new((4, 3, *mx), rank=0.5, factorization=fac)
+        ref = SpectralWeight.new(((4,) if sep else (4, 3)) + tuple(mx), rank=0.5, factorization=fac)
         with torch.no_grad():
             for q, r in zip(ref.parameters(), sp.weight.parameters()):
                 q.copy_(r)
         wc = ref.to_tensor()
-    yo = so.forward_torch(xc, wc, bc, nm, mx, output_shape=out_shape, complex_data=cplx)
+    yo = so.forward_torch(xc, wc, bc, nm, mx, output_shape=out_shape, complex_data=cplx, separable=sep)
     yo.backward(g)
     assert so.rel_l2(_num(y), _num(yo)) < TOL
     assert so.rel_l2(_num(x.grad), _num(xc.grad)) < TOL

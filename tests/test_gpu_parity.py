@@ -1115,6 +1115,7 @@ def test_spatial_parallel_variants_on_device_single_rank(spatial, modes, fac, ou
     dict(spatial=(32, 24), modes=(16, 12), complex=True, out_shape=(48, 20)),
     dict(spatial=(12, 16, 20), modes=(6, 8, 8), out_shape=(12, 24, 20)),             # the middle dim changes
     dict(spatial=(12, 16, 20), modes=(8, 12, 8), out_shape=(16, 10, 28)),            # every dim, the middle one coarser than its modes
+    dict(spatial=(32, 24), modes=(16, 12), separable=True, run_modes=(12, 8)),
 ], ids=lambda c: "-".join(f"{k}={v}" for k, v in c.items()).replace(" ", ""))
 def test_spatial_parallel_round6_variants_on_device_single_rank(cfg):
     """Round 6: the spatially decomposed layer with runtime n_modes (the used centred sub-block of the stored weight, the
@@ -1128,18 +1129,19 @@ def test_spatial_parallel_round6_variants_on_device_single_rank(cfg):
     dev = torch.device("cuda:0")
     torch.manual_seed(24)
     spatial, modes, cplx, fac = cfg["spatial"], cfg["modes"], cfg.get("complex", False), cfg.get("fac", "dense")
-    out_shape = cfg.get("out_shape")
+    out_shape, sep = cfg.get("out_shape"), cfg.get("separable", False)
     mx = halve_last_mode(modes, cplx)
-    sp = SpatialParallelSpectralConv(4, 3, modes, factorization=fac, rank=0.5, complex_data=cplx).to(dev)
+    co = 4 if sep else 3
+    sp = SpatialParallelSpectralConv(4, co, modes, factorization=fac, rank=0.5, complex_data=cplx, separable=sep).to(dev)
     if cfg.get("run_modes") is not None:
         sp.n_modes = cfg["run_modes"]
     nm = list(sp.n_modes)
     dt = torch.cfloat if cplx else torch.float32
     x = torch.randn(2, 4, *spatial, device=dev, dtype=dt, requires_grad=True)
     og = list(out_shape) if out_shape is not None else list(spatial)
-    g = torch.randn(2, 3, *og, device=dev, dtype=dt)
+    g = torch.randn(2, co, *og, device=dev, dtype=dt)
     y = sp(x, output_shape=out_shape)
-    assert list(y.shape) == [2, 3, *og]
+    assert list(y.shape) == [2, co, *og]
     y.backward(g)
     xc = x.detach().cpu().requires_grad_(True)
     bc = sp.bias.detach().cpu().requires_grad_(True)
@@ -1147,12 +1149,12 @@ def test_spatial_parallel_round6_variants_on_device_single_rank(cfg):
         wc = sp.weight.detach().cpu().clone().requires_grad_(True)
     else:
         from neuraloperator_amd.factorized import SpectralWeight
-        ref = SpectralWeight.new((4, 3, *mx), rank=0.5, factorization=fac)
+        ref = SpectralWeight.new(((4,) if sep else (4, 3)) + tuple(mx), rank=0.5, factorization=fac)
         with torch.no_grad():
             for q, r in zip(ref.parameters(), sp.weight.parameters()):
                 q.copy_(r.cpu())
         wc = ref.to_tensor()
-    yo = so.forward_torch(xc, wc, bc, nm, mx, output_shape=out_shape, complex_data=cplx)
+    yo = so.forward_torch(xc, wc, bc, nm, mx, output_shape=out_shape, complex_data=cplx, separable=sep)
     yo.backward(g.cpu())
     num = lambda t: torch.view_as_real(t.detach().cpu().contiguous()).numpy() if t.is_complex() else t.detach().cpu().numpy()
     assert rel_l2(num(y), num(yo)) < TOL

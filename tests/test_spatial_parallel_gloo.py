@@ -218,20 +218,21 @@ def _worker_general(rank, world, port, cfg, ret):
 
     comm.init(model_parallel_size=world, backend="gloo")
     spatial, modes, cplx, fac = cfg["spatial"], cfg["modes"], cfg.get("complex", False), cfg.get("fac", "dense")
-    run_modes, out_shape = cfg.get("run_modes"), cfg.get("out_shape")
+    run_modes, out_shape, sep = cfg.get("run_modes"), cfg.get("out_shape"), cfg.get("separable", False)
     mx = halve_last_mode(modes, cplx)
-    B, ci, co = 2, 3, 4
+    B, ci, co = 2, 3, (3 if sep else 4)
+    lead = (ci,) if sep else (ci, co)
     dt = torch.cfloat if cplx else torch.float32
     torch.manual_seed(100 + rank)
     conv = SpatialParallelSpectralConv(ci, co, modes, ops=(PencilOracleOpsComplex if cplx else PencilOracleOps)(),
-                                       factorization=fac, rank=0.6, complex_data=cplx)
+                                       factorization=fac, rank=0.6, complex_data=cplx, separable=sep)
     if fac != "dense":
         conv.sync_replicated_parameters()
     else:
         torch.manual_seed(5)
-        w = torch.empty(ci, co, *mx, dtype=torch.cfloat).normal_(0, 0.4)
+        w = torch.empty(*lead, *mx, dtype=torch.cfloat).normal_(0, 0.4)
         with torch.no_grad():
-            conv.weight.copy_(SpatialParallelSpectralConv.shard_dense_weight(w, rank, world))
+            conv.weight.copy_(SpatialParallelSpectralConv.shard_dense_weight(w, rank, world, separable=sep))
         conv.sync_replicated_parameters()     # the bias
     if run_modes is not None:
         conv.n_modes = run_modes
@@ -252,14 +253,14 @@ def _worker_general(rank, world, port, cfg, ret):
     xf, bf = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
     if fac != "dense":
         from neuraloperator_amd.factorized import SpectralWeight
-        ref = SpectralWeight.new((ci, co, *mx), rank=0.6, factorization=fac)
+        ref = SpectralWeight.new((*lead, *mx), rank=0.6, factorization=fac)
         with torch.no_grad():
             for q, r in zip(ref.parameters(), conv.weight.parameters()):
                 q.copy_(r)
         wf = ref.to_tensor()
     else:
         wf = w.clone().requires_grad_(True)
-    yf = so.forward_torch(xf, wf, bf, nm, mx, output_shape=out_shape, complex_data=cplx)
+    yf = so.forward_torch(xf, wf, bf, nm, mx, output_shape=out_shape, complex_data=cplx, separable=sep)
     yf.backward(g)
     num = lambda t: torch.view_as_real(t.detach().contiguous()).numpy() if t.is_complex() else t.detach().numpy()
     errs = dict(
@@ -271,7 +272,7 @@ def _worker_general(rank, world, port, cfg, ret):
         for i, (q, r) in enumerate(zip(conv.weight.parameters(), ref.parameters())):
             errs[f"gfac{i}"] = so.rel_l2(torch.view_as_real(q.grad).numpy(), torch.view_as_real(r.grad).numpy())
     else:
-        gw_ref = SpatialParallelSpectralConv.shard_dense_weight(wf.grad, rank, world)
+        gw_ref = SpatialParallelSpectralConv.shard_dense_weight(wf.grad, rank, world, separable=sep)
         errs["gw"] = float(np.linalg.norm((conv.weight.grad - gw_ref).numpy().ravel()) /
                            np.linalg.norm(wf.grad.numpy().ravel()))
     ret[rank] = errs
@@ -279,6 +280,8 @@ def _worker_general(rank, world, port, cfg, ret):
 
 
 @pytest.mark.parametrize("cfg", [
+    dict(spatial=(16, 12), modes=(8, 6), separable=True),                         # one (C, modes) weight
+    dict(spatial=(8, 8, 6), modes=(6, 5, 4), separable=True, run_modes=(4, 3, 4), fac="cp"),
     dict(spatial=(16, 12), modes=(8, 6), run_modes=(6, 4)),                       # runtime n_modes, 2-d: fewer rows, fewer columns
     dict(spatial=(16, 12), modes=(8, 10), run_modes=(5, 7)),                      # odd row count, k2: 6 stored -> 4 used
     dict(spatial=(8, 8, 6), modes=(6, 5, 4), run_modes=(4, 3, 4)),                # 3-d: the sharded mode dim is a CENTRED one (offset 1)
