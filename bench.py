@@ -648,6 +648,8 @@ def cpu_baseline_subprocess(workload):
               for t, v in runs.items() if t != best]
     if others:
         out["sample"] += " (" + "; ".join(others) + ")"
+    if best < cores:                                       # say it on the line
+        out["sample"] += f" -- the host is NOT saturated ({best} of {cores} hardware threads): context, not a tuned CPU number"
     return out
 
 
