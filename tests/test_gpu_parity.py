@@ -1321,6 +1321,36 @@ def test_fourier_layer_fused_epilogue(spatial, modes):
         assert rel_l2(y_lin.cpu().numpy(), (conv(xd.detach()) + sd.detach()).cpu().numpy()) < TOL
 
 
+@pytest.mark.parametrize("kept,n_img,mode", [((256, 129), 6, "adjoint"), ((101, 129), 3, "padded")])
+def test_two_pass_row_kernel_adds_the_epilogue_skip_on_device(lib, kept, n_img, mode):
+    """Round 6: at 1024-point rows with 129 kept columns (configs[4]) the SC_ACT_NONE addend of sc_transform_inverse_ex rides
+    in the store path of k_f2p_c2r_w1024<true> (the block backward's gradient around the spectral convolution): bit for bit
+    the plain transform followed by the sum (the same two additions in the same order); both inverse modes, several images
+    (the chunked host loop offsets the addend with the output)."""
+    from neuraloperator_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(33)
+    spatial = (1024, 1024)
+    md = _lib.SC_INV_PADDED if mode == "padded" else _lib.SC_INV_ADJ_R2C
+    plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+    try:
+        ws = torch.empty(max(lib.plan_workspace_bytes(plan, n_img), 256), dtype=torch.uint8, device=dev)
+        yhat = torch.randn(n_img, *kept, 2, device=dev)
+        bias = torch.randn(n_img, device=dev) if mode == "padded" else None
+        bp = 0 if bias is None else bias.data_ptr()
+        skip = torch.randn(n_img, *spatial, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        plain = torch.full((n_img, *spatial), float("nan"), device=dev)
+        lib.transform_inverse(plan, md, yhat.data_ptr(), bp, n_img, plain.data_ptr(), n_img, ws.data_ptr(), st)
+        fused = torch.full((n_img, *spatial), float("nan"), device=dev)
+        lib.transform_inverse_ex(plan, md, yhat.data_ptr(), bp, n_img, skip.data_ptr(), 0, _lib.SC_ACT_NONE,
+                                 fused.data_ptr(), n_img, ws.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, plain + skip)
+    finally:
+        lib.plan_destroy(plan)
+
+
 @pytest.mark.parametrize("chans", [(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)], ids=str)
 def test_pointwise_mlp_pass(chans):
     # (128, 64, 128) has the forward kernel only: with gradients it takes the composition, checked like the others
