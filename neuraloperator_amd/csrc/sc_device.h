@@ -585,8 +585,9 @@ SC_HD T* sc_at(T* base, const uint32_t byte_off) {
 //     polynomial, the Newton step and the products of two values per instruction; the two transcendentals and the sign
 //     select stay per value.  12 / 13 instructions per value instead of 27 / 33.
 // Every operation is an IEEE fma / mul / add or one of the two transcendentals, in the same order in the scalar and the
-// pair form (packed and scalar fma / mul / add round alike): the bits do not depend on which form a kernel uses.  (The
-// host-emulation tier evaluates the scalar form everywhere.)
+// pair form (packed and scalar fma / mul / add round alike): the bits do not depend on which form a kernel uses
+// (tests/test_gpu_parity.py::test_one_activation_on_every_route_bit_for_bit; the host-emulation tier evaluates the
+// scalar form everywhere).
 // 1 + erf(z) = erfc(|z|) for z < 0 and 2 - erfc(|z|) for z >= 0: the negative tail is taken from erfc DIRECTLY, so it does
 // not cancel (1 + erf loses every digit for v < -4) -- as fma(-cs, q, 1 + cs) with cs = copysign(1, v), exact.
 #define SC_GELU_P   0.23164189298270723f      // 0.3275911 / sqrt 2: t = 1 / (1 + P |v|)

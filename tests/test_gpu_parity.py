@@ -1351,6 +1351,48 @@ def test_two_pass_row_kernel_adds_the_epilogue_skip_on_device(lib, kept, n_img, 
         lib.plan_destroy(plan)
 
 
+def test_one_activation_on_every_route_bit_for_bit(lib):
+    """sc_gelu (sc_device.h) is evaluated by the fused store path of the 2-D inverse transform (scalar form), by the
+    streaming k_epilogue pass behind the other transforms (scalar form) and by the pointwise kernels (PAIR form on packed
+    fp32 instructions, round 6): the same IEEE operations in the same order -> the same bits for the same argument.
+    Every route is made to compute gelu(0 + s): a zero spectrum under the two transform routes, a zero weight and a unit
+    gate in the 1 x 1 map."""
+    from neuraloperator_amd import _lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(41)
+    B, C = 2, 32
+    s = (torch.randn(B, C, 4096, device=dev) * 3.0).contiguous()
+    s.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-30, -1e-30, 6.5, -6.5, 40.0, -40.0], device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for tag, spatial, kept in (("fused 2-D store path", (64, 64), (16, 9)), ("k_epilogue pass", (16, 16, 16), (4, 4, 3))):
+        plan = lib.plan_create(list(spatial), list(kept), fft_norm="forward", flags=0)
+        try:
+            ws = torch.empty(max(lib.plan_workspace_bytes(plan, B * C), 256), dtype=torch.uint8, device=dev)
+            yhat = torch.zeros(B * C, *kept, 2, device=dev)
+            y = torch.full((B, C, 4096), float("nan"), device=dev)
+            lib.transform_inverse_ex(plan, _lib.SC_INV_PADDED, yhat.data_ptr(), 0, C, s.data_ptr(), 0, _lib.SC_ACT_GELU,
+                                     y.data_ptr(), B * C, ws.data_ptr(), st)
+            outs[tag] = y
+        finally:
+            lib.plan_destroy(plan)
+    w = torch.zeros(C, C, device=dev)
+    gate = torch.ones(C, device=dev)
+    x = torch.randn(B, C, 4096, device=dev)
+    y = torch.full((B, C, 4096), float("nan"), device=dev)
+    lib.pointwise_linear_forward_ex(B, C, C, 4096, _lib.SC_PLX_ACT, x.data_ptr(), w.data_ptr(), 0, s.data_ptr(), gate.data_ptr(),
+                                    y.data_ptr(), 0, st)
+    outs["1 x 1 map (pair form)"] = y
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.gelu(s.double()).float()
+    tags = list(outs)
+    for t in tags:
+        assert torch.isfinite(outs[t]).all(), t
+        assert rel_l2(outs[t].cpu().numpy(), ref.cpu().numpy()) < 1e-6, t
+    for t in tags[1:]:
+        assert torch.equal(outs[t].view(torch.int32), outs[tags[0]].view(torch.int32)), (tags[0], t)
+
+
 @pytest.mark.parametrize("chans", [(32, 32, 32), (64, 32, 64), (64, 64, 64), (128, 64, 128)], ids=str)
 def test_pointwise_mlp_pass(chans):
     # (128, 64, 128) has the forward kernel only: with gradients it takes the composition, checked like the others
