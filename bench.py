@@ -508,13 +508,43 @@ def _extra_traffic(shape, io, kind, alg_bytes_step):
             "traffic_source": note + "; `traffic` = sum over the step's launches"}
 
 
+def rank_of_8_extra(steps, warmup, timeout_s=150):
+    """configs[3]'s per-rank step of an 8-rank mode-parallel group on THIS device (a child process: `--parallel modeshard
+    --emulate-world 8 --workload fno3d_128_m32_c32_b1`: one 128^3 sample per rank, the contraction load of one rank of eight, the exchanges degenerate) --
+    TIMING ONLY: the kernel budget of a rank before real exchanges, i.e. the bound of configs[3]'s strong-scaling ratio
+    that this box can show (`configs.c3_rank_of_8.bound_x` = one-GPU step / this).  A child process because the form needs a
+    process group; whatever happens there never reaches the line's other numbers."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--parallel", "modeshard", "--emulate-world", "8", "--workload",
+           "fno3d_128_m32_c32_b1", "--steps", str(steps), "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline",
+           "--no-gpu-reference", "--no-pmc"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"ms_per_step": None, "note": f"did not finish within {timeout_s} s"}
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                d = json.loads(line)
+            except ValueError:
+                break
+            return {"ms_per_step": d.get("ms_per_step"), "cold_start_ms_per_step": d.get("cold_start", {}).get("ms_per_step"),
+                    "launch": d.get("config", {}).get("launch"), "what": "one rank of an emulated 8-rank mode-parallel group, "
+                    "B = 8 / 8 = one 128^3 sample per rank, timing only (bench.py --parallel modeshard --emulate-world 8)"}
+    return {"ms_per_step": None, "note": "failed: " + (r.stderr.strip()[-200:] or "no JSON line")}
+
+
 def compact_configs(out, extra, world):
     """The LAST key of the JSON line: every BASELINE config in <= 1500 characters, so that a record that
     keeps only the tail of the line still shows them.  Per entry: ms = ms per step of the settled region, cold = of the
     contract's first region, frac = algorithmic bytes / ms / 8 TB/s, toa = counter traffic / algorithmic bytes (null = not
     measured in this run), sps = samples/s of the whole job.  c1 = configs[1] (the headline workload, fp32 and bf16 real
     tensors), c2 = configs[2] TFNO Tucker rank 0.1, c3 = configs[3] FNO3d 128^3 B = 8 (one GPU: `c3_single`; N GPUs:
-    `c3_modeshard` strong-scaled next to the one-GPU replica step and their ratio), c4 = configs[4] 1024^2."""
+    `c3_modeshard` strong-scaled next to the one-GPU replica step and their ratio; one GPU: `c3_rank_of_8` = the per-rank
+    step of an emulated 8-rank group, timing only, and the ratio it bounds), c4 = configs[4] 1024^2."""
     def ent(e, frac_key="frac_of_8TBs"):
         if not e or e.get("ms_per_step") is None:
             return None
@@ -544,6 +574,9 @@ def compact_configs(out, extra, world):
             c[k] = e
     if "c3_modeshard" in c and "c3_single" in c:           # configs[3]'s >= 6 x question on one line (strong scaling, B = 8 in all)
         c["c3_speedup"] = round(c["c3_single"]["ms"] / c["c3_modeshard"]["ms"], 3)
+    r8 = extra.get("fno3d_rank_of_8")
+    if r8 and r8.get("ms_per_step") and "c3_single" in c:  # one GPU: the per-rank kernel budget of 8 ranks and what it bounds
+        c["c3_rank_of_8"] = {"ms": r8["ms_per_step"], "bound_x": round(c["c3_single"]["ms"] / r8["ms_per_step"], 2)}
     fb = extra.get("fno_block")
     if fb and fb.get("fused_ms") is not None:
         c["block"] = {"fused_ms": fb["fused_ms"], "ref_ms": fb.get("reference_op_sequence_ms")}
@@ -1144,6 +1177,10 @@ def main():
             except Exception as e:                           # an extra never kills the line
                 extra["sfno"] = {"engine_ms": None, "note": f"failed: {type(e).__name__}: {str(e)[:160]}"}
             torch.cuda.empty_cache()
+            try:
+                extra["fno3d_rank_of_8"] = rank_of_8_extra(args.steps, args.warmup)
+            except Exception as e:                           # an extra never kills the line
+                extra["fno3d_rank_of_8"] = {"ms_per_step": None, "note": f"failed: {type(e).__name__}: {str(e)[:160]}"}
 
     if rank == 0:
         nm = halve_last_mode(n_modes)

@@ -137,9 +137,12 @@ def test_compact_configs_is_the_last_key_and_fits_the_record_tail(bench):
            "step_roofline": {"frac_of_8TBs": 0.6413, "traffic_over_alg_bytes": 1.029},
            "config": {"workload": "fno2d_256_m64_c64_b32", "real_tensor_io": "f32", "parallelism": "single"}}
     extra = {"bf16_io": ex(0.3722), "tfno_rank01": ex(0.7259), "fno3d_single": ex(1.904), "fno2d_1024_b4": ex(5.37),
-             "darcy_421": ex(0.9), "fno_block": {"fused_ms": 2.79, "reference_op_sequence_ms": 12.3}}
+             "darcy_421": ex(0.9), "fno_block": {"fused_ms": 2.79, "reference_op_sequence_ms": 12.3},
+             "sfno": {"engine_ms": 0.59, "op_sequence_ms": 0.71},
+             "fno3d_rank_of_8": {"ms_per_step": 0.34, "cold_start_ms_per_step": 0.36, "launch": "hipGraph replay"}}
     c = bench.compact_configs(out, extra, 1)
-    assert set(c) >= {"c1_f32", "c1_bf16", "c2_tfno", "c3_single", "c4_1024", "block"}
+    assert set(c) >= {"c1_f32", "c1_bf16", "c2_tfno", "c3_single", "c4_1024", "block", "sfno", "c3_rank_of_8"}
+    assert c["c3_rank_of_8"] == {"ms": 0.34, "bound_x": 5.6}       # one GPU: the per-rank budget of 8 ranks (timing only)
     assert c["c1_f32"] == {"ms": 0.5197, "cold": 0.5934, "sps": 61575.31, "frac": 0.6413, "toa": 1.029}
     out["configs"] = c
     line = json.dumps(out)
