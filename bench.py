@@ -13,7 +13,9 @@ metric at every N; the line also carries `extra.dp_allreduce` (data-parallel rep
 all-reduce of the 69 MB dense weight, what mode sharding avoids) and `extra.fno3d_modeshard` (BASELINE
 configs[3]: 128^3, B=8 in total, strong scaling; its single-GPU number is `extra.fno3d_single` of the N=1 line).
 The N=1 line also carries `extra.fno_block`: one whole FNO block forward + backward at the metric
-shape, the reference's op sequence around the engine's convolution against the engine's fused passes.
+shape, the reference's op sequence around the engine's convolution against the engine's fused passes; `extra.sfno`
+(one SphericalConv); and `extra.fno3d_rank_of_8` (a child process: the per-rank step of an emulated 8-rank mode-parallel
+group of configs[3] on this device -- timing only, the bound of its strong-scaling ratio this box can show).
 --parallel replicas | modeshard | pencil selects one explicitly.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant
