@@ -733,21 +733,30 @@ SETTLE_MS = 250.0          # default of --settle-ms
 
 
 def _timed_region(step, steps, warmup, dist, dev, share):
-    """W untimed steps, then K steps between barrier + synchronize on both sides; max over ranks (ms per step)."""
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    """W untimed steps, then K steps between barrier + synchronize on both sides; max over ranks (ms per step).
+    The interpreter's cyclic collector is held off for the region (a collection inside the 10-15 ms of a 20-step region
+    shows up as 0.1-0.2 ms per step on the host-sensitive steps: the Tucker chain issues ~20 launches per step)."""
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()                                           # (no collection here either: the device would idle behind it)
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
     if dist is not None:
         t = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
